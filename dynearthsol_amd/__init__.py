@@ -1,0 +1,283 @@
+"""dynearthsol_amd -- MI355X-native explicit time-stepper behind DynEarthSol's host surface.
+
+Python is plumbing only: the package loads two in-tree shared libraries through ctypes,
+
+* ``libdes_host.so`` -- C++ host side (``.cfg`` front-end, mesh topology, initial
+  conditions, driver loop; mirrors input.cxx / mesh.cxx / ic.cxx / dynearthsol.cxx), and
+* ``libdes_hip.so``  -- the hand-written HIP kernels for gfx950 behind the C-ABI of
+  ``include/des_dev.h``.
+
+There is no CPU fallback: constructing a :class:`DeviceEngine` without the HIP library or
+without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._structs import DesMesh, DesParams, DesScalars, F, FIELDS, INT_FIELDS
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+HOST_LIB_PATH = os.path.join(_HERE, "libdes_host.so")
+HIP_LIB_PATH = os.path.join(_HERE, "libdes_hip.so")
+
+_host_lib = None
+_hip_lib = None
+
+
+class DesError(RuntimeError):
+    """Carries the reference's ExitCode number (utils.hpp:20-55)."""
+
+    def __init__(self, code, msg):
+        super().__init__("[DES exit %d] %s" % (code, msg))
+        self.code = code
+
+
+def load_host_lib():
+    global _host_lib
+    if _host_lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise DesError(31, "libdes_host.so is not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(HOST_LIB_PATH)
+        lib.des_host_create.restype = C.c_void_p
+        lib.des_host_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+        lib.des_host_create_from_string.restype = C.c_void_p
+        lib.des_host_create_from_string.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+        lib.des_host_destroy.argtypes = [C.c_void_p]
+        lib.des_host_params.restype = C.POINTER(DesParams)
+        lib.des_host_params.argtypes = [C.c_void_p]
+        lib.des_host_mesh.restype = C.POINTER(DesMesh)
+        lib.des_host_mesh.argtypes = [C.c_void_p]
+        lib.des_host_array.restype = C.c_void_p
+        lib.des_host_array.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]
+        lib.des_host_cfg_int.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+        lib.des_host_cfg_double.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        lib.des_host_save_mesh.argtypes = [C.c_void_p, C.c_char_p]
+        lib.des_host_last_error.restype = C.c_char_p
+        _host_lib = lib
+    return _host_lib
+
+
+def bind_engine_api(lib, prefix):
+    """Declare the argument types of an engine library (`des_dev_*` or, in tests, the
+    oracle's `des_oracle_*`, which has the same call shape)."""
+    g = lambda name: getattr(lib, prefix + "_" + name)
+    g("destroy").argtypes = [C.c_void_p]
+    g("upload").argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+    g("download").argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong]
+    g("field_count").restype = C.c_longlong
+    g("field_count").argtypes = [C.c_void_p, C.c_int]
+    g("set_clock").argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_longlong]
+    g("init_geometry").argtypes = [C.c_void_p]
+    g("compute_dt").argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    g("step").argtypes = [C.c_void_p, C.c_int, C.POINTER(DesScalars)]
+    g("check_nan").argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    return lib
+
+
+def load_hip_lib():
+    """Load the HIP extension; fails loudly if it is missing (no CPU fallback)."""
+    global _hip_lib
+    if _hip_lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise DesError(31, "libdes_hip.so (HIP kernels for gfx950) is not built; "
+                               "there is no CPU fallback for the device path")
+        lib = C.CDLL(HIP_LIB_PATH)
+        bind_engine_api(lib, "des_dev")
+        lib.des_dev_device_count.restype = C.c_int
+        lib.des_dev_create.restype = C.c_void_p
+        lib.des_dev_create.argtypes = [C.c_int, C.POINTER(DesParams), C.POINTER(DesMesh), C.POINTER(C.c_int)]
+        lib.des_dev_sync.argtypes = [C.c_void_p]
+        lib.des_dev_timer_start.argtypes = [C.c_void_p]
+        lib.des_dev_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.des_dev_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        lib.des_dev_profile_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_longlong)]
+        lib.des_dev_algorithmic_bytes_per_step.restype = C.c_double
+        lib.des_dev_algorithmic_bytes_per_step.argtypes = [C.c_void_p]
+        lib.des_dev_last_error.restype = C.c_char_p
+        _hip_lib = lib
+    return _hip_lib
+
+
+class Host:
+    """Host-side model: parsed ``.cfg``, mesh topology and initial fields
+    (get_input_parameters + init(), input.cxx:1503 / dynearthsol.cxx:159-228)."""
+
+    def __init__(self, cfg_path=None, cfg_text=None, overrides=None, mesh_file=None):
+        lib = load_host_lib()
+        err = C.c_int(0)
+        ov = overrides.encode() if overrides else None
+        mf = mesh_file.encode() if mesh_file else None
+        if cfg_path is not None:
+            h = lib.des_host_create(cfg_path.encode(), ov, mf, C.byref(err))
+        else:
+            h = lib.des_host_create_from_string((cfg_text or "").encode(), ov, mf, C.byref(err))
+        if not h:
+            raise DesError(err.value, lib.des_host_last_error().decode())
+        self._lib, self._h = lib, C.c_void_p(h)
+        self.params = lib.des_host_params(self._h).contents
+        self.mesh = lib.des_host_mesh(self._h).contents
+        self.nnode, self.nelem = self.mesh.nnode, self.mesh.nelem
+
+    def array(self, name):
+        n = C.c_longlong(0)
+        p = self._lib.des_host_array(self._h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        ctype = C.c_int if name in ("elemmarkers", "connectivity", "segment", "segflag") else C.c_double
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n.value,)).copy()
+
+    def cfg_int(self, key):
+        v = C.c_int(0)
+        if self._lib.des_host_cfg_int(self._h, key.encode(), C.byref(v)):
+            raise KeyError(key)
+        return v.value
+
+    def cfg_double(self, key):
+        v = C.c_double(0)
+        if self._lib.des_host_cfg_double(self._h, key.encode(), C.byref(v)):
+            raise KeyError(key)
+        return v.value
+
+    def save_mesh(self, path):
+        rc = self._lib.des_host_save_mesh(self._h, path.encode())
+        if rc:
+            raise DesError(rc, self._lib.des_host_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._lib.des_host_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EngineBase:
+    """Shared ctypes plumbing for an engine with the des_dev call shape."""
+
+    prefix = None
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, C.c_void_p(handle)
+
+    def _f(self, name):
+        return getattr(self._lib, self.prefix + "_" + name)
+
+    def _check(self, rc, what):
+        if rc:
+            raise DesError(rc, "%s_%s failed" % (self.prefix, what))
+
+    def field_count(self, field):
+        return self._f("field_count")(self._h, F[field])
+
+    def upload(self, field, arr):
+        dt = np.int32 if field in INT_FIELDS else np.float64
+        a = np.ascontiguousarray(arr, dtype=dt).ravel()
+        self._check(self._f("upload")(self._h, F[field], a.ctypes.data_as(C.c_void_p), a.size), "upload(%s)" % field)
+
+    def download(self, field):
+        n = self.field_count(field)
+        a = np.empty(n, dtype=np.int32 if field in INT_FIELDS else np.float64)
+        self._check(self._f("download")(self._h, F[field], a.ctypes.data_as(C.c_void_p), n), "download(%s)" % field)
+        return a
+
+    def set_clock(self, dt, time=0.0, steps=0):
+        self._check(self._f("set_clock")(self._h, dt, time, steps), "set_clock")
+
+    def init_geometry(self):
+        self._check(self._f("init_geometry")(self._h), "init_geometry")
+
+    def compute_dt(self):
+        dt = C.c_double(0)
+        self._check(self._f("compute_dt")(self._h, C.byref(dt)), "compute_dt")
+        return dt.value
+
+    def step(self, nsteps, want_scalars=True):
+        sc = DesScalars()
+        self._check(self._f("step")(self._h, nsteps, C.byref(sc) if want_scalars else None), "step")
+        return sc if want_scalars else None
+
+    def check_nan(self):
+        n = C.c_longlong(0)
+        self._f("check_nan")(self._h, C.byref(n))
+        return n.value
+
+    def close(self):
+        if self._h:
+            self._f("destroy")(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init_from_host(self, host):
+        """Replays init() + the first compute_dt of main() (dynearthsol.cxx:175-221, 643)."""
+        coord = host.array("coord")
+        self.upload("COORD", coord)
+        self.upload("COORD0", coord)
+        self.upload("ELEMMARKERS", host.array("elemmarkers"))
+        self.upload("VEL", host.array("vel"))
+        # compute_volume, volume_old = volume, apply_vbcs, compute_mass -- with T still 0,
+        # exactly as init() orders them (compute_mass precedes initial_temperature)
+        self.init_geometry()
+        self.upload("TEMPERATURE", host.array("temperature"))
+        self.upload("RADIOGENIC", host.array("radiogenic"))
+        self.upload("STRESS", host.array("stress"))
+        self.upload("STRAIN", host.array("strain"))
+        self.upload("PLSTRAIN", host.array("plstrain"))
+        self.upload("VISCOSITY", host.array("viscosity"))
+        return self.compute_dt()
+
+
+class DeviceEngine(EngineBase):
+    """The MI355X engine behind include/des_dev.h."""
+
+    prefix = "des_dev"
+
+    def __init__(self, host, device=0):
+        lib = load_hip_lib()
+        if lib.des_dev_device_count() <= device:
+            raise DesError(31, "no HIP device %d visible; the device path has no CPU fallback" % device)
+        err = C.c_int(0)
+        h = lib.des_dev_create(device, C.byref(host.params), C.byref(host.mesh), C.byref(err))
+        if not h:
+            raise DesError(err.value, lib.des_dev_last_error().decode())
+        super().__init__(lib, h)
+        self._host = host      # keeps the mesh arrays alive
+
+    def sync(self):
+        self._check(self._lib.des_dev_sync(self._h), "sync")
+
+    def timer_start(self):
+        self._check(self._lib.des_dev_timer_start(self._h), "timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        self._check(self._lib.des_dev_timer_stop(self._h, C.byref(ms)), "timer_stop")
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.des_dev_profile_enable(self._h, int(on)), "profile_enable")
+
+    def profile_read(self, cap=64):
+        names = ((C.c_char * 64) * cap)()
+        ms = (C.c_double * cap)()
+        calls = (C.c_longlong * cap)()
+        n = self._lib.des_dev_profile_read(self._h, cap, names, ms, calls)
+        return [(names[i].value.decode(), ms[i], calls[i]) for i in range(n)]
+
+    def algorithmic_bytes_per_step(self):
+        return self._lib.des_dev_algorithmic_bytes_per_step(self._h)
+
+
+__all__ = ["Host", "DeviceEngine", "EngineBase", "DesError", "DesParams", "DesMesh", "DesScalars",
+           "F", "FIELDS", "load_host_lib", "load_hip_lib", "bind_engine_api"]

@@ -1,0 +1,105 @@
+// des_host.hpp -- host side of the MI355X time-stepper: the part of DynEarthSol that stays
+// on the CPU (".cfg" input, mesh topology, initial conditions, the driver loop, output).
+// It mirrors the reference's host surface so the same .cfg gives the same model:
+//   Config      <-> input.cxx (boost::program_options front-end)
+//   HostMesh    <-> mesh.cxx topology builders + bc.cxx:create_boundary_normals
+//   HostFields  <-> the Variables arrays allocate_variables() owns (fields.cxx:56-122)
+//   ic_*        <-> ic.cxx
+// All 2-D arrays use the reference's SoA layout a[d*n+i] (array2d.hpp:410-425).
+#ifndef DES_HOST_HPP
+#define DES_HOST_HPP
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "des_params.h"
+
+namespace des {
+
+// Error carrying one of the reference's ExitCode numbers (utils.hpp:20-55).
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &msg) : std::runtime_error(msg), code(c) {}
+};
+
+enum CfgType { CFG_STR, CFG_INT, CFG_DBL, CFG_BOOL, CFG_UINT };
+
+// ".cfg" front-end: same keys, defaults, syntax and error behaviour as
+// get_input_parameters() (input.cxx:1503-1519) without boost.
+class Config {
+public:
+    // Parse `filename`, then apply `overrides` ("key = value" lines, same syntax) on top.
+    void load(const std::string &filename, const std::string &overrides = "");
+    void load_string(const std::string &text, const std::string &overrides = "");
+
+    bool has(const std::string &key) const;      // explicitly given OR defaulted
+    bool given(const std::string &key) const;    // explicitly given (vm.count() semantics for no-default keys)
+    std::string s(const std::string &key) const;
+    int i(const std::string &key) const;
+    double d(const std::string &key) const;
+    bool b(const std::string &key) const;
+    // "[a, b, c]" list of exactly `len` numbers; optional_size as input.cxx:970-996
+    std::vector<double> list(const std::string &key, int len, int optional_size = 0) const;
+
+private:
+    void parse(const std::string &text, const std::string &origin, bool allow_dup);
+    std::map<std::string, std::string> values_;
+    std::map<std::string, bool> explicit_;
+};
+
+// validate_parameters() (input.cxx:999-1500) for the options the host uses; fills the
+// POD handed to the device.  Throws Error with the reference's exit code.
+void build_params(const Config &cfg, des_params &out);
+
+struct HostMesh {
+    int nnode = 0, nelem = 0, nseg = 0;
+    std::vector<double> coord;      // [3][nnode]
+    std::vector<int> conn;          // [4][nelem]
+    std::vector<int> segment;       // [3][nseg]
+    std::vector<int> segflag;       // [nseg]
+    std::vector<double> regattr;    // [nelem]
+
+    std::vector<unsigned> bcflag;
+    std::vector<int> bnodes[DES_NBDRY];
+    std::vector<int> bfacet_elem[DES_NBDRY], bfacet_facet[DES_NBDRY];
+    std::vector<int> sup_idx, sup_arr, sup_lidx;
+    std::vector<int> conn_surf;     // [4][etop]
+    std::vector<int> top_nodes, elem_and_nodes, ssup_idx, ssup_arr, top_elems;
+    std::vector<double> bnormals;   // [3][10]
+    std::vector<double> edge_vec;
+    int edge_slot[DES_NBDRY * DES_NBDRY];
+
+    des_mesh view() const;
+};
+
+// create_new_mesh (mesh.cxx:3460-3506): meshing_option 1 with meshing_elem_shape 1
+// (regular grid split into 5 tets per cell, mesh.cxx:147-346, 1431-1459) is built here;
+// tetgen-based options need a mesh file written by tools/ (see DESIGN.md).
+void create_new_mesh(const Config &cfg, HostMesh &m, const std::string &mesh_file);
+void load_mesh_file(const std::string &path, HostMesh &m);
+void save_mesh_file(const std::string &path, const HostMesh &m);
+// renumbering_mesh (mesh.cxx:2696-2821)
+void renumbering_mesh(const Config &cfg, HostMesh &m);
+// create_boundary_flags/nodes/facets, create_support, create_top_elems,
+// create_surface_info (mesh.cxx:2837-3329) and create_boundary_normals (bc.cxx:94-224)
+void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY]);
+
+struct HostFields {
+    std::vector<double> vel, temperature, radiogenic, stress, strain, plstrain, viscosity;
+    std::vector<int> elemmarkers;   // [nelem][nmat]
+    double compensation_pressure = 0;
+    double bottom_temperature = 0;
+};
+
+// init() after the mesh exists (dynearthsol.cxx:172-221): markers counts, temperature,
+// lithostatic stress, weak zone, initial viscosity.
+void initial_conditions(const Config &cfg, des_params &p, const HostMesh &m, HostFields &f);
+
+// ref_pressure (matprops.cxx:153-174)
+double ref_pressure(const des_params &p, double z);
+
+} // namespace des
+
+#endif

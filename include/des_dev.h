@@ -1,0 +1,99 @@
+/* des_dev.h -- C-ABI of the MI355X-native explicit time-stepper (libdes_hip.so).
+ *
+ * What it replaces.  The reference calls, on a process-global `Variables var`, the
+ * free functions below once per step (dynearthsol.cxx:768-894):
+ *     MatProps::refresh_elem_cache   matprops.cxx:259
+ *     update_temperature             fields.cxx:197       (fields.hpp:7)
+ *     update_strain_rate             fields.cxx:405       (fields.hpp:11)
+ *     compute_dvoldt / compute_edvoldt geometry.cxx:203/249 (geometry.hpp:15-19)
+ *     update_stress                  rheology.cxx:703     (rheology.hpp:4)
+ *     NMD_stress                     geometry.cxx:282     (geometry.hpp:21)
+ *     update_force (+apply_stress_bcs, apply_stress_bcs_neumann, apply_damping)
+ *                                    fields.cxx:609, bc.cxx:661/829, fields.cxx:483
+ *     update_velocity                fields.cxx:725
+ *     calculate_residual_force       fields.cxx:700
+ *     apply_vbcs                     bc.cxx:227           (bc.hpp:8)
+ *     update_mesh = update_coordinate + surface_processes + compute_volume + compute_mass
+ *                                    dynearthsol.cxx:448-493
+ *     rotate_stress                  fields.cxx:827
+ *     compute_dt (every 10 steps)    geometry.cxx:1480
+ * des_dev_step() runs that whole sequence on the GPU with all state resident in HBM.
+ * Ownership, threading and error behaviour mirror the reference: the host
+ * owns the Variables arrays; the caller is single-threaded; errors are returned as the
+ * reference's ExitCode numbers instead of std::exit().
+ *
+ * All arrays crossing this boundary are host pointers in the reference's SoA layout
+ * (des_params.h).  No torch / HIP types appear in any signature.
+ */
+#ifndef DES_DEV_H
+#define DES_DEV_H
+
+#include "des_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct des_dev des_dev;   /* opaque engine handle */
+
+/* Number of visible HIP devices (0 when there is no GPU). Does not initialise a context. */
+int des_dev_device_count(void);
+
+/* Create an engine on HIP device `device`, copy params and mesh topology to HBM and
+ * allocate every field.  Replaces allocate_variables (fields.cxx:56-122) + the topology
+ * uploads an OpenACC build does implicitly.  `coord` is array_t SoA [3][nnode].
+ * Returns NULL on failure and stores a DES_ERR_* code in *err (may be NULL). */
+des_dev *des_dev_create(int device, const des_params *params, const des_mesh *mesh, int *err);
+
+void des_dev_destroy(des_dev *h);
+
+/* Copy one field host->device / device->host (blocking). `count` is the number of
+ * scalar entries the caller's buffer holds and must match the field's size. */
+int des_dev_upload(des_dev *h, int field, const void *host, long long count);
+int des_dev_download(des_dev *h, int field, void *host, long long count);
+long long des_dev_field_count(const des_dev *h, int field);
+
+/* Set time-step scalars: dt (Variables::dt), time, steps.  compute_dt semantics: if
+ * fixed_dt != 0 it always wins (geometry.cxx:1487). */
+int des_dev_set_clock(des_dev *h, double dt, double time, long long steps);
+
+/* (Re)compute the derived start-of-run state on the device exactly as init() does after
+ * coord/elemmarkers/vel are set (dynearthsol.cxx:184-194): compute_volume, volume_old =
+ * volume, apply_vbcs(vel), compute_mass -- in that order, with whatever temperature is
+ * resident (the reference runs this before initial_temperature, i.e. with T = 0). */
+int des_dev_init_geometry(des_dev *h);
+
+/* compute_dt (geometry.cxx:1480-1647) on the device; writes the new dt into the engine
+ * clock and returns it through *dt (may be NULL).  Returns DES_ERR_RUNTIME_NAN if dt<=0. */
+int des_dev_compute_dt(des_dev *h, double *dt);
+
+/* Advance `nsteps` explicit time steps (dynearthsol.cxx:768-894 with PT, RSF, phase
+ * changes, hydraulics, monitor and output off).  Asynchronous on the engine's stream;
+ * des_dev_sync or any download waits.  `out` (may be NULL) receives the scalars after
+ * the last step and forces a sync. */
+int des_dev_step(des_dev *h, int nsteps, des_scalars *out);
+
+int des_dev_sync(des_dev *h);
+
+/* check_nan (utils.hpp:323-394) on the device: number of NaN entries in
+ * volume, dpressure, viscosity, stress, temperature, tmass, force, vel, coord. */
+int des_dev_check_nan(des_dev *h, long long *n_nan);
+
+/* Timing helpers for bench.py: HIP-event bracket on the engine's own stream. */
+int des_dev_timer_start(des_dev *h);
+int des_dev_timer_stop(des_dev *h, float *ms);
+/* Per-kernel accumulated device time since the last reset (HIP events around every
+ * launch when profiling is enabled).  names/ms/calls hold up to `cap` entries. */
+int des_dev_profile_enable(des_dev *h, int on);
+int des_dev_profile_read(des_dev *h, int cap, char (*names)[64], double *ms, long long *calls);
+
+/* Algorithmic HBM bytes of one step for this engine's mesh and options (SURVEY.md 8d:
+ * 1420*nelem + 348*nnode with the evp / thermal / NMD variants). */
+double des_dev_algorithmic_bytes_per_step(const des_dev *h);
+
+const char *des_dev_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,47 @@
+/* des_host.h -- C entry points of the host side (libdes_host.so): ".cfg" front-end,
+ * mesh/topology builders, initial conditions and the driver loop.  This is the part of
+ * DynEarthSol that stays on the CPU; it mirrors main()/init() (dynearthsol.cxx:159-228,
+ * 593-982) and feeds the device engine declared in des_dev.h.
+ */
+#ifndef DES_HOST_H
+#define DES_HOST_H
+
+#include "des_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct des_host des_host;
+
+/* get_input_parameters + init_var + init() up to the point where fields exist
+ * (input.cxx:1503, dynearthsol.cxx:36-228).  `overrides`: extra "section.key = value"
+ * lines applied on top of the file (may be NULL).  `mesh_file`: a mesh written by the
+ * reference mesher for tetgen-based meshing options (may be NULL / empty).
+ * On failure returns NULL and stores the reference ExitCode in *err. */
+des_host *des_host_create(const char *cfg_path, const char *overrides, const char *mesh_file, int *err);
+/* same, from an in-memory config text */
+des_host *des_host_create_from_string(const char *cfg_text, const char *overrides, const char *mesh_file, int *err);
+void des_host_destroy(des_host *h);
+
+const des_params *des_host_params(const des_host *h);
+const des_mesh *des_host_mesh(const des_host *h);
+
+/* Named host arrays in the reference's SoA layout: "coord", "vel", "temperature",
+ * "radiogenic", "stress", "strain", "plstrain", "viscosity" (double); "elemmarkers",
+ * "connectivity", "segment", "segflag" (int32). Returns NULL for an unknown name. */
+const void *des_host_array(const des_host *h, const char *name, long long *count);
+
+/* typed access to any .cfg option after defaults/normalisation (as strings are parsed) */
+int des_host_cfg_int(const des_host *h, const char *key, int *out);
+int des_host_cfg_double(const des_host *h, const char *key, double *out);
+
+/* write the mesh in the loader's binary format (tools and tests) */
+int des_host_save_mesh(const des_host *h, const char *path);
+
+const char *des_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

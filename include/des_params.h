@@ -1,0 +1,189 @@
+/* des_params.h -- plain-data view of the reference's run parameters, mesh topology
+ * and field arrays, as they cross the C-ABI of the MI355X explicit time-stepper.
+ *
+ * The reference (GeoFLAC/DynEarthSol) has no FFI layer: its hot path is a set of free
+ * C++ functions reading `const Param&` / `Variables&` (fields.hpp:4-18, rheology.hpp:4-13,
+ * geometry.hpp:7-21,96-111, bc.hpp:4-17).  The structs below are a POD copy of exactly the
+ * members those functions read, so a maintainer can fill them from `Param`/`Variables`
+ * without conversion.
+ *
+ * Array layout is the reference's own: Array2D<T,N> compiled -DSOA (array2d.hpp:410-425,
+ * Makefile:831), i.e. component-major `a[d*n + i]`.  Every `double*`/`int*` below that
+ * is documented "SoA [N][n]" uses that layout.
+ */
+#ifndef DES_PARAMS_H
+#define DES_PARAMS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DES_MAX_MAT     16   /* max. number of material types carried in des_params */
+#define DES_NBDRY       10   /* constants.hpp:27-38  (x0,x1,y0,y1,z0,z1,n0..n3)      */
+#define DES_NBDRY_SIDE   6
+
+/* rheology bit flags, matprops.hpp:88-97 */
+enum {
+    DES_RH_ELASTIC = 1, DES_RH_VISCOUS = 2, DES_RH_PLASTIC = 4,
+    DES_RH_MAXWELL = 3, DES_RH_EP = 5, DES_RH_EVP = 7
+};
+
+/* Return codes of the C-ABI; the values are the reference's ExitCode categories
+ * (utils.hpp:20-55) so a caller can forward them to die(). */
+enum {
+    DES_OK = 0,
+    DES_ERR_CONFIG_VALUE = 11,     /* EXIT_CONFIG_VALUE: unknown option value          */
+    DES_ERR_UNSUPPORTED_DIM = 30,  /* EXIT_UNSUPPORTED_DIM                              */
+    DES_ERR_UNSUPPORTED = 31,      /* EXIT_UNSUPPORTED_LIB: feature/HIP device missing  */
+    DES_ERR_RUNTIME_NAN = 50,      /* EXIT_RUNTIME_NAN: dt<=0 or NaN in state           */
+    DES_ERR_RESOURCE = 52,         /* EXIT_RUNTIME_RESOURCE: device allocation failed   */
+    DES_ERR_INTERNAL = 60          /* EXIT_INTERNAL_ASSERT: bad handle / argument       */
+};
+
+/* POD copy of the Param members the hot path reads (parameters.hpp:206-473) plus the
+ * run constants main() derives once (dynearthsol.cxx:55-124, 207). */
+typedef struct des_params {
+    int ndims;                      /* 3 (THREED build); 2 is rejected by the device path for now */
+    int nmat;                       /* mat.nmat                                                     */
+    int rheol_type;                 /* mat.rheol_type, DES_RH_*                                     */
+    int mattype_ref;                /* mat.mattype_ref                                              */
+
+    /* control.* */
+    double gravity;
+    double inertial_scaling;
+    double damping_factor;
+    double dt_fraction;
+    double fixed_dt;
+    double characteristic_speed;
+    double surface_diffusivity;
+    double surf_base_level;
+    int damping_option;
+    int ref_pressure_option;
+    int surface_process_option;     /* 0 or 1 (simple_diffusion, bc.cxx:916-1112)                   */
+    int is_quasi_static;
+    int has_thermal_diffusion;
+    int is_using_mixed_stress;
+    int has_moving_mesh;
+    int quality_check_step_interval; /* mesh.quality_check_step_interval (bc.cxx:1830: dhacc reset) */
+
+    /* bc.* */
+    double surface_temperature;
+    double winkler_delta_rho;
+    double elastic_foundation_constant;
+    double sea_water_density;
+    double vbc_val_z1_loading_period;
+    int has_winkler_foundation;
+    int has_elastic_foundation;
+    int has_water_loading;
+    int pad1_;
+    int vbc_types[DES_NBDRY];       /* Variables::vbc_types  (dynearthsol.cxx:63-72)               */
+    double vbc_values[DES_NBDRY];   /* Variables::vbc_values (dynearthsol.cxx:74-83)               */
+    double vbc_val_l[4];            /* bc.vbc_val_{x0,x1,y0,y1}_l (lateral shear, type 6)          */
+    int stress_bc_types[DES_NBDRY_SIDE];
+    double stress_bc_values[DES_NBDRY_SIDE];
+
+    /* mesh.* */
+    double xlength, ylength, zlength;
+
+    /* mat.* scalars */
+    double visc_min, visc_max, tension_max, therm_diff_max;
+
+    /* mat.* per-material lists, already broadcast to nmat entries (input.cxx:983-989) */
+    double rho0[DES_MAX_MAT];
+    double alpha[DES_MAX_MAT];
+    double bulk_modulus[DES_MAX_MAT];
+    double shear_modulus[DES_MAX_MAT];
+    double visc_exponent[DES_MAX_MAT];
+    double visc_coefficient[DES_MAX_MAT];
+    double visc_activation_energy[DES_MAX_MAT];
+    double visc_activation_volume[DES_MAX_MAT];
+    double heat_capacity[DES_MAX_MAT];
+    double therm_cond[DES_MAX_MAT];
+    double pls0[DES_MAX_MAT], pls1[DES_MAX_MAT];
+    double cohesion0[DES_MAX_MAT], cohesion1[DES_MAX_MAT];
+    double friction_angle0[DES_MAX_MAT], friction_angle1[DES_MAX_MAT];
+    double dilation_angle0[DES_MAX_MAT], dilation_angle1[DES_MAX_MAT];
+    double porosity[DES_MAX_MAT];
+
+    /* run constants derived once by the driver */
+    double max_vbc_val;             /* Variables::max_vbc_val   (dynearthsol.cxx:55-59)            */
+    double compensation_pressure;   /* Variables::compensation_pressure (ic.cxx:361)               */
+} des_params;
+
+/* Mesh topology as the reference builds it once per (re)mesh (mesh.cxx:2837-3329,
+ * bc.cxx:94-224).  All pointers are host pointers, read during create() only. */
+typedef struct des_mesh {
+    int nnode, nelem;
+    const int *connectivity;        /* conn_t, SoA [4][nelem]                                       */
+    /* Support CSR (parameters.hpp:585-610): node n owns [idx[n], idx[n+1]) */
+    const int *support_idx;         /* [nnode+1] */
+    const int *support_arr;         /* [4*nelem] element ids, ascending per node                    */
+    const int *support_lidx;        /* [4*nelem] local node number inside that element              */
+    const unsigned *bcflag;         /* [nnode] boundary bit flags (constants.hpp:41-55)             */
+    int nbfacets[DES_NBDRY];        /* Variables::bfacets[i]->size()                                */
+    const int *bfacet_elem[DES_NBDRY];   /* .first  of each pair                                    */
+    const int *bfacet_facet[DES_NBDRY];  /* .second of each pair                                    */
+    int nbnodes[DES_NBDRY];
+    const int *bnodes[DES_NBDRY];
+    const double *bnormals;         /* array_t(nbdrytypes), SoA [3][10]                             */
+    const double *edge_vec;         /* Variables::edge_vec, [nedge*3]                               */
+    int nedge;
+    int edge_slot[DES_NBDRY * DES_NBDRY];
+    /* surface info (parameters.hpp:612-662, mesh.cxx:3031-3103, 2882-2933) */
+    int ntop, etop, ntop_elems;
+    const int *top_nodes;           /* [ntop]  surfinfo.top_nodes                                   */
+    const int *elem_and_nodes;      /* segment_t(etop), SoA [3][etop]: surface-local node numbers   */
+    const int *connectivity_surface;/* conn_t(etop), SoA [4][etop] (3 used)                         */
+    const int *support_surf_idx;    /* [ntop+1] */
+    const int *support_surf_arr;    /* top-facet ids per surface node                               */
+    const int *top_elems;           /* [ntop_elems] Variables::top_elems                            */
+} des_mesh;
+
+/* Field ids for upload/download.  "E" = per element, "N" = per node. */
+enum des_field {
+    DES_F_COORD = 0,        /* N  array_t   SoA [3][nnode]  */
+    DES_F_VEL,              /* N  array_t                   */
+    DES_F_FORCE,            /* N  array_t                   */
+    DES_F_FORCE_RESIDUAL,   /* N  array_t                   */
+    DES_F_COORD0,           /* N  array_t                   */
+    DES_F_TEMPERATURE,      /* N  double_vec                */
+    DES_F_VOLUME_N,         /* N  double_vec                */
+    DES_F_MASS,             /* N  double_vec                */
+    DES_F_TMASS,            /* N  double_vec                */
+    DES_F_DHACC,            /* N  surfinfo.dhacc            */
+    DES_F_STRESS,           /* E  tensor_t  SoA [6][nelem]  */
+    DES_F_STRAIN,           /* E  tensor_t                  */
+    DES_F_STRAIN_RATE,      /* E  tensor_t                  */
+    DES_F_PLSTRAIN,         /* E  double_vec                */
+    DES_F_DELTA_PLSTRAIN,   /* E  double_vec                */
+    DES_F_VISCOSITY,        /* E  double_vec                */
+    DES_F_VOLUME,           /* E  double_vec                */
+    DES_F_VOLUME_OLD,       /* E  double_vec                */
+    DES_F_DPRESSURE,        /* E  double_vec                */
+    DES_F_EDVOLDT,          /* E  double_vec                */
+    DES_F_RADIOGENIC,       /* E  double_vec radiogenic_source */
+    DES_F_ELEMMARKERS,      /* E  int32 [nelem][nmat] flat copy of int_vec2D elemmarkers */
+    DES_F_EDVACC_SURF,      /* surfinfo.edvacc_surf [etop]  */
+    DES_F_DH,               /* surfinfo.dh [ntop]           */
+    DES_F_NTMP,             /* N  double_vec Variables::ntmp (scratch, exposed for tests) */
+    DES_F_COUNT
+};
+
+/* Scalars the driver reads back (dynearthsol.cxx:773-774, 801, 893; bc.cxx:1825;
+ * geometry.cxx:1609-1610). */
+typedef struct des_scalars {
+    double dt;
+    double time;
+    double l2_residual;
+    double max_surf_vel;
+    double max_global_vel_mag;
+    double global_dt_min;
+    long long steps;
+    int status;                     /* DES_OK or DES_ERR_RUNTIME_NAN (dt <= 0)                      */
+    int pad_;
+} des_scalars;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,52 @@
+/* des_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of DynEarthSol's explicit time step (reference order, unfused), used
+ * only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg to check the
+ * HIP path.  Same call shape as include/des_dev.h so a test drives both identically.
+ */
+#ifndef DES_ORACLE_H
+#define DES_ORACLE_H
+
+#include "../include/des_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct des_oracle des_oracle;
+
+des_oracle *des_oracle_create(const des_params *params, const des_mesh *mesh);
+void des_oracle_destroy(des_oracle *h);
+int des_oracle_upload(des_oracle *h, int field, const void *host, long long count);
+int des_oracle_download(des_oracle *h, int field, void *host, long long count);
+long long des_oracle_field_count(const des_oracle *h, int field);
+int des_oracle_set_clock(des_oracle *h, double dt, double time, long long steps);
+int des_oracle_init_geometry(des_oracle *h);
+int des_oracle_compute_dt(des_oracle *h, double *dt);
+int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out);
+int des_oracle_check_nan(des_oracle *h, long long *n_nan);
+/* number of OpenMP threads the oracle loops run on (1 unless built with -fopenmp) */
+int des_oracle_threads(void);
+
+/* Stand-alone pieces exposed for known-answer tests. */
+/* eigenvalues (ascending) of the symmetric tensor s = {XX,YY,ZZ,XY,XZ,YZ};
+ * rheology.cxx:63-71 -> 3x3-C/dsyevc3.c:31-80 */
+void des_oracle_principal_values3(const double s[6], double p[3]);
+/* eigenvalues ascending + eigenvectors as columns; rheology.cxx:76-84 -> dsyevh3.c:112-215 */
+void des_oracle_principal_stresses3(const double s[6], double p[3], double v[9]);
+/* raw restatements of the vendored solvers, row-major A[9], Q[9] */
+int des_oracle_dsyevc3(const double A[9], double w[3]);
+int des_oracle_dsyevh3(const double A[9], double Q[9], double w[3]);
+int des_oracle_dsyevq3(const double A[9], double Q[9], double w[3]);
+/* one constitutive update of a single element, rheology.cxx:312-484 (3D):
+ * s is updated in place, returns depls; failure_mode out */
+double des_oracle_elasto_plastic(double bulkm, double shearm, double amc, double anphi,
+                                 double anpsi, double hardn, double ten_max,
+                                 const double de[6], double s[6], int *failure_mode);
+void des_oracle_maxwell(double bulkm, double shearm, double viscosity, double dt, double dv,
+                        const double de[6], double s[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,51 @@
+"""ctypes binding of the CPU oracle (oracle/libdes_oracle.so) -- tests only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dynearthsol_amd import EngineBase, bind_engine_api, DesParams, DesMesh, REPO_ROOT
+
+ORACLE_DIR = os.path.join(REPO_ROOT, "oracle")
+_libs = {}
+
+
+def load_oracle(omp=False):
+    name = "libdes_oracle_omp.so" if omp else "libdes_oracle.so"
+    if name not in _libs:
+        path = os.path.join(ORACLE_DIR, name)
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"])
+        lib = C.CDLL(path)
+        bind_engine_api(lib, "des_oracle")
+        lib.des_oracle_create.restype = C.c_void_p
+        lib.des_oracle_create.argtypes = [C.POINTER(DesParams), C.POINTER(DesMesh)]
+        lib.des_oracle_threads.restype = C.c_int
+        d6 = C.POINTER(C.c_double)
+        lib.des_oracle_principal_values3.argtypes = [d6, d6]
+        lib.des_oracle_principal_stresses3.argtypes = [d6, d6, d6]
+        for f in ("dsyevh3", "dsyevq3"):
+            getattr(lib, "des_oracle_" + f).argtypes = [d6, d6, d6]
+        lib.des_oracle_dsyevc3.argtypes = [d6, d6]
+        lib.des_oracle_elasto_plastic.restype = C.c_double
+        lib.des_oracle_elasto_plastic.argtypes = [C.c_double] * 7 + [d6, d6, C.POINTER(C.c_int)]
+        lib.des_oracle_maxwell.argtypes = [C.c_double] * 5 + [d6, d6]
+        _libs[name] = lib
+    return _libs[name]
+
+
+class OracleEngine(EngineBase):
+    prefix = "des_oracle"
+
+    def __init__(self, host, omp=False):
+        lib = load_oracle(omp)
+        h = lib.des_oracle_create(C.byref(host.params), C.byref(host.mesh))
+        if not h:
+            raise RuntimeError("des_oracle_create failed")
+        super().__init__(lib, h)
+        self._host = host
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
