@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py -- explicit time-steps/s x #elements of the MI355X time-stepper.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one explicit time step (dynearthsol.cxx:768-894) of the whole mesh.  The
+workload at N=1 is BASELINE.json configs[2] as SURVEY.md 8(d) pins it down: the
+benchmarks-cores/test-3d-big.cfg box (400 x 20 x 10 km, elasto-visco-plastic variant) at
+>= 1M tetrahedra.  The reference's TetGen mesher is a host-side library that cannot run on
+the GPU box, so the mesh is the reference's own regular mesher (meshing_option = 1,
+meshing_elem_shape = 1: 5 tets per grid cell, mesh.cxx:1431-1459), rebuilt by the host
+library: 560 x 28 x 14 cells = 1,097,600 tets / 244,035 nodes.  Fields are the model's own
+initial conditions (synthetic in the sense of: no input data files).
+
+Prints ONE JSON line (rank 0).  `value` = elements x steps / s summed over all ranks, timed
+with state resident in HBM; `roofline` is the dominant kernel's algorithmic bytes over its
+measured HIP-event duration against 8 TB/s; `cpu_baseline` is the CPU oracle (OpenMP build,
+kind "port") timed on this box's host cores on a bounded number of steps of the same mesh.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+BENCH_CFG = """
+[sim]
+modelname = bench
+max_steps = 1000000
+output_step_interval = 1000000
+is_outputting_averaged_fields = no
+[mesh]
+meshing_option = 1
+meshing_elem_shape = 1
+xlength = 400e3
+ylength = 20e3
+zlength = 10e3
+resolution = {res}
+quality_check_step_interval = 1000000
+[control]
+surface_process_option = 1
+surface_diffusivity = 1e-6
+dt_fraction = 1.0
+inertial_scaling = 1e4
+[bc]
+vbc_x0 = 1
+vbc_x1 = 1
+vbc_val_x0 = -1e-9
+vbc_val_x1 = 1e-9
+vbc_y0 = 1
+vbc_y1 = 1
+vbc_val_y0 = 0
+vbc_val_y1 = 0
+has_water_loading = no
+surface_temperature = 273
+mantle_temperature = 1573
+[ic]
+oceanic_plate_age_in_yr = 1e6
+weakzone_option = 1
+weakzone_azimuth = 15
+weakzone_inclination = -60
+weakzone_halfwidth = 1.2
+weakzone_depth_min = 0.5
+weakzone_depth_max = 1.0
+weakzone_xcenter = 0.5
+weakzone_ycenter = 0.5
+weakzone_zcenter = 0
+weakzone_plstrain = 0.5
+[mat]
+rheology_type = elasto-visco-plastic
+rho0 = [2700]
+alpha = [3e-5]
+bulk_modulus = [50e9]
+shear_modulus = [30e9]
+pls0 = [0]
+pls1 = [0.5]
+cohesion0 = [4.4e7]
+cohesion1 = [4e6]
+friction_angle0 = [30]
+friction_angle1 = [30]
+min_viscosity = 1e19
+"""
+
+# Algorithmic HBM bytes of each pass per element / per node (the
+# six rows sum to B_alg = 1420*ne + 348*nn; evp adds 24*ne + 8*nn to E2).
+KERNEL_BYTES = {
+    "E1_geom_rotate_strainrate":  (364, 56),
+    "N1_mass_temperature_dvoldt": (224, 64),
+    "E2_update_stress":           (364, 8),
+    "N2_nmd_gather":              (48, 20),
+    "E3_nmd_force":               (260, 40),
+    "N3_force_velocity_coord":    (160, 160),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--resolution", type=float, default=400e3 / 560)
+    ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+
+    import dynearthsol_amd as des
+
+    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution)))
+    dev = des.DeviceEngine(host, device=local_rank)
+    dev.init_from_host(host)
+    ne, nn = host.nelem, host.nnode
+
+    dev.step(args.warmup, want_scalars=False) if args.warmup > 0 else None
+    dev.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        dev.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    dev.timer_start()
+    dev.step(args.steps, want_scalars=False)
+    ev_ms = dev.timer_stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    sc = dev.step(0)
+    nan = dev.check_nan()
+
+    value = float(ne) * args.steps * world / wall
+    result = {
+        "metric": "explicit time-steps/sec x #elements",
+        "value": value,
+        "unit": "element-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * wall / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "test-3d-big.cfg box 400x20x10 km, elasto-visco-plastic, thermal+NMD+surface diffusion on, "
+                        "regular 5-tet mesh %d tets / %d nodes per GPU" % (ne, nn),
+            "nelem": ne, "nnode": nn,
+            "parallelism": "single GPU" if world == 1 else "%d independent replicas (domain decomposition pending)" % world,
+            "steps_per_s": args.steps / wall,
+            "hip_event_ms_per_step": ev_ms / args.steps,
+            "nan_entries": nan, "status": sc.status,
+        },
+    }
+
+    if rank == 0:
+        bytes_step = dev.algorithmic_bytes_per_step()
+        result["config"]["algorithmic_bytes_per_step"] = bytes_step
+        result["config"]["whole_step_frac_of_hbm_peak"] = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof = None
+        if not args.no_profile:
+            # per-kernel HIP-event timing on the engine's own stream (separate short run)
+            dev.profile_enable(True)
+            dev.step(20, want_scalars=False)
+            prof = dev.profile_read()
+            dev.profile_enable(False)
+            kern = {n: (ms, calls) for n, ms, calls in prof}
+            result["config"]["kernel_ms_per_call"] = {n: ms / calls for n, (ms, calls) in kern.items()}
+            cands = [(ms, n) for n, (ms, calls) in kern.items() if n in KERNEL_BYTES]
+            if cands:
+                _, dom = max(cands)
+                ms, calls = kern[dom]
+                be, bn = KERNEL_BYTES[dom]
+                if dom == "E2_update_stress" and "visco" in BENCH_CFG:
+                    be, bn = be + 24, bn + 8
+                kbytes = be * ne + bn * nn
+                achieved = kbytes / (ms / calls * 1e-3) / 1e9
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(tpath):
+                    try:
+                        traffic = json.load(open(tpath)).get(dom)
+                    except Exception:
+                        traffic = None
+                roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": ms / calls}
+        result["roofline"] = roof
+
+        cpu = None
+        cpu_steps = args.cpu_steps
+        if world == 1 and cpu_steps != 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_binding import OracleEngine, load_oracle
+            threads = load_oracle(omp=True).des_oracle_threads()
+            ora = OracleEngine(host, omp=True)
+            ora.init_from_host(host)
+            ora.step(1)
+            if cpu_steps < 0:
+                t1 = time.perf_counter(); ora.step(1); one = time.perf_counter() - t1
+                cpu_steps = max(2, min(200, int(15.0 / max(one, 1e-6))))
+            t1 = time.perf_counter()
+            ora.step(cpu_steps)
+            cw = time.perf_counter() - t1
+            cpu = {"value": float(ne) * cpu_steps / cw, "unit": "element-steps/s", "cores": threads,
+                   "kind": "port", "sample": "%d steps of the same %d-tet mesh (oracle, OpenMP, %d threads)"
+                                                % (cpu_steps, ne, threads)}
+        result["cpu_baseline"] = cpu
+        print(json.dumps(result))
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1640 @@
+// des_dev.hip -- MI355X (gfx950) engine behind include/des_dev.h.
+//
+// One explicit time step of the reference (dynearthsol.cxx:768-894) is ~24 OpenMP/OpenACC
+// loops with five element->node barriers.  Here it is six streaming passes over HBM plus
+// O(surface) kernels, all state resident on the device:
+//
+//   E1  elements  [end of step t]   compute_volume, compute_mass (element part), rotate_stress,
+//                                   compute_dt reduction (every 10th step)
+//                 [start of t+1]    update_temperature (element part), update_strain_rate,
+//                                   compute_dvoldt (element part)
+//   N1  nodes     compute_mass gather, update_temperature gather + update, compute_dvoldt gather
+//   E2  elements  compute_edvoldt, update_stress, NMD_stress (element part)
+//   N2  nodes     NMD_stress gather
+//   E3  elements  NMD_stress apply, update_force (element part)
+//   N3  nodes     update_force gather, apply_stress_bcs, apply_damping, update_velocity,
+//                 calculate_residual_force (partials), apply_vbcs, update_coordinate
+//   S*  surface   surface_processes (simple_diffusion, correct_surface_element)
+//
+// Node assembly is a deterministic gather over the reference's CSR support graph in
+// ascending element order (fields.cxx:659-676): no atomics on the data path, and the
+// same summation order as the CPU build.
+//
+// HBM layout (DESIGN.md "Data layout"): element fields are SoA planes a[c*ne + e] so a
+// wavefront of 64 consecutive elements reads 512 contiguous bytes per plane; nodal fields
+// that elements gather are packed per node into 32-byte records {x,y,z,T} and
+// {vx,vy,vz,mass} so that one gather is one aligned 32-byte sector; per-incidence
+// temporaries are element-major records so a node reads 24-32 contiguous bytes per
+// incident element.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "des_dev.h"
+#include "des_kernels.hpp"
+
+using desk::d4;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    g_last_error = std::string(#call) + ": " + hipGetErrorString(e_); return DES_ERR_RESOURCE; } } while (0)
+
+const int NODE_OF_FACET_H[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};
+__device__ const int NODE_OF_FACET_D[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};
+
+// device-resident clock and reduction scratch
+struct DevClock {
+    double dt, time, l2_residual, max_surf_vel, max_global_vel_mag, global_dt_min;
+    // compute_dt reduction slots (geometry.cxx:1490-1503)
+    double r_minl, r_dt_maxwell, r_dt_diffusion, r_global_dt_min, r_max_vem;
+    double maxdh;
+    long long steps;
+    int status;
+    int pad;
+};
+
+enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };   // INIT: C part without rotate_stress
+
+enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_BCF, K_N3, K_RES, K_S1, K_S2, K_S3, K_S4, K_S5,
+                K_DTFIN, K_MISC, K_COUNT };
+const char *kKernelNames[K_COUNT] = {
+    "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "N2_nmd_gather",
+    "E3_nmd_force", "BC_facets", "N3_force_velocity_coord", "residual_finalize", "S1_surf_facets",
+    "S2_surf_nodes", "S3_surf_edvacc", "S4_surf_maxdh", "S5_correct_surface_element",
+    "dt_finalize", "misc" };
+
+struct ProfRec { int k; hipEvent_t a, b; };
+
+} // namespace
+
+struct des_dev {
+    int device;
+    des_params p;
+    int nn, ne, nmat;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+
+    des_params *d_p;
+    desk::ViscTerms *d_vt;
+    DevClock *d_clk;
+    DevClock *h_clk;         // pinned mirror
+
+    // topology
+    int4 *conn;
+    int *sup_idx, *sup_pack;             // pack = elem*4 + local node
+    unsigned *bcflag;
+    // nodal
+    d4 *xt, *vm;                          // {x,y,z,T}, {vx,vy,vz,mass}
+    double *ntmp, *volume_n, *tmass, *ymass, *force, *fres, *coord0, *dhacc;
+    // element
+    double *stress, *strain, *strain_rate, *plstrain, *delta_plstrain, *viscosity, *volume,
+           *volume_old, *dpressure, *radiogenic;
+    int *markers;
+    double *props;                        // [5][ne] bulkm, shearm, phi, cp, k  (nmat > 1 only)
+    // temporaries
+    d4 *mrec, *ttmp;                      // {vol, m, tm, dvol}, thermal tr[4]
+    double *etmp2, *ftmp;                 // dp*vol ; force tr [ne][4][3]
+    double *res_part;                     // per-block partial sums of the residual
+    int n3_blocks;
+    // stress-bc lists
+    int nbcf;                             // facets with a stress bc (incl. neumann)
+    int *bcf_elem, *bcf_facet, *bcf_kind; // kind: 0 winkler, 1 water, 2 side wall, 3+d neumann dir d
+    double *bcf_val;                      // neumann value per facet
+    double *bcf_tmp;                      // [nbcf][9]
+    int *bcn_idx, *bcn_ent;               // per-node CSR of entries (facet*3+l)*2 + is_neumann
+    unsigned bc_mask;                     // bcflag bits that have any entry
+    // surface
+    int ntop, etop, ntop_elems;
+    int *top_nodes, *ean, *conn_surf, *ssup_idx, *ssup_arr, *top_elems, *topf_elem, *topf_facet;
+    double *dh, *edvacc, *sarea, *sslope; // sslope [etop][3]
+    // bnormals / edges for slanted boundaries
+    double *bnormals, *edge_vec; int *edge_slot;
+
+    bool markers_dirty;
+    bool pending_c;                       // C part of the last step has been run (always true outside step())
+    long long steps_host;
+    // profiling
+    bool prof;
+    std::vector<ProfRec> prof_recs;
+    double prof_ms[K_COUNT]; long long prof_calls[K_COUNT];
+};
+
+namespace {
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+struct ElemProps { double bulkm, shearm, phi, cp, k; };
+
+__device__ __forceinline__ ElemProps load_props(const des_params *p, const double *props, int ne, int e)
+{
+    ElemProps r;
+    if (props) {
+        r.bulkm = props[e]; r.shearm = props[(size_t)ne + e]; r.phi = props[(size_t)2*ne + e];
+        r.cp = props[(size_t)3*ne + e]; r.k = props[(size_t)4*ne + e];
+    } else {
+        r.bulkm = p->bulk_modulus[0]; r.shearm = p->shear_modulus[0]; r.phi = p->porosity[0];
+        r.cp = p->heat_capacity[0]; r.k = p->therm_cond[0];
+    }
+    return r;
+}
+
+// refresh_elem_cache (matprops.cxx:259-303) for nmat > 1
+__global__ void __launch_bounds__(DES_BLOCK)
+k_props(const des_params *p, const int *markers, double *props, int ne)
+{
+    int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const int nmat = p->nmat;
+    const int *mk = markers + (size_t)e * nmat;
+    props[e]                = desk::harmonic_mean(p->bulk_modulus, mk, nmat);
+    props[(size_t)ne + e]   = desk::harmonic_mean(p->shear_modulus, mk, nmat);
+    props[(size_t)2*ne + e] = desk::arithmetic_mean(p->porosity, mk, nmat);
+    props[(size_t)3*ne + e] = desk::arithmetic_mean(p->heat_capacity, mk, nmat);
+    props[(size_t)4*ne + e] = desk::arithmetic_mean(p->therm_cond, mk, nmat);
+}
+
+// ---- E1 --------------------------------------------------------------------------
+// MODE_C: compute_volume (geometry.cxx:170-201) after the volume swap (dynearthsol.cxx:466-470),
+//         compute_mass element part (geometry.cxx:1795-1840), rotate_stress (fields.cxx:827-902);
+//         MODE_DT adds the compute_dt reduction (geometry.cxx:1513-1593).
+// MODE_A: update_temperature element part (fields.cxx:211-239), update_strain_rate
+//         (fields.cxx:415-476), compute_dvoldt element part (geometry.cxx:218-224).
+template <int MODE>
+__global__ void __launch_bounds__(DES_BLOCK)
+k_e1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int nblocks,
+     const int4 *__restrict__ conn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
+     const int *__restrict__ markers, const double *__restrict__ props,
+     const double *__restrict__ radiogenic,
+     double *__restrict__ stress, double *__restrict__ strain,
+     double *__restrict__ volume, double *__restrict__ volume_old,
+     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp)
+{
+    const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    const bool active = e < ne;
+
+    double r_minl = DBL_MAX, r_maxw = DBL_MAX, r_diff = DBL_MAX, r_gdt = DBL_MAX, r_vem = 0.0;
+
+    if (active) {
+        const int4 cn = conn[e];
+        d4 c[4], v[4];
+        c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
+        v[0] = vm[cn.x]; v[1] = vm[cn.y]; v[2] = vm[cn.z]; v[3] = vm[cn.w];
+        const int nmat = p->nmat;
+        const int *mk = markers + (size_t)e * nmat;
+        const ElemProps pr = load_props(p, props, ne, e);
+
+        // mean nodal temperature, matprops.cxx:338-343
+        double T = 0;
+        T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
+        T /= 4;
+        const double rho = desk::mat_rho(p, mk, T);
+
+        double vol;
+        d4 rec;
+        if (MODE & MODE_C) {
+            volume_old[e] = volume[e];           // pointer swap of dynearthsol.cxx:466-470
+            vol = desk::tet_volume(c);
+            volume[e] = vol;
+            // compute_mass, element part
+            const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+            double rho_m = p->is_quasi_static ? pr.bulkm / (pseudo_speed * pseudo_speed) : rho;
+            rec.x = vol;
+            rec.y = rho_m * vol / 4;
+            rec.z = rho * pr.cp * vol / 4;
+        } else {
+            vol = volume[e];
+            if (MODE & MODE_A) {
+                const d4 old = mrec[e];
+                rec.x = old.x; rec.y = old.y; rec.z = old.z;
+            }
+        }
+
+        double sx[4], sy[4], sz[4];
+        desk::shape_fn(c, vol, sx, sy, sz);
+
+        if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
+            if (p->rheol_type & DES_RH_ELASTIC) {
+                const double dt = clk->dt;
+                double w3 = 0, w4 = 0, w5 = 0;
+                for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
+                for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
+                for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
+                double s[6], es[6];
+                for (int i = 0; i < 6; ++i) { s[i] = stress[(size_t)i*ne + e]; es[i] = strain[(size_t)i*ne + e]; }
+                desk::jaumann_rate_3d(s, dt, w3, w4, w5);
+                desk::jaumann_rate_3d(es, dt, w3, w4, w5);
+                for (int i = 0; i < 6; ++i) { stress[(size_t)i*ne + e] = s[i]; strain[(size_t)i*ne + e] = es[i]; }
+            }
+        }
+
+        if (MODE & MODE_DT) {
+            double vx = 0.0, vy = 0.0, vz = 0.0;
+            const double weight = 1.0 / 4;
+            for (int j = 0; j < 4; ++j) { vx += v[j].x * weight; vy += v[j].y * weight; vz += v[j].z * weight; }
+            r_vem = sqrt(vx*vx + vy*vy + vz*vz);
+            double maxa = fmax(fmax(desk::tri_area(c[0], c[1], c[2]), desk::tri_area(c[0], c[1], c[3])),
+                               fmax(desk::tri_area(c[2], c[3], c[0]), desk::tri_area(c[2], c[3], c[1])));
+            double minh = 3 * vol / maxa;
+            r_maxw = 0.5 * p->visc_min / (1e-40 + pr.shearm);
+            if (p->has_thermal_diffusion) r_diff = 0.5 * minh * minh / p->therm_diff_max;
+            r_minl = minh;
+            r_gdt = minh / sqrt(pr.shearm / rho) / 5.0;
+        }
+
+        if (MODE & MODE_A) {
+            if (p->has_thermal_diffusion) {
+                double kv = pr.k * vol;
+                double rh = radiogenic[e] * vol * rho / 4;
+                d4 tr;
+                double *trp = &tr.x;
+                for (int i = 0; i < 4; ++i) {
+                    double diffusion = 0.;
+                    for (int j = 0; j < 4; ++j)
+                        diffusion += (sx[i] * sx[j] + sy[i] * sy[j] + sz[i] * sz[j]) * c[j].w;
+                    trp[i] = diffusion * kv - rh;
+                }
+                ttmp[e] = tr;
+            }
+            double s[6];
+            s[0] = 0; for (int i = 0; i < 4; ++i) s[0] += v[i].x * sx[i];
+            s[1] = 0; for (int i = 0; i < 4; ++i) s[1] += v[i].y * sy[i];
+            s[2] = 0; for (int i = 0; i < 4; ++i) s[2] += v[i].z * sz[i];
+            s[3] = 0; for (int i = 0; i < 4; ++i) s[3] += 0.5 * (v[i].x * sy[i] + v[i].y * sx[i]);
+            s[4] = 0; for (int i = 0; i < 4; ++i) s[4] += 0.5 * (v[i].x * sz[i] + v[i].z * sx[i]);
+            s[5] = 0; for (int i = 0; i < 4; ++i) s[5] += 0.5 * (v[i].y * sz[i] + v[i].z * sy[i]);
+            for (int i = 0; i < 6; ++i) strain_rate[(size_t)i*ne + e] = s[i];
+            double dj = s[0] + s[1] + s[2];
+            rec.w = dj * vol;
+        } else {
+            rec.w = 0;
+        }
+        if (MODE & (MODE_C | MODE_A)) mrec[e] = rec;
+    }
+
+    if (MODE & MODE_DT) {
+        __shared__ double red[5][DES_BLOCK / 64];
+        r_minl = desk::wave_min(r_minl); r_maxw = desk::wave_min(r_maxw); r_diff = desk::wave_min(r_diff);
+        r_gdt = desk::wave_min(r_gdt);   r_vem = desk::wave_max(r_vem);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) { red[0][w] = r_minl; red[1][w] = r_maxw; red[2][w] = r_diff; red[3][w] = r_gdt; red[4][w] = r_vem; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < DES_BLOCK / 64; ++i) {
+                red[0][0] = fmin(red[0][0], red[0][i]); red[1][0] = fmin(red[1][0], red[1][i]);
+                red[2][0] = fmin(red[2][0], red[2][i]); red[3][0] = fmin(red[3][0], red[3][i]);
+                red[4][0] = fmax(red[4][0], red[4][i]);
+            }
+            desk::atomic_min_double(&clk->r_minl, red[0][0]);
+            desk::atomic_min_double(&clk->r_dt_maxwell, red[1][0]);
+            desk::atomic_min_double(&clk->r_dt_diffusion, red[2][0]);
+            desk::atomic_min_double(&clk->r_global_dt_min, red[3][0]);
+            desk::atomic_max_double(&clk->r_max_vem, red[4][0]);
+        }
+    }
+}
+
+// compute_dt tail (geometry.cxx:1597-1646); one thread
+__global__ void k_dt_finalize(const des_params *p, DevClock *clk)
+{
+    double dt_maxwell = clk->r_dt_maxwell, dt_diffusion = clk->r_dt_diffusion, minl = clk->r_minl;
+    const double dt_hydro_diffusion = DBL_MAX;
+    double global_max_vem = clk->r_max_vem;
+    double max_vbc_val;
+    if (p->characteristic_speed == 0) {
+        max_vbc_val = p->max_vbc_val;
+        if (p->surface_process_option > 0)
+            max_vbc_val = fmax(max_vbc_val, clk->max_surf_vel * 5e-1);
+    } else
+        max_vbc_val = p->characteristic_speed;
+    global_max_vem = fmax(global_max_vem, p->max_vbc_val);
+    clk->max_global_vel_mag = global_max_vem;
+    clk->global_dt_min = clk->r_global_dt_min;
+    double dt_advection = 0.5 * minl / max_vbc_val;
+    double dt_elastic = p->is_quasi_static
+        ? 0.5 * minl / (max_vbc_val * p->inertial_scaling)
+        : 0.5 * minl / sqrt(p->bulk_modulus[p->mattype_ref] / p->rho0[p->mattype_ref]);
+    double dt = fmin(fmin(fmin(dt_elastic, dt_maxwell), fmin(dt_advection, dt_diffusion)), dt_hydro_diffusion)
+                * p->dt_fraction;
+    if (p->fixed_dt != 0) dt = p->fixed_dt;
+    if (!(dt > 0)) clk->status = DES_ERR_RUNTIME_NAN;
+    clk->dt = dt;
+    clk->r_minl = DBL_MAX; clk->r_dt_maxwell = DBL_MAX; clk->r_dt_diffusion = DBL_MAX;
+    clk->r_global_dt_min = DBL_MAX; clk->r_max_vem = 0.0;
+}
+
+// ---- N1 --------------------------------------------------------------------------
+// compute_mass gather (geometry.cxx:1846-1864), update_temperature node loop
+// (fields.cxx:245-262), compute_dvoldt gather (geometry.cxx:231-238).
+// Also advances the clock: steps++, time += dt (dynearthsol.cxx:773-774).
+__global__ void __launch_bounds__(DES_BLOCK)
+k_n1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int nblocks, int advance_clock,
+     const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
+     const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp,
+     d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
+     double *__restrict__ ntmp)
+{
+    const int n = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    const double dt = clk->dt;
+    if (advance_clock && blockIdx.x == 0 && threadIdx.x == 0) {
+        clk->steps += 1;
+        clk->time += dt;
+    }
+    if (n >= nn) return;
+    const int k0 = sup_idx[n], k1 = sup_idx[n+1];
+    const bool thermal = p->has_thermal_diffusion;
+    double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0;
+    for (int k = k0; k < k1; ++k) {
+        const int pk = sup_pack[k];
+        const int e = pk >> 2, li = pk & 3;
+        const d4 r = mrec[e];
+        vn += r.x;
+        ms += r.y;
+        if (thermal) {
+            tms += r.z;
+            tdot += (&ttmp[e].x)[li];
+        }
+        acc += r.w;
+    }
+    volume_n[n] = vn;
+    tmass[n] = tms;
+    d4 m4 = vm[n];
+    m4.w = ms;
+    vm[n] = m4;
+    if (thermal) {
+        d4 x4 = xt[n];
+        if (bcflag[n] & (1u << 5))
+            x4.w = p->surface_temperature;
+        else
+            x4.w -= dt * tdot / tms;
+        xt[n] = x4;
+    }
+    ntmp[n] = acc / vn;
+}
+
+// mass-only variant used by init_geometry (compute_mass without the temperature update)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_mass_gather(int nn, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
+              const d4 *__restrict__ mrec, d4 *__restrict__ vm, double *__restrict__ volume_n,
+              double *__restrict__ tmass, int thermal)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    double vn = 0, ms = 0, tms = 0;
+    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) {
+        const d4 r = mrec[sup_pack[k] >> 2];
+        vn += r.x; ms += r.y;
+        if (thermal) tms += r.z;
+    }
+    volume_n[n] = vn; tmass[n] = tms;
+    d4 m4 = vm[n]; m4.w = ms; vm[n] = m4;
+}
+
+// ---- E2 --------------------------------------------------------------------------
+// compute_edvoldt (geometry.cxx:264-272), update_stress (rheology.cxx:728-1026),
+// NMD_stress element part (geometry.cxx:294-296)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_e2(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
+     int ne, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const int *__restrict__ markers, const double *__restrict__ props,
+     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
+     double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
+     double *__restrict__ dpressure, double *__restrict__ etmp2)
+{
+    const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const double dt = clk->dt;
+    const int4 cn = conn[e];
+    const int rheol = p->rheol_type;
+    const int *mk = markers + (size_t)e * p->nmat;
+    const ElemProps pr = load_props(p, props, ne, e);
+
+    double dj = 0;
+    dj += ntmp[cn.x]; dj += ntmp[cn.y]; dj += ntmp[cn.z]; dj += ntmp[cn.w];
+    const double edvoldt = dj / 4;
+
+    double s[6], es[6], edot[6];
+    for (int i = 0; i < 6; ++i) {
+        s[i] = stress[(size_t)i*ne + e];
+        es[i] = strain[(size_t)i*ne + e];
+        edot[i] = strain_rate[(size_t)i*ne + e];
+    }
+    const double old_s = desk::trace3(s);
+    {
+        double div = desk::trace3(edot);
+        for (int i = 0; i < 3; ++i) edot[i] += (edvoldt - div) / 3;
+    }
+    for (int i = 0; i < 6; ++i) es[i] += edot[i] * dt;
+    double de[6];
+    for (int i = 0; i < 6; ++i) de[i] = edot[i] * dt;
+    double dpl = 0.;
+    const double vol = volume[e];
+
+    double visc = 0;
+    if (rheol & DES_RH_VISCOUS) {
+        double T = 0;
+        T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
+        T /= 4;
+        visc = desk::mat_visc(p, vt, mk, T, s, edot);
+        viscosity[e] = visc;
+    }
+
+    switch (rheol) {
+    case DES_RH_ELASTIC:
+        desk::elastic(pr.bulkm, pr.shearm, de, s);
+        break;
+    case DES_RH_VISCOUS:
+        desk::viscous(pr.bulkm, visc, desk::trace3(es), edot, s);
+        break;
+    case DES_RH_MAXWELL: {
+        double dv = vol / volume_old[e] - 1;
+        desk::maxwell(pr.bulkm, pr.shearm, visc, dt, dv, de, s);
+        break;
+    }
+    case DES_RH_EP: {
+        double amc, anphi, anpsi, hardn, ten_max;
+        double pls = plstrain[e];
+        desk::plastic_props(p, mk, pls, amc, anphi, anpsi, hardn, ten_max);
+        double depls = desk::elasto_plastic(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s);
+        if (depls != 0) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
+        dpl = depls;
+        break;
+    }
+    case DES_RH_EVP: {
+        double dv = vol / volume_old[e] - 1;
+        double sv[6];
+        for (int i = 0; i < 6; ++i) sv[i] = s[i];
+        desk::maxwell(pr.bulkm, pr.shearm, visc, dt, dv, de, sv);
+        double svII = desk::second_invariant2(sv);
+        double amc, anphi, anpsi, hardn, ten_max;
+        double pls = plstrain[e];
+        desk::plastic_props(p, mk, pls, amc, anphi, anpsi, hardn, ten_max);
+        double sp[6];
+        for (int i = 0; i < 6; ++i) sp[i] = s[i];
+        double depls = desk::elasto_plastic(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp);
+        double spII = desk::second_invariant2(sp);
+        if (svII < spII) {
+            for (int i = 0; i < 6; ++i) s[i] = sv[i];
+        } else {
+            for (int i = 0; i < 6; ++i) s[i] = sp[i];
+            plstrain[e] = pls + depls;
+            dpl = depls;
+        }
+        break;
+    }
+    default: break;
+    }
+    delta_plstrain[e] = dpl;
+    for (int i = 0; i < 6; ++i) {
+        stress[(size_t)i*ne + e] = s[i];
+        strain[(size_t)i*ne + e] = es[i];
+    }
+    for (int i = 0; i < 3; ++i) strain_rate[(size_t)i*ne + e] = edot[i];   // only the diagonal changed
+    if (p->is_using_mixed_stress) {
+        double dp = desk::trace3(s) - old_s;
+        dpressure[e] = dp;
+        etmp2[e] = dp * vol;
+    }
+}
+
+// ---- N2 --------------------------------------------------------------------------
+// NMD_stress gather (geometry.cxx:302-309)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_n2(int nn, int nblocks, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
+     const double *__restrict__ etmp2, const double *__restrict__ volume_n, double *__restrict__ ntmp)
+{
+    const int n = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    double acc = 0;
+    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k)
+        acc += etmp2[sup_pack[k] >> 2];
+    ntmp[n] = acc / volume_n[n];
+}
+
+// ---- E3 --------------------------------------------------------------------------
+// NMD_stress apply (geometry.cxx:316-331), update_force element part (fields.cxx:623-653)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_e3(const des_params *__restrict__ p, int ne, int nblocks, const int4 *__restrict__ conn,
+     const d4 *__restrict__ xt, const double *__restrict__ ntmp, const int *__restrict__ markers,
+     const double *__restrict__ props, const double *__restrict__ volume,
+     const double *__restrict__ dpressure, double *__restrict__ stress, double *__restrict__ ftmp)
+{
+    const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const int4 cn = conn[e];
+    d4 c[4];
+    c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
+    double s[6];
+    for (int i = 0; i < 6; ++i) s[i] = stress[(size_t)i*ne + e];
+    if (p->is_using_mixed_stress) {
+        double dp = 0;
+        dp += ntmp[cn.x]; dp += ntmp[cn.y]; dp += ntmp[cn.z]; dp += ntmp[cn.w];
+        double dp_el = dp / 4;
+        double dp_orig = dpressure[e];
+        double ddp = (-dp_orig + dp_el) / 3;
+        for (int i = 0; i < 3; ++i) { s[i] += ddp; stress[(size_t)i*ne + e] = s[i]; }
+    }
+    const double vol = volume[e];
+    double sx[4], sy[4], sz[4];
+    desk::shape_fn(c, vol, sx, sy, sz);
+    double buoy = 0;
+    if (p->gravity != 0) {
+        double T = 0;
+        T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
+        T /= 4;
+        const double rho = desk::mat_rho(p, markers + (size_t)e * p->nmat, T);
+        const double phi = props ? props[(size_t)2*ne + e] : p->porosity[0];
+        buoy = (rho * (1 - phi) + 1000.0 * phi) * p->gravity / 4;
+    }
+    double *out = ftmp + (size_t)e * 12;
+    for (int i = 0; i < 4; ++i) {
+        out[i*3 + 0] = (s[0]*sx[i] + s[3]*sy[i] + s[4]*sz[i]) * vol;
+        out[i*3 + 1] = (s[3]*sx[i] + s[1]*sy[i] + s[5]*sz[i]) * vol;
+        out[i*3 + 2] = (s[4]*sx[i] + s[5]*sy[i] + s[2]*sz[i] + buoy) * vol;
+    }
+}
+
+// ---- stress-bc facets ------------------------------------------------------------
+// apply_stress_bcs facet loop (bc.cxx:707-777) and apply_stress_bcs_neumann (bc.cxx:846-905)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_bc_facets(const des_params *__restrict__ p, int nf, int ne, const int4 *__restrict__ conn,
+            const d4 *__restrict__ xt, const int *__restrict__ markers,
+            const int *__restrict__ f_elem, const int *__restrict__ f_facet, const int *__restrict__ f_kind,
+            const double *__restrict__ f_val, double *__restrict__ f_tmp)
+{
+    const int g = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (g >= nf) return;
+    const int e = f_elem[g], f = f_facet[g], kind = f_kind[g];
+    const int4 cn = conn[e];
+    const int cna[4] = {cn.x, cn.y, cn.z, cn.w};
+    d4 fc[3];
+    for (int j = 0; j < 3; ++j) fc[j] = xt[cna[NODE_OF_FACET_D[f][j]]];
+    // normal_vector_of_facet, bc.cxx:24-54
+    double v01[3] = {fc[1].x - fc[0].x, fc[1].y - fc[0].y, fc[1].z - fc[0].z};
+    double v02[3] = {fc[2].x - fc[0].x, fc[2].y - fc[0].y, fc[2].z - fc[0].z};
+    double normal[3];
+    normal[0] = (v01[1] * v02[2] - v01[2] * v02[1]) / 2;
+    normal[1] = (v01[2] * v02[0] - v01[0] * v02[2]) / 2;
+    normal[2] = (v01[0] * v02[1] - v01[1] * v02[0]) / 2;
+    double zcenter = (fc[0].z + fc[1].z + fc[2].z) / 3;
+    double *out = f_tmp + (size_t)g * 9;
+    if (kind >= 3) {
+        double traction[3] = {0, 0, 0};
+        traction[kind - 3] = f_val[g];
+        for (int j = 0; j < 3; ++j)
+            for (int d = 0; d < 3; ++d) out[j*3 + d] = traction[d] * normal[d] / 3;
+        return;
+    }
+    double pr;
+    if (kind == 0) {
+        double T = 0;
+        T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
+        T /= 4;
+        double rho_effective = desk::mat_rho(p, markers + (size_t)e * p->nmat, T);
+        pr = p->compensation_pressure -
+             (rho_effective + p->winkler_delta_rho) * p->gravity * (zcenter + p->zlength);
+    } else if (kind == 1) {
+        pr = 0;
+        if (zcenter < p->surf_base_level)
+            pr = p->sea_water_density * p->gravity * (p->surf_base_level - zcenter);
+    } else {
+        pr = desk::ref_pressure(p, zcenter);
+        if (pr < 0.0) pr = 0.0;
+    }
+    for (int j = 0; j < 3; ++j)
+        for (int d = 0; d < 3; ++d) out[j*3 + d] = pr * normal[d] / 3;
+}
+
+// ---- N3 --------------------------------------------------------------------------
+// apply_vbcs for one node (bc.cxx:400-651, THREED)
+__device__ __forceinline__ void apply_vbcs_node(const des_params *p, unsigned flag, double time,
+                                                const double *bnormals, const double *edge_vec,
+                                                const int *edge_slot, double v[3])
+{
+    for (int lf = 0; lf < 4; ++lf) {
+        if (!(flag & (1u << lf))) continue;
+        const int ni = (lf < 2) ? 0 : 1, li = (lf < 2) ? 1 : 0;
+        const double val = p->vbc_values[lf], val_l = p->vbc_val_l[lf];
+        switch (p->vbc_types[lf]) {
+        case 0: break;
+        case 1: v[ni] = val; break;
+        case 2: v[li] = 0; v[2] = 0; break;
+        case 3: v[ni] = val; v[li] = 0; v[2] = 0; break;
+        case 4: v[li] = val; v[2] = 0; break;
+        case 5: v[ni] = 0; v[li] = val; v[2] = 0; break;
+        case 6: v[ni] = val; v[li] = val_l; break;
+        case 7: v[ni] = val; v[li] = 0; break;
+        }
+    }
+    if (flag & 0x3c0u) {
+        for (int ib = 6; ib <= 9; ib++) {
+            if (!(flag & (1u << ib))) continue;
+            const double n[3] = {bnormals[ib], bnormals[DES_NBDRY + ib], bnormals[2*DES_NBDRY + ib]};
+            const int type = p->vbc_types[ib];
+            double fac = 0;
+            if (type == 1 || type == 11) {
+                const int nd = (type == 1) ? 3 : 2;
+                double target = p->vbc_values[ib];
+                if (type == 11) {
+                    fac = 1 / sqrt(1 - n[2]*n[2]);
+                    target = p->vbc_values[ib] * fac;
+                }
+                if (flag == (1u << ib)) {
+                    double vn = 0;
+                    for (int d = 0; d < nd; d++) vn += v[d] * n[d];
+                    for (int d = 0; d < nd; d++) v[d] += (target - vn) * n[d];
+                } else {
+                    for (int ic = 0; ic < ib; ic++) {
+                        if (!(flag & (1u << ic))) continue;
+                        if (p->vbc_types[ic] == 0) {
+                            double vn = 0;
+                            for (int d = 0; d < nd; d++) vn += v[d] * n[d];
+                            for (int d = 0; d < nd; d++) v[d] += (target - vn) * n[d];
+                        } else if (p->vbc_types[ic] == 1) {
+                            const int slot = edge_slot[ic*DES_NBDRY + ib];
+                            if (slot < 0) continue;
+                            const double *edge = &edge_vec[slot*3];
+                            double ve = 0;
+                            for (int d = 0; d < 3; d++) ve += v[d] * edge[d];
+                            for (int d = 0; d < 3; d++) v[d] = ve * edge[d];
+                        }
+                    }
+                }
+            } else if (type == 3) {
+                for (int d = 0; d < 3; d++) v[d] = p->vbc_values[ib] * n[d];
+            } else if (type == 13) {
+                fac = 1 / sqrt(1 - n[2]*n[2]);
+                for (int d = 0; d < 2; d++) v[d] = p->vbc_values[ib] * fac * n[d];
+                v[2] = 0;
+            }
+        }
+    }
+    int bc_z0 = p->vbc_types[4], bc_z1 = p->vbc_types[5];
+    if (time > p->vbc_val_z1_loading_period) bc_z1 = 0;
+    if (bc_z0 == 0 && bc_z1 == 0) return;
+    const double bc_vz0 = p->vbc_values[4], bc_vz1 = p->vbc_values[5];
+    if (flag & (1u << 4)) {
+        switch (bc_z0) {
+        case 1: v[2] = bc_vz0; break;
+        case 2: v[0] = 0; v[1] = 0; break;
+        case 3: v[0] = 0; v[1] = 0; v[2] = bc_vz0; break;
+        }
+    }
+    if (flag & (1u << 5)) {
+        switch (bc_z1) {
+        case 1: v[2] = bc_vz1; break;
+        case 2: v[0] = 0; v[1] = 0; break;
+        case 3: v[0] = 0.0; v[1] = 0; v[2] = bc_vz1; break;
+        case 4: v[0] = bc_vz1; v[1] = 0; v[2] = 0; break;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(DES_BLOCK)
+k_apply_vbcs(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn,
+             const unsigned *__restrict__ bcflag, const double *__restrict__ bnormals,
+             const double *__restrict__ edge_vec, const int *__restrict__ edge_slot, d4 *__restrict__ vm)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    const unsigned flag = bcflag[n];
+    if (!(flag & 0x3ffu)) return;
+    d4 m4 = vm[n];
+    double v[3] = {m4.x, m4.y, m4.z};
+    apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
+    m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
+    vm[n] = m4;
+}
+
+// update_force node loop (fields.cxx:659-676), apply_stress_bcs node loop (bc.cxx:783-802,
+// 817-823), apply_stress_bcs_neumann, apply_damping (fields.cxx:483-579), update_velocity
+// (fields.cxx:725-742), residual partial sums (fields.cxx:700-722), apply_vbcs,
+// update_coordinate (fields.cxx:761-784)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_n3(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn, int nblocks,
+     const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
+     const double *__restrict__ ftmp, unsigned bc_mask, const int *__restrict__ bcn_idx,
+     const int *__restrict__ bcn_ent, const double *__restrict__ bcf_tmp,
+     const double *__restrict__ coord0, const double *__restrict__ ymass,
+     const double *__restrict__ bnormals, const double *__restrict__ edge_vec, const int *__restrict__ edge_slot,
+     d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ force, double *__restrict__ fres,
+     double *__restrict__ res_part)
+{
+    const int lb = desk::logical_block(nblocks);
+    const int n = lb * DES_BLOCK + threadIdx.x;
+    double l2 = 0.0;
+    if (n < nn) {
+        const double dt = clk->dt;
+        double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
+        const int k0 = sup_idx[n], k1 = sup_idx[n+1];
+        for (int k = k0; k < k1; ++k) {
+            const int pk = sup_pack[k];
+            const double *tr = ftmp + (size_t)(pk >> 2) * 12 + (pk & 3) * 3;
+            const double t0 = tr[0], t1 = tr[1], t2 = tr[2];
+            f[0] -= t0; f[1] -= t1; f[2] -= t2;
+            fr[0] = t0; fr[1] = t1; fr[2] = t2;          // assignment: fields.cxx:673
+        }
+        const unsigned flag = bcflag[n];
+        d4 x4 = xt[n];
+        if (flag & bc_mask) {
+            const int b0 = bcn_idx[n], b1 = bcn_idx[n+1];
+            int b = b0;
+            for (; b < b1; ++b) {
+                const int ent = bcn_ent[b];
+                if (ent & 1) break;
+                const double *t = bcf_tmp + (size_t)(ent >> 1) * 3;
+                f[0] -= t[0]; f[1] -= t[1]; f[2] -= t[2];
+            }
+            if (p->has_elastic_foundation && (flag & (1u << 4)))
+                f[2] -= p->elastic_foundation_constant * (x4.z - coord0[(size_t)2*nn + n]);
+            for (; b < b1; ++b) {
+                const double *t = bcf_tmp + (size_t)(bcn_ent[b] >> 1) * 3;
+                f[0] += t[0]; f[1] += t[1]; f[2] += t[2];
+            }
+        }
+        d4 m4 = vm[n];
+        double v[3] = {m4.x, m4.y, m4.z};
+        const double small_vel = 1e-13;
+        const double dfac = p->damping_factor;
+        switch (p->damping_option) {
+        case 1:
+            for (int j = 0; j < 3; j++)
+                if (fabs(v[j]) > small_vel) f[j] -= dfac * copysign(f[j], v[j]);
+            break;
+        case 2:
+            for (int j = 0; j < 3; j++) f[j] -= dfac * f[j];
+            break;
+        case 3:
+            for (int j = 0; j < 3; j++) {
+                if ((f[j] < 0) == (v[j] < 0)) f[j] -= dfac * f[j];
+                else                          f[j] += (1 - dfac) * f[j];
+            }
+            break;
+        case 4: {
+            double critical_coeff = 2.0 * sqrt(m4.w * ymass[n]);
+            for (int j = 0; j < 3; j++)
+                if (fabs(v[j]) > small_vel) {
+                    double f_C = dfac * copysign(f[j], v[j]);
+                    double f_V = critical_coeff * v[j];
+                    double f_damping = (fabs(f_C) < fabs(f_V)) ? f_V : f_C;
+                    f[j] -= f_damping;
+                }
+            break;
+        }
+        default: break;
+        }
+        for (int j = 0; j < 3; j++) {
+            force[(size_t)j*nn + n] = f[j];
+            fres[(size_t)j*nn + n] = fr[j];
+            v[j] += dt * f[j] / m4.w;
+        }
+        const double num = (double)nn * 3;
+        l2 = fr[0]*fr[0] / num;
+        l2 += fr[1]*fr[1] / num;
+        l2 += fr[2]*fr[2] / num;
+        if (flag & 0x3ffu)
+            apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
+        m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
+        vm[n] = m4;
+        if (p->has_moving_mesh) {
+            x4.x += v[0] * dt; x4.y += v[1] * dt; x4.z += v[2] * dt;
+            xt[n] = x4;
+        }
+    }
+    // per-block partial of the residual; the partials are added in block order afterwards
+    __shared__ double red[DES_BLOCK / 64];
+    l2 = desk::wave_sum(l2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+        for (int i = 1; i < DES_BLOCK / 64; ++i) t += red[i];
+        if (lb < nblocks) res_part[lb] = t;
+    }
+}
+
+__global__ void k_res_finalize(DevClock *clk, const double *res_part, int nblocks)
+{
+    __shared__ double red[DES_BLOCK];
+    double t = 0;
+    for (int i = threadIdx.x; i < nblocks; i += DES_BLOCK) t += res_part[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = DES_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) clk->l2_residual = sqrt(red[0]);
+}
+
+// ---- surface processes -----------------------------------------------------------
+// simple_diffusion facet loop (bc.cxx:954-1039)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_s1(int etop, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const int *__restrict__ topf_elem, const int *__restrict__ topf_facet,
+     double *__restrict__ sarea, double *__restrict__ sslope)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= etop) return;
+    const int4 cn = conn[topf_elem[i]];
+    const int cna[4] = {cn.x, cn.y, cn.z, cn.w};
+    const int f = topf_facet[i];
+    d4 cf[3];
+    for (int j = 0; j < 3; ++j) cf[j] = xt[cna[NODE_OF_FACET_D[f][j]]];
+    double x01 = cf[1].x - cf[0].x, y01 = cf[1].y - cf[0].y;
+    double x02 = cf[2].x - cf[0].x, y02 = cf[2].y - cf[0].y;
+    double projected_area = 0.5 * (x01*y02 - y01*x02);
+    sarea[i] = projected_area;
+    double shp2dx[3], shp2dy[3];
+    double iv = 1 / (2 * projected_area);
+    shp2dx[0] = iv * (cf[1].y - cf[2].y);
+    shp2dx[1] = iv * (cf[2].y - cf[0].y);
+    shp2dx[2] = iv * (cf[0].y - cf[1].y);
+    shp2dy[0] = iv * (cf[2].x - cf[1].x);
+    shp2dy[1] = iv * (cf[0].x - cf[2].x);
+    shp2dy[2] = iv * (cf[1].x - cf[0].x);
+    const double zz[3] = {cf[0].z, cf[1].z, cf[2].z};
+    for (int j = 0; j < 3; j++) {
+        double slope = 0;
+        for (int k = 0; k < 3; k++)
+            slope += (shp2dx[j] * shp2dx[k] + shp2dy[j] * shp2dy[k]) * zz[k];
+        sslope[(size_t)i*3 + j] = slope * projected_area;
+    }
+}
+
+// simple_diffusion node loops (bc.cxx:1045-1107) + coordinate/dhacc update (bc.cxx:1770-1777)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_s2(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int ntop, int diffuse,
+     const int *__restrict__ top_nodes, const int *__restrict__ ssup_idx, const int *__restrict__ ssup_arr,
+     const int *__restrict__ conn_surf, int etop, const double *__restrict__ sarea,
+     const double *__restrict__ sslope, double *__restrict__ dh, double *__restrict__ dhacc, d4 *__restrict__ xt)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= ntop) return;
+    const int n = top_nodes[i];
+    double d = 0.;
+    if (diffuse) {
+        double total_dx = 0., total_slope = 0.;
+        for (int j = ssup_idx[i]; j < ssup_idx[i+1]; ++j) {
+            const int k = ssup_arr[j];
+            total_dx += sarea[k];
+            for (int m = 0; m < 3; ++m) {
+                if (conn_surf[(size_t)m*etop + k] == n) {
+                    total_slope += sslope[(size_t)k*3 + m];
+                    break;
+                }
+            }
+        }
+        double conv = p->surface_diffusivity * clk->dt * total_slope / total_dx;
+        d -= conv;
+    }
+    dh[i] = d;
+    d4 x4 = xt[n];
+    x4.z += d;
+    xt[n] = x4;
+    dhacc[n] += d;
+}
+
+// edvacc_surf update (bc.cxx:1784-1794)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_s3(int etop, const int *__restrict__ ean, const int *__restrict__ conn_surf, const d4 *__restrict__ xt,
+     const double *__restrict__ dh, double *__restrict__ edvacc)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= etop) return;
+    double dh_e = 0.;
+    for (int j = 0; j < 3; j++) dh_e += dh[ean[(size_t)j*etop + i]];
+    const d4 a = xt[conn_surf[i]], b = xt[conn_surf[(size_t)etop + i]], c = xt[conn_surf[(size_t)2*etop + i]];
+    double ab0 = b.x - a.x, ab1 = b.y - a.y, ac0 = c.x - a.x, ac1 = c.y - a.y;
+    double base = fabs(ab0*ac1 - ab1*ac0) / 2;           // triangle_area2d, geometry.cxx:59-73
+    edvacc[i] += dh_e * base / 3;
+}
+
+// max |dh| (bc.cxx:1811-1825); one block
+__global__ void k_s4(DevClock *clk, int ntop, const double *__restrict__ dh)
+{
+    __shared__ double red[DES_BLOCK / 64];
+    double m = 0.;
+    for (int i = threadIdx.x; i < ntop; i += DES_BLOCK) m = fmax(m, fabs(dh[i]));
+    m = desk::wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < DES_BLOCK / 64; ++i) m = fmax(m, red[i]);
+        clk->max_surf_vel = m / clk->dt;
+    }
+}
+
+// correct_surface_element (bc.cxx:1670-1687); the volume_n part (1693-1701) is dead:
+// compute_mass overwrites volume_n before anything reads it (dynearthsol.cxx:485)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_s5(int ntop_elems, int ne, const int *__restrict__ top_elems, const int4 *__restrict__ conn,
+     const d4 *__restrict__ xt, double *__restrict__ volume, double *__restrict__ stress,
+     double *__restrict__ strain, double *__restrict__ strain_rate, double *__restrict__ plstrain)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= ntop_elems) return;
+    const int e = top_elems[i];
+    const int4 cn = conn[e];
+    d4 c[4];
+    c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
+    double new_volumes = desk::tet_volume(c);
+    double rdv = new_volumes / volume[e];
+    volume[e] = new_volumes;
+    if (rdv < 1.0) return;
+    plstrain[e] /= rdv;
+    for (int j = 0; j < 6; j++) {
+        stress[(size_t)j*ne + e] /= rdv;
+        strain[(size_t)j*ne + e] /= rdv;
+        strain_rate[(size_t)j*ne + e] /= rdv;
+    }
+}
+
+__global__ void k_dhacc_reset(int ntop, const int *__restrict__ top_nodes, double *__restrict__ dhacc)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < ntop) dhacc[top_nodes[i]] = 0.;
+}
+
+// check_nan (utils.hpp:323-394)
+__global__ void k_count_nan(const double *a, long long n, unsigned long long *count)
+{
+    long long i = (long long)blockIdx.x * DES_BLOCK + threadIdx.x;
+    unsigned long long c = 0;
+    for (; i < n; i += (long long)gridDim.x * DES_BLOCK) c += isnan(a[i]) ? 1 : 0;
+    if (c) atomicAdd(count, c);
+}
+
+// =====================================================================================
+// host side of the engine
+// =====================================================================================
+template <typename T>
+int dev_alloc(T *&ptr, size_t count)
+{
+    ptr = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)&ptr, count * sizeof(T));
+    if (e != hipSuccess) { g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return DES_ERR_RESOURCE; }
+    return DES_OK;
+}
+
+template <typename T>
+int dev_upload(T *dst, const T *src, size_t count, hipStream_t s)
+{
+    if (count == 0) return DES_OK;
+    HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return DES_OK;
+}
+
+inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
+// grids are rounded up to a multiple of 8 so the XCD-aware block map covers every chunk
+inline int nblk8(long long n) { int b = nblk(n); return (b + 7) / 8 * 8; }
+
+struct Launch {
+    des_dev *h; int k; ProfRec rec; bool on;
+    Launch(des_dev *h_, int k_) : h(h_), k(k_), on(h_->prof) {
+        if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, h->stream); }
+    }
+    ~Launch() { if (on) { hipEventRecord(rec.b, h->stream); h->prof_recs.push_back(rec); } }
+};
+
+void refresh_props(des_dev *h)
+{
+    if (!h->markers_dirty) return;
+    if (h->props) {
+        Launch l(h, K_MISC);
+        hipLaunchKernelGGL(k_props, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->markers, h->props, h->ne);
+    }
+    h->markers_dirty = false;
+}
+
+template <int MODE>
+void launch_e1(des_dev *h)
+{
+    Launch l(h, K_E1);
+    const int nb = nblk(h->ne);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_e1<MODE>), dim3(nblk8(h->ne)), dim3(DES_BLOCK), 0, h->stream,
+                       h->d_p, h->d_clk, h->ne, nb, h->conn, h->xt, h->vm, h->markers, h->props, h->radiogenic,
+                       h->stress, h->strain, h->volume, h->volume_old, h->strain_rate, h->mrec, h->ttmp);
+}
+
+void launch_dt_finalize(des_dev *h)
+{
+    Launch l(h, K_DTFIN);
+    hipLaunchKernelGGL(k_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk);
+}
+
+// surface_processes (bc.cxx:1709-1872) as far as the device state is concerned
+void launch_surface(des_dev *h, long long step_no)
+{
+    const int diffuse = h->p.surface_process_option == 1;
+    if (h->ntop > 0) {
+        if (diffuse && h->etop > 0) {
+            Launch l(h, K_S1);
+            hipLaunchKernelGGL(k_s1, dim3(nblk(h->etop)), dim3(DES_BLOCK), 0, h->stream, h->etop, h->conn, h->xt,
+                               h->topf_elem, h->topf_facet, h->sarea, h->sslope);
+        }
+        {
+            Launch l(h, K_S2);
+            hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
+                               diffuse, h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf, h->etop, h->sarea,
+                               h->sslope, h->dh, h->dhacc, h->xt);
+        }
+        if (diffuse && h->etop > 0) {
+            Launch l(h, K_S3);
+            hipLaunchKernelGGL(k_s3, dim3(nblk(h->etop)), dim3(DES_BLOCK), 0, h->stream, h->etop, h->ean,
+                               h->conn_surf, h->xt, h->dh, h->edvacc);
+        }
+        if (diffuse) {
+            Launch l(h, K_S4);
+            hipLaunchKernelGGL(k_s4, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->ntop, h->dh);
+        }
+    }
+    if (h->ntop_elems > 0) {
+        Launch l(h, K_S5);
+        hipLaunchKernelGGL(k_s5, dim3(nblk(h->ntop_elems)), dim3(DES_BLOCK), 0, h->stream, h->ntop_elems, h->ne,
+                           h->top_elems, h->conn, h->xt, h->volume, h->stress, h->strain, h->strain_rate, h->plstrain);
+    }
+    if (h->ntop > 0 && step_no != 0 && step_no % h->p.quality_check_step_interval == 0)
+        hipLaunchKernelGGL(k_dhacc_reset, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->ntop,
+                           h->top_nodes, h->dhacc);
+}
+
+// the six passes between two E1 launches
+void launch_step_body(des_dev *h, long long step_no)
+{
+    const int nn = h->nn, ne = h->ne;
+    const int nbn = nblk(nn), nbe = nblk(ne);
+    {
+        Launch l(h, K_N1);
+        hipLaunchKernelGGL(k_n1, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, nn, nbn, 1,
+                           h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->xt, h->vm, h->volume_n,
+                           h->tmass, h->ntmp);
+    }
+    {
+        Launch l(h, K_E2);
+        hipLaunchKernelGGL(k_e2, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, ne, nbe,
+                           h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->volume_old, h->stress,
+                           h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
+                           h->etmp2);
+    }
+    if (h->p.is_using_mixed_stress) {
+        Launch l(h, K_N2);
+        hipLaunchKernelGGL(k_n2, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, nn, nbn, h->sup_idx, h->sup_pack,
+                           h->etmp2, h->volume_n, h->ntmp);
+    }
+    {
+        Launch l(h, K_E3);
+        hipLaunchKernelGGL(k_e3, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nbe, h->conn, h->xt,
+                           h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp);
+    }
+    if (h->nbcf > 0) {
+        Launch l(h, K_BCF);
+        hipLaunchKernelGGL(k_bc_facets, dim3(nblk(h->nbcf)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->nbcf, ne,
+                           h->conn, h->xt, h->markers, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
+    }
+    {
+        Launch l(h, K_N3);
+        hipLaunchKernelGGL(k_n3, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, nn, nbn,
+                           h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx, h->bcn_ent,
+                           h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
+                           h->force, h->fres, h->res_part);
+    }
+    {
+        Launch l(h, K_RES);
+        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->res_part, nbn);
+    }
+    if (h->p.has_moving_mesh)
+        launch_surface(h, step_no);
+}
+
+int sync_clock(des_dev *h)
+{
+    HIP_OK(hipMemcpyAsync(h->h_clk, h->d_clk, sizeof(DevClock), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+struct FieldInfo { int kind; long long count; };   // kind: 0 none, 1 elem plane array, 2 nodal plane array, ...
+
+} // namespace
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+extern "C" {
+
+const char *des_dev_last_error(void) { return g_last_error.c_str(); }
+
+int des_dev_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void des_dev_destroy(des_dev *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    void *ptrs[] = { h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
+        h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->stress, h->strain,
+        h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
+        h->radiogenic, h->markers, h->props, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
+        h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
+        h->conn_surf, h->ssup_idx, h->ssup_arr, h->top_elems, h->topf_elem, h->topf_facet, h->dh, h->edvacc,
+        h->sarea, h->sslope, h->bnormals, h->edge_vec, h->edge_slot };
+    for (void *q : ptrs) if (q) hipFree(q);
+    if (h->h_clk) hipHostFree(h->h_clk);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+des_dev *des_dev_create(int device, const des_params *params, const des_mesh *mesh, int *err)
+{
+    int dummy; if (!err) err = &dummy;
+    *err = DES_OK;
+    if (!params || !mesh) { *err = DES_ERR_INTERNAL; g_last_error = "null argument"; return nullptr; }
+    if (params->ndims != 3) { *err = DES_ERR_UNSUPPORTED_DIM; g_last_error = "only the 3D (THREED) path is offloaded"; return nullptr; }
+    if (params->nmat < 1 || params->nmat > DES_MAX_MAT) { *err = DES_ERR_CONFIG_VALUE; g_last_error = "bad nmat"; return nullptr; }
+    switch (params->rheol_type) {
+    case DES_RH_ELASTIC: case DES_RH_VISCOUS: case DES_RH_MAXWELL: case DES_RH_EP: case DES_RH_EVP: break;
+    default: *err = DES_ERR_UNSUPPORTED; g_last_error = "rheology not offloaded"; return nullptr;
+    }
+    if (des_dev_device_count() <= device) { *err = DES_ERR_UNSUPPORTED; g_last_error = "no such HIP device"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { *err = DES_ERR_UNSUPPORTED; g_last_error = "hipSetDevice failed"; return nullptr; }
+
+    des_dev *h = new des_dev();       // value-initialised: every pointer/scalar member starts at 0
+    h->device = device;
+    h->p = *params;
+    const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
+    h->markers_dirty = true;
+    h->pending_c = true;
+
+#define CK(x) do { int rc_ = (x); if (rc_ != DES_OK) { *err = rc_; des_dev_destroy(h); return nullptr; } } while (0)
+#define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_last_error = std::string(#x) + ": " + hipGetErrorString(e_); \
+                   *err = DES_ERR_RESOURCE; des_dev_destroy(h); return nullptr; } } while (0)
+    HK(hipStreamCreate(&h->stream));
+    HK(hipEventCreate(&h->ev0)); HK(hipEventCreate(&h->ev1));
+    HK(hipHostMalloc((void **)&h->h_clk, sizeof(DevClock)));
+
+    CK(dev_alloc(h->d_p, 1)); CK(dev_alloc(h->d_vt, 1)); CK(dev_alloc(h->d_clk, 1));
+    CK(dev_upload(h->d_p, params, 1, h->stream));
+    {
+        desk::ViscTerms vt;
+        std::memset(&vt, 0, sizeof(vt));
+        const double gas_constant = 8.3144;                       // matprops.cxx:237-250
+        for (int m = 0; m < nmat; ++m) {
+            vt.pow_edot[m] = 1 / params->visc_exponent[m] - 1;
+            const double pow1 = -1 / params->visc_exponent[m];
+            vt.coef_term[m] = std::pow(0.75 * params->visc_coefficient[m], pow1);
+            vt.nR[m] = params->visc_exponent[m] * gas_constant;
+        }
+        CK(dev_upload(h->d_vt, &vt, 1, h->stream));
+    }
+    {
+        DevClock c;
+        std::memset(&c, 0, sizeof(c));
+        c.r_minl = c.r_dt_maxwell = c.r_dt_diffusion = c.r_global_dt_min = DBL_MAX;
+        *h->h_clk = c;
+        CK(dev_upload(h->d_clk, &c, 1, h->stream));
+    }
+
+    // topology
+    {
+        std::vector<int4> c4((size_t)ne);
+        for (int e = 0; e < ne; ++e)
+            c4[e] = make_int4(mesh->connectivity[e], mesh->connectivity[(size_t)ne + e],
+                              mesh->connectivity[(size_t)2*ne + e], mesh->connectivity[(size_t)3*ne + e]);
+        CK(dev_alloc(h->conn, (size_t)ne)); CK(dev_upload(h->conn, c4.data(), (size_t)ne, h->stream));
+        std::vector<int> pack((size_t)4*ne);
+        for (size_t k = 0; k < pack.size(); ++k) pack[k] = mesh->support_arr[k] * 4 + mesh->support_lidx[k];
+        CK(dev_alloc(h->sup_idx, (size_t)nn + 1)); CK(dev_upload(h->sup_idx, mesh->support_idx, (size_t)nn + 1, h->stream));
+        CK(dev_alloc(h->sup_pack, pack.size())); CK(dev_upload(h->sup_pack, pack.data(), pack.size(), h->stream));
+        CK(dev_alloc(h->bcflag, (size_t)nn)); CK(dev_upload(h->bcflag, mesh->bcflag, (size_t)nn, h->stream));
+    }
+    // fields
+    CK(dev_alloc(h->xt, (size_t)nn)); CK(dev_alloc(h->vm, (size_t)nn));
+    CK(dev_alloc(h->ntmp, (size_t)nn)); CK(dev_alloc(h->volume_n, (size_t)nn)); CK(dev_alloc(h->tmass, (size_t)nn));
+    CK(dev_alloc(h->ymass, (size_t)nn)); CK(dev_alloc(h->force, (size_t)3*nn)); CK(dev_alloc(h->fres, (size_t)3*nn));
+    CK(dev_alloc(h->coord0, (size_t)3*nn)); CK(dev_alloc(h->dhacc, (size_t)nn));
+    CK(dev_alloc(h->stress, (size_t)6*ne)); CK(dev_alloc(h->strain, (size_t)6*ne)); CK(dev_alloc(h->strain_rate, (size_t)6*ne));
+    CK(dev_alloc(h->plstrain, (size_t)ne)); CK(dev_alloc(h->delta_plstrain, (size_t)ne)); CK(dev_alloc(h->viscosity, (size_t)ne));
+    CK(dev_alloc(h->volume, (size_t)ne)); CK(dev_alloc(h->volume_old, (size_t)ne)); CK(dev_alloc(h->dpressure, (size_t)ne));
+    CK(dev_alloc(h->radiogenic, (size_t)ne)); CK(dev_alloc(h->markers, (size_t)ne * nmat));
+    if (nmat > 1) CK(dev_alloc(h->props, (size_t)5*ne));
+    CK(dev_alloc(h->mrec, (size_t)ne)); CK(dev_alloc(h->ttmp, (size_t)ne)); CK(dev_alloc(h->etmp2, (size_t)ne));
+    CK(dev_alloc(h->ftmp, (size_t)12*ne));
+    h->n3_blocks = nblk8(nn);
+    CK(dev_alloc(h->res_part, (size_t)h->n3_blocks));
+    {
+        struct { void *p; size_t bytes; } zero[] = {
+            {h->xt, sizeof(d4)*(size_t)nn}, {h->vm, sizeof(d4)*(size_t)nn}, {h->ntmp, 8*(size_t)nn},
+            {h->volume_n, 8*(size_t)nn}, {h->tmass, 8*(size_t)nn}, {h->ymass, 8*(size_t)nn},
+            {h->force, 24*(size_t)nn}, {h->fres, 24*(size_t)nn}, {h->coord0, 24*(size_t)nn}, {h->dhacc, 8*(size_t)nn},
+            {h->stress, 48*(size_t)ne}, {h->strain, 48*(size_t)ne}, {h->strain_rate, 48*(size_t)ne},
+            {h->plstrain, 8*(size_t)ne}, {h->delta_plstrain, 8*(size_t)ne}, {h->volume, 8*(size_t)ne},
+            {h->volume_old, 8*(size_t)ne}, {h->dpressure, 8*(size_t)ne}, {h->radiogenic, 8*(size_t)ne},
+            {h->markers, 4*(size_t)ne*nmat}, {h->mrec, 32*(size_t)ne}, {h->ttmp, 32*(size_t)ne},
+            {h->etmp2, 8*(size_t)ne}, {h->ftmp, 96*(size_t)ne}, {h->res_part, 8*(size_t)h->n3_blocks} };
+        for (auto &z : zero) HK(hipMemsetAsync(z.p, 0, z.bytes, h->stream));
+        std::vector<double> vmax((size_t)ne, params->visc_max);          // fields.cxx:110
+        CK(dev_upload(h->viscosity, vmax.data(), (size_t)ne, h->stream));
+    }
+
+    // stress-bc facets and per-node entry lists, in the order apply_stress_bcs (bc.cxx:681-813)
+    // and apply_stress_bcs_neumann (bc.cxx:838-907) visit them
+    {
+        std::vector<int> f_elem, f_facet, f_kind; std::vector<double> f_val;
+        std::vector<std::vector<int> > node_ent((size_t)nn);
+        unsigned mask = 0;
+        std::vector<int> etmp_int((size_t)ne, -1);
+        if (params->gravity != 0) {
+            for (int i = 0; i < DES_NBDRY; i++) {
+                const int t = params->vbc_types[i];
+                if (t != 0 && t != 2 && t != 4) continue;
+                if (i == 4 && !params->has_winkler_foundation) continue;
+                if (i == 5 && !params->has_water_loading) continue;
+                const int bound = mesh->nbfacets[i];
+                const int offset = (int)f_elem.size();
+                const int kind = (i == 4 && params->has_winkler_foundation) ? 0
+                               : (i == 5 && params->has_water_loading) ? 1 : 2;
+                for (int n = 0; n < bound; ++n) {
+                    f_elem.push_back(mesh->bfacet_elem[i][n]); f_facet.push_back(mesh->bfacet_facet[i][n]);
+                    f_kind.push_back(kind); f_val.push_back(0);
+                    etmp_int[mesh->bfacet_elem[i][n]] = n;
+                }
+                for (int j = 0; j < mesh->nbnodes[i]; ++j) {
+                    const int n = mesh->bnodes[i][j];
+                    for (int k = mesh->support_idx[n]; k < mesh->support_idx[n+1]; ++k) {
+                        const int e = mesh->support_arr[k];
+                        const int ibound = etmp_int[e];
+                        if (ibound < 0) continue;
+                        const int f = mesh->bfacet_facet[i][ibound];
+                        for (int l = 0; l < 3; ++l) {
+                            if (n == mesh->connectivity[(size_t)NODE_OF_FACET_H[f][l]*ne + e]) {
+                                node_ent[n].push_back((((offset + ibound) * 3 + l) << 1) | 0);
+                                mask |= (1u << i);
+                                break;
+                            }
+                        }
+                    }
+                }
+                for (int n = 0; n < bound; ++n) etmp_int[mesh->bfacet_elem[i][n]] = -1;
+            }
+            if (params->has_elastic_foundation) mask |= (1u << 4);
+        }
+        for (int i = 0; i < 6; ++i) {
+            const int t = params->stress_bc_types[i];
+            if (t == 0) continue;
+            if (t < 1 || t > 3) continue;
+            for (int n = 0; n < mesh->nbfacets[i]; ++n) {
+                const int e = mesh->bfacet_elem[i][n], f = mesh->bfacet_facet[i][n];
+                const int g = (int)f_elem.size();
+                f_elem.push_back(e); f_facet.push_back(f); f_kind.push_back(3 + (t - 1));
+                f_val.push_back(params->stress_bc_values[i]);
+                for (int j = 0; j < 3; ++j) {
+                    const int node = mesh->connectivity[(size_t)NODE_OF_FACET_H[f][j]*ne + e];
+                    node_ent[node].push_back(((g * 3 + j) << 1) | 1);
+                }
+                mask |= (1u << i);
+            }
+        }
+        // every flagged node must be able to index bcn_idx; interior nodes never read it
+        h->bc_mask = mask;
+        h->nbcf = (int)f_elem.size();
+        std::vector<int> idx((size_t)nn + 1, 0), ent;
+        for (int n = 0; n < nn; ++n) {
+            idx[n] = (int)ent.size();
+            ent.insert(ent.end(), node_ent[n].begin(), node_ent[n].end());
+        }
+        idx[nn] = (int)ent.size();
+        CK(dev_alloc(h->bcf_elem, f_elem.size())); CK(dev_upload(h->bcf_elem, f_elem.data(), f_elem.size(), h->stream));
+        CK(dev_alloc(h->bcf_facet, f_facet.size())); CK(dev_upload(h->bcf_facet, f_facet.data(), f_facet.size(), h->stream));
+        CK(dev_alloc(h->bcf_kind, f_kind.size())); CK(dev_upload(h->bcf_kind, f_kind.data(), f_kind.size(), h->stream));
+        CK(dev_alloc(h->bcf_val, f_val.size())); CK(dev_upload(h->bcf_val, f_val.data(), f_val.size(), h->stream));
+        CK(dev_alloc(h->bcf_tmp, f_elem.size() * 9));
+        CK(dev_alloc(h->bcn_idx, idx.size())); CK(dev_upload(h->bcn_idx, idx.data(), idx.size(), h->stream));
+        CK(dev_alloc(h->bcn_ent, ent.size())); CK(dev_upload(h->bcn_ent, ent.data(), ent.size(), h->stream));
+    }
+    // surface
+    {
+        h->ntop = mesh->ntop; h->etop = mesh->etop; h->ntop_elems = mesh->ntop_elems;
+        const size_t ntop = (size_t)h->ntop, etop = (size_t)h->etop;
+        CK(dev_alloc(h->top_nodes, ntop)); CK(dev_upload(h->top_nodes, mesh->top_nodes, ntop, h->stream));
+        CK(dev_alloc(h->ean, 3*etop)); CK(dev_upload(h->ean, mesh->elem_and_nodes, 3*etop, h->stream));
+        CK(dev_alloc(h->conn_surf, 4*etop)); CK(dev_upload(h->conn_surf, mesh->connectivity_surface, 4*etop, h->stream));
+        CK(dev_alloc(h->ssup_idx, ntop + 1));
+        if (ntop) CK(dev_upload(h->ssup_idx, mesh->support_surf_idx, ntop + 1, h->stream));
+        const size_t nss = ntop ? (size_t)mesh->support_surf_idx[ntop] : 0;
+        CK(dev_alloc(h->ssup_arr, nss)); CK(dev_upload(h->ssup_arr, mesh->support_surf_arr, nss, h->stream));
+        CK(dev_alloc(h->top_elems, (size_t)h->ntop_elems));
+        CK(dev_upload(h->top_elems, mesh->top_elems, (size_t)h->ntop_elems, h->stream));
+        CK(dev_alloc(h->topf_elem, etop)); CK(dev_upload(h->topf_elem, mesh->bfacet_elem[5], etop, h->stream));
+        CK(dev_alloc(h->topf_facet, etop)); CK(dev_upload(h->topf_facet, mesh->bfacet_facet[5], etop, h->stream));
+        CK(dev_alloc(h->dh, ntop)); CK(dev_alloc(h->edvacc, etop)); CK(dev_alloc(h->sarea, etop)); CK(dev_alloc(h->sslope, 3*etop));
+        HK(hipMemsetAsync(h->dh, 0, 8*std::max<size_t>(ntop, 1), h->stream));
+        HK(hipMemsetAsync(h->edvacc, 0, 8*std::max<size_t>(etop, 1), h->stream));
+    }
+    CK(dev_alloc(h->bnormals, (size_t)3*DES_NBDRY)); CK(dev_upload(h->bnormals, mesh->bnormals, (size_t)3*DES_NBDRY, h->stream));
+    CK(dev_alloc(h->edge_vec, (size_t)3*mesh->nedge)); CK(dev_upload(h->edge_vec, mesh->edge_vec, (size_t)3*mesh->nedge, h->stream));
+    CK(dev_alloc(h->edge_slot, (size_t)DES_NBDRY*DES_NBDRY));
+    CK(dev_upload(h->edge_slot, mesh->edge_slot, (size_t)DES_NBDRY*DES_NBDRY, h->stream));
+    HK(hipStreamSynchronize(h->stream));
+#undef CK
+#undef HK
+    return h;
+}
+
+long long des_dev_field_count(const des_dev *h, int field)
+{
+    const long long nn = h->nn, ne = h->ne;
+    switch (field) {
+    case DES_F_COORD: case DES_F_VEL: case DES_F_FORCE: case DES_F_FORCE_RESIDUAL: case DES_F_COORD0: return 3*nn;
+    case DES_F_TEMPERATURE: case DES_F_VOLUME_N: case DES_F_MASS: case DES_F_TMASS: case DES_F_DHACC: case DES_F_NTMP: return nn;
+    case DES_F_STRESS: case DES_F_STRAIN: case DES_F_STRAIN_RATE: return 6*ne;
+    case DES_F_PLSTRAIN: case DES_F_DELTA_PLSTRAIN: case DES_F_VISCOSITY: case DES_F_VOLUME: case DES_F_VOLUME_OLD:
+    case DES_F_DPRESSURE: case DES_F_RADIOGENIC: return ne;
+    case DES_F_ELEMMARKERS: return ne * h->nmat;
+    case DES_F_EDVACC_SURF: return h->etop;
+    case DES_F_DH: return h->ntop;
+    default: return -1;
+    }
+}
+
+static double *plain_field(des_dev *h, int field)
+{
+    switch (field) {
+    case DES_F_FORCE: return h->force;
+    case DES_F_FORCE_RESIDUAL: return h->fres;
+    case DES_F_COORD0: return h->coord0;
+    case DES_F_VOLUME_N: return h->volume_n;
+    case DES_F_TMASS: return h->tmass;
+    case DES_F_DHACC: return h->dhacc;
+    case DES_F_NTMP: return h->ntmp;
+    case DES_F_STRESS: return h->stress;
+    case DES_F_STRAIN: return h->strain;
+    case DES_F_STRAIN_RATE: return h->strain_rate;
+    case DES_F_PLSTRAIN: return h->plstrain;
+    case DES_F_DELTA_PLSTRAIN: return h->delta_plstrain;
+    case DES_F_VISCOSITY: return h->viscosity;
+    case DES_F_VOLUME: return h->volume;
+    case DES_F_VOLUME_OLD: return h->volume_old;
+    case DES_F_DPRESSURE: return h->dpressure;
+    case DES_F_RADIOGENIC: return h->radiogenic;
+    case DES_F_EDVACC_SURF: return h->edvacc;
+    case DES_F_DH: return h->dh;
+    default: return nullptr;
+    }
+}
+
+// packed nodal records <-> the reference's SoA arrays
+static int packed_io(des_dev *h, int field, void *host, bool upload)
+{
+    const size_t nn = (size_t)h->nn;
+    d4 *dev = (field == DES_F_COORD || field == DES_F_TEMPERATURE) ? h->xt : h->vm;
+    std::vector<d4> tmp(nn);
+    HIP_OK(hipMemcpyAsync(tmp.data(), dev, nn * sizeof(d4), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    double *a = (double *)host;
+    const bool vec = (field == DES_F_COORD || field == DES_F_VEL);
+    if (!upload) {
+        for (size_t n = 0; n < nn; ++n) {
+            if (vec) { a[n] = tmp[n].x; a[nn + n] = tmp[n].y; a[2*nn + n] = tmp[n].z; }
+            else a[n] = tmp[n].w;
+        }
+        return DES_OK;
+    }
+    for (size_t n = 0; n < nn; ++n) {
+        if (vec) { tmp[n].x = a[n]; tmp[n].y = a[nn + n]; tmp[n].z = a[2*nn + n]; }
+        else tmp[n].w = a[n];
+    }
+    HIP_OK(hipMemcpyAsync(dev, tmp.data(), nn * sizeof(d4), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int des_dev_upload(des_dev *h, int field, const void *host, long long count)
+{
+    if (!h || !host) return DES_ERR_INTERNAL;
+    if (count != des_dev_field_count(h, field)) { g_last_error = "field size mismatch"; return DES_ERR_INTERNAL; }
+    hipSetDevice(h->device);
+    if (field == DES_F_COORD || field == DES_F_VEL || field == DES_F_TEMPERATURE || field == DES_F_MASS)
+        return packed_io(h, field, const_cast<void *>(host), true);
+    if (field == DES_F_ELEMMARKERS) {
+        h->markers_dirty = true;
+        return dev_upload(h->markers, (const int *)host, (size_t)count, h->stream);
+    }
+    double *dst = plain_field(h, field);
+    if (!dst) return DES_ERR_INTERNAL;
+    return dev_upload(dst, (const double *)host, (size_t)count, h->stream);
+}
+
+int des_dev_download(des_dev *h, int field, void *host, long long count)
+{
+    if (!h || !host) return DES_ERR_INTERNAL;
+    if (count != des_dev_field_count(h, field)) { g_last_error = "field size mismatch"; return DES_ERR_INTERNAL; }
+    hipSetDevice(h->device);
+    if (field == DES_F_COORD || field == DES_F_VEL || field == DES_F_TEMPERATURE || field == DES_F_MASS)
+        return packed_io(h, field, host, false);
+    const void *src = (field == DES_F_ELEMMARKERS) ? (const void *)h->markers : (const void *)plain_field(h, field);
+    if (!src) return DES_ERR_INTERNAL;
+    if (count == 0) return DES_OK;
+    const size_t bytes = (size_t)count * (field == DES_F_ELEMMARKERS ? 4 : 8);
+    HIP_OK(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int des_dev_set_clock(des_dev *h, double dt, double time, long long steps)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    h->h_clk->dt = dt; h->h_clk->time = time; h->h_clk->steps = steps;
+    h->steps_host = steps;
+    HIP_OK(hipMemcpyAsync(h->d_clk, h->h_clk, sizeof(DevClock), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int des_dev_sync(des_dev *h)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int des_dev_init_geometry(des_dev *h)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    refresh_props(h);
+    // compute_volume; volume_old = volume (dynearthsol.cxx:184-188): run the C part twice so
+    // both arrays hold the new volume (the first run also copies the stale volume into
+    // volume_old, the second overwrites it)
+    launch_e1<MODE_C | MODE_INIT>(h);
+    launch_e1<MODE_C | MODE_INIT>(h);
+    // apply_vbcs (dynearthsol.cxx:192)
+    hipLaunchKernelGGL(k_apply_vbcs, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->nn,
+                       h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm);
+    // compute_mass (dynearthsol.cxx:194)
+    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->nn, h->sup_idx,
+                       h->sup_pack, h->mrec, h->vm, h->volume_n, h->tmass, h->p.has_thermal_diffusion);
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipGetLastError());
+    return DES_OK;
+}
+
+int des_dev_compute_dt(des_dev *h, double *dt)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    refresh_props(h);
+    // reduction only: run the geometry part on a scratch copy?  The C part rewrites
+    // volume/volume_old and rotates stress, so use the dedicated reduction mode instead.
+    launch_e1<MODE_DT>(h);
+    launch_dt_finalize(h);
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    if (dt) *dt = h->h_clk->dt;
+    return h->h_clk->status;
+}
+
+int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    refresh_props(h);
+    for (int i = 0; i < nsteps; ++i) {
+        const long long step_no = ++h->steps_host;
+        if (i == 0) launch_e1<MODE_A>(h);
+        launch_step_body(h, step_no);
+        const bool last = (i == nsteps - 1);
+        const bool do_dt = (step_no % 10 == 0);
+        if (h->p.has_moving_mesh) {
+            if (last) { if (do_dt) launch_e1<MODE_C | MODE_DT>(h); else launch_e1<MODE_C>(h); }
+            else      { if (do_dt) launch_e1<MODE_C | MODE_A | MODE_DT>(h); else launch_e1<MODE_C | MODE_A>(h); }
+        } else {
+            // no update_mesh: only rotate_stress (+dt); volumes and masses stay as they are
+            g_last_error = "control.has_moving_mesh = no is not offloaded";
+            return DES_ERR_UNSUPPORTED;
+        }
+        if (do_dt) launch_dt_finalize(h);
+    }
+    // compute_mass gather of the last update_mesh, so that volume_n / mass / tmass hold the
+    // reference's end-of-step values (inside a multi-step call it is fused into the next N1)
+    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->nn, h->sup_idx,
+                       h->sup_pack, h->mrec, h->vm, h->volume_n, h->tmass, h->p.has_thermal_diffusion);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
+    if (out) {
+        int rc = sync_clock(h);
+        if (rc) return rc;
+        const DevClock &c = *h->h_clk;
+        out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
+        out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min;
+        out->steps = c.steps; out->status = c.status; out->pad_ = 0;
+        return c.status;
+    }
+    return DES_OK;
+}
+
+int des_dev_check_nan(des_dev *h, long long *n_nan)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    unsigned long long *d_count = nullptr;
+    HIP_OK(hipMalloc((void **)&d_count, 8));
+    HIP_OK(hipMemsetAsync(d_count, 0, 8, h->stream));
+    const long long nn = h->nn, ne = h->ne;
+    struct { const double *p; long long n; } arrs[] = {
+        {h->volume, ne}, {h->dpressure, ne}, {h->viscosity, ne}, {h->stress, 6*ne}, {h->tmass, nn},
+        {h->force, 3*nn}, {(const double *)h->xt, 4*nn}, {(const double *)h->vm, 4*nn} };
+    for (auto &a : arrs)
+        hipLaunchKernelGGL(k_count_nan, dim3(std::min(nblk(a.n), 2048)), dim3(DES_BLOCK), 0, h->stream, a.p, a.n, d_count);
+    unsigned long long c = 0;
+    HIP_OK(hipMemcpyAsync(&c, d_count, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    hipFree(d_count);
+    if (n_nan) *n_nan = (long long)c;
+    return c ? DES_ERR_RUNTIME_NAN : DES_OK;
+}
+
+int des_dev_timer_start(des_dev *h)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    HIP_OK(hipEventRecord(h->ev0, h->stream));
+    return DES_OK;
+}
+
+int des_dev_timer_stop(des_dev *h, float *ms)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    HIP_OK(hipEventSynchronize(h->ev1));
+    float t = 0;
+    HIP_OK(hipEventElapsedTime(&t, h->ev0, h->ev1));
+    if (ms) *ms = t;
+    return DES_OK;
+}
+
+int des_dev_profile_enable(des_dev *h, int on)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipStreamSynchronize(h->stream);
+    for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    h->prof_recs.clear();
+    for (int k = 0; k < K_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_calls[k] = 0; }
+    h->prof = on != 0;
+    return DES_OK;
+}
+
+int des_dev_profile_read(des_dev *h, int cap, char (*names)[64], double *ms, long long *calls)
+{
+    if (!h) return 0;
+    hipStreamSynchronize(h->stream);
+    for (ProfRec &r : h->prof_recs) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { h->prof_ms[r.k] += t; h->prof_calls[r.k] += 1; }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    h->prof_recs.clear();
+    int n = 0;
+    for (int k = 0; k < K_COUNT && n < cap; ++k) {
+        if (h->prof_calls[k] == 0) continue;
+        std::strncpy(names[n], kKernelNames[k], 63); names[n][63] = 0;
+        ms[n] = h->prof_ms[k]; calls[n] = h->prof_calls[k];
+        ++n;
+    }
+    return n;
+}
+
+// B_alg = 1420*ne + 348*nn; evp +24*ne +8*nn; thermal off -88*ne -24*nn;
+// NMD off -96*ne -28*nn
+double des_dev_algorithmic_bytes_per_step(const des_dev *h)
+{
+    double be = 1420, bn = 348;
+    if (h->p.rheol_type == DES_RH_EVP) { be += 24; bn += 8; }
+    if (!h->p.has_thermal_diffusion) { be -= 88; bn -= 24; }
+    if (!h->p.is_using_mixed_stress) { be -= 96; bn -= 28; }
+    return be * h->ne + bn * h->nn;
+}
+
+} // extern "C"

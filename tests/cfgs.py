@@ -1,0 +1,99 @@
+"""Small .cfg texts used by the tests (regular meshes: built by the host library itself,
+no TetGen needed)."""
+
+BASE = """
+[sim]
+modelname = t
+max_steps = 100
+output_step_interval = 100
+is_outputting_averaged_fields = no
+[mesh]
+meshing_option = 1
+meshing_elem_shape = 1
+xlength = {lx}
+ylength = {ly}
+zlength = {lz}
+resolution = {res}
+quality_check_step_interval = {qcsi}
+[control]
+surface_process_option = {spo}
+surface_diffusivity = 1e-6
+inertial_scaling = 1e4
+{control}
+[bc]
+vbc_x0 = 1
+vbc_x1 = 1
+vbc_val_x0 = {vx0}
+vbc_val_x1 = {vx1}
+vbc_y0 = 1
+vbc_y1 = 1
+has_water_loading = {water}
+surface_temperature = 273
+mantle_temperature = {tmantle}
+{bc}
+[ic]
+weakzone_option = 1
+weakzone_azimuth = 15
+weakzone_inclination = -60
+weakzone_halfwidth = 1.2
+weakzone_depth_min = 0.5
+weakzone_depth_max = 1.0
+weakzone_xcenter = 0.5
+weakzone_ycenter = 0.5
+weakzone_zcenter = 0
+weakzone_plstrain = 0.5
+{ic}
+[mat]
+rheology_type = {rheol}
+{mat}
+"""
+
+MAT_1 = """
+rho0 = [2700]
+alpha = [{alpha}]
+bulk_modulus = [50e9]
+shear_modulus = [30e9]
+pls0 = [0]
+pls1 = [0.5]
+cohesion0 = [4.4e7]
+cohesion1 = [4e6]
+friction_angle0 = [30]
+friction_angle1 = [30]
+min_viscosity = {vmin}
+"""
+
+MAT_2 = """
+num_materials = 2
+rho0 = [2700, 3300]
+alpha = [3e-5]
+bulk_modulus = [50e9, 120e9]
+shear_modulus = [30e9, 70e9]
+visc_exponent = [3.05, 3.5]
+visc_coefficient = [1.25e-1, 1.1e5]
+visc_activation_energy = [2.76e5, 5.3e5]
+pls0 = [0]
+pls1 = [0.5, 0.1]
+cohesion0 = [4.4e7]
+cohesion1 = [4e6]
+friction_angle0 = [30]
+friction_angle1 = [30, 15]
+min_viscosity = {vmin}
+"""
+
+
+def make(rheol="elasto-plastic", lx=40e3, ly=8e3, lz=8e3, res=2e3, spo=1, qcsi=100, vx=1e-9,
+         tmantle=273, alpha=0, vmin="1e24", nmat=1, control="", bc="", ic="", water="no", mat_extra=""):
+    mat = (MAT_1 if nmat == 1 else MAT_2).format(alpha=alpha, vmin=vmin) + mat_extra
+    if nmat == 2:
+        ic += "\nmattype_option = 1\nnum_mattype_layers = 2\nlayer_mattypes = [0,1]\nmattype_layer_depths = [0.5]\n"
+    return BASE.format(rheol=rheol, lx=lx, ly=ly, lz=lz, res=res, spo=spo, qcsi=qcsi, vx0=-vx, vx1=vx,
+                       tmantle=tmantle, control=control, bc=bc, ic=ic, mat=mat, water=water)
+
+
+# the reference's benchmarks-cores/test-3d.cfg physics on a regular mesh
+EP = dict(rheol="elasto-plastic")
+# visco-elasto-plastic with a real geotherm (thermal expansion on, creep active)
+EVP = dict(rheol="elasto-visco-plastic", tmantle=1573, alpha=3e-5, vmin="1e19",
+           ic="oceanic_plate_age_in_yr = 2e5\n")
+# fast loading so that elements yield (shear and tensile return mapping) within ~100 steps
+YIELD = dict(rheol="elasto-plastic", vx=1e-6, control="characteristic_speed = 1e-9\n")
