@@ -148,6 +148,14 @@ __device__ __forceinline__ ElemProps load_props(const des_params *p, const doubl
     return r;
 }
 
+// Young's-modulus "mass" of an element, only read by damping option 4 (geometry.cxx:1832)
+__device__ __forceinline__ double elem_ym(const des_params *p, const double *props, int ne, int e)
+{
+    const double bulkm = props ? props[e] : p->bulk_modulus[0];
+    const double shearm = props ? props[(size_t)ne + e] : p->shear_modulus[0];
+    return 9 * bulkm * shearm / (3 * bulkm + shearm) / 4;
+}
+
 // refresh_elem_cache (matprops.cxx:259-303) for nmat > 1
 __global__ void __launch_bounds__(DES_BLOCK)
 k_props(const des_params *p, const int *markers, double *props, int ne)
@@ -339,9 +347,9 @@ __global__ void k_dt_finalize(const des_params *p, DevClock *clk)
 __global__ void __launch_bounds__(DES_BLOCK)
 k_n1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int nblocks, int advance_clock,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
-     const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp,
+     const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp, const double *__restrict__ props, int ne,
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
-     double *__restrict__ ntmp)
+     double *__restrict__ ymass, double *__restrict__ ntmp)
 {
     const int n = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     const double dt = clk->dt;
@@ -352,7 +360,8 @@ k_n1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int n
     if (n >= nn) return;
     const int k0 = sup_idx[n], k1 = sup_idx[n+1];
     const bool thermal = p->has_thermal_diffusion;
-    double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0;
+    const bool need_ym = p->damping_option == 4;
+    double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0, yms = 0;
     for (int k = k0; k < k1; ++k) {
         const int pk = sup_pack[k];
         const int e = pk >> 2, li = pk & 3;
@@ -363,10 +372,12 @@ k_n1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int n
             tms += r.z;
             tdot += (&ttmp[e].x)[li];
         }
+        if (need_ym) yms += elem_ym(p, props, ne, e);
         acc += r.w;
     }
     volume_n[n] = vn;
     tmass[n] = tms;
+    if (need_ym) ymass[n] = yms;
     d4 m4 = vm[n];
     m4.w = ms;
     vm[n] = m4;
@@ -383,19 +394,24 @@ k_n1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int n
 
 // mass-only variant used by init_geometry (compute_mass without the temperature update)
 __global__ void __launch_bounds__(DES_BLOCK)
-k_mass_gather(int nn, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
-              const d4 *__restrict__ mrec, d4 *__restrict__ vm, double *__restrict__ volume_n,
-              double *__restrict__ tmass, int thermal)
+k_mass_gather(const des_params *__restrict__ p, int nn, int ne, const int *__restrict__ sup_idx,
+              const int *__restrict__ sup_pack, const d4 *__restrict__ mrec, const double *__restrict__ props,
+              d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
+              double *__restrict__ ymass)
 {
     const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (n >= nn) return;
-    double vn = 0, ms = 0, tms = 0;
+    const bool thermal = p->has_thermal_diffusion, need_ym = p->damping_option == 4;
+    double vn = 0, ms = 0, tms = 0, yms = 0;
     for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) {
-        const d4 r = mrec[sup_pack[k] >> 2];
+        const int e = sup_pack[k] >> 2;
+        const d4 r = mrec[e];
         vn += r.x; ms += r.y;
         if (thermal) tms += r.z;
+        if (need_ym) yms += elem_ym(p, props, ne, e);
     }
     volume_n[n] = vn; tmass[n] = tms;
+    if (need_ym) ymass[n] = yms;
     d4 m4 = vm[n]; m4.w = ms; vm[n] = m4;
 }
 
@@ -1079,8 +1095,8 @@ void launch_step_body(des_dev *h, long long step_no)
     {
         Launch l(h, K_N1);
         hipLaunchKernelGGL(k_n1, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, nn, nbn, 1,
-                           h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->xt, h->vm, h->volume_n,
-                           h->tmass, h->ntmp);
+                           h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne, h->xt, h->vm,
+                           h->volume_n, h->tmass, h->ymass, h->ntmp);
     }
     {
         Launch l(h, K_E2);
@@ -1495,8 +1511,8 @@ int des_dev_init_geometry(des_dev *h)
     hipLaunchKernelGGL(k_apply_vbcs, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->nn,
                        h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm);
     // compute_mass (dynearthsol.cxx:194)
-    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->nn, h->sup_idx,
-                       h->sup_pack, h->mrec, h->vm, h->volume_n, h->tmass, h->p.has_thermal_diffusion);
+    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->nn, h->ne,
+                       h->sup_idx, h->sup_pack, h->mrec, h->props, h->vm, h->volume_n, h->tmass, h->ymass);
     HIP_OK(hipStreamSynchronize(h->stream));
     HIP_OK(hipGetLastError());
     return DES_OK;
@@ -1540,8 +1556,8 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     }
     // compute_mass gather of the last update_mesh, so that volume_n / mass / tmass hold the
     // reference's end-of-step values (inside a multi-step call it is fused into the next N1)
-    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->nn, h->sup_idx,
-                       h->sup_pack, h->mrec, h->vm, h->volume_n, h->tmass, h->p.has_thermal_diffusion);
+    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->nn, h->ne,
+                       h->sup_idx, h->sup_pack, h->mrec, h->props, h->vm, h->volume_n, h->tmass, h->ymass);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
     if (out) {
