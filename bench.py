@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--resolution", type=float, default=400e3 / 560)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--rheology", default="elasto-visco-plastic",
+                    help="diagnostic only: the headline workload is elasto-visco-plastic")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +128,8 @@ def main():
 
     import dynearthsol_amd as des
 
-    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution)))
+    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution)),
+                    overrides=None if args.rheology == "elasto-visco-plastic" else "mat.rheology_type = %s\n" % args.rheology)
     dev = des.DeviceEngine(host, device=local_rank)
     dev.init_from_host(host)
     ne, nn = host.nelem, host.nnode
@@ -169,7 +172,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "test-3d-big.cfg box 400x20x10 km, elasto-visco-plastic, thermal+NMD+surface diffusion on, "
+            "workload": "test-3d-big.cfg box 400x20x10 km, " + args.rheology + ", thermal+NMD+surface diffusion on, "
                         "regular 5-tet mesh %d tets / %d nodes per GPU" % (ne, nn),
             "nelem": ne, "nnode": nn,
             "parallelism": "single GPU" if world == 1 else "%d independent replicas (domain decomposition pending)" % world,
@@ -197,7 +200,7 @@ def main():
                 _, dom = max(cands)
                 ms, calls = kern[dom]
                 be, bn = KERNEL_BYTES[dom]
-                if dom == "E2_update_stress" and "visco" in BENCH_CFG:
+                if dom == "E2_update_stress" and args.rheology == "elasto-visco-plastic":
                     be, bn = be + 24, bn + 8
                 kbytes = be * ne + bn * nn
                 achieved = kbytes / (ms / calls * 1e-3) / 1e9

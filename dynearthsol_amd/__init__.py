@@ -20,7 +20,7 @@ from ._structs import DesMesh, DesParams, DesScalars, F, FIELDS, INT_FIELDS
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 HOST_LIB_PATH = os.path.join(_HERE, "libdes_host.so")
-HIP_LIB_PATH = os.path.join(_HERE, "libdes_hip.so")
+HIP_LIB_PATH = os.environ.get("DES_HIP_LIB", os.path.join(_HERE, "libdes_hip.so"))   # override: A/B of kernel builds
 
 _host_lib = None
 _hip_lib = None

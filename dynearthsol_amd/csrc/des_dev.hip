@@ -41,6 +41,18 @@
 
 using desk::d4;
 
+// minimum waves per SIMD the register allocator must leave room for (occupancy knobs,
+// chosen by measurement: profiles/README.md)
+#ifndef DES_E1_WAVES
+#define DES_E1_WAVES 2
+#endif
+#ifndef DES_E2_WAVES
+#define DES_E2_WAVES 2
+#endif
+#ifndef DES_E3_WAVES
+#define DES_E3_WAVES 2
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -64,13 +76,12 @@ struct DevClock {
 
 enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };   // INIT: C part without rotate_stress
 
-enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_BCF, K_N3, K_RES, K_S1, K_S2, K_S3, K_S4, K_S5,
+enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_BCF, K_N3, K_S1, K_S2, K_S3, K_FIN,
                 K_DTFIN, K_MISC, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "N2_nmd_gather",
-    "E3_nmd_force", "BC_facets", "N3_force_velocity_coord", "residual_finalize", "S1_surf_facets",
-    "S2_surf_nodes", "S3_surf_edvacc", "S4_surf_maxdh", "S5_correct_surface_element",
-    "dt_finalize", "misc" };
+    "E3_nmd_force", "BC_facets", "N3_force_velocity_coord", "S1_surf_facets", "S2_surf_nodes",
+    "S3_surf_edvacc", "step_finalize", "dt_finalize", "misc" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
 
@@ -99,6 +110,7 @@ struct des_dev {
     double *stress, *strain, *strain_rate, *plstrain, *delta_plstrain, *viscosity, *volume,
            *volume_old, *dpressure, *radiogenic;
     int *markers;
+    unsigned char *topflag;               // element touches the top surface (Variables::top_elems)
     double *props;                        // [5][ne] bulkm, shearm, phi, cp, k  (nmat > 1 only)
     // temporaries
     d4 *mrec, *ttmp;                      // {vol, m, tm, dvol}, thermal tr[4]
@@ -114,7 +126,7 @@ struct des_dev {
     unsigned bc_mask;                     // bcflag bits that have any entry
     // surface
     int ntop, etop, ntop_elems;
-    int *top_nodes, *ean, *conn_surf, *ssup_idx, *ssup_arr, *top_elems, *topf_elem, *topf_facet;
+    int *top_nodes, *ean, *conn_surf, *ssup_idx, *ssup_arr, *topf_elem, *topf_facet;
     double *dh, *edvacc, *sarea, *sslope; // sslope [etop][3]
     // bnormals / edges for slanted boundaries
     double *bnormals, *edge_vec; int *edge_slot;
@@ -128,7 +140,7 @@ struct des_dev {
     double prof_ms[K_COUNT]; long long prof_calls[K_COUNT];
 };
 
-namespace {
+namespace des_hip {
 
 // =====================================================================================
 // kernels
@@ -178,12 +190,12 @@ k_props(const des_params *p, const int *markers, double *props, int ne)
 // MODE_A: update_temperature element part (fields.cxx:211-239), update_strain_rate
 //         (fields.cxx:415-476), compute_dvoldt element part (geometry.cxx:218-224).
 template <int MODE>
-__global__ void __launch_bounds__(DES_BLOCK)
-k_e1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int nblocks,
+__global__ void __launch_bounds__(DES_BLOCK, DES_E1_WAVES)
+E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int nblocks,
      const int4 *__restrict__ conn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
      const int *__restrict__ markers, const double *__restrict__ props,
-     const double *__restrict__ radiogenic,
-     double *__restrict__ stress, double *__restrict__ strain,
+     const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp)
 {
@@ -209,9 +221,18 @@ k_e1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int n
 
         double vol;
         d4 rec;
+        double rdv = 0.0;                        // >= 1: correct_surface_element rescales this element
         if (MODE & MODE_C) {
-            volume_old[e] = volume[e];           // pointer swap of dynearthsol.cxx:466-470
+            const double vol_prev = volume[e];
             vol = desk::tet_volume(c);
+            if (!(MODE & MODE_INIT) && topflag[e]) {
+                // correct_surface_element (bc.cxx:1670-1687) runs before the swap: it already
+                // stored the new volume, so the swap moves the NEW volume into volume_old
+                rdv = vol / vol_prev;
+                volume_old[e] = vol;
+            } else {
+                volume_old[e] = vol_prev;        // pointer swap of dynearthsol.cxx:466-470
+            }
             volume[e] = vol;
             // compute_mass, element part
             const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
@@ -231,16 +252,26 @@ k_e1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int n
         desk::shape_fn(c, vol, sx, sy, sz);
 
         if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
-            if (p->rheol_type & DES_RH_ELASTIC) {
-                const double dt = clk->dt;
-                double w3 = 0, w4 = 0, w5 = 0;
-                for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
-                for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
-                for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
+            const bool rescale = rdv >= 1.0;                         // bc.cxx:1677
+            const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0;
+            if (rescale || rotate) {
                 double s[6], es[6];
                 for (int i = 0; i < 6; ++i) { s[i] = stress[(size_t)i*ne + e]; es[i] = strain[(size_t)i*ne + e]; }
-                desk::jaumann_rate_3d(s, dt, w3, w4, w5);
-                desk::jaumann_rate_3d(es, dt, w3, w4, w5);
+                if (rescale) {
+                    plstrain[e] /= rdv;
+                    for (int i = 0; i < 6; ++i) { s[i] /= rdv; es[i] /= rdv; }
+                    if (!(MODE & MODE_A))            // otherwise update_strain_rate overwrites it below
+                        for (int i = 0; i < 6; ++i) strain_rate[(size_t)i*ne + e] /= rdv;
+                }
+                if (rotate) {
+                    const double dt = clk->dt;
+                    double w3 = 0, w4 = 0, w5 = 0;
+                    for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
+                    for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
+                    for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
+                    desk::jaumann_rate_3d(s, dt, w3, w4, w5);
+                    desk::jaumann_rate_3d(es, dt, w3, w4, w5);
+                }
                 for (int i = 0; i < 6; ++i) { stress[(size_t)i*ne + e] = s[i]; strain[(size_t)i*ne + e] = es[i]; }
             }
         }
@@ -340,40 +371,82 @@ __global__ void k_dt_finalize(const des_params *p, DevClock *clk)
     clk->r_global_dt_min = DBL_MAX; clk->r_max_vem = 0.0;
 }
 
+// ---- node gathers: LDS-staged segmented reduction ---------------------------------
+// A workgroup owns DES_BLOCK consecutive nodes, i.e. one contiguous range [kb, ke) of the
+// CSR incidence list.  Phase 1: all lanes walk that range with stride DES_BLOCK -- the index
+// loads are fully coalesced and every lane has the same number of independent record
+// gathers in flight, whatever the valence of "its" node (8 or 32 on the regular mesh, 8-50
+// on TetGen meshes) -- and park the gathered values in LDS.  Phase 2: each lane sums the
+// slice of LDS that belongs to its node, sequentially and in ascending element order, which
+// is the reference's summation order (fields.cxx:667-675) -> bit-identical sums.
+// LDS slot of incidence j is skewed by j/8 so that row starts that are multiples of 8
+// doubles apart (regular mesh) do not land on the same banks.
+#define DES_TILE 1024
+__device__ __forceinline__ int lds_slot(int j) { return j + (j >> 3); }
+#define DES_TILE_LDS (DES_TILE + DES_TILE / 8 + 1)
+
 // ---- N1 --------------------------------------------------------------------------
 // compute_mass gather (geometry.cxx:1846-1864), update_temperature node loop
 // (fields.cxx:245-262), compute_dvoldt gather (geometry.cxx:231-238).
 // Also advances the clock: steps++, time += dt (dynearthsol.cxx:773-774).
+// FULL = 0: compute_mass only (init_geometry and the end of a des_dev_step call).
+template <int FULL>
 __global__ void __launch_bounds__(DES_BLOCK)
-k_n1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int nblocks, int advance_clock,
+N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int nblocks,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
      const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp, const double *__restrict__ props, int ne,
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
      double *__restrict__ ymass, double *__restrict__ ntmp)
 {
-    const int n = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    __shared__ double lds[5][DES_TILE_LDS];
+    const int lb = desk::logical_block(nblocks);
+    const int n0 = lb * DES_BLOCK;
+    const int n = n0 + threadIdx.x;
     const double dt = clk->dt;
-    if (advance_clock && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (FULL && blockIdx.x == 0 && threadIdx.x == 0) {
         clk->steps += 1;
         clk->time += dt;
+        clk->maxdh = 0.0;
     }
-    if (n >= nn) return;
-    const int k0 = sup_idx[n], k1 = sup_idx[n+1];
+    if (n0 >= nn) return;                                   // whole block idle (grid padding)
     const bool thermal = p->has_thermal_diffusion;
     const bool need_ym = p->damping_option == 4;
+    const int nlast = min(n0 + DES_BLOCK, nn);
+    const int kb = sup_idx[n0], ke = sup_idx[nlast];
+    int r0 = ke, r1 = ke;
+    if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0, yms = 0;
-    for (int k = k0; k < k1; ++k) {
-        const int pk = sup_pack[k];
-        const int e = pk >> 2, li = pk & 3;
-        const d4 r = mrec[e];
-        vn += r.x;
-        ms += r.y;
-        if (thermal) {
-            tms += r.z;
-            tdot += (&ttmp[e].x)[li];
+    for (int t0 = kb; t0 < ke; t0 += DES_TILE) {
+        const int tn = min(DES_TILE, ke - t0);
+        for (int j = threadIdx.x; j < tn; j += DES_BLOCK) {
+            const int pk = sup_pack[t0 + j];
+            const int e = pk >> 2;
+            const d4 r = mrec[e];
+            const int sl = lds_slot(j);
+            lds[0][sl] = r.x; lds[1][sl] = r.y; lds[2][sl] = r.z; lds[3][sl] = r.w;
+            if (FULL && thermal) lds[4][sl] = (&ttmp[e].x)[pk & 3];
+            else if (need_ym)    lds[4][sl] = elem_ym(p, props, ne, e);
         }
-        if (need_ym) yms += elem_ym(p, props, ne, e);
-        acc += r.w;
+        __syncthreads();
+        const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
+        for (int j = a; j < b; ++j) {
+            const int sl = lds_slot(j);
+            vn += lds[0][sl];
+            ms += lds[1][sl];
+            if (thermal) tms += lds[2][sl];
+            if (FULL) {
+                if (thermal) tdot += lds[4][sl];
+                acc += lds[3][sl];
+            }
+            if (need_ym && !(FULL && thermal)) yms += lds[4][sl];
+        }
+        __syncthreads();
+    }
+    if (n >= nn) return;
+    if (need_ym && FULL && thermal) {
+        // damping option 4 together with thermal diffusion: the fifth LDS plane is taken by
+        // the conduction term, so the Young's-modulus mass is summed straight from memory
+        for (int k = r0; k < r1; ++k) yms += elem_ym(p, props, ne, sup_pack[k] >> 2);
     }
     volume_n[n] = vn;
     tmass[n] = tms;
@@ -381,45 +454,24 @@ k_n1(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int n
     d4 m4 = vm[n];
     m4.w = ms;
     vm[n] = m4;
-    if (thermal) {
-        d4 x4 = xt[n];
-        if (bcflag[n] & (1u << 5))
-            x4.w = p->surface_temperature;
-        else
-            x4.w -= dt * tdot / tms;
-        xt[n] = x4;
+    if (FULL) {
+        if (thermal) {
+            d4 x4 = xt[n];
+            if (bcflag[n] & (1u << 5))
+                x4.w = p->surface_temperature;
+            else
+                x4.w -= dt * tdot / tms;
+            xt[n] = x4;
+        }
+        ntmp[n] = acc / vn;
     }
-    ntmp[n] = acc / vn;
-}
-
-// mass-only variant used by init_geometry (compute_mass without the temperature update)
-__global__ void __launch_bounds__(DES_BLOCK)
-k_mass_gather(const des_params *__restrict__ p, int nn, int ne, const int *__restrict__ sup_idx,
-              const int *__restrict__ sup_pack, const d4 *__restrict__ mrec, const double *__restrict__ props,
-              d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
-              double *__restrict__ ymass)
-{
-    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (n >= nn) return;
-    const bool thermal = p->has_thermal_diffusion, need_ym = p->damping_option == 4;
-    double vn = 0, ms = 0, tms = 0, yms = 0;
-    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) {
-        const int e = sup_pack[k] >> 2;
-        const d4 r = mrec[e];
-        vn += r.x; ms += r.y;
-        if (thermal) tms += r.z;
-        if (need_ym) yms += elem_ym(p, props, ne, e);
-    }
-    volume_n[n] = vn; tmass[n] = tms;
-    if (need_ym) ymass[n] = yms;
-    d4 m4 = vm[n]; m4.w = ms; vm[n] = m4;
 }
 
 // ---- E2 --------------------------------------------------------------------------
 // compute_edvoldt (geometry.cxx:264-272), update_stress (rheology.cxx:728-1026),
 // NMD_stress element part (geometry.cxx:294-296)
-__global__ void __launch_bounds__(DES_BLOCK)
-k_e2(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
+__global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
+E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const int *__restrict__ markers, const double *__restrict__ props,
      const double *__restrict__ volume, const double *__restrict__ volume_old,
@@ -526,21 +578,35 @@ k_e2(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, c
 // ---- N2 --------------------------------------------------------------------------
 // NMD_stress gather (geometry.cxx:302-309)
 __global__ void __launch_bounds__(DES_BLOCK)
-k_n2(int nn, int nblocks, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
+N2_nmd_gather(int nn, int nblocks, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
      const double *__restrict__ etmp2, const double *__restrict__ volume_n, double *__restrict__ ntmp)
 {
-    const int n = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
-    if (n >= nn) return;
+    __shared__ double lds[4 * DES_TILE_LDS];
+    const int TILE = 4 * DES_TILE;
+    const int n0 = desk::logical_block(nblocks) * DES_BLOCK;
+    const int n = n0 + threadIdx.x;
+    if (n0 >= nn) return;
+    const int nlast = min(n0 + DES_BLOCK, nn);
+    const int kb = sup_idx[n0], ke = sup_idx[nlast];
+    int r0 = ke, r1 = ke;
+    if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double acc = 0;
-    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k)
-        acc += etmp2[sup_pack[k] >> 2];
-    ntmp[n] = acc / volume_n[n];
+    for (int t0 = kb; t0 < ke; t0 += TILE) {
+        const int tn = min(TILE, ke - t0);
+        for (int j = threadIdx.x; j < tn; j += DES_BLOCK)
+            lds[lds_slot(j)] = etmp2[sup_pack[t0 + j] >> 2];
+        __syncthreads();
+        const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
+        for (int j = a; j < b; ++j) acc += lds[lds_slot(j)];
+        __syncthreads();
+    }
+    if (n < nn) ntmp[n] = acc / volume_n[n];
 }
 
 // ---- E3 --------------------------------------------------------------------------
 // NMD_stress apply (geometry.cxx:316-331), update_force element part (fields.cxx:623-653)
-__global__ void __launch_bounds__(DES_BLOCK)
-k_e3(const des_params *__restrict__ p, int ne, int nblocks, const int4 *__restrict__ conn,
+__global__ void __launch_bounds__(DES_BLOCK, DES_E3_WAVES)
+E3_nmd_force(const des_params *__restrict__ p, int ne, int nblocks, const int4 *__restrict__ conn,
      const d4 *__restrict__ xt, const double *__restrict__ ntmp, const int *__restrict__ markers,
      const double *__restrict__ props, const double *__restrict__ volume,
      const double *__restrict__ dpressure, double *__restrict__ stress, double *__restrict__ ftmp)
@@ -737,7 +803,7 @@ k_apply_vbcs(const des_params *__restrict__ p, const DevClock *__restrict__ clk,
 // (fields.cxx:725-742), residual partial sums (fields.cxx:700-722), apply_vbcs,
 // update_coordinate (fields.cxx:761-784)
 __global__ void __launch_bounds__(DES_BLOCK)
-k_n3(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn, int nblocks,
+N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn, int nblocks,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
      const double *__restrict__ ftmp, unsigned bc_mask, const int *__restrict__ bcn_idx,
      const int *__restrict__ bcn_ent, const double *__restrict__ bcf_tmp,
@@ -746,20 +812,38 @@ k_n3(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn,
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ force, double *__restrict__ fres,
      double *__restrict__ res_part)
 {
+    __shared__ double lds[3][DES_TILE_LDS];
+    __shared__ double red[DES_BLOCK / 64];
     const int lb = desk::logical_block(nblocks);
-    const int n = lb * DES_BLOCK + threadIdx.x;
+    const int n0 = lb * DES_BLOCK;
+    const int n = n0 + threadIdx.x;
+    if (n0 >= nn) return;
+    const int nlast = min(n0 + DES_BLOCK, nn);
+    const int kb = sup_idx[n0], ke = sup_idx[nlast];
+    int r0 = ke, r1 = ke;
+    if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
+    double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
+    for (int t0 = kb; t0 < ke; t0 += DES_TILE) {
+        const int tn = min(DES_TILE, ke - t0);
+        for (int j = threadIdx.x; j < tn; j += DES_BLOCK) {
+            const int pk = sup_pack[t0 + j];
+            const double *tr = ftmp + (size_t)(pk >> 2) * 12 + (pk & 3) * 3;
+            const int sl = lds_slot(j);
+            lds[0][sl] = tr[0]; lds[1][sl] = tr[1]; lds[2][sl] = tr[2];
+        }
+        __syncthreads();
+        const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
+        for (int j = a; j < b; ++j) {
+            const int sl = lds_slot(j);
+            const double t0v = lds[0][sl], t1v = lds[1][sl], t2v = lds[2][sl];
+            f[0] -= t0v; f[1] -= t1v; f[2] -= t2v;
+            fr[0] = t0v; fr[1] = t1v; fr[2] = t2v;          // assignment: fields.cxx:673
+        }
+        __syncthreads();
+    }
     double l2 = 0.0;
     if (n < nn) {
         const double dt = clk->dt;
-        double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
-        const int k0 = sup_idx[n], k1 = sup_idx[n+1];
-        for (int k = k0; k < k1; ++k) {
-            const int pk = sup_pack[k];
-            const double *tr = ftmp + (size_t)(pk >> 2) * 12 + (pk & 3) * 3;
-            const double t0 = tr[0], t1 = tr[1], t2 = tr[2];
-            f[0] -= t0; f[1] -= t1; f[2] -= t2;
-            fr[0] = t0; fr[1] = t1; fr[2] = t2;          // assignment: fields.cxx:673
-        }
         const unsigned flag = bcflag[n];
         d4 x4 = xt[n];
         if (flag & bc_mask) {
@@ -792,7 +876,7 @@ k_n3(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn,
             break;
         case 3:
             for (int j = 0; j < 3; j++) {
-                if ((f[j] < 0) == (v[j] < 0)) f[j] -= dfac * f[j];
+                if ((f[j] < 0) == (v[j] < 0)) f[j] -= dfac * f[j];   // fields.cxx:538 (comma operator)
                 else                          f[j] += (1 - dfac) * f[j];
             }
             break;
@@ -828,18 +912,18 @@ k_n3(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn,
         }
     }
     // per-block partial of the residual; the partials are added in block order afterwards
-    __shared__ double red[DES_BLOCK / 64];
     l2 = desk::wave_sum(l2);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = red[0];
         for (int i = 1; i < DES_BLOCK / 64; ++i) t += red[i];
-        if (lb < nblocks) res_part[lb] = t;
+        res_part[lb] = t;
     }
 }
 
-__global__ void k_res_finalize(DevClock *clk, const double *res_part, int nblocks)
+// end-of-step scalars: l2_residual (fields.cxx:721) and max_surf_vel (bc.cxx:1825); one block
+__global__ void k_step_finalize(DevClock *clk, const double *res_part, int nblocks)
 {
     __shared__ double red[DES_BLOCK];
     double t = 0;
@@ -850,7 +934,10 @@ __global__ void k_res_finalize(DevClock *clk, const double *res_part, int nblock
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) clk->l2_residual = sqrt(red[0]);
+    if (threadIdx.x == 0) {
+        clk->l2_residual = sqrt(red[0]);
+        clk->max_surf_vel = clk->maxdh / clk->dt;
+    }
 }
 
 // ---- surface processes -----------------------------------------------------------
@@ -890,15 +977,15 @@ k_s1(int etop, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
 
 // simple_diffusion node loops (bc.cxx:1045-1107) + coordinate/dhacc update (bc.cxx:1770-1777)
 __global__ void __launch_bounds__(DES_BLOCK)
-k_s2(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int ntop, int diffuse,
+k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int diffuse,
      const int *__restrict__ top_nodes, const int *__restrict__ ssup_idx, const int *__restrict__ ssup_arr,
      const int *__restrict__ conn_surf, int etop, const double *__restrict__ sarea,
      const double *__restrict__ sslope, double *__restrict__ dh, double *__restrict__ dhacc, d4 *__restrict__ xt)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= ntop) return;
-    const int n = top_nodes[i];
     double d = 0.;
+    if (i < ntop) {
+    const int n = top_nodes[i];
     if (diffuse) {
         double total_dx = 0., total_slope = 0.;
         for (int j = ssup_idx[i]; j < ssup_idx[i+1]; ++j) {
@@ -919,6 +1006,16 @@ k_s2(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nto
     x4.z += d;
     xt[n] = x4;
     dhacc[n] += d;
+    }
+    // max |dh| (bc.cxx:1811-1821); max is order-independent
+    __shared__ double red[DES_BLOCK / 64];
+    double m = desk::wave_max(fabs(d));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < DES_BLOCK / 64; ++k) m = fmax(m, red[k]);
+        if (m > 0) desk::atomic_max_double(&clk->maxdh, m);
+    }
 }
 
 // edvacc_surf update (bc.cxx:1784-1794)
@@ -934,46 +1031,6 @@ k_s3(int etop, const int *__restrict__ ean, const int *__restrict__ conn_surf, c
     double ab0 = b.x - a.x, ab1 = b.y - a.y, ac0 = c.x - a.x, ac1 = c.y - a.y;
     double base = fabs(ab0*ac1 - ab1*ac0) / 2;           // triangle_area2d, geometry.cxx:59-73
     edvacc[i] += dh_e * base / 3;
-}
-
-// max |dh| (bc.cxx:1811-1825); one block
-__global__ void k_s4(DevClock *clk, int ntop, const double *__restrict__ dh)
-{
-    __shared__ double red[DES_BLOCK / 64];
-    double m = 0.;
-    for (int i = threadIdx.x; i < ntop; i += DES_BLOCK) m = fmax(m, fabs(dh[i]));
-    m = desk::wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < DES_BLOCK / 64; ++i) m = fmax(m, red[i]);
-        clk->max_surf_vel = m / clk->dt;
-    }
-}
-
-// correct_surface_element (bc.cxx:1670-1687); the volume_n part (1693-1701) is dead:
-// compute_mass overwrites volume_n before anything reads it (dynearthsol.cxx:485)
-__global__ void __launch_bounds__(DES_BLOCK)
-k_s5(int ntop_elems, int ne, const int *__restrict__ top_elems, const int4 *__restrict__ conn,
-     const d4 *__restrict__ xt, double *__restrict__ volume, double *__restrict__ stress,
-     double *__restrict__ strain, double *__restrict__ strain_rate, double *__restrict__ plstrain)
-{
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= ntop_elems) return;
-    const int e = top_elems[i];
-    const int4 cn = conn[e];
-    d4 c[4];
-    c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
-    double new_volumes = desk::tet_volume(c);
-    double rdv = new_volumes / volume[e];
-    volume[e] = new_volumes;
-    if (rdv < 1.0) return;
-    plstrain[e] /= rdv;
-    for (int j = 0; j < 6; j++) {
-        stress[(size_t)j*ne + e] /= rdv;
-        strain[(size_t)j*ne + e] /= rdv;
-        strain_rate[(size_t)j*ne + e] /= rdv;
-    }
 }
 
 __global__ void k_dhacc_reset(int ntop, const int *__restrict__ top_nodes, double *__restrict__ dhacc)
@@ -1040,9 +1097,18 @@ void launch_e1(des_dev *h)
 {
     Launch l(h, K_E1);
     const int nb = nblk(h->ne);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_e1<MODE>), dim3(nblk8(h->ne)), dim3(DES_BLOCK), 0, h->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(h->ne)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, h->ne, nb, h->conn, h->xt, h->vm, h->markers, h->props, h->radiogenic,
-                       h->stress, h->strain, h->volume, h->volume_old, h->strain_rate, h->mrec, h->ttmp);
+                       h->topflag, h->stress, h->strain, h->plstrain, h->volume, h->volume_old, h->strain_rate,
+                       h->mrec, h->ttmp);
+}
+
+// compute_mass gather alone (N1 without the temperature / dvoldt parts)
+void launch_mass_gather(des_dev *h)
+{
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0>), dim3(nblk8(h->nn)), dim3(DES_BLOCK), 0, h->stream,
+                       h->d_p, h->d_clk, h->nn, nblk(h->nn), h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
+                       h->props, h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
 void launch_dt_finalize(des_dev *h)
@@ -1072,15 +1138,6 @@ void launch_surface(des_dev *h, long long step_no)
             hipLaunchKernelGGL(k_s3, dim3(nblk(h->etop)), dim3(DES_BLOCK), 0, h->stream, h->etop, h->ean,
                                h->conn_surf, h->xt, h->dh, h->edvacc);
         }
-        if (diffuse) {
-            Launch l(h, K_S4);
-            hipLaunchKernelGGL(k_s4, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->ntop, h->dh);
-        }
-    }
-    if (h->ntop_elems > 0) {
-        Launch l(h, K_S5);
-        hipLaunchKernelGGL(k_s5, dim3(nblk(h->ntop_elems)), dim3(DES_BLOCK), 0, h->stream, h->ntop_elems, h->ne,
-                           h->top_elems, h->conn, h->xt, h->volume, h->stress, h->strain, h->strain_rate, h->plstrain);
     }
     if (h->ntop > 0 && step_no != 0 && step_no % h->p.quality_check_step_interval == 0)
         hipLaunchKernelGGL(k_dhacc_reset, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->ntop,
@@ -1094,25 +1151,25 @@ void launch_step_body(des_dev *h, long long step_no)
     const int nbn = nblk(nn), nbe = nblk(ne);
     {
         Launch l(h, K_N1);
-        hipLaunchKernelGGL(k_n1, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, nn, nbn, 1,
-                           h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne, h->xt, h->vm,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1>), dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream,
+                           h->d_p, h->d_clk, nn, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne, h->xt, h->vm,
                            h->volume_n, h->tmass, h->ymass, h->ntmp);
     }
     {
         Launch l(h, K_E2);
-        hipLaunchKernelGGL(k_e2, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, ne, nbe,
+        hipLaunchKernelGGL(E2_update_stress, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, ne, nbe,
                            h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->volume_old, h->stress,
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                            h->etmp2);
     }
     if (h->p.is_using_mixed_stress) {
         Launch l(h, K_N2);
-        hipLaunchKernelGGL(k_n2, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, nn, nbn, h->sup_idx, h->sup_pack,
+        hipLaunchKernelGGL(N2_nmd_gather, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, nn, nbn, h->sup_idx, h->sup_pack,
                            h->etmp2, h->volume_n, h->ntmp);
     }
     {
         Launch l(h, K_E3);
-        hipLaunchKernelGGL(k_e3, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nbe, h->conn, h->xt,
+        hipLaunchKernelGGL(E3_nmd_force, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nbe, h->conn, h->xt,
                            h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp);
     }
     if (h->nbcf > 0) {
@@ -1122,17 +1179,17 @@ void launch_step_body(des_dev *h, long long step_no)
     }
     {
         Launch l(h, K_N3);
-        hipLaunchKernelGGL(k_n3, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, nn, nbn,
+        hipLaunchKernelGGL(N3_force_velocity_coord, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, nn, nbn,
                            h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx, h->bcn_ent,
                            h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
                            h->force, h->fres, h->res_part);
     }
-    {
-        Launch l(h, K_RES);
-        hipLaunchKernelGGL(k_res_finalize, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->res_part, nbn);
-    }
     if (h->p.has_moving_mesh)
         launch_surface(h, step_no);
+    {
+        Launch l(h, K_FIN);
+        hipLaunchKernelGGL(k_step_finalize, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->res_part, nbn);
+    }
 }
 
 int sync_clock(des_dev *h)
@@ -1144,7 +1201,9 @@ int sync_clock(des_dev *h)
 
 struct FieldInfo { int kind; long long count; };   // kind: 0 none, 1 elem plane array, 2 nodal plane array, ...
 
-} // namespace
+} // namespace des_hip
+
+using namespace des_hip;
 
 // =====================================================================================
 // C-ABI
@@ -1171,7 +1230,7 @@ void des_dev_destroy(des_dev *h)
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->radiogenic, h->markers, h->props, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
-        h->conn_surf, h->ssup_idx, h->ssup_arr, h->top_elems, h->topf_elem, h->topf_facet, h->dh, h->edvacc,
+        h->conn_surf, h->ssup_idx, h->ssup_arr, h->topflag, h->topf_elem, h->topf_facet, h->dh, h->edvacc,
         h->sarea, h->sslope, h->bnormals, h->edge_vec, h->edge_slot };
     for (void *q : ptrs) if (q) hipFree(q);
     if (h->h_clk) hipHostFree(h->h_clk);
@@ -1359,8 +1418,11 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         if (ntop) CK(dev_upload(h->ssup_idx, mesh->support_surf_idx, ntop + 1, h->stream));
         const size_t nss = ntop ? (size_t)mesh->support_surf_idx[ntop] : 0;
         CK(dev_alloc(h->ssup_arr, nss)); CK(dev_upload(h->ssup_arr, mesh->support_surf_arr, nss, h->stream));
-        CK(dev_alloc(h->top_elems, (size_t)h->ntop_elems));
-        CK(dev_upload(h->top_elems, mesh->top_elems, (size_t)h->ntop_elems, h->stream));
+        {
+            std::vector<unsigned char> flag((size_t)ne, 0);
+            for (int i = 0; i < h->ntop_elems; ++i) flag[mesh->top_elems[i]] = 1;
+            CK(dev_alloc(h->topflag, (size_t)ne)); CK(dev_upload(h->topflag, flag.data(), (size_t)ne, h->stream));
+        }
         CK(dev_alloc(h->topf_elem, etop)); CK(dev_upload(h->topf_elem, mesh->bfacet_elem[5], etop, h->stream));
         CK(dev_alloc(h->topf_facet, etop)); CK(dev_upload(h->topf_facet, mesh->bfacet_facet[5], etop, h->stream));
         CK(dev_alloc(h->dh, ntop)); CK(dev_alloc(h->edvacc, etop)); CK(dev_alloc(h->sarea, etop)); CK(dev_alloc(h->sslope, 3*etop));
@@ -1511,8 +1573,7 @@ int des_dev_init_geometry(des_dev *h)
     hipLaunchKernelGGL(k_apply_vbcs, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->nn,
                        h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm);
     // compute_mass (dynearthsol.cxx:194)
-    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->nn, h->ne,
-                       h->sup_idx, h->sup_pack, h->mrec, h->props, h->vm, h->volume_n, h->tmass, h->ymass);
+    launch_mass_gather(h);
     HIP_OK(hipStreamSynchronize(h->stream));
     HIP_OK(hipGetLastError());
     return DES_OK;
@@ -1556,8 +1617,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     }
     // compute_mass gather of the last update_mesh, so that volume_n / mass / tmass hold the
     // reference's end-of-step values (inside a multi-step call it is fused into the next N1)
-    hipLaunchKernelGGL(k_mass_gather, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->nn, h->ne,
-                       h->sup_idx, h->sup_pack, h->mrec, h->props, h->vm, h->volume_n, h->tmass, h->ymass);
+    launch_mass_gather(h);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
     if (out) {

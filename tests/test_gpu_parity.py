@@ -173,17 +173,26 @@ def test_mohr_coulomb_return_single_step_from_identical_state():
 
 
 def test_yield_heavy_run_stays_statistically_identical():
-    """100 steps with half of the mesh yielding every step is a chaotic map: a 1-ulp change
-    anywhere grows by ~1.2x per step (the same happens between two CPU builds of the
-    reference -- rheology.cxx:727 notes CPU and OpenACC results differ for this reason).
-    Bar: compare.py's 'something wrong' threshold does not apply; we require the same set of
-    yielding elements to within 1 % and fields within 1e-3."""
+    """Half of the mesh yielding every step is a chaotic map: the CPU oracle itself turns a
+    1-ulp change of ONE stress component into 2e-8 after 20 steps and 2e-5 after 100 (yield
+    decisions and the dsyevh3 -> dsyevq3 fallback are discontinuities; see the next test, and
+    rheology.cxx:727 for the reference's own CPU-vs-OpenACC remark).  The device differs from
+    glibc by <= 2 ulp in EVERY element, so the bar is: after 30 steps fields within 1e-4 and the
+    same set of yielding elements to 1 %; after 100 steps the same statistics (number of
+    yielding elements, mean plastic strain) to 1 %."""
     host, dev, ora = pair(cfgs.YIELD)
-    dev.step(100); ora.step(100)
+    dev.step(30); ora.step(30)
     yd, yo = dev.download("DELTA_PLSTRAIN") > 0, ora.download("DELTA_PLSTRAIN") > 0
+    assert yo.sum() > host.nelem // 4
     assert (yd != yo).sum() <= 0.01 * host.nelem
     for f in ("COORD", "STRESS", "STRAIN", "PLSTRAIN", "VEL"):
-        assert reldiff(ora.download(f), dev.download(f)) <= 1e-3, f
+        assert reldiff(ora.download(f), dev.download(f)) <= 1e-4, f
+    dev.step(70); ora.step(70)
+    yd, yo = dev.download("DELTA_PLSTRAIN") > 0, ora.download("DELTA_PLSTRAIN") > 0
+    assert abs(int(yd.sum()) - int(yo.sum())) <= 0.01 * host.nelem
+    assert dev.download("PLSTRAIN").mean() == pytest.approx(ora.download("PLSTRAIN").mean(), rel=1e-2)
+    assert reldiff(ora.download("COORD"), dev.download("COORD")) <= 1e-4
+    assert dev.check_nan() == 0
 
 
 def test_oracle_is_equally_sensitive_to_one_ulp():
