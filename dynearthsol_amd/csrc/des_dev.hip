@@ -76,12 +76,12 @@ struct DevClock {
 
 enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };   // INIT: C part without rotate_stress
 
-enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_BCF, K_N3, K_S1, K_S2, K_S3, K_FIN,
+enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_N3, K_S1, K_S2, K_S3,
                 K_DTFIN, K_MISC, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "N2_nmd_gather",
-    "E3_nmd_force", "BC_facets", "N3_force_velocity_coord", "S1_surf_facets", "S2_surf_nodes",
-    "S3_surf_edvacc", "step_finalize", "dt_finalize", "misc" };
+    "E3_nmd_force", "N3_force_velocity_coord", "S1_surf_facets", "S2_surf_nodes",
+    "S3_edvacc_step_finalize", "dt_finalize", "misc" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
 
@@ -132,6 +132,7 @@ struct des_dev {
     double *bnormals, *edge_vec; int *edge_slot;
 
     bool markers_dirty;
+    bool const_mass;                      // quasi-static, one material: nodal mass from volumes alone
     bool pending_c;                       // C part of the last step has been run (always true outside step())
     long long steps_host;
     // profiling
@@ -381,16 +382,30 @@ __global__ void k_dt_finalize(const des_params *p, DevClock *clk)
 // is the reference's summation order (fields.cxx:667-675) -> bit-identical sums.
 // LDS slot of incidence j is skewed by j/8 so that row starts that are multiples of 8
 // doubles apart (regular mesh) do not land on the same banks.
-#define DES_TILE 1024
+#ifndef DES_TILE_N1
+#define DES_TILE_N1 768
+#endif
+#ifndef DES_TILE_N1C
+#define DES_TILE_N1C 1024
+#endif
+#ifndef DES_TILE_N3
+#define DES_TILE_N3 1024
+#endif
+#ifndef DES_TILE_N2
+#define DES_TILE_N2 2048
+#endif
 __device__ __forceinline__ int lds_slot(int j) { return j + (j >> 3); }
-#define DES_TILE_LDS (DES_TILE + DES_TILE / 8 + 1)
+#define DES_TILE_LDS(T) ((T) + (T) / 8 + 1)
 
 // ---- N1 --------------------------------------------------------------------------
 // compute_mass gather (geometry.cxx:1846-1864), update_temperature node loop
 // (fields.cxx:245-262), compute_dvoldt gather (geometry.cxx:231-238).
 // Also advances the clock: steps++, time += dt (dynearthsol.cxx:773-774).
 // FULL = 0: compute_mass only (init_geometry and the end of a des_dev_step call).
-template <int FULL>
+// CONSTM = 1: quasi-static run with one material -- the inertial mass of an element is
+// (K / pseudo_speed^2) * V / 4 with a run constant factor (geometry.cxx:1814-1816, 1829), so it
+// is formed from the gathered volume instead of being gathered itself (one LDS plane less).
+template <int FULL, int CONSTM>
 __global__ void __launch_bounds__(DES_BLOCK)
 N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int nblocks,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
@@ -398,7 +413,9 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
      double *__restrict__ ymass, double *__restrict__ ntmp)
 {
-    __shared__ double lds[5][DES_TILE_LDS];
+    constexpr int TILE = CONSTM ? DES_TILE_N1C : DES_TILE_N1;
+    constexpr int NPL = CONSTM ? 4 : 5;
+    __shared__ double lds[NPL][DES_TILE_LDS(TILE)];
     const int lb = desk::logical_block(nblocks);
     const int n0 = lb * DES_BLOCK;
     const int n = n0 + threadIdx.x;
@@ -411,40 +428,45 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     if (n0 >= nn) return;                                   // whole block idle (grid padding)
     const bool thermal = p->has_thermal_diffusion;
     const bool need_ym = p->damping_option == 4;
+    const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+    const double rho_m = p->bulk_modulus[0] / (pseudo_speed * pseudo_speed);
     const int nlast = min(n0 + DES_BLOCK, nn);
     const int kb = sup_idx[n0], ke = sup_idx[nlast];
     int r0 = ke, r1 = ke;
     if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0, yms = 0;
-    for (int t0 = kb; t0 < ke; t0 += DES_TILE) {
-        const int tn = min(DES_TILE, ke - t0);
+    for (int t0 = kb; t0 < ke; t0 += TILE) {
+        const int tn = min(TILE, ke - t0);
         for (int j = threadIdx.x; j < tn; j += DES_BLOCK) {
             const int pk = sup_pack[t0 + j];
             const int e = pk >> 2;
             const d4 r = mrec[e];
             const int sl = lds_slot(j);
-            lds[0][sl] = r.x; lds[1][sl] = r.y; lds[2][sl] = r.z; lds[3][sl] = r.w;
-            if (FULL && thermal) lds[4][sl] = (&ttmp[e].x)[pk & 3];
-            else if (need_ym)    lds[4][sl] = elem_ym(p, props, ne, e);
+            lds[0][sl] = r.x; lds[1][sl] = r.z; lds[2][sl] = r.w;
+            if (FULL && thermal) lds[3][sl] = (&ttmp[e].x)[pk & 3];
+            else if (need_ym)    lds[3][sl] = elem_ym(p, props, ne, e);
+            if (!CONSTM) lds[NPL - 1][sl] = r.y;
         }
         __syncthreads();
         const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
         for (int j = a; j < b; ++j) {
             const int sl = lds_slot(j);
-            vn += lds[0][sl];
-            ms += lds[1][sl];
-            if (thermal) tms += lds[2][sl];
+            const double vol = lds[0][sl];
+            vn += vol;
+            if (CONSTM) ms += rho_m * vol / 4;
+            else        ms += lds[NPL - 1][sl];
+            if (thermal) tms += lds[1][sl];
             if (FULL) {
-                if (thermal) tdot += lds[4][sl];
-                acc += lds[3][sl];
+                if (thermal) tdot += lds[3][sl];
+                acc += lds[2][sl];
             }
-            if (need_ym && !(FULL && thermal)) yms += lds[4][sl];
+            if (need_ym && !(FULL && thermal)) yms += lds[3][sl];
         }
         __syncthreads();
     }
     if (n >= nn) return;
     if (need_ym && FULL && thermal) {
-        // damping option 4 together with thermal diffusion: the fifth LDS plane is taken by
+        // damping option 4 together with thermal diffusion: the spare LDS plane is taken by
         // the conduction term, so the Young's-modulus mass is summed straight from memory
         for (int k = r0; k < r1; ++k) yms += elem_ym(p, props, ne, sup_pack[k] >> 2);
     }
@@ -581,8 +603,8 @@ __global__ void __launch_bounds__(DES_BLOCK)
 N2_nmd_gather(int nn, int nblocks, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
      const double *__restrict__ etmp2, const double *__restrict__ volume_n, double *__restrict__ ntmp)
 {
-    __shared__ double lds[4 * DES_TILE_LDS];
-    const int TILE = 4 * DES_TILE;
+    __shared__ double lds[DES_TILE_LDS(DES_TILE_N2)];
+    const int TILE = DES_TILE_N2;
     const int n0 = desk::logical_block(nblocks) * DES_BLOCK;
     const int n = n0 + threadIdx.x;
     if (n0 >= nn) return;
@@ -604,58 +626,84 @@ N2_nmd_gather(int nn, int nblocks, const int *__restrict__ sup_idx, const int *_
 }
 
 // ---- E3 --------------------------------------------------------------------------
-// NMD_stress apply (geometry.cxx:316-331), update_force element part (fields.cxx:623-653)
+// NMD_stress apply (geometry.cxx:316-331), update_force element part (fields.cxx:623-653).
+// The 12 force terms of an element are one 96-byte record; a wavefront's records are staged
+// in LDS and written back as contiguous 16-byte pieces instead of 64 strided 8-byte stores.
+// Workgroups past the element range compute the stress-bc facet terms (bc_facet_work):
+// both only read the nodal records, and N3 consumes both.
+__device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int4 *__restrict__ conn,
+                              const d4 *__restrict__ xt, const int *__restrict__ markers,
+                              const int *__restrict__ f_elem, const int *__restrict__ f_facet,
+                              const int *__restrict__ f_kind, const double *__restrict__ f_val,
+                              double *__restrict__ f_tmp);
+
 __global__ void __launch_bounds__(DES_BLOCK, DES_E3_WAVES)
-E3_nmd_force(const des_params *__restrict__ p, int ne, int nblocks, const int4 *__restrict__ conn,
+E3_nmd_force(const des_params *__restrict__ p, int ne, int nblocks, int nblocks8, const int4 *__restrict__ conn,
      const d4 *__restrict__ xt, const double *__restrict__ ntmp, const int *__restrict__ markers,
      const double *__restrict__ props, const double *__restrict__ volume,
-     const double *__restrict__ dpressure, double *__restrict__ stress, double *__restrict__ ftmp)
+     const double *__restrict__ dpressure, double *__restrict__ stress, double *__restrict__ ftmp,
+     int nbcf, const int *__restrict__ f_elem, const int *__restrict__ f_facet,
+     const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp)
 {
-    const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
-    if (e >= ne) return;
-    const int4 cn = conn[e];
-    d4 c[4];
-    c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
-    double s[6];
-    for (int i = 0; i < 6; ++i) s[i] = stress[(size_t)i*ne + e];
-    if (p->is_using_mixed_stress) {
-        double dp = 0;
-        dp += ntmp[cn.x]; dp += ntmp[cn.y]; dp += ntmp[cn.z]; dp += ntmp[cn.w];
-        double dp_el = dp / 4;
-        double dp_orig = dpressure[e];
-        double ddp = (-dp_orig + dp_el) / 3;
-        for (int i = 0; i < 3; ++i) { s[i] += ddp; stress[(size_t)i*ne + e] = s[i]; }
+    if ((int)blockIdx.x >= nblocks8) {                    // facet blocks (uniform per workgroup)
+        const int g = ((int)blockIdx.x - nblocks8) * DES_BLOCK + threadIdx.x;
+        if (g < nbcf) bc_facet_work(p, g, conn, xt, markers, f_elem, f_facet, f_kind, f_val, f_tmp);
+        return;
     }
-    const double vol = volume[e];
-    double sx[4], sy[4], sz[4];
-    desk::shape_fn(c, vol, sx, sy, sz);
-    double buoy = 0;
-    if (p->gravity != 0) {
-        double T = 0;
-        T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
-        T /= 4;
-        const double rho = desk::mat_rho(p, markers + (size_t)e * p->nmat, T);
-        const double phi = props ? props[(size_t)2*ne + e] : p->porosity[0];
-        buoy = (rho * (1 - phi) + 1000.0 * phi) * p->gravity / 4;
+    __shared__ double stage[DES_BLOCK * 13];              // 12 doubles per element, row stride 13
+    const int e0 = desk::logical_block(nblocks) * DES_BLOCK;
+    const int e = e0 + threadIdx.x;
+    if (e0 >= ne) return;
+    if (e < ne) {
+        const int4 cn = conn[e];
+        d4 c[4];
+        c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
+        double s[6];
+        for (int i = 0; i < 6; ++i) s[i] = stress[(size_t)i*ne + e];
+        if (p->is_using_mixed_stress) {
+            double dp = 0;
+            dp += ntmp[cn.x]; dp += ntmp[cn.y]; dp += ntmp[cn.z]; dp += ntmp[cn.w];
+            double dp_el = dp / 4;
+            double dp_orig = dpressure[e];
+            double ddp = (-dp_orig + dp_el) / 3;
+            for (int i = 0; i < 3; ++i) { s[i] += ddp; stress[(size_t)i*ne + e] = s[i]; }
+        }
+        const double vol = volume[e];
+        double sx[4], sy[4], sz[4];
+        desk::shape_fn(c, vol, sx, sy, sz);
+        double buoy = 0;
+        if (p->gravity != 0) {
+            double T = 0;
+            T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
+            T /= 4;
+            const double rho = desk::mat_rho(p, markers + (size_t)e * p->nmat, T);
+            const double phi = props ? props[(size_t)2*ne + e] : p->porosity[0];
+            buoy = (rho * (1 - phi) + 1000.0 * phi) * p->gravity / 4;
+        }
+        double *out = stage + threadIdx.x * 13;
+        for (int i = 0; i < 4; ++i) {
+            out[i*3 + 0] = (s[0]*sx[i] + s[3]*sy[i] + s[4]*sz[i]) * vol;
+            out[i*3 + 1] = (s[3]*sx[i] + s[1]*sy[i] + s[5]*sz[i]) * vol;
+            out[i*3 + 2] = (s[4]*sx[i] + s[5]*sy[i] + s[2]*sz[i] + buoy) * vol;
+        }
     }
-    double *out = ftmp + (size_t)e * 12;
-    for (int i = 0; i < 4; ++i) {
-        out[i*3 + 0] = (s[0]*sx[i] + s[3]*sy[i] + s[4]*sz[i]) * vol;
-        out[i*3 + 1] = (s[3]*sx[i] + s[1]*sy[i] + s[5]*sz[i]) * vol;
-        out[i*3 + 2] = (s[4]*sx[i] + s[5]*sy[i] + s[2]*sz[i] + buoy) * vol;
+    __syncthreads();
+    const int nvalid = min(DES_BLOCK, ne - e0) * 12;
+    double *dst = ftmp + (size_t)e0 * 12;
+    for (int idx = threadIdx.x; idx < nvalid; idx += DES_BLOCK) {
+        const int t = idx / 12, k = idx - t * 12;
+        dst[idx] = stage[t * 13 + k];
     }
 }
 
 // ---- stress-bc facets ------------------------------------------------------------
 // apply_stress_bcs facet loop (bc.cxx:707-777) and apply_stress_bcs_neumann (bc.cxx:846-905)
-__global__ void __launch_bounds__(DES_BLOCK)
-k_bc_facets(const des_params *__restrict__ p, int nf, int ne, const int4 *__restrict__ conn,
-            const d4 *__restrict__ xt, const int *__restrict__ markers,
-            const int *__restrict__ f_elem, const int *__restrict__ f_facet, const int *__restrict__ f_kind,
-            const double *__restrict__ f_val, double *__restrict__ f_tmp)
+__device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int4 *__restrict__ conn,
+                              const d4 *__restrict__ xt, const int *__restrict__ markers,
+                              const int *__restrict__ f_elem, const int *__restrict__ f_facet,
+                              const int *__restrict__ f_kind, const double *__restrict__ f_val,
+                              double *__restrict__ f_tmp)
 {
-    const int g = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (g >= nf) return;
     const int e = f_elem[g], f = f_facet[g], kind = f_kind[g];
     const int4 cn = conn[e];
     const int cna[4] = {cn.x, cn.y, cn.z, cn.w};
@@ -812,7 +860,7 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ force, double *__restrict__ fres,
      double *__restrict__ res_part)
 {
-    __shared__ double lds[3][DES_TILE_LDS];
+    __shared__ double lds[3][DES_TILE_LDS(DES_TILE_N3)];
     __shared__ double red[DES_BLOCK / 64];
     const int lb = desk::logical_block(nblocks);
     const int n0 = lb * DES_BLOCK;
@@ -823,8 +871,8 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
     int r0 = ke, r1 = ke;
     if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
-    for (int t0 = kb; t0 < ke; t0 += DES_TILE) {
-        const int tn = min(DES_TILE, ke - t0);
+    for (int t0 = kb; t0 < ke; t0 += DES_TILE_N3) {
+        const int tn = min(DES_TILE_N3, ke - t0);
         for (int j = threadIdx.x; j < tn; j += DES_BLOCK) {
             const int pk = sup_pack[t0 + j];
             const double *tr = ftmp + (size_t)(pk >> 2) * 12 + (pk & 3) * 3;
@@ -922,24 +970,6 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
     }
 }
 
-// end-of-step scalars: l2_residual (fields.cxx:721) and max_surf_vel (bc.cxx:1825); one block
-__global__ void k_step_finalize(DevClock *clk, const double *res_part, int nblocks)
-{
-    __shared__ double red[DES_BLOCK];
-    double t = 0;
-    for (int i = threadIdx.x; i < nblocks; i += DES_BLOCK) t += res_part[i];
-    red[threadIdx.x] = t;
-    __syncthreads();
-    for (int off = DES_BLOCK / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        clk->l2_residual = sqrt(red[0]);
-        clk->max_surf_vel = clk->maxdh / clk->dt;
-    }
-}
-
 // ---- surface processes -----------------------------------------------------------
 // simple_diffusion facet loop (bc.cxx:954-1039)
 __global__ void __launch_bounds__(DES_BLOCK)
@@ -1018,19 +1048,37 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
     }
 }
 
-// edvacc_surf update (bc.cxx:1784-1794)
+// edvacc_surf update (bc.cxx:1784-1794); the last workgroup of the launch does the
+// end-of-step scalars: l2_residual (fields.cxx:721) and max_surf_vel (bc.cxx:1825)
 __global__ void __launch_bounds__(DES_BLOCK)
-k_s3(int etop, const int *__restrict__ ean, const int *__restrict__ conn_surf, const d4 *__restrict__ xt,
-     const double *__restrict__ dh, double *__restrict__ edvacc)
+k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int *__restrict__ ean,
+              const int *__restrict__ conn_surf, const d4 *__restrict__ xt, const double *__restrict__ dh,
+              double *__restrict__ edvacc, const double *__restrict__ res_part, int nres)
 {
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= etop) return;
-    double dh_e = 0.;
-    for (int j = 0; j < 3; j++) dh_e += dh[ean[(size_t)j*etop + i]];
-    const d4 a = xt[conn_surf[i]], b = xt[conn_surf[(size_t)etop + i]], c = xt[conn_surf[(size_t)2*etop + i]];
-    double ab0 = b.x - a.x, ab1 = b.y - a.y, ac0 = c.x - a.x, ac1 = c.y - a.y;
-    double base = fabs(ab0*ac1 - ab1*ac0) / 2;           // triangle_area2d, geometry.cxx:59-73
-    edvacc[i] += dh_e * base / 3;
+    if ((int)blockIdx.x < nsurf_blocks) {
+        const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+        if (i >= etop) return;
+        double dh_e = 0.;
+        for (int j = 0; j < 3; j++) dh_e += dh[ean[(size_t)j*etop + i]];
+        const d4 a = xt[conn_surf[i]], b = xt[conn_surf[(size_t)etop + i]], c = xt[conn_surf[(size_t)2*etop + i]];
+        double ab0 = b.x - a.x, ab1 = b.y - a.y, ac0 = c.x - a.x, ac1 = c.y - a.y;
+        double base = fabs(ab0*ac1 - ab1*ac0) / 2;           // triangle_area2d, geometry.cxx:59-73
+        edvacc[i] += dh_e * base / 3;
+        return;
+    }
+    __shared__ double red[DES_BLOCK];
+    double t = 0;
+    for (int i = threadIdx.x; i < nres; i += DES_BLOCK) t += res_part[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = DES_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        clk->l2_residual = sqrt(red[0]);
+        clk->max_surf_vel = clk->maxdh / clk->dt;
+    }
 }
 
 __global__ void k_dhacc_reset(int ntop, const int *__restrict__ top_nodes, double *__restrict__ dhacc)
@@ -1106,7 +1154,7 @@ void launch_e1(des_dev *h)
 // compute_mass gather alone (N1 without the temperature / dvoldt parts)
 void launch_mass_gather(des_dev *h)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0>), dim3(nblk8(h->nn)), dim3(DES_BLOCK), 0, h->stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(nblk8(h->nn)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, h->nn, nblk(h->nn), h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
                        h->props, h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
@@ -1133,11 +1181,6 @@ void launch_surface(des_dev *h, long long step_no)
                                diffuse, h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf, h->etop, h->sarea,
                                h->sslope, h->dh, h->dhacc, h->xt);
         }
-        if (diffuse && h->etop > 0) {
-            Launch l(h, K_S3);
-            hipLaunchKernelGGL(k_s3, dim3(nblk(h->etop)), dim3(DES_BLOCK), 0, h->stream, h->etop, h->ean,
-                               h->conn_surf, h->xt, h->dh, h->edvacc);
-        }
     }
     if (h->ntop > 0 && step_no != 0 && step_no % h->p.quality_check_step_interval == 0)
         hipLaunchKernelGGL(k_dhacc_reset, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->ntop,
@@ -1151,9 +1194,14 @@ void launch_step_body(des_dev *h, long long step_no)
     const int nbn = nblk(nn), nbe = nblk(ne);
     {
         Launch l(h, K_N1);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1>), dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream,
-                           h->d_p, h->d_clk, nn, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne, h->xt, h->vm,
-                           h->volume_n, h->tmass, h->ymass, h->ntmp);
+        if (h->const_mass)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream,
+                               h->d_p, h->d_clk, nn, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne,
+                               h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream,
+                               h->d_p, h->d_clk, nn, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne,
+                               h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
     }
     {
         Launch l(h, K_E2);
@@ -1169,13 +1217,10 @@ void launch_step_body(des_dev *h, long long step_no)
     }
     {
         Launch l(h, K_E3);
-        hipLaunchKernelGGL(E3_nmd_force, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nbe, h->conn, h->xt,
-                           h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp);
-    }
-    if (h->nbcf > 0) {
-        Launch l(h, K_BCF);
-        hipLaunchKernelGGL(k_bc_facets, dim3(nblk(h->nbcf)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->nbcf, ne,
-                           h->conn, h->xt, h->markers, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
+        const int nbe8 = nblk8(ne);
+        hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nblk(h->nbcf)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nbe, nbe8,
+                           h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp,
+                           h->nbcf, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
     }
     {
         Launch l(h, K_N3);
@@ -1187,8 +1232,11 @@ void launch_step_body(des_dev *h, long long step_no)
     if (h->p.has_moving_mesh)
         launch_surface(h, step_no);
     {
-        Launch l(h, K_FIN);
-        hipLaunchKernelGGL(k_step_finalize, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->res_part, nbn);
+        // edvacc_surf (surface diffusion only) + end-of-step scalars in one launch
+        Launch l(h, K_S3);
+        const int nsb = (h->p.has_moving_mesh && h->p.surface_process_option == 1 && h->ntop > 0) ? nblk(h->etop) : 0;
+        hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb, h->ean,
+                           h->conn_surf, h->xt, h->dh, h->edvacc, h->res_part, nbn);
     }
 }
 
@@ -1260,6 +1308,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
     h->markers_dirty = true;
     h->pending_c = true;
+    h->const_mass = params->is_quasi_static && params->nmat == 1;
 
 #define CK(x) do { int rc_ = (x); if (rc_ != DES_OK) { *err = rc_; des_dev_destroy(h); return nullptr; } } while (0)
 #define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_last_error = std::string(#x) + ": " + hipGetErrorString(e_); \
