@@ -76,11 +76,11 @@ struct DevClock {
 
 enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };   // INIT: C part without rotate_stress
 
-enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_N3, K_S1, K_S2, K_S3,
+enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_N3, K_S2, K_S3,
                 K_DTFIN, K_MISC, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "N2_nmd_gather",
-    "E3_nmd_force", "N3_force_velocity_coord", "S1_surf_facets", "S2_surf_nodes",
+    "E3_nmd_force", "N3_force_velocity_coord", "S2_surface_diffusion",
     "S3_edvacc_step_finalize", "dt_finalize", "misc" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
@@ -126,8 +126,8 @@ struct des_dev {
     unsigned bc_mask;                     // bcflag bits that have any entry
     // surface
     int ntop, etop, ntop_elems;
-    int *top_nodes, *ean, *conn_surf, *ssup_idx, *ssup_arr, *topf_elem, *topf_facet;
-    double *dh, *edvacc, *sarea, *sslope; // sslope [etop][3]
+    int *top_nodes, *ean, *conn_surf, *ssup_idx, *ssup_arr;
+    double *dh, *edvacc, *znew;           // znew: surface heights between k_s2 and their commit
     // bnormals / edges for slanted boundaries
     double *bnormals, *edge_vec; int *edge_slot;
 
@@ -971,71 +971,59 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
 }
 
 // ---- surface processes -----------------------------------------------------------
-// simple_diffusion facet loop (bc.cxx:954-1039)
-__global__ void __launch_bounds__(DES_BLOCK)
-k_s1(int etop, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
-     const int *__restrict__ topf_elem, const int *__restrict__ topf_facet,
-     double *__restrict__ sarea, double *__restrict__ sslope)
-{
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= etop) return;
-    const int4 cn = conn[topf_elem[i]];
-    const int cna[4] = {cn.x, cn.y, cn.z, cn.w};
-    const int f = topf_facet[i];
-    d4 cf[3];
-    for (int j = 0; j < 3; ++j) cf[j] = xt[cna[NODE_OF_FACET_D[f][j]]];
-    double x01 = cf[1].x - cf[0].x, y01 = cf[1].y - cf[0].y;
-    double x02 = cf[2].x - cf[0].x, y02 = cf[2].y - cf[0].y;
-    double projected_area = 0.5 * (x01*y02 - y01*x02);
-    sarea[i] = projected_area;
-    double shp2dx[3], shp2dy[3];
-    double iv = 1 / (2 * projected_area);
-    shp2dx[0] = iv * (cf[1].y - cf[2].y);
-    shp2dx[1] = iv * (cf[2].y - cf[0].y);
-    shp2dx[2] = iv * (cf[0].y - cf[1].y);
-    shp2dy[0] = iv * (cf[2].x - cf[1].x);
-    shp2dy[1] = iv * (cf[0].x - cf[2].x);
-    shp2dy[2] = iv * (cf[1].x - cf[0].x);
-    const double zz[3] = {cf[0].z, cf[1].z, cf[2].z};
-    for (int j = 0; j < 3; j++) {
-        double slope = 0;
-        for (int k = 0; k < 3; k++)
-            slope += (shp2dx[j] * shp2dx[k] + shp2dy[j] * shp2dy[k]) * zz[k];
-        sslope[(size_t)i*3 + j] = slope * projected_area;
-    }
-}
-
-// simple_diffusion node loops (bc.cxx:1045-1107) + coordinate/dhacc update (bc.cxx:1770-1777)
+// simple_diffusion (bc.cxx:954-1107) + coordinate/dhacc update (bc.cxx:1770-1777), one thread
+// per surface node.  The facet quantities of bc.cxx:954-1039 (projected area, slope term of the
+// facet's local node) are recomputed by every node that touches the facet -- ~6x redundant
+// work on O(surface) data, in exchange for one launch and no facet temporaries; the values are
+// the same deterministic expressions, so the sums are bit-identical.
 __global__ void __launch_bounds__(DES_BLOCK)
 k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int diffuse,
      const int *__restrict__ top_nodes, const int *__restrict__ ssup_idx, const int *__restrict__ ssup_arr,
-     const int *__restrict__ conn_surf, int etop, const double *__restrict__ sarea,
-     const double *__restrict__ sslope, double *__restrict__ dh, double *__restrict__ dhacc, d4 *__restrict__ xt)
+     const int *__restrict__ conn_surf, int etop, const d4 *__restrict__ xt_in,
+     double *__restrict__ dh, double *__restrict__ dhacc, double *__restrict__ znew)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     double d = 0.;
     if (i < ntop) {
-    const int n = top_nodes[i];
-    if (diffuse) {
-        double total_dx = 0., total_slope = 0.;
-        for (int j = ssup_idx[i]; j < ssup_idx[i+1]; ++j) {
-            const int k = ssup_arr[j];
-            total_dx += sarea[k];
-            for (int m = 0; m < 3; ++m) {
-                if (conn_surf[(size_t)m*etop + k] == n) {
-                    total_slope += sslope[(size_t)k*3 + m];
-                    break;
+        const int n = top_nodes[i];
+        if (diffuse) {
+            double total_dx = 0., total_slope = 0.;
+            for (int j = ssup_idx[i]; j < ssup_idx[i+1]; ++j) {
+                const int k = ssup_arr[j];
+                int nd[3];
+                d4 cf[3];
+                for (int m = 0; m < 3; ++m) { nd[m] = conn_surf[(size_t)m*etop + k]; cf[m] = xt_in[nd[m]]; }
+                double x01 = cf[1].x - cf[0].x, y01 = cf[1].y - cf[0].y;
+                double x02 = cf[2].x - cf[0].x, y02 = cf[2].y - cf[0].y;
+                double projected_area = 0.5 * (x01*y02 - y01*x02);
+                total_dx += projected_area;
+                double shp2dx[3], shp2dy[3];
+                double iv = 1 / (2 * projected_area);
+                shp2dx[0] = iv * (cf[1].y - cf[2].y);
+                shp2dx[1] = iv * (cf[2].y - cf[0].y);
+                shp2dx[2] = iv * (cf[0].y - cf[1].y);
+                shp2dy[0] = iv * (cf[2].x - cf[1].x);
+                shp2dy[1] = iv * (cf[0].x - cf[2].x);
+                shp2dy[2] = iv * (cf[1].x - cf[0].x);
+                const double zz[3] = {cf[0].z, cf[1].z, cf[2].z};
+                for (int m = 0; m < 3; ++m) {
+                    if (nd[m] == n) {
+                        double slope = 0;
+                        for (int q = 0; q < 3; q++)
+                            slope += (shp2dx[m] * shp2dx[q] + shp2dy[m] * shp2dy[q]) * zz[q];
+                        total_slope += slope * projected_area;
+                        break;
+                    }
                 }
             }
+            double conv = p->surface_diffusivity * clk->dt * total_slope / total_dx;
+            d -= conv;
         }
-        double conv = p->surface_diffusivity * clk->dt * total_slope / total_dx;
-        d -= conv;
-    }
-    dh[i] = d;
-    d4 x4 = xt[n];
-    x4.z += d;
-    xt[n] = x4;
-    dhacc[n] += d;
+        dh[i] = d;
+        // neighbours still need this node's OLD height: the new one goes to a side buffer and
+        // is committed by the next launch (k_s3_finalize)
+        znew[i] = xt_in[n].z + d;
+        dhacc[n] += d;
     }
     // max |dh| (bc.cxx:1811-1821); max is order-independent
     __shared__ double red[DES_BLOCK / 64];
@@ -1052,9 +1040,17 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
 // end-of-step scalars: l2_residual (fields.cxx:721) and max_surf_vel (bc.cxx:1825)
 __global__ void __launch_bounds__(DES_BLOCK)
 k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int *__restrict__ ean,
-              const int *__restrict__ conn_surf, const d4 *__restrict__ xt, const double *__restrict__ dh,
-              double *__restrict__ edvacc, const double *__restrict__ res_part, int nres)
+              const int *__restrict__ conn_surf, d4 *__restrict__ xt, const double *__restrict__ dh,
+              double *__restrict__ edvacc, const double *__restrict__ res_part, int nres,
+              int ntop, int nz_blocks, const int *__restrict__ top_nodes, const double *__restrict__ znew)
 {
+    if ((int)blockIdx.x >= nsurf_blocks && (int)blockIdx.x < nsurf_blocks + nz_blocks) {
+        // commit the surface heights computed by k_s2 (bc.cxx:1775); the facet-area term below
+        // only reads x and y, so the two kinds of workgroup do not depend on each other
+        const int i = ((int)blockIdx.x - nsurf_blocks) * DES_BLOCK + threadIdx.x;
+        if (i < ntop) xt[top_nodes[i]].z = znew[i];
+        return;
+    }
     if ((int)blockIdx.x < nsurf_blocks) {
         const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
         if (i >= etop) return;
@@ -1170,17 +1166,10 @@ void launch_surface(des_dev *h, long long step_no)
 {
     const int diffuse = h->p.surface_process_option == 1;
     if (h->ntop > 0) {
-        if (diffuse && h->etop > 0) {
-            Launch l(h, K_S1);
-            hipLaunchKernelGGL(k_s1, dim3(nblk(h->etop)), dim3(DES_BLOCK), 0, h->stream, h->etop, h->conn, h->xt,
-                               h->topf_elem, h->topf_facet, h->sarea, h->sslope);
-        }
-        {
-            Launch l(h, K_S2);
-            hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
-                               diffuse, h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf, h->etop, h->sarea,
-                               h->sslope, h->dh, h->dhacc, h->xt);
-        }
+        Launch l(h, K_S2);
+        hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
+                           diffuse, h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf, h->etop, h->xt,
+                           h->dh, h->dhacc, h->znew);
     }
     if (h->ntop > 0 && step_no != 0 && step_no % h->p.quality_check_step_interval == 0)
         hipLaunchKernelGGL(k_dhacc_reset, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->ntop,
@@ -1234,9 +1223,11 @@ void launch_step_body(des_dev *h, long long step_no)
     {
         // edvacc_surf (surface diffusion only) + end-of-step scalars in one launch
         Launch l(h, K_S3);
-        const int nsb = (h->p.has_moving_mesh && h->p.surface_process_option == 1 && h->ntop > 0) ? nblk(h->etop) : 0;
-        hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb, h->ean,
-                           h->conn_surf, h->xt, h->dh, h->edvacc, h->res_part, nbn);
+        const bool surf = h->p.has_moving_mesh && h->ntop > 0;
+        const int nsb = (surf && h->p.surface_process_option == 1) ? nblk(h->etop) : 0;
+        const int nzb = surf ? nblk(h->ntop) : 0;
+        hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + nzb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb, h->ean,
+                           h->conn_surf, h->xt, h->dh, h->edvacc, h->res_part, nbn, h->ntop, nzb, h->top_nodes, h->znew);
     }
 }
 
@@ -1278,8 +1269,8 @@ void des_dev_destroy(des_dev *h)
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->radiogenic, h->markers, h->props, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
-        h->conn_surf, h->ssup_idx, h->ssup_arr, h->topflag, h->topf_elem, h->topf_facet, h->dh, h->edvacc,
-        h->sarea, h->sslope, h->bnormals, h->edge_vec, h->edge_slot };
+        h->conn_surf, h->ssup_idx, h->ssup_arr, h->topflag, h->dh, h->edvacc,
+        h->znew, h->bnormals, h->edge_vec, h->edge_slot };
     for (void *q : ptrs) if (q) hipFree(q);
     if (h->h_clk) hipHostFree(h->h_clk);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -1472,9 +1463,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             for (int i = 0; i < h->ntop_elems; ++i) flag[mesh->top_elems[i]] = 1;
             CK(dev_alloc(h->topflag, (size_t)ne)); CK(dev_upload(h->topflag, flag.data(), (size_t)ne, h->stream));
         }
-        CK(dev_alloc(h->topf_elem, etop)); CK(dev_upload(h->topf_elem, mesh->bfacet_elem[5], etop, h->stream));
-        CK(dev_alloc(h->topf_facet, etop)); CK(dev_upload(h->topf_facet, mesh->bfacet_facet[5], etop, h->stream));
-        CK(dev_alloc(h->dh, ntop)); CK(dev_alloc(h->edvacc, etop)); CK(dev_alloc(h->sarea, etop)); CK(dev_alloc(h->sslope, 3*etop));
+        CK(dev_alloc(h->dh, ntop)); CK(dev_alloc(h->edvacc, etop)); CK(dev_alloc(h->znew, ntop));
         HK(hipMemsetAsync(h->dh, 0, 8*std::max<size_t>(ntop, 1), h->stream));
         HK(hipMemsetAsync(h->edvacc, 0, 8*std::max<size_t>(etop, 1), h->stream));
     }
