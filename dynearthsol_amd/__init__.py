@@ -208,6 +208,52 @@ class EngineBase:
         self._f("check_nan")(self._h, C.byref(n))
         return n.value
 
+    # ---- domain decomposition hooks (same call shape on the device engine and the oracle)
+    def set_halo(self, part):
+        f = self._f("set_halo")
+        if self.prefix == "des_oracle":
+            f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+            self._check(f(self._h, part.owned[0], part.owned[1], part.host.nnode), "set_halo")
+        else:
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+            self._check(f(self._h, C.byref(part.halo), part.host.nnode), "set_halo")
+        self._part = part
+
+    def phase(self, ph):
+        f = self._f("phase")
+        f.argtypes = [C.c_void_p, C.c_int]
+        return f(self._h, ph)
+
+    def halo_pack(self, kind, idx, width):
+        f = self._f("halo_pack")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        buf = np.empty(len(idx) * width)
+        self._check(f(self._h, kind, idx.ctypes.data_as(C.c_void_p), len(idx), buf.ctypes.data_as(C.c_void_p)), "halo_pack")
+        return buf
+
+    def halo_unpack(self, kind, idx, buf):
+        f = self._f("halo_unpack")
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        buf = np.ascontiguousarray(buf, dtype=np.float64)
+        self._check(f(self._h, kind, idx.ctypes.data_as(C.c_void_p), len(idx), buf.ctypes.data_as(C.c_void_p)), "halo_unpack")
+
+    def dt_partials(self, recompute):
+        f = self._f("dt_partials")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        out = np.empty(6)
+        self._check(f(self._h, out.ctypes.data_as(C.c_void_p), int(recompute)), "dt_partials")
+        return out
+
+    def dt_finalize(self, red):
+        f = self._f("dt_finalize")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        red = np.ascontiguousarray(red, dtype=np.float64)
+        dt = C.c_double(0)
+        self._check(f(self._h, red.ctypes.data_as(C.c_void_p), C.byref(dt)), "dt_finalize")
+        return dt.value
+
     def close(self):
         if self._h:
             self._f("destroy")(self._h)

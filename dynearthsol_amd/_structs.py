@@ -61,6 +61,14 @@ class DesMesh(C.Structure):
     ]
 
 
+class DesHalo(C.Structure):
+    _fields_ = [
+        ("owned_begin", C.c_int), ("owned_end", C.c_int), ("nnbr", C.c_int),
+        ("nbr_rank", _pint), ("send_ptr", _pint), ("send_idx", _pint),
+        ("recv_ptr", _pint), ("recv_idx", _pint),
+    ]
+
+
 class DesScalars(C.Structure):
     _fields_ = [
         ("dt", C.c_double), ("time", C.c_double), ("l2_residual", C.c_double),

@@ -102,4 +102,8 @@ int des_host_save_mesh(const des_host *h, const char *path)
 
 const char *des_host_last_error(void) { return g_last_error.c_str(); }
 
+// used by partition.cpp
+const des::HostMesh *des_host_mesh_internal(const des_host *h) { return &h->mesh; }
+void des_host_set_error(const char *msg) { g_last_error = msg; }
+
 } // extern "C"

@@ -1,0 +1,221 @@
+// partition.cpp -- slab decomposition of the renumbered mesh for one-process-per-GPU runs.
+//
+// New work: the reference is single-process.  The renumbered mesh is sorted
+// along its longest axis (mesh.cxx:2742-2766), so a contiguous range of node ids is a slab.
+// Rank r OWNS such a range; its local mesh is the union of the supports of its nodes (all
+// elements touching an owned node) with local numbering in ascending global order.  That keeps
+// (a) every owned node's element patch complete and (b) in the same ascending element order
+// as on one GPU, so the nodal sums are bit-identical to an undecomposed run.
+#include "des_host.h"
+#include "des_host.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <set>
+#include <unordered_map>
+
+namespace {
+const int NODE_OF_FACET[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};
+}
+
+struct des_part {
+    des::HostMesh local;
+    des_mesh view;
+    des_halo halo;
+    std::vector<int> l2g_node, l2g_elem;
+    std::vector<int> nbr_rank, send_ptr, send_idx, recv_ptr, recv_idx;
+    std::vector<int> node_start;        // [nranks+1] global ownership ranges
+};
+
+namespace des {
+
+// split nodes into `nranks` contiguous ranges of about equal support size (element work)
+static std::vector<int> split_nodes(const HostMesh &g, int nranks)
+{
+    std::vector<int> start(nranks + 1, 0);
+    const long long total = g.sup_idx[g.nnode];
+    int n = 0;
+    for (int r = 1; r < nranks; ++r) {
+        const long long target = total * r / nranks;
+        while (n < g.nnode && g.sup_idx[n] < target) ++n;
+        start[r] = n;
+    }
+    start[nranks] = g.nnode;
+    return start;
+}
+
+static inline int owner_of(const std::vector<int> &start, int n)
+{
+    return (int)(std::upper_bound(start.begin(), start.end(), n) - start.begin()) - 1;
+}
+
+void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) throw Error(60, "bad rank / nranks");
+    const int ne = g.nelem, nn = g.nnode;
+    P.node_start = split_nodes(g, nranks);
+    const int a = P.node_start[rank], b = P.node_start[rank + 1];
+    if (b <= a) throw Error(52, "a rank owns no node: too many ranks for this mesh");
+
+    // local elements: any node owned by this rank; local nodes: their nodes
+    std::vector<char> node_local((size_t)nn, 0);
+    P.l2g_elem.clear();
+    for (int e = 0; e < ne; ++e) {
+        bool mine = false;
+        for (int i = 0; i < 4; ++i) { int n = g.conn[(size_t)i*ne + e]; if (n >= a && n < b) { mine = true; break; } }
+        if (!mine) continue;
+        P.l2g_elem.push_back(e);
+        for (int i = 0; i < 4; ++i) node_local[g.conn[(size_t)i*ne + e]] = 1;
+    }
+    P.l2g_node.clear();
+    std::vector<int> g2l((size_t)nn, -1);
+    for (int n = 0; n < nn; ++n) if (node_local[n]) { g2l[n] = (int)P.l2g_node.size(); P.l2g_node.push_back(n); }
+    const int lnn = (int)P.l2g_node.size(), lne = (int)P.l2g_elem.size();
+    std::vector<int> g2l_elem((size_t)ne, -1);
+    for (int e = 0; e < lne; ++e) g2l_elem[P.l2g_elem[e]] = e;
+
+    HostMesh &m = P.local;
+    m = HostMesh();
+    m.nnode = lnn; m.nelem = lne; m.nseg = 0;
+    m.coord.resize((size_t)3*lnn);
+    for (int n = 0; n < lnn; ++n)
+        for (int d = 0; d < 3; ++d) m.coord[(size_t)d*lnn + n] = g.coord[(size_t)d*nn + P.l2g_node[n]];
+    m.conn.resize((size_t)4*lne);
+    for (int e = 0; e < lne; ++e)
+        for (int i = 0; i < 4; ++i) m.conn[(size_t)i*lne + e] = g2l[g.conn[(size_t)i*ne + P.l2g_elem[e]]];
+    m.regattr.resize((size_t)lne);
+    for (int e = 0; e < lne; ++e) m.regattr[e] = g.regattr[P.l2g_elem[e]];
+    m.bcflag.resize((size_t)lnn);
+    for (int n = 0; n < lnn; ++n) m.bcflag[n] = g.bcflag[P.l2g_node[n]];
+    for (int i = 0; i < DES_NBDRY; ++i) {
+        m.bnodes[i].clear();
+        for (int n = 0; n < lnn; ++n) if (m.bcflag[n] & (1u << i)) m.bnodes[i].push_back(n);
+        m.bfacet_elem[i].clear(); m.bfacet_facet[i].clear();
+        for (size_t q = 0; q < g.bfacet_elem[i].size(); ++q) {
+            int le = g2l_elem[g.bfacet_elem[i][q]];
+            if (le < 0) continue;
+            m.bfacet_elem[i].push_back(le);
+            m.bfacet_facet[i].push_back(g.bfacet_facet[i][q]);
+        }
+    }
+    // support of the local mesh (complete for owned nodes, partial for halo nodes)
+    m.sup_idx.assign((size_t)lnn + 1, 0);
+    for (int e = 0; e < lne; ++e)
+        for (int i = 0; i < 4; ++i) m.sup_idx[m.conn[(size_t)i*lne + e] + 1]++;
+    for (int n = 1; n <= lnn; ++n) m.sup_idx[n] += m.sup_idx[n-1];
+    m.sup_arr.resize((size_t)m.sup_idx[lnn]); m.sup_lidx.resize((size_t)m.sup_idx[lnn]);
+    {
+        std::vector<int> cursor(m.sup_idx.begin(), m.sup_idx.end() - 1);
+        for (int e = 0; e < lne; ++e)
+            for (int i = 0; i < 4; ++i) {
+                int slot = cursor[m.conn[(size_t)i*lne + e]]++;
+                m.sup_arr[slot] = e; m.sup_lidx[slot] = i;
+            }
+    }
+    // surface lists, in the global x-sorted order of surfinfo.top_nodes
+    m.top_nodes.clear();
+    for (size_t i = 0; i < g.top_nodes.size(); ++i) { int l = g2l[g.top_nodes[i]]; if (l >= 0) m.top_nodes.push_back(l); }
+    const int etop = (int)m.bfacet_elem[5].size(), ntop = (int)m.top_nodes.size();
+    m.conn_surf.assign((size_t)4*etop, 0);
+    for (int i = 0; i < etop; ++i)
+        for (int j = 0; j < 3; ++j)
+            m.conn_surf[(size_t)j*etop + i] = m.conn[(size_t)NODE_OF_FACET[m.bfacet_facet[5][i]][j]*lne + m.bfacet_elem[5][i]];
+    std::unordered_map<int,int> arctop;
+    for (int i = 0; i < ntop; ++i) arctop[m.top_nodes[i]] = i;
+    m.elem_and_nodes.assign((size_t)3*etop, 0);
+    for (int i = 0; i < etop; ++i)
+        for (int k = 0; k < 3; ++k) m.elem_and_nodes[(size_t)k*etop + i] = arctop[m.conn_surf[(size_t)k*etop + i]];
+    m.ssup_idx.assign((size_t)ntop + 1, 0);
+    for (int i = 0; i < etop; ++i)
+        for (int k = 0; k < 3; ++k) m.ssup_idx[m.elem_and_nodes[(size_t)k*etop + i] + 1]++;
+    for (int n = 1; n <= ntop; ++n) m.ssup_idx[n] += m.ssup_idx[n-1];
+    m.ssup_arr.resize((size_t)m.ssup_idx[ntop]);
+    {
+        std::vector<int> cursor(m.ssup_idx.begin(), m.ssup_idx.end() - 1);
+        for (int i = 0; i < etop; ++i)
+            for (int k = 0; k < 3; ++k) m.ssup_arr[cursor[m.elem_and_nodes[(size_t)k*etop + i]]++] = i;
+    }
+    m.top_elems.clear();
+    for (size_t i = 0; i < g.top_elems.size(); ++i) { int le = g2l_elem[g.top_elems[i]]; if (le >= 0) m.top_elems.push_back(le); }
+    m.bnormals = g.bnormals;
+    m.edge_vec = g.edge_vec;
+    std::memcpy(m.edge_slot, g.edge_slot, sizeof(m.edge_slot));
+
+    // halo lists.  Node n (owner q) is needed by rank s != q iff some element contains n and
+    // a node owned by s.  Both sides derive the same ascending lists from the same rule.
+    std::map<int, std::set<int> > send_to, recv_from;         // neighbour rank -> GLOBAL node ids
+    for (int le = 0; le < lne; ++le) {
+        int own[4], nd[4];
+        for (int i = 0; i < 4; ++i) { nd[i] = g.conn[(size_t)i*ne + P.l2g_elem[le]]; own[i] = owner_of(P.node_start, nd[i]); }
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                if (own[i] == own[j]) continue;
+                if (own[i] == rank) send_to[own[j]].insert(nd[i]);      // my node i is needed by owner of j
+                if (own[j] == rank) recv_from[own[i]].insert(nd[i]);    // I need node i from its owner
+            }
+    }
+    std::set<int> nbrs;
+    for (auto &kv : send_to) nbrs.insert(kv.first);
+    for (auto &kv : recv_from) nbrs.insert(kv.first);
+    P.nbr_rank.assign(nbrs.begin(), nbrs.end());
+    P.send_ptr.assign(1, 0); P.recv_ptr.assign(1, 0);
+    P.send_idx.clear(); P.recv_idx.clear();
+    for (int q : P.nbr_rank) {
+        for (int gn : send_to[q]) P.send_idx.push_back(g2l[gn]);
+        for (int gn : recv_from[q]) P.recv_idx.push_back(g2l[gn]);
+        P.send_ptr.push_back((int)P.send_idx.size());
+        P.recv_ptr.push_back((int)P.recv_idx.size());
+    }
+    // every halo node must be received from exactly one neighbour
+    {
+        std::vector<char> got((size_t)lnn, 0);
+        for (int l : P.recv_idx) { if (got[l]) throw Error(60, "halo node received twice"); got[l] = 1; }
+        for (int n = 0; n < lnn; ++n) {
+            bool owned = P.l2g_node[n] >= a && P.l2g_node[n] < b;
+            if (owned == (bool)got[n]) throw Error(60, "halo lists do not cover the non-owned nodes exactly");
+        }
+    }
+    P.view = m.view();
+    P.halo.owned_begin = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), a) - P.l2g_node.begin());
+    P.halo.owned_end = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), b) - P.l2g_node.begin());
+    P.halo.nnbr = (int)P.nbr_rank.size();
+    P.halo.nbr_rank = P.nbr_rank.data();
+    P.halo.send_ptr = P.send_ptr.data(); P.halo.send_idx = P.send_idx.data();
+    P.halo.recv_ptr = P.recv_ptr.data(); P.halo.recv_idx = P.recv_idx.data();
+}
+
+} // namespace des
+
+extern "C" {
+
+// defined in capi.cpp
+const des::HostMesh *des_host_mesh_internal(const des_host *h);
+void des_host_set_error(const char *msg);
+
+des_part *des_host_partition(const des_host *h, int nranks, int rank, int *err)
+{
+    des_part *P = new des_part();
+    try {
+        des::build_partition(*des_host_mesh_internal(h), nranks, rank, *P);
+        if (err) *err = DES_OK;
+        return P;
+    } catch (const des::Error &e) {
+        des_host_set_error(e.what());
+        if (err) *err = e.code;
+    } catch (const std::exception &e) {
+        des_host_set_error(e.what());
+        if (err) *err = DES_ERR_INTERNAL;
+    }
+    delete P;
+    return nullptr;
+}
+
+void des_part_destroy(des_part *p) { delete p; }
+const des_mesh *des_part_mesh(const des_part *p) { return &p->view; }
+const des_halo *des_part_halo(const des_part *p) { return &p->halo; }
+const int *des_part_l2g_node(const des_part *p, int *n) { if (n) *n = (int)p->l2g_node.size(); return p->l2g_node.data(); }
+const int *des_part_l2g_elem(const des_part *p, int *n) { if (n) *n = (int)p->l2g_elem.size(); return p->l2g_elem.data(); }
+const int *des_part_node_ranges(const des_part *p, int *n) { if (n) *n = (int)p->node_start.size(); return p->node_start.data(); }
+
+} // extern "C"

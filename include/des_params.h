@@ -139,6 +139,32 @@ typedef struct des_mesh {
     const int *top_elems;           /* [ntop_elems] Variables::top_elems                            */
 } des_mesh;
 
+/* Domain decomposition (new: the reference is single-process).  A rank's mesh is
+ * the union of the supports of the nodes it OWNS -- a contiguous id range of the renumbered
+ * (x-sorted, mesh.cxx:2742-2766) global mesh -- so every owned node has its complete element
+ * patch locally and is assembled in the same element order as on one GPU.  Elements that
+ * straddle a cut are computed by both neighbours from identical inputs; only nodal values of
+ * HALO nodes (local but owned elsewhere) are exchanged, three or four times per step. */
+typedef struct des_halo {
+    int owned_begin, owned_end;      /* owned nodes = local ids [owned_begin, owned_end)             */
+    int nnbr;                        /* neighbour ranks                                             */
+    const int *nbr_rank;             /* [nnbr]                                                      */
+    const int *send_ptr;             /* [nnbr+1] offsets into send_idx                              */
+    const int *send_idx;             /* local ids of OWNED nodes each neighbour needs, ascending    */
+    const int *recv_ptr;             /* [nnbr+1] offsets into recv_idx                              */
+    const int *recv_idx;             /* local ids of HALO nodes owned by each neighbour, ascending  */
+} des_halo;
+
+/* Nodal exchanges of one step and their width in doubles per node.  A step is five phases
+ * (des_dev_phase 0..4) with one exchange after each of the first four:
+ *   0 -> {T, ntmp}   1 -> {ntmp} (NMD only)   2 -> {vx,vy,vz,x,y,z}
+ *   3 -> {z, dh} (surface diffusion only: it reads the neighbours' NEW coordinates)   4 */
+enum { DES_X_TEMP_NTMP = 0, DES_X_NTMP = 1, DES_X_VEL_COORD = 2, DES_X_SURFACE = 3, DES_X_COUNT = 4 };
+#define DES_X_WIDTH_0 2
+#define DES_X_WIDTH_1 1
+#define DES_X_WIDTH_2 6
+#define DES_X_WIDTH_3 2
+
 /* Field ids for upload/download.  "E" = per element, "N" = per node. */
 enum des_field {
     DES_F_COORD = 0,        /* N  array_t   SoA [3][nnode]  */

@@ -66,7 +66,11 @@ struct des_oracle {
     dvec stress, strain, strain_rate, plstrain, delta_plstrain, viscosity, volume,
          volume_old, dpressure, edvoldt, radiogenic, etmp, tmp_result;
     ivec elemmarkers, etmp_int;
-    dvec dh, edvacc_surf;
+    dvec dh, edvacc_surf, dh_n;
+    int o0, o1;                         // owned nodes [o0, o1) (whole mesh unless decomposed)
+    double dt_part[6];
+    double l2_part;
+    int nn_global;                  // compute_dt partials: minl, dt_maxwell, dt_diffusion, gdt_min, -max_vem, -max_surf_vel
     // matprops cache (matprops.cxx:259-303): bulkm, shearm, phi, cp, k per element
     dvec c_bulkm, c_shearm, c_phi, c_cp, c_k;
     bool markers_dirty;
@@ -751,7 +755,7 @@ void update_temperature(des_oracle &o)
         }
     }
     #pragma omp parallel for
-    for (int n = 0; n < nn; n++) {
+    for (int n = o.o0; n < o.o1; n++) {
         if (o.bcflag[n] & BOUNDZ1)
             o.temperature[n] = o.p.surface_temperature;
         else {
@@ -795,7 +799,7 @@ void compute_dvoldt(des_oracle &o)
         o.etmp[e] = dj * o.volume[e];
     }
     #pragma omp parallel for
-    for (int n = 0; n < o.nn; n++) {
+    for (int n = o.o0; n < o.o1; n++) {
         double acc = 0.;
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k)
             acc += o.etmp[o.sup_arr[k]];
@@ -917,20 +921,26 @@ void update_stress(des_oracle &o)
     }
 }
 
-// geometry.cxx:282-336
-void NMD_stress(des_oracle &o)
+// geometry.cxx:282-336, element part + nodal gather
+void NMD_stress_gather(des_oracle &o)
 {
     const int ne = o.ne;
     #pragma omp parallel for
     for (int e = 0; e < ne; e++)
         o.etmp[e] = o.dpressure[e] * o.volume[e];
     #pragma omp parallel for
-    for (int n = 0; n < o.nn; n++) {
+    for (int n = o.o0; n < o.o1; n++) {
         double acc = 0;
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k)
             acc += o.etmp[o.sup_arr[k]];
         o.ntmp[n] = acc / o.volume_n[n];
     }
+}
+
+// geometry.cxx:311-331, after the nodal pressure change is known on every local node
+void NMD_stress_apply(des_oracle &o)
+{
+    const int ne = o.ne;
     #pragma omp parallel for
     for (int e = 0; e < ne; ++e) {
         double dp = 0;
@@ -1007,6 +1017,7 @@ void apply_stress_bcs(des_oracle &o)
 
         for (int j = 0; j < nbdry_nodes; ++j) {
             const int n = o.bnodes[i][j];
+            if (n < o.o0 || n >= o.o1) continue;
             for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k) {
                 int e = o.sup_arr[k];
                 int ibound = o.etmp_int[e];
@@ -1077,18 +1088,18 @@ void apply_damping(des_oracle &o)
     case 0: break;
     case 1:
         #pragma omp parallel for
-        for (int i = 0; i < nn; ++i)
+        for (int i = o.o0; i < o.o1; ++i)
             for (int j = 0; j < ND; j++)
                 if (std::fabs(o.vel[j*nn+i]) > small_vel)
                     o.force[j*nn+i] -= p.damping_factor * std::copysign(o.force[j*nn+i], o.vel[j*nn+i]);
         break;
     case 2:
-        for (int i = 0; i < nn; ++i)
+        for (int i = o.o0; i < o.o1; ++i)
             for (int j = 0; j < ND; j++)
                 o.force[j*nn+i] -= p.damping_factor * o.force[j*nn+i];
         break;
     case 3:
-        for (int i = 0; i < nn; ++i)
+        for (int i = o.o0; i < o.o1; ++i)
             for (int j = 0; j < ND; j++) {
                 if ((o.force[j*nn+i] < 0) == (o.vel[j*nn+i] < 0)) {
                     // fields.cxx:538 -- comma operator: the trailing vel term has no effect
@@ -1099,7 +1110,7 @@ void apply_damping(des_oracle &o)
             }
         break;
     case 4:
-        for (int i = 0; i < nn; ++i) {
+        for (int i = o.o0; i < o.o1; ++i) {
             double critical_coeff = 2.0 * std::sqrt(o.mass[i] * o.ymass[i]);
             for (int j = 0; j < ND; j++)
                 if (std::fabs(o.vel[j*nn+i]) > small_vel) {
@@ -1137,7 +1148,7 @@ void update_force(des_oracle &o)
         }
     }
     #pragma omp parallel for
-    for (int n = 0; n < nn; n++) {
+    for (int n = o.o0; n < o.o1; n++) {
         double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k) {
             const int e = o.sup_arr[k], i = o.sup_lidx[k];
@@ -1160,10 +1171,11 @@ void update_force(des_oracle &o)
 double calculate_residual_force(des_oracle &o)
 {
     double l2 = 0.0;
-    double num = o.nn * ND;
-    for (int i = 0; i < o.nn; ++i)
+    double num = (double)o.nn_global * ND;
+    for (int i = o.o0; i < o.o1; ++i)
         for (int j = 0; j < ND; ++j)
             l2 += std::pow(o.force_residual[j*o.nn+i], 2) / num;
+    o.l2_part = l2;                      // summed over ranks before the root in a decomposed run
     return std::sqrt(l2);
 }
 
@@ -1172,16 +1184,19 @@ void update_velocity(des_oracle &o)
 {
     const int nn = o.nn;
     #pragma omp parallel for
-    for (int i = 0; i < nn; ++i)
+    for (int i = o.o0; i < o.o1; ++i)
         for (int j = 0; j < ND; j++)
             o.vel[j*nn+i] += o.dt * o.force[j*nn+i] / o.mass[i];
 }
 
 // bc.cxx:227-659 (THREED branch)
-void apply_vbcs(des_oracle &o)
+void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
 {
     const des_params &p = o.p;
     const int nn = o.nn;
+    // init() applies the bcs to every local node (a purely local operation that gives halo
+    // nodes the owner's values); inside a step only owned nodes are touched
+    const int vb0 = all_local_nodes ? 0 : o.o0, vb1 = all_local_nodes ? nn : o.o1;
     int bc_z0 = p.vbc_types[4], bc_z1 = p.vbc_types[5];
     const double bc_vz0 = p.vbc_values[4], bc_vz1 = p.vbc_values[5];
     if (o.time > p.vbc_val_z1_loading_period) bc_z1 = 0;
@@ -1195,7 +1210,7 @@ void apply_vbcs(des_oracle &o)
     };
 
     #pragma omp parallel for
-    for (int i = 0; i < nn; ++i) {
+    for (int i = vb0; i < vb1; ++i) {
         unsigned flag = o.bcflag[i];
         if (!(flag & BOUND_ANY)) continue;
         double v[3] = {o.vel[i], o.vel[nn+i], o.vel[2*nn+i]};
@@ -1292,7 +1307,7 @@ void update_coordinate(des_oracle &o)
 {
     const int nn = o.nn;
     #pragma omp parallel for
-    for (int i = 0; i < nn; ++i)
+    for (int i = o.o0; i < o.o1; ++i)
         for (int j = 0; j < ND; ++j)
             o.coord[j*nn+i] += o.vel[j*nn+i] * o.dt;
 }
@@ -1338,6 +1353,7 @@ void simple_diffusion(des_oracle &o)
 
     for (int i = 0; i < o.ntop; ++i) {
         int n = o.top_nodes[i];
+        if (n < o.o0 || n >= o.o1) continue;
         for (int j = o.ssup_idx[i]; j < o.ssup_idx[i+1]; ++j) {
             int k = o.ssup_arr[j];
             o.total_dx[n] += o.etmp[k];
@@ -1353,6 +1369,7 @@ void simple_diffusion(des_oracle &o)
 
     for (int i = 0; i < o.ntop; ++i) {
         int n = o.top_nodes[i];
+        if (n < o.o0 || n >= o.o1) continue;
         double conv = o.p.surface_diffusivity * o.dt * o.total_slope[n] / o.total_dx[n];
         o.dh[i] -= conv;
     }
@@ -1379,6 +1396,7 @@ void correct_surface_element(des_oracle &o)
     }
     for (int n = 0; n < o.ntop; n++) {
         int nt = o.top_nodes[n];
+        if (nt < o.o0 || nt >= o.o1) continue;
         double acc = 0.;
         for (int k = o.sup_idx[nt]; k < o.sup_idx[nt+1]; ++k)
             acc += o.volume[o.sup_arr[k]];
@@ -1386,8 +1404,9 @@ void correct_surface_element(des_oracle &o)
     }
 }
 
-// bc.cxx:1709-1872 (THREED; marker corrections are host-side and out of scope)
-void surface_processes(des_oracle &o)
+// bc.cxx:1709-1872 (THREED; marker corrections are host-side and out of scope), first half:
+// everything that produces nodal values other ranks need (dh, surface coordinates)
+void surface_processes_a(des_oracle &o)
 {
     const int nn = o.nn;
     for (int i = 0; i < o.ntop; i++) o.dh[i] = 0.;
@@ -1400,9 +1419,18 @@ void surface_processes(des_oracle &o)
 
     for (int i = 0; i < o.ntop; i++) {
         int nt = o.top_nodes[i];
+        if (nt < o.o0 || nt >= o.o1) continue;
         o.coord[2*nn + nt] += o.dh[i];
         o.dhacc[nt] += o.dh[i];
+        o.dh_n[nt] = o.dh[i];
     }
+}
+
+// second half, after the halo exchange delivered dh and coordinates of halo nodes
+void surface_processes_b(des_oracle &o)
+{
+    const int nn = o.nn;
+    for (int i = 0; i < o.ntop; i++) o.dh[i] = o.dh_n[o.top_nodes[i]];
     for (int i = 0; i < o.etop; i++) {
         double dh_e = 0.;
         for (int j = 0; j < ND; j++)
@@ -1456,7 +1484,7 @@ void compute_mass(des_oracle &o)
         o.tmp_result[4 * ne + e] = ym;
     }
     #pragma omp parallel for
-    for (int n = 0; n < o.nn; n++) {
+    for (int n = o.o0; n < o.o1; n++) {
         double vn = 0, ms = 0, tms = 0, yms = 0;
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k) {
             const int e = o.sup_arr[k];
@@ -1471,10 +1499,10 @@ void compute_mass(des_oracle &o)
 }
 
 // dynearthsol.cxx:448-493
-void update_mesh(des_oracle &o)
+
+void update_mesh_b(des_oracle &o)
 {
-    update_coordinate(o);
-    surface_processes(o);
+    surface_processes_b(o);
     o.volume.swap(o.volume_old);
     compute_volume(o, o.volume);
     refresh_elem_cache(o);
@@ -1517,16 +1545,16 @@ void rotate_stress(des_oracle &o)
     }
 }
 
-// geometry.cxx:1480-1647 (use_global_velocity_scaling == false, no hydraulics)
-double compute_dt(des_oracle &o)
+// geometry.cxx:1480-1647 (use_global_velocity_scaling == false, no hydraulics).
+// The element reduction (1513-1593) gives six partial values; in a decomposed run they are
+// min-reduced over the ranks before the tail (1597-1646) turns them into dt.
+void compute_dt_partials(des_oracle &o)
 {
     const des_params &p = o.p;
-    if (p.fixed_dt != 0) return p.fixed_dt;
     const int ne = o.ne, nn = o.nn;
     Mat mat(o);
     double dt_maxwell = std::numeric_limits<double>::max();
     double dt_diffusion = std::numeric_limits<double>::max();
-    double dt_hydro_diffusion = std::numeric_limits<double>::max();
     double minl = std::numeric_limits<double>::max();
     double global_max_vem = 0.0;
     double global_dt_min = std::numeric_limits<double>::max();
@@ -1556,7 +1584,17 @@ double compute_dt(des_oracle &o)
         minl = std::min(minl, minh);
         global_dt_min = std::min(global_dt_min, minh / std::sqrt(mat.shearm(e) / mat.rho(e)) / 5.0);
     }
+    o.dt_part[0] = minl; o.dt_part[1] = dt_maxwell; o.dt_part[2] = dt_diffusion;
+    o.dt_part[3] = global_dt_min; o.dt_part[4] = -global_max_vem; o.dt_part[5] = -o.max_surf_vel;
+}
 
+double compute_dt_finalize(des_oracle &o)
+{
+    const des_params &p = o.p;
+    const double minl = o.dt_part[0], dt_maxwell = o.dt_part[1], dt_diffusion = o.dt_part[2];
+    const double dt_hydro_diffusion = std::numeric_limits<double>::max();
+    double global_max_vem = -o.dt_part[4];
+    o.max_surf_vel = -o.dt_part[5];
     double max_vbc_val;
     if (p.characteristic_speed == 0) {
         max_vbc_val = p.max_vbc_val;
@@ -1567,7 +1605,7 @@ double compute_dt(des_oracle &o)
 
     global_max_vem = std::max(global_max_vem, p.max_vbc_val);
     o.max_global_vel_mag = global_max_vem;
-    o.global_dt_min = global_dt_min;
+    o.global_dt_min = o.dt_part[3];
 
     double dt_advection = 0.5 * minl / max_vbc_val;
     double dt_elastic = p.is_quasi_static
@@ -1576,37 +1614,71 @@ double compute_dt(des_oracle &o)
 
     double dt = std::min(std::min(std::min(dt_elastic, dt_maxwell), std::min(dt_advection, dt_diffusion)),
                          dt_hydro_diffusion) * p.dt_fraction;
+    if (p.fixed_dt != 0) dt = p.fixed_dt;               // geometry.cxx:1487
     if (dt <= 0) o.status = DES_ERR_RUNTIME_NAN;
     return dt;
 }
 
-// one pass of dynearthsol.cxx:768-894
-void one_step(des_oracle &o)
+double compute_dt(des_oracle &o)
+{
+    compute_dt_partials(o);
+    return compute_dt_finalize(o);
+}
+
+// One pass of dynearthsol.cxx:768-894 in four phases; a decomposed run exchanges halo values
+// between them (des_params.h: DES_X_*).  phase 4 returns 1 when the dt partials are ready.
+int step_phase(des_oracle &o, int phase)
 {
     const des_params &p = o.p;
-    o.steps++;
-    o.time += o.dt;
-    refresh_elem_cache(o);
-    if (p.has_thermal_diffusion)
-        update_temperature(o);
-    update_strain_rate(o);
-    compute_dvoldt(o);
-    compute_edvoldt(o);
-    update_stress(o);
-    if (p.is_using_mixed_stress)
-        NMD_stress(o);
-    update_force(o);
-    update_velocity(o);
-    o.l2_residual = calculate_residual_force(o);
-    apply_vbcs(o);
-    if (p.has_moving_mesh)
-        update_mesh(o);
-    if (p.rheol_type & DES_RH_ELASTIC)
-        rotate_stress(o);
-    if (o.steps % 10 == 0) {
+    switch (phase) {
+    case 0:
+        o.steps++;
+        o.time += o.dt;
         refresh_elem_cache(o);
-        o.dt = compute_dt(o);
+        if (p.has_thermal_diffusion)
+            update_temperature(o);
+        update_strain_rate(o);
+        compute_dvoldt(o);
+        return 0;                                   // -> exchange DES_X_TEMP_NTMP
+    case 1:
+        compute_edvoldt(o);
+        update_stress(o);
+        if (p.is_using_mixed_stress)
+            NMD_stress_gather(o);
+        return 0;                                   // -> exchange DES_X_NTMP
+    case 2:
+        if (p.is_using_mixed_stress)
+            NMD_stress_apply(o);
+        update_force(o);
+        update_velocity(o);
+        o.l2_residual = calculate_residual_force(o);
+        apply_vbcs(o);
+        if (p.has_moving_mesh)
+            update_coordinate(o);
+        return 0;                                   // -> exchange DES_X_VEL_COORD
+    case 3:
+        if (p.has_moving_mesh)
+            surface_processes_a(o);
+        return 0;                                   // -> exchange DES_X_SURFACE (diffusion only)
+    case 4:
+        if (p.has_moving_mesh)
+            update_mesh_b(o);
+        if (p.rheol_type & DES_RH_ELASTIC)
+            rotate_stress(o);
+        if (o.steps % 10 == 0) {
+            refresh_elem_cache(o);
+            compute_dt_partials(o);
+            return 1;                               // -> min-reduce dt_part, then dt finalize
+        }
+        return 0;
     }
+    return 0;
+}
+
+void one_step(des_oracle &o)
+{
+    for (int ph = 0; ph < 4; ++ph) step_phase(o, ph);
+    if (step_phase(o, 4)) o.dt = compute_dt_finalize(o);
 }
 
 template <typename T>
@@ -1696,6 +1768,9 @@ des_oracle *des_oracle_create(const des_params *params, const des_mesh *mesh)
     o.elemmarkers.assign((size_t)ne * params->nmat, 0);
     o.etmp_int.assign((size_t)ne, -1);
     o.dh.assign((size_t)o.ntop, 0.0);
+    o.dh_n.assign((size_t)nn, 0.0);
+    o.o0 = 0; o.o1 = nn; o.nn_global = nn; o.l2_part = 0;
+    for (int i = 0; i < 6; ++i) o.dt_part[i] = 0;
     o.edvacc_surf.assign((size_t)o.etop, 0.0);
     o.markers_dirty = true;
 
@@ -1749,7 +1824,7 @@ int des_oracle_init_geometry(des_oracle *h)
     refresh_elem_cache(*h);
     compute_volume(*h, h->volume);
     h->volume_old = h->volume;
-    apply_vbcs(*h);
+    apply_vbcs(*h, true);
     compute_mass(*h);
     return DES_OK;
 }
@@ -1785,6 +1860,63 @@ int des_oracle_check_nan(des_oracle *h, long long *n_nan)
     if (n_nan) *n_nan = n;
     return n ? DES_ERR_RUNTIME_NAN : DES_OK;
 }
+
+// ---- domain decomposition hooks (tests drive the exchanges with torch.distributed/gloo) ----
+int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global)
+{
+    if (owned_begin < 0 || owned_end > h->nn || owned_begin > owned_end) return DES_ERR_INTERNAL;
+    h->o0 = owned_begin; h->o1 = owned_end; h->nn_global = nnode_global;
+    return DES_OK;
+}
+
+int des_oracle_phase(des_oracle *h, int phase) { return step_phase(*h, phase); }
+
+// nodal values of exchange `kind` for the local nodes idx[0..n): buf[i*width + c]
+int des_oracle_halo_pack(des_oracle *h, int kind, const int *idx, int n, double *buf)
+{
+    const int nn = h->nn;
+    for (int i = 0; i < n; ++i) {
+        const int k = idx[i];
+        if (kind == DES_X_TEMP_NTMP) { buf[2*i] = h->temperature[k]; buf[2*i+1] = h->ntmp[k]; }
+        else if (kind == DES_X_NTMP) { buf[i] = h->ntmp[k]; }
+        else if (kind == DES_X_VEL_COORD) {
+            for (int d = 0; d < 3; ++d) { buf[6*i+d] = h->vel[d*nn+k]; buf[6*i+3+d] = h->coord[d*nn+k]; }
+        } else { buf[2*i] = h->coord[2*nn+k]; buf[2*i+1] = h->dh_n[k]; }
+    }
+    return DES_OK;
+}
+
+int des_oracle_halo_unpack(des_oracle *h, int kind, const int *idx, int n, const double *buf)
+{
+    const int nn = h->nn;
+    for (int i = 0; i < n; ++i) {
+        const int k = idx[i];
+        if (kind == DES_X_TEMP_NTMP) { h->temperature[k] = buf[2*i]; h->ntmp[k] = buf[2*i+1]; }
+        else if (kind == DES_X_NTMP) { h->ntmp[k] = buf[i]; }
+        else if (kind == DES_X_VEL_COORD) {
+            for (int d = 0; d < 3; ++d) { h->vel[d*nn+k] = buf[6*i+d]; h->coord[d*nn+k] = buf[6*i+3+d]; }
+        } else { h->coord[2*nn+k] = buf[2*i]; h->dh_n[k] = buf[2*i+1]; }
+    }
+    return DES_OK;
+}
+
+// compute_dt across ranks: partials out (6 doubles, all to be MIN-reduced), reduced values in
+int des_oracle_dt_partials(des_oracle *h, double out[6], int recompute)
+{
+    if (recompute) { refresh_elem_cache(*h); compute_dt_partials(*h); }
+    for (int i = 0; i < 6; ++i) out[i] = h->dt_part[i];
+    return DES_OK;
+}
+
+int des_oracle_dt_finalize(des_oracle *h, const double in[6], double *dt)
+{
+    for (int i = 0; i < 6; ++i) h->dt_part[i] = in[i];
+    h->dt = compute_dt_finalize(*h);
+    if (dt) *dt = h->dt;
+    return h->dt > 0 ? DES_OK : DES_ERR_RUNTIME_NAN;
+}
+
+double des_oracle_l2_partial(des_oracle *h) { return h->l2_part; }
 
 int des_oracle_threads(void)
 {

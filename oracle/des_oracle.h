@@ -25,6 +25,15 @@ int des_oracle_init_geometry(des_oracle *h);
 int des_oracle_compute_dt(des_oracle *h, double *dt);
 int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out);
 int des_oracle_check_nan(des_oracle *h, long long *n_nan);
+/* domain decomposition: owned node range, phased stepping (0..3, halo exchanges in between --
+ * DES_X_* in des_params.h), nodal pack/unpack by local index list, compute_dt across ranks */
+int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global);
+int des_oracle_phase(des_oracle *h, int phase);
+int des_oracle_halo_pack(des_oracle *h, int kind, const int *idx, int n, double *buf);
+int des_oracle_halo_unpack(des_oracle *h, int kind, const int *idx, int n, const double *buf);
+int des_oracle_dt_partials(des_oracle *h, double out[6], int recompute);
+int des_oracle_dt_finalize(des_oracle *h, const double in[6], double *dt);
+double des_oracle_l2_partial(des_oracle *h);
 /* number of OpenMP threads the oracle loops run on (1 unless built with -fopenmp) */
 int des_oracle_threads(void);
 

@@ -1,0 +1,125 @@
+"""Domain decomposition on the CPU: the slab partition (host library), the halo lists and the
+four-phase step with exchanges, checked with the oracle against an undecomposed run.
+(a) several ranks in one process (loopback); (b) world_size-2 gloo over torch.distributed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cfgs
+import dynearthsol_amd as des
+from dynearthsol_amd.decomp import Partition, PhasedStepper, init_rank, run_loopback, LoopbackComm, TorchComm, assemble
+from oracle_binding import OracleEngine
+
+NODE_FIELDS = (("COORD", 3), ("VEL", 3), ("TEMPERATURE", 1), ("MASS", 1), ("VOLUME_N", 1), ("FORCE", 3))
+ELEM_FIELDS = (("STRESS", 6), ("STRAIN", 6), ("STRAIN_RATE", 6), ("PLSTRAIN", 1), ("VISCOSITY", 1), ("VOLUME", 1))
+
+
+class _LocalMeshHost:
+    """Duck-typed host for OracleEngine(host): the engine only needs .params and .mesh."""
+    def __init__(self, part):
+        self.params, self.mesh, self._keep = part.params, part.mesh, part
+
+
+def build(kw, nranks, overrides=None):
+    host = des.Host(cfg_text=cfgs.make(**kw), overrides=overrides)
+    parts = [Partition(host, nranks, r) for r in range(nranks)]
+    return host, parts
+
+
+def test_partition_covers_the_mesh_exactly():
+    host, parts = build(cfgs.EP, 3)
+    owned = np.concatenate([p.l2g_node[p.owned[0]:p.owned[1]] for p in parts])
+    assert np.array_equal(np.sort(owned), np.arange(host.nnode))            # every node owned once
+    assert set(np.concatenate([p.l2g_elem for p in parts])) == set(range(host.nelem))
+    conn = host.array("connectivity").reshape(4, -1)
+    for p in parts:
+        a, b = p.node_ranges[p.rank], p.node_ranges[p.rank + 1]
+        # the local elements are exactly the supports of the owned nodes
+        touches = ((conn >= a) & (conn < b)).any(axis=0)
+        assert np.array_equal(np.nonzero(touches)[0], p.l2g_elem)
+        assert np.all(np.diff(p.l2g_node) > 0) and np.all(np.diff(p.l2g_elem) > 0)   # global order kept
+        # send list of r towards q == recv list of q from r, as GLOBAL ids
+        for q, sidx in zip(p.nbr_rank, p.send_idx):
+            other = parts[q]
+            ridx = other.recv_idx[other.nbr_rank.index(p.rank)]
+            assert np.array_equal(p.l2g_node[sidx], other.l2g_node[ridx])
+        halo = np.concatenate(p.recv_idx) if p.recv_idx else np.zeros(0, int)
+        non_owned = np.setdiff1d(np.arange(p.nnode), np.arange(p.owned[0], p.owned[1]))
+        assert np.array_equal(np.sort(halo), non_owned)
+    # load balance: element work within 15 %
+    w = [p.nelem for p in parts]
+    assert max(w) < 1.15 * min(w) + 200
+
+
+@pytest.mark.parametrize("name,kw,nranks", [
+    ("ep_2", cfgs.EP, 2), ("ep_3", cfgs.EP, 3), ("evp_4", cfgs.EVP, 4), ("yield_2", cfgs.YIELD, 2),
+    ("evp_2mat_3", dict(cfgs.EVP, nmat=2), 3),
+])
+def test_decomposed_oracle_is_bit_identical_to_one_rank(name, kw, nranks):
+    host, parts = build(kw, nranks)
+    ref = OracleEngine(host)
+    dt_ref = ref.init_from_host(host)
+    engines = [OracleEngine(_LocalMeshHost(p)) for p in parts]
+    steppers = [PhasedStepper(e, p, None) for e, p in zip(engines, parts)]
+    comm = LoopbackComm(steppers)
+    for e, p in zip(engines, parts):
+        e.set_halo(p)
+    # init(): same order as EngineBase.init_from_host, then the first compute_dt across ranks
+    class _C:                                         # reduce_dt is collective: do it for all at once below
+        def reduce_dt(self, engine, recompute): return None
+    for e, p in zip(engines, parts):
+        init_rank(e, p, _C())
+    dts = comm.reduce_dt_all(recompute=True)
+    assert all(d == dt_ref for d in dts)
+    nsteps = 30
+    ref.step(nsteps)
+    run_loopback(steppers, nsteps)
+    for f, c in NODE_FIELDS:
+        got = assemble(parts, [e.download(f) for e in engines], c, host.nnode, "node")
+        assert np.array_equal(got, ref.download(f)), f
+    for f, c in ELEM_FIELDS:
+        got = assemble(parts, [e.download(f) for e in engines], c, host.nelem, "elem")
+        assert np.array_equal(got, ref.download(f)), f
+    assert all(e.step(0).dt == ref.step(0).dt for e in engines)
+
+
+def _gloo_worker(rank, world, port, nsteps, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EVP))
+    part = Partition(host, world, rank)
+    eng = OracleEngine(_LocalMeshHost(part))
+    comm = TorchComm(dist)
+    dt = init_rank(eng, part, comm)
+    PhasedStepper(eng, part, comm).step(nsteps)
+    o0, o1 = part.owned
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dt0=dt, dt=eng.step(0).dt,
+             nodes=part.l2g_node[o0:o1], elems=part.l2g_elem,
+             vel=eng.download("VEL").reshape(3, -1)[:, o0:o1],
+             T=eng.download("TEMPERATURE")[o0:o1], stress=eng.download("STRESS").reshape(6, -1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_gloo_match_one_rank(tmp_path):
+    import torch.multiprocessing as mp
+    nsteps, world = 25, 2
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_gloo_worker, args=(world, port, nsteps, str(tmp_path)), nprocs=world, join=True)
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EVP))
+    ref = OracleEngine(host)
+    dt0 = ref.init_from_host(host)
+    sc = ref.step(nsteps)
+    vel, T, stress = ref.download("VEL").reshape(3, -1), ref.download("TEMPERATURE"), ref.download("STRESS").reshape(6, -1)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert d["dt0"] == dt0 and d["dt"] == sc.dt
+        assert np.array_equal(d["vel"], vel[:, d["nodes"]])
+        assert np.array_equal(d["T"], T[d["nodes"]])
+        assert np.array_equal(d["stress"], stress[:, d["elems"]])
