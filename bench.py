@@ -37,7 +37,7 @@ is_outputting_averaged_fields = no
 [mesh]
 meshing_option = 1
 meshing_elem_shape = 1
-xlength = 400e3
+xlength = {xlen}
 ylength = 20e3
 zlength = 10e3
 resolution = {res}
@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--resolution", type=float, default=400e3 / 560)
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: keep the 1.1M-tet mesh and cut it N ways (default: weak scaling, "
+                         "the box grows N times in x so every GPU keeps 1.1M tets)")
     ap.add_argument("--rheology", default="elasto-visco-plastic",
                     help="diagnostic only: the headline workload is elasto-visco-plastic")
     args = ap.parse_args()
@@ -123,16 +126,36 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+        backend = os.environ.get("DES_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for rehearsals
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend)
 
     import dynearthsol_amd as des
 
-    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution)),
+    # weak scaling: the test-3d-big box is repeated N times along x (same resolution), then cut
+    # into N slabs of contiguous node ids -- every GPU holds ~1.1M tets plus one ghost layer
+    xlen = 400e3 * (1 if args.strong else world)
+    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)),
                     overrides=None if args.rheology == "elasto-visco-plastic" else "mat.rheology_type = %s\n" % args.rheology)
-    dev = des.DeviceEngine(host, device=local_rank)
-    dev.init_from_host(host)
-    ne, nn = host.nelem, host.nnode
+    device = int(os.environ.get("DES_BENCH_DEVICE", local_rank))
+    if world == 1:
+        dev = des.DeviceEngine(host, device=device)
+        dev.init_from_host(host)
+        ne_local = host.nelem
+    else:
+        from dynearthsol_amd.decomp import Partition, init_rank
+
+        class _Comm:          # init only: the first compute_dt goes through the engine's own allreduce
+            def reduce_dt(self, engine, recompute):
+                return engine.compute_dt()
+        part = Partition(host, world, rank)
+        dev = des.DeviceEngine(part, device=device)
+        dev.set_halo(part)
+        dev.comm_init(dist, rank, world)
+        init_rank(dev, part, _Comm())
+        ne_local = part.nelem
+    ne, nn = host.nelem, host.nnode          # global counts: `value` counts every element once
 
     dev.step(args.warmup, want_scalars=False) if args.warmup > 0 else None
     dev.sync()
@@ -151,13 +174,13 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     sc = dev.step(0)
     nan = dev.check_nan()
 
-    value = float(ne) * args.steps * world / wall
+    value = float(ne) * args.steps / wall
     result = {
         "metric": "explicit time-steps/sec x #elements",
         "value": value,
@@ -167,15 +190,16 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * wall / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": "test-3d-big.cfg box 400x20x10 km, " + args.rheology + ", thermal+NMD+surface diffusion on, "
-                        "regular 5-tet mesh %d tets / %d nodes per GPU" % (ne, nn),
-            "nelem": ne, "nnode": nn,
-            "parallelism": "single GPU" if world == 1 else "%d independent replicas (domain decomposition pending)" % world,
+                        "regular 5-tet mesh %d tets / %d nodes in total" % (ne, nn),
+            "nelem": ne, "nnode": nn, "nelem_local_rank0": ne_local,
+            "parallelism": "single GPU" if world == 1 else
+                           "%d slabs of contiguous node ids, one ghost-element layer, RCCL send/recv halo of nodal values" % world,
             "steps_per_s": args.steps / wall,
             "hip_event_ms_per_step": ev_ms / args.steps,
             "nan_entries": nan, "status": sc.status,
@@ -183,9 +207,10 @@ def main():
     }
 
     if rank == 0:
-        bytes_step = dev.algorithmic_bytes_per_step()
+        bytes_step = dev.algorithmic_bytes_per_step() if world == 1 else (
+            dev.algorithmic_bytes_per_step() / max(ne_local, 1) * ne)       # whole job, all ranks
         result["config"]["algorithmic_bytes_per_step"] = bytes_step
-        result["config"]["whole_step_frac_of_hbm_peak"] = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        result["config"]["whole_step_frac_of_hbm_peak"] = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
         roof = None
         if not args.no_profile:
             # per-kernel HIP-event timing on the engine's own stream (separate short run)
@@ -202,7 +227,7 @@ def main():
                 be, bn = KERNEL_BYTES[dom]
                 if dom == "E2_update_stress" and args.rheology == "elasto-visco-plastic":
                     be, bn = be + 24, bn + 8
-                kbytes = be * ne + bn * nn
+                kbytes = be * ne_local + bn * (nn if world == 1 else (part.owned[1] - part.owned[0]))
                 achieved = kbytes / (ms / calls * 1e-3) / 1e9
                 traffic = None
                 tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

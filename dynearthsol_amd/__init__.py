@@ -290,6 +290,7 @@ class DeviceEngine(EngineBase):
     prefix = "des_dev"
 
     def __init__(self, host, device=0):
+        """`host` is a Host (whole mesh) or a decomp.Partition (one rank's local mesh)."""
         lib = load_hip_lib()
         if lib.des_dev_device_count() <= device:
             raise DesError(31, "no HIP device %d visible; the device path has no CPU fallback" % device)
@@ -323,6 +324,24 @@ class DeviceEngine(EngineBase):
 
     def algorithmic_bytes_per_step(self):
         return self._lib.des_dev_algorithmic_bytes_per_step(self._h)
+
+    def comm_init(self, dist, rank, world):
+        """Attach an RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed only
+        carries those 128 bytes; all halo traffic then stays inside the engine."""
+        import torch
+        idbuf = (C.c_ubyte * 128)()
+        if rank == 0:
+            self._lib.des_dev_comm_unique_id.argtypes = [C.c_void_p]
+            self._check(self._lib.des_dev_comm_unique_id(idbuf), "comm_unique_id")
+        t = torch.tensor(list(idbuf), dtype=torch.uint8)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        idbuf = (C.c_ubyte * 128)(*t.cpu().tolist())
+        self._lib.des_dev_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        rc = self._lib.des_dev_comm_init(self._h, world, rank, idbuf)
+        if rc:
+            raise DesError(rc, self._lib.des_dev_last_error().decode())
 
 
 __all__ = ["Host", "DeviceEngine", "EngineBase", "DesError", "DesParams", "DesMesh", "DesScalars",

@@ -36,6 +36,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "des_dev.h"
 #include "des_kernels.hpp"
 
@@ -68,7 +70,7 @@ struct DevClock {
     double dt, time, l2_residual, max_surf_vel, max_global_vel_mag, global_dt_min;
     // compute_dt reduction slots (geometry.cxx:1490-1503)
     double r_minl, r_dt_maxwell, r_dt_diffusion, r_global_dt_min, r_max_vem;
-    double maxdh;
+    double maxdh, l2_sum;
     long long steps;
     int status;
     int pad;
@@ -131,6 +133,16 @@ struct des_dev {
     // bnormals / edges for slanted boundaries
     double *bnormals, *edge_vec; int *edge_slot;
 
+    // domain decomposition (des_halo): owned nodes [o0, o1), halo lists, exchange buffers
+    int o0, o1, nn_global;
+    int nnbr;
+    std::vector<int> nbr_rank, send_ptr, recv_ptr;         // host copies of the list offsets
+    int *d_send_idx, *d_recv_idx;
+    double *d_sendbuf, *d_recvbuf;                         // DES_X_WIDTH_2 doubles per listed node
+    double *d_red;                                         // 8 doubles: dt partials / scalar reductions
+    double *dh_n;                                          // nodal copy of surfinfo.dh
+    ncclComm_t comm;
+    int comm_rank, comm_size;
     bool markers_dirty;
     bool const_mass;                      // quasi-static, one material: nodal mass from volumes alone
     bool pending_c;                       // C part of the last step has been run (always true outside step())
@@ -344,8 +356,12 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
 }
 
 // compute_dt tail (geometry.cxx:1597-1646); one thread
-__global__ void k_dt_finalize(const des_params *p, DevClock *clk)
+__global__ void k_dt_finalize(const des_params *p, DevClock *clk, const double *red)
 {
+    if (red) {          // partials min-reduced over the ranks (k_dt_pack layout)
+        clk->r_minl = red[0]; clk->r_dt_maxwell = red[1]; clk->r_dt_diffusion = red[2];
+        clk->r_global_dt_min = red[3]; clk->r_max_vem = -red[4]; clk->max_surf_vel = -red[5];
+    }
     double dt_maxwell = clk->r_dt_maxwell, dt_diffusion = clk->r_dt_diffusion, minl = clk->r_minl;
     const double dt_hydro_diffusion = DBL_MAX;
     double global_max_vem = clk->r_max_vem;
@@ -407,7 +423,7 @@ __device__ __forceinline__ int lds_slot(int j) { return j + (j >> 3); }
 // is formed from the gathered volume instead of being gathered itself (one LDS plane less).
 template <int FULL, int CONSTM>
 __global__ void __launch_bounds__(DES_BLOCK)
-N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int nblocks,
+N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int o0, int nn, int nblocks,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
      const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp, const double *__restrict__ props, int ne,
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
@@ -416,8 +432,9 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     constexpr int TILE = CONSTM ? DES_TILE_N1C : DES_TILE_N1;
     constexpr int NPL = CONSTM ? 4 : 5;
     __shared__ double lds[NPL][DES_TILE_LDS(TILE)];
+    // nodes [o0, nn) are this rank's owned nodes (the whole mesh on one GPU)
     const int lb = desk::logical_block(nblocks);
-    const int n0 = lb * DES_BLOCK;
+    const int n0 = o0 + lb * DES_BLOCK;
     const int n = n0 + threadIdx.x;
     const double dt = clk->dt;
     if (FULL && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -600,12 +617,12 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
 // ---- N2 --------------------------------------------------------------------------
 // NMD_stress gather (geometry.cxx:302-309)
 __global__ void __launch_bounds__(DES_BLOCK)
-N2_nmd_gather(int nn, int nblocks, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
+N2_nmd_gather(int o0, int nn, int nblocks, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
      const double *__restrict__ etmp2, const double *__restrict__ volume_n, double *__restrict__ ntmp)
 {
     __shared__ double lds[DES_TILE_LDS(DES_TILE_N2)];
     const int TILE = DES_TILE_N2;
-    const int n0 = desk::logical_block(nblocks) * DES_BLOCK;
+    const int n0 = o0 + desk::logical_block(nblocks) * DES_BLOCK;
     const int n = n0 + threadIdx.x;
     if (n0 >= nn) return;
     const int nlast = min(n0 + DES_BLOCK, nn);
@@ -851,7 +868,8 @@ k_apply_vbcs(const des_params *__restrict__ p, const DevClock *__restrict__ clk,
 // (fields.cxx:725-742), residual partial sums (fields.cxx:700-722), apply_vbcs,
 // update_coordinate (fields.cxx:761-784)
 __global__ void __launch_bounds__(DES_BLOCK)
-N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn, int nblocks,
+N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int o0, int nn_own_end,
+     int nn, int nn_global, int nblocks,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
      const double *__restrict__ ftmp, unsigned bc_mask, const int *__restrict__ bcn_idx,
      const int *__restrict__ bcn_ent, const double *__restrict__ bcf_tmp,
@@ -862,14 +880,15 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
 {
     __shared__ double lds[3][DES_TILE_LDS(DES_TILE_N3)];
     __shared__ double red[DES_BLOCK / 64];
+    // owned nodes are [o0, nn_own_end); nn is the local node count (stride of the SoA planes)
     const int lb = desk::logical_block(nblocks);
-    const int n0 = lb * DES_BLOCK;
+    const int n0 = o0 + lb * DES_BLOCK;
     const int n = n0 + threadIdx.x;
-    if (n0 >= nn) return;
-    const int nlast = min(n0 + DES_BLOCK, nn);
+    if (n0 >= nn_own_end) return;
+    const int nlast = min(n0 + DES_BLOCK, nn_own_end);
     const int kb = sup_idx[n0], ke = sup_idx[nlast];
     int r0 = ke, r1 = ke;
-    if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
+    if (n < nn_own_end) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
     for (int t0 = kb; t0 < ke; t0 += DES_TILE_N3) {
         const int tn = min(DES_TILE_N3, ke - t0);
@@ -890,7 +909,7 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
         __syncthreads();
     }
     double l2 = 0.0;
-    if (n < nn) {
+    if (n < nn_own_end) {
         const double dt = clk->dt;
         const unsigned flag = bcflag[n];
         d4 x4 = xt[n];
@@ -946,7 +965,7 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
             fres[(size_t)j*nn + n] = fr[j];
             v[j] += dt * f[j] / m4.w;
         }
-        const double num = (double)nn * 3;
+        const double num = (double)nn_global * 3;
         l2 = fr[0]*fr[0] / num;
         l2 += fr[1]*fr[1] / num;
         l2 += fr[2]*fr[2] / num;
@@ -979,13 +998,13 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
 __global__ void __launch_bounds__(DES_BLOCK)
 k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int diffuse,
      const int *__restrict__ top_nodes, const int *__restrict__ ssup_idx, const int *__restrict__ ssup_arr,
-     const int *__restrict__ conn_surf, int etop, const d4 *__restrict__ xt_in,
-     double *__restrict__ dh, double *__restrict__ dhacc, double *__restrict__ znew)
+     const int *__restrict__ conn_surf, int etop, const d4 *__restrict__ xt_in, int o0, int o1,
+     double *__restrict__ dh, double *__restrict__ dhacc, double *__restrict__ znew, double *__restrict__ dh_n)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     double d = 0.;
-    if (i < ntop) {
-        const int n = top_nodes[i];
+    const int n = (i < ntop) ? top_nodes[i] : -1;
+    if (n >= o0 && n < o1) {                    // owned surface nodes; halo ones arrive by exchange
         if (diffuse) {
             double total_dx = 0., total_slope = 0.;
             for (int j = ssup_idx[i]; j < ssup_idx[i+1]; ++j) {
@@ -1024,6 +1043,7 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
         // is committed by the next launch (k_s3_finalize)
         znew[i] = xt_in[n].z + d;
         dhacc[n] += d;
+        dh_n[n] = d;
     }
     // max |dh| (bc.cxx:1811-1821); max is order-independent
     __shared__ double red[DES_BLOCK / 64];
@@ -1036,32 +1056,38 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
     }
 }
 
-// edvacc_surf update (bc.cxx:1784-1794); the last workgroup of the launch does the
-// end-of-step scalars: l2_residual (fields.cxx:721) and max_surf_vel (bc.cxx:1825)
+// edvacc_surf update (bc.cxx:1784-1794), commit of the surface heights k_s2 computed
+// (bc.cxx:1775), and -- in the last workgroup -- the end-of-step scalars: l2_residual
+// (fields.cxx:721) and max_surf_vel (bc.cxx:1825).  The three kinds of workgroup do not depend on
+// each other (the facet-area term only reads x and y); a decomposed run launches the commit
+// before the surface halo exchange and the rest after it.
 __global__ void __launch_bounds__(DES_BLOCK)
-k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int *__restrict__ ean,
-              const int *__restrict__ conn_surf, d4 *__restrict__ xt, const double *__restrict__ dh,
-              double *__restrict__ edvacc, const double *__restrict__ res_part, int nres,
-              int ntop, int nz_blocks, const int *__restrict__ top_nodes, const double *__restrict__ znew)
+k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int *__restrict__ conn_surf,
+              d4 *__restrict__ xt, const double *__restrict__ dh_n, double *__restrict__ edvacc,
+              const double *__restrict__ res_part, int nres, int ntop, int nz_blocks,
+              const int *__restrict__ top_nodes, const double *__restrict__ znew, int o0, int o1, int do_finalize)
 {
     if ((int)blockIdx.x >= nsurf_blocks && (int)blockIdx.x < nsurf_blocks + nz_blocks) {
-        // commit the surface heights computed by k_s2 (bc.cxx:1775); the facet-area term below
-        // only reads x and y, so the two kinds of workgroup do not depend on each other
         const int i = ((int)blockIdx.x - nsurf_blocks) * DES_BLOCK + threadIdx.x;
-        if (i < ntop) xt[top_nodes[i]].z = znew[i];
+        if (i < ntop) {
+            const int n = top_nodes[i];
+            if (n >= o0 && n < o1) xt[n].z = znew[i];
+        }
         return;
     }
     if ((int)blockIdx.x < nsurf_blocks) {
         const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
         if (i >= etop) return;
+        const int na = conn_surf[i], nb = conn_surf[(size_t)etop + i], nc = conn_surf[(size_t)2*etop + i];
         double dh_e = 0.;
-        for (int j = 0; j < 3; j++) dh_e += dh[ean[(size_t)j*etop + i]];
-        const d4 a = xt[conn_surf[i]], b = xt[conn_surf[(size_t)etop + i]], c = xt[conn_surf[(size_t)2*etop + i]];
+        dh_e += dh_n[na]; dh_e += dh_n[nb]; dh_e += dh_n[nc];
+        const d4 a = xt[na], b = xt[nb], c = xt[nc];
         double ab0 = b.x - a.x, ab1 = b.y - a.y, ac0 = c.x - a.x, ac1 = c.y - a.y;
         double base = fabs(ab0*ac1 - ab1*ac0) / 2;           // triangle_area2d, geometry.cxx:59-73
         edvacc[i] += dh_e * base / 3;
         return;
     }
+    if (!do_finalize) return;
     __shared__ double red[DES_BLOCK];
     double t = 0;
     for (int i = threadIdx.x; i < nres; i += DES_BLOCK) t += res_part[i];
@@ -1072,9 +1098,50 @@ k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        clk->l2_sum = red[0];
         clk->l2_residual = sqrt(red[0]);
         clk->max_surf_vel = clk->maxdh / clk->dt;
     }
+}
+
+// ---- halo exchange ---------------------------------------------------------------
+// nodal values of exchange `kind` (des_params.h DES_X_*) for the local nodes idx[0..n)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_halo_pack(int kind, int n, const int *__restrict__ idx, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
+            const double *__restrict__ ntmp, const double *__restrict__ dh_n, double *__restrict__ buf)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int k = idx[i];
+    if (kind == DES_X_TEMP_NTMP) { buf[2*i] = xt[k].w; buf[2*i+1] = ntmp[k]; }
+    else if (kind == DES_X_NTMP) { buf[i] = ntmp[k]; }
+    else if (kind == DES_X_VEL_COORD) {
+        const d4 v = vm[k], x = xt[k];
+        buf[6*i] = v.x; buf[6*i+1] = v.y; buf[6*i+2] = v.z; buf[6*i+3] = x.x; buf[6*i+4] = x.y; buf[6*i+5] = x.z;
+    } else { buf[2*i] = xt[k].z; buf[2*i+1] = dh_n[k]; }
+}
+
+__global__ void __launch_bounds__(DES_BLOCK)
+k_halo_unpack(int kind, int n, const int *__restrict__ idx, const double *__restrict__ buf, d4 *__restrict__ xt,
+              d4 *__restrict__ vm, double *__restrict__ ntmp, double *__restrict__ dh_n)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int k = idx[i];
+    if (kind == DES_X_TEMP_NTMP) { xt[k].w = buf[2*i]; ntmp[k] = buf[2*i+1]; }
+    else if (kind == DES_X_NTMP) { ntmp[k] = buf[i]; }
+    else if (kind == DES_X_VEL_COORD) {
+        d4 v = vm[k], x = xt[k];
+        v.x = buf[6*i]; v.y = buf[6*i+1]; v.z = buf[6*i+2]; x.x = buf[6*i+3]; x.y = buf[6*i+4]; x.z = buf[6*i+5];
+        vm[k] = v; xt[k] = x;
+    } else { xt[k].z = buf[2*i]; dh_n[k] = buf[2*i+1]; }
+}
+
+// compute_dt partials of this rank, all arranged for a MIN reduction across ranks
+__global__ void k_dt_pack(const DevClock *clk, double *red)
+{
+    red[0] = clk->r_minl; red[1] = clk->r_dt_maxwell; red[2] = clk->r_dt_diffusion;
+    red[3] = clk->r_global_dt_min; red[4] = -clk->r_max_vem; red[5] = -clk->max_surf_vel;
 }
 
 __global__ void k_dhacc_reset(int ntop, const int *__restrict__ top_nodes, double *__restrict__ dhacc)
@@ -1150,85 +1217,137 @@ void launch_e1(des_dev *h)
 // compute_mass gather alone (N1 without the temperature / dvoldt parts)
 void launch_mass_gather(des_dev *h)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(nblk8(h->nn)), dim3(DES_BLOCK), 0, h->stream,
-                       h->d_p, h->d_clk, h->nn, nblk(h->nn), h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
+    const int nown = h->o1 - h->o0;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream,
+                       h->d_p, h->d_clk, h->o0, h->o1, nblk(nown), h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
                        h->props, h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
-void launch_dt_finalize(des_dev *h)
+void launch_dt_finalize(des_dev *h, const double *red)
 {
     Launch l(h, K_DTFIN);
-    hipLaunchKernelGGL(k_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk);
+    hipLaunchKernelGGL(k_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk, red);
 }
 
-// surface_processes (bc.cxx:1709-1872) as far as the device state is concerned
-void launch_surface(des_dev *h, long long step_no)
+inline bool surface_diffusion_on(const des_dev *h)
 {
-    const int diffuse = h->p.surface_process_option == 1;
+    return h->p.has_moving_mesh && h->p.surface_process_option == 1 && h->ntop > 0;
+}
+
+// ---- passes of one step, in launch order -----------------------------------------
+void launch_n1(des_dev *h)
+{
+    Launch l(h, K_N1);
+    const int nown = h->o1 - h->o0, nbn = nblk(nown);
+    if (h->const_mass)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream,
+                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+                           h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream,
+                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+                           h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+}
+
+void launch_e2(des_dev *h)
+{
+    Launch l(h, K_E2);
+    const int ne = h->ne;
+    hipLaunchKernelGGL(E2_update_stress, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, ne, nblk(ne),
+                       h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->volume_old, h->stress,
+                       h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
+                       h->etmp2);
+}
+
+void launch_n2(des_dev *h)
+{
+    Launch l(h, K_N2);
+    const int nown = h->o1 - h->o0;
+    hipLaunchKernelGGL(N2_nmd_gather, dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream, h->o0, h->o1, nblk(nown), h->sup_idx,
+                       h->sup_pack, h->etmp2, h->volume_n, h->ntmp);
+}
+
+void launch_e3(des_dev *h)
+{
+    Launch l(h, K_E3);
+    const int ne = h->ne, nbe8 = nblk8(ne);
+    hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nblk(h->nbcf)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nblk(ne), nbe8,
+                       h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp,
+                       h->nbcf, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
+}
+
+void launch_n3(des_dev *h)
+{
+    Launch l(h, K_N3);
+    const int nown = h->o1 - h->o0;
+    hipLaunchKernelGGL(N3_force_velocity_coord, dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->o0, h->o1,
+                       h->nn, h->nn_global, nblk(nown), h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx,
+                       h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
+                       h->force, h->fres, h->res_part);
+}
+
+// surface_processes (bc.cxx:1709-1872) as far as the device state is concerned, first part:
+// diffusion of the owned surface nodes
+void launch_s2(des_dev *h, long long step_no)
+{
     if (h->ntop > 0) {
         Launch l(h, K_S2);
         hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
-                           diffuse, h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf, h->etop, h->xt,
-                           h->dh, h->dhacc, h->znew);
+                           (int)(h->p.surface_process_option == 1), h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf,
+                           h->etop, h->xt, h->o0, h->o1, h->dh, h->dhacc, h->znew, h->dh_n);
     }
     if (h->ntop > 0 && step_no != 0 && step_no % h->p.quality_check_step_interval == 0)
         hipLaunchKernelGGL(k_dhacc_reset, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->ntop,
                            h->top_nodes, h->dhacc);
 }
 
-// the six passes between two E1 launches
-void launch_step_body(des_dev *h, long long step_no)
+// commit of the new surface heights / edvacc_surf / end-of-step scalars (k_s3_finalize)
+void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
 {
-    const int nn = h->nn, ne = h->ne;
-    const int nbn = nblk(nn), nbe = nblk(ne);
-    {
-        Launch l(h, K_N1);
-        if (h->const_mass)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream,
-                               h->d_p, h->d_clk, nn, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne,
-                               h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream,
-                               h->d_p, h->d_clk, nn, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props, ne,
-                               h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+    Launch l(h, K_S3);
+    const bool surf = h->p.has_moving_mesh && h->ntop > 0;
+    const int nsb = (edvacc && surface_diffusion_on(h)) ? nblk(h->etop) : 0;
+    const int nzb = (commit && surf) ? nblk(h->ntop) : 0;
+    const int nown = h->o1 - h->o0;
+    hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + nzb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb,
+                       h->conn_surf, h->xt, h->dh_n, h->edvacc, h->res_part, nblk(nown), h->ntop, nzb, h->top_nodes,
+                       h->znew, h->o0, h->o1, (int)finalize);
+}
+
+// ---- halo exchange through RCCL on the engine's stream ---------------------------
+const int kXWidth[DES_X_COUNT] = {DES_X_WIDTH_0, DES_X_WIDTH_1, DES_X_WIDTH_2, DES_X_WIDTH_3};
+
+int exchange(des_dev *h, int kind)
+{
+    if (h->nnbr == 0) return DES_OK;
+    if (!h->comm) { g_last_error = "decomposed engine without a communicator: call des_dev_comm_init"; return DES_ERR_INTERNAL; }
+    const int w = kXWidth[kind];
+    const int nsend = h->send_ptr[h->nnbr], nrecv = h->recv_ptr[h->nnbr];
+    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(nsend)), dim3(DES_BLOCK), 0, h->stream, kind, nsend, h->d_send_idx, h->xt, h->vm,
+                       h->ntmp, h->dh_n, h->d_sendbuf);
+    ncclGroupStart();
+    for (int q = 0; q < h->nnbr; ++q) {
+        ncclSend(h->d_sendbuf + (size_t)h->send_ptr[q] * w, (size_t)(h->send_ptr[q+1] - h->send_ptr[q]) * w, ncclDouble,
+                 h->nbr_rank[q], h->comm, h->stream);
+        ncclRecv(h->d_recvbuf + (size_t)h->recv_ptr[q] * w, (size_t)(h->recv_ptr[q+1] - h->recv_ptr[q]) * w, ncclDouble,
+                 h->nbr_rank[q], h->comm, h->stream);
     }
-    {
-        Launch l(h, K_E2);
-        hipLaunchKernelGGL(E2_update_stress, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, ne, nbe,
-                           h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->volume_old, h->stress,
-                           h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
-                           h->etmp2);
-    }
-    if (h->p.is_using_mixed_stress) {
-        Launch l(h, K_N2);
-        hipLaunchKernelGGL(N2_nmd_gather, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, nn, nbn, h->sup_idx, h->sup_pack,
-                           h->etmp2, h->volume_n, h->ntmp);
-    }
-    {
-        Launch l(h, K_E3);
-        const int nbe8 = nblk8(ne);
-        hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nblk(h->nbcf)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nbe, nbe8,
-                           h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp,
-                           h->nbcf, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
-    }
-    {
-        Launch l(h, K_N3);
-        hipLaunchKernelGGL(N3_force_velocity_coord, dim3(nblk8(nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, nn, nbn,
-                           h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx, h->bcn_ent,
-                           h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
-                           h->force, h->fres, h->res_part);
-    }
-    if (h->p.has_moving_mesh)
-        launch_surface(h, step_no);
-    {
-        // edvacc_surf (surface diffusion only) + end-of-step scalars in one launch
-        Launch l(h, K_S3);
-        const bool surf = h->p.has_moving_mesh && h->ntop > 0;
-        const int nsb = (surf && h->p.surface_process_option == 1) ? nblk(h->etop) : 0;
-        const int nzb = surf ? nblk(h->ntop) : 0;
-        hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + nzb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb, h->ean,
-                           h->conn_surf, h->xt, h->dh, h->edvacc, h->res_part, nbn, h->ntop, nzb, h->top_nodes, h->znew);
-    }
+    ncclResult_t r = ncclGroupEnd();
+    if (r != ncclSuccess) { g_last_error = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
+    hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(nrecv)), dim3(DES_BLOCK), 0, h->stream, kind, nrecv, h->d_recv_idx, h->d_recvbuf,
+                       h->xt, h->vm, h->ntmp, h->dh_n);
+    return DES_OK;
+}
+
+// compute_dt across ranks: pack the six partials, MIN-allreduce, finalize
+int reduce_dt(des_dev *h)
+{
+    if (h->comm_size <= 1) { launch_dt_finalize(h, nullptr); return DES_OK; }
+    hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    ncclResult_t r = ncclAllReduce(h->d_red, h->d_red, 6, ncclDouble, ncclMin, h->comm, h->stream);
+    if (r != ncclSuccess) { g_last_error = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
+    launch_dt_finalize(h, h->d_red);
+    return DES_OK;
 }
 
 int sync_clock(des_dev *h)
@@ -1263,9 +1382,11 @@ void des_dev_destroy(des_dev *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     void *ptrs[] = { h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
-        h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->stress, h->strain,
+        h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red,
+        h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->radiogenic, h->markers, h->props, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
@@ -1300,6 +1421,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     h->markers_dirty = true;
     h->pending_c = true;
     h->const_mass = params->is_quasi_static && params->nmat == 1;
+    h->o0 = 0; h->o1 = nn; h->nn_global = nn; h->nnbr = 0; h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
 
 #define CK(x) do { int rc_ = (x); if (rc_ != DES_OK) { *err = rc_; des_dev_destroy(h); return nullptr; } } while (0)
 #define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_last_error = std::string(#x) + ": " + hipGetErrorString(e_); \
@@ -1347,7 +1469,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->xt, (size_t)nn)); CK(dev_alloc(h->vm, (size_t)nn));
     CK(dev_alloc(h->ntmp, (size_t)nn)); CK(dev_alloc(h->volume_n, (size_t)nn)); CK(dev_alloc(h->tmass, (size_t)nn));
     CK(dev_alloc(h->ymass, (size_t)nn)); CK(dev_alloc(h->force, (size_t)3*nn)); CK(dev_alloc(h->fres, (size_t)3*nn));
-    CK(dev_alloc(h->coord0, (size_t)3*nn)); CK(dev_alloc(h->dhacc, (size_t)nn));
+    CK(dev_alloc(h->coord0, (size_t)3*nn)); CK(dev_alloc(h->dhacc, (size_t)nn)); CK(dev_alloc(h->dh_n, (size_t)nn));
+    CK(dev_alloc(h->d_red, 8));
     CK(dev_alloc(h->stress, (size_t)6*ne)); CK(dev_alloc(h->strain, (size_t)6*ne)); CK(dev_alloc(h->strain_rate, (size_t)6*ne));
     CK(dev_alloc(h->plstrain, (size_t)ne)); CK(dev_alloc(h->delta_plstrain, (size_t)ne)); CK(dev_alloc(h->viscosity, (size_t)ne));
     CK(dev_alloc(h->volume, (size_t)ne)); CK(dev_alloc(h->volume_old, (size_t)ne)); CK(dev_alloc(h->dpressure, (size_t)ne));
@@ -1362,6 +1485,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             {h->xt, sizeof(d4)*(size_t)nn}, {h->vm, sizeof(d4)*(size_t)nn}, {h->ntmp, 8*(size_t)nn},
             {h->volume_n, 8*(size_t)nn}, {h->tmass, 8*(size_t)nn}, {h->ymass, 8*(size_t)nn},
             {h->force, 24*(size_t)nn}, {h->fres, 24*(size_t)nn}, {h->coord0, 24*(size_t)nn}, {h->dhacc, 8*(size_t)nn},
+            {h->dh_n, 8*(size_t)nn}, {h->d_red, 64},
             {h->stress, 48*(size_t)ne}, {h->strain, 48*(size_t)ne}, {h->strain_rate, 48*(size_t)ne},
             {h->plstrain, 8*(size_t)ne}, {h->delta_plstrain, 8*(size_t)ne}, {h->volume, 8*(size_t)ne},
             {h->volume_old, 8*(size_t)ne}, {h->dpressure, 8*(size_t)ne}, {h->radiogenic, 8*(size_t)ne},
@@ -1607,7 +1731,8 @@ int des_dev_init_geometry(des_dev *h)
     // volume_old, the second overwrites it)
     launch_e1<MODE_C | MODE_INIT>(h);
     launch_e1<MODE_C | MODE_INIT>(h);
-    // apply_vbcs (dynearthsol.cxx:192)
+    // apply_vbcs (dynearthsol.cxx:192) on every local node: a purely nodal operation that
+    // gives halo nodes the same values their owners compute
     hipLaunchKernelGGL(k_apply_vbcs, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->nn,
                        h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm);
     // compute_mass (dynearthsol.cxx:194)
@@ -1622,52 +1747,225 @@ int des_dev_compute_dt(des_dev *h, double *dt)
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     refresh_props(h);
-    // reduction only: run the geometry part on a scratch copy?  The C part rewrites
-    // volume/volume_old and rotates stress, so use the dedicated reduction mode instead.
     launch_e1<MODE_DT>(h);
-    launch_dt_finalize(h);
-    int rc = sync_clock(h);
+    int rc = reduce_dt(h);
+    if (rc) return rc;
+    rc = sync_clock(h);
     if (rc) return rc;
     if (dt) *dt = h->h_clk->dt;
     return h->h_clk->status;
 }
 
+// One step = five phases with a halo exchange after each of the first four (des_params.h).
+// On one GPU the exchanges vanish and the passes are back to back; the end of step t (E1's
+// C part) stays fused with the start of step t+1 (A part) whenever another step follows.
 int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
 {
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
+    if (!h->p.has_moving_mesh) {
+        g_last_error = "control.has_moving_mesh = no is not offloaded";
+        return DES_ERR_UNSUPPORTED;
+    }
     refresh_props(h);
+    const bool multi = h->nnbr > 0;
+    const bool nmd = h->p.is_using_mixed_stress;
+    int rc;
     for (int i = 0; i < nsteps; ++i) {
         const long long step_no = ++h->steps_host;
         if (i == 0) launch_e1<MODE_A>(h);
-        launch_step_body(h, step_no);
+        launch_n1(h);                                              // phase 0
+        if (multi && (rc = exchange(h, DES_X_TEMP_NTMP))) return rc;
+        launch_e2(h);                                              // phase 1
+        if (nmd) {
+            launch_n2(h);
+            if (multi && (rc = exchange(h, DES_X_NTMP))) return rc;
+        }
+        launch_e3(h);                                              // phase 2
+        launch_n3(h);
+        if (multi && (rc = exchange(h, DES_X_VEL_COORD))) return rc;
+        launch_s2(h, step_no);                                     // phase 3
+        if (multi && surface_diffusion_on(h)) {
+            launch_s3(h, true, false, false);
+            if ((rc = exchange(h, DES_X_SURFACE))) return rc;
+            launch_s3(h, false, true, true);                       // phase 4
+        } else {
+            launch_s3(h, true, true, true);
+        }
         const bool last = (i == nsteps - 1);
         const bool do_dt = (step_no % 10 == 0);
-        if (h->p.has_moving_mesh) {
-            if (last) { if (do_dt) launch_e1<MODE_C | MODE_DT>(h); else launch_e1<MODE_C>(h); }
-            else      { if (do_dt) launch_e1<MODE_C | MODE_A | MODE_DT>(h); else launch_e1<MODE_C | MODE_A>(h); }
-        } else {
-            // no update_mesh: only rotate_stress (+dt); volumes and masses stay as they are
-            g_last_error = "control.has_moving_mesh = no is not offloaded";
-            return DES_ERR_UNSUPPORTED;
-        }
-        if (do_dt) launch_dt_finalize(h);
+        if (last) { if (do_dt) launch_e1<MODE_C | MODE_DT>(h); else launch_e1<MODE_C>(h); }
+        else      { if (do_dt) launch_e1<MODE_C | MODE_A | MODE_DT>(h); else launch_e1<MODE_C | MODE_A>(h); }
+        if (do_dt && (rc = reduce_dt(h))) return rc;
     }
     // compute_mass gather of the last update_mesh, so that volume_n / mass / tmass hold the
     // reference's end-of-step values (inside a multi-step call it is fused into the next N1)
-    launch_mass_gather(h);
+    if (nsteps > 0) launch_mass_gather(h);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
     if (out) {
-        int rc = sync_clock(h);
+        if (h->comm_size > 1) {
+            // l2_residual is a sum over all ranks' owned nodes
+            HIP_OK(hipMemcpyAsync(h->d_red + 6, &h->d_clk->l2_sum, 8, hipMemcpyDeviceToDevice, h->stream));
+            ncclAllReduce(h->d_red + 6, h->d_red + 6, 1, ncclDouble, ncclSum, h->comm, h->stream);
+        }
+        rc = sync_clock(h);
         if (rc) return rc;
         const DevClock &c = *h->h_clk;
         out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
+        if (h->comm_size > 1) {
+            double l2sum = 0;
+            HIP_OK(hipMemcpy(&l2sum, h->d_red + 6, 8, hipMemcpyDeviceToHost));
+            out->l2_residual = std::sqrt(l2sum);
+        }
         out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min;
         out->steps = c.steps; out->status = c.status; out->pad_ = 0;
         return c.status;
     }
     return DES_OK;
+}
+
+// ---- domain decomposition ---------------------------------------------------------
+int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
+{
+    if (!h || !halo) return DES_ERR_INTERNAL;
+    if (halo->owned_begin < 0 || halo->owned_end > h->nn || halo->owned_begin >= halo->owned_end) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    h->o0 = halo->owned_begin; h->o1 = halo->owned_end; h->nn_global = nnode_global;
+    h->nnbr = halo->nnbr;
+    h->nbr_rank.assign(halo->nbr_rank, halo->nbr_rank + halo->nnbr);
+    h->send_ptr.assign(halo->send_ptr, halo->send_ptr + halo->nnbr + 1);
+    h->recv_ptr.assign(halo->recv_ptr, halo->recv_ptr + halo->nnbr + 1);
+    const size_t ns = (size_t)h->send_ptr[h->nnbr], nr = (size_t)h->recv_ptr[h->nnbr];
+    for (void *q : {(void *)h->d_send_idx, (void *)h->d_recv_idx, (void *)h->d_sendbuf, (void *)h->d_recvbuf}) if (q) hipFree(q);
+    int rc;
+    if ((rc = dev_alloc(h->d_send_idx, ns))) return rc;
+    if ((rc = dev_alloc(h->d_recv_idx, nr))) return rc;
+    if ((rc = dev_alloc(h->d_sendbuf, ns * DES_X_WIDTH_2))) return rc;
+    if ((rc = dev_alloc(h->d_recvbuf, nr * DES_X_WIDTH_2))) return rc;
+    if ((rc = dev_upload(h->d_send_idx, halo->send_idx, ns, h->stream))) return rc;
+    if ((rc = dev_upload(h->d_recv_idx, halo->recv_idx, nr, h->stream))) return rc;
+    // the residual partials are indexed by owned-node block
+    if (h->res_part) hipFree(h->res_part);
+    h->n3_blocks = nblk8(h->o1 - h->o0);
+    return dev_alloc(h->res_part, (size_t)h->n3_blocks);
+}
+
+int des_dev_comm_unique_id(unsigned char *id128)
+{
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) { g_last_error = "ncclGetUniqueId failed"; return DES_ERR_RESOURCE; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, 128);
+    return DES_OK;
+}
+
+int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128)
+{
+    if (!h || !id128) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, 128);
+    ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
+    if (r != ncclSuccess) { g_last_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); h->comm = nullptr; return DES_ERR_RESOURCE; }
+    h->comm_rank = rank; h->comm_size = nranks;
+    return DES_OK;
+}
+
+// One phase of a step without any communication: the caller moves the halo values
+// (des_dev_halo_pack / des_dev_halo_unpack) -- used to test the decomposition with several
+// engines on one GPU.  Returns 1 after phase 4 when the compute_dt partials are ready.
+int des_dev_phase(des_dev *h, int phase)
+{
+    if (!h) return -DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    switch (phase) {
+    case 0:
+        refresh_props(h);
+        ++h->steps_host;
+        launch_e1<MODE_A>(h);
+        launch_n1(h);
+        return 0;
+    case 1:
+        launch_e2(h);
+        if (h->p.is_using_mixed_stress) launch_n2(h);
+        return 0;
+    case 2:
+        launch_e3(h);
+        launch_n3(h);
+        return 0;
+    case 3:
+        launch_s2(h, h->steps_host);
+        launch_s3(h, true, false, false);
+        return 0;
+    case 4: {
+        launch_s3(h, false, true, true);
+        const bool do_dt = (h->steps_host % 10 == 0);
+        if (do_dt) launch_e1<MODE_C | MODE_DT>(h); else launch_e1<MODE_C>(h);
+        launch_mass_gather(h);
+        return do_dt ? 1 : 0;
+    }
+    }
+    return -DES_ERR_INTERNAL;
+}
+
+int des_dev_halo_pack(des_dev *h, int kind, const int *idx, int n, double *buf)
+{
+    if (!h || kind < 0 || kind >= DES_X_COUNT) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    if (n == 0) return DES_OK;
+    int *d_idx = nullptr; double *d_buf = nullptr;
+    const size_t w = kXWidth[kind];
+    int rc;
+    if ((rc = dev_alloc(d_idx, (size_t)n))) return rc;
+    if ((rc = dev_alloc(d_buf, (size_t)n * w))) return rc;
+    if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
+    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, kind, n, d_idx, h->xt, h->vm, h->ntmp, h->dh_n, d_buf);
+    HIP_OK(hipMemcpyAsync(buf, d_buf, (size_t)n * w * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    hipFree(d_idx); hipFree(d_buf);
+    return DES_OK;
+}
+
+int des_dev_halo_unpack(des_dev *h, int kind, const int *idx, int n, const double *buf)
+{
+    if (!h || kind < 0 || kind >= DES_X_COUNT) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    if (n == 0) return DES_OK;
+    int *d_idx = nullptr; double *d_buf = nullptr;
+    const size_t w = kXWidth[kind];
+    int rc;
+    if ((rc = dev_alloc(d_idx, (size_t)n))) return rc;
+    if ((rc = dev_alloc(d_buf, (size_t)n * w))) return rc;
+    if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
+    if ((rc = dev_upload(d_buf, buf, (size_t)n * w, h->stream))) return rc;
+    hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, kind, n, d_idx, d_buf, h->xt, h->vm, h->ntmp, h->dh_n);
+    HIP_OK(hipStreamSynchronize(h->stream));
+    hipFree(d_idx); hipFree(d_buf);
+    return DES_OK;
+}
+
+int des_dev_dt_partials(des_dev *h, double out[6], int recompute)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    if (recompute) { refresh_props(h); launch_e1<MODE_DT>(h); }
+    hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    HIP_OK(hipMemcpyAsync(out, h->d_red, 48, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    HIP_OK(hipMemcpyAsync(h->d_red, in, 48, hipMemcpyHostToDevice, h->stream));
+    launch_dt_finalize(h, h->d_red);
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    if (dt) *dt = h->h_clk->dt;
+    return h->h_clk->status;
 }
 
 int des_dev_check_nan(des_dev *h, long long *n_nan)

@@ -91,6 +91,26 @@ int des_dev_profile_read(des_dev *h, int cap, char (*names)[64], double *ms, lon
  * 1420*nelem + 348*nnode with the evp / thermal / NMD variants). */
 double des_dev_algorithmic_bytes_per_step(const des_dev *h);
 
+/* ---- multi-GPU (one process per GPU; new: the reference is single-process) -------------
+ * A rank's engine is created on its LOCAL mesh (des_host_partition) and told which nodes it
+ * owns and which it exchanges (des_halo, des_params.h).  With a communicator attached,
+ * des_dev_step / des_dev_compute_dt exchange halo values with ncclSend/ncclRecv (RCCL) on the
+ * engine's own stream and min-reduce the six compute_dt partials with one ncclAllReduce:
+ * no host synchronisation is added. */
+int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global);
+/* rank 0 creates the 128-byte ncclUniqueId; the caller broadcasts it (e.g. torch.distributed) */
+int des_dev_comm_unique_id(unsigned char *id128);
+int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128);
+
+/* The same step cut into its five phases WITHOUT communication, plus raw access to the halo
+ * values and the compute_dt partials: lets a host harness move the halos itself (tests with
+ * several engines on one GPU; any other transport). */
+int des_dev_phase(des_dev *h, int phase);
+int des_dev_halo_pack(des_dev *h, int kind, const int *idx, int n, double *buf);
+int des_dev_halo_unpack(des_dev *h, int kind, const int *idx, int n, const double *buf);
+int des_dev_dt_partials(des_dev *h, double out[6], int recompute);
+int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt);
+
 const char *des_dev_last_error(void);
 
 #ifdef __cplusplus
