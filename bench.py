@@ -245,6 +245,11 @@ def main():
         cpu_steps = args.cpu_steps
         if world == 1 and cpu_steps != 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
+            # host cores this job may really use: the affinity mask, capped at the GPU box's
+            # per-GPU CPU share (16); must be set before libgomp starts its pool
+            ncores = min(16, len(os.sched_getaffinity(0)))
+            os.environ["OMP_NUM_THREADS"] = str(ncores)
+            os.environ.setdefault("OMP_PROC_BIND", "close")
             from oracle_binding import OracleEngine, load_oracle
             threads = load_oracle(omp=True).des_oracle_threads()
             ora = OracleEngine(host, omp=True)

@@ -417,16 +417,22 @@ __device__ __forceinline__ void viscous(double bulkm, double viscosity, double t
 }
 
 // The Mohr-Coulomb return after the pre-filter said "maybe yielding" (rheology.cxx:363-475).
-// ~0.2 % of the elements get here, so it is out of line to keep the common path lean.
-__device__ __noinline__ double mohr_coulomb_return(double bulkm, double shearm, double amc, double anphi,
-                                                   double anpsi, double hardn, double ten_max, double *s)
+// ~0.2 % of the elements get here, so it is out of line to keep the common path lean.  The
+// stress travels BY VALUE (in registers): passing a pointer to the caller's array would force
+// that array -- the stress every element works on -- into scratch memory for all elements.
+struct Stress7 { double s0, s1, s2, s3, s4, s5, depls; };
+
+__device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm, double amc, double anphi,
+                                                    double anpsi, double hardn, double ten_max, Stress7 io)
 {
+    double s[6] = {io.s0, io.s1, io.s2, io.s3, io.s4, io.s5};
+    io.depls = 0;
     double p[3], v[3][3];
     principal_stresses3(s, p, v);
 
     double fs = p[0] - p[2] * anphi + amc;
     double ft = p[2] - ten_max;
-    if (fs > 0 && ft < 0) return 0;
+    if (fs > 0 && ft < 0) return io;
 
     double pa = sqrt(1 + anphi*anphi) + anphi;
     double ps = ten_max * anphi - amc;
@@ -454,9 +460,10 @@ __device__ __noinline__ double mohr_coulomb_return(double bulkm, double shearm, 
         for (int n = m; n < 3; n++)
             for (int k = 0; k < 3; k++)
                 ss[m][n] += v[m][k] * v[n][k] * p[k];
-    s[0] = ss[0][0]; s[1] = ss[1][1]; s[2] = ss[2][2];
-    s[3] = ss[0][1]; s[4] = ss[0][2]; s[5] = ss[1][2];
-    return depls;
+    io.s0 = ss[0][0]; io.s1 = ss[1][1]; io.s2 = ss[2][2];
+    io.s3 = ss[0][1]; io.s4 = ss[0][2]; io.s5 = ss[1][2];
+    io.depls = depls;
+    return io;
 }
 
 // rheology.cxx:312-484 (THREED)
@@ -492,7 +499,10 @@ __device__ __forceinline__ double elasto_plastic(double bulkm, double shearm, do
         if (pf[0] - pf[2] * anphi + amc > band && pf[2] - ten_max < -band)
             return 0;
     }
-    return mohr_coulomb_return(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, s);
+    Stress7 io = {s[0], s[1], s[2], s[3], s[4], s[5], 0.0};
+    io = mohr_coulomb_return(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, io);
+    s[0] = io.s0; s[1] = io.s1; s[2] = io.s2; s[3] = io.s3; s[4] = io.s4; s[5] = io.s5;
+    return io.depls;
 }
 
 // fields.cxx:791-805

@@ -214,7 +214,7 @@ def test_full_size_mesh_against_the_oracle():
     (evp: 1e-12 after 3 steps), then size-independent properties on the device alone:
     run-to-run reproducibility to the bit and invisibility of the step split."""
     import bench
-    host = des.Host(cfg_text=bench.BENCH_CFG.format(res=repr(400e3 / 560)))
+    host = des.Host(cfg_text=bench.BENCH_CFG.format(res=repr(400e3 / 560), xlen=repr(400e3)))
     assert host.nelem == 1097600 and host.nnode == 244035
     dev, ora = des.DeviceEngine(host), OracleEngine(host, omp=True)
     assert dev.init_from_host(host) == ora.init_from_host(host)
