@@ -258,13 +258,17 @@ void save_mesh_file(const std::string &path, const HostMesh &m)
     if (!ok) throw Error(21, "write failed: " + path);
 }
 
-void load_mesh_file(const std::string &path, HostMesh &m)
+// DESMESH1: a finished mesh (after create_new_mesh).  DESMESH0: the raw output of the
+// reference mesher (oracle/ref_tetmesh) incl. region attributes; returns true for those so
+// the caller finishes the job (discard internal segments, renumber).
+bool load_mesh_file_raw(const std::string &path, HostMesh &m)
 {
     FILE *fp = std::fopen(path.c_str(), "rb");
     if (!fp) throw Error(20, "cannot open mesh file: " + path);
     char magic[8]; int hdr[3];
-    bool ok = std::fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, kMeshMagic, 8) == 0
-              && std::fread(hdr, sizeof(int), 3, fp) == 3;
+    bool ok = std::fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, kMeshMagic, 7) == 0
+              && (magic[7] == '0' || magic[7] == '1') && std::fread(hdr, sizeof(int), 3, fp) == 3;
+    const bool raw = ok && magic[7] == '0';
     if (ok) {
         m.nnode = hdr[0]; m.nelem = hdr[1]; m.nseg = hdr[2];
         m.coord.resize((size_t)3*m.nnode); m.conn.resize((size_t)4*m.nelem);
@@ -274,9 +278,18 @@ void load_mesh_file(const std::string &path, HostMesh &m)
           && std::fread(m.segment.data(), sizeof(int), m.segment.size(), fp) == m.segment.size()
           && std::fread(m.segflag.data(), sizeof(int), m.segflag.size(), fp) == m.segflag.size();
     }
+    m.regattr.assign((size_t)m.nelem, 0.0);
+    if (ok && raw)
+        ok = std::fread(m.regattr.data(), sizeof(double), m.regattr.size(), fp) == m.regattr.size();
     std::fclose(fp);
     if (!ok) throw Error(12, "malformed mesh file: " + path);
-    m.regattr.assign((size_t)m.nelem, 0.0);
+    return raw;
+}
+
+void load_mesh_file(const std::string &path, HostMesh &m)
+{
+    if (load_mesh_file_raw(path, m))
+        throw Error(12, "raw mesher output needs a .cfg to be finished: " + path);
 }
 
 // mesh.cxx:3460-3506
@@ -285,7 +298,12 @@ void create_new_mesh(const Config &cfg, HostMesh &m, const std::string &mesh_fil
     if (!mesh_file.empty()) {
         // a mesh written after create_new_mesh() by the reference mesher (tools/), i.e.
         // already renumbered and with internal segments discarded
-        load_mesh_file(mesh_file, m);
+        if (load_mesh_file_raw(mesh_file, m)) {
+            // raw mesher output: finish as create_new_mesh does (mesh.cxx:3499-3502)
+            if (cfg.b("mesh.is_discarding_internal_segments"))
+                discard_internal_segments(m);
+            renumbering_mesh(cfg, m);
+        }
         return;
     }
     const int opt = cfg.i("mesh.meshing_option");

@@ -97,3 +97,73 @@ EVP = dict(rheol="elasto-visco-plastic", tmantle=1573, alpha=3e-5, vmin="1e19",
            ic="oceanic_plate_age_in_yr = 2e5\n")
 # fast loading so that elements yield (shear and tensile return mapping) within ~100 steps
 YIELD = dict(rheol="elasto-plastic", vx=1e-6, control="characteristic_speed = 1e-9\n")
+
+
+# Parameter values of the reference's benchmarks-cores/test-3d.cfg (BASELINE configs[1]); the
+# mesh itself (meshing_option = 2 needs TetGen) comes from tests/golden/test-3d.desmesh.
+TEST3D = """
+[sim]
+modelname = benchmark
+max_time_in_yr = 200
+output_time_interval_in_yr = 50
+output_step_interval = 100
+has_output_during_remeshing = no
+is_outputting_averaged_fields = no
+checkpoint_frame_interval = 5
+[mesh]
+meshing_option = 2
+xlength = 100e3
+ylength = 10e3
+zlength = 10e3
+resolution = 1e3
+largest_size = 10
+smallest_size = 0.001
+refined_zonex = [0.3, 0.7]
+refined_zoney = [0.0, 1.0]
+refined_zonez = [0.0, 1.0]
+quality_check_step_interval = 100
+min_quality = 0.2
+max_boundary_distortion = 0.2
+remeshing_option = 11
+[control]
+surface_process_option = 1
+surface_diffusivity = 1e-6
+dt_fraction = 1.0
+inertial_scaling = 1e4
+[bc]
+vbc_x0 = 1
+vbc_x1 = 1
+vbc_val_x0 = -1e-9
+vbc_val_x1 = 1e-9
+vbc_y0 = 1
+vbc_y1 = 1
+vbc_val_y0 = 0
+vbc_val_y1 = 0
+has_water_loading = no
+surface_temperature = 273
+mantle_temperature = 273
+[ic]
+weakzone_option = 1
+weakzone_azimuth = 15
+weakzone_inclination = -60
+weakzone_halfwidth = 1.2
+weakzone_depth_min = 0.5
+weakzone_depth_max = 1.0
+weakzone_xcenter = 0.5
+weakzone_ycenter = 0.5
+weakzone_zcenter = 0
+weakzone_plstrain = 0.5
+[mat]
+rheology_type = elasto-plastic
+rho0 = [2700]
+alpha = [0]
+bulk_modulus = [50e9]
+shear_modulus = [30e9]
+pls0 = [0]
+pls1 = [0.5]
+cohesion0 = [4.4e7]
+cohesion1 = [4e6]
+friction_angle0 = [30]
+friction_angle1 = [30]
+min_viscosity = 1e24
+"""
