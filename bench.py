@@ -233,7 +233,9 @@ def main():
                 tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 if os.path.exists(tpath):
                     try:
-                        traffic = json.load(open(tpath)).get(dom)
+                        # PMC passes cannot share a run with the timed one: the committed summary of
+                        # `tools/summarize_pmc.py` for the same workload is reported (bytes per launch)
+                        traffic = json.load(open(tpath)).get(dom, {}).get("traffic_bytes_per_launch")
                     except Exception:
                         traffic = None
                 roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -251,7 +253,7 @@ def main():
             os.environ["OMP_NUM_THREADS"] = str(ncores)
             os.environ.setdefault("OMP_PROC_BIND", "close")
             from oracle_binding import OracleEngine, load_oracle
-            threads = load_oracle(omp=True).des_oracle_threads()
+            threads = load_oracle(omp=True).des_oracle_set_threads(ncores)
             ora = OracleEngine(host, omp=True)
             ora.init_from_host(host)
             ora.step(1)

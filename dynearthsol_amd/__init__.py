@@ -325,6 +325,10 @@ class DeviceEngine(EngineBase):
     def algorithmic_bytes_per_step(self):
         return self._lib.des_dev_algorithmic_bytes_per_step(self._h)
 
+    def exchange(self, kind):
+        self._lib.des_dev_exchange.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._lib.des_dev_exchange(self._h, kind), "exchange")
+
     def comm_init(self, dist, rank, world):
         """Attach an RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed only
         carries those 128 bytes; all halo traffic then stays inside the engine."""

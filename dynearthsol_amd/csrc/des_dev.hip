@@ -1872,6 +1872,15 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
     return DES_OK;
 }
 
+// One RCCL halo exchange of the given kind on the engine's stream (what des_dev_step issues
+// between phases); asynchronous.
+int des_dev_exchange(des_dev *h, int kind)
+{
+    if (!h || kind < 0 || kind >= DES_X_COUNT) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    return exchange(h, kind);
+}
+
 // One phase of a step without any communication: the caller moves the halo values
 // (des_dev_halo_pack / des_dev_halo_unpack) -- used to test the decomposition with several
 // engines on one GPU.  Returns 1 after phase 4 when the compute_dt partials are ready.

@@ -101,6 +101,9 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global);
 /* rank 0 creates the 128-byte ncclUniqueId; the caller broadcasts it (e.g. torch.distributed) */
 int des_dev_comm_unique_id(unsigned char *id128);
 int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128);
+/* one halo exchange (DES_X_*) through the attached communicator, asynchronous on the engine's
+ * stream: what des_dev_step issues after phases 0..3 */
+int des_dev_exchange(des_dev *h, int kind);
 
 /* The same step cut into its five phases WITHOUT communication, plus raw access to the halo
  * values and the compute_dt partials: lets a host harness move the halos itself (tests with

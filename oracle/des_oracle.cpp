@@ -1918,6 +1918,17 @@ int des_oracle_dt_finalize(des_oracle *h, const double in[6], double *dt)
 
 double des_oracle_l2_partial(des_oracle *h) { return h->l2_part; }
 
+int des_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 int des_oracle_threads(void)
 {
 #ifdef _OPENMP

@@ -36,6 +36,9 @@ int des_oracle_dt_finalize(des_oracle *h, const double in[6], double *dt);
 double des_oracle_l2_partial(des_oracle *h);
 /* number of OpenMP threads the oracle loops run on (1 unless built with -fopenmp) */
 int des_oracle_threads(void);
+/* libgomp may already be initialised by the host process (torch loads it), so OMP_NUM_THREADS
+ * set late is ignored: set the team size explicitly; returns the size in effect */
+int des_oracle_set_threads(int n);
 
 /* Stand-alone pieces exposed for known-answer tests. */
 /* eigenvalues (ascending) of the symmetric tensor s = {XX,YY,ZZ,XY,XZ,YZ};

@@ -22,6 +22,8 @@ def load_oracle(omp=False):
         lib.des_oracle_create.restype = C.c_void_p
         lib.des_oracle_create.argtypes = [C.POINTER(DesParams), C.POINTER(DesMesh)]
         lib.des_oracle_threads.restype = C.c_int
+        lib.des_oracle_set_threads.restype = C.c_int
+        lib.des_oracle_set_threads.argtypes = [C.c_int]
         d6 = C.POINTER(C.c_double)
         lib.des_oracle_principal_values3.argtypes = [d6, d6]
         lib.des_oracle_principal_stresses3.argtypes = [d6, d6, d6]

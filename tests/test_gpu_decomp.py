@@ -76,3 +76,53 @@ def test_single_rank_communicator_is_a_no_op():
             assert np.array_equal(a.download(f), b.download(f)), f
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_send_recv_path_moves_halo_values():
+    """The 1-GPU box cannot hold two RCCL ranks, so the ncclSend/ncclRecv path of
+    des_dev_exchange is driven with the rank as its own neighbour: the values of the `send`
+    nodes must arrive, for every exchange kind, at the `recv` nodes -- through pack kernel,
+    grouped RCCL p2p on the engine's stream and unpack kernel."""
+    import ctypes as C
+    import os
+    import types
+    import torch.distributed as dist
+    from dynearthsol_amd._structs import DesHalo
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29900 + os.getpid() % 90))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        host = des.Host(cfg_text=cfgs.make(**cfgs.EVP))
+        eng = des.DeviceEngine(host)
+        nn = host.nnode
+        rng = np.random.default_rng(5)
+        perm = rng.permutation(nn).astype(np.int32)
+        k = nn // 3
+        send, recv = np.sort(perm[:k]), np.sort(perm[k:2 * k])
+        # two "neighbours", both rank 0, to cover the grouped loop
+        cut = k // 2
+        arrs = dict(nbr=np.zeros(2, np.int32), sp=np.array([0, cut, k], np.int32), rp=np.array([0, cut, k], np.int32),
+                    send=send, recv=recv)
+        pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        halo = DesHalo(0, nn, 2, pi(arrs["nbr"]), pi(arrs["sp"]), pi(send), pi(arrs["rp"]), pi(recv))
+        eng.set_halo(types.SimpleNamespace(halo=halo, owned=(0, nn), host=host))
+        eng.comm_init(dist, 0, 1)
+        eng.init_from_host(host)
+        vel = rng.standard_normal((3, nn)); eng.upload("VEL", vel)
+        tem = rng.standard_normal(nn); eng.upload("TEMPERATURE", tem)
+        ntmp = rng.standard_normal(nn); eng.upload("NTMP", ntmp)
+        coord = eng.download("COORD").reshape(3, nn).copy()
+        eng.exchange(2)          # {vx,vy,vz,x,y,z}
+        eng.exchange(0)          # {T, ntmp}
+        eng.sync()
+        v2 = eng.download("VEL").reshape(3, nn); c2 = eng.download("COORD").reshape(3, nn)
+        t2 = eng.download("TEMPERATURE"); n2 = eng.download("NTMP")
+        assert np.array_equal(v2[:, recv], vel[:, send]) and np.array_equal(c2[:, recv], coord[:, send])
+        assert np.array_equal(t2[recv], tem[send]) and np.array_equal(n2[recv], ntmp[send])
+        untouched = np.setdiff1d(np.arange(nn), recv)
+        assert np.array_equal(v2[:, untouched], vel[:, untouched]) and np.array_equal(t2[untouched], tem[untouched])
+        ntmp3 = rng.standard_normal(nn); eng.upload("NTMP", ntmp3)
+        eng.exchange(1); eng.sync()
+        assert np.array_equal(eng.download("NTMP")[recv], ntmp3[send])
+    finally:
+        dist.destroy_process_group()
