@@ -22,7 +22,7 @@ class DesParams(C.Structure):
         ("elastic_foundation_constant", C.c_double), ("sea_water_density", C.c_double),
         ("vbc_val_z1_loading_period", C.c_double),
         ("has_winkler_foundation", C.c_int), ("has_elastic_foundation", C.c_int),
-        ("has_water_loading", C.c_int), ("pad1_", C.c_int),
+        ("has_water_loading", C.c_int), ("is_outputting_averaged_fields", C.c_int),
         ("vbc_types", C.c_int * DES_NBDRY), ("vbc_values", C.c_double * DES_NBDRY),
         ("vbc_val_l", C.c_double * 4),
         ("stress_bc_types", C.c_int * DES_NBDRY_SIDE), ("stress_bc_values", C.c_double * DES_NBDRY_SIDE),
@@ -74,6 +74,7 @@ class DesScalars(C.Structure):
         ("dt", C.c_double), ("time", C.c_double), ("l2_residual", C.c_double),
         ("max_surf_vel", C.c_double), ("max_global_vel_mag", C.c_double),
         ("global_dt_min", C.c_double), ("steps", C.c_longlong), ("status", C.c_int), ("pad_", C.c_int),
+        ("avg_time0", C.c_double),
     ]
 
 
@@ -81,6 +82,6 @@ class DesScalars(C.Structure):
 FIELDS = ["COORD", "VEL", "FORCE", "FORCE_RESIDUAL", "COORD0", "TEMPERATURE", "VOLUME_N", "MASS",
           "TMASS", "DHACC", "STRESS", "STRAIN", "STRAIN_RATE", "PLSTRAIN", "DELTA_PLSTRAIN",
           "VISCOSITY", "VOLUME", "VOLUME_OLD", "DPRESSURE", "EDVOLDT", "RADIOGENIC", "ELEMMARKERS",
-          "EDVACC_SURF", "DH", "NTMP"]
+          "EDVACC_SURF", "DH", "NTMP", "STRESS_AVG", "DPLSTRAIN_AVG", "STRAIN0", "COORD_AVG0"]
 F = {name: i for i, name in enumerate(FIELDS)}
 INT_FIELDS = {"ELEMMARKERS"}

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -74,9 +75,11 @@ struct DevClock {
     long long steps;
     int status;
     int pad;
+    double avg_time0;        // Output::time0 (output.cxx:332)
 };
 
-enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };   // INIT: C part without rotate_stress
+// INIT: C part without rotate_stress; AVG: Output::average_fields on the final stress of the step
+enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_AVG = 16 };
 
 enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_N3, K_S2, K_S3,
                 K_DTFIN, K_MISC, K_COUNT };
@@ -108,6 +111,8 @@ struct des_dev {
     // nodal
     d4 *xt, *vm;                          // {x,y,z,T}, {vx,vy,vz,mass}
     double *ntmp, *volume_n, *tmass, *ymass, *force, *fres, *coord0, *dhacc;
+    // Output::average_fields state (only allocated when is_outputting_averaged_fields)
+    double *stress_avg, *dplstrain_avg, *strain0, *coord_avg0;
     // element
     double *stress, *strain, *strain_rate, *plstrain, *delta_plstrain, *viscosity, *volume,
            *volume_old, *dpressure, *radiogenic;
@@ -210,7 +215,9 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
      const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
-     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp)
+     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp,
+     const double *__restrict__ delta_plstrain, double *__restrict__ stress_avg,
+     double *__restrict__ dplstrain_avg, double *__restrict__ strain0)
 {
     const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     const bool active = e < ne;
@@ -267,7 +274,7 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
             const bool rescale = rdv >= 1.0;                         // bc.cxx:1677
             const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0;
-            if (rescale || rotate) {
+            if (rescale || rotate || (MODE & MODE_AVG)) {
                 double s[6], es[6];
                 for (int i = 0; i < 6; ++i) { s[i] = stress[(size_t)i*ne + e]; es[i] = strain[(size_t)i*ne + e]; }
                 if (rescale) {
@@ -285,7 +292,19 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
                     desk::jaumann_rate_3d(s, dt, w3, w4, w5);
                     desk::jaumann_rate_3d(es, dt, w3, w4, w5);
                 }
-                for (int i = 0; i < 6; ++i) { stress[(size_t)i*ne + e] = s[i]; strain[(size_t)i*ne + e] = es[i]; }
+                if (rescale || rotate)
+                    for (int i = 0; i < 6; ++i) { stress[(size_t)i*ne + e] = s[i]; strain[(size_t)i*ne + e] = es[i]; }
+                if (MODE & MODE_AVG) {
+                    // Output::average_fields (output.cxx:327-370) on the end-of-step fields
+                    if (clk->steps % p->quality_check_step_interval == 1) {
+                        if (e == 0) clk->avg_time0 = clk->time;
+                        for (int i = 0; i < 6; ++i) { stress_avg[(size_t)i*ne + e] = s[i]; strain0[(size_t)i*ne + e] = es[i]; }
+                        dplstrain_avg[e] = delta_plstrain[e];
+                    } else {
+                        for (int i = 0; i < 6; ++i) stress_avg[(size_t)i*ne + e] += s[i];
+                        dplstrain_avg[e] += delta_plstrain[e];
+                    }
+                }
             }
         }
 
@@ -1159,6 +1178,43 @@ __global__ void k_count_nan(const double *a, long long n, unsigned long long *co
     if (c) atomicAdd(count, c);
 }
 
+// bad_mesh_quality reductions (remeshing.cxx:2752-2866).  slots: [0] min quality (double bits),
+// then ints: [2] first tiny element, [3] first distorted bottom node, [4] first worst element
+__device__ __forceinline__ double elem_quality3(const int4 cn, const d4 *__restrict__ xt, double vol)
+{
+    const d4 a = xt[cn.x], b = xt[cn.y], c = xt[cn.z], d = xt[cn.w];
+    const double normalization_factor = 216 * sqrt(3.0);
+    const double area_sum = (desk::tri_area(a, b, c) + desk::tri_area(a, b, d) +
+                             desk::tri_area(c, d, a) + desk::tri_area(c, d, b));
+    return normalization_factor * vol * vol / (area_sum * area_sum * area_sum);
+}
+
+__global__ void k_quality_a(int ne, int nn, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+                            const double *__restrict__ volume, const unsigned *__restrict__ bcflag,
+                            double smallest_vol, double bottom, double bottom_dist, double *qmin, int *islot)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    double q = 1.0;
+    if (i < ne) {
+        const double vol = volume[i];
+        if (vol < smallest_vol) atomicMin(&islot[0], i);
+        q = fmin(q, elem_quality3(conn[i], xt, vol));
+    }
+    if (i < nn && bottom_dist >= 0 && (bcflag[i] & (1u << 4)))            // is_bottom: BOUNDZ0
+        if (fabs(xt[i].z - bottom) > bottom_dist) atomicMin(&islot[1], i);
+    q = desk::wave_min(q);
+    if ((threadIdx.x & 63) == 0 && q < 1.0) desk::atomic_min_double(qmin, q);
+}
+
+__global__ void k_quality_b(int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+                            const double *__restrict__ volume, const double *qmin, int *islot)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const double q = elem_quality3(conn[e], xt, volume[e]);
+    if (q < 1.0 && q == *qmin) atomicMin(&islot[2], e);
+}
+
 // =====================================================================================
 // host side of the engine
 // =====================================================================================
@@ -1211,7 +1267,39 @@ void launch_e1(des_dev *h)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(h->ne)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, h->ne, nb, h->conn, h->xt, h->vm, h->markers, h->props, h->radiogenic,
                        h->topflag, h->stress, h->strain, h->plstrain, h->volume, h->volume_old, h->strain_rate,
-                       h->mrec, h->ttmp);
+                       h->mrec, h->ttmp, h->delta_plstrain, h->stress_avg, h->dplstrain_avg, h->strain0);
+}
+
+// end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
+void launch_e1_end(des_dev *h, long long step_no, bool with_next)
+{
+    const bool do_dt = (step_no % 10 == 0);
+    const int sel = (with_next ? 1 : 0) | (do_dt ? 2 : 0) | (h->p.is_outputting_averaged_fields ? 4 : 0);
+    switch (sel) {
+    case 0: launch_e1<MODE_C>(h); break;
+    case 1: launch_e1<MODE_C | MODE_A>(h); break;
+    case 2: launch_e1<MODE_C | MODE_DT>(h); break;
+    case 3: launch_e1<MODE_C | MODE_A | MODE_DT>(h); break;
+    case 4: launch_e1<MODE_C | MODE_AVG>(h); break;
+    case 5: launch_e1<MODE_C | MODE_A | MODE_AVG>(h); break;
+    case 6: launch_e1<MODE_C | MODE_DT | MODE_AVG>(h); break;
+    case 7: launch_e1<MODE_C | MODE_A | MODE_DT | MODE_AVG>(h); break;
+    }
+}
+
+// coordinates at the first step of an averaging interval (output.cxx:334-338)
+__global__ void k_avg_coord0(int nn, const d4 *__restrict__ xt, double *__restrict__ coord_avg0)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    const d4 c = xt[n];
+    coord_avg0[n] = c.x; coord_avg0[(size_t)nn + n] = c.y; coord_avg0[(size_t)2*nn + n] = c.z;
+}
+
+void launch_avg_coord0(des_dev *h, long long step_no)
+{
+    if (h->p.is_outputting_averaged_fields && step_no % h->p.quality_check_step_interval == 1)
+        hipLaunchKernelGGL(k_avg_coord0, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->nn, h->xt, h->coord_avg0);
 }
 
 // compute_mass gather alone (N1 without the temperature / dvoldt parts)
@@ -1388,6 +1476,7 @@ void des_dev_destroy(des_dev *h)
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
+        h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
         h->radiogenic, h->markers, h->props, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
         h->conn_surf, h->ssup_idx, h->ssup_arr, h->topflag, h->dh, h->edvacc,
@@ -1478,6 +1567,12 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     if (nmat > 1) CK(dev_alloc(h->props, (size_t)5*ne));
     CK(dev_alloc(h->mrec, (size_t)ne)); CK(dev_alloc(h->ttmp, (size_t)ne)); CK(dev_alloc(h->etmp2, (size_t)ne));
     CK(dev_alloc(h->ftmp, (size_t)12*ne));
+    if (h->p.is_outputting_averaged_fields) {
+        CK(dev_alloc(h->stress_avg, (size_t)6*ne)); CK(dev_alloc(h->strain0, (size_t)6*ne));
+        CK(dev_alloc(h->dplstrain_avg, (size_t)ne)); CK(dev_alloc(h->coord_avg0, (size_t)3*nn));
+        HK(hipMemsetAsync(h->stress_avg, 0, 48*(size_t)ne, h->stream)); HK(hipMemsetAsync(h->strain0, 0, 48*(size_t)ne, h->stream));
+        HK(hipMemsetAsync(h->dplstrain_avg, 0, 8*(size_t)ne, h->stream)); HK(hipMemsetAsync(h->coord_avg0, 0, 24*(size_t)nn, h->stream));
+    }
     h->n3_blocks = nblk8(nn);
     CK(dev_alloc(h->res_part, (size_t)h->n3_blocks));
     {
@@ -1606,6 +1701,9 @@ long long des_dev_field_count(const des_dev *h, int field)
     const long long nn = h->nn, ne = h->ne;
     switch (field) {
     case DES_F_COORD: case DES_F_VEL: case DES_F_FORCE: case DES_F_FORCE_RESIDUAL: case DES_F_COORD0: return 3*nn;
+    case DES_F_COORD_AVG0: return h->coord_avg0 ? 3*nn : -1;
+    case DES_F_STRESS_AVG: case DES_F_STRAIN0: return h->stress_avg ? 6*ne : -1;
+    case DES_F_DPLSTRAIN_AVG: return h->dplstrain_avg ? ne : -1;
     case DES_F_TEMPERATURE: case DES_F_VOLUME_N: case DES_F_MASS: case DES_F_TMASS: case DES_F_DHACC: case DES_F_NTMP: return nn;
     case DES_F_STRESS: case DES_F_STRAIN: case DES_F_STRAIN_RATE: return 6*ne;
     case DES_F_PLSTRAIN: case DES_F_DELTA_PLSTRAIN: case DES_F_VISCOSITY: case DES_F_VOLUME: case DES_F_VOLUME_OLD:
@@ -1639,6 +1737,10 @@ static double *plain_field(des_dev *h, int field)
     case DES_F_RADIOGENIC: return h->radiogenic;
     case DES_F_EDVACC_SURF: return h->edvacc;
     case DES_F_DH: return h->dh;
+    case DES_F_STRESS_AVG: return h->stress_avg;
+    case DES_F_DPLSTRAIN_AVG: return h->dplstrain_avg;
+    case DES_F_STRAIN0: return h->strain0;
+    case DES_F_COORD_AVG0: return h->coord_avg0;
     default: return nullptr;
     }
 }
@@ -1794,8 +1896,8 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         }
         const bool last = (i == nsteps - 1);
         const bool do_dt = (step_no % 10 == 0);
-        if (last) { if (do_dt) launch_e1<MODE_C | MODE_DT>(h); else launch_e1<MODE_C>(h); }
-        else      { if (do_dt) launch_e1<MODE_C | MODE_A | MODE_DT>(h); else launch_e1<MODE_C | MODE_A>(h); }
+        launch_avg_coord0(h, step_no);
+        launch_e1_end(h, step_no, !last);
         if (do_dt && (rc = reduce_dt(h))) return rc;
     }
     // compute_mass gather of the last update_mesh, so that volume_n / mass / tmass hold the
@@ -1819,7 +1921,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
             out->l2_residual = std::sqrt(l2sum);
         }
         out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min;
-        out->steps = c.steps; out->status = c.status; out->pad_ = 0;
+        out->steps = c.steps; out->status = c.status; out->pad_ = 0; out->avg_time0 = c.avg_time0;
         return c.status;
     }
     return DES_OK;
@@ -1910,7 +2012,8 @@ int des_dev_phase(des_dev *h, int phase)
     case 4: {
         launch_s3(h, false, true, true);
         const bool do_dt = (h->steps_host % 10 == 0);
-        if (do_dt) launch_e1<MODE_C | MODE_DT>(h); else launch_e1<MODE_C>(h);
+        launch_avg_coord0(h, h->steps_host);
+        launch_e1_end(h, h->steps_host, false);
         launch_mass_gather(h);
         return do_dt ? 1 : 0;
     }
@@ -1998,6 +2101,29 @@ int des_dev_check_nan(des_dev *h, long long *n_nan)
     return c ? DES_ERR_RUNTIME_NAN : DES_OK;
 }
 
+int des_dev_mesh_quality(des_dev *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out)
+{
+    if (!h || !out) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    struct Slots { double q; int i[4]; } init = { 1.0, { INT_MAX, INT_MAX, INT_MAX, 0 } }, res;
+    Slots *d = nullptr;
+    HIP_OK(hipMalloc((void **)&d, sizeof(Slots)));
+    HIP_OK(hipMemcpyAsync(d, &init, sizeof(Slots), hipMemcpyHostToDevice, h->stream));
+    const int n = std::max(h->ne, h->nn);
+    hipLaunchKernelGGL(k_quality_a, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, h->ne, h->nn, h->conn, h->xt, h->volume,
+                       h->bcflag, smallest_vol, bottom, bottom_dist, &d->q, d->i);
+    hipLaunchKernelGGL(k_quality_b, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->ne, h->conn, h->xt, h->volume,
+                       &d->q, d->i);
+    HIP_OK(hipMemcpyAsync(&res, d, sizeof(Slots), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    hipFree(d);
+    out->small_elem = res.i[0] == INT_MAX ? -1 : res.i[0];
+    out->bottom_node = res.i[1] == INT_MAX ? -1 : res.i[1];
+    out->worst_elem = res.i[2] == INT_MAX ? 0 : res.i[2];      // no element below quality 1: the reference keeps 0
+    out->worst_quality = res.q; out->pad_ = 0;
+    return DES_OK;
+}
+
 int des_dev_timer_start(des_dev *h)
 {
     if (!h) return DES_ERR_INTERNAL;
@@ -2055,6 +2181,8 @@ double des_dev_algorithmic_bytes_per_step(const des_dev *h)
     if (h->p.rheol_type == DES_RH_EVP) { be += 24; bn += 8; }
     if (!h->p.has_thermal_diffusion) { be -= 88; bn -= 24; }
     if (!h->p.is_using_mixed_stress) { be -= 96; bn -= 28; }
+    // average_fields: stress_avg read+write, delta_plstrain read, dplstrain_avg read+write
+    if (h->p.is_outputting_averaged_fields) be += 120;
     return be * h->ne + bn * h->nn;
 }
 

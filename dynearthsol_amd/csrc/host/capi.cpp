@@ -5,14 +5,6 @@
 #include <cstring>
 #include <string>
 
-struct des_host {
-    des::Config cfg;
-    des_params params;
-    des::HostMesh mesh;
-    des::HostFields fields;
-    des_mesh view;
-};
-
 namespace {
 thread_local std::string g_last_error;
 

@@ -251,6 +251,11 @@ void build_params(const Config &c, des_params &p)
         throw Error(11, "mesh.quality_check_step_interval must be positive.");
     if (c.i("sim.checkpoint_frame_interval") < 1)
         throw Error(11, "sim.checkpoint_frame_interval must be positive.");
+    // input.cxx:1042-1047
+    p.is_outputting_averaged_fields = c.b("sim.is_outputting_averaged_fields");
+    if (p.is_outputting_averaged_fields && c.given("sim.output_step_interval") &&
+        c.i("sim.output_step_interval") % p.quality_check_step_interval != 0)
+        throw Error(11, "sim.output_step_interval must be a multiple of mesh.quality_check_step_interval!.");
 
     // control
     p.gravity = c.d("control.gravity");

@@ -100,6 +100,19 @@ void initial_conditions(const Config &cfg, des_params &p, const HostMesh &m, Hos
 // ref_pressure (matprops.cxx:153-174)
 double ref_pressure(const des_params &p, double z);
 
+// MatProps::rho (matprops.cxx:642-664) of one element for the "density" output field
+double elem_density(const des_params &p, const int *conn, int nelem, const double *temperature,
+                    const int *elemmarkers, int e);
+
 } // namespace des
+
+// the handle behind include/des_host.h
+struct des_host {
+    des::Config cfg;
+    des_params params;
+    des::HostMesh mesh;
+    des::HostFields fields;
+    des_mesh view;
+};
 
 #endif

@@ -102,6 +102,26 @@ struct ElemView {
     }
 };
 
+} // namespace
+
+double elem_density(const des_params &p, const int *conn, int nelem, const double *temperature,
+                    const int *elemmarkers, int e)
+{
+    double T = 0;
+    for (int i = 0; i < 4; ++i) T += temperature[conn[(size_t)i*nelem + e]];
+    T /= 4;
+    double TinCelsius = T - 273;
+    double result = 0; int n = 0;
+    const int *mk = &elemmarkers[(size_t)e*p.nmat];
+    for (int k = 0; k < p.nmat; k++) {
+        result += p.rho0[k] * (1 - p.alpha[k] * TinCelsius) * mk[k];
+        n += mk[k];
+    }
+    return result / n;
+}
+
+namespace {
+
 // MarkerSet::random_eta (markerset.cxx:116-133)
 void random_eta(double eta[4])
 {

@@ -87,6 +87,10 @@ int des_dev_timer_stop(des_dev *h, float *ms);
 int des_dev_profile_enable(des_dev *h, int on);
 int des_dev_profile_read(des_dev *h, int cap, char (*names)[64], double *ms, long long *calls);
 
+/* bad_mesh_quality's three reductions (remeshing.cxx:2752-2866) on the device: tiny element,
+ * distorted bottom (skipped when bottom_dist < 0), worst elem_quality.  Synchronises. */
+int des_dev_mesh_quality(des_dev *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out);
+
 /* Algorithmic HBM bytes of one step for this engine's mesh and options (SURVEY.md 8d:
  * 1420*nelem + 348*nnode with the evp / thermal / NMD variants). */
 double des_dev_algorithmic_bytes_per_step(const des_dev *h);

@@ -75,7 +75,7 @@ typedef struct des_params {
     int has_winkler_foundation;
     int has_elastic_foundation;
     int has_water_loading;
-    int pad1_;
+    int is_outputting_averaged_fields; /* sim.*: Output::average_fields runs every step (output.cxx:327-370) */
     int vbc_types[DES_NBDRY];       /* Variables::vbc_types  (dynearthsol.cxx:63-72)               */
     double vbc_values[DES_NBDRY];   /* Variables::vbc_values (dynearthsol.cxx:74-83)               */
     double vbc_val_l[4];            /* bc.vbc_val_{x0,x1,y0,y1}_l (lateral shear, type 6)          */
@@ -192,6 +192,12 @@ enum des_field {
     DES_F_EDVACC_SURF,      /* surfinfo.edvacc_surf [etop]  */
     DES_F_DH,               /* surfinfo.dh [ntop]           */
     DES_F_NTMP,             /* N  double_vec Variables::ntmp (scratch, exposed for tests) */
+    /* state of Output::average_fields (output.hpp:30-36), kept by the engine when
+     * is_outputting_averaged_fields: */
+    DES_F_STRESS_AVG,       /* E  tensor_t  running sum of stress over the averaging interval   */
+    DES_F_DPLSTRAIN_AVG,    /* E  double_vec running sum of delta_plstrain                       */
+    DES_F_STRAIN0,          /* E  tensor_t  strain at the first step of the interval             */
+    DES_F_COORD_AVG0,       /* N  array_t   coordinates at the first step of the interval        */
     DES_F_COUNT
 };
 
@@ -207,7 +213,18 @@ typedef struct des_scalars {
     long long steps;
     int status;                     /* DES_OK or DES_ERR_RUNTIME_NAN (dt <= 0)                      */
     int pad_;
+    double avg_time0;               /* Output::time0: time at the first step of the averaging interval */
 } des_scalars;
+
+/* Reductions behind bad_mesh_quality (remeshing.cxx:2752-2866), so the driver can take the
+ * remesh decision every mesh.quality_check_step_interval steps without downloading the mesh. */
+typedef struct des_quality {
+    int small_elem;         /* first element with volume < smallest_vol, -1 if none (code 3)      */
+    int bottom_node;        /* first bottom node with |z - bottom| > bottom_dist, -1 if none (2)   */
+    int worst_elem;         /* first element attaining the minimum elem_quality                    */
+    int pad_;
+    double worst_quality;   /* min over elements of elem_quality (geometry.cxx:1873-1909)          */
+} des_quality;
 
 #ifdef __cplusplus
 }

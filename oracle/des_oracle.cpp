@@ -67,6 +67,9 @@ struct des_oracle {
          volume_old, dpressure, edvoldt, radiogenic, etmp, tmp_result;
     ivec elemmarkers, etmp_int;
     dvec dh, edvacc_surf, dh_n;
+    // Output::average_fields state (output.hpp:30-36)
+    dvec stress_avg, dplstrain_avg, strain0, coord_avg0;
+    double avg_time0;
     int o0, o1;                         // owned nodes [o0, o1) (whole mesh unless decomposed)
     double dt_part[6];
     double l2_part;
@@ -1627,6 +1630,23 @@ double compute_dt(des_oracle &o)
 
 // One pass of dynearthsol.cxx:768-894 in four phases; a decomposed run exchanges halo values
 // between them (des_params.h: DES_X_*).  phase 4 returns 1 when the dt partials are ready.
+// Output::average_fields, output.cxx:327-370 (called every step, dynearthsol.cxx:897-898;
+// nothing on the step reads its state, so its place after rotate_stress is immaterial)
+void average_fields(des_oracle &o)
+{
+    const int average_interval = o.p.quality_check_step_interval;
+    if (o.steps % average_interval == 1) {
+        o.avg_time0 = o.time;
+        o.coord_avg0 = o.coord;
+        o.strain0 = o.strain;
+        o.stress_avg = o.stress;
+        o.dplstrain_avg = o.delta_plstrain;
+    } else {
+        for (size_t i = 0; i < o.stress_avg.size(); ++i) o.stress_avg[i] += o.stress[i];
+        for (size_t i = 0; i < o.dplstrain_avg.size(); ++i) o.dplstrain_avg[i] += o.delta_plstrain[i];
+    }
+}
+
 int step_phase(des_oracle &o, int phase)
 {
     const des_params &p = o.p;
@@ -1665,6 +1685,8 @@ int step_phase(des_oracle &o, int phase)
             update_mesh_b(o);
         if (p.rheol_type & DES_RH_ELASTIC)
             rotate_stress(o);
+        if (p.is_outputting_averaged_fields)
+            average_fields(o);
         if (o.steps % 10 == 0) {
             refresh_elem_cache(o);
             compute_dt_partials(o);
@@ -1715,6 +1737,10 @@ FieldRef field_ref(des_oracle &o, int field)
     case DES_F_ELEMMARKERS: return {o.elemmarkers.data(), ne * o.p.nmat, 4};
     case DES_F_EDVACC_SURF: return {o.edvacc_surf.data(), (long long)o.etop, 8};
     case DES_F_DH: return {o.dh.data(), (long long)o.ntop, 8};
+    case DES_F_STRESS_AVG: return {o.stress_avg.data(), 6*ne, 8};
+    case DES_F_DPLSTRAIN_AVG: return {o.dplstrain_avg.data(), ne, 8};
+    case DES_F_STRAIN0: return {o.strain0.data(), 6*ne, 8};
+    case DES_F_COORD_AVG0: return {o.coord_avg0.data(), 3*nn, 8};
     default: return {nullptr, 0, 0};
     }
 }
@@ -1764,6 +1790,9 @@ des_oracle *des_oracle_create(const des_params *params, const des_mesh *mesh)
                     &o.c_cp, &o.c_k})
         v->assign((size_t)ne, 0.0);
     o.viscosity.assign((size_t)ne, params->visc_max);          // fields.cxx:110
+    o.stress_avg.assign((size_t)6 * ne, 0.0); o.strain0.assign((size_t)6 * ne, 0.0);
+    o.dplstrain_avg.assign((size_t)ne, 0.0); o.coord_avg0.assign((size_t)3 * nn, 0.0);
+    o.avg_time0 = 0;
     o.tmp_result.assign((size_t)12 * ne, 0.0);
     o.elemmarkers.assign((size_t)ne * params->nmat, 0);
     o.etmp_int.assign((size_t)ne, -1);
@@ -1845,7 +1874,7 @@ int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out)
         out->dt = h->dt; out->time = h->time; out->l2_residual = h->l2_residual;
         out->max_surf_vel = h->max_surf_vel; out->max_global_vel_mag = h->max_global_vel_mag;
         out->global_dt_min = h->global_dt_min; out->steps = h->steps; out->status = h->status;
-        out->pad_ = 0;
+        out->pad_ = 0; out->avg_time0 = h->avg_time0;
     }
     return h->status;
 }
@@ -1859,6 +1888,35 @@ int des_oracle_check_nan(des_oracle *h, long long *n_nan)
         for (double x : *v) if (std::isnan(x)) ++n;
     if (n_nan) *n_nan = n;
     return n ? DES_ERR_RUNTIME_NAN : DES_OK;
+}
+
+// bad_mesh_quality's loops (remeshing.cxx:2765-2798, 2841-2844) + elem_quality /
+// worst_elem_quality (geometry.cxx:1873-1927)
+int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out)
+{
+    des_oracle &o = *h;
+    out->small_elem = out->bottom_node = -1; out->pad_ = 0;
+    for (int e = 0; e < o.ne; e++)
+        if (o.volume[e] < smallest_vol) { out->small_elem = e; break; }
+    if (bottom_dist >= 0)
+        for (int i = 0; i < o.nn; ++i)
+            if (o.bcflag[i] & BOUNDZ0) {
+                double z = o.coord[2 * (size_t)o.nn + i];
+                if (std::fabs(z - bottom) > bottom_dist) { out->bottom_node = i; break; }
+            }
+    double q = 1; int worst = 0;
+    for (int e = 0; e < o.ne; e++) {
+        double d[4][3];
+        elem_coords(o, e, d);
+        double normalization_factor = 216 * std::sqrt(3);
+        double area_sum = (triangle_area(d[0], d[1], d[2]) + triangle_area(d[0], d[1], d[3]) +
+                           triangle_area(d[2], d[3], d[0]) + triangle_area(d[2], d[3], d[1]));
+        double vol = o.volume[e];
+        double quality = normalization_factor * vol * vol / (area_sum * area_sum * area_sum);
+        if (quality < q) { q = quality; worst = e; }
+    }
+    out->worst_quality = q; out->worst_elem = worst;
+    return DES_OK;
 }
 
 // ---- domain decomposition hooks (tests drive the exchanges with torch.distributed/gloo) ----

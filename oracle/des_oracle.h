@@ -25,6 +25,7 @@ int des_oracle_init_geometry(des_oracle *h);
 int des_oracle_compute_dt(des_oracle *h, double *dt);
 int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out);
 int des_oracle_check_nan(des_oracle *h, long long *n_nan);
+int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out);
 /* domain decomposition: owned node range, phased stepping (0..3, halo exchanges in between --
  * DES_X_* in des_params.h), nodal pack/unpack by local index list, compute_dt across ranks */
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global);

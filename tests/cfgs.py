@@ -167,3 +167,17 @@ friction_angle0 = [30]
 friction_angle1 = [30]
 min_viscosity = 1e24
 """
+
+
+def apply_overrides(text, overrides):
+    """Rewrite "section.key = value" lines into a .cfg text (for the executable, which takes
+    the reference's single config-file argument)."""
+    import re
+    for line in overrides.strip().splitlines():
+        key, val = [x.strip() for x in line.split("=", 1)]
+        sec, k = key.split(".")
+        if re.search(r"^%s = " % re.escape(k), text, flags=re.M):
+            text = re.sub(r"(?m)^%s = .*$" % re.escape(k), "%s = %s" % (k, val), text)
+        else:
+            text = text.replace("[%s]\n" % sec, "[%s]\n%s = %s\n" % (sec, k, val), 1)
+    return text

@@ -1,0 +1,72 @@
+"""The drop-in executable and des_run over the HIP engine: frames of a device run against frames
+of the same loop over the CPU oracle (bit for bit for elasto-plastic physics)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cfgs
+import dynearthsol_amd as des
+from dynearthsol_amd import driver
+from oracle_binding import OracleEngine
+from test_driver_output import oracle_api, read_frame, in_tmp  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(des.REPO_ROOT, "dynearthsol_amd", "bin", "dynearthsol3d-hip")
+OV = ("sim.max_steps = 40\nsim.output_step_interval = 20\nsim.is_outputting_averaged_fields = yes\n"
+      "mesh.quality_check_step_interval = 10\nsim.checkpoint_frame_interval = 2\n")
+
+
+def test_executable_writes_the_frames_the_oracle_loop_writes(in_tmp):
+    # overrides go into the file: the executable takes the reference's single argument
+    with open("model.cfg", "w") as f:
+        f.write(cfgs.apply_overrides(cfgs.make(**cfgs.EP), OV + "sim.modelname = gpu\n"))
+    out = subprocess.run([EXE, "model.cfg"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Output # 2" in out.stdout and "Ending simulation." in out.stdout
+    host = des.Host(cfg_path="model.cfg", overrides="sim.modelname = cpu\n")
+    st = driver.run(host, api=oracle_api())
+    assert st.frames == 3 and st.checkpoints == 1
+    for frame in (0, 1, 2):
+        a, b = read_frame("gpu.save.%06d" % frame), read_frame("cpu.save.%06d" % frame)
+        assert sorted(a) == sorted(b)
+        for name in a:
+            if name == "walltime_sec":
+                continue
+            assert np.array_equal(a[name], b[name]), (frame, name)
+    a, b = read_frame("gpu.chkpt.000002"), read_frame("cpu.chkpt.000002")
+    for name in a:
+        assert np.array_equal(a[name], b[name]), name
+    ia, ib = np.loadtxt("gpu.info").reshape(-1, 8), np.loadtxt("cpu.info").reshape(-1, 8)
+    assert np.array_equal(np.delete(ia, 4, axis=1), np.delete(ib, 4, axis=1))
+
+
+def test_python_run_binds_the_hip_engine(in_tmp):
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=OV + "sim.modelname = py\n")
+    st = driver.run(host)
+    assert (st.steps, st.frames, st.exit_code) == (40, 3, 0) and st.compute_seconds > 0
+    fr = read_frame("py.save.000002")
+    assert fr["steps"].view(np.int32)[0] == 40
+
+
+def test_mesh_quality_reductions_match_the_oracle():
+    # elasto-plastic below yield: device and oracle states are bit-identical, so must be the reductions
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EP))
+    dev, ora = des.DeviceEngine(host), OracleEngine(host)
+    dev.init_from_host(host); ora.init_from_host(host)
+    dev.step(30); ora.step(30)
+    res = []
+    for eng, prefix in ((dev, "des_dev"), (ora, "des_oracle")):
+        q = driver.DesQuality()
+        f = getattr(eng._lib, prefix + "_mesh_quality")
+        f.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.POINTER(driver.DesQuality)]
+        vol = eng.download("VOLUME")
+        zmin = -host.params.zlength
+        # thresholds chosen so that every branch reports something
+        assert f(eng._h, float(vol.mean()), zmin, 1e-3, C.byref(q)) == 0
+        res.append((q.small_elem, q.bottom_node, q.worst_elem, q.worst_quality))
+    assert res[0] == res[1]
+    assert res[0][0] >= 0 and res[0][2] >= 0 and 0 < res[0][3] < 1

@@ -237,3 +237,31 @@ def test_errors_are_reference_exit_codes():
     with pytest.raises(des.DesError) as e:
         des.DeviceEngine(host, device=99)
     assert e.value.code == 31
+
+
+AVG_FIELDS = ("STRESS_AVG", "DPLSTRAIN_AVG", "STRAIN0", "COORD_AVG0")
+
+
+@pytest.mark.parametrize("splits", [(27,), (1, 4, 5, 7, 10)])
+def test_averaged_output_fields_bit_exact(splits):
+    """Output::average_fields (output.cxx:327-370) runs inside the device step when
+    sim.is_outputting_averaged_fields is on (the reference's default): running sums of stress /
+    delta_plstrain and the interval-start snapshots agree with the oracle to the bit, across
+    interval boundaries (interval 10) and however the steps are batched."""
+    kw = dict(cfgs.YIELD, qcsi=10)
+    ov = "sim.is_outputting_averaged_fields = yes\nsim.output_step_interval = 100\nmat.rheology_type = elasto-plastic\n"
+    host, dev, ora = pair(kw, overrides=ov)
+    assert host.params.is_outputting_averaged_fields == 1
+    for n in splits:
+        sd, so = dev.step(n), ora.step(n)
+        # (with half of the elements yielding dt itself differs in the last digits, see
+        # test_yield_heavy_run_stays_statistically_identical)
+        assert sd.avg_time0 == pytest.approx(so.avg_time0, rel=1e-9) and sd.steps == so.steps
+    assert so.avg_time0 > 0
+    assert np.abs(ora.download("DPLSTRAIN_AVG")).max() > 0
+    assert_close(dev, ora, 1e-4, fields=AVG_FIELDS)
+    host, dev, ora = pair(cfgs.EP, overrides="sim.is_outputting_averaged_fields = yes\nmesh.quality_check_step_interval = 10\n")
+    for n in splits:
+        sd, so = dev.step(n), ora.step(n)
+        assert sd.avg_time0 == so.avg_time0
+    assert_bit_exact(dev, ora, STATE + AVG_FIELDS)

@@ -78,3 +78,23 @@ def test_creep_limits_viscosity_between_bounds():
     h, o, dt, sc = run(cfgs.EVP, 20)
     visc = o.download("VISCOSITY")
     assert visc.min() == 1e19 and visc.max() == 1e24 and np.unique(visc).size > 100
+
+
+def test_average_fields_follow_the_reference_schedule():
+    """Output::average_fields (output.cxx:327-370): at steps % interval == 1 the snapshots are
+    taken and the sums restart, otherwise stress / delta_plstrain are accumulated."""
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EP, qcsi=5)),
+                    overrides="sim.is_outputting_averaged_fields = yes\n")
+    ora = OracleEngine(host)
+    ora.init_from_host(host)
+    acc = None
+    for step in range(1, 13):
+        sc = ora.step(1)
+        s = ora.download("STRESS")
+        if step % 5 == 1:
+            acc, t0, c0, e0 = s.copy(), sc.time, ora.download("COORD"), ora.download("STRAIN")
+        else:
+            acc += s
+        assert np.array_equal(ora.download("STRESS_AVG"), acc)
+        assert sc.avg_time0 == t0
+        assert np.array_equal(ora.download("COORD_AVG0"), c0) and np.array_equal(ora.download("STRAIN0"), e0)
