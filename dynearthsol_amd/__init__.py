@@ -126,7 +126,8 @@ class Host:
         p = self._lib.des_host_array(self._h, name.encode(), C.byref(n))
         if not p:
             raise KeyError(name)
-        ctype = C.c_int if name in ("elemmarkers", "connectivity", "segment", "segflag") else C.c_double
+        ints = ("elemmarkers", "connectivity", "segment", "segflag", "markerset.elem", "markerset.mattype", "markerset.id")
+        ctype = C.c_int if name in ints else C.c_double
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n.value,)).copy()
 
     def cfg_int(self, key):

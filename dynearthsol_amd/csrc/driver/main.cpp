@@ -17,6 +17,7 @@ void eng_destroy(void *h) { des_dev_destroy((des_dev *)h); }
 int eng_upload(void *h, int f, const void *a, long long n) { return des_dev_upload((des_dev *)h, f, a, n); }
 int eng_download(void *h, int f, void *a, long long n) { return des_dev_download((des_dev *)h, f, a, n); }
 long long eng_field_count(const void *h, int f) { return des_dev_field_count((const des_dev *)h, f); }
+int eng_set_clock(void *h, double dt, double t, long long s) { return des_dev_set_clock((des_dev *)h, dt, t, s); }
 int eng_init_geometry(void *h) { return des_dev_init_geometry((des_dev *)h); }
 int eng_compute_dt(void *h, double *dt) { return des_dev_compute_dt((des_dev *)h, dt); }
 int eng_step(void *h, int n, des_scalars *s) { return des_dev_step((des_dev *)h, n, s); }
@@ -50,7 +51,7 @@ int main(int argc, const char *argv[])
         return err ? err : DES_ERR_INTERNAL;
     }
     const des_engine_api api = { eng_create, eng_destroy, eng_upload, eng_download, eng_field_count,
-                                 eng_init_geometry, eng_compute_dt, eng_step, eng_check_nan, eng_quality,
+                                 eng_set_clock, eng_init_geometry, eng_compute_dt, eng_step, eng_check_nan, eng_quality,
                                  des_dev_last_error };
     des_run_stats st;
     int rc = des_run(host, &api, device, quiet, &st);

@@ -17,9 +17,14 @@ des_host *create_impl(const char *path, const char *text, const char *overrides,
         if (path) h->cfg.load(path, ov);
         else      h->cfg.load_string(text ? text : "", ov);
         des::build_params(h->cfg, h->params);
-        des::create_new_mesh(h->cfg, h->mesh, mesh_file ? mesh_file : "");
-        des::build_topology(h->mesh, h->params.vbc_types);
-        des::initial_conditions(h->cfg, h->params, h->mesh, h->fields);
+        if (h->cfg.b("sim.is_restarting")) {
+            des::restart_from_files(h->cfg, h->params, h->mesh, h->fields);
+            des::build_topology(h->mesh, h->params.vbc_types);
+        } else {
+            des::create_new_mesh(h->cfg, h->mesh, mesh_file ? mesh_file : "");
+            des::build_topology(h->mesh, h->params.vbc_types);
+            des::initial_conditions(h->cfg, h->params, h->mesh, h->fields);
+        }
         h->view = h->mesh.view();
         if (err) *err = DES_OK;
         return h;
@@ -67,6 +72,10 @@ const void *des_host_array(const des_host *h, const char *name, long long *count
         {"plstrain", h->fields.plstrain.data(), (long long)h->fields.plstrain.size()},
         {"viscosity", h->fields.viscosity.data(), (long long)h->fields.viscosity.size()},
         {"elemmarkers", h->fields.elemmarkers.data(), (long long)h->fields.elemmarkers.size()},
+        {"markerset.eta", h->fields.markers.eta.data(), (long long)h->fields.markers.eta.size()},
+        {"markerset.elem", h->fields.markers.elem.data(), (long long)h->fields.markers.elem.size()},
+        {"markerset.mattype", h->fields.markers.mattype.data(), (long long)h->fields.markers.mattype.size()},
+        {"markerset.id", h->fields.markers.id.data(), (long long)h->fields.markers.id.size()},
     };
     for (size_t i = 0; i < sizeof(t)/sizeof(t[0]); ++i)
         if (std::strcmp(name, t[i].n) == 0) { if (count) *count = t[i].c; return t[i].p; }

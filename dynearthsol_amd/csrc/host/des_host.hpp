@@ -86,9 +86,29 @@ void renumbering_mesh(const Config &cfg, HostMesh &m);
 // create_surface_info (mesh.cxx:2837-3329) and create_boundary_normals (bc.cxx:94-224)
 void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY]);
 
+// MarkerSet "markerset" (markerset.hpp:14-60).  Markers stay with the host: between remeshings
+// they only ride with their element, so the time step needs their per-element counts alone;
+// the set is kept for the output frames / checkpoints (write_save_file, write_chkpt_file).
+struct HostMarkers {
+    int nmarkers = 0, last_id = 0, reserved_space = 0;
+    std::vector<double> eta;        // shapefn, SoA [4][nmarkers]
+    std::vector<int> elem, mattype, id, genesis;
+    std::vector<double> time, z, distance, slope;
+};
+
+// What restart() (dynearthsol.cxx:231-435) restores besides the fields a fresh init() builds.
+struct RestartState {
+    bool active = false;
+    int frame = 0, steps = 0, info_display_next_step = 0;
+    double time = 0, dt = 0, max_global_vel_mag = 0, reference_frame_time = 0, last_remesh_time = 0;
+    std::vector<double> coord0, volume_old, edvacc_surf, dhacc, strain_rate, force, delta_plstrain;
+};
+
 struct HostFields {
+    RestartState restart;
     std::vector<double> vel, temperature, radiogenic, stress, strain, plstrain, viscosity;
     std::vector<int> elemmarkers;   // [nelem][nmat]
+    HostMarkers markers;
     double compensation_pressure = 0;
     double bottom_temperature = 0;
 };
@@ -96,6 +116,11 @@ struct HostFields {
 // init() after the mesh exists (dynearthsol.cxx:172-221): markers counts, temperature,
 // lithostatic stress, weak zone, initial viscosity.
 void initial_conditions(const Config &cfg, des_params &p, const HostMesh &m, HostFields &f);
+
+// restart() (dynearthsol.cxx:231-435): mesh, marker set and fields from <model>.save.N /
+// <model>.chkpt.N / <model>.info instead of create_new_mesh() + initial conditions.  Leaves the
+// mesh ready for build_topology().
+void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostFields &f);
 
 // ref_pressure (matprops.cxx:153-174)
 double ref_pressure(const des_params &p, double z);

@@ -135,8 +135,9 @@ void random_eta(double eta[4])
     }
 }
 
-// Only the per-element material counts reach the time-stepper; markers themselves stay
-// with the host (MarkerSet::random_markers, markerset.cxx:524-553; initial_mattype 666-700).
+// MarkerSet::random_markers + initial_mattype (markerset.cxx:524-553, 666-700).  Only the
+// per-element material counts reach the time-stepper; the markers themselves stay with the host
+// (same libc rand() sequence as the reference, so the set is the one the reference would build).
 void create_elemmarkers(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f)
 {
     const int ne = m.nelem, nmat = p.nmat;
@@ -145,33 +146,45 @@ void create_elemmarkers(const Config &cfg, const des_params &p, const HostMesh &
     const int mattype_option = cfg.i("ic.mattype_option");
     if (cfg.i("markers.init_marker_option") != 1)
         throw Error(31, "markers.init_marker_option != 1 (regularly spaced markers) is not offloaded");
-    if (mattype_option == 0) {
-        for (int e = 0; e < ne; ++e) {
-            int mt = (int)m.regattr[e];
-            if (mt < 0 || mt >= nmat) throw Error(11, "region attribute is not a valid material");
-            f.elemmarkers[(size_t)e*nmat + mt] = mpe;
-        }
-        return;
-    }
-    if (mattype_option != 1)
+    if (mattype_option != 0 && mattype_option != 1)
         throw Error(11, "Error: unknown ic.mattype_option");
-    const int nlayers = cfg.i("ic.num_mattype_layers");
-    std::vector<double> layer_mt = cfg.list("ic.layer_mattypes", nlayers);
-    std::vector<double> depths = cfg.list("ic.mattype_layer_depths", nlayers - 1);
-    if (!std::is_sorted(depths.begin(), depths.end()))
-        throw Error(11, "Error: the content of ic.mattype_layer_depths is not ordered from small to big values.");
+    std::vector<double> layer_mt, depths;
+    if (mattype_option == 1) {
+        const int nlayers = cfg.i("ic.num_mattype_layers");
+        layer_mt = cfg.list("ic.layer_mattypes", nlayers);
+        depths = cfg.list("ic.mattype_layer_depths", nlayers - 1);
+        if (!std::is_sorted(depths.begin(), depths.end()))
+            throw Error(11, "Error: the content of ic.mattype_layer_depths is not ordered from small to big values.");
+    }
+    HostMarkers &mk = f.markers;
+    const size_t nm = (size_t)ne * mpe;
+    mk.nmarkers = mk.last_id = (int)nm;
+    mk.reserved_space = (int)(nm * 2.0);                       // over_alloc_ratio, markerset.cxx:25
+    mk.eta.assign(4 * nm, 0.0);
+    mk.elem.assign(nm, 0); mk.mattype.assign(nm, 0); mk.id.assign(nm, 0); mk.genesis.assign(nm, 0);
+    mk.time.assign(nm, 0.0); mk.z.assign(nm, 0.0); mk.distance.assign(nm, 0.0); mk.slope.assign(nm, 0.0);
+
     unsigned seed = (unsigned)cfg.i("markers.random_seed");
     srand(seed ? seed : 1u);
+    size_t im = 0;
     for (int e = 0; e < ne; e++)
-        for (int k = 0; k < mpe; k++) {
+        for (int k = 0; k < mpe; k++, im++) {
             double eta[4];
             random_eta(eta);
-            double z = 0;
-            for (int j = 0; j < 4; j++)
-                z += m.coord[(size_t)2*m.nnode + m.conn[(size_t)j*ne + e]] * eta[j];
-            int mt = (int)layer_mt[layer_mt.size() - 1];
-            for (size_t i = 0; i < depths.size(); ++i)
-                if (z >= -p.zlength * depths[i]) { mt = (int)layer_mt[i]; break; }
+            int mt;
+            if (mattype_option == 0) {
+                mt = (int)m.regattr[e];
+                if (mt < 0 || mt >= nmat) throw Error(11, "region attribute is not a valid material");
+            } else {
+                double z = 0;
+                for (int j = 0; j < 4; j++)
+                    z += m.coord[(size_t)2*m.nnode + m.conn[(size_t)j*ne + e]] * eta[j];
+                mt = (int)layer_mt[layer_mt.size() - 1];
+                for (size_t i = 0; i < depths.size(); ++i)
+                    if (z >= -p.zlength * depths[i]) { mt = (int)layer_mt[i]; break; }
+            }
+            for (int j = 0; j < 4; j++) mk.eta[(size_t)j*nm + im] = eta[j];
+            mk.elem[im] = e; mk.mattype[im] = mt; mk.id[im] = (int)im;
             ++f.elemmarkers[(size_t)e*nmat + mt];
         }
 }

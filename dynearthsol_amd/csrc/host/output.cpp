@@ -26,11 +26,27 @@ long long now_ns()
         std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// binaryio.cxx:44-60: keep a previous file of that name as .old, .old2, ...
+void rename_to_old_backup(const std::string &fpath)
+{
+    int max_n = 0;
+    for (int n = 1; n <= max_n + 200; ++n) {
+        std::string candidate = fpath + ".old" + (n == 1 ? "" : std::to_string(n));
+        if (std::FILE *f = std::fopen(candidate.c_str(), "r")) { std::fclose(f); max_n = n; }
+    }
+    const int next_n = max_n + 1;
+    const std::string backup = fpath + ".old" + (next_n == 1 ? "" : std::to_string(next_n));
+    if (std::rename(fpath.c_str(), backup.c_str()) == 0)
+        std::fprintf(stderr, "[Runtime][IO] Renamed '%s' -> '%s' (preserving previous output)\n", fpath.c_str(), backup.c_str());
+}
+
 // binaryio.cxx:64-204
 class FrameFile {
 public:
-    explicit FrameFile(const std::string &filename) : header_(headerlen, '\0'), eof_pos_(headerlen)
+    explicit FrameFile(const std::string &filename, bool rename_if_exists = false)
+        : header_(headerlen, '\0'), eof_pos_(headerlen)
     {
+        if (rename_if_exists) rename_to_old_backup(filename);
         f_ = std::fopen(filename.c_str(), "wb");
         if (!f_) throw des::Error(20, "Error: cannot open file: " + filename);             // EXIT_IO_OPEN
         const std::string rev = "# DynEarthSol ndims=3 revision=4\n";
@@ -113,8 +129,10 @@ struct des_output {
     long long start_time;
     bool is_averaged;
     int average_interval;
-    int frame;
+    int frame, start_frame;
     bool quiet;
+    bool has_marker_output;
+    bool may_overwrite;         // same-name restart (output.cxx:30-31)
 };
 
 extern "C" {
@@ -127,8 +145,11 @@ des_output *des_output_create(const des_host *host, int start_frame)
     o->start_time = now_ns();
     o->is_averaged = host->cfg.b("sim.is_outputting_averaged_fields");
     o->average_interval = host->cfg.i("mesh.quality_check_step_interval");
-    o->frame = start_frame;
+    o->frame = o->start_frame = start_frame;
+    o->may_overwrite = host->cfg.b("sim.is_restarting") &&
+                       o->modelname == host->cfg.s("sim.restarting_from_modelname");
     o->quiet = false;
+    o->has_marker_output = host->cfg.b("sim.has_marker_output");
     return o;
 }
 
@@ -142,6 +163,23 @@ static void write_info(des_output *o, const des_frame *f, double dt, long long r
     std::snprintf(buffer, 255, "%6d\t%10d\t%12.6e\t%12.4e\t%12.6e\t%8d\t%8d\t%8d\n",
                   o->frame, (int)f->steps, f->time, dt, run_time_ns * 1e-9, m.nnode, m.nelem, m.nseg);
     const std::string filename = o->modelname + ".info";
+    // first output of a same-name restart: keep only the rows of earlier frames (output.cxx:51-72)
+    if (o->may_overwrite && o->frame == o->start_frame) {
+        std::vector<std::string> kept_lines;
+        if (std::FILE *r = std::fopen(filename.c_str(), "r")) {
+            char line[256];
+            while (std::fgets(line, sizeof(line), r)) {
+                int f_col;
+                if (std::sscanf(line, "%d", &f_col) == 1 && f_col < o->start_frame) kept_lines.push_back(line);
+            }
+            std::fclose(r);
+        }
+        rename_to_old_backup(filename);
+        if (std::FILE *w = std::fopen(filename.c_str(), "w")) {
+            for (const std::string &line : kept_lines) std::fputs(line.c_str(), w);
+            std::fclose(w);
+        }
+    }
     std::FILE *fp = std::fopen(filename.c_str(), o->frame == 0 ? "w" : "a");
     if (!fp) throw des::Error(20, "Error: cannot open file '" + filename + "' for writing");
     if (std::fputs(buffer, fp) == EOF) { std::fclose(fp); throw des::Error(21, "Error: failed writing to file '" + filename + "'"); }
@@ -167,7 +205,7 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
 
         char filename[256];
         std::snprintf(filename, 255, "%s.save.%06d", o->modelname.c_str(), o->frame);
-        FrameFile bin(filename);
+        FrameFile bin(filename, o->may_overwrite && o->frame == o->start_frame);
 
         bin.array2d(f->coord, 3, "coordinate", nn);
         bin.array2d(m.conn.data(), 4, "connectivity", ne);
@@ -248,6 +286,32 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
         bin.array2d(f->force, 3, "force", nn);
         bin.array2d(f->coord0, 3, "coord0", nn);
         bin.array(m.bcflag.data(), "bcflag", nn);
+
+        if (o->has_marker_output) {
+            // MarkerSet::write_save_file (markerset.cxx:939-970)
+            const des::HostMarkers &mk = h->fields.markers;
+            const std::size_t nm = (std::size_t)mk.nmarkers;
+            const int itmp[1] = { mk.nmarkers };
+            bin.array(itmp, "markerset size", 1);
+            tmp.assign(3 * nm, 0.0);                              // calculate_marker_coord (:989-1007)
+            for (std::size_t n = 0; n < nm; ++n)
+                for (int d = 0; d < 3; ++d) {
+                    double sum = 0;
+                    for (int k = 0; k < 4; ++k)
+                        sum += f->coord[(std::size_t)d * nn + m.conn[(std::size_t)k * ne + mk.elem[n]]] * mk.eta[(std::size_t)k * nm + n];
+                    tmp[n * 3 + d] = sum;
+                }
+            bin.array(tmp.data(), "markerset.coord", 3 * nm);
+            bin.array2d(mk.eta.data(), 4, "markerset.eta", nm);
+            bin.array(mk.elem.data(), "markerset.elem", nm);
+            bin.array(mk.mattype.data(), "markerset.mattype", nm);
+            bin.array(mk.id.data(), "markerset.id", nm);
+            bin.array(mk.time.data(), "markerset.time", nm);
+            bin.array(mk.z.data(), "markerset.z", nm);
+            bin.array(mk.distance.data(), "markerset.distance", nm);
+            bin.array(mk.slope.data(), "markerset.slope", nm);
+            bin.array(mk.genesis.data(), "markerset.genesis", nm);
+        }
         bin.close();
 
         write_info(o, f, dt, run_time_ns);
@@ -277,7 +341,7 @@ int des_output_write_checkpoint(des_output *o, const des_frame *f)
         const des::HostMesh &m = h->mesh;
         char filename[256];
         std::snprintf(filename, 255, "%s.chkpt.%06d", o->modelname.c_str(), o->frame);
-        FrameFile bin(filename);
+        FrameFile bin(filename, o->may_overwrite && o->frame == o->start_frame);
         bin.scalar(f->time, "time");
         bin.scalar(f->info_display_next_step, "info_display_next_step");
         bin.scalar(h->fields.compensation_pressure, "compensation_pressure");
@@ -291,6 +355,12 @@ int des_output_write_checkpoint(des_output *o, const des_frame *f)
         bin.array(f->edvacc_surf, "dv surface acc", m.conn_surf.size() / 4);
         bin.array(f->dhacc, "dhacc", (std::size_t)m.nnode);
         bin.array(f->volume_old, "volume_old", (std::size_t)m.nelem);
+        {   // MarkerSet::write_chkpt_file (markerset.cxx:877-891)
+            const des::HostMarkers &mk = h->fields.markers;
+            const int itmp[3] = { mk.nmarkers, mk.last_id, mk.reserved_space };
+            bin.array(itmp, "markerset size", 3);
+            bin.array(mk.genesis.data(), "markerset.genesis", (std::size_t)mk.nmarkers);
+        }
         // not in the reference's file (it rebuilds the counts from its marker sets)
         bin.array(f->elemmarkers, "elemmarkers", (std::size_t)m.nelem * h->params.nmat);
         return DES_OK;

@@ -40,6 +40,7 @@ struct Run {
     bool averaged;
     int info_display_next_step;
     double reference_frame_time, last_remesh_time;
+    double restored_vmax;         // max_global_vel_mag of the checkpoint, until compute_dt renews it
 
     void check(int rc, const char *what)
     {
@@ -66,6 +67,7 @@ struct Run {
         std::vector<int> markers((size_t)api->field_count(eng, DES_F_ELEMMARKERS));
         check(api->download(eng, DES_F_ELEMMARKERS, markers.data(), (long long)markers.size()), "download");
         des_frame f = des_frame();
+        if (sc.max_global_vel_mag == 0 && restored_vmax != 0) sc.max_global_vel_mag = restored_vmax;
         f.steps = sc.steps; f.time = sc.time; f.dt = sc.dt; f.max_global_vel_mag = sc.max_global_vel_mag;
         f.coord = coord.data(); f.vel = vel.data(); f.temperature = T.data(); f.radiogenic = radio.data();
         f.plstrain = pls.data(); f.delta_plstrain = dpls.data(); f.strain_rate = edot.data();
@@ -117,8 +119,6 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         const des::Config &cfg = host->cfg;
         const des_params &p = host->params;
         const des::HostMesh &m = host->mesh;
-        if (cfg.b("sim.is_restarting")) throw des::Error(31, "sim.is_restarting is not offloaded");
-
         const int max_steps = cfg.given("sim.max_steps") ? cfg.i("sim.max_steps") : std::numeric_limits<int>::max();
         const double max_time_in_yr = cfg.given("sim.max_time_in_yr") ? cfg.d("sim.max_time_in_yr") : std::numeric_limits<double>::max();
         const int output_step_interval = cfg.given("sim.output_step_interval") ? cfg.i("sim.output_step_interval") : std::numeric_limits<int>::max();
@@ -134,10 +134,17 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         r.eng = api->create(device, &p, &host->view, &err);
         if (!r.eng) throw des::Error(err ? err : 31, std::string("engine: ") + (api->last_error ? api->last_error() : ""));
         const des::HostFields &f = host->fields;
-        r.check(api->upload(r.eng, DES_F_COORD, m.coord.data(), (long long)m.coord.size()), "upload coord");
-        r.check(api->upload(r.eng, DES_F_COORD0, m.coord.data(), (long long)m.coord.size()), "upload coord0");
+        const des::RestartState &rs = f.restart;
+        auto up = [&](int field, const std::vector<double> &v, const char *what) {
+            r.check(api->upload(r.eng, field, v.data(), (long long)v.size()), what);
+        };
+        up(DES_F_COORD, m.coord, "upload coord");
+        up(DES_F_COORD0, rs.active ? rs.coord0 : m.coord, "upload coord0");
         r.check(api->upload(r.eng, DES_F_ELEMMARKERS, f.elemmarkers.data(), (long long)f.elemmarkers.size()), "upload elemmarkers");
-        r.check(api->upload(r.eng, DES_F_VEL, f.vel.data(), (long long)f.vel.size()), "upload vel");
+        up(DES_F_VEL, f.vel, "upload vel");
+        // restart() computes the masses with the restored temperature (dynearthsol.cxx:394-396);
+        // init() does it while T is still 0 (:175-186)
+        if (rs.active) up(DES_F_TEMPERATURE, f.temperature, "upload temperature");
         r.check(api->init_geometry(r.eng), "init_geometry");
         r.check(api->upload(r.eng, DES_F_TEMPERATURE, f.temperature.data(), (long long)f.temperature.size()), "upload temperature");
         r.check(api->upload(r.eng, DES_F_RADIOGENIC, f.radiogenic.data(), (long long)f.radiogenic.size()), "upload radiogenic");
@@ -145,13 +152,44 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         r.check(api->upload(r.eng, DES_F_STRAIN, f.strain.data(), (long long)f.strain.size()), "upload strain");
         r.check(api->upload(r.eng, DES_F_PLSTRAIN, f.plstrain.data(), (long long)f.plstrain.size()), "upload plstrain");
         r.check(api->upload(r.eng, DES_F_VISCOSITY, f.viscosity.data(), (long long)f.viscosity.size()), "upload viscosity");
-        double dt0 = 0;
-        r.check(api->compute_dt(r.eng, &dt0), "compute_dt");
+        if (!rs.active) {
+            double dt0 = 0;
+            r.check(api->compute_dt(r.eng, &dt0), "compute_dt");
+            r.info_display_next_step = info_display_step_interval;               // dynearthsol.cxx:636
+            r.last_remesh_time = 0; r.reference_frame_time = 0;
+        } else {
+            // the rest of restart(): previous-step volume, surface accumulators, fields that are
+            // "not required for restarting, yet" (:366-392), and the clock from the checkpoint
+            up(DES_F_VOLUME_OLD, rs.volume_old, "upload volume_old");
+            if (!rs.edvacc_surf.empty()) up(DES_F_EDVACC_SURF, rs.edvacc_surf, "upload edvacc_surf");
+            up(DES_F_DHACC, rs.dhacc, "upload dhacc");
+            up(DES_F_STRAIN_RATE, rs.strain_rate, "upload strain_rate");
+            up(DES_F_FORCE, rs.force, "upload force");
+            up(DES_F_DELTA_PLSTRAIN, rs.delta_plstrain, "upload delta_plstrain");
+            r.check(api->set_clock(r.eng, rs.dt, rs.time, rs.steps), "set_clock");
+            r.info_display_next_step = rs.info_display_next_step;
+            if (rs.steps % qcsi == 0 && rs.steps >= r.info_display_next_step)
+                r.info_display_next_step = rs.steps + info_display_step_interval;     // :354-356
+            r.last_remesh_time = rs.last_remesh_time; r.reference_frame_time = rs.reference_frame_time;
+            r.restored_vmax = rs.max_global_vel_mag;
+        }
         r.check(api->step(r.eng, 0, &r.sc), "clock");
 
-        r.out = des_output_create(host, 0);
+        r.out = des_output_create(host, rs.active ? rs.frame : 0);
         des::output_set_quiet(r.out, quiet != 0);
-        r.info_display_next_step = 0; r.last_remesh_time = 0; r.reference_frame_time = 0;
+
+        if (!rs.active && cfg.b("sim.has_initial_checkpoint")) {
+            // var.output->write_checkpoint(param, var) before the first frame (:646-647)
+            std::vector<double> vold = r.get(DES_F_VOLUME_OLD), edv = r.get(DES_F_EDVACC_SURF), dhacc = r.get(DES_F_DHACC);
+            des_frame cf = des_frame();
+            cf.time = r.sc.time; cf.dt = r.sc.dt; cf.max_global_vel_mag = r.sc.max_global_vel_mag;
+            cf.volume_old = vold.data(); cf.edvacc_surf = edv.data(); cf.dhacc = dhacc.data();
+            cf.elemmarkers = f.elemmarkers.data();
+            cf.info_display_next_step = r.info_display_next_step;
+            int rc = des_output_write_checkpoint(r.out, &cf);
+            if (rc) throw des::Error(rc, des::output_last_error());
+            st.checkpoints++;
+        }
 
         r.write(true, false);                                     // var.output->write_exact(var)
         st.frames++;

@@ -19,6 +19,7 @@ DESTROY_T = C.CFUNCTYPE(None, _vp)
 UPLOAD_T = C.CFUNCTYPE(_i, _vp, _i, _vp, _ll)
 DOWNLOAD_T = C.CFUNCTYPE(_i, _vp, _i, _vp, _ll)
 COUNT_T = C.CFUNCTYPE(_ll, _vp, _i)
+CLOCK_T = C.CFUNCTYPE(_i, _vp, _d, _d, _ll)
 INITGEOM_T = C.CFUNCTYPE(_i, _vp)
 DT_T = C.CFUNCTYPE(_i, _vp, C.POINTER(_d))
 STEP_T = C.CFUNCTYPE(_i, _vp, _i, C.POINTER(DesScalars))
@@ -30,7 +31,7 @@ ERR_T = C.CFUNCTYPE(C.c_char_p)
 class EngineApi(C.Structure):
     """des_engine_api"""
     _fields_ = [("create", CREATE_T), ("destroy", DESTROY_T), ("upload", UPLOAD_T), ("download", DOWNLOAD_T),
-                ("field_count", COUNT_T), ("init_geometry", INITGEOM_T), ("compute_dt", DT_T), ("step", STEP_T),
+                ("field_count", COUNT_T), ("set_clock", CLOCK_T), ("init_geometry", INITGEOM_T), ("compute_dt", DT_T), ("step", STEP_T),
                 ("check_nan", NAN_T), ("mesh_quality", QUALITY_T), ("last_error", ERR_T)]
 
 
@@ -49,6 +50,7 @@ def api_from_lib(lib, prefix, create=None):
     api.upload = g("upload", UPLOAD_T)
     api.download = g("download", DOWNLOAD_T)
     api.field_count = g("field_count", COUNT_T)
+    api.set_clock = g("set_clock", CLOCK_T)
     api.init_geometry = g("init_geometry", INITGEOM_T)
     api.compute_dt = g("compute_dt", DT_T)
     api.step = g("step", STEP_T)

@@ -29,7 +29,9 @@ const des_mesh *des_host_mesh(const des_host *h);
 
 /* Named host arrays in the reference's SoA layout: "coord", "vel", "temperature",
  * "radiogenic", "stress", "strain", "plstrain", "viscosity" (double); "elemmarkers",
- * "connectivity", "segment", "segflag" (int32). Returns NULL for an unknown name. */
+ * "connectivity", "segment", "segflag" (int32); the marker set the host keeps:
+ * "markerset.eta" (double, SoA [4][nmarkers]), "markerset.elem" / ".mattype" / ".id" (int32).
+ * Returns NULL for an unknown name. */
 const void *des_host_array(const des_host *h, const char *name, long long *count);
 
 /* typed access to any .cfg option after defaults/normalisation (as strings are parsed) */

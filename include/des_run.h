@@ -46,8 +46,8 @@ int des_output_frame(const des_output *o);            /* number of the next fram
 /* Output::write (exact = 0: averaged variants when the option is on) / write_exact (exact = 1).
  * Writes <modelname>.save.NNNNNN, appends the .info row, prints the "Output #" line. */
 int des_output_write(des_output *o, const des_frame *f, int exact);
-/* Output::write_checkpoint: <modelname>.chkpt.NNNNNN (marker sets stay with the host and are
- * not written; "elemmarkers" is added so a device run restarts from its own checkpoint) */
+/* Output::write_checkpoint: <modelname>.chkpt.NNNNNN, marker set included (the host keeps it);
+ * an extra "elemmarkers" array carries the per-element counts the device works with */
 int des_output_write_checkpoint(des_output *o, const des_frame *f);
 
 /* Entry points of an engine, same signatures and meaning as include/des_dev.h. */
@@ -57,6 +57,7 @@ typedef struct des_engine_api {
     int (*upload)(void *h, int field, const void *host, long long count);
     int (*download)(void *h, int field, void *host, long long count);
     long long (*field_count)(const void *h, int field);
+    int (*set_clock)(void *h, double dt, double time, long long steps);
     int (*init_geometry)(void *h);
     int (*compute_dt)(void *h, double *dt);
     int (*step)(void *h, int nsteps, des_scalars *out);

@@ -75,9 +75,10 @@ def test_frames_info_and_checkpoint_follow_the_reference_schedule(in_tmp):
           "sim.checkpoint_frame_interval = 2\nmesh.quality_check_step_interval = 10\n")
     host = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=ov)
     st = driver.run(host, api=oracle_api())
-    assert (st.steps, st.frames, st.checkpoints, st.exit_code) == (60, 4, 1, 0)
+    # chkpt.000000: sim.has_initial_checkpoint defaults to yes (input.cxx:56)
+    assert (st.steps, st.frames, st.checkpoints, st.exit_code) == (60, 4, 2, 0)
     files = sorted(os.listdir(in_tmp))
-    assert files == ["run1.chkpt.000002", "run1.info", "run1.save.000000", "run1.save.000001",
+    assert files == ["run1.chkpt.000000", "run1.chkpt.000002", "run1.info", "run1.save.000000", "run1.save.000001",
                      "run1.save.000002", "run1.save.000003"]
     info = np.loadtxt("run1.info").reshape(-1, 8)                    # output.cxx:45-47
     assert info[:, 0].tolist() == [0, 1, 2, 3] and info[:, 1].tolist() == [0, 20, 40, 60]
@@ -162,13 +163,57 @@ def test_time_triggered_output_fires_at_the_reference_step(in_tmp):
     assert len(expect) >= 3
 
 
+@pytest.mark.parametrize("averaged", ["no", "yes"])
+def test_restart_continues_bit_for_bit(in_tmp, averaged):
+    """restart() (dynearthsol.cxx:231-435) from our own frame + checkpoint: 20 steps, restart, 20
+    more == 40 straight, to the bit, in every array of the final frame."""
+    base = ("sim.max_steps = 40\nsim.output_step_interval = 20\nsim.checkpoint_frame_interval = 1\n"
+            "mesh.quality_check_step_interval = 10\nsim.is_outputting_averaged_fields = %s\n" % averaged)
+    kw = dict(cfgs.EVP, nmat=2)
+    driver.run(des.Host(cfg_text=cfgs.make(**kw), overrides=base + "sim.modelname = a\n"), api=oracle_api())
+    hb = des.Host(cfg_text=cfgs.make(**kw), overrides=base + "sim.modelname = b\nsim.is_restarting = yes\n"
+                  "sim.restarting_from_modelname = a\nsim.restarting_from_frame = 1\n")
+    assert (hb.nnode, hb.nelem) == (des.Host(cfg_text=cfgs.make(**kw)).nnode, des.Host(cfg_text=cfgs.make(**kw)).nelem)
+    st = driver.run(hb, api=oracle_api())
+    assert (st.steps, st.frames) == (40, 2)
+    assert sorted(f for f in os.listdir(in_tmp) if f.startswith("b.")) == \
+        ["b.chkpt.000002", "b.info", "b.save.000001", "b.save.000002"]
+    a, b = read_frame("a.save.000002"), read_frame("b.save.000002")
+    assert sorted(a) == sorted(b)
+    for name in a:
+        if name != "walltime_sec":
+            assert np.array_equal(a[name], b[name]), name
+    ca, cb = read_frame("a.chkpt.000002"), read_frame("b.chkpt.000002")
+    for name in ca:
+        assert np.array_equal(ca[name], cb[name]), name
+    # the frame written at the restart itself is the exact (un-averaged) state it started from
+    a1, b1 = read_frame("a.save.000001"), read_frame("b.save.000001")
+    for name in ("coordinate", "velocity", "stress", "strain", "temperature", "plastic strain", "markerset.eta"):
+        assert np.array_equal(a1[name], b1[name]), name
+
+
+def test_same_name_restart_keeps_earlier_info_rows(in_tmp):
+    base = ("sim.modelname = m\nsim.max_steps = 40\nsim.output_step_interval = 10\nsim.checkpoint_frame_interval = 1\n"
+            "mesh.quality_check_step_interval = 10\n")
+    driver.run(des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=base), api=oracle_api())
+    first = open("m.info").read().splitlines()
+    assert len(first) == 5
+    h = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=base + "sim.is_restarting = yes\n"
+                 "sim.restarting_from_modelname = m\nsim.restarting_from_frame = 2\n")
+    driver.run(h, api=oracle_api())
+    rows = np.loadtxt("m.info").reshape(-1, 8)
+    assert rows[:, 0].tolist() == [0, 1, 2, 3, 4] and rows[:, 1].tolist() == [0, 10, 20, 30, 40]
+    assert open("m.info").read().splitlines()[:2] == first[:2]
+    assert os.path.exists("m.info.old") and os.path.exists("m.save.000002.old")
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "Dynearthsol.py")),
                     reason="the reference's reader is only present in the build container")
 def test_reference_reader_reads_our_frames(in_tmp):
     ov = ("sim.modelname = refread\nsim.max_steps = 20\nsim.output_step_interval = 10\n"
           "sim.is_outputting_averaged_fields = yes\nmesh.quality_check_step_interval = 10\n"
           "sim.checkpoint_frame_interval = 1\n")
-    host = des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=ov)
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, nmat=2)), overrides=ov)
     driver.run(host, api=oracle_api())
     sys.path.insert(0, REF)
     try:
@@ -177,7 +222,7 @@ def test_reference_reader_reads_our_frames(in_tmp):
         sys.path.remove(REF)
     d = refpy.Dynearthsol("refread")
     assert d.ndims == 3 and d.revision == 4 and d.frames == [0, 1, 2] and d.steps == [0, 10, 20]
-    ora, sc = straight_run(des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=ov), 20)
+    ora, sc = straight_run(des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, nmat=2)), overrides=ov), 20)
     nn, ne = host.nnode, host.nelem
     assert np.array_equal(d.read_field(2, "coordinate").T.ravel(), ora.download("COORD"))
     assert np.array_equal(d.read_field(2, "connectivity").T.ravel(), host.array("connectivity"))
@@ -188,6 +233,19 @@ def test_reference_reader_reads_our_frames(in_tmp):
     for name in ("velocity", "velocity averaged", "force", "coord0", "strain", "strain-rate", "plastic strain",
                  "plastic strain-rate", "density", "material", "mesh quality", "radiogenic source", "pore pressure"):
         assert np.all(np.isfinite(d.read_field(2, name))), name
+    # the marker set (MarkerSet::write_save_file): counts per element and material are the
+    # elemmarkers the device works with; marker positions are inside their elements
+    mk = d.read_markers(2, "markerset")
+    nmat = host.params.nmat
+    assert mk["size"] == ne * host.cfg_int("markers.markers_per_element")
+    counts = np.zeros((ne, nmat), np.int32)
+    np.add.at(counts, (mk["markerset.elem"], mk["markerset.mattype"]), 1)
+    assert np.array_equal(counts.ravel(), host.array("elemmarkers"))
+    assert np.allclose(mk["markerset.eta"].sum(axis=1), 1.0) and mk["markerset.eta"].min() >= 0
+    coord = d.read_field(2, "coordinate"); conn = d.read_field(2, "connectivity")
+    expect = np.einsum("mkd,mk->md", coord[conn[mk["markerset.elem"]]], mk["markerset.eta"])
+    assert np.allclose(mk["markerset.coord"], expect, rtol=1e-14, atol=1e-6)
+    assert np.array_equal(mk["markerset.id"], np.arange(mk["size"]))
     rows = refpy.scan_frames("refread")                       # the frame-embedded .info scalars
     assert [r["steps"] for r in rows] == [0, 10, 20] and rows[2]["time"] == sc.time
     assert rows[2]["nnode"] == nn and rows[2]["nelem"] == ne

@@ -29,7 +29,7 @@ def test_executable_writes_the_frames_the_oracle_loop_writes(in_tmp):
     assert "Output # 2" in out.stdout and "Ending simulation." in out.stdout
     host = des.Host(cfg_path="model.cfg", overrides="sim.modelname = cpu\n")
     st = driver.run(host, api=oracle_api())
-    assert st.frames == 3 and st.checkpoints == 1
+    assert st.frames == 3 and st.checkpoints == 2
     for frame in (0, 1, 2):
         a, b = read_frame("gpu.save.%06d" % frame), read_frame("cpu.save.%06d" % frame)
         assert sorted(a) == sorted(b)
@@ -70,3 +70,19 @@ def test_mesh_quality_reductions_match_the_oracle():
         res.append((q.small_elem, q.bottom_node, q.worst_elem, q.worst_quality))
     assert res[0] == res[1]
     assert res[0][0] >= 0 and res[0][2] >= 0 and 0 < res[0][3] < 1
+
+
+def test_executable_restarts_from_its_own_checkpoint(in_tmp):
+    base = ("sim.max_steps = 40\nsim.output_step_interval = 20\nsim.checkpoint_frame_interval = 1\n"
+            "mesh.quality_check_step_interval = 10\nsim.is_outputting_averaged_fields = yes\n")
+    kw = dict(cfgs.EVP, nmat=2)
+    open("a.cfg", "w").write(cfgs.apply_overrides(cfgs.make(**kw), base + "sim.modelname = a\n"))
+    open("b.cfg", "w").write(cfgs.apply_overrides(cfgs.make(**kw), base + "sim.modelname = b\nsim.is_restarting = yes\n"
+                                                  "sim.restarting_from_modelname = a\nsim.restarting_from_frame = 1\n"))
+    for cfg in ("a.cfg", "b.cfg"):
+        out = subprocess.run([EXE, cfg, "--quiet"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+    a, b = read_frame("a.save.000002"), read_frame("b.save.000002")
+    for name in a:
+        if name != "walltime_sec":
+            assert np.array_equal(a[name], b[name]), name
