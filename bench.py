@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: keep the 1.1M-tet mesh and cut it N ways (default: weak scaling, "
                          "the box grows N times in x so every GPU keeps 1.1M tets)")
+    ap.add_argument("--averaged-fields", action="store_true",
+                    help="also run Output::average_fields inside the step (sim.is_outputting_averaged_fields = yes)")
     ap.add_argument("--rheology", default="elasto-visco-plastic",
                     help="diagnostic only: the headline workload is elasto-visco-plastic")
     args = ap.parse_args()
@@ -136,8 +138,10 @@ def main():
     # weak scaling: the test-3d-big box is repeated N times along x (same resolution), then cut
     # into N slabs of contiguous node ids -- every GPU holds ~1.1M tets plus one ghost layer
     xlen = 400e3 * (1 if args.strong else world)
-    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)),
-                    overrides=None if args.rheology == "elasto-visco-plastic" else "mat.rheology_type = %s\n" % args.rheology)
+    overrides = "" if args.rheology == "elasto-visco-plastic" else "mat.rheology_type = %s\n" % args.rheology
+    if args.averaged_fields:
+        overrides += "sim.is_outputting_averaged_fields = yes\nmesh.quality_check_step_interval = 100\n"
+    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)), overrides=overrides or None)
     device = int(os.environ.get("DES_BENCH_DEVICE", local_rank))
     if world == 1:
         dev = des.DeviceEngine(host, device=device)
@@ -196,6 +200,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "test-3d-big.cfg box 400x20x10 km, " + args.rheology + ", thermal+NMD+surface diffusion on, "
+                        + ("averaged output fields on, " if args.averaged_fields else "")
+                        +
                         "regular 5-tet mesh %d tets / %d nodes in total" % (ne, nn),
             "nelem": ne, "nnode": nn, "nelem_local_rank0": ne_local,
             "parallelism": "single GPU" if world == 1 else

@@ -429,6 +429,12 @@ __global__ void k_dt_finalize(const des_params *p, DevClock *clk, const double *
 #ifndef DES_TILE_N2
 #define DES_TILE_N2 2048
 #endif
+// DES_PIPE: the record gathers of incidence tile t+1 are issued before the sums of tile t are
+// formed from LDS (registers hold them across the sum), so HBM/L2 latency overlaps the LDS phase
+// instead of alternating with it.
+#ifndef DES_PIPE
+#define DES_PIPE 1
+#endif
 __device__ __forceinline__ int lds_slot(int j) { return j + (j >> 3); }
 #define DES_TILE_LDS(T) ((T) + (T) / 8 + 1)
 
@@ -471,8 +477,41 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     int r0 = ke, r1 = ke;
     if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0, yms = 0;
+#if DES_PIPE
+    constexpr int PER = TILE / DES_BLOCK;
+    static_assert(TILE % DES_BLOCK == 0, "tile must be a multiple of the block");
+    d4 rr[PER]; double r3[PER];
+    auto fetch = [&](int t0, int tn) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * DES_BLOCK;
+            if (j < tn) {
+                const int pk = sup_pack[t0 + j];
+                const int e = pk >> 2;
+                rr[u] = mrec[e];
+                if (FULL && thermal) r3[u] = (&ttmp[e].x)[pk & 3];
+                else if (need_ym)    r3[u] = elem_ym(p, props, ne, e);
+            }
+        }
+    };
+    if (kb < ke) fetch(kb, min(TILE, ke - kb));
+#endif
     for (int t0 = kb; t0 < ke; t0 += TILE) {
         const int tn = min(TILE, ke - t0);
+#if DES_PIPE
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * DES_BLOCK;
+            if (j < tn) {
+                const int sl = lds_slot(j);
+                lds[0][sl] = rr[u].x; lds[1][sl] = rr[u].z; lds[2][sl] = rr[u].w;
+                if ((FULL && thermal) || need_ym) lds[3][sl] = r3[u];
+                if (!CONSTM) lds[NPL - 1][sl] = rr[u].y;
+            }
+        }
+        __syncthreads();
+        if (t0 + TILE < ke) fetch(t0 + TILE, min(TILE, ke - t0 - TILE));
+#else
         for (int j = threadIdx.x; j < tn; j += DES_BLOCK) {
             const int pk = sup_pack[t0 + j];
             const int e = pk >> 2;
@@ -484,6 +523,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
             if (!CONSTM) lds[NPL - 1][sl] = r.y;
         }
         __syncthreads();
+#endif
         const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
         for (int j = a; j < b; ++j) {
             const int sl = lds_slot(j);
@@ -649,11 +689,33 @@ N2_nmd_gather(int o0, int nn, int nblocks, const int *__restrict__ sup_idx, cons
     int r0 = ke, r1 = ke;
     if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double acc = 0;
+#if DES_PIPE
+    constexpr int PER = DES_TILE_N2 / DES_BLOCK;
+    double rv[PER];
+    auto fetch = [&](int t0, int tn) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * DES_BLOCK;
+            if (j < tn) rv[u] = etmp2[sup_pack[t0 + j] >> 2];
+        }
+    };
+    if (kb < ke) fetch(kb, min(TILE, ke - kb));
+#endif
     for (int t0 = kb; t0 < ke; t0 += TILE) {
         const int tn = min(TILE, ke - t0);
+#if DES_PIPE
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * DES_BLOCK;
+            if (j < tn) lds[lds_slot(j)] = rv[u];
+        }
+        __syncthreads();
+        if (t0 + TILE < ke) fetch(t0 + TILE, min(TILE, ke - t0 - TILE));
+#else
         for (int j = threadIdx.x; j < tn; j += DES_BLOCK)
             lds[lds_slot(j)] = etmp2[sup_pack[t0 + j] >> 2];
         __syncthreads();
+#endif
         const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
         for (int j = a; j < b; ++j) acc += lds[lds_slot(j)];
         __syncthreads();
@@ -909,8 +971,37 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
     int r0 = ke, r1 = ke;
     if (n < nn_own_end) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
+#if DES_PIPE
+    constexpr int PER = DES_TILE_N3 / DES_BLOCK;
+    static_assert(DES_TILE_N3 % DES_BLOCK == 0, "tile must be a multiple of the block");
+    double q0[PER], q1[PER], q2[PER];
+    auto fetch = [&](int t0, int tn) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * DES_BLOCK;
+            if (j < tn) {
+                const int pk = sup_pack[t0 + j];
+                const double *tr = ftmp + (size_t)(pk >> 2) * 12 + (pk & 3) * 3;
+                q0[u] = tr[0]; q1[u] = tr[1]; q2[u] = tr[2];
+            }
+        }
+    };
+    if (kb < ke) fetch(kb, min(DES_TILE_N3, ke - kb));
+#endif
     for (int t0 = kb; t0 < ke; t0 += DES_TILE_N3) {
         const int tn = min(DES_TILE_N3, ke - t0);
+#if DES_PIPE
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = threadIdx.x + u * DES_BLOCK;
+            if (j < tn) {
+                const int sl = lds_slot(j);
+                lds[0][sl] = q0[u]; lds[1][sl] = q1[u]; lds[2][sl] = q2[u];
+            }
+        }
+        __syncthreads();
+        if (t0 + DES_TILE_N3 < ke) fetch(t0 + DES_TILE_N3, min(DES_TILE_N3, ke - t0 - DES_TILE_N3));
+#else
         for (int j = threadIdx.x; j < tn; j += DES_BLOCK) {
             const int pk = sup_pack[t0 + j];
             const double *tr = ftmp + (size_t)(pk >> 2) * 12 + (pk & 3) * 3;
@@ -918,6 +1009,7 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
             lds[0][sl] = tr[0]; lds[1][sl] = tr[1]; lds[2][sl] = tr[2];
         }
         __syncthreads();
+#endif
         const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
         for (int j = a; j < b; ++j) {
             const int sl = lds_slot(j);
