@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: keep the 1.1M-tet mesh and cut it N ways (default: weak scaling, "
                          "the box grows N times in x so every GPU keeps 1.1M tets)")
+    ap.add_argument("--mesh-file", default=None,
+                    help="take the mesh from a .desmesh file (e.g. the reference's TetGen mesh of test-3d-big.cfg at "
+                         "resolution 460 m, 1,001,310 tets, written by oracle/_ref/tetmesh) instead of the regular mesher; N=1")
     ap.add_argument("--averaged-fields", action="store_true",
                     help="also run Output::average_fields inside the step (sim.is_outputting_averaged_fields = yes)")
     ap.add_argument("--rheology", default="elasto-visco-plastic",
@@ -141,7 +144,11 @@ def main():
     overrides = "" if args.rheology == "elasto-visco-plastic" else "mat.rheology_type = %s\n" % args.rheology
     if args.averaged_fields:
         overrides += "sim.is_outputting_averaged_fields = yes\nmesh.quality_check_step_interval = 100\n"
-    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)), overrides=overrides or None)
+    if args.mesh_file:
+        assert world == 1, "--mesh-file is a single-GPU workload"
+        overrides += "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n"
+    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)), overrides=overrides or None,
+                    mesh_file=args.mesh_file)
     device = int(os.environ.get("DES_BENCH_DEVICE", local_rank))
     if world == 1:
         dev = des.DeviceEngine(host, device=device)
@@ -201,8 +208,9 @@ def main():
         "config": {
             "workload": "test-3d-big.cfg box 400x20x10 km, " + args.rheology + ", thermal+NMD+surface diffusion on, "
                         + ("averaged output fields on, " if args.averaged_fields else "")
+                        + ("mesh file %s, " % os.path.basename(args.mesh_file) if args.mesh_file else "regular 5-tet mesh, ")
                         +
-                        "regular 5-tet mesh %d tets / %d nodes in total" % (ne, nn),
+                        "%d tets / %d nodes in total" % (ne, nn),
             "nelem": ne, "nnode": nn, "nelem_local_rank0": ne_local,
             "parallelism": "single GPU" if world == 1 else
                            "%d slabs of contiguous node ids, one ghost-element layer, RCCL send/recv halo of nodal values" % world,

@@ -326,6 +326,10 @@ class DeviceEngine(EngineBase):
     def algorithmic_bytes_per_step(self):
         return self._lib.des_dev_algorithmic_bytes_per_step(self._h)
 
+    def set_overlap(self, on):
+        self._lib.des_dev_set_overlap.argtypes = [C.c_void_p, C.c_int]
+        return self._lib.des_dev_set_overlap(self._h, 1 if on else 0)
+
     def exchange(self, kind):
         self._lib.des_dev_exchange.argtypes = [C.c_void_p, C.c_int]
         self._check(self._lib.des_dev_exchange(self._h, kind), "exchange")

@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdio>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -148,6 +149,12 @@ struct des_dev {
     double *dh_n;                                          // nodal copy of surfinfo.dh
     ncclComm_t comm;
     int comm_rank, comm_size;
+    // overlap of the first two exchanges with the interior elements
+    hipStream_t comm_stream;
+    hipEvent_t ev_ready, ev_done;
+    std::vector<int> h_conn;                               // host copy of the connectivity (set_halo)
+    int e_lo_end, e_hi_begin;                              // elements in between touch no halo node
+    bool overlap;
     bool markers_dirty;
     bool const_mass;                      // quasi-static, one material: nodal mass from volumes alone
     bool pending_c;                       // C part of the last step has been run (always true outside step())
@@ -570,15 +577,18 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
 // NMD_stress element part (geometry.cxx:294-296)
 __global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
 E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
-     int ne, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const int *__restrict__ markers, const double *__restrict__ props,
      const double *__restrict__ volume, const double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2)
 {
-    const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
-    if (e >= ne) return;
+    // elements [e_begin, e_begin + e_count): the whole mesh, or the interior / boundary part of a
+    // rank's mesh when the halo exchange overlaps the interior (ne stays the SoA plane stride)
+    const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    if (el >= e_count) return;
+    const int e = e_begin + el;
     const double dt = clk->dt;
     const int4 cn = conn[e];
     const int rheol = p->rheol_type;
@@ -736,7 +746,8 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
                               double *__restrict__ f_tmp);
 
 __global__ void __launch_bounds__(DES_BLOCK, DES_E3_WAVES)
-E3_nmd_force(const des_params *__restrict__ p, int ne, int nblocks, int nblocks8, const int4 *__restrict__ conn,
+E3_nmd_force(const des_params *__restrict__ p, int ne, int e_begin, int e_count, int nblocks, int nblocks8,
+     const int4 *__restrict__ conn,
      const d4 *__restrict__ xt, const double *__restrict__ ntmp, const int *__restrict__ markers,
      const double *__restrict__ props, const double *__restrict__ volume,
      const double *__restrict__ dpressure, double *__restrict__ stress, double *__restrict__ ftmp,
@@ -749,10 +760,11 @@ E3_nmd_force(const des_params *__restrict__ p, int ne, int nblocks, int nblocks8
         return;
     }
     __shared__ double stage[DES_BLOCK * 13];              // 12 doubles per element, row stride 13
-    const int e0 = desk::logical_block(nblocks) * DES_BLOCK;
+    const int e_end = e_begin + e_count;                  // this launch's element range
+    const int e0 = e_begin + desk::logical_block(nblocks) * DES_BLOCK;
     const int e = e0 + threadIdx.x;
-    if (e0 >= ne) return;
-    if (e < ne) {
+    if (e0 >= e_end) return;
+    if (e < e_end) {
         const int4 cn = conn[e];
         d4 c[4];
         c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
@@ -786,7 +798,7 @@ E3_nmd_force(const des_params *__restrict__ p, int ne, int nblocks, int nblocks8
         }
     }
     __syncthreads();
-    const int nvalid = min(DES_BLOCK, ne - e0) * 12;
+    const int nvalid = min(DES_BLOCK, e_end - e0) * 12;
     double *dst = ftmp + (size_t)e0 * 12;
     for (int idx = threadIdx.x; idx < nvalid; idx += DES_BLOCK) {
         const int t = idx / 12, k = idx - t * 12;
@@ -1118,31 +1130,46 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
     if (n >= o0 && n < o1) {                    // owned surface nodes; halo ones arrive by exchange
         if (diffuse) {
             double total_dx = 0., total_slope = 0.;
-            for (int j = ssup_idx[i]; j < ssup_idx[i+1]; ++j) {
-                const int k = ssup_arr[j];
-                int nd[3];
-                d4 cf[3];
-                for (int m = 0; m < 3; ++m) { nd[m] = conn_surf[(size_t)m*etop + k]; cf[m] = xt_in[nd[m]]; }
-                double x01 = cf[1].x - cf[0].x, y01 = cf[1].y - cf[0].y;
-                double x02 = cf[2].x - cf[0].x, y02 = cf[2].y - cf[0].y;
-                double projected_area = 0.5 * (x01*y02 - y01*x02);
-                total_dx += projected_area;
-                double shp2dx[3], shp2dy[3];
-                double iv = 1 / (2 * projected_area);
-                shp2dx[0] = iv * (cf[1].y - cf[2].y);
-                shp2dx[1] = iv * (cf[2].y - cf[0].y);
-                shp2dx[2] = iv * (cf[0].y - cf[1].y);
-                shp2dy[0] = iv * (cf[2].x - cf[1].x);
-                shp2dy[1] = iv * (cf[0].x - cf[2].x);
-                shp2dy[2] = iv * (cf[1].x - cf[0].x);
-                const double zz[3] = {cf[0].z, cf[1].z, cf[2].z};
-                for (int m = 0; m < 3; ++m) {
-                    if (nd[m] == n) {
-                        double slope = 0;
-                        for (int q = 0; q < 3; q++)
-                            slope += (shp2dx[m] * shp2dx[q] + shp2dy[m] * shp2dy[q]) * zz[q];
-                        total_slope += slope * projected_area;
-                        break;
+            // facets in batches of four: all facet ids, then all node ids, then all node records are
+            // requested before the first is used, so a batch costs three memory latencies instead
+            // of three per facet; the sums below still run in list order
+            const int jb = ssup_idx[i], je = ssup_idx[i+1];
+            for (int j0 = jb; j0 < je; j0 += 4) {
+                int kf[4], nd[4][3];
+                d4 cf[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kf[u] = (j0 + u < je) ? ssup_arr[j0 + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    for (int m = 0; m < 3; ++m) nd[u][m] = (kf[u] >= 0) ? conn_surf[(size_t)m*etop + kf[u]] : n;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    for (int m = 0; m < 3; ++m) cf[u][m] = xt_in[nd[u][m]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (kf[u] < 0) continue;
+                    const d4 *c = cf[u];
+                    double x01 = c[1].x - c[0].x, y01 = c[1].y - c[0].y;
+                    double x02 = c[2].x - c[0].x, y02 = c[2].y - c[0].y;
+                    double projected_area = 0.5 * (x01*y02 - y01*x02);
+                    total_dx += projected_area;
+                    double shp2dx[3], shp2dy[3];
+                    double iv = 1 / (2 * projected_area);
+                    shp2dx[0] = iv * (c[1].y - c[2].y);
+                    shp2dx[1] = iv * (c[2].y - c[0].y);
+                    shp2dx[2] = iv * (c[0].y - c[1].y);
+                    shp2dy[0] = iv * (c[2].x - c[1].x);
+                    shp2dy[1] = iv * (c[0].x - c[2].x);
+                    shp2dy[2] = iv * (c[1].x - c[0].x);
+                    const double zz[3] = {c[0].z, c[1].z, c[2].z};
+                    for (int m = 0; m < 3; ++m) {
+                        if (nd[u][m] == n) {
+                            double slope = 0;
+                            for (int q = 0; q < 3; q++)
+                                slope += (shp2dx[m] * shp2dx[q] + shp2dy[m] * shp2dy[q]) * zz[q];
+                            total_slope += slope * projected_area;
+                            break;
+                        }
                     }
                 }
             }
@@ -1429,12 +1456,13 @@ void launch_n1(des_dev *h)
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
-void launch_e2(des_dev *h)
+void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
 {
+    if (e_count < 0) e_count = h->ne;
+    if (e_count == 0) return;
     Launch l(h, K_E2);
-    const int ne = h->ne;
-    hipLaunchKernelGGL(E2_update_stress, dim3(nblk8(ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, ne, nblk(ne),
-                       h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->volume_old, h->stress,
+    hipLaunchKernelGGL(E2_update_stress, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                       e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->volume_old, h->stress,
                        h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                        h->etmp2);
 }
@@ -1447,13 +1475,17 @@ void launch_n2(des_dev *h)
                        h->sup_pack, h->etmp2, h->volume_n, h->ntmp);
 }
 
-void launch_e3(des_dev *h)
+// `facets`: this launch also carries the stress-bc facet workgroups (once per step)
+void launch_e3(des_dev *h, int e_begin = 0, int e_count = -1, bool facets = true)
 {
+    if (e_count < 0) e_count = h->ne;
+    const int nbe8 = nblk8(e_count), nbf = facets ? nblk(h->nbcf) : 0;
+    if (nbe8 + nbf == 0) return;
     Launch l(h, K_E3);
-    const int ne = h->ne, nbe8 = nblk8(ne);
-    hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nblk(h->nbcf)), dim3(DES_BLOCK), 0, h->stream, h->d_p, ne, nblk(ne), nbe8,
+    hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->ne, e_begin, e_count,
+                       nblk(e_count), nbe8,
                        h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp,
-                       h->nbcf, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
+                       facets ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
 }
 
 void launch_n3(des_dev *h)
@@ -1497,25 +1529,62 @@ void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
 // ---- halo exchange through RCCL on the engine's stream ---------------------------
 const int kXWidth[DES_X_COUNT] = {DES_X_WIDTH_0, DES_X_WIDTH_1, DES_X_WIDTH_2, DES_X_WIDTH_3};
 
-int exchange(des_dev *h, int kind)
+// With `overlapped` the exchange runs on the engine's second stream between two events: it starts
+// when the compute stream has produced the values to send, and the caller makes the compute
+// stream wait for it (wait_exchange) only in front of the first kernel that reads halo values.
+int exchange(des_dev *h, int kind, bool overlapped = false)
 {
     if (h->nnbr == 0) return DES_OK;
     if (!h->comm) { g_last_error = "decomposed engine without a communicator: call des_dev_comm_init"; return DES_ERR_INTERNAL; }
+    hipStream_t st = h->stream;
+    if (overlapped) {
+        st = h->comm_stream;
+        HIP_OK(hipEventRecord(h->ev_ready, h->stream));
+        HIP_OK(hipStreamWaitEvent(st, h->ev_ready, 0));
+    }
     const int w = kXWidth[kind];
     const int nsend = h->send_ptr[h->nnbr], nrecv = h->recv_ptr[h->nnbr];
-    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(nsend)), dim3(DES_BLOCK), 0, h->stream, kind, nsend, h->d_send_idx, h->xt, h->vm,
+    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(nsend)), dim3(DES_BLOCK), 0, st, kind, nsend, h->d_send_idx, h->xt, h->vm,
                        h->ntmp, h->dh_n, h->d_sendbuf);
     ncclGroupStart();
     for (int q = 0; q < h->nnbr; ++q) {
         ncclSend(h->d_sendbuf + (size_t)h->send_ptr[q] * w, (size_t)(h->send_ptr[q+1] - h->send_ptr[q]) * w, ncclDouble,
-                 h->nbr_rank[q], h->comm, h->stream);
+                 h->nbr_rank[q], h->comm, st);
         ncclRecv(h->d_recvbuf + (size_t)h->recv_ptr[q] * w, (size_t)(h->recv_ptr[q+1] - h->recv_ptr[q]) * w, ncclDouble,
-                 h->nbr_rank[q], h->comm, h->stream);
+                 h->nbr_rank[q], h->comm, st);
     }
     ncclResult_t r = ncclGroupEnd();
     if (r != ncclSuccess) { g_last_error = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
-    hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(nrecv)), dim3(DES_BLOCK), 0, h->stream, kind, nrecv, h->d_recv_idx, h->d_recvbuf,
+    hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(nrecv)), dim3(DES_BLOCK), 0, st, kind, nrecv, h->d_recv_idx, h->d_recvbuf,
                        h->xt, h->vm, h->ntmp, h->dh_n);
+    if (overlapped) HIP_OK(hipEventRecord(h->ev_done, st));
+    return DES_OK;
+}
+
+int wait_exchange(des_dev *h)
+{
+    HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done, 0));
+    return DES_OK;
+}
+
+// E2 / E3 of a decomposed mesh around an exchange: the elements that touch no halo node
+// ([e_lo_end, e_hi_begin), des_dev_set_halo) run while the halo values travel, the two boundary
+// ranges after they have arrived.
+template <typename F>
+int exchange_under(des_dev *h, int kind, F launch)
+{
+    if (!h->overlap) {
+        int rc = exchange(h, kind);
+        if (rc) return rc;
+        launch(0, h->ne, true);
+        return DES_OK;
+    }
+    int rc = exchange(h, kind, true);
+    if (rc) return rc;
+    launch(h->e_lo_end, h->e_hi_begin - h->e_lo_end, true);
+    if ((rc = wait_exchange(h))) return rc;
+    launch(0, h->e_lo_end, false);
+    launch(h->e_hi_begin, h->ne - h->e_hi_begin, false);
     return DES_OK;
 }
 
@@ -1577,6 +1646,9 @@ void des_dev_destroy(des_dev *h)
     if (h->h_clk) hipHostFree(h->h_clk);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->ev_ready) hipEventDestroy(h->ev_ready);
+    if (h->ev_done) hipEventDestroy(h->ev_done);
+    if (h->comm_stream) hipStreamDestroy(h->comm_stream);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1640,6 +1712,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             c4[e] = make_int4(mesh->connectivity[e], mesh->connectivity[(size_t)ne + e],
                               mesh->connectivity[(size_t)2*ne + e], mesh->connectivity[(size_t)3*ne + e]);
         CK(dev_alloc(h->conn, (size_t)ne)); CK(dev_upload(h->conn, c4.data(), (size_t)ne, h->stream));
+        h->h_conn.assign(mesh->connectivity, mesh->connectivity + (size_t)4*ne);
         std::vector<int> pack((size_t)4*ne);
         for (size_t k = 0; k < pack.size(); ++k) pack[k] = mesh->support_arr[k] * 4 + mesh->support_lidx[k];
         CK(dev_alloc(h->sup_idx, (size_t)nn + 1)); CK(dev_upload(h->sup_idx, mesh->support_idx, (size_t)nn + 1, h->stream));
@@ -1969,13 +2042,17 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         const long long step_no = ++h->steps_host;
         if (i == 0) launch_e1<MODE_A>(h);
         launch_n1(h);                                              // phase 0
-        if (multi && (rc = exchange(h, DES_X_TEMP_NTMP))) return rc;
-        launch_e2(h);                                              // phase 1
-        if (nmd) {
-            launch_n2(h);
-            if (multi && (rc = exchange(h, DES_X_NTMP))) return rc;
+        if (multi) {                                               // phase 1
+            if ((rc = exchange_under(h, DES_X_TEMP_NTMP, [&](int b, int n, bool) { launch_e2(h, b, n); }))) return rc;
+        } else {
+            launch_e2(h);
         }
-        launch_e3(h);                                              // phase 2
+        if (nmd) launch_n2(h);
+        if (nmd && multi) {                                        // phase 2
+            if ((rc = exchange_under(h, DES_X_NTMP, [&](int b, int n, bool fac) { launch_e3(h, b, n, fac); }))) return rc;
+        } else {
+            launch_e3(h);
+        }
         launch_n3(h);
         if (multi && (rc = exchange(h, DES_X_VEL_COORD))) return rc;
         launch_s2(h, step_no);                                     // phase 3
@@ -2039,6 +2116,33 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     if ((rc = dev_alloc(h->d_recvbuf, nr * DES_X_WIDTH_2))) return rc;
     if ((rc = dev_upload(h->d_send_idx, halo->send_idx, ns, h->stream))) return rc;
     if ((rc = dev_upload(h->d_recv_idx, halo->recv_idx, nr, h->stream))) return rc;
+    // interior element range for the overlapped exchanges: every element with a node below the
+    // owned range has an id < e_lo_end, every one with a node above it an id >= e_hi_begin
+    // (ids follow x, mesh.cxx:2742-2792); both limits on workgroup boundaries
+    {
+        int max_lo = -1, min_hi = h->ne;
+        for (int e = 0; e < h->ne; ++e)
+            for (int i = 0; i < 4; ++i) {
+                const int n = h->h_conn[(size_t)i * h->ne + e];
+                if (n < h->o0 && e > max_lo) max_lo = e;
+                if (n >= h->o1 && e < min_hi) min_hi = e;
+            }
+        h->e_lo_end = std::min(h->ne, (max_lo + 1 + DES_BLOCK - 1) / DES_BLOCK * DES_BLOCK);
+        h->e_hi_begin = std::max(h->e_lo_end, min_hi / DES_BLOCK * DES_BLOCK);
+        // Off unless DES_OVERLAP=1 / des_dev_set_overlap: measured on one MI355X (tools/time_overlap.py,
+        // 1.1M tets, the rank as its own neighbour) an exchange costs 18.7 us in-stream, but every
+        // cross-stream event round trip costs more than that (0.368 ms/step without exchanges,
+        // 0.443 serial, 0.496 overlapped), so hiding two of the four exchanges does not pay here.
+        const char *env = std::getenv("DES_OVERLAP");
+        h->overlap = h->nnbr > 0 && h->e_hi_begin - h->e_lo_end >= 64 * DES_BLOCK && (env && env[0] == '1');
+        if (!h->comm_stream) {
+            int prio_lo = 0, prio_hi = 0;
+            hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       // the exchange must not queue behind
+            HIP_OK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio_hi));  // the interior kernel
+            HIP_OK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming | hipEventReleaseToDevice));
+            HIP_OK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming | hipEventReleaseToDevice));
+        }
+    }
     // the residual partials are indexed by owned-node block
     if (h->res_part) hipFree(h->res_part);
     h->n3_blocks = nblk8(h->o1 - h->o0);
@@ -2064,6 +2168,15 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
     if (r != ncclSuccess) { g_last_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); h->comm = nullptr; return DES_ERR_RESOURCE; }
     h->comm_rank = rank; h->comm_size = nranks;
     return DES_OK;
+}
+
+// Overlap of the first two exchanges of a step with the interior elements (default off; also
+// DES_OVERLAP=1).  Returns the setting in effect: 0 when the rank's mesh has no interior.
+int des_dev_set_overlap(des_dev *h, int on)
+{
+    if (!h) return 0;
+    h->overlap = on && h->nnbr > 0 && h->comm_stream && h->e_hi_begin - h->e_lo_end >= DES_BLOCK;
+    return h->overlap ? 1 : 0;
 }
 
 // One RCCL halo exchange of the given kind on the engine's stream (what des_dev_step issues

@@ -569,25 +569,19 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // min over IEEE doubles of either sign with a 64-bit CAS (one call per block per quantity)
+// min / max of NON-NEGATIVE doubles (lengths, time-step bounds, speeds): their bit patterns order
+// like unsigned integers, so one native 64-bit integer atomic does it -- no compare-and-swap
+// retry loop under the contention of thousands of workgroups.  The plain read in front drops
+// most calls (and NaN, as fmin/fmax would); a stale read can only let a useless atomic through.
 __device__ __forceinline__ void atomic_min_double(double *addr, double val)
 {
-    unsigned long long *a = (unsigned long long *)addr;
-    unsigned long long old = *a, assumed;
-    do {
-        assumed = old;
-        if (!(val < __longlong_as_double((long long)assumed))) break;
-        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(val));
-    } while (assumed != old);
+    if (!(val < *(volatile double *)addr)) return;
+    atomicMin((unsigned long long *)addr, (unsigned long long)__double_as_longlong(val));
 }
 __device__ __forceinline__ void atomic_max_double(double *addr, double val)
 {
-    unsigned long long *a = (unsigned long long *)addr;
-    unsigned long long old = *a, assumed;
-    do {
-        assumed = old;
-        if (!(val > __longlong_as_double((long long)assumed))) break;
-        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(val));
-    } while (assumed != old);
+    if (!(val > *(volatile double *)addr)) return;
+    atomicMax((unsigned long long *)addr, (unsigned long long)__double_as_longlong(val));
 }
 
 } // namespace desk

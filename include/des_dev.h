@@ -105,6 +105,11 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global);
 /* rank 0 creates the 128-byte ncclUniqueId; the caller broadcasts it (e.g. torch.distributed) */
 int des_dev_comm_unique_id(unsigned char *id128);
 int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128);
+/* des_dev_step can overlap the exchanges after phases 0 and 1 with the elements that touch no
+ * halo node (second stream, two events).  Off by default (also DES_OVERLAP=1): on one MI355X
+ * the cross-stream event round trips cost more than the 19-us exchanges they hide
+ * (tools/time_overlap.py).  Returns the setting in effect. */
+int des_dev_set_overlap(des_dev *h, int on);
 /* one halo exchange (DES_X_*) through the attached communicator, asynchronous on the engine's
  * stream: what des_dev_step issues after phases 0..3 */
 int des_dev_exchange(des_dev *h, int kind);

@@ -126,3 +126,54 @@ def test_rccl_send_recv_path_moves_halo_values():
         assert np.array_equal(eng.download("NTMP")[recv], ntmp3[send])
     finally:
         dist.destroy_process_group()
+
+
+def test_overlapped_exchange_schedule_is_bit_identical_to_the_serial_one():
+    """des_dev_step hides the exchanges after phases 0 and 1 behind the elements that touch no halo
+    node (second stream + events; boundary element ranges afterwards).  Same arithmetic, different
+    schedule: overlap on and off must agree to the bit.  (One GPU: the rank is its own neighbour;
+    the halo values it receives are those of other nodes, so after the coordinate exchange the
+    boundary elements degenerate -- the comparison is on raw bits, NaNs included.)"""
+    import ctypes as C
+    import os
+    import types
+    import torch.distributed as dist
+    from dynearthsol_amd._structs import DesHalo
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29990 - os.getpid() % 90))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        kw = dict(cfgs.EVP, lx=60e3, ly=10e3, lz=8e3, res=1e3)
+        results = []
+        for overlap in (0, 1):
+            host = des.Host(cfg_text=cfgs.make(**kw))
+            nn, ne = host.nnode, host.nelem
+            eng = des.DeviceEngine(host)
+            o0, o1 = 200, nn - 300                                  # "halo" = the first 200 and last 300 nodes
+            recv = np.concatenate([np.arange(0, o0), np.arange(o1, nn)]).astype(np.int32)
+            rng = np.random.default_rng(3)
+            send = np.sort(rng.choice(np.arange(o0, o1), size=len(recv), replace=False)).astype(np.int32)
+            cut = len(recv) // 2
+            arrs = [np.zeros(2, np.int32), np.array([0, cut, len(recv)], np.int32)]
+            pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+            halo = DesHalo(o0, o1, 2, pi(arrs[0]), pi(arrs[1]), pi(send), pi(arrs[1]), pi(recv))
+            eng.set_halo(types.SimpleNamespace(halo=halo, owned=(o0, o1), host=host))
+            eng.comm_init(dist, 0, 1)
+            eng.init_from_host(host)
+            assert eng.set_overlap(overlap) == overlap
+            snaps = []
+            for n in (1, 3):
+                eng.step(n)
+                snaps.append([eng.download(f).view(np.uint64).copy() for f in ("STRESS", "VEL", "COORD", "TEMPERATURE", "NTMP", "FORCE")])
+            results.append(snaps)
+            conn = host.array("connectivity").reshape(4, ne)
+            touches_halo = ((conn < o0) | (conn >= o1)).any(axis=0)
+            assert touches_halo[:256].any() and touches_halo[-256:].any() and not touches_halo[ne // 2]
+        # away from the (degenerate) boundary elements the fields are regular numbers
+        assert np.isfinite(results[0][0][0].view(np.float64)).mean() > 0.9
+        assert np.isfinite(results[0][1][1].view(np.float64)).mean() > 0.5
+        for a, b in zip(results[0], results[1]):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+    finally:
+        dist.destroy_process_group()
