@@ -58,6 +58,7 @@ class DesMesh(C.Structure):
         ("ntop", C.c_int), ("etop", C.c_int), ("ntop_elems", C.c_int),
         ("top_nodes", _pint), ("elem_and_nodes", _pint), ("connectivity_surface", _pint),
         ("support_surf_idx", _pint), ("support_surf_arr", _pint), ("top_elems", _pint),
+        ("coord", _pdbl), ("owned_begin", C.c_int), ("owned_end", C.c_int),
     ]
 
 

@@ -155,6 +155,9 @@ struct des_dev {
     std::vector<int> h_conn;                               // host copy of the connectivity (set_halo)
     int e_lo_end, e_hi_begin;                              // elements in between touch no halo node
     bool overlap;
+    // internal data order (des_mesh::coord hint): device index <-> caller's index; empty = identity
+    std::vector<int> n_new2old, n_old2new, e_new2old, e_old2new;
+    int *d_n_new2old, *d_e_new2old;
     bool markers_dirty;
     bool const_mass;                      // quasi-static, one material: nodal mass from volumes alone
     bool pending_c;                       // C part of the last step has been run (always true outside step())
@@ -1310,28 +1313,31 @@ __device__ __forceinline__ double elem_quality3(const int4 cn, const d4 *__restr
 
 __global__ void k_quality_a(int ne, int nn, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
                             const double *__restrict__ volume, const unsigned *__restrict__ bcflag,
-                            double smallest_vol, double bottom, double bottom_dist, double *qmin, int *islot)
+                            double smallest_vol, double bottom, double bottom_dist, double *qmin, int *islot,
+                            const int *__restrict__ n_id, const int *__restrict__ e_id)
 {
+    // n_id / e_id: the caller's index of a device index ("first" means first in the caller's order)
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     double q = 1.0;
     if (i < ne) {
         const double vol = volume[i];
-        if (vol < smallest_vol) atomicMin(&islot[0], i);
+        if (vol < smallest_vol) atomicMin(&islot[0], e_id ? e_id[i] : i);
         q = fmin(q, elem_quality3(conn[i], xt, vol));
     }
     if (i < nn && bottom_dist >= 0 && (bcflag[i] & (1u << 4)))            // is_bottom: BOUNDZ0
-        if (fabs(xt[i].z - bottom) > bottom_dist) atomicMin(&islot[1], i);
+        if (fabs(xt[i].z - bottom) > bottom_dist) atomicMin(&islot[1], n_id ? n_id[i] : i);
     q = desk::wave_min(q);
     if ((threadIdx.x & 63) == 0 && q < 1.0) desk::atomic_min_double(qmin, q);
 }
 
 __global__ void k_quality_b(int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
-                            const double *__restrict__ volume, const double *qmin, int *islot)
+                            const double *__restrict__ volume, const double *qmin, int *islot,
+                            const int *__restrict__ e_id)
 {
     const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (e >= ne) return;
     const double q = elem_quality3(conn[e], xt, volume[e]);
-    if (q < 1.0 && q == *qmin) atomicMin(&islot[2], e);
+    if (q < 1.0 && q == *qmin) atomicMin(&islot[2], e_id ? e_id[e] : e);
 }
 
 // =====================================================================================
@@ -1606,6 +1612,161 @@ int sync_clock(des_dev *h)
     return DES_OK;
 }
 
+// ---- internal data order ------------------------------------------------------------
+// The reference numbers nodes and elements along x only (mesh.cxx:2742-2792): 256 consecutive
+// nodes of a TetGen mesh are a thin slice scattered over the whole y-z section, so a workgroup's
+// gathers hardly share anything (test-3d-big at 460 m: every element record is fetched by 2.8
+// node workgroups, every node record by 12 element workgroups; on a Morton order 1.6 and 2.6).
+// With the coordinates at hand (des_mesh::coord) the engine therefore keeps its arrays in Morton
+// order -- nodes within [0, owned_begin), [owned_begin, owned_end), [owned_end, nnode) so that the
+// owned range stays a range; elements by centroid, those touching the low / high halo first /
+// last.  Only names change: every list keeps the caller's ORDER (the support lists stay in
+// ascending caller element id = the reference's summation order), and upload / download /
+// halo lists / reported indices translate at the boundary.
+struct PermMesh {
+    std::vector<int> n_new2old, n_old2new, e_new2old, e_old2new;
+    std::vector<int> conn, sup_idx, sup_arr, sup_lidx, top_nodes, conn_surf, top_elems;
+    std::vector<unsigned> bcflag;
+    std::vector<int> bf_elem[DES_NBDRY], bnodes[DES_NBDRY];
+    des_mesh view;
+};
+
+inline unsigned long long morton3(unsigned x, unsigned y, unsigned z)
+{
+    auto spread = [](unsigned long long v) {                 // 21 bits -> every third bit
+        v &= 0x1fffffULL;
+        v = (v | v << 32) & 0x1f00000000ffffULL;
+        v = (v | v << 16) & 0x1f0000ff0000ffULL;
+        v = (v | v << 8) & 0x100f00f00f00f00fULL;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+        v = (v | v << 2) & 0x1249249249249249ULL;
+        return v;
+    };
+    return spread(x) | spread(y) << 1 | spread(z) << 2;
+}
+
+void build_perm_mesh(const des_mesh *in, PermMesh &pm)
+{
+    const int nn = in->nnode, ne = in->nelem;
+    const double *X = in->coord;
+    double lo[3], hi[3], ext = 0;
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = hi[d] = X[(size_t)d * nn];
+        for (int n = 0; n < nn; ++n) { lo[d] = std::min(lo[d], X[(size_t)d*nn + n]); hi[d] = std::max(hi[d], X[(size_t)d*nn + n]); }
+        ext = std::max(ext, hi[d] - lo[d]);
+    }
+    const double scale = ext > 0 ? 2097151.0 / ext : 0.0;    // cubic cells: one scale for all axes
+    auto code = [&](double x, double y, double z) {
+        return morton3((unsigned)((x - lo[0]) * scale), (unsigned)((y - lo[1]) * scale), (unsigned)((z - lo[2]) * scale));
+    };
+    const int ob = in->owned_begin, oe = in->owned_end > 0 ? in->owned_end : nn;
+    {
+        std::vector<std::pair<unsigned long long, int> > key((size_t)nn);
+        for (int n = 0; n < nn; ++n) key[n] = std::make_pair(code(X[n], X[(size_t)nn + n], X[(size_t)2*nn + n]), n);
+        // Morton order inside each of the three id ranges (the pairs break ties by caller id)
+        std::sort(key.begin(), key.begin() + ob);
+        std::sort(key.begin() + ob, key.begin() + oe);
+        std::sort(key.begin() + oe, key.end());
+        pm.n_new2old.resize((size_t)nn); pm.n_old2new.resize((size_t)nn);
+        for (int i = 0; i < nn; ++i) { pm.n_new2old[i] = key[i].second; pm.n_old2new[key[i].second] = i; }
+    }
+    {
+        std::vector<std::pair<unsigned long long, int> > key((size_t)ne);
+        for (int e = 0; e < ne; ++e) {
+            double c[3] = {0, 0, 0};
+            unsigned long long grp = 1;
+            bool touches_lo = false, touches_hi = false;
+            for (int i = 0; i < 4; ++i) {
+                const int n = in->connectivity[(size_t)i*ne + e];
+                for (int d = 0; d < 3; ++d) c[d] += X[(size_t)d*nn + n] / 4;
+                touches_lo |= n < ob; touches_hi |= n >= oe;
+            }
+            if (touches_lo) grp = 0; else if (touches_hi) grp = 2;
+            key[e] = std::make_pair(grp << 62 | code(c[0], c[1], c[2]) >> 2, e);      // group, then Morton
+        }
+        std::sort(key.begin(), key.end());
+        pm.e_new2old.resize((size_t)ne); pm.e_old2new.resize((size_t)ne);
+        for (int i = 0; i < ne; ++i) { pm.e_new2old[i] = key[i].second; pm.e_old2new[key[i].second] = i; }
+    }
+    const std::vector<int> &nmap = pm.n_old2new, &emap = pm.e_old2new;
+    pm.conn.resize((size_t)4*ne);
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < ne; ++e) pm.conn[(size_t)i*ne + emap[e]] = nmap[in->connectivity[(size_t)i*ne + e]];
+    pm.sup_idx.assign((size_t)nn + 1, 0);
+    for (int i = 0; i < nn; ++i) {
+        const int n = pm.n_new2old[i];
+        pm.sup_idx[i + 1] = pm.sup_idx[i] + (in->support_idx[n + 1] - in->support_idx[n]);
+    }
+    pm.sup_arr.resize((size_t)pm.sup_idx[nn]); pm.sup_lidx.resize((size_t)pm.sup_idx[nn]);
+    for (int i = 0; i < nn; ++i) {
+        const int n = pm.n_new2old[i];
+        int k2 = pm.sup_idx[i];
+        for (int k = in->support_idx[n]; k < in->support_idx[n + 1]; ++k, ++k2) {   // caller's order kept
+            pm.sup_arr[k2] = emap[in->support_arr[k]];
+            pm.sup_lidx[k2] = in->support_lidx[k];
+        }
+    }
+    pm.bcflag.resize((size_t)nn);
+    for (int i = 0; i < nn; ++i) pm.bcflag[i] = in->bcflag[pm.n_new2old[i]];
+    pm.view = *in;
+    for (int b = 0; b < DES_NBDRY; ++b) {
+        pm.bf_elem[b].resize((size_t)in->nbfacets[b]);
+        for (int q = 0; q < in->nbfacets[b]; ++q) pm.bf_elem[b][q] = emap[in->bfacet_elem[b][q]];
+        pm.bnodes[b].resize((size_t)in->nbnodes[b]);
+        for (int q = 0; q < in->nbnodes[b]; ++q) pm.bnodes[b][q] = nmap[in->bnodes[b][q]];
+        pm.view.bfacet_elem[b] = pm.bf_elem[b].data();
+        pm.view.bnodes[b] = pm.bnodes[b].data();
+    }
+    pm.top_nodes.resize((size_t)in->ntop);
+    for (int i = 0; i < in->ntop; ++i) pm.top_nodes[i] = nmap[in->top_nodes[i]];
+    pm.conn_surf.assign(in->connectivity_surface, in->connectivity_surface + (size_t)4 * in->etop);
+    for (int m = 0; m < 3; ++m)
+        for (int k = 0; k < in->etop; ++k) pm.conn_surf[(size_t)m * in->etop + k] = nmap[in->connectivity_surface[(size_t)m * in->etop + k]];
+    pm.top_elems.resize((size_t)in->ntop_elems);
+    for (int i = 0; i < in->ntop_elems; ++i) pm.top_elems[i] = emap[in->top_elems[i]];
+    pm.view.connectivity = pm.conn.data();
+    pm.view.support_idx = pm.sup_idx.data(); pm.view.support_arr = pm.sup_arr.data(); pm.view.support_lidx = pm.sup_lidx.data();
+    pm.view.bcflag = pm.bcflag.data();
+    pm.view.top_nodes = pm.top_nodes.data();
+    pm.view.connectivity_surface = pm.conn_surf.data();
+    pm.view.top_elems = pm.top_elems.data();
+    pm.view.coord = nullptr;
+}
+
+// which index space a plain field lives in: 1 nodal, 2 elemental, 0 neither (surface lists)
+int field_space(int field)
+{
+    switch (field) {
+    case DES_F_FORCE: case DES_F_FORCE_RESIDUAL: case DES_F_COORD0: case DES_F_VOLUME_N: case DES_F_TMASS:
+    case DES_F_DHACC: case DES_F_NTMP: case DES_F_COORD_AVG0: return 1;
+    case DES_F_STRESS: case DES_F_STRAIN: case DES_F_STRAIN_RATE: case DES_F_PLSTRAIN: case DES_F_DELTA_PLSTRAIN:
+    case DES_F_VISCOSITY: case DES_F_VOLUME: case DES_F_VOLUME_OLD: case DES_F_DPRESSURE: case DES_F_RADIOGENIC:
+    case DES_F_STRESS_AVG: case DES_F_DPLSTRAIN_AVG: case DES_F_STRAIN0: return 2;
+    default: return 0;
+    }
+}
+
+// SoA planes [ncomp][n] (or rows of `row` items when ncomp == 0) between the caller's numbering
+// and the engine's; `to_dev`: out[new] = in[new2old[new]], else out[new2old[new]] = in[new]
+template <typename T>
+void permute_planes(const T *in, T *out, size_t n, size_t ncomp, size_t row, const std::vector<int> &new2old, bool to_dev)
+{
+    if (ncomp == 0) {                                   // AoS rows (elemmarkers)
+        for (size_t i = 0; i < n; ++i) {
+            const size_t o = (size_t)new2old[i];
+            const T *src = in + (to_dev ? o : i) * row;
+            T *dst = out + (to_dev ? i : o) * row;
+            for (size_t k = 0; k < row; ++k) dst[k] = src[k];
+        }
+        return;
+    }
+    for (size_t c = 0; c < ncomp; ++c)
+        for (size_t i = 0; i < n; ++i) {
+            const size_t o = (size_t)new2old[i];
+            if (to_dev) out[c*n + i] = in[c*n + o]; else out[c*n + o] = in[c*n + i];
+        }
+}
+
 struct FieldInfo { int kind; long long count; };   // kind: 0 none, 1 elem plane array, 2 nodal plane array, ...
 
 } // namespace des_hip
@@ -1634,7 +1795,7 @@ void des_dev_destroy(des_dev *h)
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     void *ptrs[] = { h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
-        h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red,
+        h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
@@ -1670,6 +1831,16 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     des_dev *h = new des_dev();       // value-initialised: every pointer/scalar member starts at 0
     h->device = device;
     h->p = *params;
+    PermMesh pm;
+    {
+        const char *env = std::getenv("DES_REORDER");
+        if (mesh->coord && mesh->nnode > 0 && mesh->nelem > 0 && !(env && env[0] == '0')) {
+            build_perm_mesh(mesh, pm);
+            h->n_new2old.swap(pm.n_new2old); h->n_old2new.swap(pm.n_old2new);
+            h->e_new2old.swap(pm.e_new2old); h->e_old2new.swap(pm.e_old2new);
+            mesh = &pm.view;             // everything below builds the device state in the internal order
+        }
+    }
     const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
     h->markers_dirty = true;
     h->pending_c = true;
@@ -1718,6 +1889,10 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         CK(dev_alloc(h->sup_idx, (size_t)nn + 1)); CK(dev_upload(h->sup_idx, mesh->support_idx, (size_t)nn + 1, h->stream));
         CK(dev_alloc(h->sup_pack, pack.size())); CK(dev_upload(h->sup_pack, pack.data(), pack.size(), h->stream));
         CK(dev_alloc(h->bcflag, (size_t)nn)); CK(dev_upload(h->bcflag, mesh->bcflag, (size_t)nn, h->stream));
+        if (!h->n_new2old.empty()) {
+            CK(dev_alloc(h->d_n_new2old, (size_t)nn)); CK(dev_upload(h->d_n_new2old, h->n_new2old.data(), (size_t)nn, h->stream));
+            CK(dev_alloc(h->d_e_new2old, (size_t)ne)); CK(dev_upload(h->d_e_new2old, h->e_new2old.data(), (size_t)ne, h->stream));
+        }
     }
     // fields
     CK(dev_alloc(h->xt, (size_t)nn)); CK(dev_alloc(h->vm, (size_t)nn));
@@ -1920,16 +2095,19 @@ static int packed_io(des_dev *h, int field, void *host, bool upload)
     HIP_OK(hipStreamSynchronize(h->stream));
     double *a = (double *)host;
     const bool vec = (field == DES_F_COORD || field == DES_F_VEL);
+    const int *o2n = h->n_old2new.empty() ? nullptr : h->n_old2new.data();     // caller's id -> device id
     if (!upload) {
         for (size_t n = 0; n < nn; ++n) {
-            if (vec) { a[n] = tmp[n].x; a[nn + n] = tmp[n].y; a[2*nn + n] = tmp[n].z; }
-            else a[n] = tmp[n].w;
+            const d4 &t = tmp[o2n ? (size_t)o2n[n] : n];
+            if (vec) { a[n] = t.x; a[nn + n] = t.y; a[2*nn + n] = t.z; }
+            else a[n] = t.w;
         }
         return DES_OK;
     }
     for (size_t n = 0; n < nn; ++n) {
-        if (vec) { tmp[n].x = a[n]; tmp[n].y = a[nn + n]; tmp[n].z = a[2*nn + n]; }
-        else tmp[n].w = a[n];
+        d4 &t = tmp[o2n ? (size_t)o2n[n] : n];
+        if (vec) { t.x = a[n]; t.y = a[nn + n]; t.z = a[2*nn + n]; }
+        else t.w = a[n];
     }
     HIP_OK(hipMemcpyAsync(dev, tmp.data(), nn * sizeof(d4), hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -1945,11 +2123,19 @@ int des_dev_upload(des_dev *h, int field, const void *host, long long count)
         return packed_io(h, field, const_cast<void *>(host), true);
     if (field == DES_F_ELEMMARKERS) {
         h->markers_dirty = true;
-        return dev_upload(h->markers, (const int *)host, (size_t)count, h->stream);
+        if (h->e_new2old.empty()) return dev_upload(h->markers, (const int *)host, (size_t)count, h->stream);
+        std::vector<int> tmp((size_t)count);
+        permute_planes((const int *)host, tmp.data(), (size_t)h->ne, 0, (size_t)h->nmat, h->e_new2old, true);
+        return dev_upload(h->markers, tmp.data(), (size_t)count, h->stream);
     }
     double *dst = plain_field(h, field);
     if (!dst) return DES_ERR_INTERNAL;
-    return dev_upload(dst, (const double *)host, (size_t)count, h->stream);
+    const int space = field_space(field);
+    if (space == 0 || h->n_new2old.empty()) return dev_upload(dst, (const double *)host, (size_t)count, h->stream);
+    const size_t n = space == 1 ? (size_t)h->nn : (size_t)h->ne;
+    std::vector<double> tmp((size_t)count);
+    permute_planes((const double *)host, tmp.data(), n, (size_t)count / n, 0, space == 1 ? h->n_new2old : h->e_new2old, true);
+    return dev_upload(dst, tmp.data(), (size_t)count, h->stream);
 }
 
 int des_dev_download(des_dev *h, int field, void *host, long long count)
@@ -1963,8 +2149,22 @@ int des_dev_download(des_dev *h, int field, void *host, long long count)
     if (!src) return DES_ERR_INTERNAL;
     if (count == 0) return DES_OK;
     const size_t bytes = (size_t)count * (field == DES_F_ELEMMARKERS ? 4 : 8);
-    HIP_OK(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    const int space = field == DES_F_ELEMMARKERS ? 2 : field_space(field);
+    if (space == 0 || h->n_new2old.empty()) {
+        HIP_OK(hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        return DES_OK;
+    }
+    std::vector<char> tmp(bytes);
+    HIP_OK(hipMemcpyAsync(tmp.data(), src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
+    if (field == DES_F_ELEMMARKERS)
+        permute_planes((const int *)tmp.data(), (int *)host, (size_t)h->ne, 0, (size_t)h->nmat, h->e_new2old, false);
+    else {
+        const size_t n = space == 1 ? (size_t)h->nn : (size_t)h->ne;
+        permute_planes((const double *)tmp.data(), (double *)host, n, (size_t)count / n, 0,
+                       space == 1 ? h->n_new2old : h->e_new2old, false);
+    }
     return DES_OK;
 }
 
@@ -2114,8 +2314,21 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     if ((rc = dev_alloc(h->d_recv_idx, nr))) return rc;
     if ((rc = dev_alloc(h->d_sendbuf, ns * DES_X_WIDTH_2))) return rc;
     if ((rc = dev_alloc(h->d_recvbuf, nr * DES_X_WIDTH_2))) return rc;
-    if ((rc = dev_upload(h->d_send_idx, halo->send_idx, ns, h->stream))) return rc;
-    if ((rc = dev_upload(h->d_recv_idx, halo->recv_idx, nr, h->stream))) return rc;
+    if (h->n_old2new.empty()) {
+        if ((rc = dev_upload(h->d_send_idx, halo->send_idx, ns, h->stream))) return rc;
+        if ((rc = dev_upload(h->d_recv_idx, halo->recv_idx, nr, h->stream))) return rc;
+    } else {
+        // the internal order was laid out around des_mesh::owned_begin/end: it must be this range
+        bool range_ok = true;
+        for (int n = 0; n < h->nn && range_ok; ++n)
+            range_ok = (n >= h->o0 && n < h->o1) == (h->n_old2new[n] >= h->o0 && h->n_old2new[n] < h->o1);
+        if (!range_ok) { g_last_error = "des_halo owned range differs from des_mesh::owned_begin/owned_end"; return DES_ERR_INTERNAL; }
+        std::vector<int> sidx(ns), ridx(nr);
+        for (size_t k = 0; k < ns; ++k) sidx[k] = h->n_old2new[halo->send_idx[k]];
+        for (size_t k = 0; k < nr; ++k) ridx[k] = h->n_old2new[halo->recv_idx[k]];
+        if ((rc = dev_upload(h->d_send_idx, sidx.data(), ns, h->stream))) return rc;
+        if ((rc = dev_upload(h->d_recv_idx, ridx.data(), nr, h->stream))) return rc;
+    }
     // interior element range for the overlapped exchanges: every element with a node below the
     // owned range has an id < e_lo_end, every one with a node above it an id >= e_hi_begin
     // (ids follow x, mesh.cxx:2742-2792); both limits on workgroup boundaries
@@ -2236,7 +2449,13 @@ int des_dev_halo_pack(des_dev *h, int kind, const int *idx, int n, double *buf)
     int rc;
     if ((rc = dev_alloc(d_idx, (size_t)n))) return rc;
     if ((rc = dev_alloc(d_buf, (size_t)n * w))) return rc;
-    if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
+    if (h->n_old2new.empty()) {
+        if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
+    } else {
+        std::vector<int> midx((size_t)n);
+        for (int k = 0; k < n; ++k) midx[k] = h->n_old2new[idx[k]];
+        if ((rc = dev_upload(d_idx, midx.data(), (size_t)n, h->stream))) return rc;
+    }
     hipLaunchKernelGGL(k_halo_pack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, kind, n, d_idx, h->xt, h->vm, h->ntmp, h->dh_n, d_buf);
     HIP_OK(hipMemcpyAsync(buf, d_buf, (size_t)n * w * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -2254,7 +2473,13 @@ int des_dev_halo_unpack(des_dev *h, int kind, const int *idx, int n, const doubl
     int rc;
     if ((rc = dev_alloc(d_idx, (size_t)n))) return rc;
     if ((rc = dev_alloc(d_buf, (size_t)n * w))) return rc;
-    if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
+    if (h->n_old2new.empty()) {
+        if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
+    } else {
+        std::vector<int> midx((size_t)n);
+        for (int k = 0; k < n; ++k) midx[k] = h->n_old2new[idx[k]];
+        if ((rc = dev_upload(d_idx, midx.data(), (size_t)n, h->stream))) return rc;
+    }
     if ((rc = dev_upload(d_buf, buf, (size_t)n * w, h->stream))) return rc;
     hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, kind, n, d_idx, d_buf, h->xt, h->vm, h->ntmp, h->dh_n);
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -2316,9 +2541,9 @@ int des_dev_mesh_quality(des_dev *h, double smallest_vol, double bottom, double 
     HIP_OK(hipMemcpyAsync(d, &init, sizeof(Slots), hipMemcpyHostToDevice, h->stream));
     const int n = std::max(h->ne, h->nn);
     hipLaunchKernelGGL(k_quality_a, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, h->ne, h->nn, h->conn, h->xt, h->volume,
-                       h->bcflag, smallest_vol, bottom, bottom_dist, &d->q, d->i);
+                       h->bcflag, smallest_vol, bottom, bottom_dist, &d->q, d->i, h->d_n_new2old, h->d_e_new2old);
     hipLaunchKernelGGL(k_quality_b, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->ne, h->conn, h->xt, h->volume,
-                       &d->q, d->i);
+                       &d->q, d->i, h->d_e_new2old);
     HIP_OK(hipMemcpyAsync(&res, d, sizeof(Slots), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     hipFree(d);

@@ -559,6 +559,8 @@ des_mesh HostMesh::view() const
     v.support_surf_idx = ssup_idx.data();
     v.support_surf_arr = ssup_arr.data();
     v.top_elems = top_elems.data();
+    v.coord = coord.empty() ? nullptr : coord.data();         // layout hint for the engine
+    v.owned_begin = 0; v.owned_end = nnode;
     return v;
 }
 

@@ -177,6 +177,8 @@ void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
         }
     }
     P.view = m.view();
+    P.view.owned_begin = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), a) - P.l2g_node.begin());
+    P.view.owned_end = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), b) - P.l2g_node.begin());
     P.halo.owned_begin = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), a) - P.l2g_node.begin());
     P.halo.owned_end = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), b) - P.l2g_node.begin());
     P.halo.nnbr = (int)P.nbr_rank.size();

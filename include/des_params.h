@@ -137,6 +137,13 @@ typedef struct des_mesh {
     const int *support_surf_idx;    /* [ntop+1] */
     const int *support_surf_arr;    /* top-facet ids per surface node                               */
     const int *top_elems;           /* [ntop_elems] Variables::top_elems                            */
+    /* Layout hints (optional; the reference has no counterpart).  With `coord` -- the initial
+     * coordinates, SoA [3][nnode] -- the engine stores its arrays in a space-filling-curve order
+     * of its own (nodes within the three id ranges below, elements by centroid) so that a
+     * workgroup's nodes / elements are neighbours in space; every array crossing the C-ABI stays
+     * in the caller's numbering and every list keeps the caller's order.  NULL: caller's order. */
+    const double *coord;
+    int owned_begin, owned_end;     /* the des_halo range this mesh will be given (0, nnode if none) */
 } des_mesh;
 
 /* Domain decomposition (new: the reference is single-process).  A rank's mesh is

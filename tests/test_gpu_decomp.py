@@ -148,8 +148,11 @@ def test_overlapped_exchange_schedule_is_bit_identical_to_the_serial_one():
         for overlap in (0, 1):
             host = des.Host(cfg_text=cfgs.make(**kw))
             nn, ne = host.nnode, host.nelem
-            eng = des.DeviceEngine(host)
             o0, o1 = 200, nn - 300                                  # "halo" = the first 200 and last 300 nodes
+            from dynearthsol_amd._structs import DesMesh
+            m = DesMesh.from_buffer_copy(host.mesh)                 # the engine lays its data out around
+            m.owned_begin, m.owned_end = o0, o1                     # the owned range it is told at create
+            eng = des.DeviceEngine(types.SimpleNamespace(params=host.params, mesh=m))
             recv = np.concatenate([np.arange(0, o0), np.arange(o1, nn)]).astype(np.int32)
             rng = np.random.default_rng(3)
             send = np.sort(rng.choice(np.arange(o0, o1), size=len(recv), replace=False)).astype(np.int32)

@@ -14,8 +14,10 @@ host = des.Host(cfg_text=bench.BENCH_CFG.format(res=repr(400e3 / 560), xlen=repr
 nn = host.nnode
 k = 870
 for overlap in (-1, 0, 1, -1, 0, 1):
-    eng = des.DeviceEngine(host)
     o0, o1 = k, nn - k
+    from dynearthsol_amd._structs import DesMesh
+    m = DesMesh.from_buffer_copy(host.mesh); m.owned_begin, m.owned_end = o0, o1
+    eng = des.DeviceEngine(types.SimpleNamespace(params=host.params, mesh=m))
     recv = np.concatenate([np.arange(0, o0), np.arange(o1, nn)]).astype(np.int32)
     send = recv.copy()      # identity: the halo nodes keep their own values, the geometry stays regular
     nbr = np.zeros(2, np.int32); ptr = np.array([0, k, 2 * k], np.int32)
