@@ -181,3 +181,81 @@ def apply_overrides(text, overrides):
         else:
             text = text.replace("[%s]\n" % sec, "[%s]\n%s = %s\n" % (sec, k, val), 1)
     return text
+
+
+# Parameter values of the reference's examples/oblique-rift-3d.cfg (BASELINE configs[4]: two
+# materials, oblique extension through vbc type 6, PREM reference pressure, dt_fraction 0.5, no
+# surface process); the mesh (meshing_option = 2: TetGen) comes from
+# tests/golden/oblique-rift-3d.desmesh (676 nodes / 2,991 tets).
+OBLIQUE = """
+[sim]
+modelname = result
+max_time_in_yr = 0.1e6
+output_time_interval_in_yr = 50000
+is_outputting_averaged_fields = no
+[mesh]
+meshing_option = 2
+xlength = 200e3
+ylength = 100e3
+zlength = 50e3
+resolution = 5e3
+smallest_size = 0.01
+refined_zonex = [0.3, 0.7]
+refined_zoney = [0.3, 0.7]
+refined_zonez = [0.7, 1.0]
+quality_check_step_interval = 500
+remeshing_option = 11
+[control]
+ref_pressure_option = 1
+dt_fraction = 0.5
+[bc]
+vbc_x0 = 6
+vbc_x1 = 6
+vbc_val_x0 = -3.17e-10
+vbc_val_x1 = 3.17e-10
+vbc_val_x0_l = 1.59e-10
+vbc_val_x1_l = -1.59e-10
+vbc_y0 = 1
+vbc_y1 = 1
+vbc_val_y0 = 0
+vbc_val_y1 = 0
+vbc_n0 = 1
+vbc_val_n0 = 0
+has_water_loading = no
+surface_temperature = 273
+mantle_temperature = 1573
+[ic]
+weakzone_option = 1
+weakzone_azimuth = 0
+weakzone_inclination = 60
+weakzone_halfwidth = 1.5
+weakzone_depth_min = 0.0
+weakzone_depth_max = 1.0
+weakzone_xcenter = 0.5
+weakzone_ycenter = 0.5
+weakzone_zcenter = 0.5
+weakzone_plstrain = 0.5
+oceanic_plate_age_in_yr = 60e6
+[mat]
+rheology_type = elasto-visco-plastic
+num_materials = 2
+rho0 = [2800, 3300]
+alpha = [3e-5]
+bulk_modulus = [50e9]
+shear_modulus = [30e9]
+visc_exponent = [3.05]
+visc_coefficient = [1.25e-1]
+visc_activation_energy = [3.76e5]
+heat_capacity = [1000]
+therm_cond = [3.3]
+pls0 = [0]
+pls1 = [0.1]
+cohesion0 = [4e7]
+cohesion1 = [4e6]
+friction_angle0 = [30]
+friction_angle1 = [30]
+dilation_angle0 = [0]
+dilation_angle1 = [0]
+max_viscosity = 1e24
+min_viscosity = 1e19
+"""
