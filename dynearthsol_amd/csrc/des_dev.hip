@@ -125,6 +125,7 @@ struct des_dev {
     double *etmp2, *ftmp;                 // dp*vol ; force tr [ne][4][3]
     double *res_part;                     // per-block partial sums of the residual
     int n3_blocks;
+    int npb;                              // nodes per node-kernel workgroup (choose_npb)
     // stress-bc lists
     int nbcf;                             // facets with a stress bc (incl. neumann)
     int *bcf_elem, *bcf_facet, *bcf_kind; // kind: 0 winkler, 1 water, 2 side wall, 3+d neumann dir d
@@ -458,7 +459,7 @@ __device__ __forceinline__ int lds_slot(int j) { return j + (j >> 3); }
 // is formed from the gathered volume instead of being gathered itself (one LDS plane less).
 template <int FULL, int CONSTM>
 __global__ void __launch_bounds__(DES_BLOCK)
-N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int o0, int nn, int nblocks,
+N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int o0, int nn, int nblocks, int npb,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
      const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp, const double *__restrict__ props, int ne,
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
@@ -468,9 +469,11 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     constexpr int NPL = CONSTM ? 4 : 5;
     __shared__ double lds[NPL][DES_TILE_LDS(TILE)];
     // nodes [o0, nn) are this rank's owned nodes (the whole mesh on one GPU)
+    // a workgroup owns `npb` consecutive nodes (256, or 64 on small meshes so that there are
+    // enough workgroups: all 256 lanes still share the gather phase, the first npb do the sums)
     const int lb = desk::logical_block(nblocks);
-    const int n0 = o0 + lb * DES_BLOCK;
-    const int n = n0 + threadIdx.x;
+    const int n0 = o0 + lb * npb;
+    const int n = (threadIdx.x < npb) ? n0 + threadIdx.x : nn;
     const double dt = clk->dt;
     if (FULL && blockIdx.x == 0 && threadIdx.x == 0) {
         clk->steps += 1;
@@ -482,7 +485,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     const bool need_ym = p->damping_option == 4;
     const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
     const double rho_m = p->bulk_modulus[0] / (pseudo_speed * pseudo_speed);
-    const int nlast = min(n0 + DES_BLOCK, nn);
+    const int nlast = min(n0 + npb, nn);
     const int kb = sup_idx[n0], ke = sup_idx[nlast];
     int r0 = ke, r1 = ke;
     if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
@@ -689,15 +692,15 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
 // ---- N2 --------------------------------------------------------------------------
 // NMD_stress gather (geometry.cxx:302-309)
 __global__ void __launch_bounds__(DES_BLOCK)
-N2_nmd_gather(int o0, int nn, int nblocks, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
+N2_nmd_gather(int o0, int nn, int nblocks, int npb, const int *__restrict__ sup_idx, const int *__restrict__ sup_pack,
      const double *__restrict__ etmp2, const double *__restrict__ volume_n, double *__restrict__ ntmp)
 {
     __shared__ double lds[DES_TILE_LDS(DES_TILE_N2)];
     const int TILE = DES_TILE_N2;
-    const int n0 = o0 + desk::logical_block(nblocks) * DES_BLOCK;
-    const int n = n0 + threadIdx.x;
+    const int n0 = o0 + desk::logical_block(nblocks) * npb;
+    const int n = (threadIdx.x < npb) ? n0 + threadIdx.x : nn;
     if (n0 >= nn) return;
-    const int nlast = min(n0 + DES_BLOCK, nn);
+    const int nlast = min(n0 + npb, nn);
     const int kb = sup_idx[n0], ke = sup_idx[nlast];
     int r0 = ke, r1 = ke;
     if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
@@ -965,7 +968,7 @@ k_apply_vbcs(const des_params *__restrict__ p, const DevClock *__restrict__ clk,
 // update_coordinate (fields.cxx:761-784)
 __global__ void __launch_bounds__(DES_BLOCK)
 N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int o0, int nn_own_end,
-     int nn, int nn_global, int nblocks,
+     int nn, int nn_global, int nblocks, int npb,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
      const double *__restrict__ ftmp, unsigned bc_mask, const int *__restrict__ bcn_idx,
      const int *__restrict__ bcn_ent, const double *__restrict__ bcf_tmp,
@@ -978,10 +981,10 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
     __shared__ double red[DES_BLOCK / 64];
     // owned nodes are [o0, nn_own_end); nn is the local node count (stride of the SoA planes)
     const int lb = desk::logical_block(nblocks);
-    const int n0 = o0 + lb * DES_BLOCK;
-    const int n = n0 + threadIdx.x;
+    const int n0 = o0 + lb * npb;
+    const int n = (threadIdx.x < npb) ? n0 + threadIdx.x : nn_own_end;
     if (n0 >= nn_own_end) return;
-    const int nlast = min(n0 + DES_BLOCK, nn_own_end);
+    const int nlast = min(n0 + npb, nn_own_end);
     const int kb = sup_idx[n0], ke = sup_idx[nlast];
     int r0 = ke, r1 = ke;
     if (n < nn_own_end) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
@@ -1427,12 +1430,26 @@ void launch_avg_coord0(des_dev *h, long long step_no)
         hipLaunchKernelGGL(k_avg_coord0, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->nn, h->xt, h->coord_avg0);
 }
 
+// node workgroups: ceil(owned nodes / nodes per workgroup), and the grid rounded up to the 8 XCDs
+inline int node_blocks(const des_dev *h) { return (h->o1 - h->o0 + h->npb - 1) / h->npb; }
+inline int node_grid(const des_dev *h) { return (node_blocks(h) + 7) / 8 * 8; }
+
+// nodes per node-kernel workgroup: 256, or 64 while that leaves fewer than two workgroups per CU
+// (a 137k-tet mesh has 31k nodes = 120 workgroups of 256 on 256 CUs, each walking 4-5 incidence
+// tiles one after the other)
+void choose_npb(des_dev *h)
+{
+    const char *env = std::getenv("DES_NPB");
+    const int nown = h->o1 - h->o0;
+    h->npb = (nown < 512 * DES_BLOCK) ? 64 : DES_BLOCK;
+    if (env && (std::atoi(env) == 64 || std::atoi(env) == 128 || std::atoi(env) == 256)) h->npb = std::atoi(env);
+}
+
 // compute_mass gather alone (N1 without the temperature / dvoldt parts)
 void launch_mass_gather(des_dev *h)
 {
-    const int nown = h->o1 - h->o0;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream,
-                       h->d_p, h->d_clk, h->o0, h->o1, nblk(nown), h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
+                       h->d_p, h->d_clk, h->o0, h->o1, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
                        h->props, h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
@@ -1451,14 +1468,14 @@ inline bool surface_diffusion_on(const des_dev *h)
 void launch_n1(des_dev *h)
 {
     Launch l(h, K_N1);
-    const int nown = h->o1 - h->o0, nbn = nblk(nown);
+    const int nbn = node_blocks(h);
     if (h->const_mass)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream,
-                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
+                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
     else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream,
-                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
+                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
@@ -1476,8 +1493,10 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
 void launch_n2(des_dev *h)
 {
     Launch l(h, K_N2);
-    const int nown = h->o1 - h->o0;
-    hipLaunchKernelGGL(N2_nmd_gather, dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream, h->o0, h->o1, nblk(nown), h->sup_idx,
+    // one double per incidence: the lightest gather, best with at most 128 nodes per workgroup
+    // even on large meshes (1.1M tets: 22.7 us at 256, 17.6 at 128)
+    const int npb2 = std::min(h->npb, 128), nb2 = (h->o1 - h->o0 + npb2 - 1) / npb2;
+    hipLaunchKernelGGL(N2_nmd_gather, dim3((nb2 + 7) / 8 * 8), dim3(DES_BLOCK), 0, h->stream, h->o0, h->o1, nb2, npb2, h->sup_idx,
                        h->sup_pack, h->etmp2, h->volume_n, h->ntmp);
 }
 
@@ -1498,8 +1517,8 @@ void launch_n3(des_dev *h)
 {
     Launch l(h, K_N3);
     const int nown = h->o1 - h->o0;
-    hipLaunchKernelGGL(N3_force_velocity_coord, dim3(nblk8(nown)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->o0, h->o1,
-                       h->nn, h->nn_global, nblk(nown), h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx,
+    hipLaunchKernelGGL(N3_force_velocity_coord, dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->o0, h->o1,
+                       h->nn, h->nn_global, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx,
                        h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
                        h->force, h->fres, h->res_part);
 }
@@ -1528,7 +1547,7 @@ void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
     const int nzb = (commit && surf) ? nblk(h->ntop) : 0;
     const int nown = h->o1 - h->o0;
     hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + nzb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb,
-                       h->conn_surf, h->xt, h->dh_n, h->edvacc, h->res_part, nblk(nown), h->ntop, nzb, h->top_nodes,
+                       h->conn_surf, h->xt, h->dh_n, h->edvacc, h->res_part, node_blocks(h), h->ntop, nzb, h->top_nodes,
                        h->znew, h->o0, h->o1, (int)finalize);
 }
 
@@ -1913,7 +1932,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         HK(hipMemsetAsync(h->stress_avg, 0, 48*(size_t)ne, h->stream)); HK(hipMemsetAsync(h->strain0, 0, 48*(size_t)ne, h->stream));
         HK(hipMemsetAsync(h->dplstrain_avg, 0, 8*(size_t)ne, h->stream)); HK(hipMemsetAsync(h->coord_avg0, 0, 24*(size_t)nn, h->stream));
     }
-    h->n3_blocks = nblk8(nn);
+    choose_npb(h);
+    h->n3_blocks = node_grid(h);
     CK(dev_alloc(h->res_part, (size_t)h->n3_blocks));
     {
         struct { void *p; size_t bytes; } zero[] = {
@@ -2358,7 +2378,8 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     }
     // the residual partials are indexed by owned-node block
     if (h->res_part) hipFree(h->res_part);
-    h->n3_blocks = nblk8(h->o1 - h->o0);
+    choose_npb(h);
+    h->n3_blocks = node_grid(h);
     return dev_alloc(h->res_part, (size_t)h->n3_blocks);
 }
 
