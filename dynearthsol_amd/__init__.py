@@ -326,13 +326,9 @@ class DeviceEngine(EngineBase):
     def algorithmic_bytes_per_step(self):
         return self._lib.des_dev_algorithmic_bytes_per_step(self._h)
 
-    def set_overlap(self, on):
-        self._lib.des_dev_set_overlap.argtypes = [C.c_void_p, C.c_int]
-        return self._lib.des_dev_set_overlap(self._h, 1 if on else 0)
-
-    def exchange(self, kind):
-        self._lib.des_dev_exchange.argtypes = [C.c_void_p, C.c_int]
-        self._check(self._lib.des_dev_exchange(self._h, kind), "exchange")
+    def exchange(self):
+        self._lib.des_dev_exchange.argtypes = [C.c_void_p]
+        self._check(self._lib.des_dev_exchange(self._h), "exchange")
 
     def comm_init(self, dist, rank, world):
         """Attach an RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed only

@@ -64,9 +64,10 @@ class DesMesh(C.Structure):
 
 class DesHalo(C.Structure):
     _fields_ = [
-        ("owned_begin", C.c_int), ("owned_end", C.c_int), ("nnbr", C.c_int),
+        ("owned_begin", C.c_int), ("owned_end", C.c_int), ("nlayers", C.c_int), ("nnbr", C.c_int),
         ("nbr_rank", _pint), ("send_ptr", _pint), ("send_idx", _pint),
         ("recv_ptr", _pint), ("recv_idx", _pint),
+        ("esend_ptr", _pint), ("esend_idx", _pint), ("erecv_ptr", _pint), ("erecv_idx", _pint),
     ]
 
 

@@ -145,17 +145,15 @@ struct des_dev {
     int nnbr;
     std::vector<int> nbr_rank, send_ptr, recv_ptr;         // host copies of the list offsets
     int *d_send_idx, *d_recv_idx;
-    double *d_sendbuf, *d_recvbuf;                         // DES_X_WIDTH_2 doubles per listed node
+    double *d_sendbuf, *d_recvbuf;                         // one message per neighbour: node records, then element records
     double *d_red;                                         // 8 doubles: dt partials / scalar reductions
     double *dh_n;                                          // nodal copy of surfinfo.dh
     ncclComm_t comm;
     int comm_rank, comm_size;
-    // overlap of the first two exchanges with the interior elements
-    hipStream_t comm_stream;
-    hipEvent_t ev_ready, ev_done;
-    std::vector<int> h_conn;                               // host copy of the connectivity (set_halo)
-    int e_lo_end, e_hi_begin;                              // elements in between touch no halo node
-    bool overlap;
+    // element part of the exchange lists and the record offsets inside the message buffers
+    std::vector<int> esend_ptr, erecv_ptr;
+    std::vector<long long> send_off, recv_off;             // [nnbr+1] message offsets (doubles) per neighbour
+    int *d_esend_idx, *d_erecv_idx, *d_send_noff, *d_send_eoff, *d_recv_noff, *d_recv_eoff;
     // internal data order (des_mesh::coord hint): device index <-> caller's index; empty = identity
     std::vector<int> n_new2old, n_old2new, e_new2old, e_old2new;
     int *d_n_new2old, *d_e_new2old;
@@ -979,15 +977,16 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
 {
     __shared__ double lds[3][DES_TILE_LDS(DES_TILE_N3)];
     __shared__ double red[DES_BLOCK / 64];
-    // owned nodes are [o0, nn_own_end); nn is the local node count (stride of the SoA planes)
+    // every local node is updated (nn = local node count = stride of the SoA planes); the owned
+    // nodes [o0, nn_own_end) alone enter the residual
     const int lb = desk::logical_block(nblocks);
-    const int n0 = o0 + lb * npb;
-    const int n = (threadIdx.x < npb) ? n0 + threadIdx.x : nn_own_end;
-    if (n0 >= nn_own_end) return;
-    const int nlast = min(n0 + npb, nn_own_end);
+    const int n0 = lb * npb;
+    const int n = (threadIdx.x < npb) ? n0 + threadIdx.x : nn;
+    if (n0 >= nn) return;
+    const int nlast = min(n0 + npb, nn);
     const int kb = sup_idx[n0], ke = sup_idx[nlast];
     int r0 = ke, r1 = ke;
-    if (n < nn_own_end) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
+    if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n+1]; }
     double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
 #if DES_PIPE
     constexpr int PER = DES_TILE_N3 / DES_BLOCK;
@@ -1038,7 +1037,7 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
         __syncthreads();
     }
     double l2 = 0.0;
-    if (n < nn_own_end) {
+    if (n < nn) {
         const double dt = clk->dt;
         const unsigned flag = bcflag[n];
         d4 x4 = xt[n];
@@ -1094,10 +1093,12 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
             fres[(size_t)j*nn + n] = fr[j];
             v[j] += dt * f[j] / m4.w;
         }
-        const double num = (double)nn_global * 3;
-        l2 = fr[0]*fr[0] / num;
-        l2 += fr[1]*fr[1] / num;
-        l2 += fr[2]*fr[2] / num;
+        if (n >= o0 && n < nn_own_end) {
+            const double num = (double)nn_global * 3;
+            l2 = fr[0]*fr[0] / num;
+            l2 += fr[1]*fr[1] / num;
+            l2 += fr[2]*fr[2] / num;
+        }
         if (flag & 0x3ffu)
             apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
         m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
@@ -1133,7 +1134,7 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     double d = 0.;
     const int n = (i < ntop) ? top_nodes[i] : -1;
-    if (n >= o0 && n < o1) {                    // owned surface nodes; halo ones arrive by exchange
+    if (n >= 0) {                               // every local surface node; [o0, o1) = the owned ones
         if (diffuse) {
             double total_dx = 0., total_slope = 0.;
             // facets in batches of four: all facet ids, then all node ids, then all node records are
@@ -1191,7 +1192,7 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
     }
     // max |dh| (bc.cxx:1811-1821); max is order-independent
     __shared__ double red[DES_BLOCK / 64];
-    double m = desk::wave_max(fabs(d));
+    double m = desk::wave_max((n >= o0 && n < o1) ? fabs(d) : 0.0);      // owned nodes only: ghosts may be stale
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1214,8 +1215,7 @@ k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int 
     if ((int)blockIdx.x >= nsurf_blocks && (int)blockIdx.x < nsurf_blocks + nz_blocks) {
         const int i = ((int)blockIdx.x - nsurf_blocks) * DES_BLOCK + threadIdx.x;
         if (i < ntop) {
-            const int n = top_nodes[i];
-            if (n >= o0 && n < o1) xt[n].z = znew[i];
+            xt[top_nodes[i]].z = znew[i];
         }
         return;
     }
@@ -1248,37 +1248,52 @@ k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int 
     }
 }
 
-// ---- halo exchange ---------------------------------------------------------------
-// nodal values of exchange `kind` (des_params.h DES_X_*) for the local nodes idx[0..n)
+// ---- ghost-region exchange (des_halo, des_params.h) ------------------------------------
+// State of the listed nodes {x,y,z,vx,vy,vz,T,dh} and elements {stress, strain, plstrain} to /
+// from a message buffer; off[i] = position (in doubles) of item i's record in the buffer, so one
+// launch fills the messages of all neighbours (a message = node records, then element records).
 __global__ void __launch_bounds__(DES_BLOCK)
-k_halo_pack(int kind, int n, const int *__restrict__ idx, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
-            const double *__restrict__ ntmp, const double *__restrict__ dh_n, double *__restrict__ buf)
+k_state_pack(int nnodes, const int *__restrict__ nidx, const int *__restrict__ noff,
+             int nelems, const int *__restrict__ eidx, const int *__restrict__ eoff,
+             const d4 *__restrict__ xt, const d4 *__restrict__ vm, const double *__restrict__ dh_n,
+             const double *__restrict__ stress, const double *__restrict__ strain,
+             const double *__restrict__ plstrain, int ne, double *__restrict__ buf)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int k = idx[i];
-    if (kind == DES_X_TEMP_NTMP) { buf[2*i] = xt[k].w; buf[2*i+1] = ntmp[k]; }
-    else if (kind == DES_X_NTMP) { buf[i] = ntmp[k]; }
-    else if (kind == DES_X_VEL_COORD) {
-        const d4 v = vm[k], x = xt[k];
-        buf[6*i] = v.x; buf[6*i+1] = v.y; buf[6*i+2] = v.z; buf[6*i+3] = x.x; buf[6*i+4] = x.y; buf[6*i+5] = x.z;
-    } else { buf[2*i] = xt[k].z; buf[2*i+1] = dh_n[k]; }
+    if (i < nnodes) {
+        const int k = nidx[i];
+        const d4 x = xt[k], v = vm[k];
+        double *b = buf + noff[i];
+        b[0] = x.x; b[1] = x.y; b[2] = x.z; b[3] = v.x; b[4] = v.y; b[5] = v.z; b[6] = x.w; b[7] = dh_n[k];
+    } else if (i < nnodes + nelems) {
+        const int j = i - nnodes, e = eidx[j];
+        double *b = buf + eoff[j];
+        for (int c = 0; c < 6; ++c) { b[c] = stress[(size_t)c*ne + e]; b[6 + c] = strain[(size_t)c*ne + e]; }
+        b[12] = plstrain[e];
+    }
 }
 
 __global__ void __launch_bounds__(DES_BLOCK)
-k_halo_unpack(int kind, int n, const int *__restrict__ idx, const double *__restrict__ buf, d4 *__restrict__ xt,
-              d4 *__restrict__ vm, double *__restrict__ ntmp, double *__restrict__ dh_n)
+k_state_unpack(int nnodes, const int *__restrict__ nidx, const int *__restrict__ noff,
+               int nelems, const int *__restrict__ eidx, const int *__restrict__ eoff,
+               d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ dh_n,
+               double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
+               int ne, const double *__restrict__ buf)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int k = idx[i];
-    if (kind == DES_X_TEMP_NTMP) { xt[k].w = buf[2*i]; ntmp[k] = buf[2*i+1]; }
-    else if (kind == DES_X_NTMP) { ntmp[k] = buf[i]; }
-    else if (kind == DES_X_VEL_COORD) {
-        d4 v = vm[k], x = xt[k];
-        v.x = buf[6*i]; v.y = buf[6*i+1]; v.z = buf[6*i+2]; x.x = buf[6*i+3]; x.y = buf[6*i+4]; x.z = buf[6*i+5];
-        vm[k] = v; xt[k] = x;
-    } else { xt[k].z = buf[2*i]; dh_n[k] = buf[2*i+1]; }
+    if (i < nnodes) {
+        const int k = nidx[i];
+        const double *b = buf + noff[i];
+        d4 x, v = vm[k];                                   // the nodal mass stays this rank's own
+        x.x = b[0]; x.y = b[1]; x.z = b[2]; x.w = b[6];
+        v.x = b[3]; v.y = b[4]; v.z = b[5];
+        xt[k] = x; vm[k] = v; dh_n[k] = b[7];
+    } else if (i < nnodes + nelems) {
+        const int j = i - nnodes, e = eidx[j];
+        const double *b = buf + eoff[j];
+        for (int c = 0; c < 6; ++c) { stress[(size_t)c*ne + e] = b[c]; strain[(size_t)c*ne + e] = b[6 + c]; }
+        plstrain[e] = b[12];
+    }
 }
 
 // compute_dt partials of this rank, all arranged for a MIN reduction across ranks
@@ -1431,7 +1446,9 @@ void launch_avg_coord0(des_dev *h, long long step_no)
 }
 
 // node workgroups: ceil(owned nodes / nodes per workgroup), and the grid rounded up to the 8 XCDs
-inline int node_blocks(const des_dev *h) { return (h->o1 - h->o0 + h->npb - 1) / h->npb; }
+// The node kernels run over EVERY local node: on a decomposed mesh the ghost region is computed
+// redundantly (des_halo); only the reductions are restricted to the owned range [o0, o1).
+inline int node_blocks(const des_dev *h) { return (h->nn + h->npb - 1) / h->npb; }
 inline int node_grid(const des_dev *h) { return (node_blocks(h) + 7) / 8 * 8; }
 
 // nodes per node-kernel workgroup: 256, or 64 while that leaves fewer than two workgroups per CU
@@ -1440,7 +1457,7 @@ inline int node_grid(const des_dev *h) { return (node_blocks(h) + 7) / 8 * 8; }
 void choose_npb(des_dev *h)
 {
     const char *env = std::getenv("DES_NPB");
-    const int nown = h->o1 - h->o0;
+    const int nown = h->nn;
     h->npb = (nown < 512 * DES_BLOCK) ? 64 : DES_BLOCK;
     if (env && (std::atoi(env) == 64 || std::atoi(env) == 128 || std::atoi(env) == 256)) h->npb = std::atoi(env);
 }
@@ -1449,7 +1466,7 @@ void choose_npb(des_dev *h)
 void launch_mass_gather(des_dev *h)
 {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
-                       h->d_p, h->d_clk, h->o0, h->o1, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
+                       h->d_p, h->d_clk, 0, h->nn, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
                        h->props, h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
@@ -1471,11 +1488,11 @@ void launch_n1(des_dev *h)
     const int nbn = node_blocks(h);
     if (h->const_mass)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
-                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
-                           h->d_p, h->d_clk, h->o0, h->o1, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
@@ -1495,8 +1512,8 @@ void launch_n2(des_dev *h)
     Launch l(h, K_N2);
     // one double per incidence: the lightest gather, best with at most 128 nodes per workgroup
     // even on large meshes (1.1M tets: 22.7 us at 256, 17.6 at 128)
-    const int npb2 = std::min(h->npb, 128), nb2 = (h->o1 - h->o0 + npb2 - 1) / npb2;
-    hipLaunchKernelGGL(N2_nmd_gather, dim3((nb2 + 7) / 8 * 8), dim3(DES_BLOCK), 0, h->stream, h->o0, h->o1, nb2, npb2, h->sup_idx,
+    const int npb2 = std::min(h->npb, 128), nb2 = (h->nn + npb2 - 1) / npb2;
+    hipLaunchKernelGGL(N2_nmd_gather, dim3((nb2 + 7) / 8 * 8), dim3(DES_BLOCK), 0, h->stream, 0, h->nn, nb2, npb2, h->sup_idx,
                        h->sup_pack, h->etmp2, h->volume_n, h->ntmp);
 }
 
@@ -1552,64 +1569,30 @@ void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
 }
 
 // ---- halo exchange through RCCL on the engine's stream ---------------------------
-const int kXWidth[DES_X_COUNT] = {DES_X_WIDTH_0, DES_X_WIDTH_1, DES_X_WIDTH_2, DES_X_WIDTH_3};
 
-// With `overlapped` the exchange runs on the engine's second stream between two events: it starts
-// when the compute stream has produced the values to send, and the caller makes the compute
-// stream wait for it (wait_exchange) only in front of the first kernel that reads halo values.
-int exchange(des_dev *h, int kind, bool overlapped = false)
+// The exchange of a step: one grouped send/recv per neighbour carrying the state of the whole
+// ghost region, between a pack and an unpack launch, all on the engine's stream.
+int exchange(des_dev *h)
 {
     if (h->nnbr == 0) return DES_OK;
     if (!h->comm) { g_last_error = "decomposed engine without a communicator: call des_dev_comm_init"; return DES_ERR_INTERNAL; }
-    hipStream_t st = h->stream;
-    if (overlapped) {
-        st = h->comm_stream;
-        HIP_OK(hipEventRecord(h->ev_ready, h->stream));
-        HIP_OK(hipStreamWaitEvent(st, h->ev_ready, 0));
-    }
-    const int w = kXWidth[kind];
-    const int nsend = h->send_ptr[h->nnbr], nrecv = h->recv_ptr[h->nnbr];
-    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(nsend)), dim3(DES_BLOCK), 0, st, kind, nsend, h->d_send_idx, h->xt, h->vm,
-                       h->ntmp, h->dh_n, h->d_sendbuf);
+    const int ns = h->send_ptr[h->nnbr], nes = h->esend_ptr[h->nnbr];
+    const int nr = h->recv_ptr[h->nnbr], ner = h->erecv_ptr[h->nnbr];
+    hipLaunchKernelGGL(k_state_pack, dim3(nblk(ns + nes)), dim3(DES_BLOCK), 0, h->stream, ns, h->d_send_idx, h->d_send_noff,
+                       nes, h->d_esend_idx, h->d_send_eoff, h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain,
+                       h->ne, h->d_sendbuf);
     ncclGroupStart();
     for (int q = 0; q < h->nnbr; ++q) {
-        ncclSend(h->d_sendbuf + (size_t)h->send_ptr[q] * w, (size_t)(h->send_ptr[q+1] - h->send_ptr[q]) * w, ncclDouble,
-                 h->nbr_rank[q], h->comm, st);
-        ncclRecv(h->d_recvbuf + (size_t)h->recv_ptr[q] * w, (size_t)(h->recv_ptr[q+1] - h->recv_ptr[q]) * w, ncclDouble,
-                 h->nbr_rank[q], h->comm, st);
+        ncclSend(h->d_sendbuf + h->send_off[q], (size_t)(h->send_off[q+1] - h->send_off[q]), ncclDouble,
+                 h->nbr_rank[q], h->comm, h->stream);
+        ncclRecv(h->d_recvbuf + h->recv_off[q], (size_t)(h->recv_off[q+1] - h->recv_off[q]), ncclDouble,
+                 h->nbr_rank[q], h->comm, h->stream);
     }
     ncclResult_t r = ncclGroupEnd();
     if (r != ncclSuccess) { g_last_error = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
-    hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(nrecv)), dim3(DES_BLOCK), 0, st, kind, nrecv, h->d_recv_idx, h->d_recvbuf,
-                       h->xt, h->vm, h->ntmp, h->dh_n);
-    if (overlapped) HIP_OK(hipEventRecord(h->ev_done, st));
-    return DES_OK;
-}
-
-int wait_exchange(des_dev *h)
-{
-    HIP_OK(hipStreamWaitEvent(h->stream, h->ev_done, 0));
-    return DES_OK;
-}
-
-// E2 / E3 of a decomposed mesh around an exchange: the elements that touch no halo node
-// ([e_lo_end, e_hi_begin), des_dev_set_halo) run while the halo values travel, the two boundary
-// ranges after they have arrived.
-template <typename F>
-int exchange_under(des_dev *h, int kind, F launch)
-{
-    if (!h->overlap) {
-        int rc = exchange(h, kind);
-        if (rc) return rc;
-        launch(0, h->ne, true);
-        return DES_OK;
-    }
-    int rc = exchange(h, kind, true);
-    if (rc) return rc;
-    launch(h->e_lo_end, h->e_hi_begin - h->e_lo_end, true);
-    if ((rc = wait_exchange(h))) return rc;
-    launch(0, h->e_lo_end, false);
-    launch(h->e_hi_begin, h->ne - h->e_hi_begin, false);
+    hipLaunchKernelGGL(k_state_unpack, dim3(nblk(nr + ner)), dim3(DES_BLOCK), 0, h->stream, nr, h->d_recv_idx, h->d_recv_noff,
+                       ner, h->d_erecv_idx, h->d_recv_eoff, h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain,
+                       h->ne, h->d_recvbuf);
     return DES_OK;
 }
 
@@ -1815,7 +1798,8 @@ void des_dev_destroy(des_dev *h)
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     void *ptrs[] = { h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
-        h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->stress, h->strain,
+        h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->d_esend_idx, h->d_erecv_idx, h->d_send_noff,
+        h->d_send_eoff, h->d_recv_noff, h->d_recv_eoff, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
         h->radiogenic, h->markers, h->props, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
@@ -1826,9 +1810,6 @@ void des_dev_destroy(des_dev *h)
     if (h->h_clk) hipHostFree(h->h_clk);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->ev_ready) hipEventDestroy(h->ev_ready);
-    if (h->ev_done) hipEventDestroy(h->ev_done);
-    if (h->comm_stream) hipStreamDestroy(h->comm_stream);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1902,7 +1883,6 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             c4[e] = make_int4(mesh->connectivity[e], mesh->connectivity[(size_t)ne + e],
                               mesh->connectivity[(size_t)2*ne + e], mesh->connectivity[(size_t)3*ne + e]);
         CK(dev_alloc(h->conn, (size_t)ne)); CK(dev_upload(h->conn, c4.data(), (size_t)ne, h->stream));
-        h->h_conn.assign(mesh->connectivity, mesh->connectivity + (size_t)4*ne);
         std::vector<int> pack((size_t)4*ne);
         for (size_t k = 0; k < pack.size(); ++k) pack[k] = mesh->support_arr[k] * 4 + mesh->support_lidx[k];
         CK(dev_alloc(h->sup_idx, (size_t)nn + 1)); CK(dev_upload(h->sup_idx, mesh->support_idx, (size_t)nn + 1, h->stream));
@@ -2243,9 +2223,10 @@ int des_dev_compute_dt(des_dev *h, double *dt)
     return h->h_clk->status;
 }
 
-// One step = five phases with a halo exchange after each of the first four (des_params.h).
-// On one GPU the exchanges vanish and the passes are back to back; the end of step t (E1's
-// C part) stays fused with the start of step t+1 (A part) whenever another step follows.
+// One step.  On a decomposed mesh everything up to the committed surface heights runs on the
+// local mesh alone (redundantly on the ghost region), then ONE exchange refreshes the ghost
+// region (des_halo, des_params.h), then the end-of-step geometry pass; the end of step t (E1's C
+// part) stays fused with the start of step t+1 (A part) whenever another step follows.
 int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
 {
     if (!h) return DES_ERR_INTERNAL;
@@ -2261,25 +2242,16 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     for (int i = 0; i < nsteps; ++i) {
         const long long step_no = ++h->steps_host;
         if (i == 0) launch_e1<MODE_A>(h);
-        launch_n1(h);                                              // phase 0
-        if (multi) {                                               // phase 1
-            if ((rc = exchange_under(h, DES_X_TEMP_NTMP, [&](int b, int n, bool) { launch_e2(h, b, n); }))) return rc;
-        } else {
-            launch_e2(h);
-        }
+        launch_n1(h);
+        launch_e2(h);
         if (nmd) launch_n2(h);
-        if (nmd && multi) {                                        // phase 2
-            if ((rc = exchange_under(h, DES_X_NTMP, [&](int b, int n, bool fac) { launch_e3(h, b, n, fac); }))) return rc;
-        } else {
-            launch_e3(h);
-        }
+        launch_e3(h);
         launch_n3(h);
-        if (multi && (rc = exchange(h, DES_X_VEL_COORD))) return rc;
-        launch_s2(h, step_no);                                     // phase 3
-        if (multi && surface_diffusion_on(h)) {
-            launch_s3(h, true, false, false);
-            if ((rc = exchange(h, DES_X_SURFACE))) return rc;
-            launch_s3(h, false, true, true);                       // phase 4
+        launch_s2(h, step_no);
+        if (multi) {
+            launch_s3(h, true, false, false);                      // commit the surface heights
+            if ((rc = exchange(h))) return rc;
+            launch_s3(h, false, true, true);
         } else {
             launch_s3(h, true, true, true);
         }
@@ -2325,57 +2297,56 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     h->o0 = halo->owned_begin; h->o1 = halo->owned_end; h->nn_global = nnode_global;
     h->nnbr = halo->nnbr;
     h->nbr_rank.assign(halo->nbr_rank, halo->nbr_rank + halo->nnbr);
-    h->send_ptr.assign(halo->send_ptr, halo->send_ptr + halo->nnbr + 1);
-    h->recv_ptr.assign(halo->recv_ptr, halo->recv_ptr + halo->nnbr + 1);
-    const size_t ns = (size_t)h->send_ptr[h->nnbr], nr = (size_t)h->recv_ptr[h->nnbr];
-    for (void *q : {(void *)h->d_send_idx, (void *)h->d_recv_idx, (void *)h->d_sendbuf, (void *)h->d_recvbuf}) if (q) hipFree(q);
-    int rc;
-    if ((rc = dev_alloc(h->d_send_idx, ns))) return rc;
-    if ((rc = dev_alloc(h->d_recv_idx, nr))) return rc;
-    if ((rc = dev_alloc(h->d_sendbuf, ns * DES_X_WIDTH_2))) return rc;
-    if ((rc = dev_alloc(h->d_recvbuf, nr * DES_X_WIDTH_2))) return rc;
-    if (h->n_old2new.empty()) {
-        if ((rc = dev_upload(h->d_send_idx, halo->send_idx, ns, h->stream))) return rc;
-        if ((rc = dev_upload(h->d_recv_idx, halo->recv_idx, nr, h->stream))) return rc;
-    } else {
+    const int nq = halo->nnbr;
+    h->send_ptr.assign(halo->send_ptr, halo->send_ptr + nq + 1);
+    h->recv_ptr.assign(halo->recv_ptr, halo->recv_ptr + nq + 1);
+    h->esend_ptr.assign(halo->esend_ptr, halo->esend_ptr + nq + 1);
+    h->erecv_ptr.assign(halo->erecv_ptr, halo->erecv_ptr + nq + 1);
+    const size_t ns = (size_t)h->send_ptr[nq], nr = (size_t)h->recv_ptr[nq];
+    const size_t nes = (size_t)h->esend_ptr[nq], ner = (size_t)h->erecv_ptr[nq];
+    for (void *q : {(void *)h->d_send_idx, (void *)h->d_recv_idx, (void *)h->d_sendbuf, (void *)h->d_recvbuf,
+                    (void *)h->d_esend_idx, (void *)h->d_erecv_idx, (void *)h->d_send_noff, (void *)h->d_send_eoff,
+                    (void *)h->d_recv_noff, (void *)h->d_recv_eoff}) if (q) hipFree(q);
+    if (!h->n_old2new.empty()) {
         // the internal order was laid out around des_mesh::owned_begin/end: it must be this range
         bool range_ok = true;
         for (int n = 0; n < h->nn && range_ok; ++n)
             range_ok = (n >= h->o0 && n < h->o1) == (h->n_old2new[n] >= h->o0 && h->n_old2new[n] < h->o1);
         if (!range_ok) { g_last_error = "des_halo owned range differs from des_mesh::owned_begin/owned_end"; return DES_ERR_INTERNAL; }
-        std::vector<int> sidx(ns), ridx(nr);
-        for (size_t k = 0; k < ns; ++k) sidx[k] = h->n_old2new[halo->send_idx[k]];
-        for (size_t k = 0; k < nr; ++k) ridx[k] = h->n_old2new[halo->recv_idx[k]];
-        if ((rc = dev_upload(h->d_send_idx, sidx.data(), ns, h->stream))) return rc;
-        if ((rc = dev_upload(h->d_recv_idx, ridx.data(), nr, h->stream))) return rc;
     }
-    // interior element range for the overlapped exchanges: every element with a node below the
-    // owned range has an id < e_lo_end, every one with a node above it an id >= e_hi_begin
-    // (ids follow x, mesh.cxx:2742-2792); both limits on workgroup boundaries
-    {
-        int max_lo = -1, min_hi = h->ne;
-        for (int e = 0; e < h->ne; ++e)
-            for (int i = 0; i < 4; ++i) {
-                const int n = h->h_conn[(size_t)i * h->ne + e];
-                if (n < h->o0 && e > max_lo) max_lo = e;
-                if (n >= h->o1 && e < min_hi) min_hi = e;
-            }
-        h->e_lo_end = std::min(h->ne, (max_lo + 1 + DES_BLOCK - 1) / DES_BLOCK * DES_BLOCK);
-        h->e_hi_begin = std::max(h->e_lo_end, min_hi / DES_BLOCK * DES_BLOCK);
-        // Off unless DES_OVERLAP=1 / des_dev_set_overlap: measured on one MI355X (tools/time_overlap.py,
-        // 1.1M tets, the rank as its own neighbour) an exchange costs 18.7 us in-stream, but every
-        // cross-stream event round trip costs more than that (0.368 ms/step without exchanges,
-        // 0.443 serial, 0.496 overlapped), so hiding two of the four exchanges does not pay here.
-        const char *env = std::getenv("DES_OVERLAP");
-        h->overlap = h->nnbr > 0 && h->e_hi_begin - h->e_lo_end >= 64 * DES_BLOCK && (env && env[0] == '1');
-        if (!h->comm_stream) {
-            int prio_lo = 0, prio_hi = 0;
-            hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       // the exchange must not queue behind
-            HIP_OK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio_hi));  // the interior kernel
-            HIP_OK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming | hipEventReleaseToDevice));
-            HIP_OK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming | hipEventReleaseToDevice));
+    // a message = the node records of that neighbour, then its element records
+    auto layout = [&](const std::vector<int> &np, const std::vector<int> &ep, std::vector<long long> &off,
+                      std::vector<int> &noff, std::vector<int> &eoff) {
+        off.assign((size_t)nq + 1, 0);
+        noff.resize((size_t)np[nq]); eoff.resize((size_t)ep[nq]);
+        for (int q = 0; q < nq; ++q) {
+            long long base = off[q];
+            for (int k = np[q]; k < np[q+1]; ++k) noff[k] = (int)(base + (long long)(k - np[q]) * DES_X_NODE_WIDTH);
+            base += (long long)(np[q+1] - np[q]) * DES_X_NODE_WIDTH;
+            for (int k = ep[q]; k < ep[q+1]; ++k) eoff[k] = (int)(base + (long long)(k - ep[q]) * DES_X_ELEM_WIDTH);
+            off[q+1] = base + (long long)(ep[q+1] - ep[q]) * DES_X_ELEM_WIDTH;
         }
+    };
+    std::vector<int> snoff, seoff, rnoff, reoff;
+    layout(h->send_ptr, h->esend_ptr, h->send_off, snoff, seoff);
+    layout(h->recv_ptr, h->erecv_ptr, h->recv_off, rnoff, reoff);
+    auto mapped = [&](const int *idx, size_t n, const std::vector<int> &map) {
+        std::vector<int> v(idx, idx + n);
+        if (!map.empty()) for (size_t k = 0; k < n; ++k) v[k] = map[v[k]];
+        return v;
+    };
+    const std::vector<int> sidx = mapped(halo->send_idx, ns, h->n_old2new), ridx = mapped(halo->recv_idx, nr, h->n_old2new);
+    const std::vector<int> seidx = mapped(halo->esend_idx, nes, h->e_old2new), reidx = mapped(halo->erecv_idx, ner, h->e_old2new);
+    int rc;
+    struct { int *&dst; const std::vector<int> &src; } ups[] = {
+        {h->d_send_idx, sidx}, {h->d_recv_idx, ridx}, {h->d_esend_idx, seidx}, {h->d_erecv_idx, reidx},
+        {h->d_send_noff, snoff}, {h->d_send_eoff, seoff}, {h->d_recv_noff, rnoff}, {h->d_recv_eoff, reoff} };
+    for (auto &u : ups) {
+        if ((rc = dev_alloc(u.dst, u.src.size()))) return rc;
+        if ((rc = dev_upload(u.dst, u.src.data(), u.src.size(), h->stream))) return rc;
     }
+    if ((rc = dev_alloc(h->d_sendbuf, (size_t)h->send_off[nq]))) return rc;
+    if ((rc = dev_alloc(h->d_recvbuf, (size_t)h->recv_off[nq]))) return rc;
     // the residual partials are indexed by owned-node block
     if (h->res_part) hipFree(h->res_part);
     choose_npb(h);
@@ -2404,27 +2375,18 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
     return DES_OK;
 }
 
-// Overlap of the first two exchanges of a step with the interior elements (default off; also
-// DES_OVERLAP=1).  Returns the setting in effect: 0 when the rank's mesh has no interior.
-int des_dev_set_overlap(des_dev *h, int on)
+// The exchange of the ghost region through the attached communicator (what des_dev_step issues
+// between the two phases of a step); asynchronous on the engine's stream.
+int des_dev_exchange(des_dev *h)
 {
-    if (!h) return 0;
-    h->overlap = on && h->nnbr > 0 && h->comm_stream && h->e_hi_begin - h->e_lo_end >= DES_BLOCK;
-    return h->overlap ? 1 : 0;
-}
-
-// One RCCL halo exchange of the given kind on the engine's stream (what des_dev_step issues
-// between phases); asynchronous.
-int des_dev_exchange(des_dev *h, int kind)
-{
-    if (!h || kind < 0 || kind >= DES_X_COUNT) return DES_ERR_INTERNAL;
+    if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
-    return exchange(h, kind);
+    return exchange(h);
 }
 
-// One phase of a step without any communication: the caller moves the halo values
+// One phase of a step without any communication: the caller moves the ghost-region state
 // (des_dev_halo_pack / des_dev_halo_unpack) -- used to test the decomposition with several
-// engines on one GPU.  Returns 1 after phase 4 when the compute_dt partials are ready.
+// engines on one GPU.  Returns 1 after phase 1 when the compute_dt partials are ready.
 int des_dev_phase(des_dev *h, int phase)
 {
     if (!h) return -DES_ERR_INTERNAL;
@@ -2435,20 +2397,14 @@ int des_dev_phase(des_dev *h, int phase)
         ++h->steps_host;
         launch_e1<MODE_A>(h);
         launch_n1(h);
-        return 0;
-    case 1:
         launch_e2(h);
         if (h->p.is_using_mixed_stress) launch_n2(h);
-        return 0;
-    case 2:
         launch_e3(h);
         launch_n3(h);
-        return 0;
-    case 3:
         launch_s2(h, h->steps_host);
         launch_s3(h, true, false, false);
         return 0;
-    case 4: {
+    case 1: {
         launch_s3(h, false, true, true);
         const bool do_dt = (h->steps_host % 10 == 0);
         launch_avg_coord0(h, h->steps_host);
@@ -2460,52 +2416,44 @@ int des_dev_phase(des_dev *h, int phase)
     return -DES_ERR_INTERNAL;
 }
 
-int des_dev_halo_pack(des_dev *h, int kind, const int *idx, int n, double *buf)
+// state records (what = 0: nodes, DES_X_NODE_WIDTH doubles each; 1: elements, DES_X_ELEM_WIDTH)
+// of the listed local ids to / from a host buffer
+static int state_io(des_dev *h, int what, const int *idx, int n, double *buf, bool pack)
 {
-    if (!h || kind < 0 || kind >= DES_X_COUNT) return DES_ERR_INTERNAL;
+    if (!h || what < 0 || what > 1) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     if (n == 0) return DES_OK;
-    int *d_idx = nullptr; double *d_buf = nullptr;
-    const size_t w = kXWidth[kind];
+    const size_t w = what == 0 ? DES_X_NODE_WIDTH : DES_X_ELEM_WIDTH;
+    const std::vector<int> &map = what == 0 ? h->n_old2new : h->e_old2new;
+    std::vector<int> midx(idx, idx + n), off((size_t)n);
+    for (int k = 0; k < n; ++k) { if (!map.empty()) midx[k] = map[midx[k]]; off[k] = (int)(k * w); }
+    int *d_idx = nullptr, *d_off = nullptr; double *d_buf = nullptr;
     int rc;
-    if ((rc = dev_alloc(d_idx, (size_t)n))) return rc;
-    if ((rc = dev_alloc(d_buf, (size_t)n * w))) return rc;
-    if (h->n_old2new.empty()) {
-        if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
+    if ((rc = dev_alloc(d_idx, (size_t)n)) || (rc = dev_alloc(d_off, (size_t)n)) || (rc = dev_alloc(d_buf, (size_t)n * w))) return rc;
+    if ((rc = dev_upload(d_idx, midx.data(), (size_t)n, h->stream)) || (rc = dev_upload(d_off, off.data(), (size_t)n, h->stream))) return rc;
+    const int nn_items = what == 0 ? n : 0, ne_items = what == 0 ? 0 : n;
+    if (pack) {
+        hipLaunchKernelGGL(k_state_pack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, nn_items, d_idx, d_off, ne_items, d_idx, d_off,
+                           h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain, h->ne, d_buf);
+        HIP_OK(hipMemcpyAsync(buf, d_buf, (size_t)n * w * 8, hipMemcpyDeviceToHost, h->stream));
     } else {
-        std::vector<int> midx((size_t)n);
-        for (int k = 0; k < n; ++k) midx[k] = h->n_old2new[idx[k]];
-        if ((rc = dev_upload(d_idx, midx.data(), (size_t)n, h->stream))) return rc;
+        if ((rc = dev_upload(d_buf, buf, (size_t)n * w, h->stream))) return rc;
+        hipLaunchKernelGGL(k_state_unpack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, nn_items, d_idx, d_off, ne_items, d_idx, d_off,
+                           h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain, h->ne, d_buf);
     }
-    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, kind, n, d_idx, h->xt, h->vm, h->ntmp, h->dh_n, d_buf);
-    HIP_OK(hipMemcpyAsync(buf, d_buf, (size_t)n * w * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
-    hipFree(d_idx); hipFree(d_buf);
+    hipFree(d_idx); hipFree(d_off); hipFree(d_buf);
     return DES_OK;
 }
 
-int des_dev_halo_unpack(des_dev *h, int kind, const int *idx, int n, const double *buf)
+int des_dev_halo_pack(des_dev *h, int what, const int *idx, int n, double *buf)
 {
-    if (!h || kind < 0 || kind >= DES_X_COUNT) return DES_ERR_INTERNAL;
-    hipSetDevice(h->device);
-    if (n == 0) return DES_OK;
-    int *d_idx = nullptr; double *d_buf = nullptr;
-    const size_t w = kXWidth[kind];
-    int rc;
-    if ((rc = dev_alloc(d_idx, (size_t)n))) return rc;
-    if ((rc = dev_alloc(d_buf, (size_t)n * w))) return rc;
-    if (h->n_old2new.empty()) {
-        if ((rc = dev_upload(d_idx, idx, (size_t)n, h->stream))) return rc;
-    } else {
-        std::vector<int> midx((size_t)n);
-        for (int k = 0; k < n; ++k) midx[k] = h->n_old2new[idx[k]];
-        if ((rc = dev_upload(d_idx, midx.data(), (size_t)n, h->stream))) return rc;
-    }
-    if ((rc = dev_upload(d_buf, buf, (size_t)n * w, h->stream))) return rc;
-    hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, kind, n, d_idx, d_buf, h->xt, h->vm, h->ntmp, h->dh_n);
-    HIP_OK(hipStreamSynchronize(h->stream));
-    hipFree(d_idx); hipFree(d_buf);
-    return DES_OK;
+    return state_io(h, what, idx, n, buf, true);
+}
+
+int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const double *buf)
+{
+    return state_io(h, what, idx, n, const_cast<double *>(buf), false);
 }
 
 int des_dev_dt_partials(des_dev *h, double out[6], int recompute)

@@ -6,7 +6,7 @@ engine exchanges halos itself with RCCL on its own stream (des_dev_comm_init /
 des_dev_step).  What lives here is
   * `Partition` -- ctypes view of des_host_partition();
   * `init_rank` -- init() of one rank's engine from the global host model;
-  * `PhasedStepper` + `LoopbackComm` / `TorchComm` -- the same four-phase step driven from
+  * `PhasedStepper` + `LoopbackComm` / `TorchComm` -- the same two-phase step driven from
     Python with host-mediated exchanges, used by the tests (CPU oracle over gloo, several
     device engines on one GPU) to check the partition and the exchange lists.
 """
@@ -17,7 +17,7 @@ import numpy as np
 from . import load_host_lib, DesError, DesMesh, F
 from ._structs import DesHalo
 
-X_WIDTH = (2, 1, 6, 2)        # DES_X_TEMP_NTMP, DES_X_NTMP, DES_X_VEL_COORD, DES_X_SURFACE (des_params.h)
+NODE_WIDTH, ELEM_WIDTH = 8, 13     # DES_X_NODE_WIDTH, DES_X_ELEM_WIDTH (des_params.h)
 NODAL = {"coord": 3, "vel": 3, "temperature": 1}
 ELEMENTAL = {"stress": 6, "strain": 6, "plstrain": 1, "viscosity": 1, "radiogenic": 1}
 
@@ -34,7 +34,7 @@ class Partition:
         lib.des_part_mesh.argtypes = [C.c_void_p]
         lib.des_part_halo.restype = C.POINTER(DesHalo)
         lib.des_part_halo.argtypes = [C.c_void_p]
-        for f in ("l2g_node", "l2g_elem", "node_ranges"):
+        for f in ("l2g_node", "l2g_elem", "node_ranges", "elem_owned"):
             getattr(lib, "des_part_" + f).restype = C.POINTER(C.c_int)
             getattr(lib, "des_part_" + f).argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         err = C.c_int(0)
@@ -55,14 +55,18 @@ class Partition:
         self.l2g_node = ints(lib.des_part_l2g_node)
         self.l2g_elem = ints(lib.des_part_l2g_elem)
         self.node_ranges = ints(lib.des_part_node_ranges)
+        self.elem_owned = ints(lib.des_part_elem_owned).astype(bool)
         h = self.halo
         self.owned = (h.owned_begin, h.owned_end)
         nn = h.nnbr
         self.nbr_rank = [h.nbr_rank[i] for i in range(nn)]
-        sp = [h.send_ptr[i] for i in range(nn + 1)]
-        rp = [h.recv_ptr[i] for i in range(nn + 1)]
-        self.send_idx = [np.array([h.send_idx[k] for k in range(sp[i], sp[i + 1])], dtype=np.int32) for i in range(nn)]
-        self.recv_idx = [np.array([h.recv_idx[k] for k in range(rp[i], rp[i + 1])], dtype=np.int32) for i in range(nn)]
+
+        def lists(ptr, idx):
+            p = np.ctypeslib.as_array(ptr, shape=(nn + 1,)) if nn else np.zeros(1, np.int32)
+            a = np.ctypeslib.as_array(idx, shape=(int(p[nn]),)).copy() if nn and p[nn] else np.zeros(0, np.int32)
+            return [a[p[i]:p[i + 1]].astype(np.int32) for i in range(nn)]
+        self.send_idx, self.recv_idx = lists(h.send_ptr, h.send_idx), lists(h.recv_ptr, h.recv_idx)
+        self.esend_idx, self.erecv_idx = lists(h.esend_ptr, h.esend_idx), lists(h.erecv_ptr, h.erecv_idx)
 
     def local(self, name):
         """This rank's slice of a global host array, in the reference's SoA layout."""
@@ -106,7 +110,7 @@ def init_rank(engine, part, comm):
 
 
 class PhasedStepper:
-    """Five phases per step with the halo exchanges in between (DES_X_* of des_params.h)."""
+    """The two phases of a step with the ghost-region exchange in between (des_params.h)."""
 
     def __init__(self, engine, part, comm):
         self.engine, self.part, self.comm = engine, part, comm
@@ -115,16 +119,8 @@ class PhasedStepper:
         e = self.engine
         for _ in range(nsteps):
             e.phase(0)
-            self.comm.exchange(self, 0)
-            e.phase(1)
-            if self.part.params.is_using_mixed_stress:
-                self.comm.exchange(self, 1)
-            e.phase(2)
-            self.comm.exchange(self, 2)
-            e.phase(3)
-            if self.part.params.has_moving_mesh and self.part.params.surface_process_option == 1:
-                self.comm.exchange(self, 3)
-            if e.phase(4):
+            self.comm.exchange(self)
+            if e.phase(1):
                 self.comm.reduce_dt(e, recompute=False)
 
 
@@ -135,17 +131,18 @@ class LoopbackComm:
     def __init__(self, steppers):
         self.steppers = steppers
 
-    def exchange_all(self, kind):
-        w = X_WIDTH[kind]
+    def exchange_all(self):
         boxes = {}
         for st in self.steppers:
             p = st.part
-            for q, idx in zip(p.nbr_rank, p.send_idx):
-                boxes[(p.rank, q)] = st.engine.halo_pack(kind, idx, w)
+            for q, idx, eidx in zip(p.nbr_rank, p.send_idx, p.esend_idx):
+                boxes[(p.rank, q)] = (st.engine.halo_pack(0, idx, NODE_WIDTH), st.engine.halo_pack(1, eidx, ELEM_WIDTH))
         for st in self.steppers:
             p = st.part
-            for q, idx in zip(p.nbr_rank, p.recv_idx):
-                st.engine.halo_unpack(kind, idx, boxes[(q, p.rank)])
+            for q, idx, eidx in zip(p.nbr_rank, p.recv_idx, p.erecv_idx):
+                nbuf, ebuf = boxes[(q, p.rank)]
+                st.engine.halo_unpack(0, idx, nbuf)
+                st.engine.halo_unpack(1, eidx, ebuf)
 
     def reduce_dt_all(self, recompute):
         parts = np.array([st.engine.dt_partials(recompute) for st in self.steppers])
@@ -155,21 +152,10 @@ class LoopbackComm:
 
 def run_loopback(steppers, nsteps):
     comm = LoopbackComm(steppers)
-    prm = steppers[0].part.params
-    nmd = prm.is_using_mixed_stress
-    surf = prm.has_moving_mesh and prm.surface_process_option == 1
     for _ in range(nsteps):
         for st in steppers: st.engine.phase(0)
-        comm.exchange_all(0)
-        for st in steppers: st.engine.phase(1)
-        if nmd:
-            comm.exchange_all(1)
-        for st in steppers: st.engine.phase(2)
-        comm.exchange_all(2)
-        for st in steppers: st.engine.phase(3)
-        if surf:
-            comm.exchange_all(3)
-        flags = [st.engine.phase(4) for st in steppers]
+        comm.exchange_all()
+        flags = [st.engine.phase(1) for st in steppers]
         if any(flags):
             comm.reduce_dt_all(recompute=False)
 
@@ -181,20 +167,22 @@ class TorchComm:
         import torch
         self.dist, self.torch, self.device = dist, torch, device
 
-    def exchange(self, stepper, kind):
+    def exchange(self, stepper):
         torch, dist = self.torch, self.dist
-        p, e, w = stepper.part, stepper.engine, X_WIDTH[kind]
+        p, e = stepper.part, stepper.engine
         reqs, recvs = [], []
-        for q, sidx, ridx in zip(p.nbr_rank, p.send_idx, p.recv_idx):
-            sbuf = torch.from_numpy(e.halo_pack(kind, sidx, w))
-            rbuf = torch.empty(len(ridx) * w, dtype=torch.float64)
+        for q, sidx, ridx, seidx, reidx in zip(p.nbr_rank, p.send_idx, p.recv_idx, p.esend_idx, p.erecv_idx):
+            sbuf = torch.from_numpy(np.concatenate([e.halo_pack(0, sidx, NODE_WIDTH), e.halo_pack(1, seidx, ELEM_WIDTH)]))
+            rbuf = torch.empty(len(ridx) * NODE_WIDTH + len(reidx) * ELEM_WIDTH, dtype=torch.float64)
             reqs.append(dist.isend(sbuf, dst=q))
             reqs.append(dist.irecv(rbuf, src=q))
-            recvs.append((ridx, rbuf, sbuf))
+            recvs.append((ridx, reidx, rbuf, sbuf))
         for r in reqs:
             r.wait()
-        for ridx, rbuf, _ in recvs:
-            e.halo_unpack(kind, ridx, rbuf.numpy())
+        for ridx, reidx, rbuf, _ in recvs:
+            a = rbuf.numpy()
+            e.halo_unpack(0, ridx, a[:len(ridx) * NODE_WIDTH])
+            e.halo_unpack(1, reidx, a[len(ridx) * NODE_WIDTH:])
 
     def reduce_dt(self, engine, recompute):
         t = self.torch.from_numpy(engine.dt_partials(recompute))
@@ -203,8 +191,8 @@ class TorchComm:
 
 
 def assemble(parts, locals_, ncomp, nglobal, kind):
-    """Global SoA array from per-rank local arrays: owned nodes / every local element (overlap
-    elements are computed identically on both sides, the assembly checks that)."""
+    """Global SoA array from per-rank local arrays: owned nodes / owned elements (every node and
+    every element of the global mesh has exactly one owner)."""
     out = np.full((ncomp, nglobal), np.nan)
     for p, a in zip(parts, locals_):
         a = a.reshape(ncomp, -1)
@@ -212,9 +200,6 @@ def assemble(parts, locals_, ncomp, nglobal, kind):
             o0, o1 = p.owned
             out[:, p.l2g_node[o0:o1]] = a[:, o0:o1]
         else:
-            prev = out[:, p.l2g_elem]
-            same = np.isnan(prev) | (prev == a)
-            if not same.all():
-                raise AssertionError("overlap elements differ between ranks")
-            out[:, p.l2g_elem] = a
+            out[:, p.l2g_elem[p.elem_owned]] = a[:, p.elem_owned]
+    assert not np.isnan(out).any(), "a node / element has no owner"
     return out.ravel()

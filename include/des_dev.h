@@ -96,30 +96,28 @@ int des_dev_mesh_quality(des_dev *h, double smallest_vol, double bottom, double 
 double des_dev_algorithmic_bytes_per_step(const des_dev *h);
 
 /* ---- multi-GPU (one process per GPU; new: the reference is single-process) -------------
- * A rank's engine is created on its LOCAL mesh (des_host_partition) and told which nodes it
- * owns and which it exchanges (des_halo, des_params.h).  With a communicator attached,
- * des_dev_step / des_dev_compute_dt exchange halo values with ncclSend/ncclRecv (RCCL) on the
- * engine's own stream and min-reduce the six compute_dt partials with one ncclAllReduce:
- * no host synchronisation is added. */
+ * A rank's engine is created on its LOCAL mesh (des_host_partition: node slab + four-layer ghost
+ * region) and told which nodes it owns and what it exchanges (des_halo, des_params.h).  With a
+ * communicator attached des_dev_step does a whole step on the local mesh and then refreshes the
+ * ghost region with ONE grouped ncclSend/ncclRecv per neighbour (RCCL) on the engine's own
+ * stream; des_dev_compute_dt min-reduces its six partials with one ncclAllReduce.  No host
+ * synchronisation is added. */
 int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global);
 /* rank 0 creates the 128-byte ncclUniqueId; the caller broadcasts it (e.g. torch.distributed) */
 int des_dev_comm_unique_id(unsigned char *id128);
 int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128);
-/* des_dev_step can overlap the exchanges after phases 0 and 1 with the elements that touch no
- * halo node (second stream, two events).  Off by default (also DES_OVERLAP=1): on one MI355X
- * the cross-stream event round trips cost more than the 19-us exchanges they hide
- * (tools/time_overlap.py).  Returns the setting in effect. */
-int des_dev_set_overlap(des_dev *h, int on);
-/* one halo exchange (DES_X_*) through the attached communicator, asynchronous on the engine's
- * stream: what des_dev_step issues after phases 0..3 */
-int des_dev_exchange(des_dev *h, int kind);
+/* the ghost-region exchange through the attached communicator, asynchronous on the engine's
+ * stream: what des_dev_step issues between the two phases of a step */
+int des_dev_exchange(des_dev *h);
 
-/* The same step cut into its five phases WITHOUT communication, plus raw access to the halo
- * values and the compute_dt partials: lets a host harness move the halos itself (tests with
- * several engines on one GPU; any other transport). */
+/* The same step cut into its two phases WITHOUT communication (0: up to the committed surface
+ * heights, 1: end-of-step geometry; returns 1 when compute_dt partials are ready), plus raw
+ * access to the exchanged state -- what = 0: nodes, DES_X_NODE_WIDTH doubles each; 1: elements,
+ * DES_X_ELEM_WIDTH -- and the compute_dt partials: lets a host harness move the ghost region
+ * itself (tests with several engines on one GPU; any other transport). */
 int des_dev_phase(des_dev *h, int phase);
-int des_dev_halo_pack(des_dev *h, int kind, const int *idx, int n, double *buf);
-int des_dev_halo_unpack(des_dev *h, int kind, const int *idx, int n, const double *buf);
+int des_dev_halo_pack(des_dev *h, int what, const int *idx, int n, double *buf);
+int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const double *buf);
 int des_dev_dt_partials(des_dev *h, double out[6], int recompute);
 int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt);
 

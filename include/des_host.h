@@ -41,8 +41,8 @@ int des_host_cfg_double(const des_host *h, const char *key, double *out);
 /* write the mesh in the loader's binary format (tools and tests) */
 int des_host_save_mesh(const des_host *h, const char *path);
 
-/* Slab decomposition for one-process-per-GPU runs (des_params.h: des_halo).  The local mesh
- * (des_part_mesh) feeds des_dev_create; des_part_halo feeds des_dev_set_halo; the l2g maps
+/* Slab decomposition with a four-layer ghost region for one-process-per-GPU runs (des_params.h:
+ * des_halo).  The local mesh (des_part_mesh) feeds des_dev_create; des_part_halo feeds des_dev_set_halo; the l2g maps
  * select this rank's part of every global field. */
 typedef struct des_part des_part;
 des_part *des_host_partition(const des_host *h, int nranks, int rank, int *err);
@@ -51,6 +51,9 @@ const des_mesh *des_part_mesh(const des_part *p);
 const des_halo *des_part_halo(const des_part *p);
 const int *des_part_l2g_node(const des_part *p, int *n);
 const int *des_part_l2g_elem(const des_part *p, int *n);
+/* [local nelem] 1 where this rank owns the element (its lowest-numbered node): each element of
+ * the global mesh is owned by exactly one rank -- the one whose copy goes into an output frame */
+const int *des_part_elem_owned(const des_part *p, int *n);
 const int *des_part_node_ranges(const des_part *p, int *n);
 
 const char *des_host_last_error(void);

@@ -146,31 +146,38 @@ typedef struct des_mesh {
     int owned_begin, owned_end;     /* the des_halo range this mesh will be given (0, nnode if none) */
 } des_mesh;
 
-/* Domain decomposition (new: the reference is single-process).  A rank's mesh is
- * the union of the supports of the nodes it OWNS -- a contiguous id range of the renumbered
- * (x-sorted, mesh.cxx:2742-2766) global mesh -- so every owned node has its complete element
- * patch locally and is assembled in the same element order as on one GPU.  Elements that
- * straddle a cut are computed by both neighbours from identical inputs; only nodal values of
- * HALO nodes (local but owned elsewhere) are exchanged, three or four times per step. */
+/* Domain decomposition (new: the reference is single-process).  A rank OWNS a
+ * contiguous id range of the renumbered (x-sorted, mesh.cxx:2742-2766) global nodes.  Its local
+ * mesh is that slab plus a GHOST REGION of `nlayers` element layers: layer 0 = every element
+ * touching an owned node, layer k+1 = every further element touching a node of layer k; local
+ * numbering in ascending global order, so every complete element patch is summed in the same
+ * order as on one GPU (bit-identical results).
+ *
+ * One step needs the nodal state of a whole patch three times in a row (update_temperature /
+ * dvoldt, NMD_stress, update_force) plus once for surface diffusion, so with four layers a rank
+ * computes the step of its owned nodes WITHOUT any exchange in between -- redundantly on the
+ * ghost region, whose outer layers go stale (about 1 % of the work at 1M tets per rank) -- and
+ * the whole ghost region is refreshed ONCE per step: nodal {x,y,z,vx,vy,vz,T,dh} of every ghost
+ * node from its owner, {stress, strain, plstrain} of the elements in the two outer layers from
+ * the rank that owns their lowest-numbered node.  xGMI is latency-, not bandwidth-bound at
+ * these sizes: one 0.5-MB message per neighbour instead of four 40-KB ones. */
 typedef struct des_halo {
     int owned_begin, owned_end;      /* owned nodes = local ids [owned_begin, owned_end)             */
+    int nlayers;                     /* element layers of the ghost region (4; 3 without diffusion)  */
     int nnbr;                        /* neighbour ranks                                             */
     const int *nbr_rank;             /* [nnbr]                                                      */
     const int *send_ptr;             /* [nnbr+1] offsets into send_idx                              */
-    const int *send_idx;             /* local ids of OWNED nodes each neighbour needs, ascending    */
+    const int *send_idx;             /* local ids of OWNED nodes each neighbour holds as ghosts     */
     const int *recv_ptr;             /* [nnbr+1] offsets into recv_idx                              */
-    const int *recv_idx;             /* local ids of HALO nodes owned by each neighbour, ascending  */
+    const int *recv_idx;             /* local ids of GHOST nodes owned by each neighbour, ascending */
+    const int *esend_ptr, *esend_idx;/* local ids of elements whose state each neighbour needs      */
+    const int *erecv_ptr, *erecv_idx;/* local ids of stale-layer elements, by the rank that sends   */
 } des_halo;
 
-/* Nodal exchanges of one step and their width in doubles per node.  A step is five phases
- * (des_dev_phase 0..4) with one exchange after each of the first four:
- *   0 -> {T, ntmp}   1 -> {ntmp} (NMD only)   2 -> {vx,vy,vz,x,y,z}
- *   3 -> {z, dh} (surface diffusion only: it reads the neighbours' NEW coordinates)   4 */
-enum { DES_X_TEMP_NTMP = 0, DES_X_NTMP = 1, DES_X_VEL_COORD = 2, DES_X_SURFACE = 3, DES_X_COUNT = 4 };
-#define DES_X_WIDTH_0 2
-#define DES_X_WIDTH_1 1
-#define DES_X_WIDTH_2 6
-#define DES_X_WIDTH_3 2
+/* The exchange of a step (after the surface heights are committed, before the end-of-step
+ * geometry pass): widths in doubles per node / per element. */
+#define DES_X_NODE_WIDTH 8           /* x, y, z, vx, vy, vz, T, dh                                  */
+#define DES_X_ELEM_WIDTH 13          /* stress[6], strain[6], plstrain                              */
 
 /* Field ids for upload/download.  "E" = per element, "N" = per node. */
 enum des_field {

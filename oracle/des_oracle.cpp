@@ -70,7 +70,8 @@ struct des_oracle {
     // Output::average_fields state (output.hpp:30-36)
     dvec stress_avg, dplstrain_avg, strain0, coord_avg0;
     double avg_time0;
-    int o0, o1;                         // owned nodes [o0, o1) (whole mesh unless decomposed)
+    int o0, o1;                         // owned nodes [o0, o1) (whole mesh unless decomposed): reductions
+    int c0, c1;                         // nodes the node loops run over: every local node
     double dt_part[6];
     double l2_part;
     int nn_global;                  // compute_dt partials: minl, dt_maxwell, dt_diffusion, gdt_min, -max_vem, -max_surf_vel
@@ -758,7 +759,7 @@ void update_temperature(des_oracle &o)
         }
     }
     #pragma omp parallel for
-    for (int n = o.o0; n < o.o1; n++) {
+    for (int n = o.c0; n < o.c1; n++) {
         if (o.bcflag[n] & BOUNDZ1)
             o.temperature[n] = o.p.surface_temperature;
         else {
@@ -802,7 +803,7 @@ void compute_dvoldt(des_oracle &o)
         o.etmp[e] = dj * o.volume[e];
     }
     #pragma omp parallel for
-    for (int n = o.o0; n < o.o1; n++) {
+    for (int n = o.c0; n < o.c1; n++) {
         double acc = 0.;
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k)
             acc += o.etmp[o.sup_arr[k]];
@@ -932,7 +933,7 @@ void NMD_stress_gather(des_oracle &o)
     for (int e = 0; e < ne; e++)
         o.etmp[e] = o.dpressure[e] * o.volume[e];
     #pragma omp parallel for
-    for (int n = o.o0; n < o.o1; n++) {
+    for (int n = o.c0; n < o.c1; n++) {
         double acc = 0;
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k)
             acc += o.etmp[o.sup_arr[k]];
@@ -1020,7 +1021,7 @@ void apply_stress_bcs(des_oracle &o)
 
         for (int j = 0; j < nbdry_nodes; ++j) {
             const int n = o.bnodes[i][j];
-            if (n < o.o0 || n >= o.o1) continue;
+            if (n < o.c0 || n >= o.c1) continue;
             for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k) {
                 int e = o.sup_arr[k];
                 int ibound = o.etmp_int[e];
@@ -1091,18 +1092,18 @@ void apply_damping(des_oracle &o)
     case 0: break;
     case 1:
         #pragma omp parallel for
-        for (int i = o.o0; i < o.o1; ++i)
+        for (int i = o.c0; i < o.c1; ++i)
             for (int j = 0; j < ND; j++)
                 if (std::fabs(o.vel[j*nn+i]) > small_vel)
                     o.force[j*nn+i] -= p.damping_factor * std::copysign(o.force[j*nn+i], o.vel[j*nn+i]);
         break;
     case 2:
-        for (int i = o.o0; i < o.o1; ++i)
+        for (int i = o.c0; i < o.c1; ++i)
             for (int j = 0; j < ND; j++)
                 o.force[j*nn+i] -= p.damping_factor * o.force[j*nn+i];
         break;
     case 3:
-        for (int i = o.o0; i < o.o1; ++i)
+        for (int i = o.c0; i < o.c1; ++i)
             for (int j = 0; j < ND; j++) {
                 if ((o.force[j*nn+i] < 0) == (o.vel[j*nn+i] < 0)) {
                     // fields.cxx:538 -- comma operator: the trailing vel term has no effect
@@ -1113,7 +1114,7 @@ void apply_damping(des_oracle &o)
             }
         break;
     case 4:
-        for (int i = o.o0; i < o.o1; ++i) {
+        for (int i = o.c0; i < o.c1; ++i) {
             double critical_coeff = 2.0 * std::sqrt(o.mass[i] * o.ymass[i]);
             for (int j = 0; j < ND; j++)
                 if (std::fabs(o.vel[j*nn+i]) > small_vel) {
@@ -1151,7 +1152,7 @@ void update_force(des_oracle &o)
         }
     }
     #pragma omp parallel for
-    for (int n = o.o0; n < o.o1; n++) {
+    for (int n = o.c0; n < o.c1; n++) {
         double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k) {
             const int e = o.sup_arr[k], i = o.sup_lidx[k];
@@ -1187,7 +1188,7 @@ void update_velocity(des_oracle &o)
 {
     const int nn = o.nn;
     #pragma omp parallel for
-    for (int i = o.o0; i < o.o1; ++i)
+    for (int i = o.c0; i < o.c1; ++i)
         for (int j = 0; j < ND; j++)
             o.vel[j*nn+i] += o.dt * o.force[j*nn+i] / o.mass[i];
 }
@@ -1199,7 +1200,7 @@ void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
     const int nn = o.nn;
     // init() applies the bcs to every local node (a purely local operation that gives halo
     // nodes the owner's values); inside a step only owned nodes are touched
-    const int vb0 = all_local_nodes ? 0 : o.o0, vb1 = all_local_nodes ? nn : o.o1;
+    const int vb0 = all_local_nodes ? 0 : o.c0, vb1 = all_local_nodes ? nn : o.c1;
     int bc_z0 = p.vbc_types[4], bc_z1 = p.vbc_types[5];
     const double bc_vz0 = p.vbc_values[4], bc_vz1 = p.vbc_values[5];
     if (o.time > p.vbc_val_z1_loading_period) bc_z1 = 0;
@@ -1310,7 +1311,7 @@ void update_coordinate(des_oracle &o)
 {
     const int nn = o.nn;
     #pragma omp parallel for
-    for (int i = o.o0; i < o.o1; ++i)
+    for (int i = o.c0; i < o.c1; ++i)
         for (int j = 0; j < ND; ++j)
             o.coord[j*nn+i] += o.vel[j*nn+i] * o.dt;
 }
@@ -1356,7 +1357,7 @@ void simple_diffusion(des_oracle &o)
 
     for (int i = 0; i < o.ntop; ++i) {
         int n = o.top_nodes[i];
-        if (n < o.o0 || n >= o.o1) continue;
+        if (n < o.c0 || n >= o.c1) continue;
         for (int j = o.ssup_idx[i]; j < o.ssup_idx[i+1]; ++j) {
             int k = o.ssup_arr[j];
             o.total_dx[n] += o.etmp[k];
@@ -1372,7 +1373,7 @@ void simple_diffusion(des_oracle &o)
 
     for (int i = 0; i < o.ntop; ++i) {
         int n = o.top_nodes[i];
-        if (n < o.o0 || n >= o.o1) continue;
+        if (n < o.c0 || n >= o.c1) continue;
         double conv = o.p.surface_diffusivity * o.dt * o.total_slope[n] / o.total_dx[n];
         o.dh[i] -= conv;
     }
@@ -1399,7 +1400,7 @@ void correct_surface_element(des_oracle &o)
     }
     for (int n = 0; n < o.ntop; n++) {
         int nt = o.top_nodes[n];
-        if (nt < o.o0 || nt >= o.o1) continue;
+        if (nt < o.c0 || nt >= o.c1) continue;
         double acc = 0.;
         for (int k = o.sup_idx[nt]; k < o.sup_idx[nt+1]; ++k)
             acc += o.volume[o.sup_arr[k]];
@@ -1422,7 +1423,7 @@ void surface_processes_a(des_oracle &o)
 
     for (int i = 0; i < o.ntop; i++) {
         int nt = o.top_nodes[i];
-        if (nt < o.o0 || nt >= o.o1) continue;
+        if (nt < o.c0 || nt >= o.c1) continue;
         o.coord[2*nn + nt] += o.dh[i];
         o.dhacc[nt] += o.dh[i];
         o.dh_n[nt] = o.dh[i];
@@ -1487,7 +1488,7 @@ void compute_mass(des_oracle &o)
         o.tmp_result[4 * ne + e] = ym;
     }
     #pragma omp parallel for
-    for (int n = o.o0; n < o.o1; n++) {
+    for (int n = o.c0; n < o.c1; n++) {
         double vn = 0, ms = 0, tms = 0, yms = 0;
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k) {
             const int e = o.sup_arr[k];
@@ -1647,6 +1648,9 @@ void average_fields(des_oracle &o)
     }
 }
 
+// One step in its two phases (des_params.h, des_halo): everything up to the committed surface
+// heights runs on the local mesh alone -- redundantly on the ghost region -- then the ghost
+// region is refreshed by the exchange, then the end-of-step geometry pass.
 int step_phase(des_oracle &o, int phase)
 {
     const des_params &p = o.p;
@@ -1659,28 +1663,22 @@ int step_phase(des_oracle &o, int phase)
             update_temperature(o);
         update_strain_rate(o);
         compute_dvoldt(o);
-        return 0;                                   // -> exchange DES_X_TEMP_NTMP
-    case 1:
         compute_edvoldt(o);
         update_stress(o);
-        if (p.is_using_mixed_stress)
+        if (p.is_using_mixed_stress) {
             NMD_stress_gather(o);
-        return 0;                                   // -> exchange DES_X_NTMP
-    case 2:
-        if (p.is_using_mixed_stress)
             NMD_stress_apply(o);
+        }
         update_force(o);
         update_velocity(o);
         o.l2_residual = calculate_residual_force(o);
         apply_vbcs(o);
-        if (p.has_moving_mesh)
+        if (p.has_moving_mesh) {
             update_coordinate(o);
-        return 0;                                   // -> exchange DES_X_VEL_COORD
-    case 3:
-        if (p.has_moving_mesh)
             surface_processes_a(o);
-        return 0;                                   // -> exchange DES_X_SURFACE (diffusion only)
-    case 4:
+        }
+        return 0;                                   // -> exchange of the ghost region
+    case 1:
         if (p.has_moving_mesh)
             update_mesh_b(o);
         if (p.rheol_type & DES_RH_ELASTIC)
@@ -1699,8 +1697,8 @@ int step_phase(des_oracle &o, int phase)
 
 void one_step(des_oracle &o)
 {
-    for (int ph = 0; ph < 4; ++ph) step_phase(o, ph);
-    if (step_phase(o, 4)) o.dt = compute_dt_finalize(o);
+    step_phase(o, 0);
+    if (step_phase(o, 1)) o.dt = compute_dt_finalize(o);
 }
 
 template <typename T>
@@ -1798,7 +1796,7 @@ des_oracle *des_oracle_create(const des_params *params, const des_mesh *mesh)
     o.etmp_int.assign((size_t)ne, -1);
     o.dh.assign((size_t)o.ntop, 0.0);
     o.dh_n.assign((size_t)nn, 0.0);
-    o.o0 = 0; o.o1 = nn; o.nn_global = nn; o.l2_part = 0;
+    o.o0 = 0; o.o1 = nn; o.c0 = 0; o.c1 = nn; o.nn_global = nn; o.l2_part = 0;
     for (int i = 0; i < 6; ++i) o.dt_part[i] = 0;
     o.edvacc_surf.assign((size_t)o.etop, 0.0);
     o.markers_dirty = true;
@@ -1929,31 +1927,40 @@ int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode
 
 int des_oracle_phase(des_oracle *h, int phase) { return step_phase(*h, phase); }
 
-// nodal values of exchange `kind` for the local nodes idx[0..n): buf[i*width + c]
-int des_oracle_halo_pack(des_oracle *h, int kind, const int *idx, int n, double *buf)
+// the exchange of a step: what = 0 nodal {x,y,z,vx,vy,vz,T,dh} of the local nodes idx[0..n),
+// what = 1 {stress, strain, plstrain} of the local elements idx[0..n); buf[i*width + c]
+int des_oracle_halo_pack(des_oracle *h, int what, const int *idx, int n, double *buf)
 {
-    const int nn = h->nn;
+    const int nn = h->nn, ne = h->ne;
     for (int i = 0; i < n; ++i) {
         const int k = idx[i];
-        if (kind == DES_X_TEMP_NTMP) { buf[2*i] = h->temperature[k]; buf[2*i+1] = h->ntmp[k]; }
-        else if (kind == DES_X_NTMP) { buf[i] = h->ntmp[k]; }
-        else if (kind == DES_X_VEL_COORD) {
-            for (int d = 0; d < 3; ++d) { buf[6*i+d] = h->vel[d*nn+k]; buf[6*i+3+d] = h->coord[d*nn+k]; }
-        } else { buf[2*i] = h->coord[2*nn+k]; buf[2*i+1] = h->dh_n[k]; }
+        if (what == 0) {
+            double *b = buf + (size_t)i * DES_X_NODE_WIDTH;
+            for (int d = 0; d < 3; ++d) { b[d] = h->coord[d*nn+k]; b[3+d] = h->vel[d*nn+k]; }
+            b[6] = h->temperature[k]; b[7] = h->dh_n[k];
+        } else {
+            double *b = buf + (size_t)i * DES_X_ELEM_WIDTH;
+            for (int c = 0; c < 6; ++c) { b[c] = h->stress[c*ne+k]; b[6+c] = h->strain[c*ne+k]; }
+            b[12] = h->plstrain[k];
+        }
     }
     return DES_OK;
 }
 
-int des_oracle_halo_unpack(des_oracle *h, int kind, const int *idx, int n, const double *buf)
+int des_oracle_halo_unpack(des_oracle *h, int what, const int *idx, int n, const double *buf)
 {
-    const int nn = h->nn;
+    const int nn = h->nn, ne = h->ne;
     for (int i = 0; i < n; ++i) {
         const int k = idx[i];
-        if (kind == DES_X_TEMP_NTMP) { h->temperature[k] = buf[2*i]; h->ntmp[k] = buf[2*i+1]; }
-        else if (kind == DES_X_NTMP) { h->ntmp[k] = buf[i]; }
-        else if (kind == DES_X_VEL_COORD) {
-            for (int d = 0; d < 3; ++d) { h->vel[d*nn+k] = buf[6*i+d]; h->coord[d*nn+k] = buf[6*i+3+d]; }
-        } else { h->coord[2*nn+k] = buf[2*i]; h->dh_n[k] = buf[2*i+1]; }
+        if (what == 0) {
+            const double *b = buf + (size_t)i * DES_X_NODE_WIDTH;
+            for (int d = 0; d < 3; ++d) { h->coord[d*nn+k] = b[d]; h->vel[d*nn+k] = b[3+d]; }
+            h->temperature[k] = b[6]; h->dh_n[k] = b[7];
+        } else {
+            const double *b = buf + (size_t)i * DES_X_ELEM_WIDTH;
+            for (int c = 0; c < 6; ++c) { h->stress[c*ne+k] = b[c]; h->strain[c*ne+k] = b[6+c]; }
+            h->plstrain[k] = b[12];
+        }
     }
     return DES_OK;
 }

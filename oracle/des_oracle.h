@@ -26,8 +26,9 @@ int des_oracle_compute_dt(des_oracle *h, double *dt);
 int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out);
 int des_oracle_check_nan(des_oracle *h, long long *n_nan);
 int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out);
-/* domain decomposition: owned node range, phased stepping (0..3, halo exchanges in between --
- * DES_X_* in des_params.h), nodal pack/unpack by local index list, compute_dt across ranks */
+/* domain decomposition (des_halo in des_params.h): owned node range, the two phases of a step
+ * with the ghost-region exchange in between, pack/unpack of nodal (what = 0) and element
+ * (what = 1) state by local index list, compute_dt across ranks */
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global);
 int des_oracle_phase(des_oracle *h, int phase);
 int des_oracle_halo_pack(des_oracle *h, int kind, const int *idx, int n, double *buf);

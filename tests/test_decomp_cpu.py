@@ -1,5 +1,6 @@
-"""Domain decomposition on the CPU: the slab partition (host library), the halo lists and the
-four-phase step with exchanges, checked with the oracle against an undecomposed run.
+"""Domain decomposition on the CPU: the slab partition with its four-layer ghost region (host
+library), the exchange lists and the two-phase step with ONE exchange, checked with the oracle
+against an undecomposed run.
 (a) several ranks in one process (loopback); (b) world_size-2 gloo over torch.distributed."""
 import os
 import sys
@@ -32,24 +33,33 @@ def test_partition_covers_the_mesh_exactly():
     host, parts = build(cfgs.EP, 3)
     owned = np.concatenate([p.l2g_node[p.owned[0]:p.owned[1]] for p in parts])
     assert np.array_equal(np.sort(owned), np.arange(host.nnode))            # every node owned once
-    assert set(np.concatenate([p.l2g_elem for p in parts])) == set(range(host.nelem))
+    eowned = np.concatenate([p.l2g_elem[p.elem_owned] for p in parts])
+    assert np.array_equal(np.sort(eowned), np.arange(host.nelem))           # every element owned once
     conn = host.array("connectivity").reshape(4, -1)
     for p in parts:
         a, b = p.node_ranges[p.rank], p.node_ranges[p.rank + 1]
-        # the local elements are exactly the supports of the owned nodes
-        touches = ((conn >= a) & (conn < b)).any(axis=0)
-        assert np.array_equal(np.nonzero(touches)[0], p.l2g_elem)
+        assert p.halo.nlayers == 4
+        # the local mesh: the supports of the owned nodes, grown by three more element layers
+        reach = (conn >= a) & (conn < b)
+        held = reach.any(axis=0)
+        for _ in range(3):
+            nodes = np.unique(conn[:, held])
+            held = np.isin(conn, nodes).any(axis=0)
+        assert np.array_equal(np.nonzero(held)[0], p.l2g_elem)
+        assert np.array_equal(np.unique(conn[:, held]), p.l2g_node)
         assert np.all(np.diff(p.l2g_node) > 0) and np.all(np.diff(p.l2g_elem) > 0)   # global order kept
-        # send list of r towards q == recv list of q from r, as GLOBAL ids
-        for q, sidx in zip(p.nbr_rank, p.send_idx):
+        # send list of r towards q == recv list of q from r, as GLOBAL ids, nodes and elements
+        for q, sidx, seidx in zip(p.nbr_rank, p.send_idx, p.esend_idx):
             other = parts[q]
-            ridx = other.recv_idx[other.nbr_rank.index(p.rank)]
-            assert np.array_equal(p.l2g_node[sidx], other.l2g_node[ridx])
-        halo = np.concatenate(p.recv_idx) if p.recv_idx else np.zeros(0, int)
+            k = other.nbr_rank.index(p.rank)
+            assert np.array_equal(p.l2g_node[sidx], other.l2g_node[other.recv_idx[k]])
+            assert np.array_equal(p.l2g_elem[seidx], other.l2g_elem[other.erecv_idx[k]])
+            assert p.elem_owned[seidx].all() and ((sidx >= p.owned[0]) & (sidx < p.owned[1])).all()
+        ghosts = np.concatenate(p.recv_idx) if p.recv_idx else np.zeros(0, int)
         non_owned = np.setdiff1d(np.arange(p.nnode), np.arange(p.owned[0], p.owned[1]))
-        assert np.array_equal(np.sort(halo), non_owned)
-    # load balance: element work within 15 %
-    w = [p.nelem for p in parts]
+        assert np.array_equal(np.sort(ghosts), non_owned)
+    # load balance of the owned work within 15 %
+    w = [int(p.elem_owned.sum()) for p in parts]
     assert max(w) < 1.15 * min(w) + 200
 
 
@@ -100,9 +110,9 @@ def _gloo_worker(rank, world, port, nsteps, out_dir):
     PhasedStepper(eng, part, comm).step(nsteps)
     o0, o1 = part.owned
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dt0=dt, dt=eng.step(0).dt,
-             nodes=part.l2g_node[o0:o1], elems=part.l2g_elem,
+             nodes=part.l2g_node[o0:o1], elems=part.l2g_elem[part.elem_owned],
              vel=eng.download("VEL").reshape(3, -1)[:, o0:o1],
-             T=eng.download("TEMPERATURE")[o0:o1], stress=eng.download("STRESS").reshape(6, -1))
+             T=eng.download("TEMPERATURE")[o0:o1], stress=eng.download("STRESS").reshape(6, -1)[:, part.elem_owned])
     dist.barrier()
     dist.destroy_process_group()
 
