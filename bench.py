@@ -139,7 +139,7 @@ def main():
     import dynearthsol_amd as des
 
     # weak scaling: the test-3d-big box is repeated N times along x (same resolution), then cut
-    # into N slabs of contiguous node ids -- every GPU holds ~1.1M tets plus one ghost layer
+    # into N slabs of contiguous node ids -- every GPU holds ~1.1M tets plus its four-layer ghost region
     xlen = 400e3 * (1 if args.strong else world)
     overrides = "" if args.rheology == "elasto-visco-plastic" else "mat.rheology_type = %s\n" % args.rheology
     if args.averaged_fields:
@@ -213,7 +213,7 @@ def main():
                         "%d tets / %d nodes in total" % (ne, nn),
             "nelem": ne, "nnode": nn, "nelem_local_rank0": ne_local,
             "parallelism": "single GPU" if world == 1 else
-                           "%d slabs of contiguous node ids, one ghost-element layer, RCCL send/recv halo of nodal values" % world,
+                           "%d slabs of contiguous node ids, four-layer ghost region, one RCCL send/recv exchange per step" % world,
             "steps_per_s": args.steps / wall,
             "hip_event_ms_per_step": ev_ms / args.steps,
             "nan_entries": nan, "status": sc.status,
