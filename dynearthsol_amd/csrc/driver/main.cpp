@@ -52,7 +52,7 @@ int main(int argc, const char *argv[])
     }
     const des_engine_api api = { eng_create, eng_destroy, eng_upload, eng_download, eng_field_count,
                                  eng_set_clock, eng_init_geometry, eng_compute_dt, eng_step, eng_check_nan, eng_quality,
-                                 des_dev_last_error };
+                                 des_dev_last_error, 0 };
     des_run_stats st;
     int rc = des_run(host, &api, device, quiet, &st);
     des_host_destroy(host);

@@ -20,6 +20,7 @@ namespace des {
 const std::string &output_last_error();
 void output_set_quiet(des_output *o, bool q);
 }
+extern "C" int des_output_skip(des_output *o);      // advance the frame counter without writing
 
 namespace {
 
@@ -84,10 +85,10 @@ struct Run {
             f.volume_old = vold.data(); f.edvacc_surf = edv.data(); f.dhacc = dhacc.data();
             f.info_display_next_step = info_display_next_step;
             f.reference_frame_time = reference_frame_time; f.last_remesh_time = last_remesh_time;
-            int rc = des_output_write_checkpoint(out, &f);
+            int rc = api->no_files ? 0 : des_output_write_checkpoint(out, &f);
             if (rc) throw des::Error(rc, des::output_last_error());
         }
-        int rc = des_output_write(out, &f, exact ? 1 : 0);
+        int rc = api->no_files ? des_output_skip(out) : des_output_write(out, &f, exact ? 1 : 0);
         if (rc) throw des::Error(rc, des::output_last_error());
         if (exact) {
             // write_exact: check for NaN in var (output.cxx:291-292)
@@ -176,6 +177,7 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         r.check(api->step(r.eng, 0, &r.sc), "clock");
 
         r.out = des_output_create(host, rs.active ? rs.frame : 0);
+        if (api->no_files) quiet = 1;
         des::output_set_quiet(r.out, quiet != 0);
 
         if (!rs.active && cfg.b("sim.has_initial_checkpoint")) {
@@ -186,7 +188,7 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
             cf.volume_old = vold.data(); cf.edvacc_surf = edv.data(); cf.dhacc = dhacc.data();
             cf.elemmarkers = f.elemmarkers.data();
             cf.info_display_next_step = r.info_display_next_step;
-            int rc = des_output_write_checkpoint(r.out, &cf);
+            int rc = api->no_files ? 0 : des_output_write_checkpoint(r.out, &cf);
             if (rc) throw des::Error(rc, des::output_last_error());
             st.checkpoints++;
         }

@@ -32,7 +32,7 @@ class EngineApi(C.Structure):
     """des_engine_api"""
     _fields_ = [("create", CREATE_T), ("destroy", DESTROY_T), ("upload", UPLOAD_T), ("download", DOWNLOAD_T),
                 ("field_count", COUNT_T), ("set_clock", CLOCK_T), ("init_geometry", INITGEOM_T), ("compute_dt", DT_T), ("step", STEP_T),
-                ("check_nan", NAN_T), ("mesh_quality", QUALITY_T), ("last_error", ERR_T)]
+                ("check_nan", NAN_T), ("mesh_quality", QUALITY_T), ("last_error", ERR_T), ("no_files", _i)]
 
 
 class RunStats(C.Structure):

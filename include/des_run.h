@@ -64,6 +64,11 @@ typedef struct des_engine_api {
     int (*check_nan)(void *h, long long *n_nan);
     int (*mesh_quality)(void *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out);
     const char *(*last_error)(void);
+    /* One-process-per-GPU runs: every rank runs the same loop over an engine table whose entries
+     * are collective (upload scatters, download gathers the global arrays, step / compute_dt /
+     * mesh_quality / check_nan reduce across ranks: dynearthsol_amd/distributed.py); ranks with
+     * no_files != 0 take part in every gather but write no frame, checkpoint or progress line. */
+    int no_files;
 } des_engine_api;
 
 /* What the loop did, for callers that do not parse stdout. */

@@ -86,3 +86,25 @@ def test_executable_restarts_from_its_own_checkpoint(in_tmp):
     for name in a:
         if name != "walltime_sec":
             assert np.array_equal(a[name], b[name]), name
+
+
+def test_distributed_run_with_one_rank_equals_the_plain_run(in_tmp):
+    """dynearthsol_amd.distributed on a world of one (all the 1-GPU box can hold): the collective
+    engine table over the HIP engine, RCCL communicator attached, writes the frames of driver.run."""
+    import torch.distributed as dist
+    from dynearthsol_amd.distributed import run_distributed
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 90))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        kw = dict(cfgs.EVP, nmat=2)
+        st = run_distributed(des.Host(cfg_text=cfgs.make(**kw), overrides=OV + "sim.modelname = dist\n"), dist)
+        assert (st.steps, st.frames, st.exit_code) == (40, 3, 0)
+    finally:
+        dist.destroy_process_group()
+    driver.run(des.Host(cfg_text=cfgs.make(**kw), overrides=OV + "sim.modelname = plain\n"))
+    for frame in (0, 1, 2):
+        a, b = read_frame("dist.save.%06d" % frame), read_frame("plain.save.%06d" % frame)
+        for name in a:
+            if name != "walltime_sec":
+                assert np.array_equal(a[name], b[name]), (frame, name)
