@@ -118,6 +118,10 @@ def main():
                     help="diagnostic only: the headline workload is elasto-visco-plastic")
     args = ap.parse_args()
 
+    t_begin = time.perf_counter()
+    if os.environ.get("DES_BENCH_VERBOSE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("DES_BENCH_WATCHDOG", "60")), repeat=False)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +142,10 @@ def main():
 
     import dynearthsol_amd as des
 
+    def note(msg):
+        if os.environ.get("DES_BENCH_VERBOSE"):
+            sys.stderr.write("[bench rank %d %.1fs] %s\n" % (rank, time.perf_counter() - t_begin, msg)); sys.stderr.flush()
+
     # weak scaling: the test-3d-big box is repeated N times along x (same resolution), then cut
     # into N slabs of contiguous node ids -- every GPU holds ~1.1M tets plus its four-layer ghost region
     xlen = 400e3 * (1 if args.strong else world)
@@ -147,9 +155,11 @@ def main():
     if args.mesh_file:
         assert world == 1, "--mesh-file is a single-GPU workload"
         overrides += "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n"
+    note("building the host model")
     host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)), overrides=overrides or None,
                     mesh_file=args.mesh_file)
     device = int(os.environ.get("DES_BENCH_DEVICE", local_rank))
+    transport = "RCCL ncclSend/ncclRecv on the engine stream"
     if world == 1:
         dev = des.DeviceEngine(host, device=device)
         dev.init_from_host(host)
@@ -160,12 +170,36 @@ def main():
         class _Comm:          # init only: the first compute_dt goes through the engine's own allreduce
             def reduce_dt(self, engine, recompute):
                 return engine.compute_dt()
+        note("partition")
         part = Partition(host, world, rank)
+        note("engine")
         dev = des.DeviceEngine(part, device=device)
         dev.set_halo(part)
-        dev.comm_init(dist, rank, world)
-        init_rank(dev, part, _Comm())
+        # The ghost-region exchange runs inside des_dev_step on RCCL.  Should the engine's own
+        # communicator fail to come up on this node, the same step is driven in its two phases
+        # with the ghost state staged through the host over gloo -- slower, said so in the line.
+        ok = 1
+        try:
+            if os.environ.get("DES_BENCH_TRANSPORT", "rccl") != "rccl":
+                raise des.DesError(31, "host transport requested")
+            dev.comm_init(dist, rank, world)
+        except des.DesError as e:
+            sys.stderr.write("rank %d: %s\n" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            init_rank(dev, part, _Comm())
+        else:
+            from dynearthsol_amd.decomp import PhasedStepper, TorchComm
+            transport = "host-staged over gloo (engine communicator unavailable)"
+            comm = TorchComm(dist, group=dist.new_group(backend="gloo"))
+            init_rank(dev, part, comm)
+            stepper = PhasedStepper(dev, part, comm)
+            _step = dev.step
+            dev.step = lambda n, want_scalars=True: (stepper.step(n), _step(0, want_scalars=want_scalars))[1]
         ne_local = part.nelem
+    note("initialised; warm-up")
     ne, nn = host.nelem, host.nnode          # global counts: `value` counts every element once
 
     dev.step(args.warmup, want_scalars=False) if args.warmup > 0 else None
@@ -177,6 +211,7 @@ def main():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         dev.sync()
 
+    note("timed region")
     barrier()
     t0 = time.perf_counter()
     dev.timer_start()
@@ -213,12 +248,21 @@ def main():
                         "%d tets / %d nodes in total" % (ne, nn),
             "nelem": ne, "nnode": nn, "nelem_local_rank0": ne_local,
             "parallelism": "single GPU" if world == 1 else
-                           "%d slabs of contiguous node ids, four-layer ghost region, one RCCL send/recv exchange per step" % world,
+                           "%d slabs of contiguous node ids, four-layer ghost region, one exchange per step; transport: %s" % (world, transport),
             "steps_per_s": args.steps / wall,
             "hip_event_ms_per_step": ev_ms / args.steps,
             "nan_entries": nan, "status": sc.status,
         },
     }
+
+    # per-kernel HIP-event timing on the engine's own stream (separate short run).  EVERY rank
+    # takes these steps: a step is collective on a decomposed mesh.
+    prof = None
+    if not args.no_profile:
+        dev.profile_enable(True)
+        dev.step(20, want_scalars=False)
+        prof = dev.profile_read()
+        dev.profile_enable(False)
 
     if rank == 0:
         bytes_step = dev.algorithmic_bytes_per_step() if world == 1 else (
@@ -226,12 +270,7 @@ def main():
         result["config"]["algorithmic_bytes_per_step"] = bytes_step
         result["config"]["whole_step_frac_of_hbm_peak"] = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
         roof = None
-        if not args.no_profile:
-            # per-kernel HIP-event timing on the engine's own stream (separate short run)
-            dev.profile_enable(True)
-            dev.step(20, want_scalars=False)
-            prof = dev.profile_read()
-            dev.profile_enable(False)
+        if prof is not None:
             kern = {n: (ms, calls) for n, ms, calls in prof}
             result["config"]["kernel_ms_per_call"] = {n: ms / calls for n, (ms, calls) in kern.items()}
             cands = [(ms, n) for n, (ms, calls) in kern.items() if n in KERNEL_BYTES]
@@ -241,11 +280,11 @@ def main():
                 be, bn = KERNEL_BYTES[dom]
                 if dom == "E2_update_stress" and args.rheology == "elasto-visco-plastic":
                     be, bn = be + 24, bn + 8
-                kbytes = be * ne_local + bn * (nn if world == 1 else (part.owned[1] - part.owned[0]))
+                kbytes = be * ne_local + bn * (nn if world == 1 else part.nnode)     # rank 0's launch
                 achieved = kbytes / (ms / calls * 1e-3) / 1e9
                 traffic = None
                 tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(tpath):
+                if os.path.exists(tpath) and world == 1 and not args.mesh_file:
                     try:
                         # PMC passes cannot share a run with the timed one: the committed summary of
                         # `tools/summarize_pmc.py` for the same workload is reported (bytes per launch)

@@ -163,9 +163,9 @@ def run_loopback(steppers, nsteps):
 class TorchComm:
     """One rank per process over torch.distributed (gloo on CPU in the tests)."""
 
-    def __init__(self, dist, device="cpu"):
+    def __init__(self, dist, device="cpu", group=None):
         import torch
-        self.dist, self.torch, self.device = dist, torch, device
+        self.dist, self.torch, self.device, self.group = dist, torch, device, group
 
     def exchange(self, stepper):
         torch, dist = self.torch, self.dist
@@ -174,8 +174,8 @@ class TorchComm:
         for q, sidx, ridx, seidx, reidx in zip(p.nbr_rank, p.send_idx, p.recv_idx, p.esend_idx, p.erecv_idx):
             sbuf = torch.from_numpy(np.concatenate([e.halo_pack(0, sidx, NODE_WIDTH), e.halo_pack(1, seidx, ELEM_WIDTH)]))
             rbuf = torch.empty(len(ridx) * NODE_WIDTH + len(reidx) * ELEM_WIDTH, dtype=torch.float64)
-            reqs.append(dist.isend(sbuf, dst=q))
-            reqs.append(dist.irecv(rbuf, src=q))
+            reqs.append(dist.isend(sbuf, dst=q, group=self.group))
+            reqs.append(dist.irecv(rbuf, src=q, group=self.group))
             recvs.append((ridx, reidx, rbuf, sbuf))
         for r in reqs:
             r.wait()
@@ -186,7 +186,7 @@ class TorchComm:
 
     def reduce_dt(self, engine, recompute):
         t = self.torch.from_numpy(engine.dt_partials(recompute))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return engine.dt_finalize(t.numpy())
 
 

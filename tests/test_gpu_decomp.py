@@ -129,3 +129,28 @@ def test_rccl_send_recv_path_moves_the_ghost_state():
         assert np.array_equal(s2[:, ekeep], stress[:, ekeep]) and np.array_equal(p2[ekeep], pls[ekeep])
     finally:
         dist.destroy_process_group()
+
+
+def test_two_rank_bench_rehearsal():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank),
+    rehearsed with both ranks on the one GPU of this box: RCCL refuses two ranks on one device, so
+    the ghost state is staged through the host over gloo (DES_BENCH_TRANSPORT=host); everything
+    else -- partition, engines, the collective step count on every rank, the JSON line -- is the
+    real thing.  (A profiling run taken by rank 0 alone used to hang here.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DES_BENCH_BACKEND="gloo", DES_BENCH_TRANSPORT="host", DES_BENCH_DEVICE="0",
+               DES_BENCH_VERBOSE="1", DES_BENCH_WATCHDOG="100")
+    port = 29400 + os.getpid() % 90
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(des.REPO_ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "12", "--warmup", "2", "--resolution", "2000", "--cpu-steps", "0"],
+                         capture_output=True, text=True, timeout=170, env=env, cwd=des.REPO_ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 12 and r["config"]["nan_entries"] == 0 and r["config"]["status"] == 0
+    assert r["config"]["nelem"] == 100000 and r["value"] > 0 and "kernel_ms_per_call" in r["config"]
