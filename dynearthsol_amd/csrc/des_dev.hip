@@ -588,8 +588,8 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2)
 {
-    // elements [e_begin, e_begin + e_count): the whole mesh, or the interior / boundary part of a
-    // rank's mesh when the halo exchange overlaps the interior (ne stays the SoA plane stride)
+    // elements [e_begin, e_begin + e_count): the whole local mesh, or any sub-range of it (ne
+    // stays the SoA plane stride)
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     if (el >= e_count) return;
     const int e = e_begin + el;
