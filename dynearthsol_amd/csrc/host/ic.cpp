@@ -305,9 +305,80 @@ void initial_temperature(const Config &cfg, const des_params &p, const HostMesh 
         }
         break;
     }
-    case 3:
+    case 3: {
+        // radiogenic_heat_and_adiabat (ic.cxx:724-830): continental geotherm after Hasterok &
+        // Chapman 2011 with an optional heat-flux dome, capped by the mantle adiabat; markers whose
+        // element lies in the adiabatic part become asthenosphere
+        const double F = 0.74;                                              // partition coefficient
+        const double DEG2RAD = 3.14159265358979323846 / 180;
+        const int nlayer = cfg.i("ic.num_radiogenic_heat_layer");
+        std::vector<double> layer_bdy = cfg.list("ic.radiogenic_heat_boundry", nlayer+1, 1);
+        if (layer_bdy[0] == -1) layer_bdy[0] = 0;                         // input.cxx:1434-1437
+        if (layer_bdy[nlayer] == -1) layer_bdy[nlayer] = p.zlength;
+        std::vector<double> layer_mat = cfg.list("ic.radiogenic_heat_mat_in_layer", nlayer, 1);
+        std::vector<double> mat_hp = cfg.list("mat.radiogenic_heat_prod", p.nmat, -1);
+        std::vector<double> thickness(nlayer), rho(nlayer), cond(nlayer), hp(nlayer);
+        for (int i = 0; i < nlayer; i++) {
+            const int mat = (int)layer_mat[i];
+            cond[i] = p.therm_cond[mat];
+            rho[i] = p.rho0[mat];
+            hp[i] = mat_hp[mat];
+            thickness[i] = layer_bdy[i+1] - layer_bdy[i];
+        }
+        const double wx_r = 1. / cfg.d("ic.radiogenic_heat_dome_width");
+        const double az = cfg.d("ic.radiogenic_heat_dome_azimuth") * DEG2RAD;
+        const double wy = cfg.d("ic.radiogenic_heat_dome_width_y");
+        const double wy_r = (wy == 0) ? wx_r : (wy < 0.0 ? 0. : 1. / wy);
+        const double cx = cfg.d("ic.radiogenic_heat_dome_center_x") * p.xlength;
+        const double cy = cfg.d("ic.radiogenic_heat_dome_center_y") * p.ylength;
+        const double heat_flux = cfg.d("ic.surface_heat_flux"), amplitude = cfg.d("ic.radiogenic_heat_dome_amplitude");
+        const int mt_asth = cfg.i("mat.mattype_asthenosphere");
+        std::vector<int> in_asth((size_t)nn, 0);
+        for (int n = 0; n < nn; n++) {
+            const double zz = -z[n];
+            const double zPotT = t_bot * std::exp(p.gravity * zz * 4e-8);
+            const double dx = m.coord[n] - cx, dy = m.coord[(size_t)nn + n] - cy;
+            const double dx_rot = dx * std::cos(az) - dy * std::sin(az);
+            const double dy_rot = dx * std::sin(az) + dy * std::cos(az);
+            const double radius_sq = std::pow(dx_rot * wx_r, 2) + std::pow(dy_rot * wy_r, 2);
+            const double xsfh = heat_flux + amplitude / 1e6 * std::exp(-radius_sq);
+            hp[0] = (1. - F) * xsfh / rho[0] / layer_bdy[1];
+            double t = t_top, q = xsfh;
+            for (int i = 0; i < nlayer; i++) {
+                if (zz >= layer_bdy[i]) {
+                    double dd = std::min(zz - layer_bdy[i], thickness[i]);
+                    t += q * dd / cond[i] - (rho[i] * hp[i]) / (2. * cond[i]) * dd * dd;
+                    q -= rho[i] * hp[i] * dd;
+                }
+                if (t > zPotT) { in_asth[n] = 1; break; }
+            }
+            if (in_asth[n]) {
+                t = zPotT;
+            } else {
+                double rs = 0.;
+                for (int i = 0; i < nlayer; i++)
+                    if (zz >= layer_bdy[i]) rs = hp[i];
+                for (int k = m.sup_idx[n]; k < m.sup_idx[n+1]; ++k)
+                    f.radiogenic[m.sup_arr[k]] += rs / 4;
+            }
+            f.temperature[n] = t;
+        }
+        HostMarkers &mk = f.markers;
+        const size_t nm = (size_t)mk.nmarkers;
+        for (size_t mi = 0; mi < nm; ++mi) {
+            const int e = mk.elem[mi], current_mt = mk.mattype[mi];
+            double t = 0;
+            for (int i = 0; i < 4; ++i) t += in_asth[m.conn[(size_t)i*ne + e]] * mk.eta[(size_t)i*nm + mi];
+            if (t >= 0.5 && current_mt != mt_asth) {
+                mk.mattype[mi] = mt_asth;
+                --f.elemmarkers[(size_t)e*p.nmat + current_mt];
+                ++f.elemmarkers[(size_t)e*p.nmat + mt_asth];
+            }
+        }
+        break;
+    }
     case 90:
-        throw Error(31, "ic.temperature_option 3/90 need host marker / file input that is not offloaded");
+        throw Error(31, "ic.temperature_option 90 (external temperature file) is not offloaded");
     default:
         throw Error(11, "Error: unknown ic.temperature option");
     }

@@ -259,3 +259,105 @@ dilation_angle1 = [0]
 max_viscosity = 1e24
 min_viscosity = 1e19
 """
+
+
+# Parameter values of the reference's benchmarks-cores/test-3d-equ-tiny.cfg (12,500 tets) -- and,
+# through make_equ(long=True), of test-3d-equ-long.cfg (984,375 tets / 209,664 nodes): the
+# reference's own regular-mesh 3-D benchmarks (meshing_option = 1, meshing_elem_shape = 1), which
+# the host library meshes itself: seven materials in two layers, continental geotherm with
+# radiogenic heating (temperature_option = 3), water loading, surface diffusion, evp.
+EQU = """
+[sim]
+modelname = benchmark
+{stop}
+has_output_during_remeshing = no
+is_outputting_averaged_fields = no
+checkpoint_frame_interval = {ckpt}
+[mesh]
+meshing_option = 1
+meshing_elem_shape = 1
+xlength = 250e3
+ylength = {ly}
+zlength = 125e3
+resolution = {res}
+quality_check_step_interval = {qcsi}
+min_quality = 0.2
+max_boundary_distortion = {mbd}
+remeshing_option = 13
+[markers]
+markers_per_element = 8
+[control]
+surface_process_option = 1
+surface_diffusivity = {sdiff}
+dt_fraction = 1.0
+inertial_scaling = 1e4
+surf_base_level = 15.e3
+gravity = 9.81
+[bc]
+vbc_x0 = 1
+vbc_x1 = 1
+vbc_val_x0 = -1.57e-10
+vbc_val_x1 = 1.57e-10
+vbc_y0 = 1
+vbc_y1 = 1
+vbc_val_y0 = 0
+vbc_val_y1 = 0
+has_water_loading = yes
+surface_temperature = 273
+mantle_temperature = 1723
+[ic]
+mattype_option = 1
+num_mattype_layers = 2
+layer_mattypes = [1,2]
+mattype_layer_depths = [0.24]
+temperature_option = 3
+num_radiogenic_heat_layer = 3
+radiogenic_heat_boundry = [-1, 6e3, 8e3, -1]
+radiogenic_heat_mat_in_layer = [1, 1, 2]
+radiogenic_heat_dome_amplitude = 10.e3
+radiogenic_heat_dome_width = 30.e3
+surface_heat_flux = 70e-3
+weakzone_option = 0
+[mat]
+rheology_type = elasto-visco-plastic
+num_materials = 7
+mattype_ref = 2
+mattype_oceanic_crust = 0
+mattype_crust = 1
+mattype_mantle = 2
+mattype_asthenosphere = 3
+mattype_sed = 4
+mattype_depleted_mantle = 5
+mattype_mor_extrusion = 6
+rho0 = [ 2900, 2750, 3300, 3300, 2400, 3300, 2900 ]
+alpha = [ 3e-5 ]
+bulk_modulus = [  4.0e10, 4.3e10, 6.7e10, 6.7e10, 5.5e10, 6.7e10, 4.3e10 ]
+shear_modulus = [ 4.3e10, 3.5e10, 6.7e10, 6.7e10, 3.6e10, 6.7e10, 4.3e10 ]
+visc_exponent =          [ 3.5,    3.05,     3.5,    3.5,   4.0,    3.5,   3.05 ]
+visc_coefficient =       [ 1.1e5, 1.25e-1, 1.1e+5, 1.1e+5,  5.e2,  1.1e+5, 1.25e-1 ]
+visc_activation_energy = [ 2.23e5, 2.76e5, 5.30e5, 5.30e5, 4.3e5, 5.30e+5,  2.76e5 ]
+visc_activation_volume = [ 27.E-6, 27.E-6, 27.E-6, 27.E-6, 27.E-6, 27.E-6, 27.E-6 ]
+radiogenic_heat_prod =   [ 0, 4e-10, 2e-11, 0.00E+00, 0, 2e-11, 0 ]
+heat_capacity = [ 1000 ]
+therm_cond = [ 3.3 ]
+pls0 = [ 0 ]
+pls1 = {pls1}
+cohesion0 = [ 4e7, 4e7, 4e7, 4e7, 4e7, 4e7, 4.4e7 ]
+cohesion1 = [ 4e6 ]
+friction_angle0 = {fa0}
+friction_angle1 = {fa1}
+dilation_angle0 = [ 0 ]
+dilation_angle1 = [ 0 ]
+max_viscosity = 1e24
+min_viscosity = 1e19
+"""
+
+
+def make_equ(long=False):
+    if long:
+        return EQU.format(stop="max_time_in_yr = 5.e6\noutput_time_interval_in_yr = 50.e3", ckpt=50, ly="50e3", res="2e3",
+                          qcsi=100, mbd=2.5, sdiff="7e-6", pls1="[ 0.1, 0.1, 0.5, 0.5, 0.1, 0.5, 0.1 ]",
+                          fa0="[ 30, 30, 30, 30, 20, 30, 30 ]", fa1="[ 10, 15, 15, 15, 15, 15, 5 ]")
+    return EQU.format(stop="max_steps = 400\noutput_step_interval = 100", ckpt=1, ly="10e3", res="5e3", qcsi=5, mbd="1e-3",
+                      sdiff="2e-5", pls1="[ 0.1, 0.1, 5, 5, 0.1, 5, 0.1 ]", fa0="[ 30, 30, 30, 30, 30, 30, 30 ]",
+                      fa1="[ 10, 20, 30, 30, 15, 30, 5 ]")
