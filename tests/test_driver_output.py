@@ -251,3 +251,26 @@ def test_reference_reader_reads_our_frames(in_tmp):
     assert rows[2]["nnode"] == nn and rows[2]["nelem"] == ne
     # (the reference's DynearthsolCheckpoint reader fails on its own files -- it never sets
     # self.format, Dynearthsol.py:352-359 -- so checkpoints are checked with read_frame above)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "benchmarks-cores", "compare.py")),
+                    reason="the reference's regression tool is only present in the build container")
+def test_reference_compare_tool_accepts_our_frames(in_tmp):
+    """benchmarks-cores/compare.py -- the reference's own regression check (exit 0: no field differs
+    by 1e-8 or more) -- on two runs of the driver loop: reads our .info and frames, finds them
+    bit-exact; and flags a perturbed run."""
+    import subprocess
+    ov = ("sim.max_steps = 20\nsim.output_step_interval = 10\nmesh.quality_check_step_interval = 10\n"
+          "sim.is_outputting_averaged_fields = no\n")
+    for name, extra in (("a", ""), ("b", ""), ("c", "bc.vbc_val_x1 = 1.001e-9\n")):
+        os.mkdir(name)
+        os.chdir(name)
+        driver.run(des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=ov + extra + "sim.modelname = result\n"), api=oracle_api())
+        os.chdir("..")
+    tool = os.path.join(REF, "benchmarks-cores", "compare.py")
+    env = dict(os.environ, PYTHONPATH=REF)
+    same = subprocess.run([sys.executable, tool, "a/result", "b/result", "2"], capture_output=True, text=True, env=env)
+    assert same.returncode == 0, same.stdout + same.stderr
+    assert "BIT-EXACT" in same.stdout.upper() or "bit-exact" in same.stdout
+    diff = subprocess.run([sys.executable, tool, "a/result", "c/result", "2"], capture_output=True, text=True, env=env)
+    assert diff.returncode == 1, diff.stdout + diff.stderr
