@@ -274,3 +274,21 @@ def test_reference_compare_tool_accepts_our_frames(in_tmp):
     assert "BIT-EXACT" in same.stdout.upper() or "bit-exact" in same.stdout
     diff = subprocess.run([sys.executable, tool, "a/result", "c/result", "2"], capture_output=True, text=True, env=env)
     assert diff.returncode == 1, diff.stdout + diff.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "2vtk.py")),
+                    reason="the reference's VTK converter is only present in the build container")
+def test_reference_vtk_converter_accepts_our_frames(in_tmp):
+    """2vtk.py -c -m -t (fields, all tensor components, marker set) on the frames of a driver run."""
+    import subprocess
+    ov = ("sim.max_steps = 20\nsim.output_step_interval = 10\nmesh.quality_check_step_interval = 10\n"
+          "sim.modelname = result\n")
+    driver.run(des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, nmat=2)), overrides=ov), api=oracle_api())
+    env = dict(os.environ, PYTHONPATH=REF)
+    out = subprocess.run([sys.executable, os.path.join(REF, "2vtk.py"), "-c", "-m", "-t", "result"],
+                         capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    made = sorted(f for f in os.listdir(in_tmp) if f.endswith((".vtu", ".vtp")))
+    assert [f for f in made if f.endswith(".vtu")] == ["result.%06d.vtu" % i for i in range(3)], (made, out.stdout)
+    assert any(f.endswith(".vtp") for f in made)
+    assert os.path.getsize("result.000002.vtu") > 10000
