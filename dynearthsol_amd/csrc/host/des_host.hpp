@@ -122,6 +122,9 @@ void initial_conditions(const Config &cfg, des_params &p, const HostMesh &m, Hos
 // mesh ready for build_topology().
 void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostFields &f);
 
+// ic.is_restarting_weakzone (dynearthsol.cxx:403-406)
+void restart_weak_zone(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f);
+
 // ref_pressure (matprops.cxx:153-174)
 double ref_pressure(const des_params &p, double z);
 

@@ -413,10 +413,10 @@ void initial_stress_state(des_params &p, const HostMesh &m, HostFields &f)
 }
 
 // ic.cxx:497-654, zone shapes ic.cxx:13-300
-void initial_weak_zone(const Config &c, const des_params &p, const HostMesh &m, HostFields &f)
+void initial_weak_zone(const Config &c, const des_params &p, const HostMesh &m, HostFields &f, bool fresh = true)
 {
     const int ne = m.nelem, nn = m.nnode;
-    f.plstrain.assign((size_t)ne, 0.0);
+    if (fresh) f.plstrain.assign((size_t)ne, 0.0);       // init(): plstrain starts at zero (fields.cxx:96)
     const int option = c.i("ic.weakzone_option");
     if (option == 0) return;
     const double res = c.d("mesh.resolution");
@@ -434,10 +434,31 @@ void initial_weak_zone(const Config &c, const des_params &p, const HostMesh &m, 
     const double semi[3] = {c.d("ic.weakzone_xsemi_axis"), c.d("ic.weakzone_ysemi_axis"), c.d("ic.weakzone_zsemi_axis")};
     const double sd = c.d("ic.weakzone_standard_deviation");
     const double gauss_amp = c.d("ic.weakzone_gaussian_amplitude");
-    if (option == 5)
-        throw Error(31, "ic.weakzone_option 5 (multi-segment zone) is not built by this host yet");
-    if (option < 1 || option > 4)
+    if (option < 1 || option > 5)
         throw Error(11, "Error: unknown weakzone_option");
+    // Multi_planar_zone of General_planar_zone segments (ic.cxx:72-179, 577-622): unit-normal planes
+    // bounded in x, y and z; a point is in the zone if any segment contains it
+    struct Segment { double nx, ny, nz, xmin, xmax, ymin, ymax, zmin, zmax, halfwidth, c[3]; };
+    std::vector<Segment> segs;
+    if (option == 5) {
+        const int n = c.i("ic.weakzone_num_segments");
+        auto L = [&](const char *key) { return c.list(std::string("ic.weakzone_segments_") + key, n, -1); };
+        const std::vector<double> xc = L("xcenter"), yc = L("ycenter"), zc = L("zcenter"), azs = L("azimuth"),
+            incs = L("inclination"), hws = L("halfwidth"), xmn = L("x_min"), xmx = L("x_max"), ymn = L("y_min"),
+            ymx = L("y_max"), dmn = L("depth_min"), dmx = L("depth_max");
+        for (int i = 0; i < n; ++i) {
+            Segment g;
+            g.nx = -std::cos(azs[i] * DEG2RAD) * std::sin(incs[i] * DEG2RAD);
+            g.nz = -std::cos(incs[i] * DEG2RAD);
+            g.ny = std::sin(azs[i] * DEG2RAD) * std::sin(incs[i] * DEG2RAD);
+            g.xmin = xmn[i] * p.xlength; g.xmax = xmx[i] * p.xlength;
+            g.ymin = ymn[i] * p.ylength; g.ymax = ymx[i] * p.ylength;
+            g.zmin = -dmx[i] * p.zlength; g.zmax = -dmn[i] * p.zlength;
+            g.halfwidth = hws[i] * res;
+            g.c[0] = xc[i] * p.xlength; g.c[1] = yc[i] * p.ylength; g.c[2] = -zc[i] * p.zlength;
+            segs.push_back(g);
+        }
+    }
 
     for (int e = 0; e < ne; ++e) {
         double center[3] = {0, 0, 0};
@@ -460,6 +481,15 @@ void initial_weak_zone(const Config &c, const des_params &p, const HostMesh &m, 
             double r2 = (x[0]-x0[0])*(x[0]-x0[0]) + (x[1]-x0[1])*(x[1]-x0[1]) + (x[2]-x0[2])*(x[2]-x0[2]);
             inside = r2 < (sd * sd * 16.);
             value = exp(-(r2 / (2.*sd*sd)));
+        } else if (option == 5) {
+            for (const Segment &g : segs) {
+                if (x[0] <= g.xmin || x[0] >= g.xmax) continue;
+                if (x[2] <= g.zmin || x[2] >= g.zmax) continue;
+                if (x[1] <= g.ymin || x[1] >= g.ymax) continue;
+                double dist = g.nx * (x[0] - g.c[0]) + g.nz * (x[2] - g.c[2]);
+                dist += g.ny * (x[1] - g.c[1]);
+                if (std::fabs(dist) < g.halfwidth) { inside = true; break; }
+            }
         } else {
             // Gaussian_planar_zone (ic.cxx:207-259): planar zone whose x position bulges along strike
             if (!(x[2] <= zmin || x[2] >= zmax) && !(x[1] <= ymin || x[1] >= ymax)) {
@@ -473,6 +503,13 @@ void initial_weak_zone(const Config &c, const des_params &p, const HostMesh &m, 
 }
 
 } // namespace
+
+// restart() with ic.is_restarting_weakzone (dynearthsol.cxx:403-406): a new weak zone on top of
+// the restored plastic strain (elements outside the zone keep theirs)
+void restart_weak_zone(const Config &c, const des_params &p, const HostMesh &m, HostFields &f)
+{
+    initial_weak_zone(c, p, m, f, false);                // only the elements inside the zone are overwritten
+}
 
 // matprops.cxx:153-174 (has_hydraulic_diffusion == false)
 double ref_pressure(const des_params &p, double z)

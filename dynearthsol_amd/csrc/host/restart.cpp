@@ -175,7 +175,7 @@ void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostField
     save.array(rs.delta_plstrain, "plastic strain-rate", (std::size_t)nelem);
 
     if (cfg.b("ic.is_restarting_weakzone"))
-        throw Error(31, "ic.is_restarting_weakzone is not offloaded");
+        restart_weak_zone(cfg, p, m, f);
 }
 
 } // namespace des

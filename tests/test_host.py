@@ -218,3 +218,24 @@ def test_device_path_fails_loudly_without_a_gpu():
     with pytest.raises(des.DesError) as e:
         des.DeviceEngine(h)
     assert e.value.code == 31
+
+
+def test_multi_segment_weak_zone():
+    """ic.weakzone_option = 5 (Multi_planar_zone, ic.cxx:72-179, 577-622): two bounded planes."""
+    ov = ("ic.weakzone_option = 5\nic.weakzone_num_segments = 2\nic.weakzone_segments_xcenter = [0.3, 0.7]\n"
+          "ic.weakzone_segments_zcenter = [0.5, 0.5]\nic.weakzone_segments_inclination = [90, 60]\n"
+          "ic.weakzone_segments_halfwidth = [1.2, 1.2]\nic.weakzone_segments_x_min = [0, 0.5]\n"
+          "ic.weakzone_segments_x_max = [0.5, 1]\nic.weakzone_segments_depth_max = [1, 0.6]\n")
+    h = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=ov)
+    pls = h.array("plstrain")
+    conn = h.array("connectivity").reshape(4, -1)
+    c = h.array("coord").reshape(3, -1)[:, conn].mean(axis=1)
+    lx, lz, res = 40e3, 8e3, 2e3
+    inc = np.deg2rad(60.0)
+    seg1 = (c[0] < 0.5 * lx) & (np.abs(c[0] - 0.3 * lx) < 1.2 * res)                       # vertical plane
+    d2 = -np.sin(inc) * (c[0] - 0.7 * lx) - np.cos(inc) * (c[2] + 0.5 * lz)
+    seg2 = (c[0] > 0.5 * lx) & (c[2] > -0.6 * lz) & (np.abs(d2) < 1.2 * res)
+    expect = np.where(seg1 | seg2, 0.5, 0.0)
+    # centroids exactly on a bound are decided by rounding: compare away from the bounds
+    sure = (np.abs(np.abs(c[0] - 0.3 * lx) - 1.2 * res) > 1) & (np.abs(np.abs(d2) - 1.2 * res) > 1)
+    assert np.array_equal(pls[sure], expect[sure]) and pls.max() == 0.5 and (pls > 0).sum() > 20
