@@ -118,6 +118,8 @@ struct des_dev {
     double *stress, *strain, *strain_rate, *plstrain, *delta_plstrain, *viscosity, *volume,
            *volume_old, *dpressure, *radiogenic;
     int *markers;
+    int *mono;                            // [ne] (material << 16) | count of single-material elements, else -1
+    double *ptab;                         // [nmat][DES_PTAB_CNT][5] property means of single-material elements
     unsigned char *topflag;               // element touches the top surface (Variables::top_elems)
     double *props;                        // [5][ne] bulkm, shearm, phi, cp, k  (nmat > 1 only)
     // temporaries
@@ -174,40 +176,85 @@ namespace des_hip {
 // =====================================================================================
 struct ElemProps { double bulkm, shearm, phi, cp, k; };
 
-__device__ __forceinline__ ElemProps load_props(const des_params *p, const double *props, int ne, int e)
+// What the kernels know about the materials of an element (refresh_elem_cache,
+// matprops.cxx:259-303, redone whenever the marker counts change):
+//   markers [ne][nmat]  the counts themselves
+//   mono    [ne]        (material << 16) | count where one material holds every marker, else -1:
+//                       4 bytes per element and pass instead of 4*nmat + 40
+//   props   [5][ne]     bulkm, shearm, phi, cp, k of every element (nmat > 1 only)
+//   ptab    [nmat][DES_PTAB_CNT][5]  the same five means for a single-material element with
+//                       `count` markers (the means are count-dependent in the last bit:
+//                       count / (count / s)), so those elements read a cached table row
+#define DES_PTAB_CNT 64
+struct MatData { const int *markers; const int *mono; const double *props; const double *ptab; };
+
+__device__ __forceinline__ desk::Mix mix_of(const MatData &md, int nmat, int e)
+{
+    const int mo = md.mono[e];
+    desk::Mix mx;
+    if (mo >= 0) { mx.mk = nullptr; mx.mat = mo >> 16; mx.cnt = mo & 0xffff; }
+    else         { mx.mk = md.markers + (size_t)e * nmat; mx.mat = -1; mx.cnt = 0; }
+    return mx;
+}
+
+__device__ __forceinline__ ElemProps load_props(const des_params *p, const MatData &md, const desk::Mix &mx, int ne, int e)
 {
     ElemProps r;
-    if (props) {
-        r.bulkm = props[e]; r.shearm = props[(size_t)ne + e]; r.phi = props[(size_t)2*ne + e];
-        r.cp = props[(size_t)3*ne + e]; r.k = props[(size_t)4*ne + e];
-    } else {
+    if (!md.props) {                                       // nmat == 1: the means are the values (matprops.cxx:118, 136)
         r.bulkm = p->bulk_modulus[0]; r.shearm = p->shear_modulus[0]; r.phi = p->porosity[0];
         r.cp = p->heat_capacity[0]; r.k = p->therm_cond[0];
+    } else if (!mx.mk && mx.cnt < DES_PTAB_CNT) {
+        const double *t = md.ptab + ((size_t)mx.mat * DES_PTAB_CNT + mx.cnt) * 5;
+        r.bulkm = t[0]; r.shearm = t[1]; r.phi = t[2]; r.cp = t[3]; r.k = t[4];
+    } else {
+        r.bulkm = md.props[e]; r.shearm = md.props[(size_t)ne + e]; r.phi = md.props[(size_t)2*ne + e];
+        r.cp = md.props[(size_t)3*ne + e]; r.k = md.props[(size_t)4*ne + e];
     }
     return r;
 }
 
 // Young's-modulus "mass" of an element, only read by damping option 4 (geometry.cxx:1832)
-__device__ __forceinline__ double elem_ym(const des_params *p, const double *props, int ne, int e)
+__device__ __forceinline__ double elem_ym(const des_params *p, const MatData &md, int ne, int e)
 {
-    const double bulkm = props ? props[e] : p->bulk_modulus[0];
-    const double shearm = props ? props[(size_t)ne + e] : p->shear_modulus[0];
-    return 9 * bulkm * shearm / (3 * bulkm + shearm) / 4;
+    const ElemProps pr = load_props(p, md, mix_of(md, p->nmat, e), ne, e);
+    return 9 * pr.bulkm * pr.shearm / (3 * pr.bulkm + pr.shearm) / 4;
 }
 
-// refresh_elem_cache (matprops.cxx:259-303) for nmat > 1
+// refresh_elem_cache (matprops.cxx:259-303): mono[] for every element, props[] for nmat > 1
 __global__ void __launch_bounds__(DES_BLOCK)
-k_props(const des_params *p, const int *markers, double *props, int ne)
+k_props(const des_params *p, const int *markers, double *props, int *mono, int ne)
 {
     int e = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (e >= ne) return;
     const int nmat = p->nmat;
     const int *mk = markers + (size_t)e * nmat;
+    int used = 0, mat = 0, cnt = 0;
+    for (int m = 0; m < nmat; ++m) if (mk[m] != 0) { ++used; mat = m; cnt = mk[m]; }
+    mono[e] = (used == 1 && cnt > 0 && cnt < 65536) ? ((mat << 16) | cnt) : -1;
+    if (!props) return;
     props[e]                = desk::harmonic_mean(p->bulk_modulus, mk, nmat);
     props[(size_t)ne + e]   = desk::harmonic_mean(p->shear_modulus, mk, nmat);
     props[(size_t)2*ne + e] = desk::arithmetic_mean(p->porosity, mk, nmat);
     props[(size_t)3*ne + e] = desk::arithmetic_mean(p->heat_capacity, mk, nmat);
     props[(size_t)4*ne + e] = desk::arithmetic_mean(p->therm_cond, mk, nmat);
+}
+
+// the five means of a single-material element, by (material, marker count)
+__global__ void k_ptab(const des_params *p, double *ptab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nmat = p->nmat;
+    if (i >= nmat * DES_PTAB_CNT) return;
+    const int mat = i / DES_PTAB_CNT, cnt = i % DES_PTAB_CNT;
+    int mk[DES_MAX_MAT];
+    for (int m = 0; m < DES_MAX_MAT; ++m) mk[m] = 0;
+    mk[mat] = cnt > 0 ? cnt : 1;                           // row 0 is never read
+    double *t = ptab + (size_t)i * 5;
+    t[0] = desk::harmonic_mean(p->bulk_modulus, mk, nmat);
+    t[1] = desk::harmonic_mean(p->shear_modulus, mk, nmat);
+    t[2] = desk::arithmetic_mean(p->porosity, mk, nmat);
+    t[3] = desk::arithmetic_mean(p->heat_capacity, mk, nmat);
+    t[4] = desk::arithmetic_mean(p->therm_cond, mk, nmat);
 }
 
 // ---- E1 --------------------------------------------------------------------------
@@ -220,7 +267,7 @@ template <int MODE>
 __global__ void __launch_bounds__(DES_BLOCK, DES_E1_WAVES)
 E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int nblocks,
      const int4 *__restrict__ conn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
-     const int *__restrict__ markers, const double *__restrict__ props,
+     const MatData md,
      const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
@@ -238,15 +285,14 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         d4 c[4], v[4];
         c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
         v[0] = vm[cn.x]; v[1] = vm[cn.y]; v[2] = vm[cn.z]; v[3] = vm[cn.w];
-        const int nmat = p->nmat;
-        const int *mk = markers + (size_t)e * nmat;
-        const ElemProps pr = load_props(p, props, ne, e);
+        const desk::Mix mx = mix_of(md, p->nmat, e);
+        const ElemProps pr = load_props(p, md, mx, ne, e);
 
         // mean nodal temperature, matprops.cxx:338-343
         double T = 0;
         T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
         T /= 4;
-        const double rho = desk::mat_rho(p, mk, T);
+        const double rho = desk::mat_rho(p, mx, T);
 
         double vol;
         d4 rec;
@@ -459,7 +505,7 @@ template <int FULL, int CONSTM>
 __global__ void __launch_bounds__(DES_BLOCK)
 N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int o0, int nn, int nblocks, int npb,
      const int *__restrict__ sup_idx, const int *__restrict__ sup_pack, const unsigned *__restrict__ bcflag,
-     const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp, const double *__restrict__ props, int ne,
+     const d4 *__restrict__ mrec, const d4 *__restrict__ ttmp, const MatData md, int ne,
      d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ volume_n, double *__restrict__ tmass,
      double *__restrict__ ymass, double *__restrict__ ntmp)
 {
@@ -501,7 +547,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
                 const int e = pk >> 2;
                 rr[u] = mrec[e];
                 if (FULL && thermal) r3[u] = (&ttmp[e].x)[pk & 3];
-                else if (need_ym)    r3[u] = elem_ym(p, props, ne, e);
+                else if (need_ym)    r3[u] = elem_ym(p, md, ne, e);
             }
         }
     };
@@ -530,7 +576,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
             const int sl = lds_slot(j);
             lds[0][sl] = r.x; lds[1][sl] = r.z; lds[2][sl] = r.w;
             if (FULL && thermal) lds[3][sl] = (&ttmp[e].x)[pk & 3];
-            else if (need_ym)    lds[3][sl] = elem_ym(p, props, ne, e);
+            else if (need_ym)    lds[3][sl] = elem_ym(p, md, ne, e);
             if (!CONSTM) lds[NPL - 1][sl] = r.y;
         }
         __syncthreads();
@@ -555,7 +601,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     if (need_ym && FULL && thermal) {
         // damping option 4 together with thermal diffusion: the spare LDS plane is taken by
         // the conduction term, so the Young's-modulus mass is summed straight from memory
-        for (int k = r0; k < r1; ++k) yms += elem_ym(p, props, ne, sup_pack[k] >> 2);
+        for (int k = r0; k < r1; ++k) yms += elem_ym(p, md, ne, sup_pack[k] >> 2);
     }
     volume_n[n] = vn;
     tmass[n] = tms;
@@ -582,7 +628,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
 __global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
 E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
-     const double *__restrict__ ntmp, const int *__restrict__ markers, const double *__restrict__ props,
+     const double *__restrict__ ntmp, const MatData md,
      const double *__restrict__ volume, const double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
@@ -596,8 +642,8 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     const double dt = clk->dt;
     const int4 cn = conn[e];
     const int rheol = p->rheol_type;
-    const int *mk = markers + (size_t)e * p->nmat;
-    const ElemProps pr = load_props(p, props, ne, e);
+    const desk::Mix mx = mix_of(md, p->nmat, e);
+    const ElemProps pr = load_props(p, md, mx, ne, e);
 
     double dj = 0;
     dj += ntmp[cn.x]; dj += ntmp[cn.y]; dj += ntmp[cn.z]; dj += ntmp[cn.w];
@@ -625,7 +671,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         double T = 0;
         T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
         T /= 4;
-        visc = desk::mat_visc(p, vt, mk, T, s, edot);
+        visc = desk::mat_visc(p, vt, mx, T, s, edot);
         viscosity[e] = visc;
     }
 
@@ -644,7 +690,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     case DES_RH_EP: {
         double amc, anphi, anpsi, hardn, ten_max;
         double pls = plstrain[e];
-        desk::plastic_props(p, mk, pls, amc, anphi, anpsi, hardn, ten_max);
+        desk::plastic_props(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double depls = desk::elasto_plastic(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s);
         if (depls != 0) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
         dpl = depls;
@@ -658,7 +704,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         double svII = desk::second_invariant2(sv);
         double amc, anphi, anpsi, hardn, ten_max;
         double pls = plstrain[e];
-        desk::plastic_props(p, mk, pls, amc, anphi, anpsi, hardn, ten_max);
+        desk::plastic_props(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double sp[6];
         for (int i = 0; i < 6; ++i) sp[i] = s[i];
         double depls = desk::elasto_plastic(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp);
@@ -744,7 +790,7 @@ N2_nmd_gather(int o0, int nn, int nblocks, int npb, const int *__restrict__ sup_
 // Workgroups past the element range compute the stress-bc facet terms (bc_facet_work):
 // both only read the nodal records, and N3 consumes both.
 __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int4 *__restrict__ conn,
-                              const d4 *__restrict__ xt, const int *__restrict__ markers,
+                              const d4 *__restrict__ xt, const MatData &md,
                               const int *__restrict__ f_elem, const int *__restrict__ f_facet,
                               const int *__restrict__ f_kind, const double *__restrict__ f_val,
                               double *__restrict__ f_tmp);
@@ -752,15 +798,15 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 __global__ void __launch_bounds__(DES_BLOCK, DES_E3_WAVES)
 E3_nmd_force(const des_params *__restrict__ p, int ne, int e_begin, int e_count, int nblocks, int nblocks8,
      const int4 *__restrict__ conn,
-     const d4 *__restrict__ xt, const double *__restrict__ ntmp, const int *__restrict__ markers,
-     const double *__restrict__ props, const double *__restrict__ volume,
+     const d4 *__restrict__ xt, const double *__restrict__ ntmp, const MatData md,
+     const double *__restrict__ volume,
      const double *__restrict__ dpressure, double *__restrict__ stress, double *__restrict__ ftmp,
      int nbcf, const int *__restrict__ f_elem, const int *__restrict__ f_facet,
      const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp)
 {
     if ((int)blockIdx.x >= nblocks8) {                    // facet blocks (uniform per workgroup)
         const int g = ((int)blockIdx.x - nblocks8) * DES_BLOCK + threadIdx.x;
-        if (g < nbcf) bc_facet_work(p, g, conn, xt, markers, f_elem, f_facet, f_kind, f_val, f_tmp);
+        if (g < nbcf) bc_facet_work(p, g, conn, xt, md, f_elem, f_facet, f_kind, f_val, f_tmp);
         return;
     }
     __shared__ double stage[DES_BLOCK * 13];              // 12 doubles per element, row stride 13
@@ -790,8 +836,9 @@ E3_nmd_force(const des_params *__restrict__ p, int ne, int e_begin, int e_count,
             double T = 0;
             T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
             T /= 4;
-            const double rho = desk::mat_rho(p, markers + (size_t)e * p->nmat, T);
-            const double phi = props ? props[(size_t)2*ne + e] : p->porosity[0];
+            const desk::Mix mx = mix_of(md, p->nmat, e);
+            const double rho = desk::mat_rho(p, mx, T);
+            const double phi = load_props(p, md, mx, ne, e).phi;
             buoy = (rho * (1 - phi) + 1000.0 * phi) * p->gravity / 4;
         }
         double *out = stage + threadIdx.x * 13;
@@ -813,7 +860,7 @@ E3_nmd_force(const des_params *__restrict__ p, int ne, int e_begin, int e_count,
 // ---- stress-bc facets ------------------------------------------------------------
 // apply_stress_bcs facet loop (bc.cxx:707-777) and apply_stress_bcs_neumann (bc.cxx:846-905)
 __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int4 *__restrict__ conn,
-                              const d4 *__restrict__ xt, const int *__restrict__ markers,
+                              const d4 *__restrict__ xt, const MatData &md,
                               const int *__restrict__ f_elem, const int *__restrict__ f_facet,
                               const int *__restrict__ f_kind, const double *__restrict__ f_val,
                               double *__restrict__ f_tmp)
@@ -844,7 +891,7 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
         double T = 0;
         T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
         T /= 4;
-        double rho_effective = desk::mat_rho(p, markers + (size_t)e * p->nmat, T);
+        double rho_effective = desk::mat_rho(p, mix_of(md, p->nmat, e), T);
         pr = p->compensation_pressure -
              (rho_effective + p->winkler_delta_rho) * p->gravity * (zcenter + p->zlength);
     } else if (kind == 1) {
@@ -1392,13 +1439,13 @@ struct Launch {
     ~Launch() { if (on) { hipEventRecord(rec.b, h->stream); h->prof_recs.push_back(rec); } }
 };
 
+inline MatData mat_data(const des_dev *h) { return MatData{ h->markers, h->mono, h->props, h->ptab }; }
+
 void refresh_props(des_dev *h)
 {
     if (!h->markers_dirty) return;
-    if (h->props) {
-        Launch l(h, K_MISC);
-        hipLaunchKernelGGL(k_props, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->markers, h->props, h->ne);
-    }
+    Launch l(h, K_MISC);
+    hipLaunchKernelGGL(k_props, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->markers, h->props, h->mono, h->ne);
     h->markers_dirty = false;
 }
 
@@ -1408,7 +1455,7 @@ void launch_e1(des_dev *h)
     Launch l(h, K_E1);
     const int nb = nblk(h->ne);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(h->ne)), dim3(DES_BLOCK), 0, h->stream,
-                       h->d_p, h->d_clk, h->ne, nb, h->conn, h->xt, h->vm, h->markers, h->props, h->radiogenic,
+                       h->d_p, h->d_clk, h->ne, nb, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
                        h->topflag, h->stress, h->strain, h->plstrain, h->volume, h->volume_old, h->strain_rate,
                        h->mrec, h->ttmp, h->delta_plstrain, h->stress_avg, h->dplstrain_avg, h->strain0);
 }
@@ -1467,7 +1514,7 @@ void launch_mass_gather(des_dev *h)
 {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, 0, h->nn, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
-                       h->props, h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+                       mat_data(h), h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
 void launch_dt_finalize(des_dev *h, const double *red)
@@ -1488,11 +1535,11 @@ void launch_n1(des_dev *h)
     const int nbn = node_blocks(h);
     if (h->const_mass)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
-                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, mat_data(h),
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
-                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, h->props,
+                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, mat_data(h),
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
@@ -1502,7 +1549,7 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     if (e_count == 0) return;
     Launch l(h, K_E2);
     hipLaunchKernelGGL(E2_update_stress, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
-                       e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->volume_old, h->stress,
+                       e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                        h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                        h->etmp2);
 }
@@ -1526,7 +1573,7 @@ void launch_e3(des_dev *h, int e_begin = 0, int e_count = -1, bool facets = true
     Launch l(h, K_E3);
     hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->ne, e_begin, e_count,
                        nblk(e_count), nbe8,
-                       h->conn, h->xt, h->ntmp, h->markers, h->props, h->volume, h->dpressure, h->stress, h->ftmp,
+                       h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->dpressure, h->stress, h->ftmp,
                        facets ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
 }
 
@@ -1802,7 +1849,7 @@ void des_dev_destroy(des_dev *h)
         h->d_send_eoff, h->d_recv_noff, h->d_recv_eoff, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
-        h->radiogenic, h->markers, h->props, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
+        h->radiogenic, h->markers, h->props, h->mono, h->ptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
         h->conn_surf, h->ssup_idx, h->ssup_arr, h->topflag, h->dh, h->edvacc,
         h->znew, h->bnormals, h->edge_vec, h->edge_slot };
@@ -1903,7 +1950,12 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->plstrain, (size_t)ne)); CK(dev_alloc(h->delta_plstrain, (size_t)ne)); CK(dev_alloc(h->viscosity, (size_t)ne));
     CK(dev_alloc(h->volume, (size_t)ne)); CK(dev_alloc(h->volume_old, (size_t)ne)); CK(dev_alloc(h->dpressure, (size_t)ne));
     CK(dev_alloc(h->radiogenic, (size_t)ne)); CK(dev_alloc(h->markers, (size_t)ne * nmat));
-    if (nmat > 1) CK(dev_alloc(h->props, (size_t)5*ne));
+    CK(dev_alloc(h->mono, (size_t)ne));
+    if (nmat > 1) {
+        CK(dev_alloc(h->props, (size_t)5*ne));
+        CK(dev_alloc(h->ptab, (size_t)nmat * DES_PTAB_CNT * 5));
+        hipLaunchKernelGGL(k_ptab, dim3((nmat * DES_PTAB_CNT + 63) / 64), dim3(64), 0, h->stream, h->d_p, h->ptab);
+    }
     CK(dev_alloc(h->mrec, (size_t)ne)); CK(dev_alloc(h->ttmp, (size_t)ne)); CK(dev_alloc(h->etmp2, (size_t)ne));
     CK(dev_alloc(h->ftmp, (size_t)12*ne));
     if (h->p.is_outputting_averaged_fields) {

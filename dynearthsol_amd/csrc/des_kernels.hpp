@@ -108,16 +108,33 @@ __device__ __forceinline__ double arithmetic_mean(const double *s, const int *n,
     return result / m;
 }
 
+// The marker counts of one element as the property functions see them.  Most elements hold
+// markers of ONE material: for those the engine keeps (material, count) in a single int
+// (des_dev.hip: mono[]) instead of reading the nmat counts; count(m) then answers from registers.
+// The loops still run over every material with a wave-uniform m (so the material constants stay
+// scalar loads) and do exactly the reference's arithmetic.
+struct Mix {
+    const int *mk;          // [nmat] counts of a mixed element, or NULL
+    int mat, cnt;           // single-material element: its material and marker count
+    __device__ __forceinline__ int count(int m) const { return mk ? mk[m] : (m == mat ? cnt : 0); }
+};
+
 // matprops.cxx:642-664; T = mean nodal temperature of the element
-__device__ __forceinline__ double mat_rho(const des_params *p, const int *mk, double T)
+__device__ __forceinline__ double mat_rho(const des_params *p, const Mix &mx, double T)
 {
     const double celsius0 = 273;
     double TinCelsius = T - celsius0;
     double result = 0;
     int n = 0;
+    if (!mx.mk && p->nmat > 1) {
+        // single-material element: the other terms are x * 0 added to a positive sum
+        result += p->rho0[mx.mat] * (1 - p->alpha[mx.mat] * TinCelsius) * mx.cnt;
+        return result / mx.cnt;
+    }
     for (int m = 0; m < p->nmat; m++) {
-        result += p->rho0[m] * (1 - p->alpha[m] * TinCelsius) * mk[m];
-        n += mk[m];
+        const int k = mx.count(m);
+        result += p->rho0[m] * (1 - p->alpha[m] * TinCelsius) * k;
+        n += k;
     }
     return result / n;
 }
@@ -125,7 +142,7 @@ __device__ __forceinline__ double mat_rho(const des_params *p, const int *mk, do
 struct ViscTerms { double pow_edot[DES_MAX_MAT], coef_term[DES_MAX_MAT], nR[DES_MAX_MAT]; };
 
 // matprops.cxx:333-377
-__device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms *vt, const int *mk,
+__device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms *vt, const Mix &mx,
                                            double T, const double *s, const double *edot6)
 {
     const double min_strain_rate = 1e-30;
@@ -135,7 +152,7 @@ __device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms 
     double result = 0;
     int n = 0;
     for (int m = 0; m < p->nmat; m++) {
-        const int marker_count = mk[m];
+        const int marker_count = mx.count(m);
         if (marker_count == 0) continue;
         double visc0 = 0.25 * pow(edot, vt->pow_edot[m]) * vt->coef_term[m]
             * exp((p->visc_activation_energy[m] + p->visc_activation_volume[m] * s0)
@@ -149,14 +166,14 @@ __device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms 
 }
 
 // matprops.cxx:380-418 + 589-606
-__device__ __forceinline__ void plastic_props(const des_params *p, const int *mk, double pls,
+__device__ __forceinline__ void plastic_props(const des_params *p, const Mix &mx, double pls,
                                               double &amc, double &anphi, double &anpsi,
                                               double &hardn, double &ten_max)
 {
     double c = 0, f = 0, d = 0, h = 0;
     int n = 0;
     for (int m = 0; m < p->nmat; m++) {
-        int k = mk[m];
+        int k = mx.count(m);
         if (k == 0) continue;
         n += k;
         if (pls < p->pls0[m]) {
