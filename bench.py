@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--mesh-file", default=None,
                     help="take the mesh from a .desmesh file (e.g. the reference's TetGen mesh of test-3d-big.cfg at "
                          "resolution 460 m, 1,001,310 tets, written by oracle/_ref/tetmesh) instead of the regular mesher; N=1")
+    ap.add_argument("--workload", default="test-3d-big", choices=["test-3d-big", "test-3d-equ-long"],
+                    help="test-3d-big (default, the BASELINE config) or the reference's 984,375-tet seven-material "
+                         "regular-mesh benchmark benchmarks-cores/test-3d-equ-long.cfg (values restated in tests/cfgs.py); N=1")
     ap.add_argument("--averaged-fields", action="store_true",
                     help="also run Output::average_fields inside the step (sim.is_outputting_averaged_fields = yes)")
     ap.add_argument("--rheology", default="elasto-visco-plastic",
@@ -156,8 +159,15 @@ def main():
         assert world == 1, "--mesh-file is a single-GPU workload"
         overrides += "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n"
     note("building the host model")
-    host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)), overrides=overrides or None,
-                    mesh_file=args.mesh_file)
+    if args.workload == "test-3d-equ-long":
+        assert world == 1 and not args.mesh_file, "--workload test-3d-equ-long is a single-GPU workload"
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import cfgs
+        host = des.Host(cfg_text=cfgs.make_equ(long=True),
+                        overrides=(overrides or "") + "sim.max_steps = 1000000\nsim.output_step_interval = 1000000\n")
+    else:
+        host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)), overrides=overrides or None,
+                        mesh_file=args.mesh_file)
     device = int(os.environ.get("DES_BENCH_DEVICE", local_rank))
     transport = "RCCL ncclSend/ncclRecv on the engine stream"
     if world == 1:
@@ -241,7 +251,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "test-3d-big.cfg box 400x20x10 km, " + args.rheology + ", thermal+NMD+surface diffusion on, "
+            "workload": ("test-3d-equ-long.cfg box 250x50x125 km, 7 materials, " if args.workload == "test-3d-equ-long" else
+                         "test-3d-big.cfg box 400x20x10 km, ") + args.rheology + ", thermal+NMD+surface diffusion on, "
                         + ("averaged output fields on, " if args.averaged_fields else "")
                         + ("mesh file %s, " % os.path.basename(args.mesh_file) if args.mesh_file else "regular 5-tet mesh, ")
                         +

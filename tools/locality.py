@@ -47,3 +47,37 @@ for W in (2000., 3000., 5000.):
     print("slab W=%g: node-block mult %.2f ; elem-block node fetch %.2f" % (W, node_mult(no), elem_mult(eo, no)))
 no = np.argsort(morton3(xyz[0], xyz[1], xyz[2], 460.)); eo = np.argsort(morton3(cen[0], cen[1], cen[2], 460.))
 print("full morton: node-block mult %.2f ; elem-block node fetch %.2f" % (node_mult(no), elem_mult(eo, no)))
+
+
+def hilbert3(x, y, z, h, bits=10):
+    """Skilling's transposed-axes Hilbert index of the cells (floor(x/h), ...)"""
+    X = [np.floor(x / h).astype(np.int64), np.floor(y / h).astype(np.int64), np.floor(-z / h).astype(np.int64)]
+    M = 1 << (bits - 1)
+    Q = M
+    while Q > 1:
+        P = Q - 1
+        for i in range(3):
+            m = (X[i] & Q) != 0
+            X[0] = np.where(m, X[0] ^ P, X[0])
+            t = (X[0] ^ X[i]) & P
+            t = np.where(m, 0, t)
+            X[0] ^= t; X[i] ^= t
+        Q >>= 1
+    for i in range(1, 3):
+        X[i] ^= X[i - 1]
+    t = np.zeros_like(X[0])
+    Q = M
+    while Q > 1:
+        t = np.where((X[2] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    for i in range(3):
+        X[i] ^= t
+    r = np.zeros_like(X[0])
+    for b in range(bits - 1, -1, -1):
+        for i in range(3):
+            r = (r << 1) | ((X[i] >> b) & 1)
+    return r
+
+
+no = np.argsort(hilbert3(xyz[0], xyz[1], xyz[2], 460.), kind="stable"); eo = np.argsort(hilbert3(cen[0], cen[1], cen[2], 460.), kind="stable")
+print("hilbert: node-block mult %.2f ; elem-block node fetch %.2f" % (node_mult(no), elem_mult(eo, no)))
