@@ -10,6 +10,8 @@
 //
 // usage: tetmesh xlength ylength zlength resolution largest_size x0 x1 y0 y1 z0 z1 out.desmesh
 //        [max_ratio=2 min_tet_angle=22 optlevel=3]
+//        tetmesh --uniform xlength ylength zlength resolution out.desmesh      (meshing_option = 1:
+//        new_mesh_uniform_resolution, mesh.cxx:1461-1636: the box alone, one region, a<0.7 d^3>)
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -21,8 +23,48 @@
 
 static const int BOUNDX0 = 1, BOUNDX1 = 2, BOUNDY0 = 4, BOUNDY1 = 8, BOUNDZ0 = 16, BOUNDZ1 = 32;
 
+static int write_mesh(const tetgenio &out, const char *out_path);
+
+static int uniform(int argc, char **argv)
+{
+    if (argc < 7) { std::fprintf(stderr, "usage: see header\n"); return 2; }
+    const double Lx = atof(argv[2]), Ly = atof(argv[3]), Lz = atof(argv[4]), d = atof(argv[5]);
+    const int cx[8] = {0, 0, 1, 1, 0, 0, 1, 1}, cy[8] = {0, 0, 0, 0, 1, 1, 1, 1}, cz[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+    double points[8 * 3];
+    for (int c = 0; c < 8; ++c) { points[c*3] = cx[c] * Lx; points[c*3 + 1] = cy[c] * Ly; points[c*3 + 2] = -cz[c] * Lz; }
+    const int face[6][4] = {{0,1,5,4}, {0,3,2,1}, {1,2,6,5}, {3,7,6,2}, {7,4,5,6}, {0,4,7,3}};
+    int segflags[6] = {BOUNDX0, BOUNDY0, BOUNDZ0, BOUNDX1, BOUNDY1, BOUNDZ1};
+    int segments[6 * 4];
+    for (int f = 0; f < 6; ++f) for (int k = 0; k < 4; ++k) segments[f*4 + k] = face[f][k];
+    double regattr[5] = { 0.5*Lx, 0.5*Ly, -0.5*Lz, 0, -1 };
+    const double elem_size = 0.7 * d * d * d;
+    std::string options = "Q";
+    options += 'q'; options += std::to_string((long double)2.0);
+    options += "qq"; options += std::to_string((long double)22.0);
+    options += "qqq"; options += std::to_string((long double)(180 - 3 * 22.0));
+    options += 'a'; options += std::to_string((long double)elem_size);
+    options += "pzs3A";
+    std::fprintf(stderr, "tetgen switches: %s\n", options.c_str());
+    tetgenio in, out;
+    in.pointlist = points; in.numberofpoints = 8;
+    tetgenio::polygon polys[6]; tetgenio::facet fl[6];
+    for (int i = 0; i < 6; ++i) {
+        polys[i].vertexlist = &segments[i*4]; polys[i].numberofvertices = 4;
+        fl[i].polygonlist = &polys[i]; fl[i].numberofpolygons = 1; fl[i].holelist = NULL; fl[i].numberofholes = 0;
+    }
+    in.facetlist = fl; in.facetmarkerlist = segflags; in.numberoffacets = 6;
+    in.holelist = NULL; in.numberofholes = 0;
+    in.numberofregions = 1; in.regionlist = regattr;
+    std::vector<char> opt(options.begin(), options.end()); opt.push_back(0);
+    tetrahedralize(opt.data(), &in, &out, NULL, NULL);
+    in.pointlist = NULL; in.facetmarkerlist = NULL; in.facetlist = NULL; in.regionlist = NULL;
+    for (int i = 0; i < 6; ++i) { polys[i].vertexlist = NULL; fl[i].polygonlist = NULL; }
+    return write_mesh(out, argv[6]);
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !std::strcmp(argv[1], "--uniform")) return uniform(argc, argv);
     if (argc < 13) { std::fprintf(stderr, "usage: see header\n"); return 2; }
     const double Lx = atof(argv[1]), Ly = atof(argv[2]), Lz = atof(argv[3]), d = atof(argv[4]);
     const double largest_size = atof(argv[5]);
@@ -89,7 +131,11 @@ int main(int argc, char **argv)
     tetrahedralize(opt.data(), &in, &out, NULL, NULL);
     in.pointlist = NULL; in.facetmarkerlist = NULL; in.facetlist = NULL; in.regionlist = NULL;
     for (int i = 0; i < 12; ++i) { polys[i].vertexlist = NULL; fl[i].polygonlist = NULL; }
+    return write_mesh(out, out_path);
+}
 
+static int write_mesh(const tetgenio &out, const char *out_path)
+{
     const int nn = out.numberofpoints, ne = out.numberoftetrahedra, ns = out.numberoftrifaces;
     std::fprintf(stderr, "tetgen: %d nodes, %d tets, %d boundary/internal faces\n", nn, ne, ns);
     if (ne <= 0) return 40;

@@ -361,3 +361,64 @@ def make_equ(long=False):
     return EQU.format(stop="max_steps = 400\noutput_step_interval = 100", ckpt=1, ly="10e3", res="5e3", qcsi=5, mbd="1e-3",
                       sdiff="2e-5", pls1="[ 0.1, 0.1, 5, 5, 0.1, 5, 0.1 ]", fa0="[ 30, 30, 30, 30, 30, 30, 30 ]",
                       fa1="[ 10, 20, 30, 30, 15, 30, 5 ]")
+
+
+# Parameter values of the reference's examples/conjugate-faults-3d.cfg: the oblique-rift model with
+# plain extension, a uniform TetGen mesh (meshing_option = 1: tests/golden/conjugate-faults-3d.desmesh,
+# 4,313 nodes / 20,334 tets) and two conjugate weak zones (weakzone_option = 5).
+CONJUGATE = (OBLIQUE
+             .replace("max_time_in_yr = 0.1e6", "max_time_in_yr = 5e6")
+             .replace("""meshing_option = 2
+xlength = 200e3
+ylength = 100e3
+zlength = 50e3
+resolution = 5e3
+smallest_size = 0.01
+refined_zonex = [0.3, 0.7]
+refined_zoney = [0.3, 0.7]
+refined_zonez = [0.7, 1.0]
+quality_check_step_interval = 500
+remeshing_option = 11""", """meshing_option = 1
+xlength = 200e3
+ylength = 100e3
+zlength = 50e3
+resolution = 5e3
+quality_check_step_interval = 500
+remeshing_option = 1
+min_quality = 0
+smallest_size = 0.0
+max_boundary_distortion = 1e30""")
+             .replace("""vbc_x0 = 6
+vbc_x1 = 6
+vbc_val_x0 = -3.17e-10
+vbc_val_x1 = 3.17e-10
+vbc_val_x0_l = 1.59e-10
+vbc_val_x1_l = -1.59e-10""", """vbc_x0 = 1
+vbc_x1 = 1
+vbc_val_x0 = -3.17e-10
+vbc_val_x1 = 3.17e-10""")
+             .replace("""weakzone_option = 1
+weakzone_azimuth = 0
+weakzone_inclination = 60
+weakzone_halfwidth = 1.5
+weakzone_depth_min = 0.0
+weakzone_depth_max = 1.0
+weakzone_xcenter = 0.5
+weakzone_ycenter = 0.5
+weakzone_zcenter = 0.5
+weakzone_plstrain = 0.5""", """weakzone_option = 5
+weakzone_plstrain = 0.5
+weakzone_num_segments = 2
+weakzone_segments_xcenter = [0.35, 0.65]
+weakzone_segments_ycenter = [0.5,  0.5]
+weakzone_segments_zcenter = [0.5,  0.5]
+weakzone_segments_azimuth      = [0,   180]
+weakzone_segments_inclination  = [60,  60]
+weakzone_segments_halfwidth    = [1.5, 1.5]
+weakzone_segments_x_min = [0.0, 0.5]
+weakzone_segments_x_max = [0.5, 1.0]
+weakzone_segments_y_min     = [0.0, 0.0]
+weakzone_segments_y_max     = [1.0, 1.0]
+weakzone_segments_depth_min = [0.0, 0.0]
+weakzone_segments_depth_max = [1.0, 1.0]"""))
+assert "weakzone_option = 5" in CONJUGATE and "meshing_option = 1" in CONJUGATE and "vbc_x0 = 1" in CONJUGATE
