@@ -108,3 +108,28 @@ def test_distributed_run_with_one_rank_equals_the_plain_run(in_tmp):
         for name in a:
             if name != "walltime_sec":
                 assert np.array_equal(a[name], b[name]), (frame, name)
+
+
+def test_reference_tiny_3d_benchmark_through_the_executable(in_tmp):
+    """benchmarks-cores/test-3d-tiny.cfg (= test-3d.cfg with 4 steps, a frame every step, a
+    quality check every 2nd) on the reference's TetGen mesh, through `dynearthsol3d-hip cfg --mesh`:
+    every frame and checkpoint equals the oracle loop's to the bit."""
+    mesh = os.path.join(des.REPO_ROOT, "tests", "golden", "test-3d.desmesh")
+    tiny = ("sim.max_steps = 4\nsim.output_step_interval = 1\nsim.checkpoint_frame_interval = 2\n"
+            "mesh.quality_check_step_interval = 2\n")
+    text = cfgs.apply_overrides(cfgs.TEST3D, tiny + "sim.modelname = gpu\n")
+    text = "\n".join(l for l in text.splitlines() if not l.startswith(("max_time_in_yr", "output_time_interval_in_yr")))
+    open("tiny.cfg", "w").write(text + "\n")
+    out = subprocess.run([EXE, "tiny.cfg", "--mesh", mesh], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    host = des.Host(cfg_path="tiny.cfg", overrides="sim.modelname = cpu\n", mesh_file=mesh)
+    assert (host.nnode, host.nelem) == (3018, 13850)
+    st = driver.run(host, api=oracle_api())
+    assert (st.steps, st.frames) == (4, 5)
+    names = sorted(f for f in os.listdir(in_tmp) if f.startswith("gpu.") and not f.endswith(".info"))
+    assert names == ["gpu.chkpt.%06d" % i for i in (0, 2, 4)] + ["gpu.save.%06d" % i for i in range(5)]
+    for name in names:
+        a, b = read_frame(name), read_frame(name.replace("gpu.", "cpu."))
+        for k in a:
+            if k != "walltime_sec":
+                assert np.array_equal(a[k], b[k]), (name, k)
