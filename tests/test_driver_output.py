@@ -292,3 +292,22 @@ def test_reference_vtk_converter_accepts_our_frames(in_tmp):
     assert [f for f in made if f.endswith(".vtu")] == ["result.%06d.vtu" % i for i in range(3)], (made, out.stdout)
     assert any(f.endswith(".vtp") for f in made)
     assert os.path.getsize("result.000002.vtu") > 10000
+
+
+def test_loop_stops_where_the_reference_would_remesh(in_tmp):
+    """benchmarks-cores/test-3d-remesh.cfg: max_boundary_distortion = 0.00039 makes bad_mesh_quality
+    report a displaced bottom node (code 2) at the first quality check, step 300, where the
+    reference calls remesh().  The loop leaves a frame and a checkpoint of that state and stops
+    with exit category 31 (remeshing is host work that is not offloaded)."""
+    mesh = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test-3d.desmesh")
+    text = "\n".join(l for l in cfgs.TEST3D.splitlines()
+                     if not l.startswith(("max_time_in_yr", "output_time_interval_in_yr")))
+    ov = ("sim.max_steps = 400\nmesh.quality_check_step_interval = 300\nmesh.max_boundary_distortion = 0.00039\n"
+          "sim.modelname = remesh\n")
+    host = des.Host(cfg_text=text, overrides=ov, mesh_file=mesh)
+    st = driver.run(host, api=oracle_api())
+    assert (st.steps, st.remesh_needed, st.exit_code) == (300, 2, 31)
+    # frame 3 is the regular one of step 300; frame 4 + its checkpoint hold the state to remesh
+    assert os.path.exists("remesh.save.000004") and os.path.exists("remesh.chkpt.000004")
+    info = np.loadtxt("remesh.info").reshape(-1, 8)
+    assert info[:, 1].tolist() == [0, 100, 200, 300, 300]
