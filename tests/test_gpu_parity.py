@@ -265,3 +265,45 @@ def test_averaged_output_fields_bit_exact(splits):
         sd, so = dev.step(n), ora.step(n)
         assert sd.avg_time0 == so.avg_time0
     assert_bit_exact(dev, ora, STATE + AVG_FIELDS)
+
+
+def _random_overrides(rng):
+    """A random but valid combination of the options the step depends on."""
+    pick = lambda *a: a[rng.integers(len(a))]
+    ov = []
+    ov.append("control.damping_option = %d\n" % pick(0, 1, 2, 3, 4))
+    ov.append("control.has_thermal_diffusion = %s\n" % pick("yes", "no"))
+    ov.append("control.is_using_mixed_stress = %s\n" % pick("yes", "no"))
+    ov.append("control.surface_process_option = %d\n" % pick(0, 1))
+    ov.append("control.gravity = %s\n" % pick("10", "9.81", "0"))
+    quasi = pick(True, True, False)
+    ov.append("control.is_quasi_static = %s\n" % ("yes" if quasi else "no"))
+    ov.append("control.fixed_dt = %s\n" % ("0" if quasi and pick(True, False) else ("1e7" if quasi else "1e-2")))
+    bottom = pick("winkler", "fixed", "elastic")
+    if bottom == "fixed":
+        ov.append("bc.has_winkler_foundation = no\nbc.vbc_z0 = 1\n")
+    elif bottom == "elastic":
+        ov.append("bc.has_elastic_foundation = yes\nbc.elastic_foundation_constant = 1e6\n")
+    if pick(True, False):
+        ov.append("bc.has_water_loading = yes\ncontrol.surf_base_level = 1e3\n")
+    ov.append("bc.vbc_x0 = %d\nbc.vbc_x1 = %d\n" % (pick(1, 3), pick(1, 3)))
+    ov.append("bc.vbc_y0 = %d\nbc.vbc_y1 = %d\n" % (pick(0, 1, 2, 5), pick(0, 1, 2, 7)))
+    if pick(True, False, False):
+        ov.append("bc.stress_bc_z1 = 3\nbc.stress_val_z1 = 1e6\n")
+    return "".join(ov)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_option_combinations_bit_exact(seed):
+    """Options interact (e.g. damping x quasi-static mass, thermal x surface bc, NMD x foundation):
+    seeded random combinations on top of the one-at-a-time matrix, elasto-plastic below yield and
+    elastic, one or two materials -- no transcendental on the path, so bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    ov = _random_overrides(rng)
+    kw = dict(cfgs.EVP, rheol=["elasto-plastic", "elastic"][seed % 2], nmat=1 + seed % 3 % 2)
+    host, dev, ora = pair(kw, overrides=ov)
+    dev.step(11); ora.step(11)
+    assert ora.check_nan() == 0, ov
+    for f in STATE:
+        a, b = dev.download(f), ora.download(f)
+        assert np.array_equal(a, b), "%s with\\n%s" % (f, ov)
