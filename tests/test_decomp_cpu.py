@@ -95,6 +95,33 @@ def test_decomposed_oracle_is_bit_identical_to_one_rank(name, kw, nranks):
     assert all(e.step(0).dt == ref.step(0).dt for e in engines)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_decomposed_oracle_random_option_combinations(seed):
+    from test_gpu_parity import _random_overrides
+    ov = _random_overrides(np.random.default_rng(3000 + seed))
+    kw = dict(cfgs.EVP, rheol=["elasto-plastic", "elasto-visco-plastic"][seed % 2], nmat=1 + seed % 3 % 2, lx=60e3)
+    host = des.Host(cfg_text=cfgs.make(**kw), overrides=ov)
+    nranks = 2 + seed % 3
+    parts = [Partition(host, nranks, r) for r in range(nranks)]
+    ref = OracleEngine(host)
+    dt_ref = ref.init_from_host(host)
+    engines = [OracleEngine(_LocalMeshHost(p)) for p in parts]
+    steppers = [PhasedStepper(e, p, None) for e, p in zip(engines, parts)]
+    comm = LoopbackComm(steppers)
+
+    class _C:
+        def reduce_dt(self, engine, recompute): return None
+    for e, p in zip(engines, parts):
+        init_rank(e, p, _C())
+    assert all(d == dt_ref for d in comm.reduce_dt_all(recompute=True))
+    ref.step(15)
+    run_loopback(steppers, 15)
+    for f, c in NODE_FIELDS:
+        assert np.array_equal(assemble(parts, [e.download(f) for e in engines], c, host.nnode, "node"), ref.download(f)), (f, ov)
+    for f, c in ELEM_FIELDS:
+        assert np.array_equal(assemble(parts, [e.download(f) for e in engines], c, host.nelem, "elem"), ref.download(f)), (f, ov)
+
+
 def _gloo_worker(rank, world, port, nsteps, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -55,6 +55,17 @@ def test_decomposed_engines_match_one_engine_bit_for_bit(name, kw, nranks, overr
         assert (sc.dt, sc.time, sc.steps) == (sref.dt, sref.time, sref.steps)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_decomposed_random_option_combinations(seed):
+    """The ghost-region scheme under random option combinations (test_gpu_parity._random_overrides):
+    2-4 ranks on one GPU against one engine, bit for bit."""
+    from test_gpu_parity import _random_overrides
+    rng = np.random.default_rng(2000 + seed)
+    ov = _random_overrides(rng)
+    kw = dict(cfgs.EVP, rheol=["elasto-plastic", "elastic"][seed % 2], nmat=1 + seed % 3 % 2, lx=60e3)
+    test_decomposed_engines_match_one_engine_bit_for_bit("random%d" % seed, kw, 2 + seed % 3, ov)
+
+
 def test_single_rank_communicator_is_a_no_op():
     """des_dev_step with a 1-rank RCCL communicator attached (the N=1 case of the multi-GPU
     bench) gives the same bits as without."""
