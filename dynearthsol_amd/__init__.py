@@ -97,8 +97,31 @@ def load_hip_lib():
         lib.des_dev_algorithmic_bytes_per_step.restype = C.c_double
         lib.des_dev_algorithmic_bytes_per_step.argtypes = [C.c_void_p]
         lib.des_dev_last_error.restype = C.c_char_p
+        dp = C.POINTER(C.c_double)
+        lib.des_dev_libm_eval.argtypes = [C.c_int, C.c_int, C.c_longlong, dp, dp, dp]
         _hip_lib = lib
     return _hip_lib
+
+
+LIBM_FN = {"pow": 0, "exp": 1, "sin": 2, "cos": 3, "tan": 4, "atan2": 5}       # DES_LIBM_* (des_dev.h)
+
+
+def libm_eval(fn, x, y=None, device=0):
+    """One function of the portable libm (csrc/des_libm.hpp) evaluated on the GPU."""
+    import numpy as np
+    lib = load_hip_lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        assert y.shape == x.shape
+        yp = y.ctypes.data_as(dp)
+    rc = lib.des_dev_libm_eval(device, LIBM_FN[fn], x.size, x.ctypes.data_as(dp), yp, out.ctypes.data_as(dp))
+    if rc:
+        raise DesError(rc, lib.des_dev_last_error().decode())
+    return out
 
 
 class Host:

@@ -95,6 +95,7 @@ struct ProfRec { int k; hipEvent_t a, b; };
 
 struct des_dev {
     int device;
+    int portable_libm;       // DES_LIBM=portable: des_libm.hpp instead of ocml in the stress update
     des_params p;
     int nn, ne, nmat;
     hipStream_t stream;
@@ -625,6 +626,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
 // ---- E2 --------------------------------------------------------------------------
 // compute_edvoldt (geometry.cxx:264-272), update_stress (rheology.cxx:728-1026),
 // NMD_stress element part (geometry.cxx:294-296)
+template <class M>
 __global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
 E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
@@ -671,7 +673,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         double T = 0;
         T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
         T /= 4;
-        visc = desk::mat_visc(p, vt, mx, T, s, edot);
+        visc = desk::mat_visc<M>(p, vt, mx, T, s, edot);
         viscosity[e] = visc;
     }
 
@@ -690,8 +692,8 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     case DES_RH_EP: {
         double amc, anphi, anpsi, hardn, ten_max;
         double pls = plstrain[e];
-        desk::plastic_props(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
-        double depls = desk::elasto_plastic(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s);
+        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
+        double depls = desk::elasto_plastic<M>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s);
         if (depls != 0) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
         dpl = depls;
         break;
@@ -704,10 +706,10 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         double svII = desk::second_invariant2(sv);
         double amc, anphi, anpsi, hardn, ten_max;
         double pls = plstrain[e];
-        desk::plastic_props(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
+        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double sp[6];
         for (int i = 0; i < 6; ++i) sp[i] = s[i];
-        double depls = desk::elasto_plastic(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp);
+        double depls = desk::elasto_plastic<M>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp);
         double spII = desk::second_invariant2(sp);
         if (svII < spII) {
             for (int i = 0; i < 6; ++i) s[i] = sv[i];
@@ -1357,6 +1359,25 @@ __global__ void k_dhacc_reset(int ntop, const int *__restrict__ top_nodes, doubl
 }
 
 // check_nan (utils.hpp:323-394)
+// des_dev_libm_eval: one portable-libm function over an array (diagnostic entry)
+__global__ void k_libm_eval(int fn, long long n, const double *__restrict__ x, const double *__restrict__ y,
+                            double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i], b = y ? y[i] : 0.0;
+    double r;
+    switch (fn) {
+    case DES_LIBM_POW:   r = deslibm::pow(a, b); break;
+    case DES_LIBM_EXP:   r = deslibm::exp(a); break;
+    case DES_LIBM_SIN:   r = deslibm::sin(a); break;
+    case DES_LIBM_COS:   r = deslibm::cos(a); break;
+    case DES_LIBM_TAN:   r = deslibm::tan(a); break;
+    default:             r = deslibm::atan2(a, b); break;
+    }
+    out[i] = r;
+}
+
 __global__ void k_count_nan(const double *a, long long n, unsigned long long *count)
 {
     long long i = (long long)blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -1548,7 +1569,8 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     if (e_count < 0) e_count = h->ne;
     if (e_count == 0) return;
     Launch l(h, K_E2);
-    hipLaunchKernelGGL(E2_update_stress, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+    auto k = h->portable_libm ? E2_update_stress<desk::MathPortable> : E2_update_stress<desk::MathOcml>;
+    hipLaunchKernelGGL(k, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                        e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                        h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                        h->etmp2);
@@ -1878,6 +1900,13 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     des_dev *h = new des_dev();       // value-initialised: every pointer/scalar member starts at 0
     h->device = device;
     h->p = *params;
+    {
+        const char *env = std::getenv("DES_LIBM");
+        h->portable_libm = env && std::strcmp(env, "portable") == 0;
+        if (env && !h->portable_libm && std::strcmp(env, "ocml") != 0) {
+            *err = DES_ERR_CONFIG_VALUE; g_last_error = "DES_LIBM must be 'ocml' or 'portable'"; delete h; return nullptr;
+        }
+    }
     PermMesh pm;
     {
         const char *env = std::getenv("DES_REORDER");
@@ -2529,6 +2558,26 @@ int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt)
     if (rc) return rc;
     if (dt) *dt = h->h_clk->dt;
     return h->h_clk->status;
+}
+
+int des_dev_libm_eval(int device, int fn, long long n, const double *x, const double *y, double *out)
+{
+    if (fn < DES_LIBM_POW || fn > DES_LIBM_ATAN2 || n < 0 || !x || !out) return DES_ERR_INTERNAL;
+    if ((fn == DES_LIBM_POW || fn == DES_LIBM_ATAN2) && !y) return DES_ERR_INTERNAL;
+    if (des_dev_device_count() <= device) { g_last_error = "no such HIP device"; return DES_ERR_UNSUPPORTED; }
+    if (n == 0) return DES_OK;
+    HIP_OK(hipSetDevice(device));
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    int rc = DES_OK;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == DES_OK) { rc = DES_ERR_RESOURCE; g_last_error = hipGetErrorString(e); } return e == hipSuccess; };
+    if (ok(hipMalloc((void **)&dx, n * 8)) && ok(hipMalloc((void **)&dout, n * 8)) && (!y || ok(hipMalloc((void **)&dy, n * 8)))
+        && ok(hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice)) && (!y || ok(hipMemcpy(dy, y, n * 8, hipMemcpyHostToDevice)))) {
+        hipLaunchKernelGGL(k_libm_eval, dim3((unsigned)((n + DES_BLOCK - 1) / DES_BLOCK)), dim3(DES_BLOCK), 0, 0, fn, n, dx, dy, dout);
+        ok(hipGetLastError());
+        ok(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+    }
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    return rc;
 }
 
 int des_dev_check_nan(des_dev *h, long long *n_nan)

@@ -9,6 +9,7 @@
 #include <float.h>
 
 #include "des_params.h"
+#include "des_libm.hpp"
 
 #define DES_BLOCK 256
 
@@ -139,9 +140,29 @@ __device__ __forceinline__ double mat_rho(const des_params *p, const Mix &mx, do
     return result / n;
 }
 
+// The six libm functions of the stress update, as a policy: ROCm's ocml (default) or the
+// portable set of des_libm.hpp, which a CPU build reproduces to the bit (DES_LIBM=portable).
+struct MathOcml {
+    static __device__ __forceinline__ double pow(double a, double b) { return ::pow(a, b); }
+    static __device__ __forceinline__ double exp(double a) { return ::exp(a); }
+    static __device__ __forceinline__ double sin(double a) { return ::sin(a); }
+    static __device__ __forceinline__ double cos(double a) { return ::cos(a); }
+    static __device__ __forceinline__ void sincos(double a, double *s, double *c) { ::sincos(a, s, c); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+};
+struct MathPortable {
+    static __device__ __forceinline__ double pow(double a, double b) { return deslibm::pow(a, b); }
+    static __device__ __forceinline__ double exp(double a) { return deslibm::exp(a); }
+    static __device__ __forceinline__ double sin(double a) { return deslibm::sin(a); }
+    static __device__ __forceinline__ double cos(double a) { return deslibm::cos(a); }
+    static __device__ __forceinline__ void sincos(double a, double *s, double *c) { deslibm::sincos(a, s, c); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return deslibm::atan2(y, x); }
+};
+
 struct ViscTerms { double pow_edot[DES_MAX_MAT], coef_term[DES_MAX_MAT], nR[DES_MAX_MAT]; };
 
 // matprops.cxx:333-377
+template <class M>
 __device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms *vt, const Mix &mx,
                                            double T, const double *s, const double *edot6)
 {
@@ -154,8 +175,8 @@ __device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms 
     for (int m = 0; m < p->nmat; m++) {
         const int marker_count = mx.count(m);
         if (marker_count == 0) continue;
-        double visc0 = 0.25 * pow(edot, vt->pow_edot[m]) * vt->coef_term[m]
-            * exp((p->visc_activation_energy[m] + p->visc_activation_volume[m] * s0)
+        double visc0 = 0.25 * M::pow(edot, vt->pow_edot[m]) * vt->coef_term[m]
+            * M::exp((p->visc_activation_energy[m] + p->visc_activation_volume[m] * s0)
                   / (vt->nR[m] * T)) * 1e6;
         result += marker_count / visc0;
         n += marker_count;
@@ -166,6 +187,7 @@ __device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms 
 }
 
 // matprops.cxx:380-418 + 589-606
+template <class M>
 __device__ __forceinline__ void plastic_props(const des_params *p, const Mix &mx, double pls,
                                               double &amc, double &anphi, double &anpsi,
                                               double &hardn, double &ten_max)
@@ -201,8 +223,8 @@ __device__ __forceinline__ void plastic_props(const des_params *p, const Mix &mx
     // one argument reduction for sin(phi) and tan(phi) = sin/cos (tan only enters the tension
     // cut-off); sin(0) is exactly 0, so the usual zero dilation angle needs no call at all
     double sphi, cphi;
-    sincos(phi * DEG2RAD, &sphi, &cphi);
-    double spsi = (psi == 0) ? 0.0 : sin(psi * DEG2RAD);
+    M::sincos(phi * DEG2RAD, &sphi, &cphi);
+    double spsi = (psi == 0) ? 0.0 : M::sin(psi * DEG2RAD);
     anphi = (1 + sphi) / (1 - sphi);
     anpsi = (1 + spsi) / (1 - spsi);
     amc = 2 * cohesion * sqrt(anphi);
@@ -217,6 +239,7 @@ __device__ __forceinline__ void plastic_props(const des_params *p, const Mix &mx
 __device__ __forceinline__ double sqr(double x) { return x * x; }
 
 // 3x3-C/dsyevc3.c:31-80.  a = {A00, A11, A22, A01, A02, A12}
+template <class M>
 __device__ __forceinline__ void dsyevc3(const double *a, double w[3])
 {
     const double sqrt3 = 1.73205080756887729352744634151;
@@ -234,10 +257,10 @@ __device__ __forceinline__ void dsyevc3(const double *a, double w[3])
     double sqrt_p = sqrt(fabs(p));
 
     double phi = 27.0 * (0.25*sqr(c1)*(p - c1) + c0*(q + 27.0/4.0*c0));
-    phi = (1.0/3.0) * atan2(sqrt(fabs(phi)), q);
+    phi = (1.0/3.0) * M::atan2(sqrt(fabs(phi)), q);
 
-    double c = sqrt_p*cos(phi);
-    double s = (1.0/sqrt3)*sqrt_p*sin(phi);
+    double c = sqrt_p*M::cos(phi);
+    double s = (1.0/sqrt3)*sqrt_p*M::sin(phi);
 
     w[1]  = (1.0/3.0)*(m - c);
     w[2]  = w[1] + s;
@@ -343,10 +366,11 @@ __device__ __noinline__ int dsyevq3(const double *a, double Q[3][3], double w[3]
 }
 
 // 3x3-C/dsyevh3.c:112-215
+template <class M>
 __device__ __forceinline__ void dsyevh3(const double *a, double Q[3][3], double w[3])
 {
     const double A00 = a[0], A11 = a[1], A01 = a[3], A02 = a[4], A12 = a[5];
-    dsyevc3(a, w);
+    dsyevc3<M>(a, w);
 
     double t = fabs(w[0]), u;
     if ((u = fabs(w[1])) > t) t = u;
@@ -387,16 +411,18 @@ __device__ __forceinline__ void dsyevh3(const double *a, double Q[3][3], double 
     for (int r_ = 0; r_ < 3; ++r_) { double b_ = v[r_][i]; v[r_][i] = v[r_][j]; v[r_][j] = b_; } }
 
 // rheology.cxx:63-71
+template <class M>
 __device__ __forceinline__ void principal_values3(const double *s, double p[3])
 {
-    dsyevc3(s, p);
+    dsyevc3<M>(s, p);
     DES_SWAP_P(0, 1) DES_SWAP_P(1, 2) DES_SWAP_P(0, 1)
 }
 
 // rheology.cxx:76-84
+template <class M>
 __device__ __forceinline__ void principal_stresses3(const double *s, double p[3], double v[3][3])
 {
-    dsyevh3(s, v, p);
+    dsyevh3<M>(s, v, p);
     DES_SWAP_PV(0, 1) DES_SWAP_PV(1, 2) DES_SWAP_PV(0, 1)
 }
 
@@ -439,13 +465,14 @@ __device__ __forceinline__ void viscous(double bulkm, double viscosity, double t
 // that array -- the stress every element works on -- into scratch memory for all elements.
 struct Stress7 { double s0, s1, s2, s3, s4, s5, depls; };
 
+template <class M>
 __device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm, double amc, double anphi,
                                                     double anpsi, double hardn, double ten_max, Stress7 io)
 {
     double s[6] = {io.s0, io.s1, io.s2, io.s3, io.s4, io.s5};
     io.depls = 0;
     double p[3], v[3][3];
-    principal_stresses3(s, p, v);
+    principal_stresses3<M>(s, p, v);
 
     double fs = p[0] - p[2] * anphi + amc;
     double ft = p[2] - ten_max;
@@ -484,6 +511,7 @@ __device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm,
 }
 
 // rheology.cxx:312-484 (THREED)
+template <class M>
 __device__ __forceinline__ double elasto_plastic(double bulkm, double shearm, double amc, double anphi,
                                                  double anpsi, double hardn, double ten_max,
                                                  const double *de, double *s)
@@ -511,13 +539,13 @@ __device__ __forceinline__ double elasto_plastic(double bulkm, double shearm, do
     }
     {
         double pf[3];
-        principal_values3(s, pf);
+        principal_values3<M>(s, pf);
         const double band = YIELD_PREFILTER_MARGIN * (fabs(pf[0]) + anphi * fabs(pf[2]) + fabs(amc));
         if (pf[0] - pf[2] * anphi + amc > band && pf[2] - ten_max < -band)
             return 0;
     }
     Stress7 io = {s[0], s[1], s[2], s[3], s[4], s[5], 0.0};
-    io = mohr_coulomb_return(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, io);
+    io = mohr_coulomb_return<M>(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, io);
     s[0] = io.s0; s[1] = io.s1; s[2] = io.s2; s[3] = io.s3; s[4] = io.s4; s[5] = io.s5;
     return io.depls;
 }

@@ -1,0 +1,252 @@
+// Portable libm for the stress update: pow, exp, sin, cos, tan, atan2 written in IEEE-754
+// double operations only (+, -, *, /, fma, integer bit moves, table look-ups), so that the
+// SAME source gives the SAME bits on gfx950 and on a CPU (both sides are compiled with
+// -ffp-contract=off; every fma below is explicit).
+//
+// Why it exists: the reference calls std::pow / std::exp / std::sin / std::tan (rheology.cxx:
+// 260-300 creep viscosity, 330-420 plastic_props) and the Kopp solver calls atan2 / cos / sin
+// (3x3-C/dsyevc3.c:60-70); glibc and ROCm's ocml round those differently in the last 1-2 ulp,
+// which is the ONLY source of device-vs-CPU differences on the path.  With
+// DES_LIBM=portable the engine uses these functions, the CPU checker can be switched to the
+// same ones, and the two agree to the bit for every rheology.  The default stays ocml.
+//
+// Accuracy (tools/libm_accuracy.cpp against long double / tests/test_libm.py against mpmath):
+// pow, exp <= 0.53 ulp; sin, cos <= 0.8 ulp for |x| <= 1e5; tan = sin/cos <= 2 ulp;
+// atan2 <= 1.5 ulp.  Domain notes: pow() is defined here for x >= 0 only (x < 0 gives NaN; the
+// path raises a strain-rate invariant or a material constant); sin/cos use a three-term
+// Cody-Waite reduction that is exact for |x| < 2^20*pi/2 and lose accuracy (never determinism)
+// beyond.
+//
+// The method for pow/exp is the usual table-driven one (Tang 1989/1990; the structure with an
+// exact r = fma(z, 1/c, -1) follows the published design of the ARM optimized routines):
+// tables and coefficients are our own, from tools/gen_libm_tables.py.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DES_LIBM_FN static __device__ __forceinline__
+#define DES_LIBM_TAB static __device__ const
+#else
+#define DES_LIBM_FN static inline
+#define DES_LIBM_TAB static const
+#endif
+
+#include "des_libm_tables.hpp"
+
+namespace deslibm {
+
+DES_LIBM_FN uint64_t bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
+DES_LIBM_FN double   dbl(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
+DES_LIBM_FN double   fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// s = fl(a + b), *e = (a + b) - s exactly (Knuth; no ordering assumption)
+DES_LIBM_FN double two_sum(double a, double b, double *e)
+{
+    const double s = a + b;
+    const double bb = s - a;
+    *e = (a - (s - bb)) + (b - bb);
+    return s;
+}
+
+// round-to-nearest integer of |t| < 2^51 by the shift trick; *ki = bits of the shifted value
+// (its low 52 bits hold 2^51 + n)
+DES_LIBM_FN double round_shift(double t, uint64_t *ki)
+{
+    const double shift = 6755399441055744.0;              // 1.5 * 2^52
+    double kd = t + shift;
+    *ki = bits(kd);
+    return kd - shift;
+}
+
+// ---- exp ------------------------------------------------------------------------------
+// exp(x + xtail), |xtail| << |x|.  x = k ln2/128 + r; result = 2^(k/128) (1 + tail + r + r^2 P(r)).
+DES_LIBM_FN double exp_core(double x, double xtail)
+{
+    const uint64_t ax = bits(x) & 0x7fffffffffffffffULL;
+    if (ax >= 0x4086000000000000ULL) {               // |x| >= 704 (or inf / nan)
+        if (ax > 0x7ff0000000000000ULL) return x + x;
+        if (x > 709.782712893384) return __builtin_inf();
+        if (x < -745.2) return 0.0;
+    }
+    if (ax < 0x3c90000000000000ULL)                 // |x| < 2^-54
+        return 1.0 + x;
+    uint64_t ki;
+    double kd = round_shift(des_exp_invln2N * x, &ki);
+    double r = fma_(kd, -des_exp_ln2hiN, x);          // exact: ln2hiN has 42 bits, |k| < 2^18
+    r = fma_(kd, -des_exp_ln2loN, r) + xtail;
+    const int64_t n = (int64_t)(ki & 0xfffffffffffffULL) - ((int64_t)1 << 51);
+    const int j = (int)(n & 127);
+    const int64_t k = n >> 7;                                  // floor(n / 128)
+    const double r2 = r * r;
+    const double tmp = des_exp_tail[j] + r + r2 * (des_exp_C[0] + r * des_exp_C[1]) + r2 * r2 * (des_exp_C[2] + r * des_exp_C[3]);
+    const double hi = des_exp_hi[j];
+    if (k > 1000 || k < -1000) {
+        // scale in two steps: 2^k overflows / underflows a double's exponent field on its own
+        const int64_t k1 = k > 0 ? k - 900 : k + 900;
+        const double s1 = dbl(bits(hi) + ((uint64_t)k1 << 52));
+        const double s2 = dbl((uint64_t)(1023 + (k - k1)) << 52);
+        return (s1 + s1 * tmp) * s2;
+    }
+    const double scale = dbl(bits(hi) + ((uint64_t)k << 52));
+    return scale + scale * tmp;
+}
+
+DES_LIBM_FN double exp(double x) { return exp_core(x, 0.0); }
+
+// ---- pow ------------------------------------------------------------------------------
+// log(x) for finite x > 0 as hi + lo with ~2^-68 relative error.
+DES_LIBM_FN double log_dd(uint64_t ix, int64_t kadj, double *lo_out)
+{
+    const uint64_t OFF = 0x3fe6955500000000ULL;
+    const uint64_t tmp = ix - OFF;
+    const int i = (int)((tmp >> 45) & 127);
+    const int64_t k = ((int64_t)tmp >> 52) + kadj;
+    const double z = dbl(ix - (tmp & 0xfff0000000000000ULL));
+    const double kd = (double)k;
+    const double r = fma_(z, des_log_invc[i], -1.0);          // exact (see the generator)
+    // k ln2 + log c + r - r^2/2, every partial sum kept with its rounding error
+    double e1, e2, e3;
+    const double t1 = two_sum(kd * des_ln2hi, des_log_chi[i], &e1);   // kd*ln2hi is exact (42 + 11 bits)
+    const double t2 = two_sum(t1, r, &e2);
+    const double ar = -0.5 * r;
+    const double ar2 = r * ar;
+    const double e4 = fma_(ar, r, -ar2);                      // exact error of ar2
+    const double hi = two_sum(t2, ar2, &e3);
+    const double r2 = r * r;
+    const double p = (r * r2) * (des_log_A[0] + r * des_log_A[1] + r2 * (des_log_A[2] + r * des_log_A[3]
+                     + r2 * (des_log_A[4] + r * des_log_A[5])));
+    const double lo = (kd * des_ln2lo + des_log_clo[i]) + e1 + e2 + e3 + e4 + p;
+    const double y = hi + lo;
+    *lo_out = (hi - y) + lo;                                  // |hi| >= |lo|
+    return y;
+}
+
+DES_LIBM_FN double pow(double x, double y)
+{
+    uint64_t ix = bits(x);
+    const uint64_t iy = bits(y);
+    const uint64_t ay = iy & 0x7fffffffffffffffULL;
+    if (ay == 0) return 1.0;                                   // pow(x, +-0) = 1, NaN included
+    if (ix == 0x3ff0000000000000ULL) return 1.0;               // pow(1, y) = 1
+    if (ay > 0x7ff0000000000000ULL || (ix & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL)
+        return x + y;                                          // NaN
+    if (ix >> 63) {                                            // negative (or -0)
+        if ((ix << 1) != 0) return dbl(0x7ff8000000000000ULL);  // x < 0: not on the path
+        ix = 0;                                                // -0 treated as +0 (even powers only matter)
+    }
+    if (ix == 0) return (iy >> 63) ? __builtin_inf() : 0.0;
+    if (ix == 0x7ff0000000000000ULL) return (iy >> 63) ? 0.0 : __builtin_inf();
+    if (ay == 0x7ff0000000000000ULL) {                         // y = +-inf
+        const bool big = ix > 0x3ff0000000000000ULL;
+        return (big != (bool)(iy >> 63)) ? __builtin_inf() : 0.0;
+    }
+    int64_t kadj = 0;
+    if (ix < 0x0010000000000000ULL) {                          // subnormal: scale by 2^52
+        ix = bits(x * 4503599627370496.0);
+        kadj = -52;
+    }
+    double lo;
+    const double hi = log_dd(ix, kadj, &lo);
+    const double ehi = y * hi;
+    const double elo = y * lo + fma_(y, hi, -ehi);
+    if (!(__builtin_fabs(ehi) < 1.0e300))                      // y*log(x) overflowed: far outside exp's range
+        return ehi > 0 ? __builtin_inf() : 0.0;
+    return exp_core(ehi, elo);
+}
+
+// ---- sin / cos ------------------------------------------------------------------------
+// x = n pi/2 + (r + rt), |r| <= pi/4 (+ a hair); returns n mod 4.
+DES_LIBM_FN int rem_pio2(double x, double *r, double *rt)
+{
+    if (__builtin_fabs(x) <= 0.7853981633974483) { *r = x; *rt = 0.0; return 0; }
+    uint64_t ki;
+    const double fn = round_shift(x * des_invpio2, &ki);
+    // three 33-bit pieces of pi/2: fn*piece exact for |fn| < 2^20
+    const double a = fma_(fn, -des_pio2[0], x);                 // exact (Sterbenz)
+    double e1, e2, e3;
+    const double b = two_sum(a, -(fn * des_pio2[1]), &e1);
+    const double c = two_sum(b, -(fn * des_pio2[2]), &e2);
+    const double e = (e1 + e2) - fn * des_pio2[3];
+    *r = two_sum(c, e, &e3);
+    *rt = e3;
+    return (int)(ki & 3);
+}
+
+DES_LIBM_FN double sin_kernel(double x, double t)
+{
+    const double z = x * x;
+    const double p = des_sin_S[1] + z * (des_sin_S[2] + z * (des_sin_S[3] + z * (des_sin_S[4] + z * des_sin_S[5])));
+    const double v = z * x;
+    // x + t + x^3 (S0 + z p), with the tail's first-order effect t (1 - z/2)
+    return x + (v * des_sin_S[0] + (t - z * (0.5 * t - v * p)));
+}
+
+DES_LIBM_FN double cos_kernel(double x, double t)
+{
+    const double z = x * x;
+    const double p = z * (des_cos_C[0] + z * (des_cos_C[1] + z * (des_cos_C[2] + z * (des_cos_C[3] + z * (des_cos_C[4] + z * des_cos_C[5])))));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * p - x * t));
+}
+
+DES_LIBM_FN void sincos(double x, double *s, double *c)
+{
+    if (!(__builtin_fabs(x) < __builtin_inf())) { *s = *c = x - x; return; }
+    double r, t;
+    const int n = rem_pio2(x, &r, &t);
+    const double sk = sin_kernel(r, t), ck = cos_kernel(r, t);
+    switch (n) {
+    case 0:  *s = sk;  *c = ck;  break;
+    case 1:  *s = ck;  *c = -sk; break;
+    case 2:  *s = -sk; *c = -ck; break;
+    default: *s = -ck; *c = sk;  break;
+    }
+}
+
+DES_LIBM_FN double sin(double x) { double s, c; sincos(x, &s, &c); return s; }
+DES_LIBM_FN double cos(double x) { double s, c; sincos(x, &s, &c); return c; }
+DES_LIBM_FN double tan(double x) { double s, c; sincos(x, &s, &c); return s / c; }
+
+// ---- atan2 ----------------------------------------------------------------------------
+DES_LIBM_FN double atan_pos(double x)              // x >= 0 (inf allowed)
+{
+    int id;
+    if (x < 0.4375) {
+        if (x < 7.450580596923828125e-09) return x;         // 2^-27
+        id = -1;
+    } else if (x < 1.1875) {
+        if (x < 0.6875) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); }
+        else            { id = 1; x = (x - 1.0) / (x + 1.0); }
+    } else {
+        if (x < 2.4375) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); }
+        else            { id = 3; x = -1.0 / x; }
+    }
+    const double z = x * x;
+    const double w = z * z;
+    const double pe = des_atan_T[0] + w * (des_atan_T[2] + w * (des_atan_T[4] + w * (des_atan_T[6] + w * (des_atan_T[8] + w * des_atan_T[10]))));
+    const double po = des_atan_T[1] + w * (des_atan_T[3] + w * (des_atan_T[5] + w * (des_atan_T[7] + w * des_atan_T[9])));
+    const double q = z * (pe + z * po);            // atan(x)/x - 1
+    if (id < 0) return x + x * q;
+    return des_atan_hi[id] + ((x * q + des_atan_lo[id]) + x);
+}
+
+DES_LIBM_FN double atan2(double y, double x)
+{
+    if (x != x || y != y) return x + y;
+    const uint64_t sy = bits(y) >> 63, sx = bits(x) >> 63;
+    const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
+    double r;
+    if (ay == 0.0)           r = sx ? des_pi_hi : 0.0;
+    else if (ax == 0.0)      r = des_atan_hi[3];
+    else if (ax == __builtin_inf())
+        r = (ay == __builtin_inf()) ? (sx ? 3.0 * des_atan_hi[1] : des_atan_hi[1]) : (sx ? des_pi_hi : 0.0);
+    else if (ay == __builtin_inf()) r = des_atan_hi[3];
+    else {
+        const double a = atan_pos(ay / ax);
+        r = sx ? des_pi_hi - (a - des_pi_lo) : a;
+    }
+    return sy ? -r : r;
+}
+
+}  // namespace deslibm

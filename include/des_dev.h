@@ -81,6 +81,14 @@ int des_dev_sync(des_dev *h);
  * volume, dpressure, viscosity, stress, temperature, tmass, force, vel, coord. */
 int des_dev_check_nan(des_dev *h, long long *n_nan);
 
+/* Diagnostic: evaluates one function of the portable libm (dynearthsol_amd/csrc/des_libm.hpp,
+ * what the stress update uses under DES_LIBM=portable) on the device, out[i] = fn(x[i], y[i])
+ * (y only for pow / atan2, else NULL).  Host pointers.  A CPU build of the same header must
+ * give the same bits; no reference counterpart (the reference calls the C library:
+ * rheology.cxx:260-300, matprops.cxx:380-418, 3x3-C/dsyevc3.c:60-70). */
+enum { DES_LIBM_POW = 0, DES_LIBM_EXP = 1, DES_LIBM_SIN = 2, DES_LIBM_COS = 3, DES_LIBM_TAN = 4, DES_LIBM_ATAN2 = 5 };
+int des_dev_libm_eval(int device, int fn, long long n, const double *x, const double *y, double *out);
+
 /* Timing helpers for bench.py: HIP-event bracket on the engine's own stream. */
 int des_dev_timer_start(des_dev *h);
 int des_dev_timer_stop(des_dev *h, float *ms);

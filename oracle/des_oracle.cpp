@@ -17,6 +17,7 @@
  * 3D only (the THREED build of the reference).
  */
 #include "des_oracle.h"
+#include "../dynearthsol_amd/csrc/des_libm.hpp"   /* the portable libm, for des_oracle_set_libm(1) only */
 
 #include <algorithm>
 #include <cfloat>
@@ -30,6 +31,18 @@
 #endif
 
 namespace {
+
+/* The libm calls of the path (rheology.cxx creep law / plastic_props, 3x3-C/dsyevc3.c).
+ * Default: the C library's, as in the reference.  des_oracle_set_libm(1) switches them to
+ * des_libm.hpp -- the functions the HIP engine uses under DES_LIBM=portable -- so that a test
+ * can show that device and CPU agree to the bit once the libm is the same on both sides. */
+int g_portable_libm = 0;
+inline double m_pow(double a, double b) { return g_portable_libm ? deslibm::pow(a, b) : std::pow(a, b); }
+inline double m_exp(double a) { return g_portable_libm ? deslibm::exp(a) : std::exp(a); }
+inline double m_sin(double a) { return g_portable_libm ? deslibm::sin(a) : std::sin(a); }
+inline double m_cos(double a) { return g_portable_libm ? deslibm::cos(a) : std::cos(a); }
+inline double m_tan(double a) { return g_portable_libm ? deslibm::tan(a) : std::tan(a); }
+inline double m_atan2(double y, double x) { return g_portable_libm ? deslibm::atan2(y, x) : std::atan2(y, x); }
 
 const int ND = 3;            // NDIMS, constants.hpp:12-16
 const int NPE = 4;           // NODES_PER_ELEM, constants.hpp:19
@@ -113,10 +126,10 @@ int dsyevc3(const double A[3][3], double w[3])
     double sqrt_p = std::sqrt(std::fabs(p));
 
     double phi = 27.0 * (0.25*sqr(c1)*(p - c1) + c0*(q + 27.0/4.0*c0));
-    phi = (1.0/3.0) * std::atan2(std::sqrt(std::fabs(phi)), q);
+    phi = (1.0/3.0) * m_atan2(std::sqrt(std::fabs(phi)), q);
 
-    double c = sqrt_p*std::cos(phi);
-    double s = (1.0/sqrt3)*sqrt_p*std::sin(phi);
+    double c = sqrt_p*m_cos(phi);
+    double s = (1.0/sqrt3)*sqrt_p*m_sin(phi);
 
     w[1]  = (1.0/3.0)*(m - c);
     w[2]  = w[1] + s;
@@ -538,8 +551,8 @@ struct Mat {
         for (int m = 0; m < o.p.nmat; m++) {
             const int marker_count = mk[m];
             if (marker_count == 0) continue;
-            double visc0 = 0.25 * std::pow(edot, o.visc_pow_edot[m]) * o.visc_coef_term[m]
-                * std::exp((o.p.visc_activation_energy[m] + o.p.visc_activation_volume[m] * s0)
+            double visc0 = 0.25 * m_pow(edot, o.visc_pow_edot[m]) * o.visc_coef_term[m]
+                * m_exp((o.p.visc_activation_energy[m] + o.p.visc_activation_volume[m] * s0)
                            / (o.visc_nR[m] * T)) * 1e6;
             result += marker_count / visc0;
             n += marker_count;
@@ -590,13 +603,13 @@ struct Mat {
                        double &hardn, double &ten_max) const {
         double cohesion, phi_, psi;
         plastic_weakening(e, pls, cohesion, phi_, psi, hardn);
-        double sphi = std::sin(phi_ * DEG2RAD);
-        double spsi = std::sin(psi * DEG2RAD);
+        double sphi = m_sin(phi_ * DEG2RAD);
+        double spsi = m_sin(psi * DEG2RAD);
         anphi = (1 + sphi) / (1 - sphi);
         anpsi = (1 + spsi) / (1 - spsi);
         amc = 2 * cohesion * std::sqrt(anphi);
         ten_max = (phi_ == 0) ? o.p.tension_max
-                              : std::min(o.p.tension_max, cohesion / std::tan(phi_ * DEG2RAD));
+                              : std::min(o.p.tension_max, cohesion / m_tan(phi_ * DEG2RAD));
     }
 };
 
@@ -1982,6 +1995,28 @@ int des_oracle_dt_finalize(des_oracle *h, const double in[6], double *dt)
 }
 
 double des_oracle_l2_partial(des_oracle *h) { return h->l2_part; }
+
+void des_oracle_libm_eval(int fn, long long n, const double *x, const double *y, double *out)
+{
+    for (long long i = 0; i < n; ++i) {
+        const double a = x[i], b = y ? y[i] : 0.0;
+        switch (fn) {
+        case 0:  out[i] = deslibm::pow(a, b); break;
+        case 1:  out[i] = deslibm::exp(a); break;
+        case 2:  out[i] = deslibm::sin(a); break;
+        case 3:  out[i] = deslibm::cos(a); break;
+        case 4:  out[i] = deslibm::tan(a); break;
+        default: out[i] = deslibm::atan2(a, b); break;
+        }
+    }
+}
+
+int des_oracle_set_libm(int portable)
+{
+    const int old = g_portable_libm;
+    if (portable >= 0) g_portable_libm = portable != 0;
+    return old;
+}
 
 int des_oracle_set_threads(int n)
 {

@@ -41,6 +41,12 @@ int des_oracle_threads(void);
 /* libgomp may already be initialised by the host process (torch loads it), so OMP_NUM_THREADS
  * set late is ignored: set the team size explicitly; returns the size in effect */
 int des_oracle_set_threads(int n);
+/* 0: libm calls go to the C library (default, as the reference); 1: to the portable set of
+ * dynearthsol_amd/csrc/des_libm.hpp; < 0: query only.  Process-wide; returns the old value. */
+int des_oracle_set_libm(int portable);
+/* CPU build of the portable libm, one function over an array: fn 0 pow, 1 exp, 2 sin, 3 cos,
+ * 4 tan, 5 atan2 (the numbering of des_dev_libm_eval). */
+void des_oracle_libm_eval(int fn, long long n, const double *x, const double *y, double *out);
 
 /* Stand-alone pieces exposed for known-answer tests. */
 /* eigenvalues (ascending) of the symmetric tensor s = {XX,YY,ZZ,XY,XZ,YZ};

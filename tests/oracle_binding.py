@@ -24,6 +24,10 @@ def load_oracle(omp=False):
         lib.des_oracle_threads.restype = C.c_int
         lib.des_oracle_set_threads.restype = C.c_int
         lib.des_oracle_set_threads.argtypes = [C.c_int]
+        lib.des_oracle_set_libm.restype = C.c_int
+        lib.des_oracle_set_libm.argtypes = [C.c_int]
+        lib.des_oracle_libm_eval.restype = None
+        lib.des_oracle_libm_eval.argtypes = [C.c_int, C.c_longlong] + [C.POINTER(C.c_double)] * 3
         d6 = C.POINTER(C.c_double)
         lib.des_oracle_principal_values3.argtypes = [d6, d6]
         lib.des_oracle_principal_stresses3.argtypes = [d6, d6, d6]
@@ -51,3 +55,35 @@ class OracleEngine(EngineBase):
 
 def dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def oracle_libm_eval(fn, x, y=None):
+    """CPU build of the portable libm (csrc/des_libm.hpp) through the oracle library."""
+    from dynearthsol_amd import LIBM_FN
+    lib = load_oracle()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64)
+    lib.des_oracle_libm_eval(LIBM_FN[fn], x.size, dptr(x), dptr(y) if y is not None else None, dptr(out))
+    return out
+
+
+class portable_libm:
+    """with portable_libm(): the oracle (both builds) and every device engine CREATED inside use
+    the portable libm instead of glibc / ocml."""
+
+    def __enter__(self):
+        self._old = [(lib, lib.des_oracle_set_libm(1)) for lib in (load_oracle(False), load_oracle(True))]
+        self._env = os.environ.get("DES_LIBM")
+        os.environ["DES_LIBM"] = "portable"
+        return self
+
+    def __exit__(self, *exc):
+        for lib, old in self._old:
+            lib.des_oracle_set_libm(old)
+        if self._env is None:
+            os.environ.pop("DES_LIBM", None)
+        else:
+            os.environ["DES_LIBM"] = self._env
+        return False

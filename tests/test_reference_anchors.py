@@ -13,7 +13,7 @@ import pytest
 
 import cfgs
 import dynearthsol_amd as des
-from oracle_binding import OracleEngine
+from oracle_binding import OracleEngine, portable_libm
 
 MESH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test-3d.desmesh")
 EVP = "mat.rheology_type = elasto-visco-plastic\nmat.min_viscosity = 1e19\nbc.mantle_temperature = 1573\n"
@@ -84,3 +84,35 @@ def test_device_evp_variant_within_1e10_of_the_oracle_after_1000_steps():
     for f in ("COORD", "VEL", "STRESS", "STRAIN", "TEMPERATURE", "VISCOSITY"):
         a, b = d.download(f), o.download(f)
         assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), f
+
+
+def test_anchors_hold_with_the_portable_libm_too():
+    """The oracle with its libm calls switched to csrc/des_libm.hpp (what DES_LIBM=portable uses
+    on the device) prints the same recorded digits of the reference: the substitute is a libm in
+    good standing, not a different model."""
+    with portable_libm():
+        h = des.Host(cfg_text=cfgs.TEST3D, mesh_file=MESH)
+        o = OracleEngine(h)
+        o.init_from_host(h)
+        o.step(200)
+        assert observe(o) == ("1.286196e-09", "-2.644198e+08", "6.289321e+13", 0)
+        h = des.Host(cfg_text=cfgs.TEST3D, mesh_file=MESH, overrides=EVP)
+        o = OracleEngine(h)
+        o.init_from_host(h)
+        o.step(300)
+        assert observe(o)[:3] == ("1.312445e-09", "-2.644199e+08", "6.240221e+13")
+
+
+@pytest.mark.gpu
+def test_device_evp_variant_bit_identical_after_1000_steps_with_one_libm():
+    """The same 1000 evp steps with the same libm on both sides: every field the same bits."""
+    with portable_libm():
+        h = des.Host(cfg_text=cfgs.TEST3D, mesh_file=MESH, overrides=EVP)
+        d, o = des.DeviceEngine(h), OracleEngine(h)
+        assert d.init_from_host(h) == o.init_from_host(h)
+        d.step(300); o.step(300)
+        assert observe(d)[:3] == ("1.312445e-09", "-2.644199e+08", "6.240221e+13")
+        sd, so = d.step(700), o.step(700)
+        assert (sd.dt, sd.time) == (so.dt, so.time)
+        for f in ("COORD", "VEL", "STRESS", "STRAIN", "PLSTRAIN", "TEMPERATURE", "VISCOSITY", "FORCE"):
+            assert np.array_equal(d.download(f), o.download(f)), f
