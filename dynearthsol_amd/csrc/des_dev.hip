@@ -41,6 +41,7 @@
 #include <rccl/rccl.h>
 
 #include "des_dev.h"
+#define DES_LIBM_LDS_TABLES 1     // kernels that call deslibm:: stage its tables in LDS first
 #include "des_kernels.hpp"
 
 using desk::d4;
@@ -638,6 +639,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
 {
     // elements [e_begin, e_begin + e_count): the whole local mesh, or any sub-range of it (ne
     // stays the SoA plane stride)
+    M::stage_begin();
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     if (el >= e_count) return;
     const int e = e_begin + el;
@@ -668,6 +670,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     double dpl = 0.;
     const double vol = volume[e];
 
+    M::stage_end();
     double visc = 0;
     if (rheol & DES_RH_VISCOUS) {
         double T = 0;
@@ -1363,6 +1366,7 @@ __global__ void k_dhacc_reset(int ntop, const int *__restrict__ top_nodes, doubl
 __global__ void k_libm_eval(int fn, long long n, const double *__restrict__ x, const double *__restrict__ y,
                             double *__restrict__ out)
 {
+    deslibm::lds_stage();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double a = x[i], b = y ? y[i] : 0.0;

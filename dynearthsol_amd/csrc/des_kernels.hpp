@@ -143,6 +143,8 @@ __device__ __forceinline__ double mat_rho(const des_params *p, const Mix &mx, do
 // The six libm functions of the stress update, as a policy: ROCm's ocml (default) or the
 // portable set of des_libm.hpp, which a CPU build reproduces to the bit (DES_LIBM=portable).
 struct MathOcml {
+    static __device__ __forceinline__ void stage_begin() {}
+    static __device__ __forceinline__ void stage_end() {}
     static __device__ __forceinline__ double pow(double a, double b) { return ::pow(a, b); }
     static __device__ __forceinline__ double exp(double a) { return ::exp(a); }
     static __device__ __forceinline__ double sin(double a) { return ::sin(a); }
@@ -151,6 +153,8 @@ struct MathOcml {
     static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
 };
 struct MathPortable {
+    static __device__ __forceinline__ void stage_begin() { deslibm::lds_stage_begin(); }   // whole workgroup, top of the kernel
+    static __device__ __forceinline__ void stage_end() { deslibm::lds_stage_end(); }       // barrier before the first call
     static __device__ __forceinline__ double pow(double a, double b) { return deslibm::pow(a, b); }
     static __device__ __forceinline__ double exp(double a) { return deslibm::exp(a); }
     static __device__ __forceinline__ double sin(double a) { return deslibm::sin(a); }

@@ -35,6 +35,38 @@
 
 namespace deslibm {
 
+// Table access.  A device kernel may stage the five 128-entry tables in LDS first
+// (lds_stage*(), then every call of that workgroup reads LDS instead of global memory: the two
+// dependent look-ups of a pow() cost ~2 x 64 cycles instead of ~2 x 500 at the low occupancy
+// of the stress kernel); kernels that do not stage them, and the CPU build, read the arrays.
+#if defined(__HIPCC__) && defined(DES_LIBM_LDS_TABLES)
+static __shared__ double lds_tab[5 * 128];
+// lds_stage_begin() copies (all threads of the workgroup call it, at the top of the kernel);
+// lds_stage_end() is the barrier, to be placed after the kernel's own loads have been issued
+// and before the first deslibm:: call.
+DES_LIBM_FN void lds_stage_begin()
+{
+    for (int i = threadIdx.x; i < 5 * 128; i += blockDim.x) {
+        const int t = i >> 7, j = i & 127;
+        const double *src = t == 0 ? des_log_invc : t == 1 ? des_log_chi : t == 2 ? des_log_clo : t == 3 ? des_exp_hi : des_exp_tail;
+        lds_tab[i] = src[j];
+    }
+}
+DES_LIBM_FN void lds_stage_end() { __syncthreads(); }
+DES_LIBM_FN void lds_stage() { lds_stage_begin(); lds_stage_end(); }
+#define DES_T_INVC(i) lds_tab[i]
+#define DES_T_CHI(i)  lds_tab[128 + (i)]
+#define DES_T_CLO(i)  lds_tab[256 + (i)]
+#define DES_T_EHI(i)  lds_tab[384 + (i)]
+#define DES_T_ETL(i)  lds_tab[512 + (i)]
+#else
+#define DES_T_INVC(i) des_log_invc[i]
+#define DES_T_CHI(i)  des_log_chi[i]
+#define DES_T_CLO(i)  des_log_clo[i]
+#define DES_T_EHI(i)  des_exp_hi[i]
+#define DES_T_ETL(i)  des_exp_tail[i]
+#endif
+
 DES_LIBM_FN uint64_t bits(double x) { uint64_t u; __builtin_memcpy(&u, &x, 8); return u; }
 DES_LIBM_FN double   dbl(uint64_t u) { double x; __builtin_memcpy(&x, &u, 8); return x; }
 DES_LIBM_FN double   fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -78,8 +110,8 @@ DES_LIBM_FN double exp_core(double x, double xtail)
     const int j = (int)(n & 127);
     const int64_t k = n >> 7;                                  // floor(n / 128)
     const double r2 = r * r;
-    const double tmp = des_exp_tail[j] + r + r2 * (des_exp_C[0] + r * des_exp_C[1]) + r2 * r2 * (des_exp_C[2] + r * des_exp_C[3]);
-    const double hi = des_exp_hi[j];
+    const double tmp = DES_T_ETL(j) + r + r2 * (des_exp_C[0] + r * des_exp_C[1]) + r2 * r2 * (des_exp_C[2] + r * des_exp_C[3]);
+    const double hi = DES_T_EHI(j);
     if (k > 1000 || k < -1000) {
         // scale in two steps: 2^k overflows / underflows a double's exponent field on its own
         const int64_t k1 = k > 0 ? k - 900 : k + 900;
@@ -103,10 +135,10 @@ DES_LIBM_FN double log_dd(uint64_t ix, int64_t kadj, double *lo_out)
     const int64_t k = ((int64_t)tmp >> 52) + kadj;
     const double z = dbl(ix - (tmp & 0xfff0000000000000ULL));
     const double kd = (double)k;
-    const double r = fma_(z, des_log_invc[i], -1.0);          // exact (see the generator)
+    const double r = fma_(z, DES_T_INVC(i), -1.0);          // exact (see the generator)
     // k ln2 + log c + r - r^2/2, every partial sum kept with its rounding error
     double e1, e2, e3;
-    const double t1 = two_sum(kd * des_ln2hi, des_log_chi[i], &e1);   // kd*ln2hi is exact (42 + 11 bits)
+    const double t1 = two_sum(kd * des_ln2hi, DES_T_CHI(i), &e1);   // kd*ln2hi is exact (42 + 11 bits)
     const double t2 = two_sum(t1, r, &e2);
     const double ar = -0.5 * r;
     const double ar2 = r * ar;
@@ -115,7 +147,7 @@ DES_LIBM_FN double log_dd(uint64_t ix, int64_t kadj, double *lo_out)
     const double r2 = r * r;
     const double p = (r * r2) * (des_log_A[0] + r * des_log_A[1] + r2 * (des_log_A[2] + r * des_log_A[3]
                      + r2 * (des_log_A[4] + r * des_log_A[5])));
-    const double lo = (kd * des_ln2lo + des_log_clo[i]) + e1 + e2 + e3 + e4 + p;
+    const double lo = (kd * des_ln2lo + DES_T_CLO(i)) + e1 + e2 + e3 + e4 + p;
     const double y = hi + lo;
     *lo_out = (hi - y) + lo;                                  // |hi| >= |lo|
     return y;
