@@ -69,6 +69,7 @@ def bind_engine_api(lib, prefix):
     g("field_count").restype = C.c_longlong
     g("field_count").argtypes = [C.c_void_p, C.c_int]
     g("set_clock").argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_longlong]
+    g("set_isostasy").argtypes = [C.c_void_p, C.c_int]
     g("init_geometry").argtypes = [C.c_void_p]
     g("compute_dt").argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     g("step").argtypes = [C.c_void_p, C.c_int, C.POINTER(DesScalars)]
@@ -210,6 +211,10 @@ class EngineBase:
         a = np.empty(n, dtype=np.int32 if field in INT_FIELDS else np.float64)
         self._check(self._f("download")(self._h, F[field], a.ctypes.data_as(C.c_void_p), n), "download(%s)" % field)
         return a
+
+    def set_isostasy(self, on):
+        """isostasy_adjustment mode: step() runs that loop's body instead of a time step."""
+        self._check(self._f("set_isostasy")(self._h, int(bool(on))), "set_isostasy")
 
     def set_clock(self, dt, time=0.0, steps=0):
         self._check(self._f("set_clock")(self._h, dt, time, steps), "set_clock")

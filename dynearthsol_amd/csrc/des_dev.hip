@@ -76,7 +76,7 @@ struct DevClock {
     double maxdh, l2_sum;
     long long steps;
     int status;
-    int pad;
+    int iso;                 // inside isostasy_adjustment (des_dev_set_isostasy)
     double avg_time0;        // Output::time0 (output.cxx:332)
 };
 
@@ -165,6 +165,7 @@ struct des_dev {
     bool const_mass;                      // quasi-static, one material: nodal mass from volumes alone
     bool pending_c;                       // C part of the last step has been run (always true outside step())
     long long steps_host;
+    bool iso;                 // des_dev_set_isostasy
     // profiling
     bool prof;
     std::vector<ProfRec> prof_recs;
@@ -330,7 +331,7 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
 
         if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
             const bool rescale = rdv >= 1.0;                         // bc.cxx:1677
-            const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0;
+            const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0 && !clk->iso;   // not in the isostasy loop
             if (rescale || rotate || (MODE & MODE_AVG)) {
                 double s[6], es[6];
                 for (int i = 0; i < 6; ++i) { s[i] = stress[(size_t)i*ne + e]; es[i] = strain[(size_t)i*ne + e]; }
@@ -522,8 +523,10 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     const int n = (threadIdx.x < npb) ? n0 + threadIdx.x : nn;
     const double dt = clk->dt;
     if (FULL && blockIdx.x == 0 && threadIdx.x == 0) {
-        clk->steps += 1;
-        clk->time += dt;
+        if (!clk->iso) {                                   // the isostasy loop does not advance the clock
+            clk->steps += 1;
+            clk->time += dt;
+        }
         clk->maxdh = 0.0;
     }
     if (n0 >= nn) return;                                   // whole block idle (grid padding)
@@ -612,7 +615,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     m4.w = ms;
     vm[n] = m4;
     if (FULL) {
-        if (thermal) {
+        if (thermal && !clk->iso) {                        // the isostasy loop has no update_temperature
             d4 x4 = xt[n];
             if (bcflag[n] & (1u << 5))
                 x4.w = p->surface_temperature;
@@ -801,7 +804,7 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
                               double *__restrict__ f_tmp);
 
 __global__ void __launch_bounds__(DES_BLOCK, DES_E3_WAVES)
-E3_nmd_force(const des_params *__restrict__ p, int ne, int e_begin, int e_count, int nblocks, int nblocks8,
+E3_nmd_force(const des_params *__restrict__ p, int nmd, int ne, int e_begin, int e_count, int nblocks, int nblocks8,
      const int4 *__restrict__ conn,
      const d4 *__restrict__ xt, const double *__restrict__ ntmp, const MatData md,
      const double *__restrict__ volume,
@@ -825,7 +828,7 @@ E3_nmd_force(const des_params *__restrict__ p, int ne, int e_begin, int e_count,
         c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
         double s[6];
         for (int i = 0; i < 6; ++i) s[i] = stress[(size_t)i*ne + e];
-        if (p->is_using_mixed_stress) {
+        if (nmd) {                                          // is_using_mixed_stress, outside the isostasy loop
             double dp = 0;
             dp += ntmp[cn.x]; dp += ntmp[cn.y]; dp += ntmp[cn.z]; dp += ntmp[cn.w];
             double dp_el = dp / 4;
@@ -1151,7 +1154,12 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
             l2 += fr[1]*fr[1] / num;
             l2 += fr[2]*fr[2] / num;
         }
-        if (flag & 0x3ffu)
+        if (clk->iso) {
+            // isostasy_adjustment (dynearthsol.cxx:521-535): no velocity bcs, vertical motion only,
+            // a bottom without Winkler foundation is held
+            v[0] = 0; v[1] = 0;
+            if (!p->has_winkler_foundation && (flag & (1u << 4))) v[2] = 0;       // BOUNDZ0
+        } else if (flag & 0x3ffu)
             apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
         m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
         vm[n] = m4;
@@ -1597,7 +1605,8 @@ void launch_e3(des_dev *h, int e_begin = 0, int e_count = -1, bool facets = true
     const int nbe8 = nblk8(e_count), nbf = facets ? nblk(h->nbcf) : 0;
     if (nbe8 + nbf == 0) return;
     Launch l(h, K_E3);
-    hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->ne, e_begin, e_count,
+    hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p,
+                       (int)(h->p.is_using_mixed_stress && !h->iso), h->ne, e_begin, e_count,
                        nblk(e_count), nbe8,
                        h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->dpressure, h->stress, h->ftmp,
                        facets ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
@@ -2266,6 +2275,23 @@ int des_dev_set_clock(des_dev *h, double dt, double time, long long steps)
     return DES_OK;
 }
 
+// isostasy_adjustment (dynearthsol.cxx:496-544) is the time step minus the clock, the
+// temperature update, NMD_stress, the velocity bcs, rotate_stress and compute_dt: DevClock::iso
+// tells the kernels, the host side skips the N2 launch and passes nmd = 0 to E3.  (update_stress
+// still stores dpressure and compute_mass the thermal mass, as in the reference.)
+int des_dev_set_isostasy(des_dev *h, int on)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    h->iso = on != 0;
+    h->h_clk->iso = h->iso;
+    HIP_OK(hipMemcpyAsync(h->d_clk, h->h_clk, sizeof(DevClock), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
 int des_dev_sync(des_dev *h)
 {
     if (!h) return DES_ERR_INTERNAL;
@@ -2322,10 +2348,11 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     }
     refresh_props(h);
     const bool multi = h->nnbr > 0;
-    const bool nmd = h->p.is_using_mixed_stress;
+    const bool iso = h->iso;
+    const bool nmd = h->p.is_using_mixed_stress && !iso;
     int rc;
     for (int i = 0; i < nsteps; ++i) {
-        const long long step_no = ++h->steps_host;
+        const long long step_no = iso ? h->steps_host : ++h->steps_host;
         if (i == 0) launch_e1<MODE_A>(h);
         launch_n1(h);
         launch_e2(h);
@@ -2341,6 +2368,10 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
             launch_s3(h, true, true, true);
         }
         const bool last = (i == nsteps - 1);
+        if (iso) {                                         // no averaging, no compute_dt in that loop
+            if (last) launch_e1<MODE_C>(h); else launch_e1<MODE_C | MODE_A>(h);
+            continue;
+        }
         const bool do_dt = (step_no % 10 == 0);
         launch_avg_coord0(h, step_no);
         launch_e1_end(h, step_no, !last);
@@ -2479,11 +2510,11 @@ int des_dev_phase(des_dev *h, int phase)
     switch (phase) {
     case 0:
         refresh_props(h);
-        ++h->steps_host;
+        if (!h->iso) ++h->steps_host;
         launch_e1<MODE_A>(h);
         launch_n1(h);
         launch_e2(h);
-        if (h->p.is_using_mixed_stress) launch_n2(h);
+        if (h->p.is_using_mixed_stress && !h->iso) launch_n2(h);
         launch_e3(h);
         launch_n3(h);
         launch_s2(h, h->steps_host);
@@ -2491,6 +2522,11 @@ int des_dev_phase(des_dev *h, int phase)
         return 0;
     case 1: {
         launch_s3(h, false, true, true);
+        if (h->iso) {
+            launch_e1<MODE_C>(h);
+            launch_mass_gather(h);
+            return 0;
+        }
         const bool do_dt = (h->steps_host % 10 == 0);
         launch_avg_coord0(h, h->steps_host);
         launch_e1_end(h, h->steps_host, false);

@@ -156,6 +156,19 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         if (!rs.active) {
             double dt0 = 0;
             r.check(api->compute_dt(r.eng, &dt0), "compute_dt");
+            const double iso_yr = cfg.d("ic.isostasy_adjustment_time_in_yr");
+            if (iso_yr > 0) {
+                // isostasy_adjustment (dynearthsol.cxx:496-544, called at :638-641), then the
+                // compute_dt of :643
+                if (!api->set_isostasy) throw des::Error(31, "this engine does not offload the isostasy adjustment");
+                if (!quiet && !api->no_files) { std::printf("Adjusting isostasy for %g yrs...\n", iso_yr); std::fflush(stdout); }
+                const int iso_steps = (int)(iso_yr * YEAR2SEC / dt0);
+                r.check(api->set_isostasy(r.eng, 1), "set_isostasy");
+                r.check(api->step(r.eng, iso_steps, nullptr), "isostasy steps");
+                r.check(api->set_isostasy(r.eng, 0), "set_isostasy");
+                if (!quiet && !api->no_files) { std::printf("Adjusted isostasy for %d steps.\n", iso_steps); std::fflush(stdout); }
+                r.check(api->compute_dt(r.eng, &dt0), "compute_dt");
+            }
             r.info_display_next_step = info_display_step_interval;               // dynearthsol.cxx:636
             r.last_remesh_time = 0; r.reference_frame_time = 0;
         } else {

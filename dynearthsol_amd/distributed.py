@@ -248,6 +248,12 @@ def collective_api(ce):
             C.memmove(out, C.byref(sc), C.sizeof(DesScalars))
         return sc.status
 
+    @driver.ISO_T
+    @guard
+    def set_isostasy(h, on):
+        ce.engine.set_isostasy(on)
+        return 0
+
     @driver.NAN_T
     @guard
     def check_nan(h, n_nan):
@@ -266,10 +272,10 @@ def collective_api(ce):
     api = driver.EngineApi()
     api.create, api.destroy, api.upload, api.download, api.field_count = create, destroy, upload, download, field_count
     api.set_clock, api.init_geometry, api.compute_dt, api.step = set_clock, init_geometry, compute_dt, step
-    api.check_nan, api.mesh_quality = check_nan, mesh_quality
+    api.check_nan, api.mesh_quality, api.set_isostasy = check_nan, mesh_quality, set_isostasy
     api.no_files = 0 if ce.rank == 0 else 1
     api._keep = (create, destroy, upload, download, field_count, set_clock, init_geometry, compute_dt, step,
-                 check_nan, mesh_quality)
+                 check_nan, mesh_quality, set_isostasy)
     return api
 
 

@@ -55,6 +55,15 @@ int des_dev_upload(des_dev *h, int field, const void *host, long long count);
 int des_dev_download(des_dev *h, int field, void *host, long long count);
 long long des_dev_field_count(const des_dev *h, int field);
 
+/* on = 1: des_dev_step (and des_dev_phase) run the body of isostasy_adjustment's loop
+ * (dynearthsol.cxx:506-539) instead of a time step -- strain rate, stress, force and velocity
+ * update as usual, then horizontal velocities zeroed (and vz on a bottom without Winkler
+ * foundation), update_mesh; no clock advance, temperature update, NMD, velocity bcs,
+ * rotate_stress or compute_dt.  on = 0: back to time steps.  The caller reproduces
+ * dynearthsol.cxx:503-504, 643: dt = compute_dt; iso_steps = years*YEAR2SEC/dt; set_isostasy(1);
+ * step(iso_steps); set_isostasy(0); dt = compute_dt. */
+int des_dev_set_isostasy(des_dev *h, int on);
+
 /* Set time-step scalars: dt (Variables::dt), time, steps.  compute_dt semantics: if
  * fixed_dt != 0 it always wins (geometry.cxx:1487). */
 int des_dev_set_clock(des_dev *h, double dt, double time, long long steps);

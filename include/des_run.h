@@ -64,6 +64,9 @@ typedef struct des_engine_api {
     int (*check_nan)(void *h, long long *n_nan);
     int (*mesh_quality)(void *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out);
     const char *(*last_error)(void);
+    /* isostasy_adjustment mode on / off (des_dev_set_isostasy); may be NULL, in which case a
+     * config with ic.isostasy_adjustment_time_in_yr > 0 is refused with code 31 */
+    int (*set_isostasy)(void *h, int on);
     /* One-process-per-GPU runs: every rank runs the same loop over an engine table whose entries
      * are collective (upload scatters, download gathers the global arrays, step / compute_dt /
      * mesh_quality / check_nan reduce across ranks: dynearthsol_amd/distributed.py); ranks with

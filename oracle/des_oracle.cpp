@@ -63,6 +63,7 @@ typedef std::vector<int> ivec;
 struct des_oracle {
     des_params p;
     int nn, ne;
+    int iso = 0;                        // inside isostasy_adjustment (dynearthsol.cxx:496-544)
     // topology
     ivec conn;                          // [4][ne]
     ivec sup_idx, sup_arr, sup_lidx;
@@ -1664,9 +1665,44 @@ void average_fields(des_oracle &o)
 // One step in its two phases (des_params.h, des_halo): everything up to the committed surface
 // heights runs on the local mesh alone -- redundantly on the ghost region -- then the ghost
 // region is refreshed by the exchange, then the end-of-step geometry pass.
+// isostasy_adjustment's loop body (dynearthsol.cxx:506-539): the step without the clock, the
+// temperature update, NMD, the velocity bcs, rotate_stress and compute_dt; velocities are made
+// vertical (and zero on a bottom without Winkler foundation) before update_mesh.
+void isostasy_vel(des_oracle &o)
+{
+    const int nn = o.nn;
+    #pragma omp parallel for default(none) shared(o) firstprivate(nn)
+    for (int i = o.c0; i < o.c1; ++i) {
+        for (int j = 0; j < 2; ++j) o.vel[j*nn + i] = 0;
+        if (!o.p.has_winkler_foundation && (o.bcflag[i] & BOUNDZ0))
+            o.vel[2*nn + i] = 0;
+    }
+}
+
+int isostasy_phase(des_oracle &o, int phase)
+{
+    if (phase == 0) {
+        refresh_elem_cache(o);
+        update_strain_rate(o);
+        compute_dvoldt(o);
+        compute_edvoldt(o);
+        update_stress(o);
+        update_force(o);
+        update_velocity(o);
+        o.l2_residual = calculate_residual_force(o);       // not printed by the reference here; harmless
+        isostasy_vel(o);
+        update_coordinate(o);
+        surface_processes_a(o);
+    } else {
+        update_mesh_b(o);
+    }
+    return 0;
+}
+
 int step_phase(des_oracle &o, int phase)
 {
     const des_params &p = o.p;
+    if (o.iso) return isostasy_phase(o, phase);
     switch (phase) {
     case 0:
         o.steps++;
@@ -1939,6 +1975,8 @@ int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode
 }
 
 int des_oracle_phase(des_oracle *h, int phase) { return step_phase(*h, phase); }
+
+int des_oracle_set_isostasy(des_oracle *h, int on) { h->iso = on != 0; return DES_OK; }
 
 // the exchange of a step: what = 0 nodal {x,y,z,vx,vy,vz,T,dh} of the local nodes idx[0..n),
 // what = 1 {stress, strain, plstrain} of the local elements idx[0..n); buf[i*width + c]

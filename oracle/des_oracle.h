@@ -31,6 +31,9 @@ int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, d
  * (what = 1) state by local index list, compute_dt across ranks */
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global);
 int des_oracle_phase(des_oracle *h, int phase);
+/* 1: des_oracle_step / des_oracle_phase run the body of isostasy_adjustment's loop
+ * (dynearthsol.cxx:506-539) instead of a time step; 0: back to time steps. */
+int des_oracle_set_isostasy(des_oracle *h, int on);
 int des_oracle_halo_pack(des_oracle *h, int kind, const int *idx, int n, double *buf);
 int des_oracle_halo_unpack(des_oracle *h, int kind, const int *idx, int n, const double *buf);
 int des_oracle_dt_partials(des_oracle *h, double out[6], int recompute);
