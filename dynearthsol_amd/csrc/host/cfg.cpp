@@ -288,6 +288,9 @@ void build_params(const Config &c, des_params &p)
         c.b("ic.has_body_force_adjustment"))
         throw Error(31, "hydraulic diffusion / PT loop / global velocity scaling / hydration are outside the offloaded hot path");
 
+    if (c.b("monitor.enabled"))
+        throw Error(31, "monitor.enabled: monitor-point time series (monitor.cxx) are not written by this driver");
+
     // bc, with the normalisations of input.cxx:1247-1292
     p.surface_temperature = c.d("bc.surface_temperature");
     p.winkler_delta_rho = c.d("bc.winkler_delta_rho");

@@ -61,6 +61,18 @@ def test_cfg_rejects_what_the_reference_rejects():
     assert e.value.code == 11
 
 
+def test_features_outside_the_offloaded_path_are_refused_not_ignored():
+    """Options that would change the results or the files written, but are not built: code 31,
+    never a silent no-op."""
+    base = cfgs.make(**cfgs.EP)
+    for ov in ("control.has_PT = yes\n", "control.has_hydraulic_diffusion = yes\n", "control.surface_process_option = 101\n",
+               "mat.phase_change_option = 1\n", "markers.init_marker_option = 2\n", "monitor.enabled = yes\nmonitor.num_points = 1\n",
+               "ic.temperature_option = 90\n", "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n"):
+        with pytest.raises(des.DesError) as e:
+            des.Host(cfg_text=base, overrides=ov)
+        assert e.value.code == 31, ov
+
+
 def test_cfg_list_broadcast_and_bool_spellings():
     h = des.Host(cfg_text=cfgs.make(nmat=2, **cfgs.EVP), overrides="bc.has_water_loading = on\n")
     assert list(h.params.alpha[:2]) == [3e-5, 3e-5]                       # input.cxx:983-989
