@@ -42,6 +42,7 @@
 
 #include "des_dev.h"
 #define DES_LIBM_LDS_TABLES 1     // kernels that call deslibm:: stage its tables in LDS first
+#define DES_LIBM_LDS_WAVES 4      // = DES_BLOCK / 64, one private copy per wavefront
 #include "des_kernels.hpp"
 
 using desk::d4;

@@ -10,6 +10,9 @@
 
 #include "des_params.h"
 #include "des_libm.hpp"
+#if defined(DES_LIBM_LDS_TABLES)
+static_assert(DES_LIBM_LDS_WAVES * 64 == 256, "one LDS table copy per wavefront of a DES_BLOCK workgroup");
+#endif
 
 #define DES_BLOCK 256
 

@@ -36,29 +36,40 @@
 namespace deslibm {
 
 // Table access.  A device kernel may stage the five 128-entry tables in LDS first
-// (lds_stage*(), then every call of that workgroup reads LDS instead of global memory: the two
-// dependent look-ups of a pow() cost ~2 x 64 cycles instead of ~2 x 500 at the low occupancy
-// of the stress kernel); kernels that do not stage them, and the CPU build, read the arrays.
+// (lds_stage*(), then every call of that wavefront reads its LDS copy instead of global memory:
+// E2 93 -> 85 us at 1.1M tets); kernels that do not stage them, and the CPU build, read the arrays.
 #if defined(__HIPCC__) && defined(DES_LIBM_LDS_TABLES)
-static __shared__ double lds_tab[5 * 128];
-// lds_stage_begin() copies (all threads of the workgroup call it, at the top of the kernel);
-// lds_stage_end() is the barrier, to be placed after the kernel's own loads have been issued
-// and before the first deslibm:: call.
+// One private copy per wavefront (DES_LIBM_LDS_WAVES of them per workgroup): a wave runs in
+// lockstep, so its copy needs no workgroup barrier -- a barrier would line up the load / compute
+// / store phases of all waves of the workgroup, which costs more than the staging itself.
+#ifndef DES_LIBM_LDS_WAVES
+#define DES_LIBM_LDS_WAVES 4
+#endif
+static __shared__ double lds_tab[DES_LIBM_LDS_WAVES][5 * 128];
+DES_LIBM_FN double *lds_mine() { return lds_tab[threadIdx.x >> 6]; }
+// lds_stage_begin() copies (every lane of the wave calls it, at the top of the kernel);
+// lds_stage_end() orders the copy before the first deslibm:: call of the wave.
 DES_LIBM_FN void lds_stage_begin()
 {
-    for (int i = threadIdx.x; i < 5 * 128; i += blockDim.x) {
-        const int t = i >> 7, j = i & 127;
-        const double *src = t == 0 ? des_log_invc : t == 1 ? des_log_chi : t == 2 ? des_log_clo : t == 3 ? des_exp_hi : des_exp_tail;
-        lds_tab[i] = src[j];
+    double *t = lds_mine();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = lane + 64 * u;
+        t[j] = des_log_invc[j];
+        t[128 + j] = des_log_chi[j];
+        t[256 + j] = des_log_clo[j];
+        t[384 + j] = des_exp_hi[j];
+        t[512 + j] = des_exp_tail[j];
     }
 }
-DES_LIBM_FN void lds_stage_end() { __syncthreads(); }
+DES_LIBM_FN void lds_stage_end() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 DES_LIBM_FN void lds_stage() { lds_stage_begin(); lds_stage_end(); }
-#define DES_T_INVC(i) lds_tab[i]
-#define DES_T_CHI(i)  lds_tab[128 + (i)]
-#define DES_T_CLO(i)  lds_tab[256 + (i)]
-#define DES_T_EHI(i)  lds_tab[384 + (i)]
-#define DES_T_ETL(i)  lds_tab[512 + (i)]
+#define DES_T_INVC(i) lds_mine()[i]
+#define DES_T_CHI(i)  lds_mine()[128 + (i)]
+#define DES_T_CLO(i)  lds_mine()[256 + (i)]
+#define DES_T_EHI(i)  lds_mine()[384 + (i)]
+#define DES_T_ETL(i)  lds_mine()[512 + (i)]
 #else
 #define DES_T_INVC(i) des_log_invc[i]
 #define DES_T_CHI(i)  des_log_chi[i]
@@ -92,35 +103,32 @@ DES_LIBM_FN double round_shift(double t, uint64_t *ki)
 
 // ---- exp ------------------------------------------------------------------------------
 // exp(x + xtail), |xtail| << |x|.  x = k ln2/128 + r; result = 2^(k/128) (1 + tail + r + r^2 P(r)).
+// Straight-line code: the argument is clamped into the range where the main path is valid and
+// the out-of-range / NaN results are selected at the end (on the GPU a branch costs more than
+// the few selects, and this function sits in the per-element creep law).
 DES_LIBM_FN double exp_core(double x, double xtail)
 {
-    const uint64_t ax = bits(x) & 0x7fffffffffffffffULL;
-    if (ax >= 0x4086000000000000ULL) {               // |x| >= 704 (or inf / nan)
-        if (ax > 0x7ff0000000000000ULL) return x + x;
-        if (x > 709.782712893384) return __builtin_inf();
-        if (x < -745.2) return 0.0;
-    }
-    if (ax < 0x3c90000000000000ULL)                 // |x| < 2^-54
-        return 1.0 + x;
+    double xc = (x > -746.0) ? x : -746.0;                  // NaN lands here too
+    xc = (xc < 710.0) ? xc : 710.0;
     uint64_t ki;
-    double kd = round_shift(des_exp_invln2N * x, &ki);
-    double r = fma_(kd, -des_exp_ln2hiN, x);          // exact: ln2hiN has 42 bits, |k| < 2^18
+    const double kd = round_shift(des_exp_invln2N * xc, &ki);
+    double r = fma_(kd, -des_exp_ln2hiN, xc);               // exact: ln2hiN has 42 bits, |k| < 2^18
     r = fma_(kd, -des_exp_ln2loN, r) + xtail;
     const int64_t n = (int64_t)(ki & 0xfffffffffffffULL) - ((int64_t)1 << 51);
     const int j = (int)(n & 127);
-    const int64_t k = n >> 7;                                  // floor(n / 128)
+    const int64_t k = n >> 7;                                  // floor(n / 128), -1076 .. 1025
     const double r2 = r * r;
     const double tmp = DES_T_ETL(j) + r + r2 * (des_exp_C[0] + r * des_exp_C[1]) + r2 * r2 * (des_exp_C[2] + r * des_exp_C[3]);
-    const double hi = DES_T_EHI(j);
-    if (k > 1000 || k < -1000) {
-        // scale in two steps: 2^k overflows / underflows a double's exponent field on its own
-        const int64_t k1 = k > 0 ? k - 900 : k + 900;
-        const double s1 = dbl(bits(hi) + ((uint64_t)k1 << 52));
-        const double s2 = dbl((uint64_t)(1023 + (k - k1)) << 52);
-        return (s1 + s1 * tmp) * s2;
-    }
-    const double scale = dbl(bits(hi) + ((uint64_t)k << 52));
-    return scale + scale * tmp;
+    // 2^k in two factors, so that neither leaves the exponent range; the second multiplication
+    // is exact unless the result is subnormal or overflows (then it rounds once, as it should)
+    const int64_t k1 = k >> 1, k2 = k - k1;
+    const double s1 = dbl(bits(DES_T_EHI(j)) + ((uint64_t)k1 << 52));
+    const double s2 = dbl((uint64_t)(1023 + k2) << 52);
+    double res = (s1 + s1 * tmp) * s2;
+    res = (x > 709.782712893384) ? __builtin_inf() : res;
+    res = (x < -745.2) ? 0.0 : res;
+    res = (x != x) ? x + x : res;
+    return res;
 }
 
 DES_LIBM_FN double exp(double x) { return exp_core(x, 0.0); }
@@ -155,42 +163,33 @@ DES_LIBM_FN double log_dd(uint64_t ix, int64_t kadj, double *lo_out)
 
 DES_LIBM_FN double pow(double x, double y)
 {
-    uint64_t ix = bits(x);
-    const uint64_t iy = bits(y);
-    const uint64_t ay = iy & 0x7fffffffffffffffULL;
-    if (ay == 0) return 1.0;                                   // pow(x, +-0) = 1, NaN included
-    if (ix == 0x3ff0000000000000ULL) return 1.0;               // pow(1, y) = 1
-    if (ay > 0x7ff0000000000000ULL || (ix & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL)
-        return x + y;                                          // NaN
-    if (ix >> 63) {                                            // negative (or -0)
-        if ((ix << 1) != 0) return dbl(0x7ff8000000000000ULL);  // x < 0: not on the path
-        ix = 0;                                                // -0 treated as +0 (even powers only matter)
-    }
-    if (ix == 0) return (iy >> 63) ? __builtin_inf() : 0.0;
-    if (ix == 0x7ff0000000000000ULL) return (iy >> 63) ? 0.0 : __builtin_inf();
-    if (ay == 0x7ff0000000000000ULL) {                         // y = +-inf
-        const bool big = ix > 0x3ff0000000000000ULL;
-        return (big != (bool)(iy >> 63)) ? __builtin_inf() : 0.0;
-    }
-    int64_t kadj = 0;
-    if (ix < 0x0010000000000000ULL) {                          // subnormal: scale by 2^52
-        ix = bits(x * 4503599627370496.0);
-        kadj = -52;
-    }
+    const uint64_t ix = bits(x), iy = bits(y);
+    const uint64_t ax = ix & 0x7fffffffffffffffULL, ay = iy & 0x7fffffffffffffffULL;
+    const bool yneg = (iy >> 63) != 0;
+    // main path on a base that is positive, finite and normal (anything else is replaced by 1.5
+    // here and overridden below); subnormal bases are scaled by 2^52
+    const bool x_ok = (ix - 1) < 0x7fefffffffffffffULL;        // 0 < x < inf
+    const bool sub = ix < 0x0010000000000000ULL;
+    uint64_t im = sub ? bits(x * 4503599627370496.0) : ix;
+    im = x_ok ? im : 0x3ff8000000000000ULL;
     double lo;
-    const double hi = log_dd(ix, kadj, &lo);
+    const double hi = log_dd(im, sub ? -52 : 0, &lo);
     const double ehi = y * hi;
     const double elo = y * lo + fma_(y, hi, -ehi);
-    if (!(__builtin_fabs(ehi) < 1.0e300))                      // y*log(x) overflowed: far outside exp's range
-        return ehi > 0 ? __builtin_inf() : 0.0;
-    return exp_core(ehi, elo);
+    double res = exp_core(ehi, elo);                           // y = +-inf: ehi = +-inf gives inf / 0
+    res = (ax == 0) ? (yneg ? __builtin_inf() : 0.0) : res;    // pow(+-0, y); the sign of zero is dropped
+    res = (ix == 0x7ff0000000000000ULL) ? (yneg ? 0.0 : __builtin_inf()) : res;
+    res = ((ix >> 63) && ax != 0) ? dbl(0x7ff8000000000000ULL) : res;      // x < 0: not on the path
+    res = (ax > 0x7ff0000000000000ULL || ay > 0x7ff0000000000000ULL) ? x + y : res;
+    res = (ix == 0x3ff0000000000000ULL || ay == 0) ? 1.0 : res;            // pow(1, y) = pow(x, 0) = 1
+    return res;
 }
 
 // ---- sin / cos ------------------------------------------------------------------------
 // x = n pi/2 + (r + rt), |r| <= pi/4 (+ a hair); returns n mod 4.
 DES_LIBM_FN int rem_pio2(double x, double *r, double *rt)
 {
-    if (__builtin_fabs(x) <= 0.7853981633974483) { *r = x; *rt = 0.0; return 0; }
+    // no shortcut for |x| <= pi/4: fn = 0 there and every step below returns x unchanged
     uint64_t ki;
     const double fn = round_shift(x * des_invpio2, &ki);
     // three 33-bit pieces of pi/2: fn*piece exact for |fn| < 2^20
@@ -224,16 +223,12 @@ DES_LIBM_FN double cos_kernel(double x, double t)
 
 DES_LIBM_FN void sincos(double x, double *s, double *c)
 {
-    if (!(__builtin_fabs(x) < __builtin_inf())) { *s = *c = x - x; return; }
-    double r, t;
+    double r, t;                                     // inf / NaN turn into NaN on their own (inf - inf)
     const int n = rem_pio2(x, &r, &t);
     const double sk = sin_kernel(r, t), ck = cos_kernel(r, t);
-    switch (n) {
-    case 0:  *s = sk;  *c = ck;  break;
-    case 1:  *s = ck;  *c = -sk; break;
-    case 2:  *s = -sk; *c = -ck; break;
-    default: *s = -ck; *c = sk;  break;
-    }
+    const double sv = (n & 1) ? ck : sk, cv = (n & 1) ? sk : ck;
+    *s = (n & 2) ? -sv : sv;
+    *c = ((n + 1) & 2) ? -cv : cv;
 }
 
 DES_LIBM_FN double sin(double x) { double s, c; sincos(x, &s, &c); return s; }
@@ -243,41 +238,31 @@ DES_LIBM_FN double tan(double x) { double s, c; sincos(x, &s, &c); return s / c;
 // ---- atan2 ----------------------------------------------------------------------------
 DES_LIBM_FN double atan_pos(double x)              // x >= 0 (inf allowed)
 {
-    int id;
-    if (x < 0.4375) {
-        if (x < 7.450580596923828125e-09) return x;         // 2^-27
-        id = -1;
-    } else if (x < 1.1875) {
-        if (x < 0.6875) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); }
-        else            { id = 1; x = (x - 1.0) / (x + 1.0); }
-    } else {
-        if (x < 2.4375) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); }
-        else            { id = 3; x = -1.0 / x; }
-    }
-    const double z = x * x;
+    // reduction to |t| <= 7/16 around 0, 1/2, 1, 3/2, inf: t = num/den picked by selects, one division
+    const bool b0 = x < 0.4375, b1 = x < 0.6875, b2 = x < 1.1875, b3 = x < 2.4375;
+    const double num = b0 ? x : b1 ? 2.0 * x - 1.0 : b2 ? x - 1.0 : b3 ? x - 1.5 : -1.0;
+    const double den = b0 ? 1.0 : b1 ? 2.0 + x : b2 ? x + 1.0 : b3 ? 1.0 + 1.5 * x : x;
+    const double hi = b0 ? 0.0 : b1 ? des_atan_hi[0] : b2 ? des_atan_hi[1] : b3 ? des_atan_hi[2] : des_atan_hi[3];
+    const double lo = b0 ? 0.0 : b1 ? des_atan_lo[0] : b2 ? des_atan_lo[1] : b3 ? des_atan_lo[2] : des_atan_lo[3];
+    const double t = num / den;
+    const double z = t * t;
     const double w = z * z;
     const double pe = des_atan_T[0] + w * (des_atan_T[2] + w * (des_atan_T[4] + w * (des_atan_T[6] + w * (des_atan_T[8] + w * des_atan_T[10]))));
     const double po = des_atan_T[1] + w * (des_atan_T[3] + w * (des_atan_T[5] + w * (des_atan_T[7] + w * des_atan_T[9])));
-    const double q = z * (pe + z * po);            // atan(x)/x - 1
-    if (id < 0) return x + x * q;
-    return des_atan_hi[id] + ((x * q + des_atan_lo[id]) + x);
+    const double q = z * (pe + z * po);            // atan(t)/t - 1
+    return hi + ((t * q + lo) + t);
 }
 
 DES_LIBM_FN double atan2(double y, double x)
 {
-    if (x != x || y != y) return x + y;
-    const uint64_t sy = bits(y) >> 63, sx = bits(x) >> 63;
+    const bool sy = (bits(y) >> 63) != 0, sx = (bits(x) >> 63) != 0;
     const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
-    double r;
-    if (ay == 0.0)           r = sx ? des_pi_hi : 0.0;
-    else if (ax == 0.0)      r = des_atan_hi[3];
-    else if (ax == __builtin_inf())
-        r = (ay == __builtin_inf()) ? (sx ? 3.0 * des_atan_hi[1] : des_atan_hi[1]) : (sx ? des_pi_hi : 0.0);
-    else if (ay == __builtin_inf()) r = des_atan_hi[3];
-    else {
-        const double a = atan_pos(ay / ax);
-        r = sx ? des_pi_hi - (a - des_pi_lo) : a;
-    }
+    const double inf = __builtin_inf();
+    // y/0 = inf -> pi/2, 0/x = 0 and y/inf = 0 -> 0 or pi, NaN stays NaN: the main line covers them
+    const double a = atan_pos(ay / ax);
+    double r = sx ? des_pi_hi - (a - des_pi_lo) : a;
+    r = (ay == 0.0 && x == x) ? (sx ? des_pi_hi : 0.0) : r;                                    // includes 0/0
+    r = (ax == inf && ay == inf) ? (sx ? 3.0 * des_atan_hi[1] : des_atan_hi[1]) : r;
     return sy ? -r : r;
 }
 
