@@ -75,7 +75,7 @@ class DesScalars(C.Structure):
     _fields_ = [
         ("dt", C.c_double), ("time", C.c_double), ("l2_residual", C.c_double),
         ("max_surf_vel", C.c_double), ("max_global_vel_mag", C.c_double),
-        ("global_dt_min", C.c_double), ("steps", C.c_longlong), ("status", C.c_int), ("pad_", C.c_int),
+        ("global_dt_min", C.c_double), ("steps", C.c_longlong), ("status", C.c_int), ("n_return_mapping", C.c_int),
         ("avg_time0", C.c_double),
     ]
 

@@ -55,6 +55,9 @@ using desk::d4;
 #ifndef DES_E2_WAVES
 #define DES_E2_WAVES 2
 #endif
+#ifndef DES_E2_WAVES_FAST
+#define DES_E2_WAVES_FAST 3       // first pass of the stress update without the return mapping: 168 VGPRs
+#endif
 #ifndef DES_E3_WAVES
 #define DES_E3_WAVES 2
 #endif
@@ -79,15 +82,17 @@ struct DevClock {
     int status;
     int iso;                 // inside isostasy_adjustment (des_dev_set_isostasy)
     double avg_time0;        // Output::time0 (output.cxx:332)
+    int n_defer;             // elements the first stress pass of this step handed to E2_return_mapping
+    int pad;
 };
 
 // INIT: C part without rotate_stress; AVG: Output::average_fields on the final stress of the step
 enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_AVG = 16 };
 
-enum KernelId { K_E1, K_N1, K_E2, K_N2, K_E3, K_N3, K_S2, K_S3,
+enum KernelId { K_E1, K_N1, K_E2, K_E2R, K_N2, K_E3, K_N3, K_S2, K_S3,
                 K_DTFIN, K_MISC, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
-    "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "N2_nmd_gather",
+    "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "E2_return_mapping", "N2_nmd_gather",
     "E3_nmd_force", "N3_force_velocity_coord", "S2_surface_diffusion",
     "S3_edvacc_step_finalize", "dt_finalize", "misc" };
 
@@ -121,6 +126,9 @@ struct des_dev {
     double *stress, *strain, *strain_rate, *plstrain, *delta_plstrain, *viscosity, *volume,
            *volume_old, *dpressure, *radiogenic;
     int *markers;
+    int *defer_list;                      // [ne] elements set aside by the first stress pass of the step
+    int e2_defer;                         // DES_E2_DEFER: 0 one pass, 1 two passes, 2 (default) chosen per call
+    bool e2_two_pass;                     // the current choice
     int *mono;                            // [ne] (material << 16) | count of single-material elements, else -1
     double *ptab;                         // [nmat][DES_PTAB_CNT][5] property means of single-material elements
     unsigned char *topflag;               // element touches the top surface (Variables::top_elems)
@@ -529,6 +537,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
             clk->time += dt;
         }
         clk->maxdh = 0.0;
+        clk->n_defer = 0;
     }
     if (n0 >= nn) return;                                   // whole block idle (grid padding)
     const bool thermal = p->has_thermal_diffusion;
@@ -631,22 +640,18 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
 // ---- E2 --------------------------------------------------------------------------
 // compute_edvoldt (geometry.cxx:264-272), update_stress (rheology.cxx:728-1026),
 // NMD_stress element part (geometry.cxx:294-296)
-template <class M>
-__global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
-E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
-     int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
-     const double *__restrict__ ntmp, const MatData md,
+// The stress update of element e.  DEFER = 1 (first pass): returns true WITHOUT having stored
+// anything but viscosity[e] when the element needs the Mohr-Coulomb return mapping; the second
+// pass then runs the same code with DEFER = 0 for exactly those elements.
+template <class M, int DEFER>
+__device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
+     const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const MatData &md,
      const double *__restrict__ volume, const double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2)
 {
-    // elements [e_begin, e_begin + e_count): the whole local mesh, or any sub-range of it (ne
-    // stays the SoA plane stride)
-    M::stage_begin();
-    const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
-    if (el >= e_count) return;
-    const int e = e_begin + el;
     const double dt = clk->dt;
     const int4 cn = conn[e];
     const int rheol = p->rheol_type;
@@ -672,6 +677,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     double de[6];
     for (int i = 0; i < 6; ++i) de[i] = edot[i] * dt;
     double dpl = 0.;
+    bool defer = false;
     const double vol = volume[e];
 
     M::stage_end();
@@ -700,7 +706,8 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         double amc, anphi, anpsi, hardn, ten_max;
         double pls = plstrain[e];
         desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
-        double depls = desk::elasto_plastic<M>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s);
+        double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s, &defer);
+        if (DEFER && defer) return true;
         if (depls != 0) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
         dpl = depls;
         break;
@@ -716,7 +723,8 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double sp[6];
         for (int i = 0; i < 6; ++i) sp[i] = s[i];
-        double depls = desk::elasto_plastic<M>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp);
+        double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp, &defer);
+        if (DEFER && defer) return true;
         double spII = desk::second_invariant2(sp);
         if (svII < spII) {
             for (int i = 0; i < 6; ++i) s[i] = sv[i];
@@ -740,7 +748,63 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         dpressure[e] = dp;
         etmp2[e] = dp * vol;
     }
+    return defer;                  // went past the yield pre-filter
 }
+
+// First pass: every element [e_begin, e_begin + e_count) (the whole local mesh, or a sub-range:
+// ne stays the SoA plane stride).  DEFER = 1: elements that need the return mapping are appended
+// to `list` (wave-aggregated: one atomic per wavefront) for E2_return_mapping.
+template <class M, int DEFER>
+__global__ void __launch_bounds__(DES_BLOCK, DEFER ? DES_E2_WAVES_FAST : DES_E2_WAVES)
+E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
+     int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const MatData md,
+     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
+     double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
+     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ list, int *__restrict__ count)
+{
+    M::stage_begin();
+    const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    if (el >= e_count) return;
+    const int e = e_begin + el;
+    const bool defer = e2_element<M, DEFER>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+                                            plstrain, delta_plstrain, viscosity, dpressure, etmp2);
+    // one atomic per wavefront that has such elements; without DEFER only the count is kept
+    // (des_scalars::n_return_mapping, and what the host picks the next call's mode from)
+    const unsigned long long mask = __ballot(defer);
+    if (defer) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(count, __popcll(mask));
+        if (DEFER) {
+            base = __shfl(base, leader);
+            list[base + __popcll(mask & ((1ull << lane) - 1))] = e;
+        }
+    }
+}
+
+// Second pass: the elements the first pass set aside, full stress update with the return mapping
+// (same code, same arithmetic; the order of the list does not matter, every element is its own).
+template <class M>
+__global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
+E2_return_mapping(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
+     int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const MatData md,
+     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
+     double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
+     double *__restrict__ dpressure, double *__restrict__ etmp2, const int *__restrict__ list, const int *__restrict__ count)
+{
+    M::stage_begin();
+    M::stage_end();
+    const int n = *count;
+    for (int i = blockIdx.x * DES_BLOCK + threadIdx.x; i < n; i += gridDim.x * DES_BLOCK)
+        e2_element<M, 0>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+                         plstrain, delta_plstrain, viscosity, dpressure, etmp2);
+}
+
 
 // ---- N2 --------------------------------------------------------------------------
 // NMD_stress gather (geometry.cxx:302-309)
@@ -1577,16 +1641,46 @@ void launch_n1(des_dev *h)
                            h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
 }
 
+// update_stress in two passes when the rheology has a yield surface: the first pass (3 waves
+// per SIMD) sets the few elements that need the return mapping aside, the second one (the same
+// code with the return mapping, 2 waves per SIMD) works that list off.  The list is sparse, so
+// the second pass pays ~8x per element; above DES_E2_DEFER_MAX of the mesh one pass is cheaper.
+// Both give the same bits.  DES_E2_DEFER=0 / 1 pins the mode; default: choose_e2_mode().
+#ifndef DES_E2R_GRID
+#define DES_E2R_GRID 512          // workgroups of the second pass (grid-stride loop): two per CU, all resident
+#endif
+#ifndef DES_E2_DEFER_MAX
+#define DES_E2_DEFER_MAX 0.02
+#endif
+// called whenever the host copy of the clock is fresh (end of des_dev_step / des_dev_phase calls)
+void choose_e2_mode(des_dev *h)
+{
+    if (h->e2_defer == 2) h->e2_two_pass = h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
+}
+
 void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
 {
     if (e_count < 0) e_count = h->ne;
     if (e_count == 0) return;
-    Launch l(h, K_E2);
-    auto k = h->portable_libm ? E2_update_stress<desk::MathPortable> : E2_update_stress<desk::MathOcml>;
-    hipLaunchKernelGGL(k, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
-                       e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
-                       h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
-                       h->etmp2);
+    const bool defer = h->e2_two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
+    int *count = &h->d_clk->n_defer;
+    {
+        Launch l(h, K_E2);
+        auto k = h->portable_libm ? (defer ? E2_update_stress<desk::MathPortable, 1> : E2_update_stress<desk::MathPortable, 0>)
+                                  : (defer ? E2_update_stress<desk::MathOcml, 1> : E2_update_stress<desk::MathOcml, 0>);
+        hipLaunchKernelGGL(k, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                           e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
+                           h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
+                           h->etmp2, h->defer_list, count);
+    }
+    if (defer) {
+        Launch l(h, K_E2R);
+        auto k = h->portable_libm ? E2_return_mapping<desk::MathPortable> : E2_return_mapping<desk::MathOcml>;
+        hipLaunchKernelGGL(k, dim3(std::min(nblk(e_count), DES_E2R_GRID)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                           h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
+                           h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
+                           h->etmp2, h->defer_list, count);
+    }
 }
 
 void launch_n2(des_dev *h)
@@ -1885,7 +1979,7 @@ void des_dev_destroy(des_dev *h)
         h->d_send_eoff, h->d_recv_noff, h->d_recv_eoff, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
-        h->radiogenic, h->markers, h->props, h->mono, h->ptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
+        h->radiogenic, h->markers, h->props, h->mono, h->defer_list, h->ptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
         h->conn_surf, h->ssup_idx, h->ssup_arr, h->topflag, h->dh, h->edvacc,
         h->znew, h->bnormals, h->edge_vec, h->edge_slot };
@@ -1915,6 +2009,9 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     h->device = device;
     h->p = *params;
     {
+        const char *e2d = std::getenv("DES_E2_DEFER");
+        h->e2_defer = (e2d && (e2d[0] == '0' || e2d[0] == '1')) ? e2d[0] - '0' : 2;
+        h->e2_two_pass = h->e2_defer != 0;
         const char *env = std::getenv("DES_LIBM");
         h->portable_libm = env && std::strcmp(env, "portable") == 0;
         if (env && !h->portable_libm && std::strcmp(env, "ocml") != 0) {
@@ -1994,6 +2091,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->volume, (size_t)ne)); CK(dev_alloc(h->volume_old, (size_t)ne)); CK(dev_alloc(h->dpressure, (size_t)ne));
     CK(dev_alloc(h->radiogenic, (size_t)ne)); CK(dev_alloc(h->markers, (size_t)ne * nmat));
     CK(dev_alloc(h->mono, (size_t)ne));
+    CK(dev_alloc(h->defer_list, (size_t)ne));
     if (nmat > 1) {
         CK(dev_alloc(h->props, (size_t)5*ne));
         CK(dev_alloc(h->ptab, (size_t)nmat * DES_PTAB_CNT * 5));
@@ -2391,6 +2489,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         }
         rc = sync_clock(h);
         if (rc) return rc;
+        choose_e2_mode(h);
         const DevClock &c = *h->h_clk;
         out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
         if (h->comm_size > 1) {
@@ -2399,7 +2498,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
             out->l2_residual = std::sqrt(l2sum);
         }
         out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min;
-        out->steps = c.steps; out->status = c.status; out->pad_ = 0; out->avg_time0 = c.avg_time0;
+        out->steps = c.steps; out->status = c.status; out->n_return_mapping = c.n_defer; out->avg_time0 = c.avg_time0;
         return c.status;
     }
     return DES_OK;

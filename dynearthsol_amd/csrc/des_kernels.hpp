@@ -517,11 +517,14 @@ __device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm,
     return io;
 }
 
-// rheology.cxx:312-484 (THREED)
-template <class M>
+// rheology.cxx:312-484 (THREED).  DEFER = 1: an element that gets past the pre-filter is not
+// returned to the yield surface here; *defer is set and the caller hands the element to the
+// second pass (the return mapping with dsyevh3 / dsyevq3 needs 40 more registers than the rest
+// of the stress update and is taken by well under 1 % of the elements of a typical model).
+template <class M, int DEFER = 0>
 __device__ __forceinline__ double elasto_plastic(double bulkm, double shearm, double amc, double anphi,
                                                  double anpsi, double hardn, double ten_max,
-                                                 const double *de, double *s)
+                                                 const double *de, double *s, bool *defer = nullptr)
 {
     elastic(bulkm, shearm, de, s);
     const double YIELD_PREFILTER_MARGIN = 1e-2;            // rheology.cxx:18
@@ -551,6 +554,8 @@ __device__ __forceinline__ double elasto_plastic(double bulkm, double shearm, do
         if (pf[0] - pf[2] * anphi + amc > band && pf[2] - ten_max < -band)
             return 0;
     }
+    if (defer) *defer = true;                  // past the pre-filter (counted; DEFER: handed on)
+    if (DEFER) return 0.0;
     Stress7 io = {s[0], s[1], s[2], s[3], s[4], s[5], 0.0};
     io = mohr_coulomb_return<M>(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, io);
     s[0] = io.s0; s[1] = io.s1; s[2] = io.s2; s[3] = io.s3; s[4] = io.s4; s[5] = io.s5;

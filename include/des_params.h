@@ -226,7 +226,8 @@ typedef struct des_scalars {
     double global_dt_min;
     long long steps;
     int status;                     /* DES_OK or DES_ERR_RUNTIME_NAN (dt <= 0)                      */
-    int pad_;
+    int n_return_mapping;           /* local elements past the yield pre-filter (rheology.cxx:354-361) in
+                                     * the last step, i.e. through dsyevh3 + the return mapping       */
     double avg_time0;               /* Output::time0: time at the first step of the averaging interval */
 } des_scalars;
 

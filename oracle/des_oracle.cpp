@@ -64,6 +64,7 @@ struct des_oracle {
     des_params p;
     int nn, ne;
     int iso = 0;                        // inside isostasy_adjustment (dynearthsol.cxx:496-544)
+    int n_return_mapping = 0;           // elements past the yield pre-filter in the last update_stress
     // topology
     ivec conn;                          // [4][ne]
     ivec sup_idx, sup_arr, sup_lidx;
@@ -397,7 +398,7 @@ const double YIELD_PREFILTER_MARGIN = 1e-2;   // rheology.cxx:18
 // rheology.cxx:312-484 (THREED branch, has_hydraulic_diffusion == false)
 void elasto_plastic(double bulkm, double shearm, double amc, double anphi, double anpsi,
                     double hardn, double ten_max, const double *de, double &depls,
-                    double *s, int &failure_mode)
+                    double *s, int &failure_mode, int *past_prefilter = nullptr)
 {
     elastic(bulkm, shearm, de, s);
     depls = 0;
@@ -414,6 +415,7 @@ void elasto_plastic(double bulkm, double shearm, double amc, double anphi, doubl
         if (pf[0] - pf[2] * anphi + amc > band && pf[2] - ten_max < -band)
             return;
     }
+    if (past_prefilter) *past_prefilter = 1;       // statistics only (des_scalars::n_return_mapping)
     principal_stresses3(s, p, v);
 
     double fs = p[0] - p[2] * anphi + amc;
@@ -844,8 +846,10 @@ void update_stress(des_oracle &o)
     const int ne = o.ne;
     const des_params &p = o.p;
     Mat mat(o);
-    #pragma omp parallel for
+    int n_past = 0;
+    #pragma omp parallel for reduction(+:n_past)
     for (int e = 0; e < ne; e++) {
+        int past = 0;
         double s[6], es[6], edot[6];
         for (int i = 0; i < NSTR; ++i) {
             s[i] = o.stress[i * ne + e];
@@ -893,7 +897,8 @@ void update_stress(des_oracle &o)
             mat.plastic_props(e, o.plstrain[e], amc, anphi, anpsi, hardn, ten_max);
             int failure_mode;
             elasto_plastic(mat.bulkm(e), mat.shearm(e), amc, anphi, anpsi, hardn, ten_max,
-                           de, depls, s, failure_mode);
+                           de, depls, s, failure_mode, &past);
+            n_past += past;
             o.plstrain[e] += depls;
             o.delta_plstrain[e] = depls;
             break;
@@ -914,7 +919,8 @@ void update_stress(des_oracle &o)
             for (int i = 0; i < NSTR; ++i) sp[i] = s[i];
             int failure_mode;
             elasto_plastic(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max,
-                           de, depls, sp, failure_mode);
+                           de, depls, sp, failure_mode, &past);
+            n_past += past;
             double spII = second_invariant2(sp);
 
             if (svII < spII) {
@@ -937,6 +943,7 @@ void update_stress(des_oracle &o)
             o.strain[i * ne + e] = es[i];
         }
     }
+    o.n_return_mapping = n_past;
 }
 
 // geometry.cxx:282-336, element part + nodal gather
@@ -1921,7 +1928,7 @@ int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out)
         out->dt = h->dt; out->time = h->time; out->l2_residual = h->l2_residual;
         out->max_surf_vel = h->max_surf_vel; out->max_global_vel_mag = h->max_global_vel_mag;
         out->global_dt_min = h->global_dt_min; out->steps = h->steps; out->status = h->status;
-        out->pad_ = 0; out->avg_time0 = h->avg_time0;
+        out->n_return_mapping = h->n_return_mapping; out->avg_time0 = h->avg_time0;
     }
     return h->status;
 }

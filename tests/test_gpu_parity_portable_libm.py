@@ -93,14 +93,33 @@ def test_mohr_coulomb_return_bit_exact():
         march.init_from_host(host)
         sc = march.step(60)
         dev, ora = des.DeviceEngine(host), OracleEngine(host)
+        last = []
         for eng in (dev, ora):
             eng.init_from_host(host)
             transplant(march, eng)
             eng.init_geometry()
             eng.set_clock(sc.dt, sc.time, 0)
-            eng.step(1)
+            last.append(eng.step(1))
         assert (ora.download("DELTA_PLSTRAIN") > 0).sum() > host.nelem // 4
         bit_exact(dev, ora)
+        # the same elements went through dsyevh3 + the return mapping (second pass on the device)
+        assert last[0].n_return_mapping == last[1].n_return_mapping >= (ora.download("DELTA_PLSTRAIN") > 0).sum()
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_one_pass_and_two_pass_stress_update_give_the_same_bits(mode, monkeypatch):
+    """DES_E2_DEFER pins the stress update to one pass (return mapping inline) or two (yield
+    candidates set aside for E2_return_mapping); by default the engine picks per call."""
+    monkeypatch.setenv("DES_E2_DEFER", mode)
+    with portable_libm():
+        for kw in (cfgs.YIELD, dict(cfgs.YIELD, rheol="elasto-visco-plastic", tmantle=1573, alpha=3e-5, vmin="1e19")):
+            host = des.Host(cfg_text=cfgs.make(**kw))
+            dev, ora = pair(host)
+            for k in range(4):
+                sd, so = dev.step(25), ora.step(25)
+                assert sd.n_return_mapping == so.n_return_mapping
+                bit_exact(dev, ora, note="mode %s after %d steps" % (mode, 25 * (k + 1)))
+            assert so.n_return_mapping > 0
 
 
 def test_yield_heavy_chaotic_run_bit_exact():
