@@ -7,8 +7,18 @@ import collections, csv, glob, json, sys
 
 NAMES = {"E1_geom_rotate_strainrate<3>": "E1_geom_rotate_strainrate",
          "N1_mass_temperature_dvoldt<1, 1>": "N1_mass_temperature_dvoldt",
-         "E2_update_stress": "E2_update_stress", "N2_nmd_gather": "N2_nmd_gather",
+         "E2_update_stress<desk::MathOcml, 1>": "E2_update_stress", "E2_return_mapping<desk::MathOcml>": "E2_return_mapping",
+         "N2_nmd_gather": "N2_nmd_gather",
          "E3_nmd_force": "E3_nmd_force", "N3_force_velocity_coord": "N3_force_velocity_coord"}
+
+
+def short(name):
+    """'void des_hip::E2_update_stress<desk::MathOcml, 1>(args)' -> 'E2_update_stress<desk::MathOcml, 1>'"""
+    k = name.split("(")[0].replace("void ", "").strip()
+    for ns in ("des_hip::", "(anonymous namespace)::"):
+        if k.startswith(ns):
+            k = k[len(ns):]
+    return k
 
 
 def agg(d, counter):
@@ -17,7 +27,7 @@ def agg(d, counter):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("::")[-1]
+            k = short(r["Kernel_Name"])
             out[k].append(float(r["Counter_Value"]))
     return out
 
