@@ -317,6 +317,9 @@ void create_new_mesh(const Config &cfg, HostMesh &m, const std::string &mesh_fil
     } else if (opt == 1 || opt == 2 || opt == 90 || opt == 91) {
         throw Error(31, "this meshing_option needs TetGen, which is a host-side library of the "
                         "reference; pass a mesh file generated with it (see DESIGN.md)");
+    } else if (opt == 95) {
+        // mesh.cxx:3482-3489 without USEEXODUS
+        throw Error(31, "Error: Install Exodus library and rebuild with 'useexo' turned on in Makefile.");
     } else {
         throw Error(11, "Error: unknown meshing option");
     }

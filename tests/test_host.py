@@ -67,7 +67,8 @@ def test_features_outside_the_offloaded_path_are_refused_not_ignored():
     base = cfgs.make(**cfgs.EP)
     for ov in ("control.has_PT = yes\n", "control.has_hydraulic_diffusion = yes\n", "control.surface_process_option = 101\n",
                "mat.phase_change_option = 1\n", "markers.init_marker_option = 2\n", "monitor.enabled = yes\nmonitor.num_points = 1\n",
-               "ic.temperature_option = 90\n", "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n"):
+               "ic.temperature_option = 90\n", "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n",
+               "mesh.meshing_option = 95\nmesh.meshing_elem_shape = 0\n"):
         with pytest.raises(des.DesError) as e:
             des.Host(cfg_text=base, overrides=ov)
         assert e.value.code == 31, ov
@@ -251,3 +252,29 @@ def test_multi_segment_weak_zone():
     # centroids exactly on a bound are decided by rounding: compare away from the bounds
     sure = (np.abs(np.abs(c[0] - 0.3 * lx) - 1.2 * res) > 1) & (np.abs(np.abs(d2) - 1.2 * res) > 1)
     assert np.array_equal(pls[sure], expect[sure]) and pls.max() == 0.5 and (pls > 0).sum() > 20
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/benchmarks-cores"), reason="reference tree only in the build container")
+def test_every_reference_cfg_is_accepted_or_refused_with_a_reference_exit_code(monkeypatch):
+    """All .cfg files the reference ships: the front-end either builds the model or stops with
+    one of the reference's exit codes -- 10 for the three stale files whose options input.cxx no
+    longer declares (the reference stops on them too), 30 for 2-D-only settings, 31 for features
+    outside the offloaded path (TetGen meshing without a mesh file, PT loop, terrigenous surface
+    processes, Exodus ...); never a crash, never a silent acceptance of an unbuilt feature."""
+    import glob
+    ref = "/root/reference"
+    files = sorted(glob.glob(ref + "/examples/*.cfg") + glob.glob(ref + "/examples/*/*.cfg") +
+                   glob.glob(ref + "/benchmarks-cores/*.cfg") + glob.glob(ref + "/*.cfg"))
+    assert len(files) >= 30
+    outcome = {}
+    for f in files:
+        monkeypatch.chdir(os.path.dirname(f))
+        try:
+            des.Host(cfg_path=f)
+            outcome[os.path.basename(f)] = 0
+        except des.DesError as e:
+            outcome[os.path.basename(f)] = e.code
+    assert set(outcome.values()) <= {0, 10, 30, 31}, outcome
+    assert outcome["test-3d-equ-long.cfg"] == 0 and outcome["test-3d-equ-tiny.cfg"] == 0
+    assert sorted(k for k, v in outcome.items() if v == 10) == ["core-complex-mmg.cfg", "test-3d-equ-big.cfg", "test_gospl_coupling.cfg"]
+    assert outcome["kenner_and_segall.cfg"] == 31 and outcome["test-rect-tiny.cfg"] == 30
