@@ -108,3 +108,32 @@ def test_device_build_gives_the_same_bits():
         cpu, gpu = oracle_libm_eval(fn, *args), des.libm_eval(fn, *args)
         assert np.array_equal(cpu.view(np.uint64), gpu.view(np.uint64)) or \
             (np.isnan(cpu) == np.isnan(gpu)).all() and np.array_equal(cpu[~np.isnan(cpu)].view(np.uint64), gpu[~np.isnan(gpu)].view(np.uint64)), fn
+
+
+def _golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "libm_bits.json")) as f:
+        g = json.load(f)
+    un = lambda h: np.array([int(v, 16) for v in h], dtype=np.uint64).view(np.float64)
+    return {fn: (un(c["x"]), un(c["y"]) if c["y"] is not None else None, np.array([int(v, 16) for v in c["result"]], dtype=np.uint64))
+            for fn, c in g.items()}
+
+
+def _same_bits(got, want_bits):
+    g = got.view(np.uint64)
+    nan = np.isnan(got) & np.isnan(want_bits.view(np.float64))       # any NaN payload / sign
+    return bool(((g == want_bits) | nan).all())
+
+
+def test_cpu_build_reproduces_the_committed_bits():
+    """tests/golden/libm_bits.json (make_libm_golden.py): pins the functions across compilers."""
+    for fn, (x, y, want) in _golden().items():
+        assert _same_bits(oracle_libm_eval(fn, x, y), want), fn
+
+
+@pytest.mark.gpu
+def test_device_build_reproduces_the_committed_bits():
+    import dynearthsol_amd as des
+    for fn, (x, y, want) in _golden().items():
+        assert _same_bits(des.libm_eval(fn, x, y), want), fn
