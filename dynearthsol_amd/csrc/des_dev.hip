@@ -307,7 +307,14 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         double vol;
         d4 rec;
         double rdv = 0.0;                        // >= 1: correct_surface_element rescales this element
-        if (MODE & MODE_C) {
+        // update_mesh only runs on a moving mesh (dynearthsol.cxx:870-873; always in the isostasy
+        // loop): without it volumes and masses keep their values, rotate_stress below still runs
+        const bool remesh_geom = (MODE & MODE_INIT) || p->has_moving_mesh || clk->iso;
+        if ((MODE & MODE_C) && !remesh_geom) {
+            vol = volume[e];
+            const d4 old = mrec[e];
+            rec.x = old.x; rec.y = old.y; rec.z = old.z;
+        } else if (MODE & MODE_C) {
             const double vol_prev = volume[e];
             vol = desk::tet_volume(c);
             if (!(MODE & MODE_INIT) && topflag[e]) {
@@ -1215,7 +1222,7 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
             apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
         m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
         vm[n] = m4;
-        if (p->has_moving_mesh) {
+        if (p->has_moving_mesh || clk->iso) {
             x4.x += v[0] * dt; x4.y += v[1] * dt; x4.z += v[2] * dt;
             xt[n] = x4;
         }
@@ -1356,7 +1363,7 @@ k_s3_finalize(DevClock *__restrict__ clk, int etop, int nsurf_blocks, const int 
     if (threadIdx.x == 0) {
         clk->l2_sum = red[0];
         clk->l2_residual = sqrt(red[0]);
-        clk->max_surf_vel = clk->maxdh / clk->dt;
+        if (do_finalize == 1) clk->max_surf_vel = clk->maxdh / clk->dt;     // part of surface_processes: moving mesh only
     }
 }
 
@@ -1635,7 +1642,7 @@ void launch_dt_finalize(des_dev *h, const double *red)
 
 inline bool surface_diffusion_on(const des_dev *h)
 {
-    return h->p.has_moving_mesh && h->p.surface_process_option == 1 && h->ntop > 0;
+    return (h->p.has_moving_mesh || h->iso) && h->p.surface_process_option == 1 && h->ntop > 0;
 }
 
 // ---- passes of one step, in launch order -----------------------------------------
@@ -1733,6 +1740,7 @@ void launch_n3(des_dev *h)
 // diffusion of the owned surface nodes
 void launch_s2(des_dev *h, long long step_no)
 {
+    if (!(h->p.has_moving_mesh || h->iso)) return;          // surface_processes is part of update_mesh
     if (h->ntop > 0) {
         Launch l(h, K_S2);
         hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
@@ -1748,13 +1756,13 @@ void launch_s2(des_dev *h, long long step_no)
 void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
 {
     Launch l(h, K_S3);
-    const bool surf = h->p.has_moving_mesh && h->ntop > 0;
+    const bool surf = (h->p.has_moving_mesh || h->iso) && h->ntop > 0;
     const int nsb = (edvacc && surface_diffusion_on(h)) ? nblk(h->etop) : 0;
     const int nzb = (commit && surf) ? nblk(h->ntop) : 0;
     const int nown = h->o1 - h->o0;
     hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + nzb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb,
                        h->conn_surf, h->xt, h->dh_n, h->edvacc, h->res_part, node_blocks(h), h->ntop, nzb, h->top_nodes,
-                       h->znew, h->o0, h->o1, (int)finalize);
+                       h->znew, h->o0, h->o1, finalize ? ((h->p.has_moving_mesh || h->iso) ? 1 : 2) : 0);
 }
 
 // ---- halo exchange through RCCL on the engine's stream ---------------------------
@@ -2453,10 +2461,6 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
 {
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
-    if (!h->p.has_moving_mesh) {
-        g_last_error = "control.has_moving_mesh = no is not offloaded";
-        return DES_ERR_UNSUPPORTED;
-    }
     refresh_props(h);
     const bool multi = h->nnbr > 0;
     const bool iso = h->iso;

@@ -102,6 +102,22 @@ def test_option_matrix_bit_exact(name, overrides):
     assert_bit_exact(dev, ora)
 
 
+@pytest.mark.parametrize("name,kw,overrides", [
+    ("ep_quasi_static", cfgs.EP, "control.has_moving_mesh = no\n"),
+    ("elastic_geotherm_dynamic", dict(cfgs.EVP, rheol="elastic"), "control.has_moving_mesh = no\ncontrol.is_quasi_static = no\ncontrol.fixed_dt = 1e-2\n"),
+    ("ep_two_materials_no_nmd", dict(cfgs.EP, nmat=2), "control.has_moving_mesh = no\ncontrol.is_using_mixed_stress = no\n"),
+])
+def test_fixed_mesh_runs_bit_exact(name, kw, overrides):
+    """control.has_moving_mesh = no: main() skips update_mesh (dynearthsol.cxx:870-873) -- no
+    coordinate update, no surface processes, volumes and masses keep their initial values (also the
+    thermal mass, although rho(T) changes) -- while rotate_stress and compute_dt still run."""
+    host, dev, ora = pair(kw, overrides=overrides)
+    sd, so = dev.step(35), ora.step(35)
+    assert (sd.dt, sd.time, sd.steps, sd.max_surf_vel) == (so.dt, so.time, so.steps, so.max_surf_vel)
+    assert np.array_equal(dev.download("COORD"), host.array("coord"))
+    assert_bit_exact(dev, ora)
+
+
 def test_thermal_diffusion_with_a_geotherm_bit_exact():
     # elastic rheology keeps libm out; the geotherm makes update_temperature and rho(T) matter
     host, dev, ora = pair(dict(cfgs.EVP, rheol="elastic"))
