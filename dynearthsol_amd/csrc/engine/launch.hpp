@@ -1,0 +1,271 @@
+// engine/launch.hpp -- Host side: allocation helpers and the launch of every pass, in step order.
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// =====================================================================================
+// host side of the engine
+// =====================================================================================
+template <typename T>
+int dev_alloc(T *&ptr, size_t count)
+{
+    ptr = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)&ptr, count * sizeof(T));
+    if (e != hipSuccess) { g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return DES_ERR_RESOURCE; }
+    return DES_OK;
+}
+
+template <typename T>
+int dev_upload(T *dst, const T *src, size_t count, hipStream_t s)
+{
+    if (count == 0) return DES_OK;
+    HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return DES_OK;
+}
+
+inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
+// grids are rounded up to a multiple of 8 so the XCD-aware block map covers every chunk
+inline int nblk8(long long n) { int b = nblk(n); return (b + 7) / 8 * 8; }
+
+struct Launch {
+    des_dev *h; int k; ProfRec rec; bool on;
+    Launch(des_dev *h_, int k_) : h(h_), k(k_), on(h_->prof) {
+        if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, h->stream); }
+    }
+    ~Launch() { if (on) { hipEventRecord(rec.b, h->stream); h->prof_recs.push_back(rec); } }
+};
+
+inline MatData mat_data(const des_dev *h) { return MatData{ h->markers, h->mono, h->props, h->ptab }; }
+
+void refresh_props(des_dev *h)
+{
+    if (!h->markers_dirty) return;
+    Launch l(h, K_MISC);
+    hipLaunchKernelGGL(k_props, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->markers, h->props, h->mono, h->ne);
+    h->markers_dirty = false;
+}
+
+template <int MODE>
+void launch_e1(des_dev *h)
+{
+    Launch l(h, K_E1);
+    const int nb = nblk(h->ne);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(h->ne)), dim3(DES_BLOCK), 0, h->stream,
+                       h->d_p, h->d_clk, h->ne, nb, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
+                       h->topflag, h->stress, h->strain, h->plstrain, h->volume, h->volume_old, h->strain_rate,
+                       h->mrec, h->ttmp);
+}
+
+// Output::average_fields (output.cxx:327-370) on the end-of-step fields, i.e. after the C part
+// of E1.  A kernel of its own: fused into E1 it cost that kernel a wave of occupancy (186 VGPRs;
+// E1 117 us instead of 74 + 30 for this pure stream of 168 B per element).
+__global__ void __launch_bounds__(DES_BLOCK)
+k_average_fields(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne,
+                 const double *__restrict__ stress, const double *__restrict__ strain,
+                 const double *__restrict__ delta_plstrain, double *__restrict__ stress_avg,
+                 double *__restrict__ dplstrain_avg, double *__restrict__ strain0)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    if (clk->steps % p->quality_check_step_interval == 1) {
+        if (e == 0) clk->avg_time0 = clk->time;
+        for (int i = 0; i < 6; ++i) {
+            stress_avg[(size_t)i*ne + e] = stress[(size_t)i*ne + e];
+            strain0[(size_t)i*ne + e] = strain[(size_t)i*ne + e];
+        }
+        dplstrain_avg[e] = delta_plstrain[e];
+    } else {
+        for (int i = 0; i < 6; ++i) stress_avg[(size_t)i*ne + e] += stress[(size_t)i*ne + e];
+        dplstrain_avg[e] += delta_plstrain[e];
+    }
+}
+
+// end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
+void launch_e1_end(des_dev *h, long long step_no, bool with_next)
+{
+    const bool do_dt = (step_no % 10 == 0);
+    const int sel = (with_next ? 1 : 0) | (do_dt ? 2 : 0);
+    switch (sel) {
+    case 0: launch_e1<MODE_C>(h); break;
+    case 1: launch_e1<MODE_C | MODE_A>(h); break;
+    case 2: launch_e1<MODE_C | MODE_DT>(h); break;
+    case 3: launch_e1<MODE_C | MODE_A | MODE_DT>(h); break;
+    }
+    if (h->p.is_outputting_averaged_fields) {
+        Launch l(h, K_MISC);
+        hipLaunchKernelGGL(k_average_fields, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ne,
+                           h->stress, h->strain, h->delta_plstrain, h->stress_avg, h->dplstrain_avg, h->strain0);
+    }
+}
+
+// coordinates at the first step of an averaging interval (output.cxx:334-338)
+__global__ void k_avg_coord0(int nn, const d4 *__restrict__ xt, double *__restrict__ coord_avg0)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nn) return;
+    const d4 c = xt[n];
+    coord_avg0[n] = c.x; coord_avg0[(size_t)nn + n] = c.y; coord_avg0[(size_t)2*nn + n] = c.z;
+}
+
+void launch_avg_coord0(des_dev *h, long long step_no)
+{
+    if (h->p.is_outputting_averaged_fields && step_no % h->p.quality_check_step_interval == 1)
+        hipLaunchKernelGGL(k_avg_coord0, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->nn, h->xt, h->coord_avg0);
+}
+
+// node workgroups: ceil(owned nodes / nodes per workgroup), and the grid rounded up to the 8 XCDs
+// The node kernels run over EVERY local node: on a decomposed mesh the ghost region is computed
+// redundantly (des_halo); only the reductions are restricted to the owned range [o0, o1).
+inline int node_blocks(const des_dev *h) { return (h->nn + h->npb - 1) / h->npb; }
+inline int node_grid(const des_dev *h) { return (node_blocks(h) + 7) / 8 * 8; }
+
+// nodes per node-kernel workgroup: 256, or 64 while that leaves fewer than two workgroups per CU
+// (a 137k-tet mesh has 31k nodes = 120 workgroups of 256 on 256 CUs, each walking 4-5 incidence
+// tiles one after the other)
+void choose_npb(des_dev *h)
+{
+    const char *env = std::getenv("DES_NPB");
+    const int nown = h->nn;
+    h->npb = (nown < 512 * DES_BLOCK) ? 64 : DES_BLOCK;
+    if (env && (std::atoi(env) == 64 || std::atoi(env) == 128 || std::atoi(env) == 256)) h->npb = std::atoi(env);
+}
+
+// compute_mass gather alone (N1 without the temperature / dvoldt parts)
+void launch_mass_gather(des_dev *h)
+{
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<0, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
+                       h->d_p, h->d_clk, 0, h->nn, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp,
+                       mat_data(h), h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+}
+
+void launch_dt_finalize(des_dev *h, const double *red)
+{
+    Launch l(h, K_DTFIN);
+    hipLaunchKernelGGL(k_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk, red);
+}
+
+inline bool surface_diffusion_on(const des_dev *h)
+{
+    return (h->p.has_moving_mesh || h->iso) && h->p.surface_process_option == 1 && h->ntop > 0;
+}
+
+// ---- passes of one step, in launch order -----------------------------------------
+void launch_n1(des_dev *h)
+{
+    Launch l(h, K_N1);
+    const int nbn = node_blocks(h);
+    if (h->const_mass)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 1>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
+                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, mat_data(h),
+                           h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(N1_mass_temperature_dvoldt<1, 0>), dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream,
+                           h->d_p, h->d_clk, 0, h->nn, nbn, h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->mrec, h->ttmp, mat_data(h),
+                           h->ne, h->xt, h->vm, h->volume_n, h->tmass, h->ymass, h->ntmp);
+}
+
+// update_stress in two passes when the rheology has a yield surface: the first pass (3 waves
+// per SIMD) sets the few elements that need the return mapping aside, the second one (the same
+// code with the return mapping, 2 waves per SIMD) works that list off.  The list is sparse, so
+// the second pass pays ~8x per element; above DES_E2_DEFER_MAX of the mesh one pass is cheaper.
+// Both give the same bits.  DES_E2_DEFER=0 / 1 pins the mode; default: choose_e2_mode().
+#ifndef DES_E2R_GRID
+#define DES_E2R_GRID 512          // workgroups of the second pass (grid-stride loop): two per CU, all resident
+#endif
+#ifndef DES_E2_DEFER_MAX
+#define DES_E2_DEFER_MAX 0.02
+#endif
+// called whenever the host copy of the clock is fresh (end of des_dev_step / des_dev_phase calls)
+void choose_e2_mode(des_dev *h)
+{
+    if (h->e2_defer == 2) h->e2_two_pass = h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
+}
+
+void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
+{
+    if (e_count < 0) e_count = h->ne;
+    if (e_count == 0) return;
+    const bool defer = h->e2_two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
+    int *count = &h->d_clk->n_defer;
+    {
+        Launch l(h, K_E2);
+        auto k = h->portable_libm ? (defer ? E2_update_stress<desk::MathPortable, 1> : E2_update_stress<desk::MathPortable, 0>)
+                                  : (defer ? E2_update_stress<desk::MathOcml, 1> : E2_update_stress<desk::MathOcml, 0>);
+        hipLaunchKernelGGL(k, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                           e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
+                           h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
+                           h->etmp2, h->defer_list, count);
+    }
+    if (defer) {
+        Launch l(h, K_E2R);
+        auto k = h->portable_libm ? E2_return_mapping<desk::MathPortable> : E2_return_mapping<desk::MathOcml>;
+        hipLaunchKernelGGL(k, dim3(std::min(nblk(e_count), DES_E2R_GRID)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                           h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
+                           h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
+                           h->etmp2, h->defer_list, count);
+    }
+}
+
+void launch_n2(des_dev *h)
+{
+    Launch l(h, K_N2);
+    // one double per incidence: the lightest gather, best with at most 128 nodes per workgroup
+    // even on large meshes (1.1M tets: 22.7 us at 256, 17.6 at 128)
+    const int npb2 = std::min(h->npb, 128), nb2 = (h->nn + npb2 - 1) / npb2;
+    hipLaunchKernelGGL(N2_nmd_gather, dim3((nb2 + 7) / 8 * 8), dim3(DES_BLOCK), 0, h->stream, 0, h->nn, nb2, npb2, h->sup_idx,
+                       h->sup_pack, h->etmp2, h->volume_n, h->ntmp);
+}
+
+// `facets`: this launch also carries the stress-bc facet workgroups (once per step)
+void launch_e3(des_dev *h, int e_begin = 0, int e_count = -1, bool facets = true)
+{
+    if (e_count < 0) e_count = h->ne;
+    const int nbe8 = nblk8(e_count), nbf = facets ? nblk(h->nbcf) : 0;
+    if (nbe8 + nbf == 0) return;
+    Launch l(h, K_E3);
+    hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p,
+                       (int)(h->p.is_using_mixed_stress && !h->iso), h->ne, e_begin, e_count,
+                       nblk(e_count), nbe8,
+                       h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->dpressure, h->stress, h->ftmp,
+                       facets ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
+}
+
+void launch_n3(des_dev *h)
+{
+    Launch l(h, K_N3);
+    const int nown = h->o1 - h->o0;
+    hipLaunchKernelGGL(N3_force_velocity_coord, dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->o0, h->o1,
+                       h->nn, h->nn_global, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx,
+                       h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
+                       h->force, h->fres, h->res_part);
+}
+
+// surface_processes (bc.cxx:1709-1872) as far as the device state is concerned, first part:
+// diffusion of the owned surface nodes
+void launch_s2(des_dev *h, long long step_no)
+{
+    if (!(h->p.has_moving_mesh || h->iso)) return;          // surface_processes is part of update_mesh
+    if (h->ntop > 0) {
+        Launch l(h, K_S2);
+        hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
+                           (int)(h->p.surface_process_option == 1), h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf,
+                           h->etop, h->xt, h->o0, h->o1, h->dh, h->dhacc, h->znew, h->dh_n);
+    }
+    if (h->ntop > 0 && step_no != 0 && step_no % h->p.quality_check_step_interval == 0)
+        hipLaunchKernelGGL(k_dhacc_reset, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->ntop,
+                           h->top_nodes, h->dhacc);
+}
+
+// commit of the new surface heights / edvacc_surf / end-of-step scalars (k_s3_finalize)
+void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
+{
+    Launch l(h, K_S3);
+    const bool surf = (h->p.has_moving_mesh || h->iso) && h->ntop > 0;
+    const int nsb = (edvacc && surface_diffusion_on(h)) ? nblk(h->etop) : 0;
+    const int nzb = (commit && surf) ? nblk(h->ntop) : 0;
+    const int nown = h->o1 - h->o0;
+    hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + nzb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb,
+                       h->conn_surf, h->xt, h->dh_n, h->edvacc, h->res_part, node_blocks(h), h->ntop, nzb, h->top_nodes,
+                       h->znew, h->o0, h->o1, finalize ? ((h->p.has_moving_mesh || h->iso) ? 1 : 2) : 0);
+}

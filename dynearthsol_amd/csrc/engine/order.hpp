@@ -1,0 +1,160 @@
+// engine/order.hpp -- Engine-internal (Morton) order and the translation tables.
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// ---- internal data order ------------------------------------------------------------
+// The reference numbers nodes and elements along x only (mesh.cxx:2742-2792): 256 consecutive
+// nodes of a TetGen mesh are a thin slice scattered over the whole y-z section, so a workgroup's
+// gathers hardly share anything (test-3d-big at 460 m: every element record is fetched by 2.8
+// node workgroups, every node record by 12 element workgroups; on a Morton order 1.6 and 2.6).
+// With the coordinates at hand (des_mesh::coord) the engine therefore keeps its arrays in Morton
+// order -- nodes within [0, owned_begin), [owned_begin, owned_end), [owned_end, nnode) so that the
+// owned range stays a range; elements by centroid, those touching the low / high halo first /
+// last.  Only names change: every list keeps the caller's ORDER (the support lists stay in
+// ascending caller element id = the reference's summation order), and upload / download /
+// halo lists / reported indices translate at the boundary.
+struct PermMesh {
+    std::vector<int> n_new2old, n_old2new, e_new2old, e_old2new;
+    std::vector<int> conn, sup_idx, sup_arr, sup_lidx, top_nodes, conn_surf, top_elems;
+    std::vector<unsigned> bcflag;
+    std::vector<int> bf_elem[DES_NBDRY], bnodes[DES_NBDRY];
+    des_mesh view;
+};
+
+inline unsigned long long morton3(unsigned x, unsigned y, unsigned z)
+{
+    auto spread = [](unsigned long long v) {                 // 21 bits -> every third bit
+        v &= 0x1fffffULL;
+        v = (v | v << 32) & 0x1f00000000ffffULL;
+        v = (v | v << 16) & 0x1f0000ff0000ffULL;
+        v = (v | v << 8) & 0x100f00f00f00f00fULL;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+        v = (v | v << 2) & 0x1249249249249249ULL;
+        return v;
+    };
+    return spread(x) | spread(y) << 1 | spread(z) << 2;
+}
+
+void build_perm_mesh(const des_mesh *in, PermMesh &pm)
+{
+    const int nn = in->nnode, ne = in->nelem;
+    const double *X = in->coord;
+    double lo[3], hi[3], ext = 0;
+    for (int d = 0; d < 3; ++d) {
+        lo[d] = hi[d] = X[(size_t)d * nn];
+        for (int n = 0; n < nn; ++n) { lo[d] = std::min(lo[d], X[(size_t)d*nn + n]); hi[d] = std::max(hi[d], X[(size_t)d*nn + n]); }
+        ext = std::max(ext, hi[d] - lo[d]);
+    }
+    const double scale = ext > 0 ? 2097151.0 / ext : 0.0;    // cubic cells: one scale for all axes
+    auto code = [&](double x, double y, double z) {
+        return morton3((unsigned)((x - lo[0]) * scale), (unsigned)((y - lo[1]) * scale), (unsigned)((z - lo[2]) * scale));
+    };
+    const int ob = in->owned_begin, oe = in->owned_end > 0 ? in->owned_end : nn;
+    {
+        std::vector<std::pair<unsigned long long, int> > key((size_t)nn);
+        for (int n = 0; n < nn; ++n) key[n] = std::make_pair(code(X[n], X[(size_t)nn + n], X[(size_t)2*nn + n]), n);
+        // Morton order inside each of the three id ranges (the pairs break ties by caller id)
+        std::sort(key.begin(), key.begin() + ob);
+        std::sort(key.begin() + ob, key.begin() + oe);
+        std::sort(key.begin() + oe, key.end());
+        pm.n_new2old.resize((size_t)nn); pm.n_old2new.resize((size_t)nn);
+        for (int i = 0; i < nn; ++i) { pm.n_new2old[i] = key[i].second; pm.n_old2new[key[i].second] = i; }
+    }
+    {
+        std::vector<std::pair<unsigned long long, int> > key((size_t)ne);
+        for (int e = 0; e < ne; ++e) {
+            double c[3] = {0, 0, 0};
+            unsigned long long grp = 1;
+            bool touches_lo = false, touches_hi = false;
+            for (int i = 0; i < 4; ++i) {
+                const int n = in->connectivity[(size_t)i*ne + e];
+                for (int d = 0; d < 3; ++d) c[d] += X[(size_t)d*nn + n] / 4;
+                touches_lo |= n < ob; touches_hi |= n >= oe;
+            }
+            if (touches_lo) grp = 0; else if (touches_hi) grp = 2;
+            key[e] = std::make_pair(grp << 62 | code(c[0], c[1], c[2]) >> 2, e);      // group, then Morton
+        }
+        std::sort(key.begin(), key.end());
+        pm.e_new2old.resize((size_t)ne); pm.e_old2new.resize((size_t)ne);
+        for (int i = 0; i < ne; ++i) { pm.e_new2old[i] = key[i].second; pm.e_old2new[key[i].second] = i; }
+    }
+    const std::vector<int> &nmap = pm.n_old2new, &emap = pm.e_old2new;
+    pm.conn.resize((size_t)4*ne);
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < ne; ++e) pm.conn[(size_t)i*ne + emap[e]] = nmap[in->connectivity[(size_t)i*ne + e]];
+    pm.sup_idx.assign((size_t)nn + 1, 0);
+    for (int i = 0; i < nn; ++i) {
+        const int n = pm.n_new2old[i];
+        pm.sup_idx[i + 1] = pm.sup_idx[i] + (in->support_idx[n + 1] - in->support_idx[n]);
+    }
+    pm.sup_arr.resize((size_t)pm.sup_idx[nn]); pm.sup_lidx.resize((size_t)pm.sup_idx[nn]);
+    for (int i = 0; i < nn; ++i) {
+        const int n = pm.n_new2old[i];
+        int k2 = pm.sup_idx[i];
+        for (int k = in->support_idx[n]; k < in->support_idx[n + 1]; ++k, ++k2) {   // caller's order kept
+            pm.sup_arr[k2] = emap[in->support_arr[k]];
+            pm.sup_lidx[k2] = in->support_lidx[k];
+        }
+    }
+    pm.bcflag.resize((size_t)nn);
+    for (int i = 0; i < nn; ++i) pm.bcflag[i] = in->bcflag[pm.n_new2old[i]];
+    pm.view = *in;
+    for (int b = 0; b < DES_NBDRY; ++b) {
+        pm.bf_elem[b].resize((size_t)in->nbfacets[b]);
+        for (int q = 0; q < in->nbfacets[b]; ++q) pm.bf_elem[b][q] = emap[in->bfacet_elem[b][q]];
+        pm.bnodes[b].resize((size_t)in->nbnodes[b]);
+        for (int q = 0; q < in->nbnodes[b]; ++q) pm.bnodes[b][q] = nmap[in->bnodes[b][q]];
+        pm.view.bfacet_elem[b] = pm.bf_elem[b].data();
+        pm.view.bnodes[b] = pm.bnodes[b].data();
+    }
+    pm.top_nodes.resize((size_t)in->ntop);
+    for (int i = 0; i < in->ntop; ++i) pm.top_nodes[i] = nmap[in->top_nodes[i]];
+    pm.conn_surf.assign(in->connectivity_surface, in->connectivity_surface + (size_t)4 * in->etop);
+    for (int m = 0; m < 3; ++m)
+        for (int k = 0; k < in->etop; ++k) pm.conn_surf[(size_t)m * in->etop + k] = nmap[in->connectivity_surface[(size_t)m * in->etop + k]];
+    pm.top_elems.resize((size_t)in->ntop_elems);
+    for (int i = 0; i < in->ntop_elems; ++i) pm.top_elems[i] = emap[in->top_elems[i]];
+    pm.view.connectivity = pm.conn.data();
+    pm.view.support_idx = pm.sup_idx.data(); pm.view.support_arr = pm.sup_arr.data(); pm.view.support_lidx = pm.sup_lidx.data();
+    pm.view.bcflag = pm.bcflag.data();
+    pm.view.top_nodes = pm.top_nodes.data();
+    pm.view.connectivity_surface = pm.conn_surf.data();
+    pm.view.top_elems = pm.top_elems.data();
+    pm.view.coord = nullptr;
+}
+
+// which index space a plain field lives in: 1 nodal, 2 elemental, 0 neither (surface lists)
+int field_space(int field)
+{
+    switch (field) {
+    case DES_F_FORCE: case DES_F_FORCE_RESIDUAL: case DES_F_COORD0: case DES_F_VOLUME_N: case DES_F_TMASS:
+    case DES_F_DHACC: case DES_F_NTMP: case DES_F_COORD_AVG0: return 1;
+    case DES_F_STRESS: case DES_F_STRAIN: case DES_F_STRAIN_RATE: case DES_F_PLSTRAIN: case DES_F_DELTA_PLSTRAIN:
+    case DES_F_VISCOSITY: case DES_F_VOLUME: case DES_F_VOLUME_OLD: case DES_F_DPRESSURE: case DES_F_RADIOGENIC:
+    case DES_F_STRESS_AVG: case DES_F_DPLSTRAIN_AVG: case DES_F_STRAIN0: return 2;
+    default: return 0;
+    }
+}
+
+// SoA planes [ncomp][n] (or rows of `row` items when ncomp == 0) between the caller's numbering
+// and the engine's; `to_dev`: out[new] = in[new2old[new]], else out[new2old[new]] = in[new]
+template <typename T>
+void permute_planes(const T *in, T *out, size_t n, size_t ncomp, size_t row, const std::vector<int> &new2old, bool to_dev)
+{
+    if (ncomp == 0) {                                   // AoS rows (elemmarkers)
+        for (size_t i = 0; i < n; ++i) {
+            const size_t o = (size_t)new2old[i];
+            const T *src = in + (to_dev ? o : i) * row;
+            T *dst = out + (to_dev ? i : o) * row;
+            for (size_t k = 0; k < row; ++k) dst[k] = src[k];
+        }
+        return;
+    }
+    for (size_t c = 0; c < ncomp; ++c)
+        for (size_t i = 0; i < n; ++i) {
+            const size_t o = (size_t)new2old[i];
+            if (to_dev) out[c*n + i] = in[c*n + o]; else out[c*n + o] = in[c*n + i];
+        }
+}
+
+struct FieldInfo { int kind; long long count; };   // kind: 0 none, 1 elem plane array, 2 nodal plane array, ...

@@ -1,0 +1,89 @@
+// passes/common.hpp -- Element material data shared by the passes: per-element marker mix, property means, k_props / k_ptab.
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+struct ElemProps { double bulkm, shearm, phi, cp, k; };
+
+// What the kernels know about the materials of an element (refresh_elem_cache,
+// matprops.cxx:259-303, redone whenever the marker counts change):
+//   markers [ne][nmat]  the counts themselves
+//   mono    [ne]        (material << 16) | count where one material holds every marker, else -1:
+//                       4 bytes per element and pass instead of 4*nmat + 40
+//   props   [5][ne]     bulkm, shearm, phi, cp, k of every element (nmat > 1 only)
+//   ptab    [nmat][DES_PTAB_CNT][5]  the same five means for a single-material element with
+//                       `count` markers (the means are count-dependent in the last bit:
+//                       count / (count / s)), so those elements read a cached table row
+#define DES_PTAB_CNT 64
+struct MatData { const int *markers; const int *mono; const double *props; const double *ptab; };
+
+__device__ __forceinline__ desk::Mix mix_of(const MatData &md, int nmat, int e)
+{
+    const int mo = md.mono[e];
+    desk::Mix mx;
+    if (mo >= 0) { mx.mk = nullptr; mx.mat = mo >> 16; mx.cnt = mo & 0xffff; }
+    else         { mx.mk = md.markers + (size_t)e * nmat; mx.mat = -1; mx.cnt = 0; }
+    return mx;
+}
+
+__device__ __forceinline__ ElemProps load_props(const des_params *p, const MatData &md, const desk::Mix &mx, int ne, int e)
+{
+    ElemProps r;
+    if (!md.props) {                                       // nmat == 1: the means are the values (matprops.cxx:118, 136)
+        r.bulkm = p->bulk_modulus[0]; r.shearm = p->shear_modulus[0]; r.phi = p->porosity[0];
+        r.cp = p->heat_capacity[0]; r.k = p->therm_cond[0];
+    } else if (!mx.mk && mx.cnt < DES_PTAB_CNT) {
+        const double *t = md.ptab + ((size_t)mx.mat * DES_PTAB_CNT + mx.cnt) * 5;
+        r.bulkm = t[0]; r.shearm = t[1]; r.phi = t[2]; r.cp = t[3]; r.k = t[4];
+    } else {
+        r.bulkm = md.props[e]; r.shearm = md.props[(size_t)ne + e]; r.phi = md.props[(size_t)2*ne + e];
+        r.cp = md.props[(size_t)3*ne + e]; r.k = md.props[(size_t)4*ne + e];
+    }
+    return r;
+}
+
+// Young's-modulus "mass" of an element, only read by damping option 4 (geometry.cxx:1832)
+__device__ __forceinline__ double elem_ym(const des_params *p, const MatData &md, int ne, int e)
+{
+    const ElemProps pr = load_props(p, md, mix_of(md, p->nmat, e), ne, e);
+    return 9 * pr.bulkm * pr.shearm / (3 * pr.bulkm + pr.shearm) / 4;
+}
+
+// refresh_elem_cache (matprops.cxx:259-303): mono[] for every element, props[] for nmat > 1
+__global__ void __launch_bounds__(DES_BLOCK)
+k_props(const des_params *p, const int *markers, double *props, int *mono, int ne)
+{
+    int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const int nmat = p->nmat;
+    const int *mk = markers + (size_t)e * nmat;
+    int used = 0, mat = 0, cnt = 0;
+    for (int m = 0; m < nmat; ++m) if (mk[m] != 0) { ++used; mat = m; cnt = mk[m]; }
+    mono[e] = (used == 1 && cnt > 0 && cnt < 65536) ? ((mat << 16) | cnt) : -1;
+    if (!props) return;
+    props[e]                = desk::harmonic_mean(p->bulk_modulus, mk, nmat);
+    props[(size_t)ne + e]   = desk::harmonic_mean(p->shear_modulus, mk, nmat);
+    props[(size_t)2*ne + e] = desk::arithmetic_mean(p->porosity, mk, nmat);
+    props[(size_t)3*ne + e] = desk::arithmetic_mean(p->heat_capacity, mk, nmat);
+    props[(size_t)4*ne + e] = desk::arithmetic_mean(p->therm_cond, mk, nmat);
+}
+
+// the five means of a single-material element, by (material, marker count)
+__global__ void k_ptab(const des_params *p, double *ptab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nmat = p->nmat;
+    if (i >= nmat * DES_PTAB_CNT) return;
+    const int mat = i / DES_PTAB_CNT, cnt = i % DES_PTAB_CNT;
+    int mk[DES_MAX_MAT];
+    for (int m = 0; m < DES_MAX_MAT; ++m) mk[m] = 0;
+    mk[mat] = cnt > 0 ? cnt : 1;                           // row 0 is never read
+    double *t = ptab + (size_t)i * 5;
+    t[0] = desk::harmonic_mean(p->bulk_modulus, mk, nmat);
+    t[1] = desk::harmonic_mean(p->shear_modulus, mk, nmat);
+    t[2] = desk::arithmetic_mean(p->porosity, mk, nmat);
+    t[3] = desk::arithmetic_mean(p->heat_capacity, mk, nmat);
+    t[4] = desk::arithmetic_mean(p->therm_cond, mk, nmat);
+}

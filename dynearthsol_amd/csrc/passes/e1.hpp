@@ -1,0 +1,202 @@
+// passes/e1.hpp -- Pass E1 (elements): end of step t + start of step t+1.
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// ---- E1 --------------------------------------------------------------------------
+// MODE_C: compute_volume (geometry.cxx:170-201) after the volume swap (dynearthsol.cxx:466-470),
+//         compute_mass element part (geometry.cxx:1795-1840), rotate_stress (fields.cxx:827-902);
+//         MODE_DT adds the compute_dt reduction (geometry.cxx:1513-1593).
+// MODE_A: update_temperature element part (fields.cxx:211-239), update_strain_rate
+//         (fields.cxx:415-476), compute_dvoldt element part (geometry.cxx:218-224).
+template <int MODE>
+__global__ void __launch_bounds__(DES_BLOCK, DES_E1_WAVES)
+E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int nblocks,
+     const int4 *__restrict__ conn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
+     const MatData md,
+     const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
+     double *__restrict__ volume, double *__restrict__ volume_old,
+     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp)
+{
+    const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    const bool active = e < ne;
+
+    double r_minl = DBL_MAX, r_maxw = DBL_MAX, r_diff = DBL_MAX, r_gdt = DBL_MAX, r_vem = 0.0;
+
+    if (active) {
+        const int4 cn = conn[e];
+        d4 c[4], v[4];
+        c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
+        v[0] = vm[cn.x]; v[1] = vm[cn.y]; v[2] = vm[cn.z]; v[3] = vm[cn.w];
+        const desk::Mix mx = mix_of(md, p->nmat, e);
+        const ElemProps pr = load_props(p, md, mx, ne, e);
+
+        // mean nodal temperature, matprops.cxx:338-343
+        double T = 0;
+        T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
+        T /= 4;
+        const double rho = desk::mat_rho(p, mx, T);
+
+        double vol;
+        d4 rec;
+        double rdv = 0.0;                        // >= 1: correct_surface_element rescales this element
+        // update_mesh only runs on a moving mesh (dynearthsol.cxx:870-873; always in the isostasy
+        // loop): without it volumes and masses keep their values, rotate_stress below still runs
+        const bool remesh_geom = (MODE & MODE_INIT) || p->has_moving_mesh || clk->iso;
+        if ((MODE & MODE_C) && !remesh_geom) {
+            vol = volume[e];
+            const d4 old = mrec[e];
+            rec.x = old.x; rec.y = old.y; rec.z = old.z;
+        } else if (MODE & MODE_C) {
+            const double vol_prev = volume[e];
+            vol = desk::tet_volume(c);
+            if (!(MODE & MODE_INIT) && topflag[e]) {
+                // correct_surface_element (bc.cxx:1670-1687) runs before the swap: it already
+                // stored the new volume, so the swap moves the NEW volume into volume_old
+                rdv = vol / vol_prev;
+                volume_old[e] = vol;
+            } else {
+                volume_old[e] = vol_prev;        // pointer swap of dynearthsol.cxx:466-470
+            }
+            volume[e] = vol;
+            // compute_mass, element part
+            const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+            double rho_m = p->is_quasi_static ? pr.bulkm / (pseudo_speed * pseudo_speed) : rho;
+            rec.x = vol;
+            rec.y = rho_m * vol / 4;
+            rec.z = rho * pr.cp * vol / 4;
+        } else {
+            vol = volume[e];
+            if (MODE & MODE_A) {
+                const d4 old = mrec[e];
+                rec.x = old.x; rec.y = old.y; rec.z = old.z;
+            }
+        }
+
+        double sx[4], sy[4], sz[4];
+        desk::shape_fn(c, vol, sx, sy, sz);
+
+        if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
+            const bool rescale = rdv >= 1.0;                         // bc.cxx:1677
+            const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0 && !clk->iso;   // not in the isostasy loop
+            if (rescale || rotate) {
+                double s[6], es[6];
+                for (int i = 0; i < 6; ++i) { s[i] = stress[(size_t)i*ne + e]; es[i] = strain[(size_t)i*ne + e]; }
+                if (rescale) {
+                    plstrain[e] /= rdv;
+                    for (int i = 0; i < 6; ++i) { s[i] /= rdv; es[i] /= rdv; }
+                    if (!(MODE & MODE_A))            // otherwise update_strain_rate overwrites it below
+                        for (int i = 0; i < 6; ++i) strain_rate[(size_t)i*ne + e] /= rdv;
+                }
+                if (rotate) {
+                    const double dt = clk->dt;
+                    double w3 = 0, w4 = 0, w5 = 0;
+                    for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
+                    for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
+                    for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
+                    desk::jaumann_rate_3d(s, dt, w3, w4, w5);
+                    desk::jaumann_rate_3d(es, dt, w3, w4, w5);
+                }
+                if (rescale || rotate)
+                    for (int i = 0; i < 6; ++i) { stress[(size_t)i*ne + e] = s[i]; strain[(size_t)i*ne + e] = es[i]; }
+            }
+        }
+
+        if (MODE & MODE_DT) {
+            double vx = 0.0, vy = 0.0, vz = 0.0;
+            const double weight = 1.0 / 4;
+            for (int j = 0; j < 4; ++j) { vx += v[j].x * weight; vy += v[j].y * weight; vz += v[j].z * weight; }
+            r_vem = sqrt(vx*vx + vy*vy + vz*vz);
+            double maxa = fmax(fmax(desk::tri_area(c[0], c[1], c[2]), desk::tri_area(c[0], c[1], c[3])),
+                               fmax(desk::tri_area(c[2], c[3], c[0]), desk::tri_area(c[2], c[3], c[1])));
+            double minh = 3 * vol / maxa;
+            r_maxw = 0.5 * p->visc_min / (1e-40 + pr.shearm);
+            if (p->has_thermal_diffusion) r_diff = 0.5 * minh * minh / p->therm_diff_max;
+            r_minl = minh;
+            r_gdt = minh / sqrt(pr.shearm / rho) / 5.0;
+        }
+
+        if (MODE & MODE_A) {
+            if (p->has_thermal_diffusion) {
+                double kv = pr.k * vol;
+                double rh = radiogenic[e] * vol * rho / 4;
+                d4 tr;
+                double *trp = &tr.x;
+                for (int i = 0; i < 4; ++i) {
+                    double diffusion = 0.;
+                    for (int j = 0; j < 4; ++j)
+                        diffusion += (sx[i] * sx[j] + sy[i] * sy[j] + sz[i] * sz[j]) * c[j].w;
+                    trp[i] = diffusion * kv - rh;
+                }
+                ttmp[e] = tr;
+            }
+            double s[6];
+            s[0] = 0; for (int i = 0; i < 4; ++i) s[0] += v[i].x * sx[i];
+            s[1] = 0; for (int i = 0; i < 4; ++i) s[1] += v[i].y * sy[i];
+            s[2] = 0; for (int i = 0; i < 4; ++i) s[2] += v[i].z * sz[i];
+            s[3] = 0; for (int i = 0; i < 4; ++i) s[3] += 0.5 * (v[i].x * sy[i] + v[i].y * sx[i]);
+            s[4] = 0; for (int i = 0; i < 4; ++i) s[4] += 0.5 * (v[i].x * sz[i] + v[i].z * sx[i]);
+            s[5] = 0; for (int i = 0; i < 4; ++i) s[5] += 0.5 * (v[i].y * sz[i] + v[i].z * sy[i]);
+            for (int i = 0; i < 6; ++i) strain_rate[(size_t)i*ne + e] = s[i];
+            double dj = s[0] + s[1] + s[2];
+            rec.w = dj * vol;
+        } else {
+            rec.w = 0;
+        }
+        if (MODE & (MODE_C | MODE_A)) mrec[e] = rec;
+    }
+
+    if (MODE & MODE_DT) {
+        __shared__ double red[5][DES_BLOCK / 64];
+        r_minl = desk::wave_min(r_minl); r_maxw = desk::wave_min(r_maxw); r_diff = desk::wave_min(r_diff);
+        r_gdt = desk::wave_min(r_gdt);   r_vem = desk::wave_max(r_vem);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) { red[0][w] = r_minl; red[1][w] = r_maxw; red[2][w] = r_diff; red[3][w] = r_gdt; red[4][w] = r_vem; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < DES_BLOCK / 64; ++i) {
+                red[0][0] = fmin(red[0][0], red[0][i]); red[1][0] = fmin(red[1][0], red[1][i]);
+                red[2][0] = fmin(red[2][0], red[2][i]); red[3][0] = fmin(red[3][0], red[3][i]);
+                red[4][0] = fmax(red[4][0], red[4][i]);
+            }
+            desk::atomic_min_double(&clk->r_minl, red[0][0]);
+            desk::atomic_min_double(&clk->r_dt_maxwell, red[1][0]);
+            desk::atomic_min_double(&clk->r_dt_diffusion, red[2][0]);
+            desk::atomic_min_double(&clk->r_global_dt_min, red[3][0]);
+            desk::atomic_max_double(&clk->r_max_vem, red[4][0]);
+        }
+    }
+}
+
+// compute_dt tail (geometry.cxx:1597-1646); one thread
+__global__ void k_dt_finalize(const des_params *p, DevClock *clk, const double *red)
+{
+    if (red) {          // partials min-reduced over the ranks (k_dt_pack layout)
+        clk->r_minl = red[0]; clk->r_dt_maxwell = red[1]; clk->r_dt_diffusion = red[2];
+        clk->r_global_dt_min = red[3]; clk->r_max_vem = -red[4]; clk->max_surf_vel = -red[5];
+    }
+    double dt_maxwell = clk->r_dt_maxwell, dt_diffusion = clk->r_dt_diffusion, minl = clk->r_minl;
+    const double dt_hydro_diffusion = DBL_MAX;
+    double global_max_vem = clk->r_max_vem;
+    double max_vbc_val;
+    if (p->characteristic_speed == 0) {
+        max_vbc_val = p->max_vbc_val;
+        if (p->surface_process_option > 0)
+            max_vbc_val = fmax(max_vbc_val, clk->max_surf_vel * 5e-1);
+    } else
+        max_vbc_val = p->characteristic_speed;
+    global_max_vem = fmax(global_max_vem, p->max_vbc_val);
+    clk->max_global_vel_mag = global_max_vem;
+    clk->global_dt_min = clk->r_global_dt_min;
+    double dt_advection = 0.5 * minl / max_vbc_val;
+    double dt_elastic = p->is_quasi_static
+        ? 0.5 * minl / (max_vbc_val * p->inertial_scaling)
+        : 0.5 * minl / sqrt(p->bulk_modulus[p->mattype_ref] / p->rho0[p->mattype_ref]);
+    double dt = fmin(fmin(fmin(dt_elastic, dt_maxwell), fmin(dt_advection, dt_diffusion)), dt_hydro_diffusion)
+                * p->dt_fraction;
+    if (p->fixed_dt != 0) dt = p->fixed_dt;
+    if (!(dt > 0)) clk->status = DES_ERR_RUNTIME_NAN;
+    clk->dt = dt;
+    clk->r_minl = DBL_MAX; clk->r_dt_maxwell = DBL_MAX; clk->r_dt_diffusion = DBL_MAX;
+    clk->r_global_dt_min = DBL_MAX; clk->r_max_vem = 0.0;
+}

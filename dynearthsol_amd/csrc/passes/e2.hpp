@@ -1,0 +1,171 @@
+// passes/e2.hpp -- Pass E2 (elements): update_stress, first pass and return-mapping pass.
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// ---- E2 --------------------------------------------------------------------------
+// compute_edvoldt (geometry.cxx:264-272), update_stress (rheology.cxx:728-1026),
+// NMD_stress element part (geometry.cxx:294-296)
+// The stress update of element e.  DEFER = 1 (first pass): returns true WITHOUT having stored
+// anything but viscosity[e] when the element needs the Mohr-Coulomb return mapping; the second
+// pass then runs the same code with DEFER = 0 for exactly those elements.
+template <class M, int DEFER>
+__device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
+     const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const MatData &md,
+     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
+     double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
+     double *__restrict__ dpressure, double *__restrict__ etmp2)
+{
+    const double dt = clk->dt;
+    const int4 cn = conn[e];
+    const int rheol = p->rheol_type;
+    const desk::Mix mx = mix_of(md, p->nmat, e);
+    const ElemProps pr = load_props(p, md, mx, ne, e);
+
+    double dj = 0;
+    dj += ntmp[cn.x]; dj += ntmp[cn.y]; dj += ntmp[cn.z]; dj += ntmp[cn.w];
+    const double edvoldt = dj / 4;
+
+    double s[6], es[6], edot[6];
+    for (int i = 0; i < 6; ++i) {
+        s[i] = stress[(size_t)i*ne + e];
+        es[i] = strain[(size_t)i*ne + e];
+        edot[i] = strain_rate[(size_t)i*ne + e];
+    }
+    const double old_s = desk::trace3(s);
+    {
+        double div = desk::trace3(edot);
+        for (int i = 0; i < 3; ++i) edot[i] += (edvoldt - div) / 3;
+    }
+    for (int i = 0; i < 6; ++i) es[i] += edot[i] * dt;
+    double de[6];
+    for (int i = 0; i < 6; ++i) de[i] = edot[i] * dt;
+    double dpl = 0.;
+    bool defer = false;
+    const double vol = volume[e];
+
+    M::stage_end();
+    double visc = 0;
+    if (rheol & DES_RH_VISCOUS) {
+        double T = 0;
+        T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
+        T /= 4;
+        visc = desk::mat_visc<M>(p, vt, mx, T, s, edot);
+        viscosity[e] = visc;
+    }
+
+    switch (rheol) {
+    case DES_RH_ELASTIC:
+        desk::elastic(pr.bulkm, pr.shearm, de, s);
+        break;
+    case DES_RH_VISCOUS:
+        desk::viscous(pr.bulkm, visc, desk::trace3(es), edot, s);
+        break;
+    case DES_RH_MAXWELL: {
+        double dv = vol / volume_old[e] - 1;
+        desk::maxwell(pr.bulkm, pr.shearm, visc, dt, dv, de, s);
+        break;
+    }
+    case DES_RH_EP: {
+        double amc, anphi, anpsi, hardn, ten_max;
+        double pls = plstrain[e];
+        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
+        double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s, &defer);
+        if (DEFER && defer) return true;
+        if (depls != 0) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
+        dpl = depls;
+        break;
+    }
+    case DES_RH_EVP: {
+        double dv = vol / volume_old[e] - 1;
+        double sv[6];
+        for (int i = 0; i < 6; ++i) sv[i] = s[i];
+        desk::maxwell(pr.bulkm, pr.shearm, visc, dt, dv, de, sv);
+        double svII = desk::second_invariant2(sv);
+        double amc, anphi, anpsi, hardn, ten_max;
+        double pls = plstrain[e];
+        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
+        double sp[6];
+        for (int i = 0; i < 6; ++i) sp[i] = s[i];
+        double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp, &defer);
+        if (DEFER && defer) return true;
+        double spII = desk::second_invariant2(sp);
+        if (svII < spII) {
+            for (int i = 0; i < 6; ++i) s[i] = sv[i];
+        } else {
+            for (int i = 0; i < 6; ++i) s[i] = sp[i];
+            plstrain[e] = pls + depls;
+            dpl = depls;
+        }
+        break;
+    }
+    default: break;
+    }
+    delta_plstrain[e] = dpl;
+    for (int i = 0; i < 6; ++i) {
+        stress[(size_t)i*ne + e] = s[i];
+        strain[(size_t)i*ne + e] = es[i];
+    }
+    for (int i = 0; i < 3; ++i) strain_rate[(size_t)i*ne + e] = edot[i];   // only the diagonal changed
+    if (p->is_using_mixed_stress) {
+        double dp = desk::trace3(s) - old_s;
+        dpressure[e] = dp;
+        etmp2[e] = dp * vol;
+    }
+    return defer;                  // went past the yield pre-filter
+}
+
+// First pass: every element [e_begin, e_begin + e_count) (the whole local mesh, or a sub-range:
+// ne stays the SoA plane stride).  DEFER = 1: elements that need the return mapping are appended
+// to `list` (wave-aggregated: one atomic per wavefront) for E2_return_mapping.
+template <class M, int DEFER>
+__global__ void __launch_bounds__(DES_BLOCK, DEFER ? DES_E2_WAVES_FAST : DES_E2_WAVES)
+E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
+     int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const MatData md,
+     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
+     double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
+     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ list, int *__restrict__ count)
+{
+    M::stage_begin();
+    const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    if (el >= e_count) return;
+    const int e = e_begin + el;
+    const bool defer = e2_element<M, DEFER>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+                                            plstrain, delta_plstrain, viscosity, dpressure, etmp2);
+    // one atomic per wavefront that has such elements; without DEFER only the count is kept
+    // (des_scalars::n_return_mapping, and what the host picks the next call's mode from)
+    const unsigned long long mask = __ballot(defer);
+    if (defer) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(count, __popcll(mask));
+        if (DEFER) {
+            base = __shfl(base, leader);
+            list[base + __popcll(mask & ((1ull << lane) - 1))] = e;
+        }
+    }
+}
+
+// Second pass: the elements the first pass set aside, full stress update with the return mapping
+// (same code, same arithmetic; the order of the list does not matter, every element is its own).
+template <class M>
+__global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
+E2_return_mapping(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
+     int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const MatData md,
+     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
+     double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
+     double *__restrict__ dpressure, double *__restrict__ etmp2, const int *__restrict__ list, const int *__restrict__ count)
+{
+    M::stage_begin();
+    M::stage_end();
+    const int n = *count;
+    for (int i = blockIdx.x * DES_BLOCK + threadIdx.x; i < n; i += gridDim.x * DES_BLOCK)
+        e2_element<M, 0>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+                         plstrain, delta_plstrain, viscosity, dpressure, etmp2);
+}

@@ -1,0 +1,133 @@
+// passes/small_kernels.hpp -- Ghost-region pack / unpack and the small service kernels (dt, NaN count, mesh quality, libm check).
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// ---- ghost-region exchange (des_halo, des_params.h) ------------------------------------
+// State of the listed nodes {x,y,z,vx,vy,vz,T,dh} and elements {stress, strain, plstrain} to /
+// from a message buffer; off[i] = position (in doubles) of item i's record in the buffer, so one
+// launch fills the messages of all neighbours (a message = node records, then element records).
+__global__ void __launch_bounds__(DES_BLOCK)
+k_state_pack(int nnodes, const int *__restrict__ nidx, const int *__restrict__ noff,
+             int nelems, const int *__restrict__ eidx, const int *__restrict__ eoff,
+             const d4 *__restrict__ xt, const d4 *__restrict__ vm, const double *__restrict__ dh_n,
+             const double *__restrict__ stress, const double *__restrict__ strain,
+             const double *__restrict__ plstrain, int ne, double *__restrict__ buf)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < nnodes) {
+        const int k = nidx[i];
+        const d4 x = xt[k], v = vm[k];
+        double *b = buf + noff[i];
+        b[0] = x.x; b[1] = x.y; b[2] = x.z; b[3] = v.x; b[4] = v.y; b[5] = v.z; b[6] = x.w; b[7] = dh_n[k];
+    } else if (i < nnodes + nelems) {
+        const int j = i - nnodes, e = eidx[j];
+        double *b = buf + eoff[j];
+        for (int c = 0; c < 6; ++c) { b[c] = stress[(size_t)c*ne + e]; b[6 + c] = strain[(size_t)c*ne + e]; }
+        b[12] = plstrain[e];
+    }
+}
+
+__global__ void __launch_bounds__(DES_BLOCK)
+k_state_unpack(int nnodes, const int *__restrict__ nidx, const int *__restrict__ noff,
+               int nelems, const int *__restrict__ eidx, const int *__restrict__ eoff,
+               d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ dh_n,
+               double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
+               int ne, const double *__restrict__ buf)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < nnodes) {
+        const int k = nidx[i];
+        const double *b = buf + noff[i];
+        d4 x, v = vm[k];                                   // the nodal mass stays this rank's own
+        x.x = b[0]; x.y = b[1]; x.z = b[2]; x.w = b[6];
+        v.x = b[3]; v.y = b[4]; v.z = b[5];
+        xt[k] = x; vm[k] = v; dh_n[k] = b[7];
+    } else if (i < nnodes + nelems) {
+        const int j = i - nnodes, e = eidx[j];
+        const double *b = buf + eoff[j];
+        for (int c = 0; c < 6; ++c) { stress[(size_t)c*ne + e] = b[c]; strain[(size_t)c*ne + e] = b[6 + c]; }
+        plstrain[e] = b[12];
+    }
+}
+
+// compute_dt partials of this rank, all arranged for a MIN reduction across ranks
+__global__ void k_dt_pack(const DevClock *clk, double *red)
+{
+    red[0] = clk->r_minl; red[1] = clk->r_dt_maxwell; red[2] = clk->r_dt_diffusion;
+    red[3] = clk->r_global_dt_min; red[4] = -clk->r_max_vem; red[5] = -clk->max_surf_vel;
+}
+
+__global__ void k_dhacc_reset(int ntop, const int *__restrict__ top_nodes, double *__restrict__ dhacc)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < ntop) dhacc[top_nodes[i]] = 0.;
+}
+
+// check_nan (utils.hpp:323-394)
+// des_dev_libm_eval: one portable-libm function over an array (diagnostic entry)
+__global__ void k_libm_eval(int fn, long long n, const double *__restrict__ x, const double *__restrict__ y,
+                            double *__restrict__ out)
+{
+    deslibm::lds_stage();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x[i], b = y ? y[i] : 0.0;
+    double r;
+    switch (fn) {
+    case DES_LIBM_POW:   r = deslibm::pow(a, b); break;
+    case DES_LIBM_EXP:   r = deslibm::exp(a); break;
+    case DES_LIBM_SIN:   r = deslibm::sin(a); break;
+    case DES_LIBM_COS:   r = deslibm::cos(a); break;
+    case DES_LIBM_TAN:   r = deslibm::tan(a); break;
+    default:             r = deslibm::atan2(a, b); break;
+    }
+    out[i] = r;
+}
+
+__global__ void k_count_nan(const double *a, long long n, unsigned long long *count)
+{
+    long long i = (long long)blockIdx.x * DES_BLOCK + threadIdx.x;
+    unsigned long long c = 0;
+    for (; i < n; i += (long long)gridDim.x * DES_BLOCK) c += isnan(a[i]) ? 1 : 0;
+    if (c) atomicAdd(count, c);
+}
+
+// bad_mesh_quality reductions (remeshing.cxx:2752-2866).  slots: [0] min quality (double bits),
+// then ints: [2] first tiny element, [3] first distorted bottom node, [4] first worst element
+__device__ __forceinline__ double elem_quality3(const int4 cn, const d4 *__restrict__ xt, double vol)
+{
+    const d4 a = xt[cn.x], b = xt[cn.y], c = xt[cn.z], d = xt[cn.w];
+    const double normalization_factor = 216 * sqrt(3.0);
+    const double area_sum = (desk::tri_area(a, b, c) + desk::tri_area(a, b, d) +
+                             desk::tri_area(c, d, a) + desk::tri_area(c, d, b));
+    return normalization_factor * vol * vol / (area_sum * area_sum * area_sum);
+}
+
+__global__ void k_quality_a(int ne, int nn, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+                            const double *__restrict__ volume, const unsigned *__restrict__ bcflag,
+                            double smallest_vol, double bottom, double bottom_dist, double *qmin, int *islot,
+                            const int *__restrict__ n_id, const int *__restrict__ e_id)
+{
+    // n_id / e_id: the caller's index of a device index ("first" means first in the caller's order)
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    double q = 1.0;
+    if (i < ne) {
+        const double vol = volume[i];
+        if (vol < smallest_vol) atomicMin(&islot[0], e_id ? e_id[i] : i);
+        q = fmin(q, elem_quality3(conn[i], xt, vol));
+    }
+    if (i < nn && bottom_dist >= 0 && (bcflag[i] & (1u << 4)))            // is_bottom: BOUNDZ0
+        if (fabs(xt[i].z - bottom) > bottom_dist) atomicMin(&islot[1], n_id ? n_id[i] : i);
+    q = desk::wave_min(q);
+    if ((threadIdx.x & 63) == 0 && q < 1.0) desk::atomic_min_double(qmin, q);
+}
+
+__global__ void k_quality_b(int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+                            const double *__restrict__ volume, const double *qmin, int *islot,
+                            const int *__restrict__ e_id)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const double q = elem_quality3(conn[e], xt, volume[e]);
+    if (q < 1.0 && q == *qmin) atomicMin(&islot[2], e_id ? e_id[e] : e);
+}
