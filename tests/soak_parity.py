@@ -5,7 +5,7 @@ the oracle against itself after a 1-ulp change of its initial stress -- the yard
 "equal" can mean on this model.  Not part of the test suite (minutes of CPU); results are
 kept in profiles/.
 
-  python tools/soak_parity.py [--steps 1000] [--sensitivity | --portable-libm] [--threads 16]
+  python tests/soak_parity.py [--steps 1000] [--sensitivity | --portable-libm] [--threads 16]
 """
 import argparse
 import os
@@ -16,7 +16,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, ROOT)          # (lives under tests/ because it drives the oracle: test infrastructure)
 import bench                                             # noqa: E402
 import dynearthsol_amd as des                            # noqa: E402
 from oracle_binding import OracleEngine, load_oracle     # noqa: E402
