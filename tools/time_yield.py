@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cost of the two-pass stress update when MANY elements yield: the fast-loading elasto-plastic
-model of tests/cfgs.py (YIELD) on a 640k-tet regular mesh, marched until a large share of the
+model of tests/cfgs.py (YIELD) on a 1.6M-tet regular mesh, marched until a large share of the
 mesh yields, then E2 timed with and without the deferral (DES_E2_DEFER).  One process per
 setting (the switch is read at engine creation).
 
