@@ -127,6 +127,9 @@ struct des_dev {
            *volume_old, *dpressure, *radiogenic;
     int *markers;
     int *defer_list;                      // [ne] elements set aside by the first stress pass of the step
+    bool use_graph;                       // DES_GRAPH=1
+    hipGraphExec_t graph_exec[2];
+    bool graph_two_pass[2];
     int e2_defer;                         // DES_E2_DEFER: 0 one pass, 1 two passes, 2 (default) chosen per call
     bool e2_two_pass;                     // the current choice
     int *mono;                            // [ne] (material << 16) | count of single-material elements, else -1
@@ -222,6 +225,7 @@ void des_dev_destroy(des_dev *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
     void *ptrs[] = { h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->d_esend_idx, h->d_erecv_idx, h->d_send_noff,
@@ -258,6 +262,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     h->device = device;
     h->p = *params;
     {
+        const char *gr = std::getenv("DES_GRAPH");
+        h->use_graph = gr && gr[0] == '1';
         const char *e2d = std::getenv("DES_E2_DEFER");
         h->e2_defer = (e2d && (e2d[0] == '0' || e2d[0] == '1')) ? e2d[0] - '0' : 2;
         h->e2_two_pass = h->e2_defer != 0;
@@ -694,10 +700,33 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     const bool multi = h->nnbr > 0;
     const bool iso = h->iso;
     const bool nmd = h->p.is_using_mixed_stress && !iso;
+    // DES_GRAPH=1: the launches of an interior step of a single-GPU call are replayed from a
+    // hipGraph captured once (two graphs: with and without the compute_dt variant of E1)
+    const bool graphs = h->use_graph && !multi && !iso && !h->prof && !h->p.is_outputting_averaged_fields;
+    const long long qcsi = h->p.quality_check_step_interval;
     int rc;
     for (int i = 0; i < nsteps; ++i) {
         const long long step_no = iso ? h->steps_host : ++h->steps_host;
         if (i == 0) launch_e1<MODE_A>(h);
+        if (graphs && i < nsteps - 1 && step_no % qcsi != 0) {
+            const int which = (step_no % 10 == 0) ? 1 : 0;
+            if (!h->graph_exec[which] || h->graph_two_pass[which] != h->e2_two_pass) {
+                if (h->graph_exec[which]) { hipGraphExecDestroy(h->graph_exec[which]); h->graph_exec[which] = nullptr; }
+                hipGraph_t g = nullptr;
+                HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+                launch_n1(h); launch_e2(h); if (nmd) launch_n2(h); launch_e3(h); launch_n3(h);
+                launch_s2(h, 1);                                   // (no dhacc reset: those steps are not replayed)
+                launch_s3(h, true, true, true);
+                launch_e1_end(h, which ? 10 : 1, true);
+                if (which) launch_dt_finalize(h, nullptr);
+                HIP_OK(hipStreamEndCapture(h->stream, &g));
+                HIP_OK(hipGraphInstantiate(&h->graph_exec[which], g, nullptr, nullptr, 0));
+                hipGraphDestroy(g);
+                h->graph_two_pass[which] = h->e2_two_pass;
+            }
+            HIP_OK(hipGraphLaunch(h->graph_exec[which], h->stream));
+            continue;
+        }
         launch_n1(h);
         launch_e2(h);
         if (nmd) launch_n2(h);

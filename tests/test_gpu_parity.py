@@ -65,6 +65,22 @@ def test_elasto_plastic_100_steps_bit_exact():
     assert dev.check_nan() == 0
 
 
+def test_hipgraph_replay_of_interior_steps_gives_the_same_bits(monkeypatch):
+    """DES_GRAPH=1 replays the launches of interior steps from two captured hipGraphs (with /
+    without the compute_dt variant of E1); steps at call boundaries and quality-check steps are
+    launched directly.  Off by default: the stream is not launch-bound."""
+    ov = "mesh.quality_check_step_interval = 15\n"
+    host, dev, ora = pair(cfgs.EVP, overrides=ov)
+    monkeypatch.setenv("DES_GRAPH", "1")
+    host2 = des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=ov)
+    devg = des.DeviceEngine(host2)
+    devg.init_from_host(host2)
+    for n in (47, 3, 1, 26):
+        sd, sg = dev.step(n), devg.step(n)
+        assert (sd.dt, sd.time, sd.steps) == (sg.dt, sg.time, sg.steps)
+        assert_bit_exact(dev, devg)
+
+
 def test_step_splitting_is_invisible_on_the_device():
     # E1 fuses the end of step t with the start of step t+1; the API boundary must not show
     host, dev, ora = pair(cfgs.EP)
