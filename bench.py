@@ -295,7 +295,9 @@ def main():
                 achieved = kbytes / (ms / calls * 1e-3) / 1e9
                 traffic = None
                 tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(tpath) and world == 1 and not args.mesh_file:
+                same_workload = (world == 1 and not args.mesh_file and args.workload == "test-3d-big"
+                                 and args.resolution == 400e3 / 560 and args.rheology == "elasto-visco-plastic")
+                if os.path.exists(tpath) and same_workload:       # the PMC passes were made on exactly this workload
                     try:
                         # PMC passes cannot share a run with the timed one: the committed summary of
                         # `tools/summarize_pmc.py` for the same workload is reported (bytes per launch)
