@@ -151,7 +151,7 @@ struct des_dev {
     unsigned bc_mask;                     // bcflag bits that have any entry
     // surface
     int ntop, etop, ntop_elems;
-    int *top_nodes, *ean, *conn_surf, *ssup_idx, *ssup_arr;
+    int *top_nodes, *ean, *conn_surf, *ssup_idx, *ssup_arr, *ssup_nodes;
     double *dh, *edvacc, *znew;           // znew: surface heights between k_s2 and their commit
     // bnormals / edges for slanted boundaries
     double *bnormals, *edge_vec; int *edge_slot;
@@ -234,7 +234,7 @@ void des_dev_destroy(des_dev *h)
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
         h->radiogenic, h->markers, h->props, h->mono, h->defer_list, h->ptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
-        h->conn_surf, h->ssup_idx, h->ssup_arr, h->topflag, h->dh, h->edvacc,
+        h->conn_surf, h->ssup_idx, h->ssup_arr, h->ssup_nodes, h->topflag, h->dh, h->edvacc,
         h->znew, h->bnormals, h->edge_vec, h->edge_slot };
     for (void *q : ptrs) if (q) hipFree(q);
     if (h->h_clk) hipHostFree(h->h_clk);
@@ -465,6 +465,12 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         if (ntop) CK(dev_upload(h->ssup_idx, mesh->support_surf_idx, ntop + 1, h->stream));
         const size_t nss = ntop ? (size_t)mesh->support_surf_idx[ntop] : 0;
         CK(dev_alloc(h->ssup_arr, nss)); CK(dev_upload(h->ssup_arr, mesh->support_surf_arr, nss, h->stream));
+        {
+            std::vector<int> sn(3 * nss);
+            for (size_t k = 0; k < nss; ++k)
+                for (int m = 0; m < 3; ++m) sn[3*k + m] = mesh->connectivity_surface[(size_t)m*etop + mesh->support_surf_arr[k]];
+            CK(dev_alloc(h->ssup_nodes, 3 * nss)); CK(dev_upload(h->ssup_nodes, sn.data(), 3 * nss, h->stream));
+        }
         {
             std::vector<unsigned char> flag((size_t)ne, 0);
             for (int i = 0; i < h->ntop_elems; ++i) flag[mesh->top_elems[i]] = 1;

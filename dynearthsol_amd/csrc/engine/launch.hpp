@@ -249,7 +249,7 @@ void launch_s2(des_dev *h, long long step_no)
     if (h->ntop > 0) {
         Launch l(h, K_S2);
         hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
-                           (int)(h->p.surface_process_option == 1), h->top_nodes, h->ssup_idx, h->ssup_arr, h->conn_surf,
+                           (int)(h->p.surface_process_option == 1), h->top_nodes, h->ssup_idx, h->ssup_nodes, h->conn_surf,
                            h->etop, h->xt, h->o0, h->o1, h->dh, h->dhacc, h->znew, h->dh_n);
     }
     if (h->ntop > 0 && step_no != 0 && step_no % h->p.quality_check_step_interval == 0)

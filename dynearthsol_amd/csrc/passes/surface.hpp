@@ -10,7 +10,7 @@
 // the same deterministic expressions, so the sums are bit-identical.
 __global__ void __launch_bounds__(DES_BLOCK)
 k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int diffuse,
-     const int *__restrict__ top_nodes, const int *__restrict__ ssup_idx, const int *__restrict__ ssup_arr,
+     const int *__restrict__ top_nodes, const int *__restrict__ ssup_idx, const int *__restrict__ ssup_nodes,
      const int *__restrict__ conn_surf, int etop, const d4 *__restrict__ xt_in, int o0, int o1,
      double *__restrict__ dh, double *__restrict__ dhacc, double *__restrict__ znew, double *__restrict__ dh_n)
 {
@@ -27,11 +27,13 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
             for (int j0 = jb; j0 < je; j0 += 4) {
                 int kf[4], nd[4][3];
                 d4 cf[4][3];
+                // ssup_nodes[3k + m] = conn_surf[m*etop + ssup_arr[k]], flattened once at create
+                // (one dependent look-up less on this latency-bound kernel)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kf[u] = (j0 + u < je) ? ssup_arr[j0 + u] : -1;
+                for (int u = 0; u < 4; ++u) kf[u] = (j0 + u < je) ? 0 : -1;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    for (int m = 0; m < 3; ++m) nd[u][m] = (kf[u] >= 0) ? conn_surf[(size_t)m*etop + kf[u]] : n;
+                    for (int m = 0; m < 3; ++m) nd[u][m] = (kf[u] >= 0) ? ssup_nodes[3 * (size_t)(j0 + u) + m] : n;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     for (int m = 0; m < 3; ++m) cf[u][m] = xt_in[nd[u][m]];
