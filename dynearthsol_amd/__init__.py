@@ -25,6 +25,26 @@ HIP_LIB_PATH = os.environ.get("DES_HIP_LIB", os.path.join(_HERE, "libdes_hip.so"
 _host_lib = None
 _hip_lib = None
 
+DATA_DIR = os.path.join(REPO_ROOT, "data")
+
+
+def reference_mesh(name="test-3d-big-460"):
+    """Path of a mesh made by the reference's own TetGen and kept under data/ as `<name>.desmesh.xz`
+    (recipe: `make -C oracle refmesh`, which needs /root/reference; the file itself is data and
+    travels).  `test-3d-big-460` is test-3d-big.cfg's box at mesh.resolution = 460 m: 1,001,310 tets /
+    185,637 nodes, the headline mesh of SURVEY.md 8(d).  Unpacked once, next to the archive."""
+    path = os.path.join(DATA_DIR, name + ".desmesh")
+    if not os.path.exists(path):
+        import lzma
+        import shutil
+        if not os.path.exists(path + ".xz"):
+            return None
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with lzma.open(path + ".xz", "rb") as src, open(tmp, "wb") as dst:
+            shutil.copyfileobj(src, dst, 1 << 24)
+        os.replace(tmp, path)                 # atomic: several ranks may unpack at once
+    return path
+
 
 class DesError(RuntimeError):
     """Carries the reference's ExitCode number (utils.hpp:20-55)."""
@@ -100,6 +120,9 @@ def load_hip_lib():
         lib.des_dev_last_error.restype = C.c_char_p
         dp = C.POINTER(C.c_double)
         lib.des_dev_libm_eval.argtypes = [C.c_int, C.c_int, C.c_longlong, dp, dp, dp]
+        ip = C.POINTER(C.c_int)
+        lib.des_dev_eigen_eval.argtypes = [C.c_int, C.c_int, C.c_int, C.c_longlong, dp, dp, dp, ip]
+        lib.des_dev_elasto_plastic_eval.argtypes = [C.c_int, C.c_int, C.c_longlong, dp, dp, dp, dp, ip]
         _hip_lib = lib
     return _hip_lib
 
@@ -123,6 +146,38 @@ def libm_eval(fn, x, y=None, device=0):
     if rc:
         raise DesError(rc, lib.des_dev_last_error().decode())
     return out
+
+
+def eigen_eval(fn, a, libm="ocml", device=0):
+    """The device build of the 3x3 solvers (des_dev_eigen_eval): fn in 'c', 'h', 'q'; a[n][6] =
+    {A00, A11, A22, A01, A02, A12}.  Returns (w[n][3], q[n][3][3] or None, branch[n])."""
+    lib = load_hip_lib()
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 6)
+    n = a.shape[0]
+    w, q, br = np.zeros((n, 3)), np.zeros((n, 3, 3)), np.zeros(n, dtype=np.int32)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    rc = lib.des_dev_eigen_eval(device, "chq".index(fn), {"ocml": 0, "portable": 1}[libm], n, a.ctypes.data_as(dp),
+                                w.ctypes.data_as(dp), q.ctypes.data_as(dp), br.ctypes.data_as(ip))
+    if rc:
+        raise DesError(rc, lib.des_dev_last_error().decode())
+    return w, (None if fn == "c" else q), br
+
+
+def elasto_plastic_eval(props, de, s, libm="ocml", device=0):
+    """n calls of the device's elasto_plastic (des_dev_elasto_plastic_eval): props[n][7] = {bulkm,
+    shearm, amc, anphi, anpsi, hardn, ten_max}, de[n][6], s[n][6].  Returns (s_new, depls, mode)."""
+    lib = load_hip_lib()
+    props = np.ascontiguousarray(props, dtype=np.float64).reshape(-1, 7)
+    n = props.shape[0]
+    de = np.ascontiguousarray(de, dtype=np.float64).reshape(n, 6)
+    s = np.array(s, dtype=np.float64).reshape(n, 6).copy()
+    depls, mode = np.zeros(n), np.zeros(n, dtype=np.int32)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    rc = lib.des_dev_elasto_plastic_eval(device, {"ocml": 0, "portable": 1}[libm], n, props.ctypes.data_as(dp), de.ctypes.data_as(dp),
+                                         s.ctypes.data_as(dp), depls.ctypes.data_as(dp), mode.ctypes.data_as(ip))
+    if rc:
+        raise DesError(rc, lib.des_dev_last_error().decode())
+    return s, depls, mode
 
 
 class Host:
@@ -377,5 +432,5 @@ class DeviceEngine(EngineBase):
             raise DesError(rc, self._lib.des_dev_last_error().decode())
 
 
-__all__ = ["Host", "DeviceEngine", "EngineBase", "DesError", "DesParams", "DesMesh", "DesScalars",
+__all__ = ["Host", "DeviceEngine", "reference_mesh", "EngineBase", "DesError", "DesParams", "DesMesh", "DesScalars",
            "F", "FIELDS", "load_host_lib", "load_hip_lib", "bind_engine_api"]

@@ -373,8 +373,9 @@ __device__ __noinline__ int dsyevq3(const double *a, double Q[3][3], double w[3]
 }
 
 // 3x3-C/dsyevh3.c:112-215
+// *fallback (diagnostics, des_dev_eigen_eval) is set when the QL solver took over
 template <class M>
-__device__ __forceinline__ void dsyevh3(const double *a, double Q[3][3], double w[3])
+__device__ __forceinline__ void dsyevh3(const double *a, double Q[3][3], double w[3], int *fallback = nullptr)
 {
     const double A00 = a[0], A11 = a[1], A01 = a[3], A02 = a[4], A12 = a[5];
     dsyevc3<M>(a, w);
@@ -395,7 +396,7 @@ __device__ __forceinline__ void dsyevh3(const double *a, double Q[3][3], double 
     Q[2][0] = (A00 - w[0]) * (A11 - w[0]) - Q[2][1];
     double norm = sqr(Q[0][0]) + sqr(Q[1][0]) + sqr(Q[2][0]);
 
-    if (norm <= error) { dsyevq3(a, Q, w); return; }
+    if (norm <= error) { if (fallback) *fallback = 1; dsyevq3(a, Q, w); return; }
     norm = sqrt(1.0 / norm);
     Q[0][0] = Q[0][0] * norm; Q[1][0] = Q[1][0] * norm; Q[2][0] = Q[2][0] * norm;
 
@@ -403,7 +404,7 @@ __device__ __forceinline__ void dsyevh3(const double *a, double Q[3][3], double 
     Q[1][1] = Q[1][1] + A12*w[1];
     Q[2][1] = (A00 - w[1]) * (A11 - w[1]) - Q[2][1];
     norm = sqr(Q[0][1]) + sqr(Q[1][1]) + sqr(Q[2][1]);
-    if (norm <= error) { dsyevq3(a, Q, w); return; }
+    if (norm <= error) { if (fallback) *fallback = 1; dsyevq3(a, Q, w); return; }
     norm = sqrt(1.0 / norm);
     Q[0][1] = Q[0][1] * norm; Q[1][1] = Q[1][1] * norm; Q[2][1] = Q[2][1] * norm;
 
@@ -427,9 +428,9 @@ __device__ __forceinline__ void principal_values3(const double *s, double p[3])
 
 // rheology.cxx:76-84
 template <class M>
-__device__ __forceinline__ void principal_stresses3(const double *s, double p[3], double v[3][3])
+__device__ __forceinline__ void principal_stresses3(const double *s, double p[3], double v[3][3], int *fallback = nullptr)
 {
-    dsyevh3<M>(s, v, p);
+    dsyevh3<M>(s, v, p, fallback);
     DES_SWAP_PV(0, 1) DES_SWAP_PV(1, 2) DES_SWAP_PV(0, 1)
 }
 
@@ -470,7 +471,9 @@ __device__ __forceinline__ void viscous(double bulkm, double viscosity, double t
 // ~0.2 % of the elements get here, so it is out of line to keep the common path lean.  The
 // stress travels BY VALUE (in registers): passing a pointer to the caller's array would force
 // that array -- the stress every element works on -- into scratch memory for all elements.
-struct Stress7 { double s0, s1, s2, s3, s4, s5, depls; };
+// mode: the reference's failure_mode (0 none, 1 tensile, 10 shear; a local there, rheology.cxx:322)
+// + 100 when dsyevh3 fell back to dsyevq3 -- only read by des_dev_elasto_plastic_eval.
+struct Stress7 { double s0, s1, s2, s3, s4, s5, depls; int mode; };
 
 template <class M>
 __device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm, double amc, double anphi,
@@ -479,7 +482,9 @@ __device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm,
     double s[6] = {io.s0, io.s1, io.s2, io.s3, io.s4, io.s5};
     io.depls = 0;
     double p[3], v[3][3];
-    principal_stresses3<M>(s, p, v);
+    int ql = 0;
+    principal_stresses3<M>(s, p, v, &ql);
+    io.mode = 100 * ql;
 
     double fs = p[0] - p[2] * anphi + amc;
     double ft = p[2] - ten_max;
@@ -492,6 +497,7 @@ __device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm,
     double a2 = bulkm - 2. / 3 * shearm;
 
     double alam, depls;
+    io.mode += (h < 0) ? 10 : 1;
     if (h < 0) {
         alam = fs / (a1 - a2*anpsi + a1*anphi*anpsi - a2*anphi + 2*sqrt(anphi)*hardn);
         p[0] -= alam * (a1 - a2 * anpsi);
@@ -524,7 +530,7 @@ __device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm,
 template <class M, int DEFER = 0>
 __device__ __forceinline__ double elasto_plastic(double bulkm, double shearm, double amc, double anphi,
                                                  double anpsi, double hardn, double ten_max,
-                                                 const double *de, double *s, bool *defer = nullptr)
+                                                 const double *de, double *s, bool *defer = nullptr, int *mode = nullptr)
 {
     elastic(bulkm, shearm, de, s);
     const double YIELD_PREFILTER_MARGIN = 1e-2;            // rheology.cxx:18
@@ -556,8 +562,9 @@ __device__ __forceinline__ double elasto_plastic(double bulkm, double shearm, do
     }
     if (defer) *defer = true;                  // past the pre-filter (counted; DEFER: handed on)
     if (DEFER) return 0.0;
-    Stress7 io = {s[0], s[1], s[2], s[3], s[4], s[5], 0.0};
+    Stress7 io = {s[0], s[1], s[2], s[3], s[4], s[5], 0.0, 0};
     io = mohr_coulomb_return<M>(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, io);
+    if (mode) *mode = io.mode;
     s[0] = io.s0; s[1] = io.s1; s[2] = io.s2; s[3] = io.s3; s[4] = io.s4; s[5] = io.s5;
     return io.depls;
 }

@@ -84,6 +84,49 @@ __global__ void k_libm_eval(int fn, long long n, const double *__restrict__ x, c
     out[i] = r;
 }
 
+// des_dev_eigen_eval: the device build of the reference's 3x3 solvers over an array of tensors
+// {A00, A11, A22, A01, A02, A12}.  fn 0 dsyevc3, 1 dsyevh3, 2 dsyevq3; q row-major, eigenvectors
+// in columns as in 3x3-C; branch[i] = 1 where dsyevh3 handed over to dsyevq3 (dsyevh3.c:152, 177).
+template <class M>
+__global__ void k_eigen_eval(int fn, long long n, const double *__restrict__ a, double *__restrict__ w,
+                             double *__restrict__ q, int *__restrict__ branch)
+{
+    M::stage_begin();
+    M::stage_end();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double A[6], W[3] = {0, 0, 0}, Q[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int k = 0; k < 6; ++k) A[k] = a[i*6 + k];
+    int fb = 0;
+    if (fn == 0)      desk::dsyevc3<M>(A, W);
+    else if (fn == 1) desk::dsyevh3<M>(A, Q, W, &fb);
+    else              fb = desk::dsyevq3(A, Q, W);
+    for (int k = 0; k < 3; ++k) w[i*3 + k] = W[k];
+    if (fn != 0) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) q[i*9 + r*3 + c] = Q[r][c];
+    branch[i] = fb;
+}
+
+// des_dev_elasto_plastic_eval: one elasto_plastic call (rheology.cxx:312-484) per item, the very
+// function E2 runs.  props[i] = {bulkm, shearm, amc, anphi, anpsi, hardn, ten_max}.
+template <class M>
+__global__ void k_elasto_plastic_eval(long long n, const double *__restrict__ props, const double *__restrict__ de,
+                                      double *__restrict__ s, double *__restrict__ depls, int *__restrict__ mode)
+{
+    M::stage_begin();
+    M::stage_end();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *pp = props + i*7;
+    double d[6], t[6];
+    for (int k = 0; k < 6; ++k) { d[k] = de[i*6 + k]; t[k] = s[i*6 + k]; }
+    bool past = false;
+    int fm = 0;
+    const double dp = desk::elasto_plastic<M, 0>(pp[0], pp[1], pp[2], pp[3], pp[4], pp[5], pp[6], d, t, &past, &fm);
+    for (int k = 0; k < 6; ++k) s[i*6 + k] = t[k];
+    depls[i] = dp;
+    mode[i] = fm + (past ? 1000 : 0);
+}
+
 __global__ void k_count_nan(const double *a, long long n, unsigned long long *count)
 {
     long long i = (long long)blockIdx.x * DES_BLOCK + threadIdx.x;

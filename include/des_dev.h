@@ -98,6 +98,25 @@ int des_dev_check_nan(des_dev *h, long long *n_nan);
 enum { DES_LIBM_POW = 0, DES_LIBM_EXP = 1, DES_LIBM_SIN = 2, DES_LIBM_COS = 3, DES_LIBM_TAN = 4, DES_LIBM_ATAN2 = 5 };
 int des_dev_libm_eval(int device, int fn, long long n, const double *x, const double *y, double *out);
 
+/* Diagnostic: the device build of the reference's 3x3 symmetric eigen-solvers over n tensors, so
+ * that the vectors produced by the reference's own compiled 3x3-C (tests/golden/eigen_kat.json)
+ * can be put to the HIP code itself.  a[n][6] = {A00, A11, A22, A01, A02, A12}; w[n][3];
+ * q[n][9] row-major with the eigenvectors in columns (unused for dsyevc3); branch[n] (may be
+ * NULL) = 1 where dsyevh3 handed over to the QL solver (3x3-C/dsyevh3.c:152, 177), for dsyevq3
+ * its return value.  libm: 0 ocml, 1 the portable set (des_libm.hpp).  Host pointers.
+ * Replaces: dsyevc3 (3x3-C/dsyevc3.c:31-80), dsyevh3 (dsyevh3.c:112-215), dsyevq3 + dsytrd3
+ * (dsyevq3.c:245-350, dsytrd3.c:379-455). */
+enum { DES_EIG_DSYEVC3 = 0, DES_EIG_DSYEVH3 = 1, DES_EIG_DSYEVQ3 = 2 };
+int des_dev_eigen_eval(int device, int fn, int libm, long long n, const double *a, double *w, double *q, int *branch);
+
+/* Diagnostic: n independent calls of the device's elasto_plastic (rheology.cxx:312-484, THREED):
+ * props[n][7] = {bulkm, shearm, amc, anphi, anpsi, hardn, ten_max}, de[n][6] strain increment,
+ * s[n][6] stress in / out, depls[n] out; mode[n] (may be NULL) = the reference's failure_mode
+ * (0 none, 1 tensile, 10 shear) + 100 if dsyevh3 fell back to dsyevq3 + 1000 if the element got
+ * past the eigenvalue pre-filter (rheology.cxx:354-361). */
+int des_dev_elasto_plastic_eval(int device, int libm, long long n, const double *props, const double *de,
+                                double *s, double *depls, int *mode);
+
 /* Timing helpers for bench.py: HIP-event bracket on the engine's own stream. */
 int des_dev_timer_start(des_dev *h);
 int des_dev_timer_stop(des_dev *h, float *ms);

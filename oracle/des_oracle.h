@@ -50,6 +50,8 @@ int des_oracle_set_libm(int portable);
 /* CPU build of the portable libm, one function over an array: fn 0 pow, 1 exp, 2 sin, 3 cos,
  * 4 tan, 5 atan2 (the numbering of des_dev_libm_eval). */
 void des_oracle_libm_eval(int fn, long long n, const double *x, const double *y, double *out);
+/* the same call with the C library's functions (std::pow ...) */
+void des_oracle_clib_eval(int fn, long long n, const double *x, const double *y, double *out);
 
 /* Stand-alone pieces exposed for known-answer tests. */
 /* eigenvalues (ascending) of the symmetric tensor s = {XX,YY,ZZ,XY,XZ,YZ};

@@ -28,6 +28,8 @@ def load_oracle(omp=False):
         lib.des_oracle_set_libm.argtypes = [C.c_int]
         lib.des_oracle_libm_eval.restype = None
         lib.des_oracle_libm_eval.argtypes = [C.c_int, C.c_longlong] + [C.POINTER(C.c_double)] * 3
+        lib.des_oracle_clib_eval.restype = None
+        lib.des_oracle_clib_eval.argtypes = [C.c_int, C.c_longlong] + [C.POINTER(C.c_double)] * 3
         d6 = C.POINTER(C.c_double)
         lib.des_oracle_principal_values3.argtypes = [d6, d6]
         lib.des_oracle_principal_stresses3.argtypes = [d6, d6, d6]
@@ -57,15 +59,17 @@ def dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def oracle_libm_eval(fn, x, y=None):
-    """CPU build of the portable libm (csrc/des_libm.hpp) through the oracle library."""
+def oracle_libm_eval(fn, x, y=None, clib=False, omp=False):
+    """CPU build of the portable libm (csrc/des_libm.hpp) through the oracle library; with
+    clib=True the C library's own function (std::pow ...), i.e. what the oracle calls by default."""
     from dynearthsol_amd import LIBM_FN
-    lib = load_oracle()
+    lib = load_oracle(omp)
     x = np.ascontiguousarray(x, dtype=np.float64)
     out = np.empty_like(x)
     if y is not None:
         y = np.ascontiguousarray(y, dtype=np.float64)
-    lib.des_oracle_libm_eval(LIBM_FN[fn], x.size, dptr(x), dptr(y) if y is not None else None, dptr(out))
+    f = lib.des_oracle_clib_eval if clib else lib.des_oracle_libm_eval
+    f(LIBM_FN[fn], x.size, dptr(x), dptr(y) if y is not None else None, dptr(out))
     return out
 
 

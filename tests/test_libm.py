@@ -1,8 +1,17 @@
 """The portable libm (dynearthsol_amd/csrc/des_libm.hpp): accuracy against mpmath and glibc on
 the CPU build, special values, and -- on the GPU -- that the device build returns the same
 bits as the CPU build.  It exists so that device-vs-oracle parity of the creep / yield
-rheologies can be checked to the bit (tests/test_gpu_parity.py, portable-libm cases)."""
+rheologies can be checked to the bit (tests/test_gpu_parity.py, portable-libm cases).
+
+pow and exp go further: they must return the bits of the C library the CPU reference runs on
+(glibc >= 2.28 on an x86-64 host with FMA), because the creep law is the one libm use that
+reaches the state of a model that does not yield -- test_pow_exp_return_the_c_librarys_bits
+(CPU build) and test_device_pow_exp_return_the_c_librarys_bits (gfx950 build), 2e7 arguments
+each, zero mismatches allowed."""
 import math
+import os
+import platform
+import subprocess
 
 import numpy as np
 import pytest
@@ -76,7 +85,8 @@ def test_special_values():
     got = oracle_libm_eval("pow", X, Y)
     same = (got == want) | (np.isnan(got) & np.isnan(want)) | (np.abs(got - want) <= np.spacing(np.abs(want)))
     assert same.all(), list(zip(X[~same], Y[~same], got[~same], want[~same]))
-    assert np.isnan(oracle_libm_eval("pow", np.array([-2.0]), np.array([0.5]))).all()   # x < 0: NaN by contract
+    assert np.isnan(oracle_libm_eval("pow", np.array([-2.0]), np.array([0.5]))).all()   # x < 0, y not an integer
+    assert oracle_libm_eval("pow", np.array([-2.0]), np.array([3.0]))[0] == -8.0
     e = np.array([0.0, -0.0, inf, -inf, nan, 710.0, -746.0, 709.0, -745.0, 1e-320])
     with np.errstate(all="ignore"):
         want = np.exp(e)
@@ -89,6 +99,133 @@ def test_special_values():
     assert (np.signbit(got) == np.signbit(want)).all()
     assert oracle_libm_eval("sin", np.array([0.0]))[0] == 0.0 and oracle_libm_eval("cos", np.array([0.0]))[0] == 1.0
     assert np.isnan(oracle_libm_eval("sin", np.array([inf, nan]))).all()
+
+
+def _host_runs_the_fma_variant_of_glibc():
+    """glibc picks __ieee754_pow_fma / __ieee754_exp_fma when the CPU has FMA and AVX2
+    (sysdeps/x86_64/fpu/multiarch/ifunc-fma4.h); des_libm.hpp restates that variant."""
+    kind, ver = platform.libc_ver()
+    if kind != "glibc" or tuple(int(v) for v in ver.split(".")[:2]) < (2, 28) or platform.machine() != "x86_64":
+        return False
+    with open("/proc/cpuinfo") as f:
+        flags = next((ln for ln in f if ln.startswith("flags")), "").split()
+    return "fma" in flags and "avx2" in flags
+
+
+needs_glibc_fma = pytest.mark.skipif(not _host_runs_the_fma_variant_of_glibc(),
+                                     reason="host C library is not glibc >= 2.28 on x86-64 with FMA + AVX2: its pow/exp "
+                                            "take another code path (last-bit differences in a few calls per thousand)")
+
+
+def _c_library_cases(rng, n):
+    """Arguments of the creep law (matprops.cxx:359-366: pow(edot, 1/n - 1), exp((E + V p)/(n R T)))
+    over and beyond the range any model reaches, plus everything off the main path."""
+    lu = lambda a, b: np.exp(rng.uniform(np.log(a), np.log(b), n))
+    sgn = lambda: rng.choice([-1.0, 1.0], n)
+    return {
+        "pow creep law": ("pow", lu(1e-30, 1e-8), 1 / rng.uniform(1, 6, n) - 1),
+        "pow wide": ("pow", lu(1e-320, 1e308), rng.uniform(-3, 3, n)),
+        "pow near 1": ("pow", rng.uniform(0.99, 1.01, n), rng.uniform(-6e4, 6e4, n)),
+        "pow tiny / huge exponents": ("pow", rng.uniform(0.5, 2, n), rng.standard_normal(n) * 10.0 ** rng.integers(-70, 66, n)),
+        "pow negative base": ("pow", -lu(1e-5, 1e5), np.where(rng.random(n) < 0.85, np.round(rng.uniform(-20, 20, n)), rng.uniform(-20, 20, n))),
+        "exp creep law": ("exp", rng.uniform(0, 400, n), None),
+        "exp wide": ("exp", rng.uniform(-760, 720, n), None),
+        "exp tiny": ("exp", lu(1e-320, 1) * sgn(), None),
+    }
+
+
+def _mismatches(a, b):
+    return int(((a.view(np.uint64) != b.view(np.uint64)) & ~(np.isnan(a) & np.isnan(b))).sum())
+
+
+@needs_glibc_fma
+def test_pow_exp_return_the_c_librarys_bits():
+    """CPU build of deslibm::pow / exp against std::pow / std::exp of this host: 2e7 arguments
+    (5e6 of them in the creep law's own range), special values included -- no mismatch."""
+    rng = np.random.default_rng(2028)
+    total = 0
+    for name, (fn, x, y) in _c_library_cases(rng, 2_500_000).items():
+        ours, libc = oracle_libm_eval(fn, x, y, omp=True), oracle_libm_eval(fn, x, y, clib=True, omp=True)
+        assert _mismatches(ours, libc) == 0, (name, _mismatches(ours, libc))
+        total += x.size
+    assert total >= 20_000_000
+    inf, nan = np.inf, np.nan
+    v = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0, -2.0, 3.0, -3.0, inf, -inf, nan, 5e-324, -5e-324, 1e-310, 1e308, -1e308,
+                  2.2250738585072014e-308, 709.78, -745.13, -708.4, 1024.0, 1e-20])
+    X, Y = [a.ravel().copy() for a in np.meshgrid(v, v)]
+    assert _mismatches(oracle_libm_eval("pow", X, Y), oracle_libm_eval("pow", X, Y, clib=True)) == 0
+    assert _mismatches(oracle_libm_eval("exp", v), oracle_libm_eval("exp", v, clib=True)) == 0
+    # results in the subnormal range and at the overflow threshold (e_exp.c specialcase)
+    e = np.concatenate([rng.uniform(-745.2, -707.5, 200000), rng.uniform(709.0, 709.8, 200000)])
+    assert _mismatches(oracle_libm_eval("exp", e), oracle_libm_eval("exp", e, clib=True)) == 0
+    xs, ys = rng.uniform(1e-3, 1e-1, 200000), rng.uniform(100, 160, 200000)
+    assert _mismatches(oracle_libm_eval("pow", xs, ys), oracle_libm_eval("pow", xs, ys, clib=True)) == 0
+
+
+def test_tables_equal_the_c_librarys():
+    """The pow / exp tables of des_libm_tables.hpp (recomputed by tools/gen_libm_tables.py from the
+    recipe glibc's sources document) and the quoted coefficients against the data objects
+    __exp_data / __pow_log_data of this image's static libm."""
+    import glob
+    import re
+    import struct
+    import tempfile
+    arch = glob.glob("/lib/x86_64-linux-gnu/libm-2.*.a") + glob.glob("/usr/lib/x86_64-linux-gnu/libm-2.*.a")
+    if not arch:
+        pytest.skip("no static libm to read the C library's tables from")
+
+    def rodata(member):
+        with tempfile.TemporaryDirectory() as d:
+            subprocess.check_call(["ar", "x", arch[0], member], cwd=d)
+            path = os.path.join(d, member)
+            for ln in subprocess.check_output(["readelf", "-S", "-W", path]).decode().splitlines():
+                m = re.search(r"\]\s+\.rodata\s+PROGBITS\s+\S+\s+(\S+)\s+(\S+)", ln)
+                if m:
+                    off, size = int(m.group(1), 16), int(m.group(2), 16)
+                    with open(path, "rb") as f:
+                        return f.read()[off:off + size]
+        raise AssertionError("no .rodata in " + member)
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "dynearthsol_amd", "csrc", "des_libm_tables.hpp")) as f:
+        src = f.read()
+
+    def arr(name):
+        m = re.search(r"double %s\[\d+\] = \{(.*?)\};" % name, src, re.S)
+        return np.array([float(t) for t in m.group(1).replace("\n", " ").split(",") if t.strip()])
+
+    def scalar(name):
+        return float(re.search(r"%s = ([-+0-9.e]+)" % name, src).group(1))
+
+    e = rodata("e_exp_data.o")           # struct exp_data (sysdeps/ieee754/dbl-64/math_config.h)
+    invln2N, shift, nhi, nlo = struct.unpack("<4d", e[:32])
+    assert (invln2N, nhi, nlo) == (scalar("des_exp_invln2N"), scalar("des_exp_negln2hiN"), scalar("des_exp_negln2loN"))
+    assert shift == 6755399441055744.0
+    assert np.array_equal(np.frombuffer(e[32:64]), arr("des_exp_C"))
+    tab = np.frombuffer(e[112:112 + 2048], dtype=np.uint64)
+    assert np.array_equal(tab[0::2], arr("des_exp_tail").view(np.uint64))
+    k = np.arange(128, dtype=np.uint64)
+    assert np.array_equal(tab[1::2], arr("des_exp_hi").view(np.uint64) - (k << np.uint64(45)))
+    p = rodata("e_pow_log_data.o")       # struct pow_log_data
+    assert struct.unpack("<2d", p[:16]) == (scalar("des_ln2hi"), scalar("des_ln2lo"))
+    assert np.array_equal(np.frombuffer(p[16:72]), arr("des_log_A"))
+    t = np.frombuffer(p[72:72 + 128 * 32]).reshape(128, 4)
+    assert np.array_equal(t[:, 0], arr("des_log_invc")) and np.array_equal(t[:, 2], arr("des_log_chi"))
+    assert np.array_equal(t[:, 3], arr("des_log_clo"))
+
+
+@pytest.mark.gpu
+@needs_glibc_fma
+def test_device_pow_exp_return_the_c_librarys_bits():
+    """The gfx950 build against the C library of the GPU box's host: 2e7 arguments, no mismatch."""
+    import dynearthsol_amd as des
+    rng = np.random.default_rng(2029)
+    total = 0
+    for name, (fn, x, y) in _c_library_cases(rng, 2_500_000).items():
+        dev, libc = des.libm_eval(fn, x, y), oracle_libm_eval(fn, x, y, clib=True, omp=True)
+        assert _mismatches(dev, libc) == 0, (name, _mismatches(dev, libc))
+        total += x.size
+    assert total >= 20_000_000
 
 
 @pytest.mark.gpu
