@@ -3,19 +3,28 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" is one explicit time step (dynearthsol.cxx:768-894) of the whole mesh.  The
-workload at N=1 is BASELINE.json configs[2] as SURVEY.md 8(d) pins it down: the
-benchmarks-cores/test-3d-big.cfg box (400 x 20 x 10 km, elasto-visco-plastic variant) at
->= 1M tetrahedra.  The reference's TetGen mesher is a host-side library that cannot run on
-the GPU box, so the mesh is the reference's own regular mesher (meshing_option = 1,
-meshing_elem_shape = 1: 5 tets per grid cell, mesh.cxx:1431-1459), rebuilt by the host
-library: 560 x 28 x 14 cells = 1,097,600 tets / 244,035 nodes.  Fields are the model's own
-initial conditions (synthetic in the sense of: no input data files).
+One "step" is one explicit time step (dynearthsol.cxx:768-894) of the whole mesh.  The workload
+is BASELINE.json configs[2] / configs[3] as SURVEY.md 8(d) pins it down: the
+benchmarks-cores/test-3d-big.cfg box (400 x 20 x 10 km), elasto-visco-plastic variant, thermal
+diffusion + mixed stress + surface diffusion on, on the REFERENCE'S OWN MESH of that box at
+mesh.resolution = 460 m: 1,001,310 tets / 185,637 nodes, made by the reference's TetGen
+(data/test-3d-big-460.desmesh.xz; recipe `make -C oracle refmesh`).  Fields are the model's own
+initial conditions (synthetic in the sense of: no input data files).  Where the mesh file is
+missing, or with --mesh regular, the reference's regular mesher (meshing_option = 1,
+meshing_elem_shape = 1: 5 tets per grid cell, mesh.cxx:1431-1459) builds 560 x 28 x 14 cells =
+1,097,600 tets instead; `config.workload` says which.
 
-Prints ONE JSON line (rank 0).  `value` = elements x steps / s summed over all ranks, timed
-with state resident in HBM; `roofline` is the dominant kernel's algorithmic bytes over its
-measured HIP-event duration against 8 TB/s; `cpu_baseline` is the CPU oracle (OpenMP build,
-kind "port") timed on this box's host cores on a bounded number of steps of the same mesh.
+N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling by default -- the same
+~1M-tet mesh cut into N slabs of contiguous node ids (configs[3]); --weak keeps 1.1M tets per GPU
+(regular mesh, box N times as long).  The ghost-region exchange is RCCL inside des_dev_step; if
+the engine's communicator does not come up the run FAILS (exit 3) unless DES_BENCH_TRANSPORT=host
+asks for the host-staged rehearsal transport.  DES_OVERLAP=1 selects the overlapped schedule.
+
+Prints ONE JSON line (rank 0).  `value` = elements x steps / s of the whole job, timed with state
+resident in HBM; `roofline` is the dominant kernel's algorithmic bytes over its measured
+HIP-event duration against 8 TB/s, with a measured device-copy ceiling beside it;
+`cpu_baseline` is the CPU oracle (OpenMP build, kind "port") timed on this box's host cores on a
+bounded number of steps of the same mesh.
 """
 import argparse
 import json
@@ -103,15 +112,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--resolution", type=float, default=400e3 / 560)
+    ap.add_argument("--mesh", default=None, choices=["tetgen", "regular"],
+                    help="tetgen: the reference's TetGen mesh of the box at 460 m, 1,001,310 tets (default when "
+                         "data/test-3d-big-460.desmesh.xz is there); regular: the reference's regular mesher, 1,097,600 tets")
+    ap.add_argument("--resolution", type=float, default=None, help="regular mesh: cell size in m (default 400e3/560); implies --mesh regular")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="steps of the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: keep the 1.1M-tet mesh and cut it N ways (default: weak scaling, "
-                         "the box grows N times in x so every GPU keeps 1.1M tets)")
-    ap.add_argument("--mesh-file", default=None,
-                    help="take the mesh from a .desmesh file (e.g. the reference's TetGen mesh of test-3d-big.cfg at "
-                         "resolution 460 m, 1,001,310 tets, written by oracle/_ref/tetmesh) instead of the regular mesher; N=1")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: weak scaling (regular mesh, the box grows N times in x so every GPU keeps 1.1M tets) "
+                         "instead of the default strong scaling on the fixed ~1M-tet mesh")
+    ap.add_argument("--strong", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--mesh-file", default=None, help="another .desmesh file of the same box instead")
     ap.add_argument("--workload", default="test-3d-big", choices=["test-3d-big", "test-3d-equ-long"],
                     help="test-3d-big (default, the BASELINE config) or the reference's 984,375-tet seven-material "
                          "regular-mesh benchmark benchmarks-cores/test-3d-equ-long.cfg (values restated in tests/cfgs.py); N=1")
@@ -149,25 +161,39 @@ def main():
         if os.environ.get("DES_BENCH_VERBOSE"):
             sys.stderr.write("[bench rank %d %.1fs] %s\n" % (rank, time.perf_counter() - t_begin, msg)); sys.stderr.flush()
 
-    # weak scaling: the test-3d-big box is repeated N times along x (same resolution), then cut
-    # into N slabs of contiguous node ids -- every GPU holds ~1.1M tets plus its four-layer ghost region
-    xlen = 400e3 * (1 if args.strong else world)
+    # which mesh: the reference's TetGen mesh of the box unless a regular one is asked for / needed
+    strong = not args.weak
+    mesh_file = args.mesh_file
+    mesh_kind = "file" if mesh_file else args.mesh
+    if mesh_kind is None:
+        mesh_kind = "regular" if (args.resolution is not None or args.weak or args.workload != "test-3d-big") else "tetgen"
+    if mesh_kind == "tetgen":
+        mesh_file = des.reference_mesh("test-3d-big-460")
+        if mesh_file is None:
+            if args.mesh == "tetgen":
+                sys.exit("bench.py: data/test-3d-big-460.desmesh.xz is missing (make -C oracle refmesh)")
+            mesh_kind = "regular"
+        elif args.weak:
+            sys.exit("bench.py: --weak scales the regular mesh; it cannot be combined with --mesh tetgen")
+    resolution = args.resolution if args.resolution is not None else 400e3 / 560
+    # weak scaling: the box is repeated N times along x (same resolution), then cut into N slabs of
+    # contiguous node ids -- every GPU holds ~1.1M tets plus its four-layer ghost region
+    xlen = 400e3 * (1 if strong else world)
     overrides = "" if args.rheology == "elasto-visco-plastic" else "mat.rheology_type = %s\n" % args.rheology
     if args.averaged_fields:
         overrides += "sim.is_outputting_averaged_fields = yes\nmesh.quality_check_step_interval = 100\n"
-    if args.mesh_file:
-        assert world == 1, "--mesh-file is a single-GPU workload"
+    if mesh_file:
         overrides += "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n"
     note("building the host model")
     if args.workload == "test-3d-equ-long":
-        assert world == 1 and not args.mesh_file, "--workload test-3d-equ-long is a single-GPU workload"
+        assert world == 1 and not mesh_file, "--workload test-3d-equ-long is a single-GPU regular-mesh workload"
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import cfgs
         host = des.Host(cfg_text=cfgs.make_equ(long=True),
                         overrides=(overrides or "") + "sim.max_steps = 1000000\nsim.output_step_interval = 1000000\n")
     else:
-        host = des.Host(cfg_text=BENCH_CFG.format(res=repr(args.resolution), xlen=repr(xlen)), overrides=overrides or None,
-                        mesh_file=args.mesh_file)
+        host = des.Host(cfg_text=BENCH_CFG.format(res="460.0" if mesh_kind == "tetgen" else repr(resolution), xlen=repr(xlen)),
+                        overrides=overrides or None, mesh_file=mesh_file)
     device = int(os.environ.get("DES_BENCH_DEVICE", local_rank))
     transport = "RCCL ncclSend/ncclRecv on the engine stream"
     if world == 1:
@@ -185,24 +211,29 @@ def main():
         note("engine")
         dev = des.DeviceEngine(part, device=device)
         dev.set_halo(part)
-        # The ghost-region exchange runs inside des_dev_step on RCCL.  Should the engine's own
-        # communicator fail to come up on this node, the same step is driven in its two phases
-        # with the ghost state staged through the host over gloo -- slower, said so in the line.
+        # The ghost-region exchange runs inside des_dev_step on RCCL.  If the engine's communicator
+        # does not come up the bench FAILS: a number over another transport must not pass for the
+        # real thing.  DES_BENCH_TRANSPORT=host asks for the rehearsal transport explicitly (the same
+        # step driven in its two phases, ghost state staged through the host over gloo).
+        want_host = os.environ.get("DES_BENCH_TRANSPORT", "rccl") != "rccl"
         ok = 1
-        try:
-            if os.environ.get("DES_BENCH_TRANSPORT", "rccl") != "rccl":
-                raise des.DesError(31, "host transport requested")
-            dev.comm_init(dist, rank, world)
-        except des.DesError as e:
-            sys.stderr.write("rank %d: %s\n" % (rank, e))
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        if not want_host:
+            try:
+                dev.comm_init(dist, rank, world)
+            except des.DesError as e:
+                sys.stderr.write("rank %d: %s\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                sys.stderr.write("bench.py: the RCCL communicator of the engine did not come up on every rank; no result "
+                                 "(DES_BENCH_TRANSPORT=host selects the host-staged rehearsal transport)\n")
+                dist.destroy_process_group()
+                sys.exit(3)
             init_rank(dev, part, _Comm())
         else:
             from dynearthsol_amd.decomp import PhasedStepper, TorchComm
-            transport = "host-staged over gloo (engine communicator unavailable)"
+            transport = "host-staged over gloo (DES_BENCH_TRANSPORT=host: rehearsal, not RCCL)"
             comm = TorchComm(dist, group=dist.new_group(backend="gloo"))
             init_rank(dev, part, comm)
             stepper = PhasedStepper(dev, part, comm)
@@ -246,25 +277,44 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * wall / args.steps,
         "higher_is_better": True,
-        "scaling": "strong" if args.strong else "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": ("test-3d-equ-long.cfg box 250x50x125 km, 7 materials, " if args.workload == "test-3d-equ-long" else
-                         "test-3d-big.cfg box 400x20x10 km, ") + args.rheology + ", thermal+NMD+surface diffusion on, "
+                         "test-3d-big.cfg box %.0fx20x10 km, " % (xlen / 1e3)) + args.rheology + ", thermal+NMD+surface diffusion on, "
                         + ("averaged output fields on, " if args.averaged_fields else "")
-                        + ("mesh file %s, " % os.path.basename(args.mesh_file) if args.mesh_file else "regular 5-tet mesh, ")
-                        +
-                        "%d tets / %d nodes in total" % (ne, nn),
+                        + {"tetgen": "the reference's TetGen mesh at mesh.resolution = 460 m (data/test-3d-big-460.desmesh.xz), ",
+                           "file": "mesh file %s, " % os.path.basename(mesh_file or ""),
+                           "regular": "the reference's regular 5-tet mesher at %.6g m, " % resolution}[mesh_kind]
+                        + "%d tets / %d nodes in total" % (ne, nn)
+                        + ("" if world == 1 else (", cut %d ways (strong scaling)" % world if strong else
+                                                  ", %d x the box (weak scaling)" % world)),
             "nelem": ne, "nnode": nn, "nelem_local_rank0": ne_local,
             "parallelism": "single GPU" if world == 1 else
                            "%d slabs of contiguous node ids, four-layer ghost region, one exchange per step; transport: %s" % (world, transport),
             "steps_per_s": args.steps / wall,
             "hip_event_ms_per_step": ev_ms / args.steps,
             "nan_entries": nan, "status": sc.status,
+            "libm": os.environ.get("DES_LIBM", "portable (pow/exp = glibc's bits)"),
         },
     }
+    if world > 1:
+        # what actually carried the ghost region: ranks of the engine's RCCL communicator (0 = none:
+        # host-staged rehearsal), and the redundant work the four ghost layers cost
+        info = dev.comm_info()
+        counts = torch.tensor([float(ne_local), float(info["rccl_ranks"])], dtype=torch.float64,
+                              device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        ne_sum = float(counts[0].item())
+        result["config"].update({
+            "rccl_ranks": info["rccl_ranks"],
+            "rccl_ranks_sum_over_ranks": int(counts[1].item()),          # = world^2 when every rank is in one communicator
+            "overlapped_schedule": info["overlapped"],
+            "ghost_work_share": (ne_sum - ne) / ne_sum,                    # elements computed redundantly / all computed
+            "nelem_local_sum": int(ne_sum),
+        })
 
     # per-kernel HIP-event timing on the engine's own stream (separate short run).  EVERY rank
     # takes these steps: a step is collective on a decomposed mesh.
@@ -274,6 +324,22 @@ def main():
         dev.step(20, want_scalars=False)
         prof = dev.profile_read()
         dev.profile_enable(False)
+
+    if world > 1 and prof is not None:
+        ex = [ms / calls * 1e3 for n, ms, calls in prof if n == "ghost_exchange"]
+        t = torch.tensor([ex[0] if ex else -1.0], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        allx = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allx, t)
+        # per rank: pack + grouped ncclSend/ncclRecv + unpack, HIP events on the stream they run on
+        # (includes waiting for the slower neighbour); -1: this rank's exchange did not go through the engine
+        result["config"]["exchange_us_per_rank"] = [float(x.item()) for x in allx]
+
+    ceiling = None
+    if rank == 0 and not args.no_ceiling:
+        try:
+            ceiling = des.copy_ceiling(1 << 30, 20, device)
+        except des.DesError as e:
+            sys.stderr.write("copy ceiling: %s\n" % e)
 
     if rank == 0:
         bytes_step = dev.algorithmic_bytes_per_step() if world == 1 else (
@@ -293,19 +359,26 @@ def main():
                     be, bn = be + 24, bn + 8
                 kbytes = be * ne_local + bn * (nn if world == 1 else part.nnode)     # rank 0's launch
                 achieved = kbytes / (ms / calls * 1e-3) / 1e9
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                same_workload = (world == 1 and not args.mesh_file and args.workload == "test-3d-big"
-                                 and args.resolution == 400e3 / 560 and args.rheology == "elasto-visco-plastic")
-                if os.path.exists(tpath) and same_workload:       # the PMC passes were made on exactly this workload
+                # HBM bytes from the PMC counters cannot be collected inside the timed run (separate
+                # rocprofv3 passes, MI355X_MICROARCH.md): tools/measure_traffic.py makes them for a
+                # named workload and commits the summary; it is quoted only for that very workload
+                traffic, tsrc = None, None
+                for tname in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+                    tpath = os.path.join(ROOT, "profiles", tname)
+                    if not os.path.exists(tpath):
+                        continue
                     try:
-                        # PMC passes cannot share a run with the timed one: the committed summary of
-                        # `tools/summarize_pmc.py` for the same workload is reported (bytes per launch)
-                        traffic = json.load(open(tpath)).get(dom, {}).get("traffic_bytes_per_launch")
+                        tj = json.load(open(tpath))
                     except Exception:
-                        traffic = None
+                        continue
+                    same = (world == 1 and args.rheology == "elasto-visco-plastic" and not args.averaged_fields
+                            and tj.get("workload", {"nelem": 1097600, "nnode": 244035}) == {"nelem": ne, "nnode": nn})
+                    if same and dom in tj:
+                        traffic, tsrc = tj[dom].get("traffic_bytes_per_launch"), "profiles/" + tname
+                        break
                 roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                        "ceiling_GBs": ceiling, "frac_of_ceiling": (achieved / ceiling) if ceiling else None,
                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": ms / calls}
         result["roofline"] = roof
 

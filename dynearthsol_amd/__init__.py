@@ -130,6 +130,17 @@ def load_hip_lib():
 LIBM_FN = {"pow": 0, "exp": 1, "sin": 2, "cos": 3, "tan": 4, "atan2": 5}       # DES_LIBM_* (des_dev.h)
 
 
+def copy_ceiling(nbytes=1 << 30, reps=20, device=0):
+    """Measured streaming-copy bandwidth of the device in GB/s (read + written bytes over time)."""
+    lib = load_hip_lib()
+    lib.des_dev_copy_ceiling.argtypes = [C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_double)]
+    g = C.c_double(0)
+    rc = lib.des_dev_copy_ceiling(device, nbytes, reps, C.byref(g))
+    if rc:
+        raise DesError(rc, lib.des_dev_last_error().decode())
+    return g.value
+
+
 def libm_eval(fn, x, y=None, device=0):
     """One function of the portable libm (csrc/des_libm.hpp) evaluated on the GPU."""
     import numpy as np
@@ -412,6 +423,13 @@ class DeviceEngine(EngineBase):
     def exchange(self):
         self._lib.des_dev_exchange.argtypes = [C.c_void_p]
         self._check(self._lib.des_dev_exchange(self._h), "exchange")
+
+    def comm_info(self):
+        """{'rccl_ranks': ncclCommCount of the attached communicator (0: none), 'rank', 'overlapped'}"""
+        n, r, o = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._lib.des_dev_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        self._check(self._lib.des_dev_comm_info(self._h, C.byref(n), C.byref(r), C.byref(o)), "comm_info")
+        return {"rccl_ranks": n.value, "rank": r.value, "overlapped": bool(o.value)}
 
     def comm_init(self, dist, rank, world):
         """Attach an RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed only

@@ -90,11 +90,11 @@ struct DevClock {
 enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };
 
 enum KernelId { K_E1, K_N1, K_E2, K_E2R, K_N2, K_E3, K_N3, K_S2, K_S3,
-                K_DTFIN, K_MISC, K_COUNT };
+                K_DTFIN, K_MISC, K_EXCH, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "E2_return_mapping", "N2_nmd_gather",
     "E3_nmd_force", "N3_force_velocity_coord", "S2_surface_diffusion",
-    "S3_edvacc_step_finalize", "dt_finalize", "misc" };
+    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
 
@@ -188,6 +188,12 @@ struct des_dev {
     double *dh_n;                                          // nodal copy of surfinfo.dh
     ncclComm_t comm;
     int comm_rank, comm_size;
+    // overlapped schedule (DES_OVERLAP=1): side stream + fork / join events; interior elements
+    // (every node owned) are [e_int0, e_int1) in the engine's order
+    bool overlap;
+    hipStream_t comm_stream;
+    hipEvent_t ev_fork, ev_join;
+    int e_int0, e_int1;
     // element part of the exchange lists and the record offsets inside the message buffers
     std::vector<int> esend_ptr, erecv_ptr;
     std::vector<long long> send_off, recv_off;             // [nnbr+1] message offsets (doubles) per neighbour
@@ -245,6 +251,9 @@ void des_dev_destroy(des_dev *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm_stream) { hipStreamSynchronize(h->comm_stream); hipStreamDestroy(h->comm_stream); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
@@ -290,6 +299,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     {
         const char *gr = std::getenv("DES_GRAPH");
         h->use_graph = gr && gr[0] == '1';
+        const char *ov = std::getenv("DES_OVERLAP");
+        h->overlap = ov && ov[0] == '1';
         const char *e2d = std::getenv("DES_E2_DEFER");
         h->e2_defer = (e2d && (e2d[0] == '0' || e2d[0] == '1')) ? e2d[0] - '0' : 2;
         h->e2_two_pass = h->e2_defer != 0;
@@ -310,7 +321,10 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             build_perm_mesh(mesh, pm);
             h->n_new2old.swap(pm.n_new2old); h->n_old2new.swap(pm.n_old2new);
             h->e_new2old.swap(pm.e_new2old); h->e_old2new.swap(pm.e_old2new);
+            h->e_int0 = pm.e_int0; h->e_int1 = pm.e_int1;
             mesh = &pm.view;             // everything below builds the device state in the internal order
+        } else {
+            h->e_int0 = 0; h->e_int1 = 0;      // caller's order kept: no interior range known, no overlap
         }
     }
     const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
@@ -324,6 +338,11 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
                    *err = DES_ERR_RESOURCE; des_dev_destroy(h); return nullptr; } } while (0)
     HK(hipStreamCreate(&h->stream));
     HK(hipEventCreate(&h->ev0)); HK(hipEventCreate(&h->ev1));
+    if (h->overlap) {
+        HK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        HK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
     HK(hipHostMalloc((void **)&h->h_clk, sizeof(DevClock)));
 
     CK(dev_alloc(h->d_p, 1)); CK(dev_alloc(h->d_vt, 1)); CK(dev_alloc(h->d_clk, 1));
@@ -769,6 +788,22 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         launch_e3(h);
         launch_n3(h);
         launch_s2(h, step_no);
+        const bool last = (i == nsteps - 1);
+        const bool overlapped = multi && h->overlap && !iso && h->e_int1 > h->e_int0;
+        if (overlapped) {
+            // exchange on the side stream || end-of-step pass of the interior elements; then the
+            // rest of the surface bookkeeping (it reads the ghost nodes' dh) and the two element
+            // groups that touch the ghost region
+            launch_s3(h, true, false, false);
+            if ((rc = exchange_begin(h))) return rc;
+            launch_e1_end(h, step_no, !last, E1_INTERIOR);
+            if ((rc = exchange_join(h))) return rc;
+            launch_avg_coord0(h, step_no);                 // owned and ghost coordinates alike: after the join
+            launch_s3(h, false, true, true);
+            launch_e1_end(h, step_no, !last, E1_GHOST_SIDE);
+            if (step_no % 10 == 0 && (rc = reduce_dt(h))) return rc;
+            continue;
+        }
         if (multi) {
             launch_s3(h, true, false, false);                      // commit the surface heights
             if ((rc = exchange(h))) return rc;
@@ -776,7 +811,6 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         } else {
             launch_s3(h, true, true, true);
         }
-        const bool last = (i == nsteps - 1);
         if (iso) {                                         // no averaging, no compute_dt in that loop
             if (last) launch_e1<MODE_C>(h); else launch_e1<MODE_C | MODE_A>(h);
             continue;
@@ -898,6 +932,21 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
     if (r != ncclSuccess) { g_last_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); h->comm = nullptr; return DES_ERR_RESOURCE; }
     h->comm_rank = rank; h->comm_size = nranks;
+    return DES_OK;
+}
+
+int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    int n = 1, r = 0;
+    if (h->comm) {
+        if (ncclCommCount(h->comm, &n) != ncclSuccess || ncclCommUserRank(h->comm, &r) != ncclSuccess) {
+            g_last_error = "ncclCommCount failed"; return DES_ERR_RESOURCE;
+        }
+    }
+    if (nranks) *nranks = h->comm ? n : 0;
+    if (rank) *rank = r;
+    if (overlapped) *overlapped = h->overlap && h->nnbr > 0 && h->e_int1 > h->e_int0;
     return DES_OK;
 }
 
@@ -1116,6 +1165,91 @@ int des_dev_mesh_quality(des_dev *h, double smallest_vol, double bottom, double 
     out->worst_elem = res.i[2] == INT_MAX ? 0 : res.i[2];      // no element below quality 1: the reference keeps 0
     out->worst_quality = res.q; out->pad_ = 0;
     return DES_OK;
+}
+
+// *gbs = the best of a few launch shapes of that copy, (bytes read + bytes written) / time
+int des_dev_copy_ceiling(int device, long long bytes, int reps, double *gbs)
+{
+    if (!gbs || bytes < 16 || reps < 1) return DES_ERR_INTERNAL;
+    if (des_dev_device_count() <= device) { g_last_error = "no such HIP device"; return DES_ERR_UNSUPPORTED; }
+    HIP_OK(hipSetDevice(device));
+    const size_t n = (size_t)bytes / 16;
+    double2 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DES_OK;
+    *gbs = 0;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == DES_OK) { rc = DES_ERR_RESOURCE; g_last_error = hipGetErrorString(e); } return e == hipSuccess; };
+    if (ok(hipMalloc((void **)&a, n * 16)) && ok(hipMalloc((void **)&b, n * 16)) && ok(hipMemset(a, 1, n * 16)) && ok(hipMemset(b, 0, n * 16))
+        && ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1))) {
+        for (int variant = 0; variant < 6 && rc == DES_OK; ++variant) {
+            const unsigned per_cu[3] = {4, 8, 16};
+            const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * per_cu[variant % 3]);
+            auto launch = [&]() {
+                if (variant < 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_copy16<4, false>), dim3(grid), dim3(256), 0, 0, a, b, n);
+                else             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_copy16<4, true>), dim3(grid), dim3(256), 0, 0, a, b, n);
+            };
+            launch();                                                                     // warm-up
+            ok(hipEventRecord(e0, 0));
+            for (int r = 0; r < reps; ++r) launch();
+            ok(hipEventRecord(e1, 0));
+            ok(hipEventSynchronize(e1));
+            float ms = 0;
+            if (ok(hipEventElapsedTime(&ms, e0, e1)) && ms > 0) *gbs = std::max(*gbs, 2.0 * n * 16 * reps / (ms * 1e-3) / 1e9);
+        }
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    return rc;
+}
+
+// items: lanes of the launch.  Bytes per launch: pattern 0 reads 16 and writes 16 per item; 1 reads 8,
+// writes 8; 2 reads 4 (index) + 32 (record), writes 8; 3 reads 4 + 8, writes 8 (gathers touch every
+// record exactly once, in a random order that defeats coalescing but not the caches' line reuse).
+int des_dev_access_bench(int device, int pattern, long long items, int reps, double *ms_per_launch)
+{
+    if (pattern < 0 || pattern > 3 || items < 1 || items > (1ll << 31) - 1 || reps < 1) return DES_ERR_INTERNAL;
+    if (des_dev_device_count() <= device) { g_last_error = "no such HIP device"; return DES_ERR_UNSUPPORTED; }
+    HIP_OK(hipSetDevice(device));
+    const size_t n = (size_t)items;
+    const size_t src_doubles = pattern == 0 ? 2 * n : pattern == 2 ? 4 * n : n, dst_doubles = pattern == 0 ? 2 * n : n;
+    DiagBuf b;
+    double *src = b.out<double>(src_doubles), *dst = b.out<double>(dst_doubles);
+    int *perm = nullptr;
+    if (b.rc) return b.rc;
+    if (pattern >= 2) {
+        std::vector<int> p(n);
+        for (size_t i = 0; i < n; ++i) p[i] = (int)i;
+        unsigned long long st = 88172645463325252ull;                      // xorshift: a fixed shuffle
+        for (size_t i = n - 1; i > 0; --i) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            std::swap(p[i], p[st % (i + 1)]);
+        }
+        perm = b.in(p.data(), n);
+        if (b.rc) return b.rc;
+    }
+    HIP_OK(hipMemset(src, 0, src_doubles * 8));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    const dim3 grid((unsigned)((n + 255) / 256));
+    auto launch = [&]() {
+        switch (pattern) {
+        case 0: hipLaunchKernelGGL(k_access<0>, grid, dim3(256), 0, 0, src, dst, perm, n); break;
+        case 1: hipLaunchKernelGGL(k_access<1>, grid, dim3(256), 0, 0, src, dst, perm, n); break;
+        case 2: hipLaunchKernelGGL(k_access<2>, grid, dim3(256), 0, 0, src, dst, perm, n); break;
+        default: hipLaunchKernelGGL(k_access<3>, grid, dim3(256), 0, 0, src, dst, perm, n); break;
+        }
+    };
+    launch();
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) launch();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms_per_launch) *ms_per_launch = ms / reps;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? DES_OK : DES_ERR_RESOURCE;
 }
 
 int des_dev_timer_start(des_dev *h)

@@ -6,27 +6,56 @@
 
 // The exchange of a step: one grouped send/recv per neighbour carrying the state of the whole
 // ghost region, between a pack and an unpack launch, all on the engine's stream.
-int exchange(des_dev *h)
+// `xs`: the stream the transfer and the unpack are issued on -- the engine's own, or (overlapped
+// schedule) the side stream; the pack always runs on the engine's stream.
+int exchange(des_dev *h, hipStream_t xs)
 {
     if (h->nnbr == 0) return DES_OK;
     if (!h->comm) { g_last_error = "decomposed engine without a communicator: call des_dev_comm_init"; return DES_ERR_INTERNAL; }
     const int ns = h->send_ptr[h->nnbr], nes = h->esend_ptr[h->nnbr];
     const int nr = h->recv_ptr[h->nnbr], ner = h->erecv_ptr[h->nnbr];
-    hipLaunchKernelGGL(k_state_pack, dim3(nblk(ns + nes)), dim3(DES_BLOCK), 0, h->stream, ns, h->d_send_idx, h->d_send_noff,
-                       nes, h->d_esend_idx, h->d_send_eoff, h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain,
-                       h->ne, h->d_sendbuf);
+    const bool side = xs != h->stream;
+    {
+        Launch l(h, K_EXCH);
+        hipLaunchKernelGGL(k_state_pack, dim3(nblk(ns + nes)), dim3(DES_BLOCK), 0, h->stream, ns, h->d_send_idx, h->d_send_noff,
+                           nes, h->d_esend_idx, h->d_send_eoff, h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain,
+                           h->ne, h->d_sendbuf);
+        if (side) {
+            // fork: everything up to and including the pack precedes the transfer.  (The pack stays on
+            // the engine's stream: it reads the stress of elements the interior pass is about to rotate.)
+            HIP_OK(hipEventRecord(h->ev_fork, h->stream));
+            HIP_OK(hipStreamWaitEvent(xs, h->ev_fork, 0));
+        }
+    }
+    Launch l(h, K_EXCH, xs);
     ncclGroupStart();
     for (int q = 0; q < h->nnbr; ++q) {
         ncclSend(h->d_sendbuf + h->send_off[q], (size_t)(h->send_off[q+1] - h->send_off[q]), ncclDouble,
-                 h->nbr_rank[q], h->comm, h->stream);
+                 h->nbr_rank[q], h->comm, xs);
         ncclRecv(h->d_recvbuf + h->recv_off[q], (size_t)(h->recv_off[q+1] - h->recv_off[q]), ncclDouble,
-                 h->nbr_rank[q], h->comm, h->stream);
+                 h->nbr_rank[q], h->comm, xs);
     }
     ncclResult_t r = ncclGroupEnd();
     if (r != ncclSuccess) { g_last_error = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
-    hipLaunchKernelGGL(k_state_unpack, dim3(nblk(nr + ner)), dim3(DES_BLOCK), 0, h->stream, nr, h->d_recv_idx, h->d_recv_noff,
+    hipLaunchKernelGGL(k_state_unpack, dim3(nblk(nr + ner)), dim3(DES_BLOCK), 0, xs, nr, h->d_recv_idx, h->d_recv_noff,
                        ner, h->d_erecv_idx, h->d_recv_eoff, h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain,
                        h->ne, h->d_recvbuf);
+    if (side) HIP_OK(hipEventRecord(h->ev_join, xs));
+    return DES_OK;
+}
+int exchange(des_dev *h) { return exchange(h, h->stream); }
+
+// Overlapped schedule (opt-in, DES_OVERLAP=1): transfer + unpack run on a side stream while the
+// engine's stream works through the end-of-step pass of the INTERIOR elements -- those whose four
+// nodes are owned: they read owned nodes only, and what they write (their own stress / strain /
+// volume / temporaries) is neither received nor -- once the pack is done -- sent.  The unpack
+// writes ghost nodes and ghost elements only.  exchange_begin() forks after the surface heights
+// are committed and the messages packed; exchange_join() makes the engine's stream wait for the
+// unpack before anything touches the ghost region.
+int exchange_begin(des_dev *h) { return exchange(h, h->comm_stream); }
+int exchange_join(des_dev *h)
+{
+    HIP_OK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     return DES_OK;
 }
 

@@ -29,12 +29,20 @@ inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
 inline int nblk8(long long n) { int b = nblk(n); return (b + 7) / 8 * 8; }
 
 struct Launch {
-    des_dev *h; int k; ProfRec rec; bool on;
-    Launch(des_dev *h_, int k_) : h(h_), k(k_), on(h_->prof) {
-        if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, h->stream); }
+    des_dev *h; int k; ProfRec rec; bool on; hipStream_t s;
+    Launch(des_dev *h_, int k_, hipStream_t s_ = nullptr) : h(h_), k(k_), on(h_->prof), s(s_ ? s_ : h_->stream) {
+        if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, s); }
     }
-    ~Launch() { if (on) { hipEventRecord(rec.b, h->stream); h->prof_recs.push_back(rec); } }
+    ~Launch() { if (on) { hipEventRecord(rec.b, s); h->prof_recs.push_back(rec); } }
 };
+
+// Timing experiments only (tools/launch_cost.py): DES_EXP_SKIP=e2r,s2,s3,dt leaves those launches
+// out, which makes the results WRONG wherever they had work -- never set outside that tool.
+inline bool exp_skip(const char *what)
+{
+    static const char *env = std::getenv("DES_EXP_SKIP");
+    return env && std::strstr(env, what) != nullptr;
+}
 
 inline MatData mat_data(const des_dev *h) { return MatData{ h->markers, h->mono, h->props, h->ptab }; }
 
@@ -46,13 +54,20 @@ void refresh_props(des_dev *h)
     h->markers_dirty = false;
 }
 
+// which elements an E1 launch covers: everything, the interior ones (every node owned), or the two
+// groups that touch the ghost nodes (first and last in the engine's order, engine/order.hpp)
+enum { E1_ALL = 0, E1_INTERIOR = 1, E1_GHOST_SIDE = 2 };
+
 template <int MODE>
-void launch_e1(des_dev *h)
+void launch_e1(des_dev *h, int part = E1_ALL)
 {
+    int b0 = 0, c0 = h->ne, b1 = 0, c1 = 0;
+    if (part == E1_INTERIOR)   { b0 = h->e_int0; c0 = h->e_int1 - h->e_int0; }
+    if (part == E1_GHOST_SIDE) { b0 = 0; c0 = h->e_int0; b1 = h->e_int1; c1 = h->ne - h->e_int1; }
+    if (c0 + c1 == 0) return;
     Launch l(h, K_E1);
-    const int nb = nblk(h->ne);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(h->ne)), dim3(DES_BLOCK), 0, h->stream,
-                       h->d_p, h->d_clk, h->ne, nb, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(c0 + c1)), dim3(DES_BLOCK), 0, h->stream,
+                       h->d_p, h->d_clk, h->ne, nblk(c0 + c1), b0, c0, b1, c1, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
                        h->topflag, h->stress, h->strain, h->plstrain, h->volume, h->volume_old, h->strain_rate,
                        h->mrec, h->ttmp);
 }
@@ -82,16 +97,17 @@ k_average_fields(const des_params *__restrict__ p, DevClock *__restrict__ clk, i
 }
 
 // end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
-void launch_e1_end(des_dev *h, long long step_no, bool with_next)
+void launch_e1_end(des_dev *h, long long step_no, bool with_next, int part = E1_ALL)
 {
     const bool do_dt = (step_no % 10 == 0);
     const int sel = (with_next ? 1 : 0) | (do_dt ? 2 : 0);
     switch (sel) {
-    case 0: launch_e1<MODE_C>(h); break;
-    case 1: launch_e1<MODE_C | MODE_A>(h); break;
-    case 2: launch_e1<MODE_C | MODE_DT>(h); break;
-    case 3: launch_e1<MODE_C | MODE_A | MODE_DT>(h); break;
+    case 0: launch_e1<MODE_C>(h, part); break;
+    case 1: launch_e1<MODE_C | MODE_A>(h, part); break;
+    case 2: launch_e1<MODE_C | MODE_DT>(h, part); break;
+    case 3: launch_e1<MODE_C | MODE_A | MODE_DT>(h, part); break;
     }
+    if (part == E1_INTERIOR) return;               // the averaging pass follows the last part
     if (h->p.is_outputting_averaged_fields) {
         Launch l(h, K_MISC);
         hipLaunchKernelGGL(k_average_fields, dim3(nblk(h->ne)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ne,
@@ -141,6 +157,7 @@ void launch_mass_gather(des_dev *h)
 
 void launch_dt_finalize(des_dev *h, const double *red)
 {
+    if (exp_skip("dt")) return;
     Launch l(h, K_DTFIN);
     hipLaunchKernelGGL(k_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk, red);
 }
@@ -197,7 +214,7 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                            h->etmp2, h->defer_list, count);
     }
-    if (defer) {
+    if (defer && !exp_skip("e2r")) {
         Launch l(h, K_E2R);
         auto k = h->portable_libm ? E2_return_mapping<desk::MathPortable> : E2_return_mapping<desk::MathOcml>;
         hipLaunchKernelGGL(k, dim3(std::min(nblk(e_count), DES_E2R_GRID)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
@@ -246,7 +263,7 @@ void launch_n3(des_dev *h)
 void launch_s2(des_dev *h, long long step_no)
 {
     if (!(h->p.has_moving_mesh || h->iso)) return;          // surface_processes is part of update_mesh
-    if (h->ntop > 0) {
+    if (h->ntop > 0 && !exp_skip("s2")) {
         Launch l(h, K_S2);
         hipLaunchKernelGGL(k_s2, dim3(nblk(h->ntop)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop,
                            (int)(h->p.surface_process_option == 1), h->top_nodes, h->ssup_idx, h->ssup_nodes, h->conn_surf,
@@ -260,6 +277,7 @@ void launch_s2(des_dev *h, long long step_no)
 // commit of the new surface heights / edvacc_surf / end-of-step scalars (k_s3_finalize)
 void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
 {
+    if (exp_skip("s3")) return;
     Launch l(h, K_S3);
     const bool surf = (h->p.has_moving_mesh || h->iso) && h->ntop > 0;
     const int nsb = (edvacc && surface_diffusion_on(h)) ? nblk(h->etop) : 0;

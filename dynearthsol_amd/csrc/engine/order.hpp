@@ -19,6 +19,7 @@ struct PermMesh {
     std::vector<unsigned> bcflag;
     std::vector<int> bf_elem[DES_NBDRY], bnodes[DES_NBDRY];
     des_mesh view;
+    int e_int0, e_int1;        // [e_int0, e_int1): elements whose four nodes are all owned
 };
 
 inline unsigned long long morton3(unsigned x, unsigned y, unsigned z)
@@ -75,6 +76,12 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
             key[e] = std::make_pair(grp << 62 | code(c[0], c[1], c[2]) >> 2, e);      // group, then Morton
         }
         std::sort(key.begin(), key.end());
+        pm.e_int0 = 0; pm.e_int1 = ne;
+        for (int i = 0; i < ne; ++i) {
+            const unsigned long long grp = key[i].first >> 62;
+            if (grp == 0) pm.e_int0 = i + 1;
+            if (grp == 2) { pm.e_int1 = i; break; }
+        }
         pm.e_new2old.resize((size_t)ne); pm.e_old2new.resize((size_t)ne);
         for (int i = 0; i < ne; ++i) { pm.e_new2old[i] = key[i].second; pm.e_old2new[key[i].second] = i; }
     }

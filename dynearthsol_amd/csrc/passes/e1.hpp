@@ -11,15 +11,19 @@
 template <int MODE>
 __global__ void __launch_bounds__(DES_BLOCK, DES_E1_WAVES)
 E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ne, int nblocks,
-     const int4 *__restrict__ conn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
+     int b0, int c0, int b1, int c1, const int4 *__restrict__ conn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
      const MatData md,
      const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp)
 {
-    const int e = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
-    const bool active = e < ne;
+    // this launch covers the elements [b0, b0 + c0) and [b1, b1 + c1) (the whole mesh: 0, ne, 0, 0;
+    // the overlapped multi-GPU schedule runs the interior elements while the ghost region is
+    // still on its way, then the two groups that touch it); ne stays the SoA plane stride
+    const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
+    const bool active = el < c0 + c1;
+    const int e = el < c0 ? b0 + el : b1 + (el - c0);
 
     double r_minl = DBL_MAX, r_maxw = DBL_MAX, r_diff = DBL_MAX, r_gdt = DBL_MAX, r_vem = 0.0;
 

@@ -127,6 +127,47 @@ __global__ void k_elasto_plastic_eval(long long n, const double *__restrict__ pr
     mode[i] = fm + (past ? 1000 : 0);
 }
 
+// Streaming device copy, 16 bytes per lane with UNROLL loads in flight per lane before the stores,
+// grid-stride: the achievable-HBM yardstick SURVEY.md 8(d) asks for next to the 8 TB/s nominal
+// peak.  NT: non-temporal loads and stores (no reuse: keeps the copy out of L2 / MALL).
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(256) k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n; i += UNROLL * stride) {
+        double2 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (NT) { v[u].x = __builtin_nontemporal_load(&src[i + u * stride].x); v[u].y = __builtin_nontemporal_load(&src[i + u * stride].y); }
+            else v[u] = src[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (NT) { __builtin_nontemporal_store(v[u].x, &dst[i + u * stride].x); __builtin_nontemporal_store(v[u].y, &dst[i + u * stride].y); }
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// des_dev_access_bench: the engine's memory access shapes on a KNOWN byte count, to calibrate the
+// rocprofv3 FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md calibrates them for 16 B per lane
+// streaming only).  PATTERN 0: 16 B/lane stream copy; 1: 8 B/lane stream copy (one SoA plane);
+// 2: 32-B record gather through a permutation (every record once; the {x,y,z,T} node records),
+// 8 B/lane result stream; 3: 8-B gather through a permutation (one double per incidence), 8 B/lane result.
+template <int PATTERN>
+__global__ void __launch_bounds__(256) k_access(const double *__restrict__ src, double *__restrict__ dst,
+                                                const int *__restrict__ perm, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (PATTERN == 0)      ((double2 *)dst)[i] = ((const double2 *)src)[i];
+    else if (PATTERN == 1) dst[i] = src[i];
+    else if (PATTERN == 2) { const d4 r = ((const d4 *)src)[perm[i]]; dst[i] = (r.x + r.y) + (r.z + r.w); }
+    else                   dst[i] = src[perm[i]];
+}
+
 __global__ void k_count_nan(const double *a, long long n, unsigned long long *count)
 {
     long long i = (long long)blockIdx.x * DES_BLOCK + threadIdx.x;

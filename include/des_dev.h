@@ -117,6 +117,15 @@ int des_dev_eigen_eval(int device, int fn, int libm, long long n, const double *
 int des_dev_elasto_plastic_eval(int device, int libm, long long n, const double *props, const double *de,
                                 double *s, double *depls, int *mode);
 
+/* Measured ceiling for the roofline: a streaming device-to-device copy of `bytes`
+ * bytes (16 B per lane), `reps` launches timed with HIP events; *gbs = (read + written) / time. */
+int des_dev_copy_ceiling(int device, long long bytes, int reps, double *gbs);
+
+/* Calibration of the rocprofv3 HBM counters on the engine's own access shapes (tools/pmc_calibrate.py):
+ * `reps` launches over `items` lanes of pattern 0 (16 B/lane stream copy), 1 (8 B/lane stream copy),
+ * 2 (32-B record gather through a permutation + 8 B/lane store), 3 (8-B gather + 8 B/lane store). */
+int des_dev_access_bench(int device, int pattern, long long items, int reps, double *ms_per_launch);
+
 /* Timing helpers for bench.py: HIP-event bracket on the engine's own stream. */
 int des_dev_timer_start(des_dev *h);
 int des_dev_timer_stop(des_dev *h, float *ms);
@@ -144,6 +153,11 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global);
 /* rank 0 creates the 128-byte ncclUniqueId; the caller broadcasts it (e.g. torch.distributed) */
 int des_dev_comm_unique_id(unsigned char *id128);
 int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128);
+/* what is attached: nranks = ncclCommCount of the communicator (0: none), this rank in it, and
+ * whether des_dev_step runs the overlapped schedule (DES_OVERLAP=1 at create: the exchange on a
+ * side stream while the end-of-step pass of the interior elements runs; default: everything
+ * in order on the engine's stream) */
+int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped);
 /* the ghost-region exchange through the attached communicator, asynchronous on the engine's
  * stream: what des_dev_step issues between the two phases of a step */
 int des_dev_exchange(des_dev *h);

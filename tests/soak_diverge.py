@@ -81,8 +81,7 @@ def main():
         host = des.Host(cfg_text=bench.BENCH_CFG.format(res=repr(a.resolution), xlen="400e3"))
     A = ob.OracleEngine(host, omp=True)
     if on_device:
-        if a.perturb == "device-portable":
-            os.environ["DES_LIBM"] = "portable"
+        os.environ["DES_LIBM"] = "portable" if a.perturb == "device-portable" else "ocml"
         B = des.DeviceEngine(host)
     else:
         B = EngineB(host, libB)

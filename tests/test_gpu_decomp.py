@@ -142,26 +142,121 @@ def test_rccl_send_recv_path_moves_the_ghost_state():
         dist.destroy_process_group()
 
 
-def test_two_rank_bench_rehearsal():
+@pytest.mark.parametrize("mode", ["strong", "weak"])
+def test_two_rank_bench_rehearsal(mode):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank),
     rehearsed with both ranks on the one GPU of this box: RCCL refuses two ranks on one device, so
-    the ghost state is staged through the host over gloo (DES_BENCH_TRANSPORT=host); everything
-    else -- partition, engines, the collective step count on every rank, the JSON line -- is the
-    real thing.  (A profiling run taken by rank 0 alone used to hang here.)"""
+    the ghost state is staged through the host over gloo (DES_BENCH_TRANSPORT=host, which the line
+    must say); everything else -- partition, engines, the collective step count on every rank, the
+    JSON line -- is the real thing.  Default = strong scaling on the fixed mesh (BASELINE configs[3]),
+    --weak keeps the per-GPU size.  (A profiling run taken by rank 0 alone used to hang here.)"""
     import json
     import os
     import subprocess
     import sys
     env = dict(os.environ, DES_BENCH_BACKEND="gloo", DES_BENCH_TRANSPORT="host", DES_BENCH_DEVICE="0",
                DES_BENCH_VERBOSE="1", DES_BENCH_WATCHDOG="100")
-    port = 29400 + os.getpid() % 90
+    port = 29400 + os.getpid() % 90 + (7 if mode == "weak" else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(des.REPO_ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "12", "--warmup", "2", "--resolution", "2000", "--cpu-steps", "0"],
+                          "--gpus", "2", "--steps", "12", "--warmup", "2", "--resolution", "2000", "--cpu-steps", "0"]
+                         + (["--weak"] if mode == "weak" else []),
                          capture_output=True, text=True, timeout=170, env=env, cwd=des.REPO_ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["steps"] == 12 and r["config"]["nan_entries"] == 0 and r["config"]["status"] == 0
-    assert r["config"]["nelem"] == 100000 and r["value"] > 0 and "kernel_ms_per_call" in r["config"]
+    c = r["config"]
+    assert r["n_gpus"] == 2 and r["steps"] == 12 and c["nan_entries"] == 0 and c["status"] == 0
+    assert r["scaling"] == mode and c["nelem"] == (50000 if mode == "strong" else 100000) and r["value"] > 0
+    assert "kernel_ms_per_call" in c and ("cut 2 ways (strong scaling)" in c["workload"]) == (mode == "strong")
+    # this rehearsal must not be mistaken for an RCCL run
+    assert c["rccl_ranks"] == 0 and "rehearsal" in c["parallelism"] and c["exchange_us_per_rank"] == [-1.0, -1.0]
+    assert 0 < c["ghost_work_share"] < 0.5 and c["nelem_local_sum"] > c["nelem"]
+
+
+def test_bench_refuses_to_report_without_rccl():
+    """Two ranks on ONE device: RCCL declines, and bench.py must then fail (exit 3) instead of
+    quietly timing another transport."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DES_BENCH_BACKEND="gloo", DES_BENCH_DEVICE="0", DES_BENCH_VERBOSE="1", DES_BENCH_WATCHDOG="100")
+    env.pop("DES_BENCH_TRANSPORT", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29300 + os.getpid() % 90), os.path.join(des.REPO_ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "4", "--warmup", "1", "--resolution", "4000", "--cpu-steps", "0"],
+                         capture_output=True, text=True, timeout=170, env=env, cwd=des.REPO_ROOT)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], "a result line was printed without RCCL"
+    assert "did not come up" in out.stderr
+
+
+def test_overlapped_schedule_gives_the_same_bits():
+    """DES_OVERLAP=1 (transfer + unpack on a side stream while the end-of-step pass of the interior
+    elements runs, engine/exchange.hpp) against the in-order schedule, on the middle slab of a
+    three-way partition: real owned range, real ghost region, real element groups.  The 1-GPU box
+    cannot hold two RCCL ranks, so the slab is its own neighbour (lists cut to equal lengths per
+    neighbour) -- the physics of that is meaningless, the dependencies between the two streams are
+    the real ones: both schedules must produce the same bits, compute_dt steps included."""
+    import ctypes as C
+    import os
+    import types
+    import torch.distributed as dist
+    from dynearthsol_amd._structs import DesHalo
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 90))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    old = os.environ.get("DES_OVERLAP")
+    try:
+        host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, lx=90e3)))
+        part = Partition(host, 3, 1)
+        assert len(part.nbr_rank) == 2
+        pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        cut = lambda s, r: [(a[:min(len(a), len(b))], b[:min(len(a), len(b))]) for a, b in zip(s, r)]
+        nodes, elems = cut(part.send_idx, part.recv_idx), cut(part.esend_idx, part.erecv_idx)
+        ptr = np.cumsum([0] + [len(a) for a, _ in nodes]).astype(np.int32)
+        eptr = np.cumsum([0] + [len(a) for a, _ in elems]).astype(np.int32)
+        send, recv = [np.ascontiguousarray(np.concatenate([p[i] for p in nodes]), dtype=np.int32) for i in (0, 1)]
+        esend, erecv = [np.ascontiguousarray(np.concatenate([p[i] for p in elems]), dtype=np.int32) for i in (0, 1)]
+        assert ptr[-1] > 100 and eptr[-1] > 100
+        nbr = np.zeros(2, np.int32)
+        halo = DesHalo(part.owned[0], part.owned[1], 4, 2, pi(nbr), pi(ptr), pi(send), pi(ptr), pi(recv),
+                       pi(eptr), pi(esend), pi(eptr), pi(erecv))
+        results = []
+        for mode in ("0", "1"):
+            os.environ["DES_OVERLAP"] = mode
+            eng = des.DeviceEngine(part)
+            eng.set_halo(types.SimpleNamespace(halo=halo, owned=part.owned, host=host))
+            eng.comm_init(dist, 0, 1)
+            info = eng.comm_info()
+            assert info["rccl_ranks"] == 1 and info["overlapped"] == (mode == "1")
+            for f, name in (("COORD", "coord"), ("COORD0", "coord"), ("ELEMMARKERS", "elemmarkers"), ("VEL", "vel")):
+                eng.upload(f, part.local(name))
+            eng.init_geometry()
+            for f, name in (("TEMPERATURE", "temperature"), ("RADIOGENIC", "radiogenic"), ("STRESS", "stress"), ("STRAIN", "strain"),
+                            ("PLSTRAIN", "plstrain"), ("VISCOSITY", "viscosity")):
+                eng.upload(f, part.local(name))
+            eng.compute_dt()
+            # Being its own neighbour scrambles the ghost region (the received coordinates belong elsewhere), so
+            # NaNs creep inwards one element layer per step: compare early (mostly finite) and across a
+            # compute_dt step, NaN == NaN -- what matters is that both schedules do the same thing to every entry.
+            fields = ("COORD", "VEL", "STRESS", "STRAIN", "TEMPERATURE", "PLSTRAIN", "VOLUME", "MASS", "STRAIN_RATE")
+            eng.step(2)
+            early = {f: eng.download(f) for f in fields}
+            eng.step(7)
+            sc = eng.step(4)                               # crosses step 10: compute_dt inside the call
+            results.append((sc.dt, early, {f: eng.download(f) for f in fields}))
+            del eng
+        o0, o1 = part.owned
+        assert np.isfinite(results[0][1]["VEL"].reshape(3, -1)[:, o0:o1]).mean() > 0.5, "nothing left to compare"
+        assert results[0][0] == results[1][0] or (np.isnan(results[0][0]) and np.isnan(results[1][0]))
+        for k in (1, 2):
+            for f in fields:
+                assert np.array_equal(results[0][k][f], results[1][k][f], equal_nan=True), (k, f)
+    finally:
+        if old is None:
+            os.environ.pop("DES_OVERLAP", None)
+        else:
+            os.environ["DES_OVERLAP"] = old
+        dist.destroy_process_group()
