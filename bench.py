@@ -104,6 +104,10 @@ KERNEL_BYTES = {
     "N2_nmd_gather":              (48, 20),
     "E3_nmd_force":               (260, 40),
     "N3_force_velocity_coord":    (160, 160),
+    # E3 + N3 as one pass over node-block patches (csrc/passes/en3.hpp): credited with the
+    # algorithmic bytes of the two rows it replaces, although it no longer moves the 96 + 96 B
+    # per element of force temporaries that figure contains
+    "EN3_force_nodes":            (260 + 160, 40 + 160),
 }
 
 

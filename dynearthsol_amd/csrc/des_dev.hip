@@ -90,11 +90,11 @@ struct DevClock {
 enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };
 
 enum KernelId { K_E1, K_N1, K_E2, K_E2R, K_N2, K_E3, K_N3, K_S2, K_S3,
-                K_DTFIN, K_MISC, K_EXCH, K_COUNT };
+                K_DTFIN, K_MISC, K_EXCH, K_EN3, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "E2_return_mapping", "N2_nmd_gather",
     "E3_nmd_force", "N3_force_velocity_coord", "S2_surface_diffusion",
-    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange" };
+    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange", "EN3_force_nodes" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
 
@@ -163,7 +163,16 @@ struct des_dev {
     double *etmp2, *ftmp;                 // dp*vol ; force tr [ne][4][3]
     double *res_part;                     // per-block partial sums of the residual
     int n3_blocks;
+    int res_nb;                           // residual partials the last N3 / EN3 launch wrote
     int npb;                              // nodes per node-kernel workgroup (choose_npb)
+    // node-block patches: EN3 replaces E3 + N3 (passes/en3.hpp, engine/patch.hpp)
+    bool patch;
+    int patch_npb, patch_nb, patch_max_inc, patch_max_pn, patch_threads;
+    int *pe_ptr, *pe_elem, *pn_ptr, *pn_id;
+    ushort4 *pe_ln;
+    short4 *pe_slot;
+    double *ddp;                          // [ne] NMD increment of the stress diagonal, applied by the next E1
+    d4 *xt_alt;                           // the other buffer of the {x,y,z,T} pair (EN3 writes it, then they swap)
     // stress-bc lists
     int nbcf;                             // facets with a stress bc (incl. neumann)
     int *bcf_elem, *bcf_facet, *bcf_kind; // kind: 0 winkler, 1 water, 2 side wall, 3+d neumann dir d
@@ -222,8 +231,10 @@ namespace des_hip {
 #include "passes/n2.hpp"
 #include "passes/e3.hpp"
 #include "passes/n3.hpp"
+#include "passes/en3.hpp"
 #include "passes/surface.hpp"
 #include "passes/small_kernels.hpp"
+#include "engine/patch.hpp"
 #include "engine/launch.hpp"
 #include "engine/exchange.hpp"
 #include "engine/order.hpp"
@@ -257,7 +268,8 @@ void des_dev_destroy(des_dev *h)
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
-    void *ptrs[] = { h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
+    void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_ln, h->pe_slot, h->ddp, h->xt_alt,
+        h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->d_esend_idx, h->d_erecv_idx, h->d_send_noff,
         h->d_send_eoff, h->d_recv_noff, h->d_recv_eoff, h->stress, h->strain,
@@ -384,6 +396,33 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             CK(dev_alloc(h->d_e_new2old, (size_t)ne)); CK(dev_upload(h->d_e_new2old, h->e_new2old.data(), (size_t)ne, h->stream));
         }
     }
+    // node-block patches for EN3 (DES_PATCH=0: the classic pair E3 + N3); blocks of 64 nodes, or 32
+    // where a block of 64 would not fit the kernel's LDS slots
+    {
+        const char *env = std::getenv("DES_PATCH");
+        h->patch = false;
+        if (!(env && env[0] == '0')) {
+            PatchLists P;
+            int want = env ? std::atoi(env) : 0;
+            const int tries[3] = {(want >= 16 && want <= 128 && want % 16 == 0) ? want : 64, 32, 16};
+            for (int t = 0; t < 3 && !h->patch; ++t)
+                h->patch = build_patches(mesh, tries[t], DES_PATCH_INC, DES_PATCH_PN, P);
+            if (h->patch) {
+                h->patch_npb = P.npb; h->patch_nb = P.nb; h->patch_max_inc = P.max_inc; h->patch_max_pn = P.max_pn;
+                const char *pt = std::getenv("DES_PATCH_THREADS");
+                h->patch_threads = (pt && std::atoi(pt) == 256) ? 256 : 512;
+                CK(dev_alloc(h->pe_ptr, P.pe_ptr.size())); CK(dev_upload(h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size(), h->stream));
+                CK(dev_alloc(h->pe_elem, P.pe_elem.size())); CK(dev_upload(h->pe_elem, P.pe_elem.data(), P.pe_elem.size(), h->stream));
+                CK(dev_alloc(h->pe_ln, P.pe_ln.size())); CK(dev_upload(h->pe_ln, P.pe_ln.data(), P.pe_ln.size(), h->stream));
+                CK(dev_alloc(h->pe_slot, P.pe_slot.size())); CK(dev_upload(h->pe_slot, P.pe_slot.data(), P.pe_slot.size(), h->stream));
+                CK(dev_alloc(h->pn_ptr, P.pn_ptr.size())); CK(dev_upload(h->pn_ptr, P.pn_ptr.data(), P.pn_ptr.size(), h->stream));
+                CK(dev_alloc(h->pn_id, P.pn_id.size())); CK(dev_upload(h->pn_id, P.pn_id.data(), P.pn_id.size(), h->stream));
+                CK(dev_alloc(h->ddp, (size_t)ne)); CK(dev_alloc(h->xt_alt, (size_t)nn));
+                HK(hipMemsetAsync(h->ddp, 0, 8*(size_t)ne, h->stream));
+                HK(hipMemsetAsync(h->xt_alt, 0, sizeof(d4)*(size_t)nn, h->stream));
+            }
+        }
+    }
     // fields
     CK(dev_alloc(h->xt, (size_t)nn)); CK(dev_alloc(h->vm, (size_t)nn));
     CK(dev_alloc(h->ntmp, (size_t)nn)); CK(dev_alloc(h->volume_n, (size_t)nn)); CK(dev_alloc(h->tmass, (size_t)nn));
@@ -410,7 +449,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         HK(hipMemsetAsync(h->dplstrain_avg, 0, 8*(size_t)ne, h->stream)); HK(hipMemsetAsync(h->coord_avg0, 0, 24*(size_t)nn, h->stream));
     }
     choose_npb(h);
-    h->n3_blocks = node_grid(h);
+    h->n3_blocks = res_part_size(h);
+    h->res_nb = 0;
     CK(dev_alloc(h->res_part, (size_t)h->n3_blocks));
     {
         struct { void *p; size_t bytes; } zero[] = {
@@ -757,7 +797,8 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     const bool nmd = h->p.is_using_mixed_stress && !iso;
     // DES_GRAPH=1: the launches of an interior step of a single-GPU call are replayed from a
     // hipGraph captured once (two graphs: with and without the compute_dt variant of E1)
-    const bool graphs = h->use_graph && !multi && !iso && !h->prof && !h->p.is_outputting_averaged_fields;
+    const bool graphs = h->use_graph && !multi && !iso && !h->prof && !h->p.is_outputting_averaged_fields
+                        && !h->patch;          // EN3 swaps the two coordinate buffers every step: nothing to replay
     const long long qcsi = h->p.quality_check_step_interval;
     int rc;
     for (int i = 0; i < nsteps; ++i) {
@@ -769,7 +810,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
                 if (h->graph_exec[which]) { hipGraphExecDestroy(h->graph_exec[which]); h->graph_exec[which] = nullptr; }
                 hipGraph_t g = nullptr;
                 HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                launch_n1(h); launch_e2(h); if (nmd) launch_n2(h); launch_e3(h); launch_n3(h);
+                launch_n1(h); launch_e2(h); if (nmd) launch_n2(h); launch_force_pass(h);
                 launch_s2(h, 1);                                   // (no dhacc reset: those steps are not replayed)
                 launch_s3(h, true, true, true);
                 launch_e1_end(h, which ? 10 : 1, true);
@@ -785,8 +826,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         launch_n1(h);
         launch_e2(h);
         if (nmd) launch_n2(h);
-        launch_e3(h);
-        launch_n3(h);
+        launch_force_pass(h);
         launch_s2(h, step_no);
         const bool last = (i == nsteps - 1);
         const bool overlapped = multi && h->overlap && !iso && h->e_int1 > h->e_int0;
@@ -910,7 +950,7 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     // the residual partials are indexed by owned-node block
     if (h->res_part) hipFree(h->res_part);
     choose_npb(h);
-    h->n3_blocks = node_grid(h);
+    h->n3_blocks = res_part_size(h);
     return dev_alloc(h->res_part, (size_t)h->n3_blocks);
 }
 
@@ -974,8 +1014,7 @@ int des_dev_phase(des_dev *h, int phase)
         launch_n1(h);
         launch_e2(h);
         if (h->p.is_using_mixed_stress && !h->iso) launch_n2(h);
-        launch_e3(h);
-        launch_n3(h);
+        launch_force_pass(h);
         launch_s2(h, h->steps_host);
         launch_s3(h, true, false, false);
         return 0;
@@ -1014,12 +1053,12 @@ static int state_io(des_dev *h, int what, const int *idx, int n, double *buf, bo
     const int nn_items = what == 0 ? n : 0, ne_items = what == 0 ? 0 : n;
     if (pack) {
         hipLaunchKernelGGL(k_state_pack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, nn_items, d_idx, d_off, ne_items, d_idx, d_off,
-                           h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain, h->ne, d_buf);
+                           h->xt, h->vm, h->dh_n, h->stress, pending_ddp(h), h->strain, h->plstrain, h->ne, d_buf);
         HIP_OK(hipMemcpyAsync(buf, d_buf, (size_t)n * w * 8, hipMemcpyDeviceToHost, h->stream));
     } else {
         if ((rc = dev_upload(d_buf, buf, (size_t)n * w, h->stream))) return rc;
         hipLaunchKernelGGL(k_state_unpack, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, nn_items, d_idx, d_off, ne_items, d_idx, d_off,
-                           h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain, h->ne, d_buf);
+                           h->xt, h->vm, h->dh_n, h->stress, pending_ddp(h), h->strain, h->plstrain, h->ne, d_buf);
     }
     HIP_OK(hipStreamSynchronize(h->stream));
     hipFree(d_idx); hipFree(d_off); hipFree(d_buf);

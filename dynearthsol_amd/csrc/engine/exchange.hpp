@@ -18,7 +18,7 @@ int exchange(des_dev *h, hipStream_t xs)
     {
         Launch l(h, K_EXCH);
         hipLaunchKernelGGL(k_state_pack, dim3(nblk(ns + nes)), dim3(DES_BLOCK), 0, h->stream, ns, h->d_send_idx, h->d_send_noff,
-                           nes, h->d_esend_idx, h->d_send_eoff, h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain,
+                           nes, h->d_esend_idx, h->d_send_eoff, h->xt, h->vm, h->dh_n, h->stress, pending_ddp(h), h->strain, h->plstrain,
                            h->ne, h->d_sendbuf);
         if (side) {
             // fork: everything up to and including the pack precedes the transfer.  (The pack stays on
@@ -38,7 +38,7 @@ int exchange(des_dev *h, hipStream_t xs)
     ncclResult_t r = ncclGroupEnd();
     if (r != ncclSuccess) { g_last_error = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
     hipLaunchKernelGGL(k_state_unpack, dim3(nblk(nr + ner)), dim3(DES_BLOCK), 0, xs, nr, h->d_recv_idx, h->d_recv_noff,
-                       ner, h->d_erecv_idx, h->d_recv_eoff, h->xt, h->vm, h->dh_n, h->stress, h->strain, h->plstrain,
+                       ner, h->d_erecv_idx, h->d_recv_eoff, h->xt, h->vm, h->dh_n, h->stress, pending_ddp(h), h->strain, h->plstrain,
                        h->ne, h->d_recvbuf);
     if (side) HIP_OK(hipEventRecord(h->ev_join, xs));
     return DES_OK;

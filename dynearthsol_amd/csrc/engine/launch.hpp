@@ -68,8 +68,8 @@ void launch_e1(des_dev *h, int part = E1_ALL)
     Launch l(h, K_E1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(c0 + c1)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, h->ne, nblk(c0 + c1), b0, c0, b1, c1, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
-                       h->topflag, h->stress, h->strain, h->plstrain, h->volume, h->volume_old, h->strain_rate,
-                       h->mrec, h->ttmp);
+                       h->topflag, h->stress, h->patch ? h->ddp : nullptr, h->strain, h->plstrain, h->volume, h->volume_old,
+                       h->strain_rate, h->mrec, h->ttmp);
 }
 
 // Output::average_fields (output.cxx:327-370) on the end-of-step fields, i.e. after the C part
@@ -135,6 +135,11 @@ void launch_avg_coord0(des_dev *h, long long step_no)
 // redundantly (des_halo); only the reductions are restricted to the owned range [o0, o1).
 inline int node_blocks(const des_dev *h) { return (h->nn + h->npb - 1) / h->npb; }
 inline int node_grid(const des_dev *h) { return (node_blocks(h) + 7) / 8 * 8; }
+// residual partials: one per N3 workgroup or one per EN3 patch block, whichever pass runs
+inline int res_part_size(const des_dev *h) { return std::max(node_grid(h), h->patch ? (h->patch_nb + 7) / 8 * 8 : 0); }
+// EN3's NMD increments that E1 has not folded into the stress yet (between the force pass and the
+// end-of-step pass of a step outside the isostasy loop): what the ghost-region pack must add
+inline double *pending_ddp(const des_dev *h) { return (h->patch && h->p.is_using_mixed_stress && !h->iso) ? h->ddp : nullptr; }
 
 // nodes per node-kernel workgroup: 256, or 64 while that leaves fewer than two workgroups per CU
 // (a 137k-tet mesh has 31k nodes = 120 workgroups of 256 on 256 CUs, each walking 4-5 incidence
@@ -209,10 +214,13 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
         Launch l(h, K_E2);
         auto k = h->portable_libm ? (defer ? E2_update_stress<desk::MathPortable, 1> : E2_update_stress<desk::MathPortable, 0>)
                                   : (defer ? E2_update_stress<desk::MathOcml, 1> : E2_update_stress<desk::MathOcml, 0>);
-        hipLaunchKernelGGL(k, dim3(nblk8(e_count)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+        // with EN3 the stress-bc facet workgroups ride here (with the classic pair: in E3's launch)
+        const int nbf = (h->patch && e_begin == 0 && e_count == h->ne) ? nblk(h->nbcf) : 0;
+        hipLaunchKernelGGL(k, dim3(nblk8(e_count) + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                            e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
-                           h->etmp2, h->defer_list, count);
+                           h->etmp2, h->defer_list, count,
+                           nblk8(e_count), nbf ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);
     }
     if (defer && !exp_skip("e2r")) {
         Launch l(h, K_E2R);
@@ -250,12 +258,45 @@ void launch_e3(des_dev *h, int e_begin = 0, int e_count = -1, bool facets = true
 
 void launch_n3(des_dev *h)
 {
+    h->res_nb = node_blocks(h);
     Launch l(h, K_N3);
     const int nown = h->o1 - h->o0;
     hipLaunchKernelGGL(N3_force_velocity_coord, dim3(node_grid(h)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->o0, h->o1,
                        h->nn, h->nn_global, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx,
                        h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
                        h->force, h->fres, h->res_part);
+}
+
+// E3 + N3 as one pass over node-block patches (passes/en3.hpp); the stress-bc facet terms, which
+// rode in E3's launch, ride in E2's instead (launch_e2)
+void launch_en3(des_dev *h)
+{
+    h->res_nb = h->patch_nb;
+    {
+        Launch l(h, K_EN3);
+        // the smallest LDS shape that holds this mesh's largest block -> most workgroups per CU
+        void (*k)(const des_params *, const DevClock *, int, int, int, int, int, int, int, int, const int *, const int *, const ushort4 *,
+                  const short4 *, const int *, const int *, const int *, const unsigned *, const double *, const MatData, const double *,
+                  const double *, const double *, double *, unsigned, const int *, const int *, const double *, const double *, const double *,
+                  const double *, const double *, const int *, const d4 *, d4 *, d4 *, double *, double *, double *);
+        const int T = h->patch_threads;
+        if (h->patch_max_inc <= 1024 && h->patch_max_pn <= 256) k = T == 512 ? EN3_force_nodes<512, 1024, 256> : EN3_force_nodes<256, 1024, 256>;
+        else if (h->patch_max_inc <= 1664 && h->patch_max_pn <= 320) k = T == 512 ? EN3_force_nodes<512, 1664, 320> : EN3_force_nodes<256, 1664, 320>;
+        else k = T == 512 ? EN3_force_nodes<512, DES_PATCH_INC, DES_PATCH_PN> : EN3_force_nodes<256, DES_PATCH_INC, DES_PATCH_PN>;
+        hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk,
+                           (int)(h->p.is_using_mixed_stress && !h->iso), h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb,
+                           h->pe_ptr, h->pe_elem, h->pe_ln, h->pe_slot, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag, h->ntmp, mat_data(h),
+                           h->volume, h->dpressure, h->stress, h->ddp, h->bc_mask, h->bcn_idx, h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass,
+                           h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part);
+    }
+    std::swap(h->xt, h->xt_alt);               // the records EN3 wrote are the current ones from here on
+}
+
+// update_force + everything nodal that follows it in a step
+void launch_force_pass(des_dev *h)
+{
+    if (h->patch) launch_en3(h);
+    else { launch_e3(h); launch_n3(h); }
 }
 
 // surface_processes (bc.cxx:1709-1872) as far as the device state is concerned, first part:
@@ -284,6 +325,6 @@ void launch_s3(des_dev *h, bool commit, bool edvacc, bool finalize)
     const int nzb = (commit && surf) ? nblk(h->ntop) : 0;
     const int nown = h->o1 - h->o0;
     hipLaunchKernelGGL(k_s3_finalize, dim3(nsb + nzb + 1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->etop, nsb,
-                       h->conn_surf, h->xt, h->dh_n, h->edvacc, h->res_part, node_blocks(h), h->ntop, nzb, h->top_nodes,
+                       h->conn_surf, h->xt, h->dh_n, h->edvacc, h->res_part, h->res_nb, h->ntop, nzb, h->top_nodes,
                        h->znew, h->o0, h->o1, finalize ? ((h->p.has_moving_mesh || h->iso) ? 1 : 2) : 0);
 }

@@ -14,7 +14,7 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
      int b0, int c0, int b1, int c1, const int4 *__restrict__ conn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
      const MatData md,
      const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
-     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
+     double *__restrict__ stress, const double *__restrict__ ddp, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp)
 {
@@ -83,9 +83,16 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
             const bool rescale = rdv >= 1.0;                         // bc.cxx:1677
             const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0 && !clk->iso;   // not in the isostasy loop
+            // NMD_stress' increment of the diagonal (geometry.cxx:316-331), left here by EN3 -- the
+            // operation E3 would have done in place, before anything else touches the stress
+            double dd = 0.0;
+            if (ddp && p->is_using_mixed_stress && !clk->iso) dd = ddp[e];
+            if (dd != 0.0 && !(rescale || rotate))
+                for (int i = 0; i < 3; ++i) stress[(size_t)i*ne + e] += dd;
             if (rescale || rotate) {
                 double s[6], es[6];
                 for (int i = 0; i < 6; ++i) { s[i] = stress[(size_t)i*ne + e]; es[i] = strain[(size_t)i*ne + e]; }
+                if (dd != 0.0) for (int i = 0; i < 3; ++i) s[i] += dd;
                 if (rescale) {
                     plstrain[e] /= rdv;
                     for (int i = 0; i < 6; ++i) { s[i] /= rdv; es[i] /= rdv; }

@@ -2,6 +2,12 @@
 // Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
 // DevClock / struct des_dev); not a stand-alone header.
 
+__device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int4 *__restrict__ conn,
+                              const d4 *__restrict__ xt, const MatData &md,
+                              const int *__restrict__ f_elem, const int *__restrict__ f_facet,
+                              const int *__restrict__ f_kind, const double *__restrict__ f_val,
+                              double *__restrict__ f_tmp);
+
 // ---- E2 --------------------------------------------------------------------------
 // compute_edvoldt (geometry.cxx:264-272), update_stress (rheology.cxx:728-1026),
 // NMD_stress element part (geometry.cxx:294-296)
@@ -127,8 +133,18 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
      const double *__restrict__ volume, const double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
-     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ list, int *__restrict__ count)
+     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ list, int *__restrict__ count,
+     int nblocks8, int nbcf, const int *__restrict__ f_elem, const int *__restrict__ f_facet,
+     const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp)
 {
+    if ((int)blockIdx.x >= nblocks8) {
+        // workgroups past the element range: the stress-bc facet terms (passes/e3.hpp, bc_facet_work).
+        // They need the temperature N1 has just updated and the coordinates of this step, and the
+        // force pass consumes them; with EN3 there is no E3 launch for them to ride in.
+        const int g = ((int)blockIdx.x - nblocks8) * DES_BLOCK + threadIdx.x;
+        if (g < nbcf) bc_facet_work(p, g, conn, xt, md, f_elem, f_facet, f_kind, f_val, f_tmp);
+        return;
+    }
     M::stage_begin();
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     if (el >= e_count) return;

@@ -1,0 +1,136 @@
+// passes/en3.hpp -- Pass EN3 (node patches): E3 + N3 in one launch, without the force temporaries.
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// ---- EN3 -------------------------------------------------------------------------
+// NMD_stress apply (geometry.cxx:316-331), update_force (fields.cxx:609-698) and everything N3
+// does after the force sums, for one block of `npb` consecutive nodes per workgroup.
+//
+// The classic pair E3 -> N3 writes the 12 force terms of every element to HBM (96 B) and gathers
+// them back per incidence (4.4M scattered 24-byte reads at 1M tets: N3 is bound by the rate of
+// those gathers, not by bandwidth).  Here a workgroup RECOMPUTES the force terms of its node
+// block's PATCH -- every element that touches one of its nodes, listed once per mesh by
+// build_patches() -- straight into LDS: the nodal records {x,y,z,T} and the NMD nodal pressure of
+// the patch's nodes are staged in LDS first (one gather per node instead of one per incidence),
+// each lane then takes patch elements (stress, volume, dpressure: the only per-element global
+// reads), and stores the terms of the element's nodes that belong to this block into the LDS
+// slot of that incidence = its position in the block's slice of the CSR support list.  After a
+// barrier each node's lane sums its slots in CSR order, i.e. in the reference's ascending element
+// order (fields.cxx:667-675): same association, same bits as the gather.  An element is
+// recomputed by every block it touches (1.96 blocks on average at 64 nodes per block on the 1M-tet
+// TetGen mesh): ~150 flops each, against 192 B of HBM traffic saved per element.
+//
+// The NMD correction of the stress diagonal is not stored into `stress` here (another block may
+// still be reading that element's old stress): the block that OWNS the element (the one holding its
+// lowest node) stores the increment ddp[e]; the end-of-step pass E1 -- the next reader of the
+// stress -- adds it with the same operation E3 would have used (and the ghost-exchange pack does
+// the same for what it sends).
+// Launch shapes: THREADS lanes per workgroup, LDS for INC incidences and PN patch nodes; the host
+// picks the smallest that holds the mesh's largest block (engine/launch.hpp, launch_en3).
+#define DES_PATCH_INC 2048        // caps of the largest shape = what build_patches() accepts
+#define DES_PATCH_PN 512
+
+template <int THREADS, int INC, int PN>
+__global__ void __launch_bounds__(THREADS)
+EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nmd, int o0, int nn_own_end,
+     int nn, int nn_global, int ne, int nblocks, int npb,
+     const int *__restrict__ pe_ptr, const int *__restrict__ pe_elem, const ushort4 *__restrict__ pe_ln,
+     const short4 *__restrict__ pe_slot, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
+     const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag,
+     const double *__restrict__ ntmp, const MatData md, const double *__restrict__ volume,
+     const double *__restrict__ dpressure, const double *__restrict__ stress, double *__restrict__ ddp_out,
+     unsigned bc_mask, const int *__restrict__ bcn_idx, const int *__restrict__ bcn_ent, const double *__restrict__ bcf_tmp,
+     const double *__restrict__ coord0, const double *__restrict__ ymass,
+     const double *__restrict__ bnormals, const double *__restrict__ edge_vec, const int *__restrict__ edge_slot,
+     const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm, double *__restrict__ force,
+     double *__restrict__ fres, double *__restrict__ res_part)
+{
+    // xt: the nodal records as the last pass left them (read for the whole patch); xt_out: the other
+    // buffer of the pair, where this block stores the records of its own nodes (the host swaps the
+    // two after the launch) -- a block must not move a node another block may still be reading
+    __shared__ d4 lxt[PN];
+    __shared__ double lnt[PN];
+    __shared__ double lf[3][INC];
+    __shared__ double red[THREADS / 64];
+    const int lb = desk::logical_block(nblocks);
+    const int n0 = lb * npb;
+    if (n0 >= nn) return;                                 // grid padding
+    const int nown = min(npb, nn - n0);
+    // 1. the patch's nodes: own range first (local id = n - n0), then the listed others
+    {
+        const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
+        for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
+            const int id = j < nown ? n0 + j : pn_id[h0 + j - nown];
+            lxt[j] = xt[id];
+            if (nmd) lnt[j] = ntmp[id];
+        }
+    }
+    __syncthreads();
+    // 2. the patch's elements
+    const double gravity = p->gravity;
+    for (int i = pe_ptr[lb] + threadIdx.x; i < pe_ptr[lb + 1]; i += THREADS) {
+        const int ew = pe_elem[i];
+        const int e = ew & 0x3fffffff;
+        const ushort4 ln = pe_ln[i];
+        const short4 sl = pe_slot[i];
+        d4 c[4];
+        c[0] = lxt[ln.x]; c[1] = lxt[ln.y]; c[2] = lxt[ln.z]; c[3] = lxt[ln.w];
+        double s[6];
+        for (int k = 0; k < 6; ++k) s[k] = stress[(size_t)k*ne + e];
+        if (nmd) {                                          // is_using_mixed_stress, outside the isostasy loop
+            double dp = 0;
+            dp += lnt[ln.x]; dp += lnt[ln.y]; dp += lnt[ln.z]; dp += lnt[ln.w];
+            double dp_el = dp / 4;
+            double dp_orig = dpressure[e];
+            double ddp = (-dp_orig + dp_el) / 3;
+            for (int k = 0; k < 3; ++k) s[k] += ddp;
+            if (ew & 0x40000000) ddp_out[e] = ddp;          // this block owns the element
+        }
+        const double vol = volume[e];
+        double sx[4], sy[4], sz[4];
+        desk::shape_fn(c, vol, sx, sy, sz);
+        double buoy = 0;
+        if (gravity != 0) {
+            double T = 0;
+            T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
+            T /= 4;
+            const desk::Mix mx = mix_of(md, p->nmat, e);
+            const double rho = desk::mat_rho(p, mx, T);
+            const double phi = load_props(p, md, mx, ne, e).phi;
+            buoy = (rho * (1 - phi) + 1000.0 * phi) * gravity / 4;
+        }
+        const int slot[4] = {sl.x, sl.y, sl.z, sl.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (slot[k] < 0) continue;
+            lf[0][slot[k]] = (s[0]*sx[k] + s[3]*sy[k] + s[4]*sz[k]) * vol;
+            lf[1][slot[k]] = (s[3]*sx[k] + s[1]*sy[k] + s[5]*sz[k]) * vol;
+            lf[2][slot[k]] = (s[4]*sx[k] + s[5]*sy[k] + s[2]*sz[k] + buoy) * vol;
+        }
+    }
+    __syncthreads();
+    // 3. the block's nodes: force sums in CSR order, then the rest of the nodal update
+    double l2 = 0.0;
+    if ((int)threadIdx.x < nown) {
+        const int n = n0 + threadIdx.x;
+        const int kb = sup_idx[n0];
+        const int r0 = sup_idx[n] - kb, r1 = sup_idx[n + 1] - kb;
+        double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
+        for (int k = r0; k < r1; ++k) {
+            const double t0v = lf[0][k], t1v = lf[1][k], t2v = lf[2][k];
+            f[0] -= t0v; f[1] -= t1v; f[2] -= t2v;
+            fr[0] = t0v; fr[1] = t1v; fr[2] = t2v;          // assignment: fields.cxx:673
+        }
+        l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
+                            coord0, ymass, bnormals, edge_vec, edge_slot, xt, xt_out, true, vm, force, fres);
+    }
+    // per-block partial of the residual; the partials are added in block order afterwards
+    l2 = desk::wave_sum(l2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = red[0];
+        for (int i = 1; i < THREADS / 64; ++i) t += red[i];
+        res_part[lb] = t;
+    }
+}

@@ -103,6 +103,100 @@ k_apply_vbcs(const des_params *__restrict__ p, const DevClock *__restrict__ clk,
     vm[n] = m4;
 }
 
+// What follows the force sums of a node, shared by N3 and EN3: apply_stress_bcs node loop
+// (bc.cxx:783-802, 817-823), apply_stress_bcs_neumann, apply_damping (fields.cxx:483-579),
+// update_velocity (fields.cxx:725-742), the node's share of the residual (fields.cxx:700-722),
+// apply_vbcs, update_coordinate (fields.cxx:761-784).  Returns that share.
+__device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ p, const DevClock *__restrict__ clk,
+     int n, int nn, int o0, int nn_own_end, int nn_global, double f[3], const double fr[3],
+     const unsigned *__restrict__ bcflag, unsigned bc_mask, const int *__restrict__ bcn_idx,
+     const int *__restrict__ bcn_ent, const double *__restrict__ bcf_tmp,
+     const double *__restrict__ coord0, const double *__restrict__ ymass,
+     const double *__restrict__ bnormals, const double *__restrict__ edge_vec, const int *__restrict__ edge_slot,
+     const d4 *xt_in, d4 *xt_out, bool always_store_xt, d4 *__restrict__ vm, double *__restrict__ force, double *__restrict__ fres)
+{
+    // xt_in / xt_out: the same array for N3; EN3 reads the coordinates of other blocks' nodes in the
+    // same launch, so it writes the records of its own nodes to the other buffer of a pair (and then
+    // always, moving mesh or not)
+    double l2 = 0.0;
+    const double dt = clk->dt;
+    const unsigned flag = bcflag[n];
+    d4 x4 = xt_in[n];
+    if (flag & bc_mask) {
+        const int b0 = bcn_idx[n], b1 = bcn_idx[n+1];
+        int b = b0;
+        for (; b < b1; ++b) {
+            const int ent = bcn_ent[b];
+            if (ent & 1) break;
+            const double *t = bcf_tmp + (size_t)(ent >> 1) * 3;
+            f[0] -= t[0]; f[1] -= t[1]; f[2] -= t[2];
+        }
+        if (p->has_elastic_foundation && (flag & (1u << 4)))
+            f[2] -= p->elastic_foundation_constant * (x4.z - coord0[(size_t)2*nn + n]);
+        for (; b < b1; ++b) {
+            const double *t = bcf_tmp + (size_t)(bcn_ent[b] >> 1) * 3;
+            f[0] += t[0]; f[1] += t[1]; f[2] += t[2];
+        }
+    }
+    d4 m4 = vm[n];
+    double v[3] = {m4.x, m4.y, m4.z};
+    const double small_vel = 1e-13;
+    const double dfac = p->damping_factor;
+    switch (p->damping_option) {
+    case 1:
+        for (int j = 0; j < 3; j++)
+            if (fabs(v[j]) > small_vel) f[j] -= dfac * copysign(f[j], v[j]);
+        break;
+    case 2:
+        for (int j = 0; j < 3; j++) f[j] -= dfac * f[j];
+        break;
+    case 3:
+        for (int j = 0; j < 3; j++) {
+            if ((f[j] < 0) == (v[j] < 0)) f[j] -= dfac * f[j];   // fields.cxx:538 (comma operator)
+            else                          f[j] += (1 - dfac) * f[j];
+        }
+        break;
+    case 4: {
+        double critical_coeff = 2.0 * sqrt(m4.w * ymass[n]);
+        for (int j = 0; j < 3; j++)
+            if (fabs(v[j]) > small_vel) {
+                double f_C = dfac * copysign(f[j], v[j]);
+                double f_V = critical_coeff * v[j];
+                double f_damping = (fabs(f_C) < fabs(f_V)) ? f_V : f_C;
+                f[j] -= f_damping;
+            }
+        break;
+    }
+    default: break;
+    }
+    for (int j = 0; j < 3; j++) {
+        force[(size_t)j*nn + n] = f[j];
+        fres[(size_t)j*nn + n] = fr[j];
+        v[j] += dt * f[j] / m4.w;
+    }
+    if (n >= o0 && n < nn_own_end) {
+        const double num = (double)nn_global * 3;
+        l2 = fr[0]*fr[0] / num;
+        l2 += fr[1]*fr[1] / num;
+        l2 += fr[2]*fr[2] / num;
+    }
+    if (clk->iso) {
+        // isostasy_adjustment (dynearthsol.cxx:521-535): no velocity bcs, vertical motion only,
+        // a bottom without Winkler foundation is held
+        v[0] = 0; v[1] = 0;
+        if (!p->has_winkler_foundation && (flag & (1u << 4))) v[2] = 0;       // BOUNDZ0
+    } else if (flag & 0x3ffu)
+        apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
+    m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
+    vm[n] = m4;
+    if (p->has_moving_mesh || clk->iso) {
+        x4.x += v[0] * dt; x4.y += v[1] * dt; x4.z += v[2] * dt;
+        xt_out[n] = x4;
+    } else if (always_store_xt)
+        xt_out[n] = x4;
+    return l2;
+}
+
 // update_force node loop (fields.cxx:659-676), apply_stress_bcs node loop (bc.cxx:783-802,
 // 817-823), apply_stress_bcs_neumann, apply_damping (fields.cxx:483-579), update_velocity
 // (fields.cxx:725-742), residual partial sums (fields.cxx:700-722), apply_vbcs,
@@ -180,82 +274,9 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
         __syncthreads();
     }
     double l2 = 0.0;
-    if (n < nn) {
-        const double dt = clk->dt;
-        const unsigned flag = bcflag[n];
-        d4 x4 = xt[n];
-        if (flag & bc_mask) {
-            const int b0 = bcn_idx[n], b1 = bcn_idx[n+1];
-            int b = b0;
-            for (; b < b1; ++b) {
-                const int ent = bcn_ent[b];
-                if (ent & 1) break;
-                const double *t = bcf_tmp + (size_t)(ent >> 1) * 3;
-                f[0] -= t[0]; f[1] -= t[1]; f[2] -= t[2];
-            }
-            if (p->has_elastic_foundation && (flag & (1u << 4)))
-                f[2] -= p->elastic_foundation_constant * (x4.z - coord0[(size_t)2*nn + n]);
-            for (; b < b1; ++b) {
-                const double *t = bcf_tmp + (size_t)(bcn_ent[b] >> 1) * 3;
-                f[0] += t[0]; f[1] += t[1]; f[2] += t[2];
-            }
-        }
-        d4 m4 = vm[n];
-        double v[3] = {m4.x, m4.y, m4.z};
-        const double small_vel = 1e-13;
-        const double dfac = p->damping_factor;
-        switch (p->damping_option) {
-        case 1:
-            for (int j = 0; j < 3; j++)
-                if (fabs(v[j]) > small_vel) f[j] -= dfac * copysign(f[j], v[j]);
-            break;
-        case 2:
-            for (int j = 0; j < 3; j++) f[j] -= dfac * f[j];
-            break;
-        case 3:
-            for (int j = 0; j < 3; j++) {
-                if ((f[j] < 0) == (v[j] < 0)) f[j] -= dfac * f[j];   // fields.cxx:538 (comma operator)
-                else                          f[j] += (1 - dfac) * f[j];
-            }
-            break;
-        case 4: {
-            double critical_coeff = 2.0 * sqrt(m4.w * ymass[n]);
-            for (int j = 0; j < 3; j++)
-                if (fabs(v[j]) > small_vel) {
-                    double f_C = dfac * copysign(f[j], v[j]);
-                    double f_V = critical_coeff * v[j];
-                    double f_damping = (fabs(f_C) < fabs(f_V)) ? f_V : f_C;
-                    f[j] -= f_damping;
-                }
-            break;
-        }
-        default: break;
-        }
-        for (int j = 0; j < 3; j++) {
-            force[(size_t)j*nn + n] = f[j];
-            fres[(size_t)j*nn + n] = fr[j];
-            v[j] += dt * f[j] / m4.w;
-        }
-        if (n >= o0 && n < nn_own_end) {
-            const double num = (double)nn_global * 3;
-            l2 = fr[0]*fr[0] / num;
-            l2 += fr[1]*fr[1] / num;
-            l2 += fr[2]*fr[2] / num;
-        }
-        if (clk->iso) {
-            // isostasy_adjustment (dynearthsol.cxx:521-535): no velocity bcs, vertical motion only,
-            // a bottom without Winkler foundation is held
-            v[0] = 0; v[1] = 0;
-            if (!p->has_winkler_foundation && (flag & (1u << 4))) v[2] = 0;       // BOUNDZ0
-        } else if (flag & 0x3ffu)
-            apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
-        m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
-        vm[n] = m4;
-        if (p->has_moving_mesh || clk->iso) {
-            x4.x += v[0] * dt; x4.y += v[1] * dt; x4.z += v[2] * dt;
-            xt[n] = x4;
-        }
-    }
+    if (n < nn)
+        l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
+                            coord0, ymass, bnormals, edge_vec, edge_slot, xt, xt, false, vm, force, fres);
     // per-block partial of the residual; the partials are added in block order afterwards
     l2 = desk::wave_sum(l2);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;

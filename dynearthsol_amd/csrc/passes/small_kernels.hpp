@@ -10,7 +10,7 @@ __global__ void __launch_bounds__(DES_BLOCK)
 k_state_pack(int nnodes, const int *__restrict__ nidx, const int *__restrict__ noff,
              int nelems, const int *__restrict__ eidx, const int *__restrict__ eoff,
              const d4 *__restrict__ xt, const d4 *__restrict__ vm, const double *__restrict__ dh_n,
-             const double *__restrict__ stress, const double *__restrict__ strain,
+             const double *__restrict__ stress, const double *__restrict__ ddp, const double *__restrict__ strain,
              const double *__restrict__ plstrain, int ne, double *__restrict__ buf)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -23,6 +23,9 @@ k_state_pack(int nnodes, const int *__restrict__ nidx, const int *__restrict__ n
         const int j = i - nnodes, e = eidx[j];
         double *b = buf + eoff[j];
         for (int c = 0; c < 6; ++c) { b[c] = stress[(size_t)c*ne + e]; b[6 + c] = strain[(size_t)c*ne + e]; }
+        // EN3 leaves the NMD increment of the diagonal for the next E1 (passes/en3.hpp): what is sent
+        // is the stress that E1 will see
+        if (ddp) { const double d = ddp[e]; if (d != 0.0) { b[0] += d; b[1] += d; b[2] += d; } }
         b[12] = plstrain[e];
     }
 }
@@ -31,7 +34,7 @@ __global__ void __launch_bounds__(DES_BLOCK)
 k_state_unpack(int nnodes, const int *__restrict__ nidx, const int *__restrict__ noff,
                int nelems, const int *__restrict__ eidx, const int *__restrict__ eoff,
                d4 *__restrict__ xt, d4 *__restrict__ vm, double *__restrict__ dh_n,
-               double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ plstrain,
+               double *__restrict__ stress, double *__restrict__ ddp, double *__restrict__ strain, double *__restrict__ plstrain,
                int ne, const double *__restrict__ buf)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -46,6 +49,7 @@ k_state_unpack(int nnodes, const int *__restrict__ nidx, const int *__restrict__
         const int j = i - nnodes, e = eidx[j];
         const double *b = buf + eoff[j];
         for (int c = 0; c < 6; ++c) { stress[(size_t)c*ne + e] = b[c]; strain[(size_t)c*ne + e] = b[6 + c]; }
+        if (ddp) ddp[e] = 0.0;                             // the received stress already holds its increment
         plstrain[e] = b[12];
     }
 }

@@ -66,7 +66,8 @@ def main():
             "fetch_counter_per_byte_read": fv / (READ[pat] * ITEMS), "write_counter_per_byte_written": wv / (WRITE[pat] * ITEMS)}
         print("%-36s FETCH_SIZE / bytes read = %.3f   WRITE_SIZE / bytes written = %.3f"
               % (NAMES[pat], fv / (READ[pat] * ITEMS), wv / (WRITE[pat] * ITEMS)))
-    with open(os.path.join(ROOT, "profiles", "r02_pmc_calibration.json"), "w") as fp:
+    # (on the GPU box only gpurun_out/ travels back: DES_PROFILE_OUT=gpurun_out/<dir>, then copy to profiles/)
+    with open(os.path.join(os.environ.get("DES_PROFILE_OUT", os.path.join(ROOT, "profiles")), "r02_pmc_calibration.json"), "w") as fp:
         json.dump(res, fp, indent=1)
 
 
