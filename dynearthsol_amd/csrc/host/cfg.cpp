@@ -345,8 +345,14 @@ void build_params(const Config &c, des_params &p)
     p.nmat = c.i("mat.num_materials");
     if (p.nmat < 1) throw Error(11, "mat.num_materials must be greater than 0.");
     if (p.nmat > DES_MAX_MAT) throw Error(52, "mat.num_materials exceeds DES_MAX_MAT");
-    if (c.i("mat.phase_change_option") != 0)
-        throw Error(31, "phase changes run on host markers and are outside the offloaded hot path");
+    {
+        // phase changes run on the host's marker set every 10 steps (host/markers.cpp, run.cpp);
+        // checks of input.cxx:1399-1404
+        const int pco = c.i("mat.phase_change_option");
+        if (pco != 0 && p.nmat == 1) throw Error(11, "mat.phase_change_option is chosen, but mat.num_materials is 1.");
+        if (pco == 1 && p.nmat < 8) throw Error(11, "mat.phase_change_option is 1, but mat.num_materials is less than 8.");
+        if (pco != 0 && pco != 1 && pco != 101) throw Error(11, "Error: unknown phase_change_option: " + std::to_string(pco));
+    }
     p.mattype_ref = c.i("mat.mattype_ref");
     if (p.mattype_ref < 0 || p.mattype_ref >= p.nmat)
         throw Error(11, "Error: mat.mattype_ref must be within [0, mat.num_materials-1]");

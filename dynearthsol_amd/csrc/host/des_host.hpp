@@ -125,6 +125,11 @@ void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostField
 // ic.is_restarting_weakzone (dynearthsol.cxx:403-406)
 void restart_weak_zone(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f);
 
+// markers.init_marker_option = 2 (markerset.cxx:556-663) and phase_changes (phasechanges.cxx:109-152): markers.cpp
+void regularly_spaced_markers(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f);
+int phase_changes(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f,
+                  const double *coord, const double *temperature);
+
 // ref_pressure (matprops.cxx:153-174)
 double ref_pressure(const des_params &p, double z);
 

@@ -144,8 +144,10 @@ void create_elemmarkers(const Config &cfg, const des_params &p, const HostMesh &
     const int mpe = cfg.i("markers.markers_per_element");
     f.elemmarkers.assign((size_t)ne*nmat, 0);
     const int mattype_option = cfg.i("ic.mattype_option");
-    if (cfg.i("markers.init_marker_option") != 1)
-        throw Error(31, "markers.init_marker_option != 1 (regularly spaced markers) is not offloaded");
+    const int imo = cfg.i("markers.init_marker_option");
+    if (imo == 2) { regularly_spaced_markers(cfg, p, m, f); return; }
+    if (imo != 1)
+        throw Error(11, "Error: unknown init_marker_option: " + std::to_string(imo));           // markerset.cxx:50-53
     if (mattype_option != 0 && mattype_option != 1)
         throw Error(11, "Error: unknown ic.mattype_option");
     std::vector<double> layer_mt, depths;

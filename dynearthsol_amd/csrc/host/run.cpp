@@ -224,6 +224,7 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         const bool check_bottom = remeshing_option == 1 || remeshing_option == 2 || remeshing_option == 11 || remeshing_option == 13;
         const double bottom_dist = check_bottom ? cfg.d("mesh.max_boundary_distortion") * cfg.d("mesh.resolution") : -1.0;
 
+        const bool phase_change_on = p.nmat > 1 && cfg.i("mat.phase_change_option") != 0;
         bool go_on = true;
         do {
             // ---- how many steps until the next point where the reference's loop does anything
@@ -252,12 +253,30 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
                     if (safe < n) n = safe;
                 }
             }
+            // phase_changes runs every 10 steps on the host's markers (dynearthsol.cxx:881-894)
+            if (phase_change_on && 10 - steps % 10 < n) n = 10 - steps % 10;
             if (n < 1) n = 1;
 
             const double t0 = seconds_now();
             int rc = api->step(r.eng, (int)n, &r.sc);
             st.compute_seconds += seconds_now() - t0;
             if (rc) throw des::Error(rc, std::string("step: ") + (api->last_error ? api->last_error() : ""));
+
+            // ---- slow updates (dynearthsol.cxx:881-894): phase_changes, then compute_dt with the new
+            // material mix.  The engine has already taken its compute_dt of this step with the old one,
+            // so it is only repeated when a marker did change.
+            if (phase_change_on && r.sc.steps % 10 == 0) {
+                std::vector<double> coord = r.get(DES_F_COORD), T = r.get(DES_F_TEMPERATURE);
+                const int changed = des::phase_changes(cfg, p, m, host->fields, coord.data(), T.data());
+                st.phase_changed_markers += changed;
+                if (changed) {
+                    r.check(api->upload(r.eng, DES_F_ELEMMARKERS, host->fields.elemmarkers.data(),
+                                        (long long)host->fields.elemmarkers.size()), "upload elemmarkers");
+                    double dt_new = 0;
+                    r.check(api->compute_dt(r.eng, &dt_new), "compute_dt");
+                    r.check(api->step(r.eng, 0, &r.sc), "clock");
+                }
+            }
 
             // ---- output (dynearthsol.cxx:906-931)
             const bool step_due = output_step_interval != std::numeric_limits<int>::max() &&

@@ -28,6 +28,15 @@ __device__ __forceinline__ desk::Mix mix_of(const MatData &md, int nmat, int e)
     return mx;
 }
 
+// the same from a mono[] value the caller has already loaded
+__device__ __forceinline__ desk::Mix mix_from_mono(const MatData &md, int nmat, int e, int mo)
+{
+    desk::Mix mx;
+    if (mo >= 0) { mx.mk = nullptr; mx.mat = mo >> 16; mx.cnt = mo & 0xffff; }
+    else         { mx.mk = md.markers + (size_t)e * nmat; mx.mat = -1; mx.cnt = 0; }
+    return mx;
+}
+
 __device__ __forceinline__ ElemProps load_props(const des_params *p, const MatData &md, const desk::Mix &mx, int ne, int e)
 {
     ElemProps r;

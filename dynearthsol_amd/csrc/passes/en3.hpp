@@ -30,8 +30,9 @@
 #define DES_PATCH_INC 2048        // caps of the largest shape = what build_patches() accepts
 #define DES_PATCH_PN 512
 
+// (512 lanes: three workgroups per CU are 6 waves per SIMD, i.e. at most 80 VGPRs)
 template <int THREADS, int INC, int PN>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 6 : 3)
 EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nmd, int o0, int nn_own_end,
      int nn, int nn_global, int ne, int nblocks, int npb,
      const int *__restrict__ pe_ptr, const int *__restrict__ pe_elem, const ushort4 *__restrict__ pe_ln,
@@ -56,37 +57,65 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     const int n0 = lb * npb;
     if (n0 >= nn) return;                                 // grid padding
     const int nown = min(npb, nn - n0);
-    // 1. the patch's nodes: own range first (local id = n - n0), then the listed others
-    {
-        const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
-        for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
-            const int id = j < nown ? n0 + j : pn_id[h0 + j - nown];
-            lxt[j] = xt[id];
-            if (nmd) lnt[j] = ntmp[id];
-        }
+    const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
+    const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
+    const double gravity = p->gravity;
+    const int nmat = p->nmat;
+
+    // Everything below is ordered so that the global loads that do not depend on each other are in
+    // flight TOGETHER: a workgroup's critical path is two round trips to memory (index, then record),
+    // not one per phase -- with three workgroups per CU there is little else to hide them behind.
+    struct Elem { int ew, mono; ushort4 ln; short4 sl; double s[6], vol, dpo; };
+    auto load_elem = [&](int i, Elem &E) {
+        E.ew = pe_elem[i]; E.ln = pe_ln[i]; E.sl = pe_slot[i];
+        const int e = E.ew & 0x3fffffff;
+        for (int k = 0; k < 6; ++k) E.s[k] = stress[(size_t)k*ne + e];
+        E.vol = volume[e];
+        E.dpo = nmd ? dpressure[e] : 0.0;
+        E.mono = gravity != 0 ? md.mono[e] : 0;
+    };
+    // (a) this lane's first patch element: list entry, then stress / volume / dpressure (holding a
+    //     second one in registers as well costs a wave of occupancy and more than it hides)
+    Elem E0;
+    const int i0 = e_begin + threadIdx.x, i1 = i0 + THREADS;
+    if (i0 < e_end) load_elem(i0, E0);
+    // (b) the node this lane will finish: its CSR segment and its records
+    const int n = n0 + threadIdx.x;
+    const bool has_node = (int)threadIdx.x < nown;
+    int r0 = 0, r1 = 0;
+    unsigned flag = 0;
+    d4 m4 = {0, 0, 0, 0};
+    if (has_node) {
+        const int kb = sup_idx[n0];
+        r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
+        flag = bcflag[n];
+        m4 = vm[n];
+    }
+    // (c) the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
+    for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
+        const int id = j < nown ? n0 + j : pn_id[h0 + j - nown];
+        lxt[j] = xt[id];
+        if (nmd) lnt[j] = ntmp[id];
     }
     __syncthreads();
-    // 2. the patch's elements
-    const double gravity = p->gravity;
-    for (int i = pe_ptr[lb] + threadIdx.x; i < pe_ptr[lb + 1]; i += THREADS) {
-        const int ew = pe_elem[i];
-        const int e = ew & 0x3fffffff;
-        const ushort4 ln = pe_ln[i];
-        const short4 sl = pe_slot[i];
+
+    // the force terms of one patch element into the LDS slots of its incidences in this block
+    auto do_elem = [&](const Elem &E) {
+        const int e = E.ew & 0x3fffffff;
         d4 c[4];
-        c[0] = lxt[ln.x]; c[1] = lxt[ln.y]; c[2] = lxt[ln.z]; c[3] = lxt[ln.w];
+        c[0] = lxt[E.ln.x]; c[1] = lxt[E.ln.y]; c[2] = lxt[E.ln.z]; c[3] = lxt[E.ln.w];
         double s[6];
-        for (int k = 0; k < 6; ++k) s[k] = stress[(size_t)k*ne + e];
+        for (int k = 0; k < 6; ++k) s[k] = E.s[k];
         if (nmd) {                                          // is_using_mixed_stress, outside the isostasy loop
             double dp = 0;
-            dp += lnt[ln.x]; dp += lnt[ln.y]; dp += lnt[ln.z]; dp += lnt[ln.w];
+            dp += lnt[E.ln.x]; dp += lnt[E.ln.y]; dp += lnt[E.ln.z]; dp += lnt[E.ln.w];
             double dp_el = dp / 4;
-            double dp_orig = dpressure[e];
+            double dp_orig = E.dpo;
             double ddp = (-dp_orig + dp_el) / 3;
             for (int k = 0; k < 3; ++k) s[k] += ddp;
-            if (ew & 0x40000000) ddp_out[e] = ddp;          // this block owns the element
+            if (E.ew & 0x40000000) ddp_out[e] = ddp;        // this block owns the element
         }
-        const double vol = volume[e];
+        const double vol = E.vol;
         double sx[4], sy[4], sz[4];
         desk::shape_fn(c, vol, sx, sy, sz);
         double buoy = 0;
@@ -94,12 +123,12 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
             double T = 0;
             T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
             T /= 4;
-            const desk::Mix mx = mix_of(md, p->nmat, e);
+            const desk::Mix mx = mix_from_mono(md, nmat, e, E.mono);
             const double rho = desk::mat_rho(p, mx, T);
             const double phi = load_props(p, md, mx, ne, e).phi;
             buoy = (rho * (1 - phi) + 1000.0 * phi) * gravity / 4;
         }
-        const int slot[4] = {sl.x, sl.y, sl.z, sl.w};
+        const int slot[4] = {E.sl.x, E.sl.y, E.sl.z, E.sl.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (slot[k] < 0) continue;
@@ -107,14 +136,18 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
             lf[1][slot[k]] = (s[3]*sx[k] + s[1]*sy[k] + s[5]*sz[k]) * vol;
             lf[2][slot[k]] = (s[4]*sx[k] + s[5]*sy[k] + s[2]*sz[k] + buoy) * vol;
         }
+    };
+    if (i0 < e_end) do_elem(E0);
+    for (int i = i1; i < e_end; i += THREADS) {             // the rest of the patch (one more round, seldom two)
+        Elem E;
+        load_elem(i, E);
+        do_elem(E);
     }
     __syncthreads();
-    // 3. the block's nodes: force sums in CSR order, then the rest of the nodal update
+
+    // the block's nodes: force sums in CSR order, then the rest of the nodal update
     double l2 = 0.0;
-    if ((int)threadIdx.x < nown) {
-        const int n = n0 + threadIdx.x;
-        const int kb = sup_idx[n0];
-        const int r0 = sup_idx[n] - kb, r1 = sup_idx[n + 1] - kb;
+    if (has_node) {
         double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
         for (int k = r0; k < r1; ++k) {
             const double t0v = lf[0][k], t1v = lf[1][k], t2v = lf[2][k];
@@ -122,7 +155,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
             fr[0] = t0v; fr[1] = t1v; fr[2] = t2v;          // assignment: fields.cxx:673
         }
         l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
-                            coord0, ymass, bnormals, edge_vec, edge_slot, xt, xt_out, true, vm, force, fres);
+                            coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres);
     }
     // per-block partial of the residual; the partials are added in block order afterwards
     l2 = desk::wave_sum(l2);

@@ -113,15 +113,15 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
      const int *__restrict__ bcn_ent, const double *__restrict__ bcf_tmp,
      const double *__restrict__ coord0, const double *__restrict__ ymass,
      const double *__restrict__ bnormals, const double *__restrict__ edge_vec, const int *__restrict__ edge_slot,
-     const d4 *xt_in, d4 *xt_out, bool always_store_xt, d4 *__restrict__ vm, double *__restrict__ force, double *__restrict__ fres)
+     const unsigned flag, d4 x4, d4 m4, d4 *xt_out, bool always_store_xt, d4 *__restrict__ vm,
+     double *__restrict__ force, double *__restrict__ fres)
 {
-    // xt_in / xt_out: the same array for N3; EN3 reads the coordinates of other blocks' nodes in the
-    // same launch, so it writes the records of its own nodes to the other buffer of a pair (and then
-    // always, moving mesh or not)
+    // flag, x4, m4: bcflag[n], the node's {x,y,z,T} and {vx,vy,vz,mass} records, loaded by the caller
+    // (EN3 has them in flight long before the force sums are ready).  xt_out: the array itself for
+    // N3; EN3 reads the coordinates of other blocks' nodes in the same launch, so it writes the
+    // records of its own nodes to the other buffer of a pair (and then always, moving mesh or not)
     double l2 = 0.0;
     const double dt = clk->dt;
-    const unsigned flag = bcflag[n];
-    d4 x4 = xt_in[n];
     if (flag & bc_mask) {
         const int b0 = bcn_idx[n], b1 = bcn_idx[n+1];
         int b = b0;
@@ -138,7 +138,6 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
             f[0] += t[0]; f[1] += t[1]; f[2] += t[2];
         }
     }
-    d4 m4 = vm[n];
     double v[3] = {m4.x, m4.y, m4.z};
     const double small_vel = 1e-13;
     const double dfac = p->damping_factor;
@@ -276,7 +275,7 @@ N3_force_velocity_coord(const des_params *__restrict__ p, const DevClock *__rest
     double l2 = 0.0;
     if (n < nn)
         l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
-                            coord0, ymass, bnormals, edge_vec, edge_slot, xt, xt, false, vm, force, fres);
+                            coord0, ymass, bnormals, edge_vec, edge_slot, bcflag[n], xt[n], vm[n], xt, false, vm, force, fres);
     // per-block partial of the residual; the partials are added in block order afterwards
     l2 = desk::wave_sum(l2);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;

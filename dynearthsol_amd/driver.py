@@ -39,7 +39,7 @@ class EngineApi(C.Structure):
 class RunStats(C.Structure):
     """des_run_stats"""
     _fields_ = [("steps", _ll), ("time", _d), ("dt", _d), ("frames", _i), ("checkpoints", _i),
-                ("exit_code", _i), ("remesh_needed", _i), ("compute_seconds", _d)]
+                ("exit_code", _i), ("remesh_needed", _i), ("compute_seconds", _d), ("phase_changed_markers", _ll)]
 
 
 def api_from_lib(lib, prefix, create=None):

@@ -82,6 +82,7 @@ typedef struct des_run_stats {
     int exit_code;              /* 0, or the reference ExitCode the run stopped with          */
     int remesh_needed;          /* bad_mesh_quality's code (1..3) if the run stopped for it   */
     double compute_seconds;     /* wall time inside engine steps                              */
+    long long phase_changed_markers;   /* markers whose material phase_changes() moved (phasechanges.cxx:109-152) */
 } des_run_stats;
 
 /* init() tail + main loop.  Returns stats->exit_code.  `quiet` suppresses the progress lines. */

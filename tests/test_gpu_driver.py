@@ -133,3 +133,30 @@ def test_reference_tiny_3d_benchmark_through_the_executable(in_tmp):
         for k in a:
             if k != "walltime_sec":
                 assert np.array_equal(a[k], b[k]), (name, k)
+
+
+def test_phase_changes_on_the_device_loop_match_the_oracle_loop(in_tmp):
+    """phase_changes on the host's markers every 10 steps, counts re-uploaded (dirty
+    flag -> k_props) and compute_dt repeated with the new material mix -- the HIP engine under
+    des_run against the CPU oracle under the same loop: the same markers change at the same steps,
+    the frames agree (bit for bit where no libm is involved; the creep law's pow / exp are glibc's
+    bits on the device too)."""
+    from test_markers import PHASE_KW, PHASE_OV
+    text = cfgs.make(**PHASE_KW)
+    hd = des.Host(cfg_text=text, overrides=PHASE_OV + "sim.modelname = gpu\n")
+    ho = des.Host(cfg_text=text, overrides=PHASE_OV + "sim.modelname = cpu\n")
+    sd = driver.run(hd)
+    so = driver.run(ho, api=oracle_api())
+    assert sd.phase_changed_markers == so.phase_changed_markers > 0
+    assert (sd.steps, sd.frames, sd.dt) == (so.steps, so.frames, so.dt)
+    for frame in range(4):
+        a, b = read_frame("gpu.save.%06d" % frame), read_frame("cpu.save.%06d" % frame)
+        assert sorted(a) == sorted(b)
+        for name in a:
+            if name == "walltime_sec":
+                continue
+            if name.startswith("markerset") or name in ("material", "connectivity", "bcflag"):
+                assert np.array_equal(a[name], b[name]), (frame, name)
+            else:
+                x, y = a[name].view(np.float64), b[name].view(np.float64)
+                assert np.abs(x - y).max() <= 1e-10 * max(np.abs(y).max(), 1e-300), (frame, name)

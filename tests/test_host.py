@@ -66,7 +66,7 @@ def test_features_outside_the_offloaded_path_are_refused_not_ignored():
     never a silent no-op."""
     base = cfgs.make(**cfgs.EP)
     for ov in ("control.has_PT = yes\n", "control.has_hydraulic_diffusion = yes\n", "control.surface_process_option = 101\n",
-               "mat.phase_change_option = 1\n", "markers.init_marker_option = 2\n", "monitor.enabled = yes\nmonitor.num_points = 1\n",
+               "control.has_hydration_processes = yes\n", "monitor.enabled = yes\nmonitor.num_points = 1\n",
                "ic.temperature_option = 90\n", "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n",
                "mesh.meshing_option = 95\nmesh.meshing_elem_shape = 0\n"):
         with pytest.raises(des.DesError) as e:
