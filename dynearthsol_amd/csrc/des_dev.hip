@@ -87,14 +87,14 @@ struct DevClock {
 };
 
 // INIT: C part without rotate_stress; AVG: Output::average_fields on the final stress of the step
-enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8 };
+enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_NOREC = 16 };
 
 enum KernelId { K_E1, K_N1, K_E2, K_E2R, K_N2, K_E3, K_N3, K_S2, K_S3,
-                K_DTFIN, K_MISC, K_EXCH, K_EN3, K_COUNT };
+                K_DTFIN, K_MISC, K_EXCH, K_EN3, K_EN1, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "E2_return_mapping", "N2_nmd_gather",
     "E3_nmd_force", "N3_force_velocity_coord", "S2_surface_diffusion",
-    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange", "EN3_force_nodes" };
+    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange", "EN3_force_nodes", "EN1_mass_temperature_dvoldt" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
 
@@ -167,7 +167,8 @@ struct des_dev {
     int npb;                              // nodes per node-kernel workgroup (choose_npb)
     // node-block patches: EN3 replaces E3 + N3 (passes/en3.hpp, engine/patch.hpp)
     bool patch;
-    int patch_npb, patch_nb, patch_max_inc, patch_max_pn, patch_threads;
+    int patch_npb, patch_nb, patch_max_inc, patch_max_pn, patch_max_pe, patch_threads;
+    bool patch_n1;                        // EN1 replaces N1 inside multi-step calls (passes/en1.hpp)
     int *pe_ptr, *pe_elem, *pn_ptr, *pn_id;
     ushort4 *pe_ln;
     short4 *pe_slot;
@@ -232,6 +233,7 @@ namespace des_hip {
 #include "passes/e3.hpp"
 #include "passes/n3.hpp"
 #include "passes/en3.hpp"
+#include "passes/en1.hpp"
 #include "passes/surface.hpp"
 #include "passes/small_kernels.hpp"
 #include "engine/patch.hpp"
@@ -403,12 +405,25 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         h->patch = false;
         if (!(env && env[0] == '0')) {
             PatchLists P;
+            // DES_PATCH=<n>: n nodes per block; default: the largest of 64, 56, 48, 40, 32 whose biggest
+            // block fits the three-workgroups-per-CU LDS shapes of both patch kernels (valence-32 nodes of
+            // the regular 5-tet mesh make smaller blocks than a TetGen mesh of the same size), else 64 /
+            // 32 / 16 with the full-size shapes
             int want = env ? std::atoi(env) : 0;
-            const int tries[3] = {(want >= 16 && want <= 128 && want % 16 == 0) ? want : 64, 32, 16};
-            for (int t = 0; t < 3 && !h->patch; ++t)
-                h->patch = build_patches(mesh, tries[t], DES_PATCH_INC, DES_PATCH_PN, P);
+            if (want >= 16 && want <= 128 && want % 8 == 0)
+                h->patch = build_patches(mesh, want, DES_PATCH_INC, DES_PATCH_PN, P);
+            else {
+                const int fits[5] = {64, 56, 48, 40, 32};
+                for (int t = 0; t < 5 && !h->patch; ++t)
+                    h->patch = build_patches(mesh, fits[t], 1600, 296, P) && P.max_pe <= 872;
+                const int tries[3] = {64, 32, 16};
+                for (int t = 0; t < 3 && !h->patch; ++t)
+                    h->patch = build_patches(mesh, tries[t], DES_PATCH_INC, DES_PATCH_PN, P);
+            }
             if (h->patch) {
-                h->patch_npb = P.npb; h->patch_nb = P.nb; h->patch_max_inc = P.max_inc; h->patch_max_pn = P.max_pn;
+                h->patch_npb = P.npb; h->patch_nb = P.nb; h->patch_max_inc = P.max_inc; h->patch_max_pn = P.max_pn; h->patch_max_pe = P.max_pe;
+                const char *pn1 = std::getenv("DES_PATCH_N1");
+                h->patch_n1 = !(pn1 && pn1[0] == '0') && P.max_pe <= DES_PATCH_PE;
                 const char *pt = std::getenv("DES_PATCH_THREADS");
                 h->patch_threads = (pt && std::atoi(pt) == 256) ? 256 : 512;
                 CK(dev_alloc(h->pe_ptr, P.pe_ptr.size())); CK(dev_upload(h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size(), h->stream));
@@ -823,7 +838,10 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
             HIP_OK(hipGraphLaunch(h->graph_exec[which], h->stream));
             continue;
         }
-        launch_n1(h);
+        // inside a multi-step call the step before ended with the fused E1<C | A | NOREC>, and EN1
+        // forms the element terms itself; the first step of a call gathers what E1 stored (the
+        // caller may have uploaded fields in between)
+        if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h);
         launch_e2(h);
         if (nmd) launch_n2(h);
         launch_force_pass(h);

@@ -96,16 +96,26 @@ k_average_fields(const des_params *__restrict__ p, DevClock *__restrict__ clk, i
     }
 }
 
+// EN1 (passes/en1.hpp) can stand in for N1 when the element terms are functions of the CURRENT nodal
+// records alone: moving mesh (volumes and masses recomputed every step), not the isostasy loop,
+// no damping option 4 (its Young's-modulus mass is a gather of its own), and not the overlapped
+// multi-GPU schedule (which cuts the end-of-step pass in two)
+inline bool en1_ok(const des_dev *h)
+{
+    return h->patch && h->patch_n1 && h->p.has_moving_mesh && !h->iso && h->p.damping_option != 4;
+}
+
 // end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
 void launch_e1_end(des_dev *h, long long step_no, bool with_next, int part = E1_ALL)
 {
     const bool do_dt = (step_no % 10 == 0);
     const int sel = (with_next ? 1 : 0) | (do_dt ? 2 : 0);
+    const bool norec = with_next && en1_ok(h);       // the next step's N1 is EN1: no mrec / ttmp needed
     switch (sel) {
     case 0: launch_e1<MODE_C>(h, part); break;
-    case 1: launch_e1<MODE_C | MODE_A>(h, part); break;
+    case 1: if (norec) launch_e1<MODE_C | MODE_A | MODE_NOREC>(h, part); else launch_e1<MODE_C | MODE_A>(h, part); break;
     case 2: launch_e1<MODE_C | MODE_DT>(h, part); break;
-    case 3: launch_e1<MODE_C | MODE_A | MODE_DT>(h, part); break;
+    case 3: if (norec) launch_e1<MODE_C | MODE_A | MODE_DT | MODE_NOREC>(h, part); else launch_e1<MODE_C | MODE_A | MODE_DT>(h, part); break;
     }
     if (part == E1_INTERIOR) return;               // the averaging pass follows the last part
     if (h->p.is_outputting_averaged_fields) {
@@ -265,6 +275,33 @@ void launch_n3(des_dev *h)
                        h->nn, h->nn_global, node_blocks(h), h->npb, h->sup_idx, h->sup_pack, h->bcflag, h->ftmp, h->bc_mask, h->bcn_idx,
                        h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass, h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->vm,
                        h->force, h->fres, h->res_part);
+}
+
+// N1 as a pass over node-block patches (passes/en1.hpp): the element terms are recomputed from the
+// nodal records instead of being stored by E1 and gathered
+void launch_en1(des_dev *h)
+{
+    {
+        Launch l(h, K_EN1);
+        void (*k)(const des_params *, DevClock *, int, int, int, int, const int *, const int *, const ushort4 *, const short4 *,
+                  const int *, const int *, const int *, const unsigned *, const MatData, const double *, const d4 *, d4 *, d4 *,
+                  double *, double *, double *);
+        const bool cm = h->const_mass;
+        static const char *tenv = std::getenv("DES_EN1_THREADS");
+        const int T = (tenv && std::atoi(tenv) == 512) ? 512 : 256;
+        if (h->patch_max_inc <= 1600 && h->patch_max_pn <= 296 && h->patch_max_pe <= 872)
+            k = T == 512 ? (cm ? EN1_mass_temperature_dvoldt<512, 1600, 296, 872, 1> : EN1_mass_temperature_dvoldt<512, 1600, 296, 872, 0>)
+                         : (cm ? EN1_mass_temperature_dvoldt<256, 1600, 296, 872, 1> : EN1_mass_temperature_dvoldt<256, 1600, 296, 872, 0>);
+        else
+            k = T == 512 ? (cm ? EN1_mass_temperature_dvoldt<512, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE, 1>
+                               : EN1_mass_temperature_dvoldt<512, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE, 0>)
+                         : (cm ? EN1_mass_temperature_dvoldt<256, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE, 1>
+                               : EN1_mass_temperature_dvoldt<256, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE, 0>);
+        hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, h->patch_nb,
+                           h->patch_npb, h->pe_ptr, h->pe_elem, h->pe_ln, h->pe_slot, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
+                           mat_data(h), h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n, h->tmass, h->ntmp);
+    }
+    std::swap(h->xt, h->xt_alt);               // EN1 wrote the records with the new temperatures there
 }
 
 // E3 + N3 as one pass over node-block patches (passes/en3.hpp); the stress-bc facet terms, which

@@ -11,7 +11,7 @@
 //          pe_slot  for each of the four nodes: position of that incidence in the block's slice of the
 //                   CSR support list (k - sup_idx[n0]) if the node is the block's own, else -1
 struct PatchLists {
-    int npb = 0, nb = 0, max_inc = 0, max_pn = 0;
+    int npb = 0, nb = 0, max_inc = 0, max_pn = 0, max_pe = 0;
     std::vector<int> pe_ptr, pe_elem, pn_ptr, pn_id;
     std::vector<ushort4> pe_ln;
     std::vector<short4> pe_slot;
@@ -67,6 +67,7 @@ bool build_patches(const des_mesh *m, int npb, int cap_inc, int cap_pn, PatchLis
         P.pn_ptr.push_back((int)P.pn_id.size());
         P.max_inc = std::max(P.max_inc, ke - kb);
         P.max_pn = std::max(P.max_pn, nown + (int)halo.size());
+        P.max_pe = std::max(P.max_pe, (int)elems.size());
     }
     return true;
 }

@@ -2,6 +2,42 @@
 // Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
 // DevClock / struct des_dev); not a stand-alone header.
 
+// Element terms that both E1 and the node-patch pass EN1 form -- one source, so that the two passes
+// produce the same bits from the same nodal records.
+// compute_mass, element part (geometry.cxx:1795-1840): inertial and thermal mass of a quarter element
+__device__ __forceinline__ void e1_mass_terms(const des_params *__restrict__ p, const ElemProps &pr, double rho, double vol,
+                                              double &m, double &tm)
+{
+    const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+    double rho_m = p->is_quasi_static ? pr.bulkm / (pseudo_speed * pseudo_speed) : rho;
+    m = rho_m * vol / 4;
+    tm = rho * pr.cp * vol / 4;
+}
+// update_temperature, element part (fields.cxx:211-239)
+__device__ __forceinline__ void e1_thermal_terms(const d4 c[4], const double sx[4], const double sy[4], const double sz[4],
+                                                 double k, double vol, double radiogenic, double rho, double tr[4])
+{
+    double kv = k * vol;
+    double rh = radiogenic * vol * rho / 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double diffusion = 0.;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            diffusion += (sx[i] * sx[j] + sy[i] * sy[j] + sz[i] * sz[j]) * c[j].w;
+        tr[i] = diffusion * kv - rh;
+    }
+}
+// update_strain_rate, the three diagonal components (fields.cxx:415-440): their sum times the
+// volume is compute_dvoldt's element term (geometry.cxx:218-224)
+__device__ __forceinline__ void e1_strain_rate_diag(const d4 v[4], const double sx[4], const double sy[4], const double sz[4],
+                                                    double &s0, double &s1, double &s2)
+{
+    s0 = 0; for (int i = 0; i < 4; ++i) s0 += v[i].x * sx[i];
+    s1 = 0; for (int i = 0; i < 4; ++i) s1 += v[i].y * sy[i];
+    s2 = 0; for (int i = 0; i < 4; ++i) s2 += v[i].z * sz[i];
+}
+
 // ---- E1 --------------------------------------------------------------------------
 // MODE_C: compute_volume (geometry.cxx:170-201) after the volume swap (dynearthsol.cxx:466-470),
 //         compute_mass element part (geometry.cxx:1795-1840), rotate_stress (fields.cxx:827-902);
@@ -64,11 +100,8 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
             }
             volume[e] = vol;
             // compute_mass, element part
-            const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
-            double rho_m = p->is_quasi_static ? pr.bulkm / (pseudo_speed * pseudo_speed) : rho;
             rec.x = vol;
-            rec.y = rho_m * vol / 4;
-            rec.z = rho * pr.cp * vol / 4;
+            e1_mass_terms(p, pr, rho, vol, rec.y, rec.z);
         } else {
             vol = volume[e];
             if (MODE & MODE_A) {
@@ -128,23 +161,14 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         }
 
         if (MODE & MODE_A) {
-            if (p->has_thermal_diffusion) {
-                double kv = pr.k * vol;
-                double rh = radiogenic[e] * vol * rho / 4;
-                d4 tr;
-                double *trp = &tr.x;
-                for (int i = 0; i < 4; ++i) {
-                    double diffusion = 0.;
-                    for (int j = 0; j < 4; ++j)
-                        diffusion += (sx[i] * sx[j] + sy[i] * sy[j] + sz[i] * sz[j]) * c[j].w;
-                    trp[i] = diffusion * kv - rh;
-                }
+            if (p->has_thermal_diffusion && !(MODE & MODE_NOREC)) {
+                double trp[4];
+                e1_thermal_terms(c, sx, sy, sz, pr.k, vol, radiogenic[e], rho, trp);
+                d4 tr = {trp[0], trp[1], trp[2], trp[3]};
                 ttmp[e] = tr;
             }
             double s[6];
-            s[0] = 0; for (int i = 0; i < 4; ++i) s[0] += v[i].x * sx[i];
-            s[1] = 0; for (int i = 0; i < 4; ++i) s[1] += v[i].y * sy[i];
-            s[2] = 0; for (int i = 0; i < 4; ++i) s[2] += v[i].z * sz[i];
+            e1_strain_rate_diag(v, sx, sy, sz, s[0], s[1], s[2]);
             s[3] = 0; for (int i = 0; i < 4; ++i) s[3] += 0.5 * (v[i].x * sy[i] + v[i].y * sx[i]);
             s[4] = 0; for (int i = 0; i < 4; ++i) s[4] += 0.5 * (v[i].x * sz[i] + v[i].z * sx[i]);
             s[5] = 0; for (int i = 0; i < 4; ++i) s[5] += 0.5 * (v[i].y * sz[i] + v[i].z * sy[i]);
@@ -154,7 +178,8 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         } else {
             rec.w = 0;
         }
-        if (MODE & (MODE_C | MODE_A)) mrec[e] = rec;
+        // MODE_NOREC (with C | A): the next pass is EN1, which forms mrec / ttmp itself from the nodal records
+        if ((MODE & (MODE_C | MODE_A)) && !(MODE & MODE_NOREC)) mrec[e] = rec;
     }
 
     if (MODE & MODE_DT) {

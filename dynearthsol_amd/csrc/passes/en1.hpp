@@ -1,0 +1,136 @@
+// passes/en1.hpp -- Pass EN1 (node patches): N1 without the element temporaries.
+// Part of the single translation unit des_dev.hip (included inside namespace des_hip, after
+// DevClock / struct des_dev); not a stand-alone header.
+
+// ---- EN1 -------------------------------------------------------------------------
+// compute_mass gather (geometry.cxx:1846-1864), update_temperature (fields.cxx:211-262),
+// compute_dvoldt (geometry.cxx:218-238), and the clock (dynearthsol.cxx:773-774) -- what N1 does,
+// for one block of `npb` nodes per workgroup over its patch (engine/patch.hpp), in the manner of
+// EN3: the element terms N1 gathers (volume, inertial / thermal mass, conduction term of each of the
+// four nodes, tr(strain rate) x volume) are functions of the nodal records {x,y,z,T}, {vx,vy,vz}
+// and of per-element constants only, so the workgroup stages the records of its patch's nodes in
+// LDS and RECOMPUTES those terms (the very expressions of E1: e1_mass_terms, e1_thermal_terms,
+// e1_strain_rate_diag) instead of E1 writing 64 B per element and N1 gathering them back per
+// incidence.  Sums per node run over the block's slice of the CSR list in order -> same bits.
+//
+// Valid when nothing but the nodal records has changed since the end-of-step pass (engine/launch.hpp,
+// en1_ok): inside a multi-step call.  The new temperatures go to the other buffer of the
+// {x,y,z,T} pair (another block may still be reading this block's nodes); the host swaps.
+#ifndef DES_PATCH_PE
+#define DES_PATCH_PE 1280         // elements of a patch (LDS records)
+#endif
+
+template <int THREADS, int INC, int PN, int PE, int CONSTM>
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 3)
+EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int ne, int nblocks, int npb,
+     const int *__restrict__ pe_ptr, const int *__restrict__ pe_elem, const ushort4 *__restrict__ pe_ln,
+     const short4 *__restrict__ pe_slot, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
+     const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag, const MatData md,
+     const double *__restrict__ radiogenic, const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm,
+     double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp)
+{
+    __shared__ d4 lxt[PN];
+    __shared__ double lvx[PN], lvy[PN], lvz[PN];
+    __shared__ double lvol[PE], ltm[PE], ldv[PE];
+    __shared__ double lm[CONSTM ? 1 : PE];
+    __shared__ double ltd[INC];
+    __shared__ unsigned short lidx[INC];
+    const int lb = desk::logical_block(nblocks);
+    const int n0 = lb * npb;
+    const double dt = clk->dt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {             // never in the isostasy loop (en1_ok)
+        clk->steps += 1;
+        clk->time += dt;
+        clk->maxdh = 0.0;
+        clk->n_defer = 0;
+    }
+    if (n0 >= nn) return;                                  // grid padding
+    const int nown = min(npb, nn - n0);
+    const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
+    const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
+    const bool thermal = p->has_thermal_diffusion;
+    const int nmat = p->nmat;
+    // the node this lane finishes
+    const int n = n0 + threadIdx.x;
+    const bool has_node = (int)threadIdx.x < nown;
+    int r0 = 0, r1 = 0;
+    unsigned flag = 0;
+    d4 m4 = {0, 0, 0, 0};
+    if (has_node) {
+        const int kb = sup_idx[n0];
+        r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
+        flag = bcflag[n];
+        m4 = vm[n];
+    }
+    // the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
+    for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
+        const int id = j < nown ? n0 + j : pn_id[h0 + j - nown];
+        lxt[j] = xt[id];
+        const d4 v = vm[id];
+        lvx[j] = v.x; lvy[j] = v.y; lvz[j] = v.z;
+    }
+    __syncthreads();
+    // the patch's elements: E1's element terms, recomputed
+    for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) {
+        const int e = pe_elem[i] & 0x3fffffff;
+        const ushort4 ln = pe_ln[i];
+        const short4 sl = pe_slot[i];
+        const int q = i - e_begin;                          // position in the patch
+        d4 c[4], v[4];
+        c[0] = lxt[ln.x]; c[1] = lxt[ln.y]; c[2] = lxt[ln.z]; c[3] = lxt[ln.w];
+        v[0].x = lvx[ln.x]; v[0].y = lvy[ln.x]; v[0].z = lvz[ln.x]; v[0].w = 0;
+        v[1].x = lvx[ln.y]; v[1].y = lvy[ln.y]; v[1].z = lvz[ln.y]; v[1].w = 0;
+        v[2].x = lvx[ln.z]; v[2].y = lvy[ln.z]; v[2].z = lvz[ln.z]; v[2].w = 0;
+        v[3].x = lvx[ln.w]; v[3].y = lvy[ln.w]; v[3].z = lvz[ln.w]; v[3].w = 0;
+        const desk::Mix mx = mix_of(md, nmat, e);
+        const ElemProps pr = load_props(p, md, mx, ne, e);
+        double T = 0;
+        T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
+        T /= 4;
+        const double rho = desk::mat_rho(p, mx, T);
+        const double vol = desk::tet_volume(c);             // = volume[e]: E1 formed it from the same records
+        double m, tm;
+        e1_mass_terms(p, pr, rho, vol, m, tm);
+        double sx[4], sy[4], sz[4];
+        desk::shape_fn(c, vol, sx, sy, sz);
+        double tr[4] = {0, 0, 0, 0};
+        if (thermal) e1_thermal_terms(c, sx, sy, sz, pr.k, vol, radiogenic[e], rho, tr);
+        double s0, s1, s2;
+        e1_strain_rate_diag(v, sx, sy, sz, s0, s1, s2);
+        double dj = s0 + s1 + s2;
+        lvol[q] = vol; ltm[q] = tm; ldv[q] = dj * vol;
+        if (!CONSTM) lm[q] = m;
+        if (sl.x >= 0) { ltd[sl.x] = tr[0]; lidx[sl.x] = (unsigned short)q; }
+        if (sl.y >= 0) { ltd[sl.y] = tr[1]; lidx[sl.y] = (unsigned short)q; }
+        if (sl.z >= 0) { ltd[sl.z] = tr[2]; lidx[sl.z] = (unsigned short)q; }
+        if (sl.w >= 0) { ltd[sl.w] = tr[3]; lidx[sl.w] = (unsigned short)q; }
+    }
+    __syncthreads();
+    if (!has_node) return;
+    // the node: sums in CSR order (compute_mass / update_temperature / compute_dvoldt node loops)
+    const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+    const double rho_m = p->bulk_modulus[0] / (pseudo_speed * pseudo_speed);
+    double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0;
+    for (int k = r0; k < r1; ++k) {
+        const int q = lidx[k];
+        const double vol = lvol[q];
+        vn += vol;
+        if (CONSTM) ms += rho_m * vol / 4;
+        else        ms += lm[q];
+        if (thermal) { tms += ltm[q]; tdot += ltd[k]; }
+        acc += ldv[q];
+    }
+    volume_n[n] = vn;
+    tmass[n] = tms;
+    m4.w = ms;
+    vm[n] = m4;
+    d4 x4 = lxt[threadIdx.x];
+    if (thermal) {
+        if (flag & (1u << 5))
+            x4.w = p->surface_temperature;
+        else
+            x4.w -= dt * tdot / tms;
+    }
+    xt_out[n] = x4;
+    ntmp[n] = acc / vn;
+}

@@ -155,7 +155,7 @@ def test_phase_changes_on_the_device_loop_match_the_oracle_loop(in_tmp):
         for name in a:
             if name == "walltime_sec":
                 continue
-            if name.startswith("markerset") or name in ("material", "connectivity", "bcflag"):
+            if name.startswith("markerset") or name in ("material", "connectivity", "bcflag") or a[name].size % 8:
                 assert np.array_equal(a[name], b[name]), (frame, name)
             else:
                 x, y = a[name].view(np.float64), b[name].view(np.float64)
