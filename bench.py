@@ -108,6 +108,8 @@ KERNEL_BYTES = {
     # algorithmic bytes of the two rows it replaces, although it no longer moves the 96 + 96 B
     # per element of force temporaries that figure contains
     "EN3_force_nodes":            (260 + 160, 40 + 160),
+    "EN1_mass_temperature_dvoldt": (224, 64),
+    "EN2_nmd_gather":             (48, 20),
 }
 
 

@@ -90,11 +90,11 @@ struct DevClock {
 enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_NOREC = 16 };
 
 enum KernelId { K_E1, K_N1, K_E2, K_E2R, K_N2, K_E3, K_N3, K_S2, K_S3,
-                K_DTFIN, K_MISC, K_EXCH, K_EN3, K_EN1, K_COUNT };
+                K_DTFIN, K_MISC, K_EXCH, K_EN3, K_EN1, K_EN2, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "E2_return_mapping", "N2_nmd_gather",
     "E3_nmd_force", "N3_force_velocity_coord", "S2_surface_diffusion",
-    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange", "EN3_force_nodes", "EN1_mass_temperature_dvoldt" };
+    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange", "EN3_force_nodes", "EN1_mass_temperature_dvoldt", "EN2_nmd_gather" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
 
@@ -234,6 +234,7 @@ namespace des_hip {
 #include "passes/n3.hpp"
 #include "passes/en3.hpp"
 #include "passes/en1.hpp"
+#include "passes/en2.hpp"
 #include "passes/surface.hpp"
 #include "passes/small_kernels.hpp"
 #include "engine/patch.hpp"

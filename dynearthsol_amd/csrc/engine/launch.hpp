@@ -244,6 +244,19 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
 
 void launch_n2(des_dev *h)
 {
+    static const char *en2 = std::getenv("DES_PATCH_N2");
+    if (h->patch && !(en2 && en2[0] == '0') && h->patch_max_pe <= DES_PATCH_PE) {
+        // the gather over node-block patches (passes/en2.hpp): one etmp2 fetch per patch element
+        Launch l(h, K_EN2);
+        const dim3 grid((h->patch_nb + 7) / 8 * 8);
+        if (h->patch_max_inc <= 1664 && h->patch_max_pe <= 896)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(EN2_nmd_gather<1664, 896>), grid, dim3(256), 0, h->stream, h->nn, h->patch_nb, h->patch_npb,
+                               h->pe_ptr, h->pe_elem, h->pe_slot, h->sup_idx, h->etmp2, h->volume_n, h->ntmp);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(EN2_nmd_gather<DES_PATCH_INC, DES_PATCH_PE>), grid, dim3(256), 0, h->stream, h->nn, h->patch_nb,
+                               h->patch_npb, h->pe_ptr, h->pe_elem, h->pe_slot, h->sup_idx, h->etmp2, h->volume_n, h->ntmp);
+        return;
+    }
     Launch l(h, K_N2);
     // one double per incidence: the lightest gather, best with at most 128 nodes per workgroup
     // even on large meshes (1.1M tets: 22.7 us at 256, 17.6 at 128)
