@@ -339,3 +339,28 @@ def test_random_option_combinations_bit_exact(seed):
     for f in STATE:
         a, b = dev.download(f), ora.download(f)
         assert np.array_equal(a, b), "%s with\\n%s" % (f, ov)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_classic_passes_and_patch_passes_give_the_same_bits(seed, monkeypatch):
+    """The engine's default since round 2 are the node-block patch passes (EN1 / EN2 / EN3,
+    csrc/passes/en*.hpp); the classic pairs (N1, N2, E3 + N3) stay behind DES_PATCH=0 and must keep
+    giving the same bits -- over random option combinations, a multi-step call (EN1 only runs inside
+    one), single steps, and a compute_dt step."""
+    rng = np.random.default_rng(4000 + seed)
+    ov = _random_overrides(rng)
+    kw = dict(cfgs.EVP if seed % 3 else cfgs.EP, nmat=1 + seed % 2, lx=60e3)
+    host = des.Host(cfg_text=cfgs.make(**kw), overrides=ov)
+    engines = []
+    for patch in ("0", "64"):
+        monkeypatch.setenv("DES_PATCH", patch)
+        e = des.DeviceEngine(host)
+        e.init_from_host(host)
+        engines.append(e)
+    for n in (1, 7, 1, 13):                                 # steps 1, 8, 9, 22: crosses 10 and 20
+        sa, sb = engines[0].step(n), engines[1].step(n)
+        assert (sa.dt, sa.steps, sa.n_return_mapping) == (sb.dt, sb.steps, sb.n_return_mapping)
+        assert abs(sa.l2_residual - sb.l2_residual) <= 1e-12 * abs(sa.l2_residual)     # summed over other blocks
+        for f in STATE:
+            a, b = engines[0].download(f), engines[1].download(f)
+            assert np.array_equal(a, b), (ov, n, f)
