@@ -226,6 +226,13 @@ class Host:
             raise KeyError(key)
         return v.value
 
+    def cfg_string(self, key):
+        buf = C.create_string_buffer(512)
+        self._lib.des_host_cfg_string.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+        if self._lib.des_host_cfg_string(self._h, key.encode(), buf, 512):
+            raise KeyError(key)
+        return buf.value.decode()
+
     def cfg_double(self, key):
         v = C.c_double(0)
         if self._lib.des_host_cfg_double(self._h, key.encode(), C.byref(v)):

@@ -28,34 +28,53 @@ int eng_quality(void *h, double sv, double b, double bd, des_quality *q) { retur
 
 int main(int argc, const char *argv[])
 {
-    std::string cfg, mesh;
+    std::string cfg, mesh, remesher = std::getenv("DES_REMESH_CMD") ? std::getenv("DES_REMESH_CMD") : "";
     int device = 0, quiet = 0;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--mesh") && i + 1 < argc) mesh = argv[++i];
+        else if (!std::strcmp(argv[i], "--remesher") && i + 1 < argc) remesher = argv[++i];
         else if (!std::strcmp(argv[i], "--quiet")) quiet = 1;
         else if (!std::strcmp(argv[i], "-h") || !std::strcmp(argv[i], "--help")) { cfg.clear(); break; }
         else cfg = argv[i];
     }
     if (cfg.empty()) {
-        std::fprintf(stderr, "Usage: %s config_file [--device N] [--mesh file.desmesh] [--quiet]\n", argv[0]);
+        std::fprintf(stderr, "Usage: %s config_file [--device N] [--mesh file.desmesh] [--remesher command] [--quiet]\n", argv[0]);
         return 1;                                                   // EXIT_USAGE
     }
     if (des_dev_device_count() <= device) {
         std::fprintf(stderr, "Error: no HIP device %d visible; the time step has no CPU fallback\n", device);
         return DES_ERR_UNSUPPORTED;
     }
-    int err = 0;
-    des_host *host = des_host_create(cfg.c_str(), nullptr, mesh.empty() ? nullptr : mesh.c_str(), &err);
-    if (!host) {
-        std::fprintf(stderr, "%s\n", des_host_last_error());
-        return err ? err : DES_ERR_INTERNAL;
-    }
     const des_engine_api api = { eng_create, eng_destroy, eng_upload, eng_download, eng_field_count,
                                  eng_set_clock, eng_init_geometry, eng_compute_dt, eng_step, eng_check_nan, eng_quality,
                                  des_dev_last_error, eng_set_isostasy, 0 };
-    des_run_stats st;
-    int rc = des_run(host, &api, device, quiet, &st);
-    des_host_destroy(host);
+    // One des_run per mesh: where the reference would call remesh() the loop returns with the state
+    // saved; with a remesher command (include/des_run.h) the run goes on from the remeshed pair.
+    std::string overrides;
+    int rc = 0;
+    for (int round = 0; ; ++round) {
+        int err = 0;
+        des_host *host = des_host_create(cfg.c_str(), overrides.empty() ? nullptr : overrides.c_str(),
+                                         (round == 0 && !mesh.empty()) ? mesh.c_str() : nullptr, &err);
+        if (!host) {
+            std::fprintf(stderr, "%s\n", des_host_last_error());
+            return err ? err : DES_ERR_INTERNAL;
+        }
+        char model[512] = "";
+        des_host_cfg_string(host, "sim.modelname", model, sizeof(model));
+        des_run_stats st;
+        rc = des_run(host, &api, device, quiet, &st);
+        des_host_destroy(host);
+        if (!st.remesh_needed || remesher.empty()) break;
+        const std::string cmd = remesher + " " + model + " " + std::to_string(st.last_frame);
+        if (!quiet) { std::printf("  Remeshing: %s\n", cmd.c_str()); std::fflush(stdout); }
+        if (std::system(cmd.c_str()) != 0) {
+            std::fprintf(stderr, "Error: the remesher command failed: %s\n", cmd.c_str());
+            return DES_ERR_UNSUPPORTED;
+        }
+        overrides = "sim.is_restarting = yes\nsim.restarting_from_modelname = " + std::string(model) +
+                    "\nsim.restarting_from_frame = " + std::to_string(st.last_frame + 1) + "\n";
+    }
     return rc;
 }

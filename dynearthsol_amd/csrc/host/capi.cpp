@@ -95,6 +95,18 @@ int des_host_cfg_double(const des_host *h, const char *key, double *out)
     catch (const des::Error &e) { g_last_error = e.what(); return e.code; }
 }
 
+int des_host_cfg_string(const des_host *h, const char *key, char *out, int cap)
+{
+    try {
+        if (!h->cfg.has(key) || cap < 1) return DES_ERR_CONFIG_VALUE;
+        const std::string v = h->cfg.s(key);
+        if ((int)v.size() >= cap) return DES_ERR_CONFIG_VALUE;
+        std::memcpy(out, v.c_str(), v.size() + 1);
+        return DES_OK;
+    }
+    catch (const des::Error &e) { g_last_error = e.what(); return e.code; }
+}
+
 int des_host_save_mesh(const des_host *h, const char *path)
 {
     try { des::save_mesh_file(path, h->mesh); return DES_OK; }

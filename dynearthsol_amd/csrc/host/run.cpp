@@ -352,6 +352,7 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         st.exit_code = DES_ERR_INTERNAL;
     }
     st.steps = r.sc.steps; st.time = r.sc.time; st.dt = r.sc.dt;
+    st.last_frame = r.out ? des_output_frame(r.out) - 1 : -1;
     if (r.out) des_output_destroy(r.out);
     if (r.eng) api->destroy(r.eng);
     if (stats) *stats = st;

@@ -39,7 +39,8 @@ class EngineApi(C.Structure):
 class RunStats(C.Structure):
     """des_run_stats"""
     _fields_ = [("steps", _ll), ("time", _d), ("dt", _d), ("frames", _i), ("checkpoints", _i),
-                ("exit_code", _i), ("remesh_needed", _i), ("compute_seconds", _d), ("phase_changed_markers", _ll)]
+                ("exit_code", _i), ("remesh_needed", _i), ("compute_seconds", _d), ("phase_changed_markers", _ll),
+                ("last_frame", _i), ("pad_", _i)]
 
 
 def api_from_lib(lib, prefix, create=None):
@@ -83,3 +84,29 @@ def run(host, device=0, quiet=True, api=None):
     if rc != 0 and not st.remesh_needed:
         raise DesError(rc, "des_run stopped")
     return st
+
+
+def run_with_remesher(make_host, remesher, device=0, quiet=True, api=None, max_rounds=100):
+    """The whole-program round trip of include/des_run.h: `make_host(overrides)` builds the Host
+    (overrides = None for the first round, the restart keys afterwards); where the loop stops for a
+    remesh, `remesher(modelname, frame)` must leave the remeshed model as frame + 1 (a callable, or a
+    command string run as `<command> <modelname> <frame>`); the run then restarts from that pair on
+    a new engine.  Returns the list of RunStats, one per mesh."""
+    import subprocess
+    stats = []
+    overrides = None
+    for _ in range(max_rounds):
+        host = make_host(overrides)
+        model = host.cfg_string("sim.modelname")
+        st = run(host, device=device, quiet=quiet, api=api)
+        host.close()
+        stats.append(st)
+        if not st.remesh_needed:
+            return stats
+        if callable(remesher):
+            remesher(model, st.last_frame)
+        else:
+            subprocess.check_call("%s %s %d" % (remesher, model, st.last_frame), shell=True)
+        overrides = ("sim.is_restarting = yes\nsim.restarting_from_modelname = %s\nsim.restarting_from_frame = %d\n"
+                     % (model, st.last_frame + 1))
+    raise DesError(31, "the mesh needed remeshing more than %d times" % max_rounds)

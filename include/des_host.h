@@ -37,6 +37,7 @@ const void *des_host_array(const des_host *h, const char *name, long long *count
 /* typed access to any .cfg option after defaults/normalisation (as strings are parsed) */
 int des_host_cfg_int(const des_host *h, const char *key, int *out);
 int des_host_cfg_double(const des_host *h, const char *key, double *out);
+int des_host_cfg_string(const des_host *h, const char *key, char *out, int cap);
 
 /* write the mesh in the loader's binary format (tools and tests) */
 int des_host_save_mesh(const des_host *h, const char *path);

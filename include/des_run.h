@@ -83,9 +83,20 @@ typedef struct des_run_stats {
     int remesh_needed;          /* bad_mesh_quality's code (1..3) if the run stopped for it   */
     double compute_seconds;     /* wall time inside engine steps                              */
     long long phase_changed_markers;   /* markers whose material phase_changes() moved (phasechanges.cxx:109-152) */
+    int last_frame;             /* number of the last frame written (with remesh_needed: the state to remesh, with its checkpoint) */
+    int pad_;
 } des_run_stats;
 
-/* init() tail + main loop.  Returns stats->exit_code.  `quiet` suppresses the progress lines. */
+/* init() tail + main loop.  Returns stats->exit_code.  `quiet` suppresses the progress lines.
+ *
+ * Remeshing is host work with a mesher the product does not have: where the
+ * reference would call remesh() (remeshing.cxx:2869-3189) the loop writes the state as an exact
+ * frame + checkpoint (stats->last_frame), sets stats->remesh_needed and returns 31.  The callers
+ * (driver/main.cpp --remesher / DES_REMESH_CMD, dynearthsol_amd/driver.py run(remesher=...)) turn
+ * that into a round trip: run `<command> <modelname> <frame>`, which must leave the remeshed model
+ * as frame + 1 (save, chkpt and the .info row, the reference's formats -- the reference binary
+ * itself, restarted from the pair, is such a tool), then restart from it (sim.is_restarting) with
+ * a new engine on the new mesh, and so on until the run ends. */
 int des_run(des_host *host, const des_engine_api *api, int device, int quiet, des_run_stats *stats);
 
 #ifdef __cplusplus

@@ -311,3 +311,41 @@ def test_loop_stops_where_the_reference_would_remesh(in_tmp):
     assert os.path.exists("remesh.save.000004") and os.path.exists("remesh.chkpt.000004")
     info = np.loadtxt("remesh.info").reshape(-1, 8)
     assert info[:, 1].tolist() == [0, 100, 200, 300, 300]
+
+
+REMESH_OV = ("sim.max_steps = 700\nmesh.quality_check_step_interval = 300\nmesh.max_boundary_distortion = 0.00039\n")
+FLATTENER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bottom_flattener.py")
+
+
+def remesh_round_trip(modelname, api):
+    """test-3d-remesh.cfg's run through the remeshing round trip of include/des_run.h, with
+    tests/bottom_flattener.py standing in for the remesher."""
+    import sys
+    mesh = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test-3d.desmesh")
+    text = "\n".join(l for l in cfgs.TEST3D.splitlines()
+                     if not l.startswith(("max_time_in_yr", "output_time_interval_in_yr")))
+
+    def make_host(extra):
+        return des.Host(cfg_text=text, overrides=REMESH_OV + "sim.modelname = %s\n" % modelname + (extra or ""),
+                        mesh_file=None if extra else mesh)
+    return driver.run_with_remesher(make_host, "%s %s" % (sys.executable, FLATTENER), api=api)
+
+
+def test_remeshing_round_trip_through_an_external_remesher(in_tmp):
+    """SURVEY.md 8 f4: where the reference would call remesh() the loop saves the state and returns;
+    the caller runs the remesher on that frame + checkpoint pair and restarts from the pair it leaves
+    (new engine, new mesh arrays, clock / frame numbering / .info continued).  Here over the oracle."""
+    stats = remesh_round_trip("rt", oracle_api())
+    assert [(s.steps, s.remesh_needed, s.exit_code, s.last_frame) for s in stats] == [(300, 2, 31, 4), (700, 0, 0, 9)]
+    info = np.loadtxt("rt.info").reshape(-1, 8)
+    assert info[:, 0].tolist() == list(range(10)) and info[:, 1].tolist() == [0, 100, 200, 300, 300, 300, 400, 500, 600, 700]
+    before, after = read_frame("rt.save.000004"), read_frame("rt.save.000005")
+    flag = before["bcflag"].view(np.uint32)
+    zb, za = as_f64(before["coordinate"], -1, 3)[:, 2], as_f64(after["coordinate"], -1, 3)[:, 2]
+    bottom = (flag & 16) != 0
+    assert np.abs(zb[bottom] + 10e3).max() > 0.39 and np.abs(za[bottom] + 10e3).max() == 0      # the repair
+    assert np.array_equal(zb[~bottom], za[~bottom])
+    assert np.array_equal(before["stress"], after["stress"])                                    # fields carried over
+    # the run went on from the repaired state: time keeps counting, the state keeps evolving
+    last = read_frame("rt.save.000009")
+    assert not np.array_equal(last["stress"], after["stress"])

@@ -160,3 +160,35 @@ def test_phase_changes_on_the_device_loop_match_the_oracle_loop(in_tmp):
             else:
                 x, y = a[name].view(np.float64), b[name].view(np.float64)
                 assert np.abs(x - y).max() <= 1e-10 * max(np.abs(y).max(), 1e-300), (frame, name)
+
+
+def test_remeshing_round_trip_on_the_device_matches_the_oracle_loop(in_tmp):
+    """The same round trip (tests/test_driver_output.py) with the HIP engine: the device run stops at
+    the same step for the same reason, hands the same state to the remesher, and after the restart on
+    a NEW engine continues to the same frames as the oracle loop, bit for bit (elasto-plastic)."""
+    from test_driver_output import remesh_round_trip
+    sd = remesh_round_trip("gpu", None)
+    so = remesh_round_trip("cpu", oracle_api())
+    assert [(s.steps, s.remesh_needed, s.exit_code, s.last_frame) for s in sd] == \
+           [(s.steps, s.remesh_needed, s.exit_code, s.last_frame) for s in so] == [(300, 2, 31, 4), (700, 0, 0, 9)]
+    for frame in range(10):
+        a, b = read_frame("gpu.save.%06d" % frame), read_frame("cpu.save.%06d" % frame)
+        for name in a:
+            if name != "walltime_sec":
+                assert np.array_equal(a[name], b[name]), (frame, name)
+
+
+def test_executable_takes_a_remesher_command(in_tmp):
+    import sys
+    from test_driver_output import REMESH_OV, FLATTENER
+    text = "\n".join(l for l in cfgs.TEST3D.splitlines()
+                     if not l.startswith(("max_time_in_yr", "output_time_interval_in_yr")))
+    with open("model.cfg", "w") as f:
+        f.write(cfgs.apply_overrides(text, REMESH_OV + "sim.modelname = exe\n"))
+    mesh = os.path.join(des.REPO_ROOT, "tests", "golden", "test-3d.desmesh")
+    out = subprocess.run([EXE, "model.cfg", "--mesh", mesh, "--remesher", "%s %s" % (sys.executable, FLATTENER)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Remeshing:" in out.stdout and "bottom_flattener" in out.stdout and out.stdout.count("Ending simulation.") == 1
+    info = np.loadtxt("exe.info").reshape(-1, 8)
+    assert info[-1, 1] == 700 and len(info) == 10
