@@ -37,6 +37,7 @@ class DesParams(C.Structure):
         ("friction_angle0", _dbl_mat), ("friction_angle1", _dbl_mat),
         ("dilation_angle0", _dbl_mat), ("dilation_angle1", _dbl_mat), ("porosity", _dbl_mat),
         ("max_vbc_val", C.c_double), ("compensation_pressure", C.c_double),
+        ("has_PT", C.c_int), ("PT_max_iter", C.c_int), ("PT_relative_tolerance", C.c_double),
     ]
 
 
@@ -76,7 +77,7 @@ class DesScalars(C.Structure):
         ("dt", C.c_double), ("time", C.c_double), ("l2_residual", C.c_double),
         ("max_surf_vel", C.c_double), ("max_global_vel_mag", C.c_double),
         ("global_dt_min", C.c_double), ("steps", C.c_longlong), ("status", C.c_int), ("n_return_mapping", C.c_int),
-        ("avg_time0", C.c_double),
+        ("avg_time0", C.c_double), ("n_pt_iterations", C.c_longlong),
     ]
 
 

@@ -81,6 +81,8 @@ struct DevClock {
     long long steps;
     int status;
     int iso;                 // inside isostasy_adjustment (des_dev_set_isostasy)
+    int pt;                  // inside the pseudo-transient loop of a step (Param::control.PT_jump)
+    int pad2;
     double avg_time0;        // Output::time0 (output.cxx:332)
     int n_defer;             // elements the first stress pass of this step handed to E2_return_mapping
     int pad;
@@ -216,6 +218,8 @@ struct des_dev {
     bool pending_c;                       // C part of the last step has been run (always true outside step())
     long long steps_host;
     bool iso;                 // des_dev_set_isostasy
+    long long n_pt_iterations; // pseudo-transient iterations of the current des_dev_step call
+    bool in_pt;                // host side of DevClock::pt
     // profiling
     bool prof;
     std::vector<ProfRec> prof_recs;
@@ -404,7 +408,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     {
         const char *env = std::getenv("DES_PATCH");
         h->patch = false;
-        if (!(env && env[0] == '0')) {
+        if (!(env && env[0] == '0') && !params->has_PT) {      // (the PT loop re-enters the passes mid-step: classic pairs)
             PatchLists P;
             // DES_PATCH=<n>: n nodes per block; default: the largest of 64, 56, 48, 40, 32 whose biggest
             // block fits the three-workgroups-per-CU LDS shapes of both patch kernels (valence-32 nodes of
@@ -777,7 +781,7 @@ int des_dev_init_geometry(des_dev *h)
     // apply_vbcs (dynearthsol.cxx:192) on every local node: a purely nodal operation that
     // gives halo nodes the same values their owners compute
     hipLaunchKernelGGL(k_apply_vbcs, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->nn,
-                       h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm);
+                       h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm, (d4 *)nullptr);
     // compute_mass (dynearthsol.cxx:194)
     launch_mass_gather(h);
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -814,9 +818,11 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     // DES_GRAPH=1: the launches of an interior step of a single-GPU call are replayed from a
     // hipGraph captured once (two graphs: with and without the compute_dt variant of E1)
     const bool graphs = h->use_graph && !multi && !iso && !h->prof && !h->p.is_outputting_averaged_fields
-                        && !h->patch;          // EN3 swaps the two coordinate buffers every step: nothing to replay
+                        && !h->patch           // EN3 swaps the two coordinate buffers every step: nothing to replay
+                        && !h->p.has_PT;
     const long long qcsi = h->p.quality_check_step_interval;
     int rc;
+    h->n_pt_iterations = 0;
     for (int i = 0; i < nsteps; ++i) {
         const long long step_no = iso ? h->steps_host : ++h->steps_host;
         if (i == 0) launch_e1<MODE_A>(h);
@@ -846,6 +852,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         launch_e2(h);
         if (nmd) launch_n2(h);
         launch_force_pass(h);
+        if (h->p.has_PT && !iso && (rc = pt_loop(h))) return rc;
         launch_s2(h, step_no);
         const bool last = (i == nsteps - 1);
         const bool overlapped = multi && h->overlap && !iso && h->e_int1 > h->e_int0;
@@ -902,6 +909,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         }
         out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min;
         out->steps = c.steps; out->status = c.status; out->n_return_mapping = c.n_defer; out->avg_time0 = c.avg_time0;
+        out->n_pt_iterations = h->n_pt_iterations;
         return c.status;
     }
     return DES_OK;
@@ -911,6 +919,10 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
 int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
 {
     if (!h || !halo) return DES_ERR_INTERNAL;
+    if (h->p.has_PT && (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn)) {
+        g_last_error = "control.has_PT on a decomposed mesh: the loop's residual test is global";
+        return DES_ERR_UNSUPPORTED;
+    }
     if (halo->owned_begin < 0 || halo->owned_end > h->nn || halo->owned_begin >= halo->owned_end) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     h->o0 = halo->owned_begin; h->o1 = halo->owned_end; h->nn_global = nnode_global;

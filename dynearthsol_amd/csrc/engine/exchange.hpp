@@ -76,3 +76,52 @@ int sync_clock(des_dev *h)
     HIP_OK(hipStreamSynchronize(h->stream));
     return DES_OK;
 }
+
+// The pseudo-transient loop of a step (dynearthsol.cxx:803-864), entered after the force pass has
+// left velocities and the residual partials (N3 stops there when has_PT): per iteration
+// apply_vbcs (boundaries at rest) + update_coordinate, update_mesh without surface processes,
+// strain rate, dvoldt / edvoldt, update_stress, update_force, update_velocity, residual -- i.e. the
+// passes of a step under DevClock::pt (no clock, no temperature update, no NMD, no rotate_stress) --
+// until the relative change of the residual drops below the tolerance.  The host joins the stream
+// once per iteration to take that decision, as the reference's loop does; afterwards the real
+// apply_vbcs + update_coordinate of the step follow.  Single domain only (des_dev_set_halo refuses).
+int set_pt(des_dev *h, int on)
+{
+    static const int vals[2] = {0, 1};
+    h->in_pt = on != 0;
+    HIP_OK(hipMemcpyAsync(&h->d_clk->pt, &vals[on ? 1 : 0], sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return DES_OK;
+}
+
+void launch_vbcs_coord(des_dev *h)
+{
+    hipLaunchKernelGGL(k_apply_vbcs, dim3(nblk(h->nn)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->nn,
+                       h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm, h->xt);
+}
+
+int pt_loop(des_dev *h)
+{
+    int rc;
+    launch_s3(h, false, false, true);                      // l2 of the step's own update_force
+    if ((rc = sync_clock(h))) return rc;
+    double residual_old = h->h_clk->l2_residual;
+    if ((rc = set_pt(h, 1))) return rc;
+    for (int pt_step = 0; pt_step < h->p.PT_max_iter; ++pt_step) {
+        launch_vbcs_coord(h);
+        launch_e1<MODE_C | MODE_A>(h);
+        launch_n1(h);
+        launch_e2(h);
+        launch_e3(h);
+        launch_n3(h);
+        launch_s3(h, false, false, true);
+        if ((rc = sync_clock(h))) return rc;
+        ++h->n_pt_iterations;
+        const double l2 = h->h_clk->l2_residual;
+        const double relative_change = std::fabs((l2 - residual_old) / residual_old);
+        if (relative_change < h->p.PT_relative_tolerance) break;
+        residual_old = l2;
+    }
+    if ((rc = set_pt(h, 0))) return rc;
+    launch_vbcs_coord(h);                                  // apply_vbcs + update_coordinate of the step itself
+    return DES_OK;
+}

@@ -273,7 +273,7 @@ void launch_e3(des_dev *h, int e_begin = 0, int e_count = -1, bool facets = true
     if (nbe8 + nbf == 0) return;
     Launch l(h, K_E3);
     hipLaunchKernelGGL(E3_nmd_force, dim3(nbe8 + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p,
-                       (int)(h->p.is_using_mixed_stress && !h->iso), h->ne, e_begin, e_count,
+                       (int)(h->p.is_using_mixed_stress && !h->iso && !h->in_pt), h->ne, e_begin, e_count,
                        nblk(e_count), nbe8,
                        h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->dpressure, h->stress, h->ftmp,
                        facets ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp);

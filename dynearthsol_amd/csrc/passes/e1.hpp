@@ -90,7 +90,7 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         } else if (MODE & MODE_C) {
             const double vol_prev = volume[e];
             vol = desk::tet_volume(c);
-            if (!(MODE & MODE_INIT) && topflag[e]) {
+            if (!(MODE & MODE_INIT) && topflag[e] && !clk->pt) {     // (no surface processes inside the PT loop)
                 // correct_surface_element (bc.cxx:1670-1687) runs before the swap: it already
                 // stored the new volume, so the swap moves the NEW volume into volume_old
                 rdv = vol / vol_prev;
@@ -115,7 +115,7 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
 
         if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
             const bool rescale = rdv >= 1.0;                         // bc.cxx:1677
-            const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0 && !clk->iso;   // not in the isostasy loop
+            const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0 && !clk->iso && !clk->pt;   // not in the isostasy / PT loops
             // NMD_stress' increment of the diagonal (geometry.cxx:316-331), left here by EN3 -- the
             // operation E3 would have done in place, before anything else touches the stress
             double dd = 0.0;

@@ -29,7 +29,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     const int n = (threadIdx.x < npb) ? n0 + threadIdx.x : nn;
     const double dt = clk->dt;
     if (FULL && blockIdx.x == 0 && threadIdx.x == 0) {
-        if (!clk->iso) {                                   // the isostasy loop does not advance the clock
+        if (!clk->iso && !clk->pt) {                       // the isostasy and PT loops do not advance the clock
             clk->steps += 1;
             clk->time += dt;
         }
@@ -122,7 +122,7 @@ N1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restric
     m4.w = ms;
     vm[n] = m4;
     if (FULL) {
-        if (thermal && !clk->iso) {                        // the isostasy loop has no update_temperature
+        if (thermal && !clk->iso && !clk->pt) {            // the isostasy / PT loops have no update_temperature
             d4 x4 = xt[n];
             if (bcflag[n] & (1u << 5))
                 x4.w = p->surface_temperature;

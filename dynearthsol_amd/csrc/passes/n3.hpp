@@ -4,14 +4,16 @@
 
 // ---- N3 --------------------------------------------------------------------------
 // apply_vbcs for one node (bc.cxx:400-651, THREED)
+// hold: Param::control.PT_jump -- inside the pseudo-transient loop the x / y / z boundaries are held
+// at rest (bc.cxx:330-343: bc_vx0 .. bc_vz1 = 0; the lateral _l values are not touched)
 __device__ __forceinline__ void apply_vbcs_node(const des_params *p, unsigned flag, double time,
                                                 const double *bnormals, const double *edge_vec,
-                                                const int *edge_slot, double v[3])
+                                                const int *edge_slot, double v[3], bool hold = false)
 {
     for (int lf = 0; lf < 4; ++lf) {
         if (!(flag & (1u << lf))) continue;
         const int ni = (lf < 2) ? 0 : 1, li = (lf < 2) ? 1 : 0;
-        const double val = p->vbc_values[lf], val_l = p->vbc_val_l[lf];
+        const double val = hold ? 0.0 : p->vbc_values[lf], val_l = p->vbc_val_l[lf];
         switch (p->vbc_types[lf]) {
         case 0: break;
         case 1: v[ni] = val; break;
@@ -69,7 +71,7 @@ __device__ __forceinline__ void apply_vbcs_node(const des_params *p, unsigned fl
     int bc_z0 = p->vbc_types[4], bc_z1 = p->vbc_types[5];
     if (time > p->vbc_val_z1_loading_period) bc_z1 = 0;
     if (bc_z0 == 0 && bc_z1 == 0) return;
-    const double bc_vz0 = p->vbc_values[4], bc_vz1 = p->vbc_values[5];
+    const double bc_vz0 = hold ? 0.0 : p->vbc_values[4], bc_vz1 = hold ? 0.0 : p->vbc_values[5];
     if (flag & (1u << 4)) {
         switch (bc_z0) {
         case 1: v[2] = bc_vz0; break;
@@ -87,20 +89,31 @@ __device__ __forceinline__ void apply_vbcs_node(const des_params *p, unsigned fl
     }
 }
 
+// xt != NULL: followed by update_coordinate (fields.cxx:761-784) -- the two nodal operations that
+// N3 leaves out when the pseudo-transient loop sits between update_velocity and them
 __global__ void __launch_bounds__(DES_BLOCK)
 k_apply_vbcs(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nn,
              const unsigned *__restrict__ bcflag, const double *__restrict__ bnormals,
-             const double *__restrict__ edge_vec, const int *__restrict__ edge_slot, d4 *__restrict__ vm)
+             const double *__restrict__ edge_vec, const int *__restrict__ edge_slot, d4 *__restrict__ vm,
+             d4 *__restrict__ xt)
 {
     const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (n >= nn) return;
     const unsigned flag = bcflag[n];
-    if (!(flag & 0x3ffu)) return;
+    if (!xt && !(flag & 0x3ffu)) return;
     d4 m4 = vm[n];
     double v[3] = {m4.x, m4.y, m4.z};
-    apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v);
-    m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
-    vm[n] = m4;
+    if (flag & 0x3ffu) {
+        apply_vbcs_node(p, flag, clk->time, bnormals, edge_vec, edge_slot, v, clk->pt != 0);
+        m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
+        vm[n] = m4;
+    }
+    if (xt && p->has_moving_mesh) {
+        const double dt = clk->dt;
+        d4 x4 = xt[n];
+        x4.x += v[0] * dt; x4.y += v[1] * dt; x4.z += v[2] * dt;
+        xt[n] = x4;
+    }
 }
 
 // What follows the force sums of a node, shared by N3 and EN3: apply_stress_bcs node loop
@@ -178,6 +191,13 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
         l2 = fr[0]*fr[0] / num;
         l2 += fr[1]*fr[1] / num;
         l2 += fr[2]*fr[2] / num;
+    }
+    if (p->has_PT) {
+        // the pseudo-transient loop comes between update_velocity / the residual and apply_vbcs /
+        // update_coordinate (dynearthsol.cxx:798-872): those two follow in k_apply_vbcs
+        m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
+        vm[n] = m4;
+        return l2;
     }
     if (clk->iso) {
         // isostasy_adjustment (dynearthsol.cxx:521-535): no velocity bcs, vertical motion only,

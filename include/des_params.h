@@ -108,6 +108,11 @@ typedef struct des_params {
     /* run constants derived once by the driver */
     double max_vbc_val;             /* Variables::max_vbc_val   (dynearthsol.cxx:55-59)            */
     double compensation_pressure;   /* Variables::compensation_pressure (ic.cxx:361)               */
+
+    /* control.has_PT: the pseudo-transient loop inside a step (dynearthsol.cxx:803-864) */
+    int has_PT;
+    int PT_max_iter;
+    double PT_relative_tolerance;
 } des_params;
 
 /* Mesh topology as the reference builds it once per (re)mesh (mesh.cxx:2837-3329,
@@ -229,6 +234,7 @@ typedef struct des_scalars {
     int n_return_mapping;           /* local elements past the yield pre-filter (rheology.cxx:354-361) in
                                      * the last step, i.e. through dsyevh3 + the return mapping       */
     double avg_time0;               /* Output::time0: time at the first step of the averaging interval */
+    long long n_pt_iterations;      /* iterations of the pseudo-transient loop taken by the steps of this call */
 } des_scalars;
 
 /* Reductions behind bad_mesh_quality (remeshing.cxx:2752-2866), so the driver can take the

@@ -64,6 +64,8 @@ struct des_oracle {
     des_params p;
     int nn, ne;
     int iso = 0;                        // inside isostasy_adjustment (dynearthsol.cxx:496-544)
+    bool pt_jump = false;               // Param::control.PT_jump while the pseudo-transient loop runs
+    long long n_pt_iterations = 0;      // iterations taken since the last des_oracle_step call began
     int n_return_mapping = 0;           // elements past the yield pre-filter in the last update_stress
     // topology
     ivec conn;                          // [4][ne]
@@ -1223,15 +1225,16 @@ void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
     // nodes the owner's values); inside a step only owned nodes are touched
     const int vb0 = all_local_nodes ? 0 : o.c0, vb1 = all_local_nodes ? nn : o.c1;
     int bc_z0 = p.vbc_types[4], bc_z1 = p.vbc_types[5];
-    const double bc_vz0 = p.vbc_values[4], bc_vz1 = p.vbc_values[5];
+    // PT_jump: the boundaries are held at rest inside the pseudo-transient loop (bc.cxx:330-343)
+    const double bc_vz0 = o.pt_jump ? 0.0 : p.vbc_values[4], bc_vz1 = o.pt_jump ? 0.0 : p.vbc_values[5];
     if (o.time > p.vbc_val_z1_loading_period) bc_z1 = 0;
 
     struct LateralFace { unsigned mask; int ni; int li; int type; double val; double val_l; };
     const LateralFace lateral_faces[] = {
-        {1u << 0, 0, 1, p.vbc_types[0], p.vbc_values[0], p.vbc_val_l[0]},
-        {1u << 1, 0, 1, p.vbc_types[1], p.vbc_values[1], p.vbc_val_l[1]},
-        {1u << 2, 1, 0, p.vbc_types[2], p.vbc_values[2], p.vbc_val_l[2]},
-        {1u << 3, 1, 0, p.vbc_types[3], p.vbc_values[3], p.vbc_val_l[3]},
+        {1u << 0, 0, 1, p.vbc_types[0], o.pt_jump ? 0.0 : p.vbc_values[0], p.vbc_val_l[0]},
+        {1u << 1, 0, 1, p.vbc_types[1], o.pt_jump ? 0.0 : p.vbc_values[1], p.vbc_val_l[1]},
+        {1u << 2, 1, 0, p.vbc_types[2], o.pt_jump ? 0.0 : p.vbc_values[2], p.vbc_val_l[2]},
+        {1u << 3, 1, 0, p.vbc_types[3], o.pt_jump ? 0.0 : p.vbc_values[3], p.vbc_val_l[3]},
     };
 
     #pragma omp parallel for
@@ -1706,6 +1709,39 @@ int isostasy_phase(des_oracle &o, int phase)
     return 0;
 }
 
+// The pseudo-transient loop of a step (dynearthsol.cxx:803-864): the quasi-static part of the step
+// repeated with the boundaries at rest (PT_jump: bc.cxx:330-343) and without surface processes
+// (update_mesh, dynearthsol.cxx:456-461) until the residual stops changing.  Not restated: the
+// mesh-quality check inside the loop (:839-859), which can only end in remesh().
+void pt_loop(des_oracle &o)
+{
+    const des_params &p = o.p;
+    double residual_old = o.l2_residual;
+    o.pt_jump = true;
+    for (int pt_step = 0; pt_step < p.PT_max_iter; ++pt_step) {
+        apply_vbcs(o);
+        if (p.has_moving_mesh) {
+            update_coordinate(o);                  // update_mesh with PT_jump: no surface_processes
+            o.volume.swap(o.volume_old);
+            compute_volume(o, o.volume);
+            refresh_elem_cache(o);
+            compute_mass(o);
+        }
+        update_strain_rate(o);
+        compute_dvoldt(o);
+        compute_edvoldt(o);
+        update_stress(o);
+        update_force(o);
+        update_velocity(o);
+        o.l2_residual = calculate_residual_force(o);
+        ++o.n_pt_iterations;
+        double relative_change = std::fabs((o.l2_residual - residual_old) / residual_old);
+        if (relative_change < p.PT_relative_tolerance) break;
+        residual_old = o.l2_residual;
+    }
+    o.pt_jump = false;
+}
+
 int step_phase(des_oracle &o, int phase)
 {
     const des_params &p = o.p;
@@ -1728,6 +1764,7 @@ int step_phase(des_oracle &o, int phase)
         update_force(o);
         update_velocity(o);
         o.l2_residual = calculate_residual_force(o);
+        if (p.has_PT) pt_loop(o);
         apply_vbcs(o);
         if (p.has_moving_mesh) {
             update_coordinate(o);
@@ -1922,6 +1959,7 @@ int des_oracle_compute_dt(des_oracle *h, double *dt)
 
 int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out)
 {
+    h->n_pt_iterations = 0;
     for (int i = 0; i < nsteps; ++i)
         one_step(*h);
     if (out) {
@@ -1929,6 +1967,7 @@ int des_oracle_step(des_oracle *h, int nsteps, des_scalars *out)
         out->max_surf_vel = h->max_surf_vel; out->max_global_vel_mag = h->max_global_vel_mag;
         out->global_dt_min = h->global_dt_min; out->steps = h->steps; out->status = h->status;
         out->n_return_mapping = h->n_return_mapping; out->avg_time0 = h->avg_time0;
+        out->n_pt_iterations = h->n_pt_iterations;
     }
     return h->status;
 }
@@ -1977,6 +2016,7 @@ int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, d
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global)
 {
     if (owned_begin < 0 || owned_end > h->nn || owned_begin > owned_end) return DES_ERR_INTERNAL;
+    if (h->p.has_PT && (owned_begin > 0 || owned_end < h->nn)) return DES_ERR_UNSUPPORTED;   // the loop's residual is global
     h->o0 = owned_begin; h->o1 = owned_end; h->nn_global = nnode_global;
     return DES_OK;
 }

@@ -364,3 +364,21 @@ def test_classic_passes_and_patch_passes_give_the_same_bits(seed, monkeypatch):
         for f in STATE:
             a, b = engines[0].download(f), engines[1].download(f)
             assert np.array_equal(a, b), (ov, n, f)
+
+
+@pytest.mark.parametrize("tol,moving", [("1e-2", "yes"), ("1e-4", "yes"), ("1e-4", "no")])
+def test_pseudo_transient_loop_bit_exact(tol, moving):
+    """control.has_PT (dynearthsol.cxx:803-864): inside every step the quasi-static part is iterated
+    with the boundaries at rest until the residual settles.  Same number of iterations, same bits
+    (elasto-plastic: no libm on the path), residual to the rounding of its tree sum."""
+    ov = ("control.has_PT = yes\ncontrol.PT_max_iter = 40\ncontrol.PT_relative_tolerance = %s\n"
+          "control.has_moving_mesh = %s\n" % (tol, moving))
+    host, dev, ora = pair(cfgs.EP, overrides=ov)
+    total = 0
+    for n in (1, 4, 8):                                     # crosses step 10 (compute_dt)
+        sd, so = dev.step(n), ora.step(n)
+        assert sd.n_pt_iterations == so.n_pt_iterations > 0 and (sd.dt, sd.steps) == (so.dt, so.steps)
+        assert abs(sd.l2_residual - so.l2_residual) <= 1e-12 * so.l2_residual
+        total += so.n_pt_iterations
+        assert_bit_exact(dev, ora)
+    assert total >= (13 if tol == "1e-2" else 30)

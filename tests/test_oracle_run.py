@@ -98,3 +98,33 @@ def test_average_fields_follow_the_reference_schedule():
         assert np.array_equal(ora.download("STRESS_AVG"), acc)
         assert sc.avg_time0 == t0
         assert np.array_equal(ora.download("COORD_AVG0"), c0) and np.array_equal(ora.download("STRAIN0"), e0)
+
+
+def test_pseudo_transient_loop_of_the_restatement():
+    """control.has_PT (dynearthsol.cxx:803-864) in the oracle: with no iteration allowed the step is
+    the plain one; a huge tolerance stops after exactly one iteration per step; a tight one iterates
+    until the residual's relative change is below it (never past PT_max_iter); the clock and the
+    temperature do not move inside the loop."""
+    import cfgs
+    import dynearthsol_amd as des
+    from oracle_binding import OracleEngine
+    base = "control.has_PT = yes\ncontrol.PT_max_iter = %d\ncontrol.PT_relative_tolerance = %s\n"
+
+    def run(ov, n=6):
+        host = des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=ov)
+        o = OracleEngine(host)
+        o.init_from_host(host)
+        sc = o.step(n)
+        return sc, {f: o.download(f) for f in ("COORD", "VEL", "STRESS", "TEMPERATURE")}
+
+    plain, fp = run(None)
+    none, f0 = run(base % (0, "1e-6"))
+    assert none.n_pt_iterations == 0 and (none.time, none.steps) == (plain.time, plain.steps)
+    assert all(np.array_equal(fp[k], f0[k]) for k in fp)
+    one, f1 = run(base % (50, "1e30"))
+    assert one.n_pt_iterations == 6 and (one.time, one.steps) == (plain.time, plain.steps)
+    assert np.array_equal(f1["TEMPERATURE"], fp["TEMPERATURE"]) and not np.array_equal(f1["STRESS"], fp["STRESS"])
+    many, _ = run(base % (7, "1e-12"))
+    assert many.n_pt_iterations == 6 * 7                   # the cap
+    some, _ = run(base % (500, "1e-3"))
+    assert 6 <= some.n_pt_iterations < 6 * 500
