@@ -195,12 +195,19 @@ class Host:
     """Host-side model: parsed ``.cfg``, mesh topology and initial fields
     (get_input_parameters + init(), input.cxx:1503 / dynearthsol.cxx:159-228)."""
 
-    def __init__(self, cfg_path=None, cfg_text=None, overrides=None, mesh_file=None):
+    def __init__(self, cfg_path=None, cfg_text=None, overrides=None, mesh_file=None, ndims=3):
+        """ndims: which build of the reference this host stands for (3: tets, 2: triangles)."""
         lib = load_host_lib()
         err = C.c_int(0)
         ov = overrides.encode() if overrides else None
         mf = mesh_file.encode() if mesh_file else None
-        if cfg_path is not None:
+        self.ndims = ndims
+        if ndims != 3:
+            lib.des_host_create_nd.restype = C.c_void_p
+            lib.des_host_create_nd.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+            h = lib.des_host_create_nd(ndims, cfg_path.encode() if cfg_path is not None else None,
+                                       None if cfg_path is not None else (cfg_text or "").encode(), ov, mf, C.byref(err))
+        elif cfg_path is not None:
             h = lib.des_host_create(cfg_path.encode(), ov, mf, C.byref(err))
         else:
             h = lib.des_host_create_from_string((cfg_text or "").encode(), ov, mf, C.byref(err))
@@ -383,6 +390,8 @@ class EngineBase:
         self.upload("STRAIN", host.array("strain"))
         self.upload("PLSTRAIN", host.array("plstrain"))
         self.upload("VISCOSITY", host.array("viscosity"))
+        if getattr(host, "ndims", 3) == 2:
+            self.upload("STRESSYY", host.array("stressyy"))
         return self.compute_dt()
 
 

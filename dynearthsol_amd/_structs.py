@@ -4,6 +4,7 @@ import ctypes as C
 DES_MAX_MAT = 16
 DES_NBDRY = 10
 DES_NBDRY_SIDE = 6
+DES_MAX_PERIOD = 8
 
 _dbl_mat = C.c_double * DES_MAX_MAT
 
@@ -38,6 +39,15 @@ class DesParams(C.Structure):
         ("dilation_angle0", _dbl_mat), ("dilation_angle1", _dbl_mat), ("porosity", _dbl_mat),
         ("max_vbc_val", C.c_double), ("compensation_pressure", C.c_double),
         ("has_PT", C.c_int), ("PT_max_iter", C.c_int), ("PT_relative_tolerance", C.c_double),
+        # read by the 2-D build only
+        ("is_plane_strain", C.c_int), ("mattype_oceanic_crust", C.c_int),
+        ("num_vbc_period_x0", C.c_int), ("num_vbc_period_x1", C.c_int),
+        ("vbc_period_x0_time_in_yr", C.c_double * DES_MAX_PERIOD), ("vbc_period_x0_ratio", C.c_double * DES_MAX_PERIOD),
+        ("vbc_period_x1_time_in_yr", C.c_double * DES_MAX_PERIOD), ("vbc_period_x1_ratio", C.c_double * DES_MAX_PERIOD),
+        ("vbc_vertical_div_x0", C.c_double * 4), ("vbc_vertical_div_x1", C.c_double * 4),
+        ("vbc_vertical_ratio_x0", C.c_double * 4), ("vbc_vertical_ratio_x1", C.c_double * 4),
+        ("bottom_shear_zone_thickness", C.c_double),
+        ("surf_diff_ratio_terrig", C.c_double), ("surf_diff_ratio_marine", C.c_double),
     ]
 
 
@@ -85,6 +95,6 @@ class DesScalars(C.Structure):
 FIELDS = ["COORD", "VEL", "FORCE", "FORCE_RESIDUAL", "COORD0", "TEMPERATURE", "VOLUME_N", "MASS",
           "TMASS", "DHACC", "STRESS", "STRAIN", "STRAIN_RATE", "PLSTRAIN", "DELTA_PLSTRAIN",
           "VISCOSITY", "VOLUME", "VOLUME_OLD", "DPRESSURE", "EDVOLDT", "RADIOGENIC", "ELEMMARKERS",
-          "EDVACC_SURF", "DH", "NTMP", "STRESS_AVG", "DPLSTRAIN_AVG", "STRAIN0", "COORD_AVG0"]
+          "EDVACC_SURF", "DH", "NTMP", "STRESS_AVG", "DPLSTRAIN_AVG", "STRAIN0", "COORD_AVG0", "STRESSYY"]
 F = {name: i for i, name in enumerate(FIELDS)}
 INT_FIELDS = {"ELEMMARKERS"}

@@ -8,7 +8,7 @@
 namespace {
 thread_local std::string g_last_error;
 
-des_host *create_impl(const char *path, const char *text, const char *overrides,
+des_host *create_impl(int ndims, const char *path, const char *text, const char *overrides,
                       const char *mesh_file, int *err)
 {
     des_host *h = new des_host();
@@ -16,7 +16,10 @@ des_host *create_impl(const char *path, const char *text, const char *overrides,
         std::string ov = overrides ? overrides : "";
         if (path) h->cfg.load(path, ov);
         else      h->cfg.load_string(text ? text : "", ov);
-        des::build_params(h->cfg, h->params);
+        des::build_params(h->cfg, h->params, ndims);
+        h->mesh.nd = ndims;
+        if (ndims == 2 && h->cfg.b("sim.is_restarting"))
+            throw des::Error(31, "sim.is_restarting: restart files are read by the 3-D host only");
         if (h->cfg.b("sim.is_restarting")) {
             des::restart_from_files(h->cfg, h->params, h->mesh, h->fields);
             des::build_topology(h->mesh, h->params.vbc_types);
@@ -44,12 +47,18 @@ extern "C" {
 
 des_host *des_host_create(const char *cfg_path, const char *overrides, const char *mesh_file, int *err)
 {
-    return create_impl(cfg_path, nullptr, overrides, mesh_file, err);
+    return create_impl(3, cfg_path, nullptr, overrides, mesh_file, err);
 }
 
 des_host *des_host_create_from_string(const char *cfg_text, const char *overrides, const char *mesh_file, int *err)
 {
-    return create_impl(nullptr, cfg_text, overrides, mesh_file, err);
+    return create_impl(3, nullptr, cfg_text, overrides, mesh_file, err);
+}
+
+des_host *des_host_create_nd(int ndims, const char *cfg_path, const char *cfg_text, const char *overrides,
+                             const char *mesh_file, int *err)
+{
+    return create_impl(ndims, cfg_path, cfg_path ? nullptr : cfg_text, overrides, mesh_file, err);
 }
 
 void des_host_destroy(des_host *h) { delete h; }
@@ -71,6 +80,7 @@ const void *des_host_array(const des_host *h, const char *name, long long *count
         {"strain", h->fields.strain.data(), (long long)h->fields.strain.size()},
         {"plstrain", h->fields.plstrain.data(), (long long)h->fields.plstrain.size()},
         {"viscosity", h->fields.viscosity.data(), (long long)h->fields.viscosity.size()},
+        {"stressyy", h->fields.stressyy.data(), (long long)h->fields.stressyy.size()},
         {"elemmarkers", h->fields.elemmarkers.data(), (long long)h->fields.elemmarkers.size()},
         {"markerset.eta", h->fields.markers.eta.data(), (long long)h->fields.markers.eta.size()},
         {"markerset.elem", h->fields.markers.elem.data(), (long long)h->fields.markers.elem.size()},

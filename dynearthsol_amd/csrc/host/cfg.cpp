@@ -236,10 +236,11 @@ static double find_max_vbc(const Config &c)
     return m;
 }
 
-void build_params(const Config &c, des_params &p)
+void build_params(const Config &c, des_params &p, int ndims)
 {
     std::memset(&p, 0, sizeof(p));
-    p.ndims = 3;
+    if (ndims != 2 && ndims != 3) throw Error(30, "ndims must be 2 or 3");
+    p.ndims = ndims;
 
     // stopping / output conditions, input.cxx:1006-1020
     if (!(c.given("sim.max_steps") || c.given("sim.max_time_in_yr")))
@@ -319,8 +320,13 @@ void build_params(const Config &c, des_params &p)
     if (p.has_winkler_foundation && p.vbc_types[4] != 0) p.vbc_types[4] = 0;
     if (p.has_water_loading && p.gravity == 0) p.has_water_loading = 0;
     if (p.has_water_loading && p.vbc_types[5] != 0) p.vbc_types[5] = 0;
-    if (p.vbc_types[4] > 3) throw Error(11, "bc.vbc_z0 is not 0, 1, 2, or 3.");
-    if (p.vbc_types[5] > 3) throw Error(11, "bc.vbc_z1 is not 0, 1, 2, or 3.");
+    if (ndims == 3) {
+        if (p.vbc_types[4] > 3) throw Error(11, "bc.vbc_z0 is not 0, 1, 2, or 3.");
+        if (p.vbc_types[5] > 3) throw Error(11, "bc.vbc_z1 is not 0, 1, 2, or 3.");
+    } else {
+        if (p.vbc_types[4] > 4) throw Error(11, "bc.vbc_z0 is not 0, 1, 2, 3, or 4.");
+        if (p.vbc_types[5] > 4) throw Error(11, "bc.vbc_z1 is not 0, 1, 2, 3, or 4.");
+    }
     for (int k = 6; k < 10; ++k) {
         int t = p.vbc_types[k];
         if (t != 1 && t != 3 && t != 11 && t != 13)
@@ -395,6 +401,39 @@ void build_params(const Config &c, des_params &p)
     // dynearthsol.cxx:55-59
     p.max_vbc_val = (p.characteristic_speed == 0) ? find_max_vbc(c) : p.characteristic_speed;
     p.compensation_pressure = 0;
+
+    // what only the 2-D build reads
+    p.is_plane_strain = (ndims == 2) ? c.b("mat.is_plane_strain") : 0;       // input.cxx:1392-1397
+    p.mattype_oceanic_crust = c.i("mat.mattype_oceanic_crust");
+    p.num_vbc_period_x0 = c.i("bc.num_vbc_period_x0");
+    p.num_vbc_period_x1 = c.i("bc.num_vbc_period_x1");
+    if (p.num_vbc_period_x0 < 1 || p.num_vbc_period_x0 > DES_MAX_PERIOD || p.num_vbc_period_x1 < 1 || p.num_vbc_period_x1 > DES_MAX_PERIOD)
+        throw Error(52, "bc.num_vbc_period_x? must be within [1, DES_MAX_PERIOD]");
+    {
+        // input.cxx:1428-1431
+        std::vector<double> t0 = c.list("bc.vbc_period_x0_time_in_yr", p.num_vbc_period_x0, 1);
+        std::vector<double> t1 = c.list("bc.vbc_period_x1_time_in_yr", p.num_vbc_period_x1, 1);
+        std::vector<double> r0 = c.list("bc.vbc_period_x0_ratio", p.num_vbc_period_x0, 1);
+        std::vector<double> r1 = c.list("bc.vbc_period_x1_ratio", p.num_vbc_period_x1, 1);
+        // a list given with a single entry stays a single entry (get_numbers' optional size): interp1
+        // sees the vectors as they were read
+        p.num_vbc_period_x0 = (int)std::min(t0.size(), r0.size());
+        p.num_vbc_period_x1 = (int)std::min(t1.size(), r1.size());
+        for (int k = 0; k < p.num_vbc_period_x0; ++k) { p.vbc_period_x0_time_in_yr[k] = t0[k]; p.vbc_period_x0_ratio[k] = r0[k]; }
+        for (int k = 0; k < p.num_vbc_period_x1; ++k) { p.vbc_period_x1_time_in_yr[k] = t1[k]; p.vbc_period_x1_ratio[k] = r1[k]; }
+    }
+    // dynearthsol.cxx:85-101
+    p.vbc_vertical_div_x0[0] = 0.; p.vbc_vertical_div_x0[1] = c.d("bc.vbc_val_division_x0_min");
+    p.vbc_vertical_div_x0[2] = c.d("bc.vbc_val_division_x0_max"); p.vbc_vertical_div_x0[3] = 1.;
+    p.vbc_vertical_div_x1[0] = 0.; p.vbc_vertical_div_x1[1] = c.d("bc.vbc_val_division_x1_min");
+    p.vbc_vertical_div_x1[2] = c.d("bc.vbc_val_division_x1_max"); p.vbc_vertical_div_x1[3] = 1.;
+    for (int k = 0; k < 4; ++k) {
+        p.vbc_vertical_ratio_x0[k] = c.d("bc.vbc_val_x0_ratio" + std::to_string(k));
+        p.vbc_vertical_ratio_x1[k] = c.d("bc.vbc_val_x1_ratio" + std::to_string(k));
+    }
+    p.bottom_shear_zone_thickness = c.d("bc.bottom_shear_zone_thickness");
+    p.surf_diff_ratio_terrig = c.d("control.surf_diff_ratio_terrig");
+    p.surf_diff_ratio_marine = c.d("control.surf_diff_ratio_marine");
 }
 
 } // namespace des

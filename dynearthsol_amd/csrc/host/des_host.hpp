@@ -50,14 +50,17 @@ private:
 };
 
 // validate_parameters() (input.cxx:999-1500) for the options the host uses; fills the
-// POD handed to the device.  Throws Error with the reference's exit code.
-void build_params(const Config &cfg, des_params &out);
+// POD handed to the device.  Throws Error with the reference's exit code.  `ndims`: which build
+// of the reference this host stands for (3: -DTHREED, tets; 2: triangles) -- a compile-time
+// switch there (constants.hpp:12-25), a run-time one here.
+void build_params(const Config &cfg, des_params &out, int ndims = 3);
 
 struct HostMesh {
+    int nd = 3;                     // NDIMS of the build (constants.hpp:12-16); NODES_PER_ELEM = nd + 1
     int nnode = 0, nelem = 0, nseg = 0;
-    std::vector<double> coord;      // [3][nnode]
-    std::vector<int> conn;          // [4][nelem]
-    std::vector<int> segment;       // [3][nseg]
+    std::vector<double> coord;      // [nd][nnode]
+    std::vector<int> conn;          // [nd+1][nelem]
+    std::vector<int> segment;       // [nd][nseg]
     std::vector<int> segflag;       // [nseg]
     std::vector<double> regattr;    // [nelem]
 
@@ -65,9 +68,9 @@ struct HostMesh {
     std::vector<int> bnodes[DES_NBDRY];
     std::vector<int> bfacet_elem[DES_NBDRY], bfacet_facet[DES_NBDRY];
     std::vector<int> sup_idx, sup_arr, sup_lidx;
-    std::vector<int> conn_surf;     // [4][etop]
+    std::vector<int> conn_surf;     // [nd+1][etop]
     std::vector<int> top_nodes, elem_and_nodes, ssup_idx, ssup_arr, top_elems;
-    std::vector<double> bnormals;   // [3][10]
+    std::vector<double> bnormals;   // [nd][10]
     std::vector<double> edge_vec;
     int edge_slot[DES_NBDRY * DES_NBDRY];
 
@@ -91,7 +94,7 @@ void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY]);
 // the set is kept for the output frames / checkpoints (write_save_file, write_chkpt_file).
 struct HostMarkers {
     int nmarkers = 0, last_id = 0, reserved_space = 0;
-    std::vector<double> eta;        // shapefn, SoA [4][nmarkers]
+    std::vector<double> eta;        // shapefn, SoA [nd+1][nmarkers]
     std::vector<int> elem, mattype, id, genesis;
     std::vector<double> time, z, distance, slope;
 };
@@ -107,6 +110,7 @@ struct RestartState {
 struct HostFields {
     RestartState restart;
     std::vector<double> vel, temperature, radiogenic, stress, strain, plstrain, viscosity;
+    std::vector<double> stressyy;   // [nelem], 2-D builds only (fields.cxx:75)
     std::vector<int> elemmarkers;   // [nelem][nmat]
     HostMarkers markers;
     double compensation_pressure = 0;
@@ -135,7 +139,7 @@ double ref_pressure(const des_params &p, double z);
 
 // MatProps::rho (matprops.cxx:642-664) of one element for the "density" output field
 double elem_density(const des_params &p, const int *conn, int nelem, const double *temperature,
-                    const int *elemmarkers, int e);
+                    const int *elemmarkers, int e);   // NODES_PER_ELEM = p.ndims + 1
 
 } // namespace des
 

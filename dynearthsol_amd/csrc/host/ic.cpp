@@ -59,9 +59,10 @@ double arithmetic_mean(const double *s, const int *n, int nmat)
 struct ElemView {
     const des_params &p; const HostMesh &m; const HostFields &f;
     double elemT(int e) const {
+        const int npe = m.nd + 1;                      // NODES_PER_ELEM
         double T = 0;
-        for (int i = 0; i < 4; ++i) T += f.temperature[m.conn[(size_t)i*m.nelem + e]];
-        T /= 4;
+        for (int i = 0; i < npe; ++i) T += f.temperature[m.conn[(size_t)i*m.nelem + e]];
+        T /= npe;
         return T;
     }
     // MatProps::rho (matprops.cxx:642-664)
@@ -83,7 +84,8 @@ struct ElemView {
         const double min_strain_rate = 1e-30;
         double T = elemT(e);
         const int ne = m.nelem;
-        double s0 = (f.stress[e] + f.stress[(size_t)ne + e] + f.stress[(size_t)2*ne + e]) / 3;
+        double s0 = (m.nd == 3) ? (f.stress[e] + f.stress[(size_t)ne + e] + f.stress[(size_t)2*ne + e]) / 3
+                                : (f.stress[e] + f.stress[(size_t)ne + e]) / 2;       // trace(s) / NDIMS
         double edot = std::max(0.0, min_strain_rate);       // strain_rate is all zero at init
         double result = 0; int n = 0;
         const int *mk = &f.elemmarkers[(size_t)e*p.nmat];
@@ -107,9 +109,10 @@ struct ElemView {
 double elem_density(const des_params &p, const int *conn, int nelem, const double *temperature,
                     const int *elemmarkers, int e)
 {
+    const int npe = p.ndims + 1;
     double T = 0;
-    for (int i = 0; i < 4; ++i) T += temperature[conn[(size_t)i*nelem + e]];
-    T /= 4;
+    for (int i = 0; i < npe; ++i) T += temperature[conn[(size_t)i*nelem + e]];
+    T /= npe;
     double TinCelsius = T - 273;
     double result = 0; int n = 0;
     const int *mk = &elemmarkers[(size_t)e*p.nmat];
@@ -123,15 +126,15 @@ double elem_density(const des_params &p, const int *conn, int nelem, const doubl
 namespace {
 
 // MarkerSet::random_eta (markerset.cxx:116-133)
-void random_eta(double eta[4])
+void random_eta(double eta[4], int nd)
 {
     while (1) {
         double sum = 0;
-        for (int n = 0; n < 3; n++) {
+        for (int n = 0; n < nd; n++) {
             eta[n] = (rand() / (double)RAND_MAX);
             sum += eta[n];
         }
-        if (sum < 1) { eta[3] = 1 - sum; break; }
+        if (sum < 1) { eta[nd] = 1 - sum; break; }
     }
 }
 
@@ -141,6 +144,7 @@ void random_eta(double eta[4])
 void create_elemmarkers(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f)
 {
     const int ne = m.nelem, nmat = p.nmat;
+    const int nd = m.nd, npe = nd + 1;
     const int mpe = cfg.i("markers.markers_per_element");
     f.elemmarkers.assign((size_t)ne*nmat, 0);
     const int mattype_option = cfg.i("ic.mattype_option");
@@ -162,7 +166,7 @@ void create_elemmarkers(const Config &cfg, const des_params &p, const HostMesh &
     const size_t nm = (size_t)ne * mpe;
     mk.nmarkers = mk.last_id = (int)nm;
     mk.reserved_space = (int)(nm * 2.0);                       // over_alloc_ratio, markerset.cxx:25
-    mk.eta.assign(4 * nm, 0.0);
+    mk.eta.assign(npe * nm, 0.0);
     mk.elem.assign(nm, 0); mk.mattype.assign(nm, 0); mk.id.assign(nm, 0); mk.genesis.assign(nm, 0);
     mk.time.assign(nm, 0.0); mk.z.assign(nm, 0.0); mk.distance.assign(nm, 0.0); mk.slope.assign(nm, 0.0);
 
@@ -172,20 +176,20 @@ void create_elemmarkers(const Config &cfg, const des_params &p, const HostMesh &
     for (int e = 0; e < ne; e++)
         for (int k = 0; k < mpe; k++, im++) {
             double eta[4];
-            random_eta(eta);
+            random_eta(eta, nd);
             int mt;
             if (mattype_option == 0) {
                 mt = (int)m.regattr[e];
                 if (mt < 0 || mt >= nmat) throw Error(11, "region attribute is not a valid material");
             } else {
                 double z = 0;
-                for (int j = 0; j < 4; j++)
-                    z += m.coord[(size_t)2*m.nnode + m.conn[(size_t)j*ne + e]] * eta[j];
+                for (int j = 0; j < npe; j++)
+                    z += m.coord[(size_t)(nd-1)*m.nnode + m.conn[(size_t)j*ne + e]] * eta[j];
                 mt = (int)layer_mt[layer_mt.size() - 1];
                 for (size_t i = 0; i < depths.size(); ++i)
                     if (z >= -p.zlength * depths[i]) { mt = (int)layer_mt[i]; break; }
             }
-            for (int j = 0; j < 4; j++) mk.eta[(size_t)j*nm + im] = eta[j];
+            for (int j = 0; j < npe; j++) mk.eta[(size_t)j*nm + im] = eta[j];
             mk.elem[im] = e; mk.mattype[im] = mt; mk.id[im] = (int)im;
             ++f.elemmarkers[(size_t)e*nmat + mt];
         }
@@ -195,7 +199,8 @@ void create_elemmarkers(const Config &cfg, const des_params &p, const HostMesh &
 void initial_temperature(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f)
 {
     const int nn = m.nnode, ne = m.nelem;
-    const double *z = &m.coord[(size_t)2*nn];
+    const int nd = m.nd, npe = nd + 1;
+    const double *z = &m.coord[(size_t)(nd-1)*nn];
     const double t_top = p.surface_temperature, t_bot = cfg.d("bc.mantle_temperature");
     ElemView ev = {p, m, f};
     f.radiogenic.assign((size_t)ne, 0.0);
@@ -289,8 +294,8 @@ void initial_temperature(const Config &cfg, const des_params &p, const HostMesh 
         }
         for (int e = 0; e < ne; ++e) {
             double zcenter = 0;
-            for (int j = 0; j < 4; ++j) zcenter += z[m.conn[(size_t)j*ne + e]];
-            zcenter /= 4;
+            for (int j = 0; j < npe; ++j) zcenter += z[m.conn[(size_t)j*ne + e]];
+            zcenter /= npe;
             double y = -zcenter;
             bool is_layer = false;
             for (int k = 0; k < nlayer; k++) {
@@ -339,10 +344,16 @@ void initial_temperature(const Config &cfg, const des_params &p, const HostMesh 
         for (int n = 0; n < nn; n++) {
             const double zz = -z[n];
             const double zPotT = t_bot * std::exp(p.gravity * zz * 4e-8);
-            const double dx = m.coord[n] - cx, dy = m.coord[(size_t)nn + n] - cy;
-            const double dx_rot = dx * std::cos(az) - dy * std::sin(az);
-            const double dy_rot = dx * std::sin(az) + dy * std::cos(az);
-            const double radius_sq = std::pow(dx_rot * wx_r, 2) + std::pow(dy_rot * wy_r, 2);
+            const double dx = m.coord[n] - cx;
+            double radius_sq;
+            if (nd == 3) {
+                const double dy = m.coord[(size_t)nn + n] - cy;
+                const double dx_rot = dx * std::cos(az) - dy * std::sin(az);
+                const double dy_rot = dx * std::sin(az) + dy * std::cos(az);
+                radius_sq = std::pow(dx_rot * wx_r, 2) + std::pow(dy_rot * wy_r, 2);
+            } else {
+                radius_sq = std::pow(dx * wx_r, 2);                        // ic.cxx:775-777
+            }
             const double xsfh = heat_flux + amplitude / 1e6 * std::exp(-radius_sq);
             hp[0] = (1. - F) * xsfh / rho[0] / layer_bdy[1];
             double t = t_top, q = xsfh;
@@ -361,7 +372,7 @@ void initial_temperature(const Config &cfg, const des_params &p, const HostMesh 
                 for (int i = 0; i < nlayer; i++)
                     if (zz >= layer_bdy[i]) rs = hp[i];
                 for (int k = m.sup_idx[n]; k < m.sup_idx[n+1]; ++k)
-                    f.radiogenic[m.sup_arr[k]] += rs / 4;
+                    f.radiogenic[m.sup_arr[k]] += rs / npe;
             }
             f.temperature[n] = t;
         }
@@ -370,7 +381,7 @@ void initial_temperature(const Config &cfg, const des_params &p, const HostMesh 
         for (size_t mi = 0; mi < nm; ++mi) {
             const int e = mk.elem[mi], current_mt = mk.mattype[mi];
             double t = 0;
-            for (int i = 0; i < 4; ++i) t += in_asth[m.conn[(size_t)i*ne + e]] * mk.eta[(size_t)i*nm + mi];
+            for (int i = 0; i < npe; ++i) t += in_asth[m.conn[(size_t)i*ne + e]] * mk.eta[(size_t)i*nm + mi];
             if (t >= 0.5 && current_mt != mt_asth) {
                 mk.mattype[mi] = mt_asth;
                 --f.elemmarkers[(size_t)e*p.nmat + current_mt];
@@ -394,21 +405,24 @@ void initial_temperature(const Config &cfg, const des_params &p, const HostMesh 
 void initial_stress_state(des_params &p, const HostMesh &m, HostFields &f)
 {
     const int ne = m.nelem, nn = m.nnode;
-    f.stress.assign((size_t)6*ne, 0.0);
-    f.strain.assign((size_t)6*ne, 0.0);
+    const int nd = m.nd, npe = nd + 1, nstr = nd * (nd + 1) / 2;
+    f.stress.assign((size_t)nstr*ne, 0.0);
+    f.strain.assign((size_t)nstr*ne, 0.0);
+    if (nd == 2) f.stressyy.assign((size_t)ne, 0.0);                        // fields.cxx:75
     if (p.gravity == 0) { f.compensation_pressure = 0; p.compensation_pressure = 0; return; }
     ElemView ev = {p, m, f};
     double ks = ev.bulkm(0);
     for (int e = 0; e < ne; ++e) {
         double zcenter = 0;
-        for (int i = 0; i < 4; ++i) zcenter += m.coord[(size_t)2*nn + m.conn[(size_t)i*ne + e]];
-        zcenter /= 4;
+        for (int i = 0; i < npe; ++i) zcenter += m.coord[(size_t)(nd-1)*nn + m.conn[(size_t)i*ne + e]];
+        zcenter /= npe;
         double pr = ref_pressure(p, zcenter);
         if (p.ref_pressure_option == 1 || p.ref_pressure_option == 2) ks = ev.bulkm(e);
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < nd; ++i) {
             f.stress[(size_t)i*ne + e] = -pr;
-            f.strain[(size_t)i*ne + e] = -pr / ks / 3;
+            f.strain[(size_t)i*ne + e] = -pr / ks / nd;
         }
+        if (p.is_plane_strain) f.stressyy[e] = -pr;                         // ic.cxx:357-358
     }
     f.compensation_pressure = ref_pressure(p, -p.zlength);
     p.compensation_pressure = f.compensation_pressure;
@@ -418,6 +432,7 @@ void initial_stress_state(des_params &p, const HostMesh &m, HostFields &f)
 void initial_weak_zone(const Config &c, const des_params &p, const HostMesh &m, HostFields &f, bool fresh = true)
 {
     const int ne = m.nelem, nn = m.nnode;
+    const int nd = m.nd, npe = nd + 1;
     if (fresh) f.plstrain.assign((size_t)ne, 0.0);       // init(): plstrain starts at zero (fields.cxx:96)
     const int option = c.i("ic.weakzone_option");
     if (option == 0) return;
@@ -464,13 +479,35 @@ void initial_weak_zone(const Config &c, const des_params &p, const HostMesh &m, 
 
     for (int e = 0; e < ne; ++e) {
         double center[3] = {0, 0, 0};
-        for (int i = 0; i < 4; ++i)
-            for (int d = 0; d < 3; ++d) center[d] += m.coord[(size_t)d*nn + m.conn[(size_t)i*ne + e]];
-        for (int d = 0; d < 3; ++d) center[d] /= 4;
+        for (int i = 0; i < npe; ++i)
+            for (int d = 0; d < nd; ++d) center[d] += m.coord[(size_t)d*nn + m.conn[(size_t)i*ne + e]];
+        for (int d = 0; d < nd; ++d) center[d] /= npe;
         const double *x = center;
         bool inside = false;
         double value = 1;
-        if (option == 1) {
+        if (nd == 2) {
+            // the !THREED forms of the zones (ic.cxx:28-300): x = {x, z}, no y terms
+            const double xz[2] = {x0[0], x0[2]};
+            if (option == 1 || option == 4) {
+                // Planar_zone; Gaussian_planar_zone degenerates to it without the strict-inequality
+                // difference of its z test (ic.cxx:241, 254-256)
+                const bool zin = (option == 1) ? (x[1] > zmin && x[1] < zmax) : !(x[1] <= zmin || x[1] >= zmax);
+                inside = zin && std::fabs((x[0] - xz[0]) + incl * (x[1] - xz[1])) < halfwidth;
+            } else if (option == 2) {
+                inside = (x[0]-xz[0])*(x[0]-xz[0]) / (semi[0]*semi[0]) + (x[1]-xz[1])*(x[1]-xz[1]) / (semi[2]*semi[2]) < 1;
+            } else if (option == 3) {
+                double r2 = (x[0]-xz[0])*(x[0]-xz[0]) + (x[1]-xz[1])*(x[1]-xz[1]);
+                inside = r2 < (sd * sd * 16.);
+                value = exp(-(r2 / (2.*sd*sd)));
+            } else {
+                for (const Segment &g : segs) {
+                    if (x[0] <= g.xmin || x[0] >= g.xmax) continue;
+                    if (x[1] <= g.zmin || x[1] >= g.zmax) continue;
+                    double dist = g.nx * (x[0] - g.c[0]) + g.nz * (x[1] - g.c[2]);
+                    if (std::fabs(dist) < g.halfwidth) { inside = true; break; }
+                }
+            }
+        } else if (option == 1) {
             inside = (x[2] > zmin && x[2] < zmax && x[1] > ymin && x[1] < ymax &&
                       std::fabs((x[0] - x0[0]) - az * (x[1] - x0[1]) + incl * (x[2] - x0[2])) < halfwidth);
         } else if (option == 2) {
@@ -530,7 +567,7 @@ double ref_pressure(const des_params &p, double z)
 void initial_conditions(const Config &cfg, des_params &p, const HostMesh &m, HostFields &f)
 {
     const int nn = m.nnode, ne = m.nelem;
-    f.vel.assign((size_t)3*nn, 0.0);
+    f.vel.assign((size_t)m.nd*nn, 0.0);
     f.temperature.assign((size_t)nn, 0.0);      // init() calls mat->rho(0) while T is still 0
     create_elemmarkers(cfg, p, m, f);
     initial_temperature(cfg, p, m, f);

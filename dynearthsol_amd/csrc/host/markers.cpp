@@ -154,6 +154,8 @@ int initial_mattype_at(const des_params &p, const HostMesh &m, int mattype_optio
 // (:56-66) that no element is left without a marker
 void regularly_spaced_markers(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f)
 {
+    if (m.nd != 3)
+        throw Error(31, "markers.init_marker_option = 2 is built for the 3-D host only");
     const int nn = m.nnode, ne = m.nelem, nmat = p.nmat;
     const int d = (int)(cfg.d("markers.init_marker_spacing") * cfg.d("mesh.resolution"));    // `const int d`, as in the reference
     if (d <= 0) throw Error(11, "markers.init_marker_spacing * mesh.resolution must be at least 1 m");
@@ -267,7 +269,7 @@ int simple_subduction(int current_mt, double Z, double P, double T)
 } // namespace
 
 // phase_changes (phasechanges.cxx:109-152) with the current nodal coordinates / temperatures
-// (SoA [3][nnode], [nnode]).  Moves the markers' material and the per-element counts; returns the
+// (SoA [nd][nnode], [nnode]).  Moves the markers' material and the per-element counts; returns the
 // number of markers that changed.
 int phase_changes(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f,
                   const double *coord, const double *temperature)
@@ -287,9 +289,9 @@ int phase_changes(const Config &cfg, const des_params &p, const HostMesh &m, Hos
         if (option == 1) {
             // MarkerSet::get_ZPT (markerset.cxx:973-986)
             double Z = 0, T = 0;
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < m.nd + 1; ++j) {
                 const int n = m.conn[(size_t)j*ne + e];
-                Z += coord[(size_t)2*nn + n] * mk.eta[(size_t)j*nm + i];
+                Z += coord[(size_t)(m.nd - 1)*nn + n] * mk.eta[(size_t)j*nm + i];
                 T += temperature[n] * mk.eta[(size_t)j*nm + i];
             }
             const double P = ref_pressure(p, Z);

@@ -14,7 +14,10 @@ namespace des {
 
 namespace {
 
-const int NODE_OF_FACET[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};   // constants.hpp:64-69
+const int NODE_OF_FACET3[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};   // constants.hpp:64-69
+const int NODE_OF_FACET2[3][2] = {{1,2},{2,0},{0,1}};                  // constants.hpp:71-75
+// local node j of facet f in an nd-dimensional build
+inline int node_of_facet(int nd, int f, int j) { return nd == 3 ? NODE_OF_FACET3[f][j] : NODE_OF_FACET2[f % 3][j & 1]; }
 const unsigned BOUNDX0 = 1, BOUNDX1 = 2, BOUNDY0 = 4, BOUNDY1 = 8, BOUNDZ0 = 16, BOUNDZ1 = 32;
 const unsigned BOUND_ANY = 0x3ff;
 const int iboundz1 = 5, iboundn0 = 6;
@@ -49,10 +52,58 @@ void cells_of_grid(RegularGrid &g)
             }
 }
 
+// The 2-D build of the same mesher (mesh.cxx:146-166, 271-297, 320-336, 350-390): quadrilateral
+// cells cut into two counter-clockwise triangles, the diagonal alternating with the parity of i+j.
+void new_mesh_regular2d(const Config &cfg, HostMesh &m)
+{
+    const double Lx = cfg.d("mesh.xlength"), Lz = cfg.d("mesh.zlength");
+    const double res = cfg.d("mesh.resolution");
+    const int nx = (int)std::round(Lx / res) + 1, nz = (int)std::round(Lz / res) + 1;   // mesh.cxx:1453-1458
+    if (nx < 2 || nz < 2) throw Error(11, "regular mesh needs at least one cell per direction");
+    const int ncell = (nx-1)*(nz-1), nnode = nx*nz, nelem = 2*ncell, nseg = 2*(nx + nz - 2);
+    m.nd = 2;
+    m.nnode = nnode; m.nelem = nelem; m.nseg = nseg;
+    m.coord.resize((size_t)2*nnode);
+    const double dx = Lx / (nx-1), dz = -Lz / (nz-1);
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < nz; ++j) {
+            m.coord[(size_t)j + (size_t)i*nz] = i * dx;
+            m.coord[(size_t)nnode + j + (size_t)i*nz] = j * dz;
+        }
+    m.conn.resize((size_t)3*nelem);
+    for (int i = 0; i < nx-1; ++i)
+        for (int j = 0; j < nz-1; ++j) {
+            const int idx = i*(nz-1) + j;
+            const int idx0 = i*nz + j, idx1 = idx0 + nz;
+            const int cell[4] = {idx0, idx1, idx1 + 1, idx0 + 1};
+            int t[6];
+            if ((i+j) % 2 == 0) { t[0] = cell[0]; t[1] = cell[2]; t[2] = cell[1]; t[3] = cell[0]; t[4] = cell[3]; t[5] = cell[2]; }
+            else                { t[0] = cell[0]; t[1] = cell[3]; t[2] = cell[1]; t[3] = cell[1]; t[4] = cell[3]; t[5] = cell[2]; }
+            for (int q = 0; q < 2; ++q)
+                for (int k = 0; k < 3; ++k) m.conn[(size_t)k*nelem + 2*idx + q] = t[3*q + k];
+        }
+    std::vector<int> seg, flag;
+    auto add = [&](int a, int b, int f) { seg.push_back(a); seg.push_back(b); flag.push_back(f); };
+    for (int i = 0; i < nx-1; ++i)
+        for (int j = 0; j < nz-1; ++j) {
+            if (i == 0) add(j + i*nz, j + i*nz + 1, (int)BOUNDX0);
+            if (j == 0) add(j + i*nz, j + i*nz + nz, (int)BOUNDZ1);
+        }
+    for (int i = 1; i < nx; ++i) add(i*nz - 1, i*nz + nz - 1, (int)BOUNDZ0);
+    for (int j = 0; j < nz-1; ++j) add(nz*(nx-1) + j, nz*(nx-1) + j + 1, (int)BOUNDX1);
+    if ((int)flag.size() != nseg) throw Error(60, "regular mesh: segment count mismatch");
+    m.segment.resize((size_t)2*nseg);
+    for (int q = 0; q < nseg; ++q)
+        for (int d = 0; d < 2; ++d) m.segment[(size_t)d*nseg + q] = seg[(size_t)q*2 + d];
+    m.segflag = flag;
+    m.regattr.assign((size_t)nelem, 0.0);     // mesh.cxx:570-575
+}
+
 // The regular mesher writes AoS scratch arrays first (as the reference's
 // create_rect_node / create_elem_from_cell / create_regular_segments do) and converts to SoA.
 void new_mesh_regular(const Config &cfg, HostMesh &m)
 {
+    if (m.nd == 2) { new_mesh_regular2d(cfg, m); return; }
     const double Lx = cfg.d("mesh.xlength"), Ly = cfg.d("mesh.ylength"), Lz = cfg.d("mesh.zlength");
     const double res = cfg.d("mesh.resolution");
     RegularGrid g;
@@ -157,23 +208,24 @@ void new_mesh_regular(const Config &cfg, HostMesh &m)
 void discard_internal_segments(HostMesh &m)
 {
     int nseg = m.nseg;
-    std::vector<int> seg((size_t)nseg*3), flag(m.segflag);
+    const int npf = m.nd;
+    std::vector<int> seg((size_t)nseg*npf), flag(m.segflag);
     for (int q = 0; q < nseg; ++q)
-        for (int d = 0; d < 3; ++d) seg[(size_t)q*3+d] = m.segment[(size_t)d*m.nseg + q];
+        for (int d = 0; d < npf; ++d) seg[(size_t)q*npf+d] = m.segment[(size_t)d*m.nseg + q];
     int n = 0;
     while (n < nseg) {
         if ((unsigned)flag[n] & BOUND_ANY) { n++; }
         else {
             nseg--;
             flag[n] = flag[nseg];
-            for (int d = 0; d < 3; ++d) seg[(size_t)n*3+d] = seg[(size_t)nseg*3+d];
+            for (int d = 0; d < npf; ++d) seg[(size_t)n*npf+d] = seg[(size_t)nseg*npf+d];
         }
     }
     m.nseg = nseg;
     m.segflag.assign(flag.begin(), flag.begin() + nseg);
-    m.segment.resize((size_t)3*nseg);
+    m.segment.resize((size_t)npf*nseg);
     for (int q = 0; q < nseg; ++q)
-        for (int d = 0; d < 3; ++d) m.segment[(size_t)d*nseg + q] = seg[(size_t)q*3+d];
+        for (int d = 0; d < npf; ++d) m.segment[(size_t)d*nseg + q] = seg[(size_t)q*npf+d];
 }
 
 struct IdxLess {
@@ -196,24 +248,38 @@ void sortindex(const std::vector<double> &x, std::vector<I> &idx)
 void renumbering_mesh(const Config &cfg, HostMesh &m)
 {
     const int nnode = m.nnode, nelem = m.nelem, nseg = m.nseg;
-    std::vector<double> lengths = {cfg.d("mesh.xlength"), cfg.d("mesh.ylength"), cfg.d("mesh.zlength")};
-    std::vector<size_t> idx(3);
-    sortindex(lengths, idx);
-    int dmin, dmid, dmax;
-    if (cfg.i("mesh.meshing_elem_shape") == 0) {
-        dmin = (int)idx[0]; dmid = (int)idx[1]; dmax = (int)idx[2];
-    } else {
-        dmax = 0; dmid = 1; dmin = 2;
-    }
-    std::vector<double> wn(nnode);
+    const int nd = m.nd, npe = nd + 1;
+    std::vector<double> wn(nnode), we(nelem);
     const double f = 1e-3;
-    for (int i = 0; i < nnode; i++)
-        wn[i] = m.coord[(size_t)dmax*nnode + i] + f * m.coord[(size_t)dmid*nnode + i]
-                + f * f * m.coord[(size_t)dmin*nnode + i];
-    std::vector<double> we(nelem);
-    for (int i = 0; i < nelem; i++)
-        we[i] = wn[m.conn[i]] + wn[m.conn[(size_t)nelem + i]] + wn[m.conn[(size_t)2*nelem + i]]
-                + wn[m.conn[(size_t)3*nelem + i]];
+    if (nd == 3) {
+        std::vector<double> lengths = {cfg.d("mesh.xlength"), cfg.d("mesh.ylength"), cfg.d("mesh.zlength")};
+        std::vector<size_t> idx(3);
+        sortindex(lengths, idx);
+        int dmin, dmid, dmax;
+        if (cfg.i("mesh.meshing_elem_shape") == 0) {
+            dmin = (int)idx[0]; dmid = (int)idx[1]; dmax = (int)idx[2];
+        } else {
+            dmax = 0; dmid = 1; dmin = 2;
+        }
+        for (int i = 0; i < nnode; i++)
+            wn[i] = m.coord[(size_t)dmax*nnode + i] + f * m.coord[(size_t)dmid*nnode + i]
+                    + f * f * m.coord[(size_t)dmin*nnode + i];
+        for (int i = 0; i < nelem; i++)
+            we[i] = wn[m.conn[i]] + wn[m.conn[(size_t)nelem + i]] + wn[m.conn[(size_t)2*nelem + i]]
+                    + wn[m.conn[(size_t)3*nelem + i]];
+    } else {
+        // the !THREED branches of mesh.cxx:2710-2760: no middle axis
+        std::vector<double> lengths = {cfg.d("mesh.xlength"), cfg.d("mesh.zlength")};
+        std::vector<size_t> idx(2);
+        sortindex(lengths, idx);
+        int dmin, dmax;
+        if (cfg.i("mesh.meshing_elem_shape") == 0) { dmin = (int)idx[0]; dmax = (int)idx[1]; }
+        else { dmax = 0; dmin = 1; }
+        for (int i = 0; i < nnode; i++)
+            wn[i] = m.coord[(size_t)dmax*nnode + i] + f * f * m.coord[(size_t)dmin*nnode + i];
+        for (int i = 0; i < nelem; i++)
+            we[i] = wn[m.conn[i]] + wn[m.conn[(size_t)nelem + i]] + wn[m.conn[(size_t)2*nelem + i]];
+    }
 
     std::vector<int> nd_idx(nnode), el_idx(nelem);
     sortindex(wn, nd_idx);
@@ -223,18 +289,18 @@ void renumbering_mesh(const Config &cfg, HostMesh &m)
 
     std::vector<double> coord2(m.coord.size());
     for (int i = 0; i < nnode; i++)
-        for (int d = 0; d < 3; ++d)
+        for (int d = 0; d < nd; ++d)
             coord2[(size_t)d*nnode + i] = m.coord[(size_t)d*nnode + nd_idx[i]];
     m.coord.swap(coord2);
 
     std::vector<int> conn2(m.conn.size());
     for (int i = 0; i < nelem; i++)
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < npe; ++j)
             conn2[(size_t)j*nelem + i] = nd_inv[m.conn[(size_t)j*nelem + el_idx[i]]];
     m.conn.swap(conn2);
 
     for (int i = 0; i < nseg; i++)
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < nd; ++j)
             m.segment[(size_t)j*nseg + i] = nd_inv[m.segment[(size_t)j*nseg + i]];
 
     std::vector<double> reg2(nelem);
@@ -242,14 +308,16 @@ void renumbering_mesh(const Config &cfg, HostMesh &m)
     m.regattr.swap(reg2);
 }
 
+// "DESMESH1" / "DESMESH0": 3-D, finished / raw mesher output; "DESMSH21" / "DESMSH20": the same in 2-D
 static const char kMeshMagic[8] = {'D','E','S','M','E','S','H','1'};
+static const char kMeshMagic2d[8] = {'D','E','S','M','S','H','2','1'};
 
 void save_mesh_file(const std::string &path, const HostMesh &m)
 {
     FILE *fp = std::fopen(path.c_str(), "wb");
     if (!fp) throw Error(20, "cannot open mesh file for writing: " + path);
     int hdr[3] = {m.nnode, m.nelem, m.nseg};
-    bool ok = std::fwrite(kMeshMagic, 1, 8, fp) == 8 && std::fwrite(hdr, sizeof(int), 3, fp) == 3
+    bool ok = std::fwrite(m.nd == 2 ? kMeshMagic2d : kMeshMagic, 1, 8, fp) == 8 && std::fwrite(hdr, sizeof(int), 3, fp) == 3
         && std::fwrite(m.coord.data(), sizeof(double), m.coord.size(), fp) == m.coord.size()
         && std::fwrite(m.conn.data(), sizeof(int), m.conn.size(), fp) == m.conn.size()
         && std::fwrite(m.segment.data(), sizeof(int), m.segment.size(), fp) == m.segment.size()
@@ -266,13 +334,19 @@ bool load_mesh_file_raw(const std::string &path, HostMesh &m)
     FILE *fp = std::fopen(path.c_str(), "rb");
     if (!fp) throw Error(20, "cannot open mesh file: " + path);
     char magic[8]; int hdr[3];
-    bool ok = std::fread(magic, 1, 8, fp) == 8 && std::memcmp(magic, kMeshMagic, 7) == 0
+    bool ok = std::fread(magic, 1, 8, fp) == 8
+              && (std::memcmp(magic, kMeshMagic, 7) == 0 || std::memcmp(magic, kMeshMagic2d, 7) == 0)
               && (magic[7] == '0' || magic[7] == '1') && std::fread(hdr, sizeof(int), 3, fp) == 3;
     const bool raw = ok && magic[7] == '0';
+    if (ok && (std::memcmp(magic, kMeshMagic2d, 7) == 0 ? 2 : 3) != m.nd) {
+        std::fclose(fp);
+        throw Error(30, "mesh file is for the other dimension: " + path);
+    }
     if (ok) {
+        const int nd = m.nd;
         m.nnode = hdr[0]; m.nelem = hdr[1]; m.nseg = hdr[2];
-        m.coord.resize((size_t)3*m.nnode); m.conn.resize((size_t)4*m.nelem);
-        m.segment.resize((size_t)3*m.nseg); m.segflag.resize((size_t)m.nseg);
+        m.coord.resize((size_t)nd*m.nnode); m.conn.resize((size_t)(nd+1)*m.nelem);
+        m.segment.resize((size_t)nd*m.nseg); m.segflag.resize((size_t)m.nseg);
         ok = std::fread(m.coord.data(), sizeof(double), m.coord.size(), fp) == m.coord.size()
           && std::fread(m.conn.data(), sizeof(int), m.conn.size(), fp) == m.conn.size()
           && std::fread(m.segment.data(), sizeof(int), m.segment.size(), fp) == m.segment.size()
@@ -310,13 +384,15 @@ void create_new_mesh(const Config &cfg, HostMesh &m, const std::string &mesh_fil
     const int shape = cfg.i("mesh.meshing_elem_shape");
     if (shape >= 1 && opt != 1)
         throw Error(30, "mesh.meshing_elem_shape >= 1 is only for mesh.meshing_option == 1.");
-    if (shape == 2)
+    if (shape == 2 && m.nd == 3)
         throw Error(30, "mesh.meshing_elem_shape == 2 is not available in 3D.");
+    if (shape == 2)
+        throw Error(31, "mesh.meshing_elem_shape == 2 (equilateral triangles, mesh.cxx:577-760) is not built by this host");
     if (opt == 1 && shape == 1) {
         new_mesh_regular(cfg, m);
     } else if (opt == 1 || opt == 2 || opt == 90 || opt == 91) {
-        throw Error(31, "this meshing_option needs TetGen, which is a host-side library of the "
-                        "reference; pass a mesh file generated with it (see DESIGN.md)");
+        throw Error(31, "this meshing_option needs TetGen / Triangle, host-side libraries of the "
+                        "reference; pass a mesh file generated with them (see DESIGN.md)");
     } else if (opt == 95) {
         // mesh.cxx:3482-3489 without USEEXODUS
         throw Error(31, "Error: Install Exodus library and rebuild with 'useexo' turned on in Makefile.");
@@ -330,6 +406,7 @@ void create_new_mesh(const Config &cfg, HostMesh &m, const std::string &mesh_fil
 
 namespace {
 
+// a facet's node set: three nodes in 3-D, two (+ -1) in 2-D (OrderedInt, mesh.cxx)
 struct Tri {
     int a, b, c;
     Tri(int x, int y, int z) {
@@ -352,9 +429,17 @@ struct TriHash {
 void facet_normal(const HostMesh &m, int e, int f, double normal[3])
 {
     double fc[3][3];
-    for (int j = 0; j < 3; ++j) {
-        int n = m.conn[(size_t)NODE_OF_FACET[f][j]*m.nelem + e];
-        for (int d = 0; d < 3; ++d) fc[j][d] = m.coord[(size_t)d*m.nnode + n];
+    for (int j = 0; j < m.nd; ++j) {
+        int n = m.conn[(size_t)node_of_facet(m.nd, f, j)*m.nelem + e];
+        for (int d = 0; d < m.nd; ++d) fc[j][d] = m.coord[(size_t)d*m.nnode + n];
+    }
+    if (m.nd == 2) {
+        // the normal vector to the edge, pointing outward (bc.cxx:42-50)
+        double v01[2];
+        for (int i = 0; i < 2; ++i) v01[i] = fc[1][i] - fc[0][i];
+        normal[0] = v01[1];
+        normal[1] = -v01[0];
+        return;
     }
     double v01[3], v02[3];
     for (int i = 0; i < 3; ++i) { v01[i] = fc[1][i] - fc[0][i]; v02[i] = fc[2][i] - fc[0][i]; }
@@ -368,11 +453,14 @@ void facet_normal(const HostMesh &m, int e, int f, double normal[3])
 void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY])
 {
     const int nnode = m.nnode, nelem = m.nelem, nseg = m.nseg;
+    const int nd = m.nd, npe = nd + 1, npf = nd;
+    // node k of facet f of element e, or -1 past the facet's last node
+    auto fnode = [&](int e, int f, int k) { return k < npf ? m.conn[(size_t)node_of_facet(nd, f, k)*nelem + e] : -1; };
 
     // create_boundary_flags (mesh.cxx:2824-2851)
     m.bcflag.assign((size_t)nnode, 0u);
     for (int i = 0; i < nseg; ++i)
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < npf; ++j)
             m.bcflag[m.segment[(size_t)j*nseg + i]] |= (unsigned)m.segflag[i];
 
     // create_boundary_nodes (mesh.cxx:2854-2880)
@@ -385,11 +473,9 @@ void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY])
     // for every segment; a facet lookup table gives the same (element, facet) pairs.
     std::unordered_map<Tri, std::pair<int,int>, TriHash> facet_of;
     for (int e = 0; e < nelem; ++e)
-        for (int f = 0; f < 4; ++f) {
-            int n0 = m.conn[(size_t)NODE_OF_FACET[f][0]*nelem + e];
-            int n1 = m.conn[(size_t)NODE_OF_FACET[f][1]*nelem + e];
-            int n2 = m.conn[(size_t)NODE_OF_FACET[f][2]*nelem + e];
-            if ((m.bcflag[n0] & m.bcflag[n1] & m.bcflag[n2]) == 0u) continue;
+        for (int f = 0; f < npe; ++f) {
+            int n0 = fnode(e, f, 0), n1 = fnode(e, f, 1), n2 = fnode(e, f, 2);
+            if ((m.bcflag[n0] & m.bcflag[n1] & (n2 >= 0 ? m.bcflag[n2] : ~0u)) == 0u) continue;
             Tri t(n0, n1, n2);
             if (!facet_of.count(t)) facet_of[t] = std::make_pair(e, f);   // first (e, f) wins
         }
@@ -397,14 +483,13 @@ void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY])
     for (int i = 0; i < nseg; ++i) {
         unsigned flag = (unsigned)m.segflag[i];
         if ((flag & BOUND_ANY) == 0) continue;
-        Tri t(m.segment[i], m.segment[(size_t)nseg + i], m.segment[(size_t)2*nseg + i]);
+        Tri t(m.segment[i], m.segment[(size_t)nseg + i], nd == 3 ? m.segment[(size_t)2*nseg + i] : -1);
         std::unordered_map<Tri, std::pair<int,int>, TriHash>::const_iterator it = facet_of.find(t);
         bool found = false;
         if (it != facet_of.end()) {
             int e = it->second.first, f = it->second.second;
-            unsigned facet_flag = m.bcflag[m.conn[(size_t)NODE_OF_FACET[f][0]*nelem + e]]
-                                & m.bcflag[m.conn[(size_t)NODE_OF_FACET[f][1]*nelem + e]]
-                                & m.bcflag[m.conn[(size_t)NODE_OF_FACET[f][2]*nelem + e]];
+            unsigned facet_flag = m.bcflag[fnode(e, f, 0)] & m.bcflag[fnode(e, f, 1)]
+                                & (nd == 3 ? m.bcflag[fnode(e, f, 2)] : ~0u);
             if (flag & facet_flag)
                 for (int k = 0; k < DES_NBDRY; ++k)
                     if (flag == (1u << k)) { bf[k].push_back(it->second); found = true; break; }
@@ -423,23 +508,22 @@ void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY])
         }
     }
     const int etop = (int)bf[iboundz1].size();
-    m.conn_surf.assign((size_t)4*etop, 0);
+    m.conn_surf.assign((size_t)npe*etop, 0);
     for (int i = 0; i < etop; ++i)
-        for (int j = 0; j < 3; ++j)
-            m.conn_surf[(size_t)j*etop + i] =
-                m.conn[(size_t)NODE_OF_FACET[bf[iboundz1][i].second][j]*nelem + bf[iboundz1][i].first];
+        for (int j = 0; j < npf; ++j)
+            m.conn_surf[(size_t)j*etop + i] = fnode(bf[iboundz1][i].first, bf[iboundz1][i].second, j);
 
     // create_support (mesh.cxx:3287-3329)
     m.sup_idx.assign((size_t)nnode + 1, 0);
     for (int e = 0; e < nelem; ++e)
-        for (int i = 0; i < 4; ++i) m.sup_idx[m.conn[(size_t)i*nelem + e] + 1]++;
+        for (int i = 0; i < npe; ++i) m.sup_idx[m.conn[(size_t)i*nelem + e] + 1]++;
     for (int n = 1; n <= nnode; ++n) m.sup_idx[n] += m.sup_idx[n-1];
     m.sup_arr.resize((size_t)m.sup_idx[nnode]);
     m.sup_lidx.resize((size_t)m.sup_idx[nnode]);
     {
         std::vector<int> cursor(m.sup_idx.begin(), m.sup_idx.end() - 1);
         for (int e = 0; e < nelem; ++e)
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < npe; ++i) {
                 int slot = cursor[m.conn[(size_t)i*nelem + e]]++;
                 m.sup_arr[slot] = e;
                 m.sup_lidx[slot] = i;
@@ -466,25 +550,25 @@ void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY])
 
     std::unordered_map<int,int> arctop;
     for (int i = 0; i < ntop; ++i) arctop[m.top_nodes[i]] = i;
-    m.elem_and_nodes.assign((size_t)3*etop, 0);
+    m.elem_and_nodes.assign((size_t)npf*etop, 0);
     for (int i = 0; i < etop; ++i)
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < npf; ++k)
             m.elem_and_nodes[(size_t)k*etop + i] = arctop[m.conn_surf[(size_t)k*etop + i]];
     // create_support_surf (mesh.cxx:2937-2962)
     m.ssup_idx.assign((size_t)ntop + 1, 0);
     for (int i = 0; i < etop; ++i)
-        for (int k = 0; k < 3; ++k) m.ssup_idx[m.elem_and_nodes[(size_t)k*etop + i] + 1]++;
+        for (int k = 0; k < npf; ++k) m.ssup_idx[m.elem_and_nodes[(size_t)k*etop + i] + 1]++;
     for (int n = 1; n <= ntop; ++n) m.ssup_idx[n] += m.ssup_idx[n-1];
     m.ssup_arr.resize((size_t)m.ssup_idx[ntop]);
     {
         std::vector<int> cursor(m.ssup_idx.begin(), m.ssup_idx.end() - 1);
         for (int i = 0; i < etop; ++i)
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < npf; ++k)
                 m.ssup_arr[cursor[m.elem_and_nodes[(size_t)k*etop + i]]++] = i;
     }
 
     // create_boundary_normals (bc.cxx:94-224)
-    m.bnormals.assign((size_t)3*DES_NBDRY, 0.0);
+    m.bnormals.assign((size_t)nd*DES_NBDRY, 0.0);
     for (int i = 0; i < DES_NBDRY; i++) {
         const size_t nf = m.bfacet_elem[i].size();
         if (nf == 0) continue;
@@ -492,16 +576,16 @@ void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY])
             double normal[3];
             facet_normal(m, m.bfacet_elem[i][j], m.bfacet_facet[i][j], normal);
             double len = 0;
-            for (int d = 0; d < 3; d++) len += normal[d]*normal[d];
+            for (int d = 0; d < nd; d++) len += normal[d]*normal[d];
             len = std::sqrt(len);
-            for (int d = 0; d < 3; d++) normal[d] = normal[d] / len;
+            for (int d = 0; d < nd; d++) normal[d] = normal[d] / len;
             if (j == 0) {
-                for (int d = 0; d < 3; d++) m.bnormals[(size_t)d*DES_NBDRY + i] = normal[d];
+                for (int d = 0; d < nd; d++) m.bnormals[(size_t)d*DES_NBDRY + i] = normal[d];
                 if (i < iboundn0) break;
             } else {
                 const double eps2 = 1e-12;
                 double diff2 = 0;
-                for (int d = 0; d < 3; d++) {
+                for (int d = 0; d < nd; d++) {
                     double t = m.bnormals[(size_t)d*DES_NBDRY + i] - normal[d];
                     diff2 += t * t;
                 }
@@ -517,6 +601,12 @@ void build_topology(HostMesh &m, const int vbc_types[DES_NBDRY])
         const double eps = 1e-15;
         for (int j = i+1; j < DES_NBDRY; j++) {
             if (m.bfacet_elem[j].empty()) continue;
+            if (nd == 2) {
+                // bc.cxx:181-184: the "edge" two boundaries share in 2-D is the vertical
+                m.edge_slot[i*DES_NBDRY + j] = (int)(m.edge_vec.size() / 2);
+                m.edge_vec.push_back(0); m.edge_vec.push_back(1);
+                continue;
+            }
             const double ni[3] = {m.bnormals[i], m.bnormals[DES_NBDRY+i], m.bnormals[2*DES_NBDRY+i]};
             const double nj[3] = {m.bnormals[j], m.bnormals[DES_NBDRY+j], m.bnormals[2*DES_NBDRY+j]};
             double s[3];
@@ -551,7 +641,7 @@ des_mesh HostMesh::view() const
     }
     v.bnormals = bnormals.data();
     v.edge_vec = edge_vec.data();
-    v.nedge = (int)(edge_vec.size() / 3);
+    v.nedge = (int)(edge_vec.size() / nd);
     std::memcpy(v.edge_slot, edge_slot, sizeof(edge_slot));
     v.ntop = (int)top_nodes.size();
     v.etop = (int)bfacet_elem[iboundz1].size();

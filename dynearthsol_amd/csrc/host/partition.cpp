@@ -246,6 +246,8 @@ des_part *des_host_partition(const des_host *h, int nranks, int rank, int *err)
 {
     des_part *P = new des_part();
     try {
+        if (des_host_mesh_internal(h)->nd != 3)
+            throw des::Error(DES_ERR_UNSUPPORTED_DIM, "the slab decomposition is built for 3-D meshes only");
         des::build_partition(*des_host_mesh_internal(h), nranks, rank, *P);
         if (err) *err = DES_OK;
         return P;

@@ -22,6 +22,13 @@ typedef struct des_host des_host;
 des_host *des_host_create(const char *cfg_path, const char *overrides, const char *mesh_file, int *err);
 /* same, from an in-memory config text */
 des_host *des_host_create_from_string(const char *cfg_text, const char *overrides, const char *mesh_file, int *err);
+/* The reference is built either -DTHREED (tets) or 2-D (triangles; constants.hpp:12-25, `make
+ * ndims=2`); the same host library serves both, the dimension being an argument: ndims = 3 or 2,
+ * exactly one of cfg_path / cfg_text given.  The two entry points above are the ndims = 3 case.
+ * In a 2-D host every array is the reference's 2-D one: coord [2][nnode] = {x, z}, connectivity
+ * [3][nelem], tensors {XX, ZZ, XZ}, "stressyy" [nelem] (plane strain). */
+des_host *des_host_create_nd(int ndims, const char *cfg_path, const char *cfg_text, const char *overrides,
+                             const char *mesh_file, int *err);
 void des_host_destroy(des_host *h);
 
 const des_params *des_host_params(const des_host *h);

@@ -21,6 +21,7 @@ extern "C" {
 #define DES_MAX_MAT     16   /* max. number of material types carried in des_params */
 #define DES_NBDRY       10   /* constants.hpp:27-38  (x0,x1,y0,y1,z0,z1,n0..n3)      */
 #define DES_NBDRY_SIDE   6
+#define DES_MAX_PERIOD   8   /* max. entries of bc.vbc_period_x{0,1}_* carried in des_params   */
 
 /* rheology bit flags, matprops.hpp:88-97 */
 enum {
@@ -43,7 +44,8 @@ enum {
 /* POD copy of the Param members the hot path reads (parameters.hpp:206-473) plus the
  * run constants main() derives once (dynearthsol.cxx:55-124, 207). */
 typedef struct des_params {
-    int ndims;                      /* 3 (THREED build); 2 is rejected by the device path for now */
+    int ndims;                      /* 3: the THREED build (tets); 2: the 2-D build (triangles; coordinates
+                                     * {x, z}, tensors {XX, ZZ, XZ}, constants.hpp:12-25)          */
     int nmat;                       /* mat.nmat                                                     */
     int rheol_type;                 /* mat.rheol_type, DES_RH_*                                     */
     int mattype_ref;                /* mat.mattype_ref                                              */
@@ -113,13 +115,25 @@ typedef struct des_params {
     int has_PT;
     int PT_max_iter;
     double PT_relative_tolerance;
+
+    /* read by the 2-D build only (the reference's !THREED branches) */
+    int is_plane_strain;            /* mat.is_plane_strain: elasto_plastic2d (rheology.cxx:486-701) + stressyy */
+    int mattype_oceanic_crust;      /* mat.mattype_oceanic_crust (surface_plstrain_diffusion, bc.cxx:1633-1653) */
+    int num_vbc_period_x0, num_vbc_period_x1;               /* bc.cxx:247-249 */
+    double vbc_period_x0_time_in_yr[DES_MAX_PERIOD], vbc_period_x0_ratio[DES_MAX_PERIOD];
+    double vbc_period_x1_time_in_yr[DES_MAX_PERIOD], vbc_period_x1_ratio[DES_MAX_PERIOD];
+    double vbc_vertical_div_x0[4], vbc_vertical_div_x1[4];     /* Variables::vbc_vertical_div_x? (dynearthsol.cxx:85-92)   */
+    double vbc_vertical_ratio_x0[4], vbc_vertical_ratio_x1[4]; /* Variables::vbc_vertical_ratio_x? (dynearthsol.cxx:94-101) */
+    double bottom_shear_zone_thickness;                        /* bc.cxx:446-451 */
+    double surf_diff_ratio_terrig, surf_diff_ratio_marine;     /* surfinfo.diff_ratio_* (mesh.cxx:3063-3064, bc.cxx:1098-1104) */
 } des_params;
 
 /* Mesh topology as the reference builds it once per (re)mesh (mesh.cxx:2837-3329,
  * bc.cxx:94-224).  All pointers are host pointers, read during create() only. */
 typedef struct des_mesh {
     int nnode, nelem;
-    const int *connectivity;        /* conn_t, SoA [4][nelem]                                       */
+    const int *connectivity;        /* conn_t, SoA [4][nelem] ([3][nelem] in 2-D: every "4" / "3" below is
+                                     * NODES_PER_ELEM / NDIMS of the build, constants.hpp:12-25)    */
     /* Support CSR (parameters.hpp:585-610): node n owns [idx[n], idx[n+1]) */
     const int *support_idx;         /* [nnode+1] */
     const int *support_arr;         /* [4*nelem] element ids, ascending per node                    */
@@ -217,6 +231,7 @@ enum des_field {
     DES_F_DPLSTRAIN_AVG,    /* E  double_vec running sum of delta_plstrain                       */
     DES_F_STRAIN0,          /* E  tensor_t  strain at the first step of the interval             */
     DES_F_COORD_AVG0,       /* N  array_t   coordinates at the first step of the interval        */
+    DES_F_STRESSYY,         /* E  double_vec Variables::stressyy (fields.cxx:75); 2-D engines only */
     DES_F_COUNT
 };
 

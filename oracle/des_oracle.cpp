@@ -14,7 +14,9 @@
  * eigen-solver restatement below.  Whole-step behaviour is pinned against the run
  * anchors recorded in SURVEY.md Appendix A.
  *
- * 3D only (the THREED build of the reference).
+ * Dimension: a compile-time switch like the reference's own (-DTHREED, constants.hpp:12-25):
+ * the default build restates the THREED branches (libdes_oracle.so), -DDES_NDIMS=2 the 2-D
+ * (triangle) ones (libdes_oracle2d.so, same exports).
  */
 #include "des_oracle.h"
 #include "../dynearthsol_amd/csrc/des_libm.hpp"   /* the portable libm, for des_oracle_set_libm(1) only */
@@ -44,12 +46,20 @@ inline double m_cos(double a) { return g_portable_libm ? deslibm::cos(a) : std::
 inline double m_tan(double a) { return g_portable_libm ? deslibm::tan(a) : std::tan(a); }
 inline double m_atan2(double y, double x) { return g_portable_libm ? deslibm::atan2(y, x) : std::atan2(y, x); }
 
-const int ND = 3;            // NDIMS, constants.hpp:12-16
-const int NPE = 4;           // NODES_PER_ELEM, constants.hpp:19
-const int NSTR = 6;          // constants.hpp:25
-const int NPF = 3;           // NODES_PER_FACET, constants.hpp:60
-// constants.hpp:64-69
+#ifndef DES_NDIMS
+#define DES_NDIMS 3
+#endif
+const int ND = DES_NDIMS;    // NDIMS, constants.hpp:12-16
+const int NPE = ND + 1;      // NODES_PER_ELEM, constants.hpp:19
+const int NSTR = ND * (ND + 1) / 2;   // constants.hpp:25
+const int NPF = ND;          // NODES_PER_FACET, constants.hpp:60
+// constants.hpp:64-76
+#if DES_NDIMS == 3
 const int NODE_OF_FACET[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};
+#else
+const int NODE_OF_FACET[3][2] = {{1,2},{2,0},{0,1}};
+#endif
+const double YEAR2SEC = 365.2422 * 86400;   // constants.hpp:76
 const unsigned BOUNDZ0 = 1u << 4, BOUNDZ1 = 1u << 5;
 const unsigned BOUND_ANY = 0x3ffu;
 const int iboundx0 = 0, iboundz0 = 4, iboundz1 = 5, iboundn0 = 6, iboundn3 = 9;
@@ -68,7 +78,7 @@ struct des_oracle {
     long long n_pt_iterations = 0;      // iterations taken since the last des_oracle_step call began
     int n_return_mapping = 0;           // elements past the yield pre-filter in the last update_stress
     // topology
-    ivec conn;                          // [4][ne]
+    ivec conn;                          // [NPE][ne]
     ivec sup_idx, sup_arr, sup_lidx;
     std::vector<unsigned> bcflag;
     ivec bf_elem[DES_NBDRY], bf_facet[DES_NBDRY], bnodes[DES_NBDRY];
@@ -80,6 +90,7 @@ struct des_oracle {
     dvec coord, vel, force, force_residual, coord0, temperature, volume_n, mass, tmass,
          hmass, ymass, dhacc, ntmp, total_dx, total_slope;
     // element fields
+    dvec stressyy;                      // plane-strain out-of-plane stress (fields.cxx:75); 2-D only
     dvec stress, strain, strain_rate, plstrain, delta_plstrain, viscosity, volume,
          volume_old, dpressure, edvoldt, radiogenic, etmp, tmp_result;
     ivec elemmarkers, etmp_int;
@@ -349,15 +360,45 @@ void principal_stresses3(const double *s, double p[3], double v[3][3])
     sort_principal3(p, v);
 }
 
-inline double trace3(const double *s) { return s[0] + s[1] + s[2]; }   // utils.hpp:211-219
+// utils.hpp:211-219
+#if DES_NDIMS == 3
+inline double trace3(const double *s) { return s[0] + s[1] + s[2]; }
+#else
+inline double trace3(const double *s) { return s[0] + s[1]; }
+#endif
 
-// utils.hpp:222-231 (3D)
+// utils.hpp:222-231
 inline double second_invariant2(const double *t)
 {
+#if DES_NDIMS == 3
     double a = (t[0] + t[1] + t[2]) / 3;
     return (0.5 * ((t[0]-a)*(t[0]-a) + (t[1]-a)*(t[1]-a) + (t[2]-a)*(t[2]-a))
             + t[3]*t[3] + t[4]*t[4] + t[5]*t[5]);
+#else
+    return 0.25*(t[0]-t[1])*(t[0]-t[1]) + t[2]*t[2];
+#endif
 }
+
+#if DES_NDIMS == 2
+// rheology.cxx:86-119: Mohr circle of {XX, ZZ, XZ}; p[0] <= p[1]
+void principal_stresses2(const double *s, double p[2], double &cos2t, double &sin2t)
+{
+    double s0 = 0.5 * (s[0] + s[1]);
+    double rad = std::sqrt(second_invariant2(s));     // second_invariant, utils.hpp:234-241
+    p[0] = s0 - rad;
+    p[1] = s0 + rad;
+    const double eps = 1e-15;
+    double a = 0.5 * (s[0] - s[1]);
+    double b = - rad;
+    if (b < -eps) {
+        cos2t = a / b;
+        sin2t = s[2] / b;
+    } else {
+        cos2t = 1;
+        sin2t = 0;
+    }
+}
+#endif
 
 // rheology.cxx:248-260
 void elastic(double bulkm, double shearm, const double *de, double *s)
@@ -397,7 +438,7 @@ void viscous(double bulkm, double viscosity, double total_dv, const double *edot
 
 const double YIELD_PREFILTER_MARGIN = 1e-2;   // rheology.cxx:18
 
-// rheology.cxx:312-484 (THREED branch, has_hydraulic_diffusion == false)
+// rheology.cxx:312-484 (has_hydraulic_diffusion == false)
 void elasto_plastic(double bulkm, double shearm, double amc, double anphi, double anpsi,
                     double hardn, double ten_max, const double *de, double &depls,
                     double *s, int &failure_mode, int *past_prefilter = nullptr)
@@ -406,6 +447,44 @@ void elasto_plastic(double bulkm, double shearm, double amc, double anphi, doubl
     depls = 0;
     failure_mode = 0;
 
+#if DES_NDIMS == 2
+    // rheology.cxx:364-369, 371-483 with NDIMS = 2: pure 2-D Mohr-Coulomb in the X-Z plane
+    double p[2];
+    double cos2t, sin2t;
+    if (past_prefilter) *past_prefilter = 1;       // no pre-filter in 2-D: every element reaches the yield test
+    principal_stresses2(s, p, cos2t, sin2t);
+
+    double fs = p[0] - p[1] * anphi + amc;
+    double ft = p[1] - ten_max;
+    if (fs > 0 && ft < 0)
+        return;
+
+    double pa = std::sqrt(1 + anphi*anphi) + anphi;
+    double ps = ten_max * anphi - amc;
+    double h = p[1] - ten_max + pa * (p[0] - ps);
+    double a1 = bulkm + 4. / 3 * shearm;
+    double a2 = bulkm - 2. / 3 * shearm;
+
+    double alam;
+    if (h < 0) {
+        failure_mode = 10;
+        alam = fs / (a1 - a2*anpsi + a1*anphi*anpsi - a2*anphi + 2*std::sqrt(anphi)*hardn);
+        p[0] -= alam * (a1 - a2 * anpsi);
+        p[1] -= alam * (a2 - a1 * anpsi);
+        depls = std::fabs(alam) * std::sqrt((3 + 2*anpsi + 3*anpsi*anpsi) / 8);
+    } else {
+        failure_mode = 1;
+        alam = ft / a1;
+        p[0] -= alam * a2;
+        p[1] -= alam * a1;
+        depls = std::fabs(alam) * std::sqrt(3. / 8);
+    }
+    double dc2 = (p[0] - p[1]) * cos2t;
+    double dss = p[0] + p[1];
+    s[0] = 0.5 * (dss + dc2);
+    s[1] = 0.5 * (dss - dc2);
+    s[2] = 0.5 * (p[0] - p[1]) * sin2t;
+#else
     double p[3];
     double v[3][3];
     {
@@ -456,7 +535,109 @@ void elasto_plastic(double bulkm, double shearm, double amc, double anphi, doubl
                 ss[m][n] += v[m][k] * v[n][k] * p[k];
     s[0] = ss[0][0]; s[1] = ss[1][1]; s[2] = ss[2][2];
     s[3] = ss[0][1]; s[4] = ss[0][2]; s[5] = ss[1][2];
+#endif
 }
+
+#if DES_NDIMS == 2
+// rheology.cxx:486-701 (plane strain: three principal stresses, two principal strains;
+// has_hydraulic_diffusion == false)
+void elasto_plastic2d(double bulkm, double shearm, double amc, double anphi, double anpsi,
+                      double hardn, double ten_max, const double *de, double &depls,
+                      double *s, double &syy, int &failure_mode)
+{
+    depls = 0;
+    failure_mode = 0;
+
+    double a1 = bulkm + 4. / 3 * shearm;
+    double a2 = bulkm - 2. / 3 * shearm;
+    double sxx = s[0] + de[1]*a2 + de[0]*a1;
+    double szz = s[1] + de[0]*a2 + de[1]*a1;
+    double sxz = s[2] + de[2]*2*shearm;
+    syy += (de[0] + de[1]) * a2;
+
+    double p[3];
+    double cos2t, sin2t;
+    int n1, n2, n3;
+    {
+        double s0 = 0.5 * (sxx + szz);
+        double rad = 0.5 * std::sqrt((sxx-szz)*(sxx-szz) + 4*sxz*sxz);
+        double si = s0 - rad;
+        double sii = s0 + rad;
+        const double eps = 1e-15;
+        if (rad > eps) {
+            cos2t = 0.5 * (szz - sxx) / rad;
+            sin2t = -sxz / rad;
+        } else {
+            cos2t = 1;
+            sin2t = 0;
+        }
+        if (syy > sii) {
+            n1 = 0; n2 = 1; n3 = 2;
+            p[0] = si; p[1] = sii; p[2] = syy;
+        } else if (syy < si) {
+            n1 = 1; n2 = 2; n3 = 0;
+            p[0] = syy; p[1] = si; p[2] = sii;
+        } else {
+            n1 = 0; n2 = 2; n3 = 1;
+            p[0] = si; p[1] = syy; p[2] = sii;
+        }
+    }
+
+    if (p[0] >= ten_max) {
+        s[0] = s[1] = syy = ten_max;
+        s[2] = 0.0;
+        failure_mode = 1;
+        return;
+    }
+    if (p[1] >= ten_max) {
+        p[1] = p[2] = ten_max;
+        failure_mode = 2;
+    } else if (p[2] >= ten_max) {
+        p[2] = ten_max;
+        failure_mode = 3;
+    }
+
+    double fs = p[0] - p[2] * anphi + amc;
+    if (fs >= 0.0) {
+        s[0] = sxx;
+        s[1] = szz;
+        s[2] = sxz;
+        return;
+    }
+
+    failure_mode += 10;
+
+    const double alams = fs / (a1 - a2*anpsi + a1*anphi*anpsi - a2*anphi + hardn);
+    p[0] -= alams * (a1 - a2 * anpsi);
+    p[1] -= alams * (a2 - a2 * anpsi);
+    p[2] -= alams * (a2 - a1 * anpsi);
+
+    depls = 0.5 * std::fabs(alams + alams * anpsi);
+
+    if (p[0] >= ten_max) {
+        s[0] = s[1] = syy = ten_max;
+        s[2] = 0.0;
+        failure_mode += 20;
+        return;
+    }
+    if (p[1] >= ten_max) {
+        p[1] = p[2] = ten_max;
+        failure_mode += 20;
+    } else if (p[2] >= ten_max) {
+        p[2] = ten_max;
+        failure_mode += 20;
+    }
+
+    {
+        double dc2 = (p[n1] - p[n2]) * cos2t;
+        double dss = p[n1] + p[n2];
+        s[0] = 0.5 * (dss + dc2);
+        s[1] = 0.5 * (dss - dc2);
+        s[2] = 0.5 * (p[n1] - p[n2]) * sin2t;
+        syy = p[n3];
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------
 // PREM reference pressure, matprops.cxx:12-101, 153-174
@@ -542,8 +723,8 @@ struct Mat {
     double visc(int e) const {
         const double min_strain_rate = 1e-30;
         double T = elemT(e);
-        double s6[6], e6[6];
-        for (int i = 0; i < 6; ++i) {
+        double s6[NSTR], e6[NSTR];
+        for (int i = 0; i < NSTR; ++i) {
             s6[i] = o.stress[i * o.ne + e];
             e6[i] = o.strain_rate[i * o.ne + e];
         }
@@ -665,9 +846,9 @@ void refresh_elem_cache(des_oracle &o)
 // ---------------------------------------------------------------------------------
 // geometry helpers
 // ---------------------------------------------------------------------------------
-inline void node_xyz(const dvec &a, int nn, int n, double x[3])
+inline void node_xyz(const dvec &a, int nn, int n, double x[ND])
 {
-    x[0] = a[n]; x[1] = a[nn + n]; x[2] = a[2 * nn + n];
+    for (int d = 0; d < ND; ++d) x[d] = a[(size_t)d * nn + n];
 }
 
 // geometry.cxx:36-56
@@ -687,16 +868,41 @@ double tetrahedron_volume(const double *d0, const double *d1, const double *d2, 
             x23*(y12*z01 - y01*z12)) / 6;
 }
 
-// geometry.cxx:77-107 (THREED)
+// geometry.cxx:77-107
 double triangle_area(const double *a, const double *b, const double *c)
 {
     double ab0 = b[0] - a[0], ab1 = b[1] - a[1];
     double ac0 = c[0] - a[0], ac1 = c[1] - a[1];
+#if DES_NDIMS == 2
+    return std::fabs(ab0*ac1 - ab1*ac0) / 2;
+#else
     double ab2 = b[2] - a[2], ac2 = c[2] - a[2];
     double d0 = ab1*ac2 - ab2*ac1;
     double d1 = ab2*ac0 - ab0*ac2;
     double d2 = ab0*ac1 - ab1*ac0;
     return std::sqrt(d0*d0 + d1*d1 + d2*d2) / 2;
+#endif
+}
+
+// compute_volume(ConstArrayIndirectAccessor), geometry.cxx:123-135
+inline double elem_volume(const double d[NPE][ND])
+{
+#if DES_NDIMS == 3
+    return tetrahedron_volume(d[0], d[1], d[2], d[3]);
+#else
+    return triangle_area(d[0], d[1], d[2]);
+#endif
+}
+
+// dist2, geometry.cxx:16-25
+inline double dist2(const double *a, const double *b)
+{
+    double sum = 0;
+    for (int i = 0; i < ND; ++i) {
+        double d = b[i] - a[i];
+        sum += d * d;
+    }
+    return sum;
 }
 
 // geometry.cxx:59-73
@@ -707,17 +913,29 @@ double triangle_area2d(const double *a, const double *b, const double *c)
     return std::fabs(ab0*ac1 - ab1*ac0) / 2;
 }
 
-void elem_coords(const des_oracle &o, int e, double d[4][3])
+void elem_coords(const des_oracle &o, int e, double d[NPE][ND])
 {
     for (int i = 0; i < NPE; ++i)
         node_xyz(o.coord, o.nn, o.conn[i * o.ne + e], d[i]);
 }
 
-// fields.cxx:11-38
-void get_local_shape_fn(const des_oracle &o, int e, double shpdx[4], double shpdy[4], double shpdz[4])
+// fields.cxx:11-38 (THREED), 40-53 (2-D: shpdy is left untouched)
+void get_local_shape_fn(const des_oracle &o, int e, double shpdx[NPE], double shpdy[NPE], double shpdz[NPE])
 {
-    double d[4][3];
+    double d[NPE][ND];
     elem_coords(o, e, d);
+#if DES_NDIMS == 2
+    (void)shpdy;
+    double iv = 1.0 / (2.0 * o.volume[e]);
+
+    shpdx[0] = iv * (d[1][1] - d[2][1]);
+    shpdx[1] = iv * (d[2][1] - d[0][1]);
+    shpdx[2] = iv * (d[0][1] - d[1][1]);
+
+    shpdz[0] = iv * (d[2][0] - d[1][0]);
+    shpdz[1] = iv * (d[0][0] - d[2][0]);
+    shpdz[2] = iv * (d[1][0] - d[0][0]);
+#else
     double iv = 1.0 / (6.0 * o.volume[e]);
 
     double x01 = d[0][0] - d[1][0]; double x02 = d[0][0] - d[2][0]; double x03 = d[0][0] - d[3][0];
@@ -741,6 +959,7 @@ void get_local_shape_fn(const des_oracle &o, int e, double shpdx[4], double shpd
     shpdz[1] = iv * (x02*y23 - x23*y02);
     shpdz[2] = iv * (x13*y03 - x03*y13);
     shpdz[3] = iv * (x01*y02 - x02*y01);
+#endif
 }
 
 // geometry.cxx:170-201
@@ -748,9 +967,9 @@ void compute_volume(des_oracle &o, dvec &volume)
 {
     #pragma omp parallel for
     for (int e = 0; e < o.ne; ++e) {
-        double d[4][3];
+        double d[NPE][ND];
         elem_coords(o, e, d);
-        volume[e] = tetrahedron_volume(d[0], d[1], d[2], d[3]);
+        volume[e] = elem_volume(d);
     }
 }
 
@@ -766,13 +985,18 @@ void update_temperature(des_oracle &o)
     for (int e = 0; e < ne; e++) {
         double kv = mat.k(e) * o.volume[e];
         double rh = o.radiogenic[e] * o.volume[e] * mat.rho(e) / NPE;
-        double shpdx[4], shpdy[4], shpdz[4];
+        double shpdx[NPE], shpdy[NPE], shpdz[NPE];
         get_local_shape_fn(o, e, shpdx, shpdy, shpdz);
         for (int i = 0; i < NPE; ++i) {
             double diffusion = 0.;
             for (int j = 0; j < NPE; ++j)
+#if DES_NDIMS == 3
                 diffusion += (shpdx[i] * shpdx[j] + shpdy[i] * shpdy[j] + shpdz[i] * shpdz[j])
                              * o.temperature[o.conn[j * ne + e]];
+#else
+                diffusion += (shpdx[i] * shpdx[j] + shpdz[i] * shpdz[j])
+                             * o.temperature[o.conn[j * ne + e]];
+#endif
             o.tmp_result[i * ne + e] = diffusion * kv - rh;
         }
     }
@@ -795,18 +1019,24 @@ void update_strain_rate(des_oracle &o)
     const int ne = o.ne, nn = o.nn;
     #pragma omp parallel for
     for (int e = 0; e < ne; ++e) {
-        double shpdx[4], shpdy[4], shpdz[4];
+        double shpdx[NPE], shpdy[NPE], shpdz[NPE];
         get_local_shape_fn(o, e, shpdx, shpdy, shpdz);
-        double v[4][3];
+        double v[NPE][ND];
         for (int i = 0; i < NPE; ++i)
             node_xyz(o.vel, nn, o.conn[i * ne + e], v[i]);
-        double s[6];
+        double s[NSTR];
+#if DES_NDIMS == 3
         s[0] = 0; for (int i = 0; i < NPE; ++i) s[0] += v[i][0] * shpdx[i];
         s[1] = 0; for (int i = 0; i < NPE; ++i) s[1] += v[i][1] * shpdy[i];
         s[2] = 0; for (int i = 0; i < NPE; ++i) s[2] += v[i][2] * shpdz[i];
         s[3] = 0; for (int i = 0; i < NPE; ++i) s[3] += 0.5 * (v[i][0] * shpdy[i] + v[i][1] * shpdx[i]);
         s[4] = 0; for (int i = 0; i < NPE; ++i) s[4] += 0.5 * (v[i][0] * shpdz[i] + v[i][2] * shpdx[i]);
         s[5] = 0; for (int i = 0; i < NPE; ++i) s[5] += 0.5 * (v[i][1] * shpdz[i] + v[i][2] * shpdy[i]);
+#else
+        s[0] = 0; for (int i = 0; i < NPE; ++i) s[0] += v[i][0] * shpdx[i];
+        s[1] = 0; for (int i = 0; i < NPE; ++i) s[1] += v[i][1] * shpdz[i];
+        s[2] = 0; for (int i = 0; i < NPE; ++i) s[2] += 0.5 * (v[i][0] * shpdz[i] + v[i][1] * shpdx[i]);
+#endif
         for (int i = 0; i < NSTR; ++i) o.strain_rate[i * ne + e] = s[i];
     }
 }
@@ -817,7 +1047,11 @@ void compute_dvoldt(des_oracle &o)
     const int ne = o.ne;
     #pragma omp parallel for
     for (int e = 0; e < ne; e++) {
+#if DES_NDIMS == 3
         double dj = o.strain_rate[e] + o.strain_rate[ne + e] + o.strain_rate[2 * ne + e];
+#else
+        double dj = o.strain_rate[e] + o.strain_rate[ne + e];      // trace(strain_rate)
+#endif
         o.etmp[e] = dj * o.volume[e];
     }
     #pragma omp parallel for
@@ -852,7 +1086,7 @@ void update_stress(des_oracle &o)
     #pragma omp parallel for reduction(+:n_past)
     for (int e = 0; e < ne; e++) {
         int past = 0;
-        double s[6], es[6], edot[6];
+        double s[NSTR], es[NSTR], edot[NSTR];
         for (int i = 0; i < NSTR; ++i) {
             s[i] = o.stress[i * ne + e];
             es[i] = o.strain[i * ne + e];
@@ -871,7 +1105,7 @@ void update_stress(des_oracle &o)
         for (int i = 0; i < NSTR; ++i) o.strain_rate[i * ne + e] = edot[i];
 
         for (int i = 0; i < NSTR; ++i) es[i] += edot[i] * o.dt;
-        double de[6];
+        double de[NSTR];
         for (int i = 0; i < NSTR; ++i) de[i] = edot[i] * o.dt;
 
         o.delta_plstrain[e] = 0.;
@@ -898,6 +1132,12 @@ void update_stress(des_oracle &o)
             double amc, anphi, anpsi, hardn, ten_max;
             mat.plastic_props(e, o.plstrain[e], amc, anphi, anpsi, hardn, ten_max);
             int failure_mode;
+#if DES_NDIMS == 2
+            if (p.is_plane_strain)
+                elasto_plastic2d(mat.bulkm(e), mat.shearm(e), amc, anphi, anpsi, hardn, ten_max,
+                                 de, depls, s, o.stressyy[e], failure_mode);
+            else
+#endif
             elasto_plastic(mat.bulkm(e), mat.shearm(e), amc, anphi, anpsi, hardn, ten_max,
                            de, depls, s, failure_mode, &past);
             n_past += past;
@@ -910,16 +1150,24 @@ void update_stress(des_oracle &o)
             double bulkm = mat.bulkm(e), shearm = mat.shearm(e);
             o.viscosity[e] = mat.visc(e);
             double dv = o.volume[e] / o.volume_old[e] - 1;
-            double sv[6];
+            double sv[NSTR];
             for (int i = 0; i < NSTR; ++i) sv[i] = s[i];
             maxwell(bulkm, shearm, o.viscosity[e], o.dt, dv, de, sv);
             double svII = second_invariant2(sv);
 
             double amc, anphi, anpsi, hardn, ten_max;
             mat.plastic_props(e, o.plstrain[e], amc, anphi, anpsi, hardn, ten_max);
-            double sp[6];
+            double sp[NSTR];
             for (int i = 0; i < NSTR; ++i) sp[i] = s[i];
             int failure_mode;
+#if DES_NDIMS == 2
+            double spyy = 0;
+            if (p.is_plane_strain) {
+                spyy = o.stressyy[e];
+                elasto_plastic2d(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max,
+                                 de, depls, sp, spyy, failure_mode);
+            } else
+#endif
             elasto_plastic(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max,
                            de, depls, sp, failure_mode, &past);
             n_past += past;
@@ -931,6 +1179,9 @@ void update_stress(des_oracle &o)
                 for (int i = 0; i < NSTR; ++i) s[i] = sp[i];
                 o.plstrain[e] += depls;
                 o.delta_plstrain[e] = depls;
+#if DES_NDIMS == 2
+                if (p.is_plane_strain) o.stressyy[e] = spyy;
+#endif
             }
             break;
         }
@@ -981,9 +1232,17 @@ void NMD_stress_apply(des_oracle &o)
     }
 }
 
-// bc.cxx:24-54 (THREED)
-void normal_vector_of_facet(const double fc[3][3], double *normal, double &zcenter)
+// bc.cxx:24-54
+void normal_vector_of_facet(const double fc[NPF][ND], double *normal, double &zcenter)
 {
+#if DES_NDIMS == 2
+    double v01[ND];
+    for (int i = 0; i < ND; ++i)
+        v01[i] = fc[1][i] - fc[0][i];
+    normal[0] = v01[1];
+    normal[1] = -v01[0];
+    zcenter = (fc[0][1] + fc[1][1]) / NPF;
+#else
     double v01[3], v02[3];
     for (int i = 0; i < ND; ++i) {
         v01[i] = fc[1][i] - fc[0][i];
@@ -993,6 +1252,7 @@ void normal_vector_of_facet(const double fc[3][3], double *normal, double &zcent
     normal[1] = (v01[2] * v02[0] - v01[0] * v02[2]) / 2;
     normal[2] = (v01[0] * v02[1] - v01[1] * v02[0]) / 2;
     zcenter = (fc[0][2] + fc[1][2] + fc[2][2]) / NPF;
+#endif
 }
 
 // bc.cxx:661-827
@@ -1016,8 +1276,8 @@ void apply_stress_bcs(des_oracle &o)
         for (int n = 0; n < bound; ++n) {
             int e = o.bf_elem[i][n];
             int f = o.bf_facet[i][n];
-            double normal[3], zcenter;
-            double fc[3][3];
+            double normal[ND], zcenter;
+            double fc[NPF][ND];
             for (int j = 0; j < NPF; ++j)
                 node_xyz(o.coord, nn, o.conn[NODE_OF_FACET[f][j] * ne + e], fc[j]);
             normal_vector_of_facet(fc, normal, zcenter);
@@ -1067,8 +1327,8 @@ void apply_stress_bcs(des_oracle &o)
     if (p.has_elastic_foundation) {
         for (size_t j = 0; j < o.bnodes[iboundz0].size(); ++j) {
             int n = o.bnodes[iboundz0][j];
-            o.force[2 * nn + n] -= p.elastic_foundation_constant
-                                   * (o.coord[2 * nn + n] - o.coord0[2 * nn + n]);
+            o.force[(ND-1) * nn + n] -= p.elastic_foundation_constant
+                                   * (o.coord[(ND-1) * nn + n] - o.coord0[(ND-1) * nn + n]);
         }
     }
 }
@@ -1084,16 +1344,21 @@ void apply_stress_bcs_neumann(des_oracle &o)
         for (int n = 0; n < bound; ++n) {
             int e = o.bf_elem[i][n];
             int f = o.bf_facet[i][n];
-            double normal[3] = {0, 0, 0}, zcenter = 0;
-            double fc[3][3];
+            double normal[ND] = {0}, zcenter = 0;
+            double fc[NPF][ND];
             for (int j = 0; j < NPF; ++j)
                 node_xyz(o.coord, nn, o.conn[NODE_OF_FACET[f][j] * ne + e], fc[j]);
             normal_vector_of_facet(fc, normal, zcenter);
-            double traction[3] = {0, 0, 0};
+            double traction[ND] = {0};
             switch (p.stress_bc_types[i]) {
+#if DES_NDIMS == 3
             case 1: traction[0] = p.stress_bc_values[i]; break;
             case 2: traction[1] = p.stress_bc_values[i]; break;
             case 3: traction[2] = p.stress_bc_values[i]; break;
+#else
+            case 1: traction[0] = p.stress_bc_values[i]; break;
+            case 3: traction[1] = p.stress_bc_values[i]; break;
+#endif
             default: continue;
             }
             for (int j = 0; j < NPF; ++j) {
@@ -1160,23 +1425,28 @@ void update_force(des_oracle &o)
     Mat mat(o);
     #pragma omp parallel for
     for (int e = 0; e < ne; e++) {
-        double shpdx[4], shpdy[4], shpdz[4];
+        double shpdx[NPE], shpdy[NPE], shpdz[NPE];
         get_local_shape_fn(o, e, shpdx, shpdy, shpdz);
-        double s[6];
+        double s[NSTR];
         for (int i = 0; i < NSTR; ++i) s[i] = o.stress[i * ne + e];
         double vol = o.volume[e];
         double buoy = 0;
         if (p.gravity != 0)
             buoy = (mat.rho(e) * (1 - mat.phi(e)) + 1000.0 * mat.phi(e)) * p.gravity / NPE;
         for (int i = 0; i < NPE; ++i) {
+#if DES_NDIMS == 3
             o.tmp_result[i * ne + e] = (s[0]*shpdx[i] + s[3]*shpdy[i] + s[4]*shpdz[i]) * vol;
             o.tmp_result[(i + NPE) * ne + e] = (s[3]*shpdx[i] + s[1]*shpdy[i] + s[5]*shpdz[i]) * vol;
             o.tmp_result[(i + NPE*2) * ne + e] = (s[4]*shpdx[i] + s[5]*shpdy[i] + s[2]*shpdz[i] + buoy) * vol;
+#else
+            o.tmp_result[i * ne + e] = (s[0]*shpdx[i] + s[2]*shpdz[i]) * vol;
+            o.tmp_result[(i + NPE) * ne + e] = (s[2]*shpdx[i] + s[1]*shpdz[i] + buoy) * vol;
+#endif
         }
     }
     #pragma omp parallel for
     for (int n = o.c0; n < o.c1; n++) {
-        double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
+        double f[ND] = {0}, fr[ND] = {0};
         for (int k = o.sup_idx[n]; k < o.sup_idx[n+1]; ++k) {
             const int e = o.sup_arr[k], i = o.sup_lidx[k];
             for (int j = 0; j < ND; j++) {
@@ -1216,6 +1486,187 @@ void update_velocity(des_oracle &o)
             o.vel[j*nn+i] += o.dt * o.force[j*nn+i] / o.mass[i];
 }
 
+#if DES_NDIMS == 2
+// utils.hpp:259-287: findNearestNeighbourIndex + interp1 over n ascending abscissae
+double interp1(const double *x, const double *y, int n, double x_new)
+{
+    double dist = DBL_MAX;
+    int idx = -1;
+    for (int i = 0; i < n; ++i) {
+        double newDist = x_new - x[i];
+        if (newDist >= 0 && newDist <= dist) {
+            dist = newDist;
+            idx = i;
+        }
+    }
+    double slope = 0;
+    if (idx < 0)
+        idx = 0;
+    else if (idx < n - 1)
+        slope = (y[idx+1] - y[idx]) / (x[idx+1] - x[idx]);
+    return slope * (x_new - x[idx]) + y[idx];
+}
+
+// bc.cxx:227-659, the !THREED branches: time-dependent x boundary values (:247-249), their
+// variation with depth along the side walls (:251-300, 427-429), the sheared bottom zone of
+// vbc_x0 = 3 (:446-451)
+void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
+{
+    const des_params &p = o.p;
+    const int nn = o.nn;
+    (void)all_local_nodes;
+    double t_now = o.time / YEAR2SEC;
+    double vbc_applied_x0 = p.vbc_values[0] * interp1(p.vbc_period_x0_time_in_yr, p.vbc_period_x0_ratio, p.num_vbc_period_x0, t_now);
+    double vbc_applied_x1 = p.vbc_values[1] * interp1(p.vbc_period_x1_time_in_yr, p.vbc_period_x1_ratio, p.num_vbc_period_x1, t_now);
+
+    double BOUNDX0_max = 0., BOUNDX0_min = 0., BOUNDX1_max = 0., BOUNDX1_min = 0.;
+    bool if_init0 = false, if_init1 = false;
+    for (int i = 0; i < nn; ++i) {
+        unsigned flag = o.bcflag[i];
+        if (!(flag & BOUND_ANY)) continue;
+        double z = o.coord[nn + i];
+        if (flag & 1u) {
+            if (!if_init0) { BOUNDX0_max = z; BOUNDX0_min = z; if_init0 = true; }
+            else { if (z > BOUNDX0_max) BOUNDX0_max = z; if (z < BOUNDX0_min) BOUNDX0_min = z; }
+        } else if (flag & 2u) {
+            if (!if_init1) { BOUNDX1_max = z; BOUNDX1_min = z; if_init1 = true; }
+            else { if (z > BOUNDX1_max) BOUNDX1_max = z; if (z < BOUNDX1_min) BOUNDX1_min = z; }
+        }
+    }
+    double BOUNDX0_width = BOUNDX0_max - BOUNDX0_min;
+    (void)BOUNDX1_max; (void)BOUNDX1_min;
+    double div_x0[4], div_x1[4];
+    for (int i = 0; i < 4; i++) {
+        div_x0[i] = - (BOUNDX0_max - p.vbc_vertical_div_x0[i] * BOUNDX0_width);
+        div_x1[i] = - (BOUNDX0_max - p.vbc_vertical_div_x1[i] * BOUNDX0_width);   // x0's extent: bc.cxx:299
+    }
+
+    int bc_x0 = p.vbc_types[0], bc_x1 = p.vbc_types[1];
+    int bc_z0 = p.vbc_types[4], bc_z1 = p.vbc_types[5];
+    double bc_vx0 = p.vbc_values[0], bc_vx1 = p.vbc_values[1];
+    double bc_vz0 = p.vbc_values[4], bc_vz1 = p.vbc_values[5];
+    const double bc_vx0_l = p.vbc_val_l[0], bc_vx1_l = p.vbc_val_l[1];
+    if (o.pt_jump) {
+        bc_vx0 = 0.0; bc_vx1 = 0.0; bc_vz0 = 0.0; bc_vz1 = 0.0;
+        vbc_applied_x0 = 0.0; vbc_applied_x1 = 0.0;
+    }
+    if (o.time > p.vbc_val_z1_loading_period) bc_z1 = 0;
+
+    double zmin = 0;
+    for (int k = 0; k < nn; ++k)
+        if (o.coord[nn + k] < zmin) zmin = o.coord[nn + k];
+
+    #pragma omp parallel for
+    for (int i = 0; i < nn; ++i) {
+        unsigned flag = o.bcflag[i];
+        if (!(flag & BOUND_ANY)) continue;
+        double v[2] = {o.vel[i], o.vel[nn+i]};
+        const double x1 = o.coord[nn + i];
+        double vbc_exact_x0 = vbc_applied_x0 * interp1(div_x0, p.vbc_vertical_ratio_x0, 4, -x1);
+        double vbc_exact_x1 = vbc_applied_x1 * interp1(div_x1, p.vbc_vertical_ratio_x1, 4, -x1);
+
+        if (flag & 1u) {
+            switch (bc_x0) {
+            case 0: break;
+            case 1: v[0] = vbc_exact_x0; break;
+            case 2: v[1] = 0; break;
+            case 3:
+                v[0] = vbc_exact_x0;
+                if (p.bottom_shear_zone_thickness > 0.) {
+                    double dz = x1 - zmin;
+                    if (dz < p.bottom_shear_zone_thickness)
+                        v[0] = v[0] * dz / p.bottom_shear_zone_thickness;
+                }
+                v[1] = 0;
+                break;
+            case 4: v[0] = 0; v[1] = bc_vx0; break;
+            case 6: v[0] = vbc_exact_x0; v[1] = bc_vx0_l; break;
+            }
+        }
+        if (flag & 2u) {
+            switch (bc_x1) {
+            case 0: break;
+            case 1: v[0] = vbc_exact_x1; break;
+            case 2: v[1] = 0; break;
+            case 3: v[0] = vbc_exact_x1; v[1] = 0; break;
+            case 4: v[0] = 0; v[1] = bc_vx1; break;
+            case 6: v[0] = vbc_exact_x1; v[1] = bc_vx1_l; break;
+            }
+        }
+
+        // slanted boundaries n0..n3, bc.cxx:491-585
+        for (int ib = iboundn0; ib <= iboundn3; ib++) {
+            if (!(flag & (1u << ib))) continue;
+            const double n[2] = {o.bnormals[ib], o.bnormals[DES_NBDRY + ib]};
+            double fac = 0;
+            switch (p.vbc_types[ib]) {
+            case 1:
+            case 11: {
+                const int nd = (p.vbc_types[ib] == 1) ? ND : ND-1;
+                double target = p.vbc_values[ib];
+                if (p.vbc_types[ib] == 11) {
+                    fac = 1 / std::sqrt(1 - n[ND-1]*n[ND-1]);
+                    target = p.vbc_values[ib] * fac;
+                }
+                if (flag == (1u << ib)) {
+                    double vn = 0;
+                    for (int d = 0; d < nd; d++) vn += v[d] * n[d];
+                    for (int d = 0; d < nd; d++) v[d] += (target - vn) * n[d];
+                } else {
+                    for (int ic = iboundx0; ic < ib; ic++) {
+                        if (!(flag & (1u << ic))) continue;
+                        if (p.vbc_types[ic] == 0) {
+                            double vn = 0;
+                            for (int d = 0; d < nd; d++) vn += v[d] * n[d];
+                            for (int d = 0; d < nd; d++) v[d] += (target - vn) * n[d];
+                        } else if (p.vbc_types[ic] == 1) {
+                            const int slot = o.edge_slot[ic*DES_NBDRY + ib];
+                            if (slot < 0) continue;
+                            const double *edge = &o.edge_vec[slot*ND];
+                            double ve = 0;
+                            for (int d = 0; d < ND; d++) ve += v[d] * edge[d];
+                            for (int d = 0; d < ND; d++) v[d] = ve * edge[d];
+                        }
+                    }
+                }
+                break;
+            }
+            case 3:
+                for (int d = 0; d < ND; d++) v[d] = p.vbc_values[ib] * n[d];
+                break;
+            case 13:
+                fac = 1 / std::sqrt(1 - n[ND-1]*n[ND-1]);
+                for (int d = 0; d < ND-1; d++) v[d] = p.vbc_values[ib] * fac * n[d];
+                v[ND-1] = 0;
+                break;
+            }
+        }
+
+        // Z last, bc.cxx:587-650
+        if (!(bc_z0 == 0 && bc_z1 == 0)) {
+            if (flag & BOUNDZ0) {
+                switch (bc_z0) {
+                case 0: break;
+                case 1: v[1] = bc_vz0; break;
+                case 2: v[0] = 0; break;
+                case 3: v[0] = 0; v[1] = bc_vz0; break;
+                case 4: v[0] = bc_vz0; v[1] = 0; break;
+                }
+            }
+            if (flag & BOUNDZ1) {
+                switch (bc_z1) {
+                case 0: break;
+                case 1: v[1] = bc_vz1; break;
+                case 2: v[0] = 0; break;
+                case 3: v[0] = 0.0; v[1] = bc_vz1; break;
+                case 4: v[0] = bc_vz1; v[1] = 0; break;
+                }
+            }
+        }
+        o.vel[i] = v[0]; o.vel[nn+i] = v[1];
+    }
+}
+#else
 // bc.cxx:227-659 (THREED branch)
 void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
 {
@@ -1329,6 +1780,7 @@ void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
         o.vel[i] = v[0]; o.vel[nn+i] = v[1]; o.vel[2*nn+i] = v[2];
     }
 }
+#endif
 
 // fields.cxx:761-784
 void update_coordinate(des_oracle &o)
@@ -1340,6 +1792,47 @@ void update_coordinate(des_oracle &o)
             o.coord[j*nn+i] += o.vel[j*nn+i] * o.dt;
 }
 
+#if DES_NDIMS == 2
+// bc.cxx:916-1112, the !THREED branches: 1-D diffusion along the sorted top nodes (:1021-1033,
+// 1067-1077) with different rates above / below the base level (:1098-1106)
+void simple_diffusion(des_oracle &o)
+{
+    const int ne = o.ne, nn = o.nn;
+    for (int i = 0; i < nn; i++) { o.total_dx[i] = 0.; o.total_slope[i] = 0.; }
+    for (int i = 0; i < o.etop; ++i) {
+        int n0 = o.top_nodes[i];
+        int n1 = o.top_nodes[i+1];
+        double dx = std::fabs(o.coord[n1] - o.coord[n0]);
+        o.etmp[i] = dx;
+        o.tmp_result[0 * ne + i] = -(o.coord[nn + n1] - o.coord[nn + n0]) / dx;
+        o.tmp_result[1 * ne + i] = (o.coord[nn + n1] - o.coord[nn + n0]) / dx;
+    }
+    const int ntop = o.ntop;
+    for (int i = 0; i < ntop; ++i) {
+        int n = o.top_nodes[i];
+        if (i == 0) {
+            o.total_dx[n] = o.etmp[i];
+            o.total_slope[n] = o.tmp_result[0 * ne + i];
+        } else if (i == ntop-1) {
+            o.total_dx[n] = o.etmp[i-1];
+            o.total_slope[n] = o.tmp_result[1 * ne + i-1];
+        } else {
+            o.total_dx[n] = o.etmp[i-1] + o.etmp[i];
+            o.total_slope[n] = o.tmp_result[1 * ne + i-1] + o.tmp_result[0 * ne + i];
+        }
+    }
+    for (int i = 0; i < ntop; ++i) {
+        int n = o.top_nodes[i];
+        double conv = o.p.surface_diffusivity * o.dt * o.total_slope[n] / o.total_dx[n];
+        if (o.coord[nn + n] > o.p.surf_base_level && conv > 0.)
+            o.dh[i] -= o.p.surf_diff_ratio_terrig * conv;
+        else if (o.coord[nn + n] <= o.p.surf_base_level && conv < 0.)
+            o.dh[i] -= o.p.surf_diff_ratio_marine * conv;
+        else
+            o.dh[i] -= conv;
+    }
+}
+#else
 // bc.cxx:916-1112 (THREED)
 void simple_diffusion(des_oracle &o)
 {
@@ -1402,6 +1895,7 @@ void simple_diffusion(des_oracle &o)
         o.dh[i] -= conv;
     }
 }
+#endif
 
 // bc.cxx:1655-1707
 void correct_surface_element(des_oracle &o)
@@ -1409,9 +1903,9 @@ void correct_surface_element(des_oracle &o)
     const int ne = o.ne;
     for (int i = 0; i < o.ntop_elems; i++) {
         const int e = o.top_elems[i];
-        double d[4][3];
+        double d[NPE][ND];
         elem_coords(o, e, d);
-        double new_volumes = tetrahedron_volume(d[0], d[1], d[2], d[3]);
+        double new_volumes = elem_volume(d);
         double rdv = new_volumes / o.volume[e];
         o.volume[e] = new_volumes;
         if (rdv < 1.0) continue;
@@ -1448,7 +1942,7 @@ void surface_processes_a(des_oracle &o)
     for (int i = 0; i < o.ntop; i++) {
         int nt = o.top_nodes[i];
         if (nt < o.c0 || nt >= o.c1) continue;
-        o.coord[2*nn + nt] += o.dh[i];
+        o.coord[(ND-1)*nn + nt] += o.dh[i];
         o.dhacc[nt] += o.dh[i];
         o.dh_n[nt] = o.dh[i];
     }
@@ -1463,10 +1957,14 @@ void surface_processes_b(des_oracle &o)
         double dh_e = 0.;
         for (int j = 0; j < ND; j++)
             dh_e += o.dh[o.elem_and_nodes[j * o.etop + i]];
-        double c[3][3];
+        double c[NPF][ND];
         for (int j = 0; j < NPF; ++j)
             node_xyz(o.coord, nn, o.conn_surf[j * o.etop + i], c[j]);
+#if DES_NDIMS == 3
         double base = triangle_area2d(c[0], c[1], c[2]);     // compute_area_facet, geometry.cxx:109-121
+#else
+        double base = std::fabs(c[0][0] - c[1][0]);
+#endif
         o.edvacc_surf[i] += dh_e * base / ND;
     }
 
@@ -1485,6 +1983,22 @@ void surface_processes_b(des_oracle &o)
         for (int i = 0; i < o.ntop; i++)
             o.dhacc[o.top_nodes[i]] = 0.;
     }
+#if DES_NDIMS == 2
+    // surface_plstrain_diffusion (bc.cxx:1633-1653) at step 0 and every quality_check_step_interval
+    // steps (bc.cxx:1848-1850): plastic strain of the top elements decays with a 100-year half life
+    // unless their most abundant material is the oceanic crust
+    if (!(o.steps % o.p.quality_check_step_interval && o.steps != 0)) {
+        double half_life = 1.e2 * YEAR2SEC;
+        double lambha = 0.69314718056 / half_life;
+        for (int i = 0; i < o.ntop_elems; i++) {
+            const int e = o.top_elems[i];
+            const int *a = &o.elemmarkers[(size_t)e * o.p.nmat];
+            int mat = (int)(std::max_element(a, a + o.p.nmat) - a);
+            if (mat != o.p.mattype_oceanic_crust)
+                o.plstrain[e] -= o.plstrain[e] * lambha * o.dt;
+        }
+    }
+#endif
 }
 
 // geometry.cxx:1743-1870 (use_global_velocity_scaling == false, no hydraulics)
@@ -1537,6 +2051,38 @@ void update_mesh_b(des_oracle &o)
     compute_mass(o);
 }
 
+#if DES_NDIMS == 2
+// fields.cxx:807-821, 885-900
+void jaumann_rate_2d(double *s, double dt, double w2)
+{
+    double s_inc[3];
+    s_inc[0] = -2.0 * s[2] * w2;
+    s_inc[1] =  2.0 * s[2] * w2;
+    s_inc[2] = s[0] * w2 - s[1] * w2;
+    for (int i = 0; i < NSTR; ++i)
+        s[i] += dt * s_inc[i];
+}
+
+void rotate_stress(des_oracle &o)
+{
+    const int ne = o.ne, nn = o.nn;
+    #pragma omp parallel for
+    for (int e = 0; e < ne; ++e) {
+        double shpdx[NPE], shpdy[NPE], shpdz[NPE];
+        get_local_shape_fn(o, e, shpdx, shpdy, shpdz);
+        double v[NPE][ND];
+        for (int i = 0; i < NPE; ++i)
+            node_xyz(o.vel, nn, o.conn[i * ne + e], v[i]);
+        double w2 = 0;
+        for (int i = 0; i < NPE; ++i) w2 += 0.5 * (v[i][ND-1] * shpdx[i] - v[i][0] * shpdz[i]);
+        double s[NSTR], es[NSTR];
+        for (int i = 0; i < NSTR; ++i) { s[i] = o.stress[i*ne+e]; es[i] = o.strain[i*ne+e]; }
+        jaumann_rate_2d(s, o.dt, w2);
+        jaumann_rate_2d(es, o.dt, w2);
+        for (int i = 0; i < NSTR; ++i) { o.stress[i*ne+e] = s[i]; o.strain[i*ne+e] = es[i]; }
+    }
+}
+#else
 // fields.cxx:787-902 (THREED)
 void jaumann_rate_3d(double *s, double dt, double w3, double w4, double w5)
 {
@@ -1572,6 +2118,7 @@ void rotate_stress(des_oracle &o)
         for (int i = 0; i < NSTR; ++i) { o.stress[i*ne+e] = s[i]; o.strain[i*ne+e] = es[i]; }
     }
 }
+#endif
 
 // geometry.cxx:1480-1647 (use_global_velocity_scaling == false, no hydraulics).
 // The element reduction (1513-1593) gives six partial values; in a decomposed run they are
@@ -1589,8 +2136,10 @@ void compute_dt_partials(des_oracle &o)
 
     #pragma omp parallel for reduction(min:minl,dt_maxwell,dt_diffusion,global_dt_min) reduction(max:global_max_vem)
     for (int e = 0; e < ne; ++e) {
-        double vx = 0.0, vy = 0.0, vz = 0.0;
+        double vx = 0.0, vy = 0.0;
         double weight = 1.0 / NPE;
+#if DES_NDIMS == 3
+        double vz = 0.0;
         for (int j = 0; j < NPE; ++j) {
             int n = o.conn[j * ne + e];
             vx += o.vel[n] * weight;
@@ -1598,14 +2147,28 @@ void compute_dt_partials(des_oracle &o)
             vz += o.vel[2*nn + n] * weight;
         }
         double max_vem = std::sqrt(vx*vx + vy*vy + vz*vz);
+#else
+        for (int j = 0; j < NPE; ++j) {
+            int n = o.conn[j * ne + e];
+            vx += o.vel[n] * weight;
+            vy += o.vel[nn + n] * weight;
+        }
+        double max_vem = std::sqrt(vx*vx + vy*vy);
+#endif
         global_max_vem = std::max(global_max_vem, max_vem);
 
-        double d[4][3];
+        double d[NPE][ND];
         elem_coords(o, e, d);
+#if DES_NDIMS == 3
         const double *a = d[0], *b = d[1], *c = d[2], *dd = d[3];
         double maxa = std::max(std::max(triangle_area(a, b, c), triangle_area(a, b, dd)),
                                std::max(triangle_area(c, dd, a), triangle_area(c, dd, b)));
         double minh = 3 * o.volume[e] / maxa;
+#else
+        // max edge length of this triangle, geometry.cxx:1569-1575
+        double maxl = std::sqrt(std::max(std::max(dist2(d[0], d[1]), dist2(d[1], d[2])), dist2(d[0], d[2])));
+        double minh = 2 * o.volume[e] / maxl;
+#endif
         dt_maxwell = std::min(dt_maxwell, 0.5 * p.visc_min / (1e-40 + mat.shearm(e)));
         if (p.has_thermal_diffusion)
             dt_diffusion = std::min(dt_diffusion, 0.5 * minh * minh / p.therm_diff_max);
@@ -1683,9 +2246,9 @@ void isostasy_vel(des_oracle &o)
     const int nn = o.nn;
     #pragma omp parallel for default(none) shared(o) firstprivate(nn)
     for (int i = o.c0; i < o.c1; ++i) {
-        for (int j = 0; j < 2; ++j) o.vel[j*nn + i] = 0;
+        for (int j = 0; j < ND-1; ++j) o.vel[j*nn + i] = 0;
         if (!o.p.has_winkler_foundation && (o.bcflag[i] & BOUNDZ0))
-            o.vel[2*nn + i] = 0;
+            o.vel[(ND-1)*nn + i] = 0;
     }
 }
 
@@ -1803,20 +2366,20 @@ FieldRef field_ref(des_oracle &o, int field)
 {
     const long long nn = o.nn, ne = o.ne;
     switch (field) {
-    case DES_F_COORD: return {o.coord.data(), 3*nn, 8};
-    case DES_F_VEL: return {o.vel.data(), 3*nn, 8};
-    case DES_F_FORCE: return {o.force.data(), 3*nn, 8};
-    case DES_F_FORCE_RESIDUAL: return {o.force_residual.data(), 3*nn, 8};
-    case DES_F_COORD0: return {o.coord0.data(), 3*nn, 8};
+    case DES_F_COORD: return {o.coord.data(), ND*nn, 8};
+    case DES_F_VEL: return {o.vel.data(), ND*nn, 8};
+    case DES_F_FORCE: return {o.force.data(), ND*nn, 8};
+    case DES_F_FORCE_RESIDUAL: return {o.force_residual.data(), ND*nn, 8};
+    case DES_F_COORD0: return {o.coord0.data(), ND*nn, 8};
     case DES_F_TEMPERATURE: return {o.temperature.data(), nn, 8};
     case DES_F_VOLUME_N: return {o.volume_n.data(), nn, 8};
     case DES_F_MASS: return {o.mass.data(), nn, 8};
     case DES_F_TMASS: return {o.tmass.data(), nn, 8};
     case DES_F_DHACC: return {o.dhacc.data(), nn, 8};
     case DES_F_NTMP: return {o.ntmp.data(), nn, 8};
-    case DES_F_STRESS: return {o.stress.data(), 6*ne, 8};
-    case DES_F_STRAIN: return {o.strain.data(), 6*ne, 8};
-    case DES_F_STRAIN_RATE: return {o.strain_rate.data(), 6*ne, 8};
+    case DES_F_STRESS: return {o.stress.data(), NSTR*ne, 8};
+    case DES_F_STRAIN: return {o.strain.data(), NSTR*ne, 8};
+    case DES_F_STRAIN_RATE: return {o.strain_rate.data(), NSTR*ne, 8};
     case DES_F_PLSTRAIN: return {o.plstrain.data(), ne, 8};
     case DES_F_DELTA_PLSTRAIN: return {o.delta_plstrain.data(), ne, 8};
     case DES_F_VISCOSITY: return {o.viscosity.data(), ne, 8};
@@ -1828,10 +2391,11 @@ FieldRef field_ref(des_oracle &o, int field)
     case DES_F_ELEMMARKERS: return {o.elemmarkers.data(), ne * o.p.nmat, 4};
     case DES_F_EDVACC_SURF: return {o.edvacc_surf.data(), (long long)o.etop, 8};
     case DES_F_DH: return {o.dh.data(), (long long)o.ntop, 8};
-    case DES_F_STRESS_AVG: return {o.stress_avg.data(), 6*ne, 8};
+    case DES_F_STRESS_AVG: return {o.stress_avg.data(), NSTR*ne, 8};
     case DES_F_DPLSTRAIN_AVG: return {o.dplstrain_avg.data(), ne, 8};
-    case DES_F_STRAIN0: return {o.strain0.data(), 6*ne, 8};
-    case DES_F_COORD_AVG0: return {o.coord_avg0.data(), 3*nn, 8};
+    case DES_F_STRAIN0: return {o.strain0.data(), NSTR*ne, 8};
+    case DES_F_COORD_AVG0: return {o.coord_avg0.data(), ND*nn, 8};
+    case DES_F_STRESSYY: return {o.stressyy.data(), (long long)o.stressyy.size(), 8};
     default: return {nullptr, 0, 0};
     }
 }
@@ -1842,47 +2406,51 @@ extern "C" {
 
 des_oracle *des_oracle_create(const des_params *params, const des_mesh *mesh)
 {
-    if (!params || !mesh || params->ndims != 3 || params->nmat < 1 || params->nmat > DES_MAX_MAT)
+    if (!params || !mesh || params->ndims != ND || params->nmat < 1 || params->nmat > DES_MAX_MAT)
+        return nullptr;
+    if (ND == 2 && (params->num_vbc_period_x0 < 1 || params->num_vbc_period_x0 > DES_MAX_PERIOD ||
+                    params->num_vbc_period_x1 < 1 || params->num_vbc_period_x1 > DES_MAX_PERIOD))
         return nullptr;
     des_oracle *h = new des_oracle();
     des_oracle &o = *h;
     o.p = *params;
     const int nn = o.nn = mesh->nnode, ne = o.ne = mesh->nelem;
-    copy_vec(o.conn, mesh->connectivity, (size_t)4 * ne);
+    copy_vec(o.conn, mesh->connectivity, (size_t)NPE * ne);
     copy_vec(o.sup_idx, mesh->support_idx, (size_t)nn + 1);
-    copy_vec(o.sup_arr, mesh->support_arr, (size_t)4 * ne);
-    copy_vec(o.sup_lidx, mesh->support_lidx, (size_t)4 * ne);
+    copy_vec(o.sup_arr, mesh->support_arr, (size_t)NPE * ne);
+    copy_vec(o.sup_lidx, mesh->support_lidx, (size_t)NPE * ne);
     copy_vec(o.bcflag, mesh->bcflag, (size_t)nn);
     for (int i = 0; i < DES_NBDRY; ++i) {
         copy_vec(o.bf_elem[i], mesh->bfacet_elem[i], (size_t)mesh->nbfacets[i]);
         copy_vec(o.bf_facet[i], mesh->bfacet_facet[i], (size_t)mesh->nbfacets[i]);
         copy_vec(o.bnodes[i], mesh->bnodes[i], (size_t)mesh->nbnodes[i]);
     }
-    copy_vec(o.bnormals, mesh->bnormals, (size_t)3 * DES_NBDRY);
-    copy_vec(o.edge_vec, mesh->edge_vec, (size_t)3 * mesh->nedge);
+    copy_vec(o.bnormals, mesh->bnormals, (size_t)ND * DES_NBDRY);
+    copy_vec(o.edge_vec, mesh->edge_vec, (size_t)ND * mesh->nedge);
     std::memcpy(o.edge_slot, mesh->edge_slot, sizeof(o.edge_slot));
     o.ntop = mesh->ntop; o.etop = mesh->etop; o.ntop_elems = mesh->ntop_elems;
     copy_vec(o.top_nodes, mesh->top_nodes, (size_t)o.ntop);
-    copy_vec(o.elem_and_nodes, mesh->elem_and_nodes, (size_t)3 * o.etop);
-    copy_vec(o.conn_surf, mesh->connectivity_surface, (size_t)4 * o.etop);
+    copy_vec(o.elem_and_nodes, mesh->elem_and_nodes, (size_t)ND * o.etop);
+    copy_vec(o.conn_surf, mesh->connectivity_surface, (size_t)NPE * o.etop);
     copy_vec(o.ssup_idx, mesh->support_surf_idx, (size_t)o.ntop + 1);
     copy_vec(o.ssup_arr, mesh->support_surf_arr, (size_t)o.ssup_idx[o.ntop]);
     copy_vec(o.top_elems, mesh->top_elems, (size_t)o.ntop_elems);
 
     for (dvec *v : {&o.coord, &o.vel, &o.force, &o.force_residual, &o.coord0})
-        v->assign((size_t)3 * nn, 0.0);
+        v->assign((size_t)ND * nn, 0.0);
     for (dvec *v : {&o.temperature, &o.volume_n, &o.mass, &o.tmass, &o.hmass, &o.ymass,
                     &o.dhacc, &o.ntmp, &o.total_dx, &o.total_slope})
         v->assign((size_t)nn, 0.0);
     for (dvec *v : {&o.stress, &o.strain, &o.strain_rate})
-        v->assign((size_t)6 * ne, 0.0);
+        v->assign((size_t)NSTR * ne, 0.0);
+    if (ND == 2) o.stressyy.assign((size_t)ne, 0.0);
     for (dvec *v : {&o.plstrain, &o.delta_plstrain, &o.volume, &o.volume_old, &o.dpressure,
                     &o.edvoldt, &o.radiogenic, &o.etmp, &o.c_bulkm, &o.c_shearm, &o.c_phi,
                     &o.c_cp, &o.c_k})
         v->assign((size_t)ne, 0.0);
     o.viscosity.assign((size_t)ne, params->visc_max);          // fields.cxx:110
-    o.stress_avg.assign((size_t)6 * ne, 0.0); o.strain0.assign((size_t)6 * ne, 0.0);
-    o.dplstrain_avg.assign((size_t)ne, 0.0); o.coord_avg0.assign((size_t)3 * nn, 0.0);
+    o.stress_avg.assign((size_t)NSTR * ne, 0.0); o.strain0.assign((size_t)NSTR * ne, 0.0);
+    o.dplstrain_avg.assign((size_t)ne, 0.0); o.coord_avg0.assign((size_t)ND * nn, 0.0);
     o.avg_time0 = 0;
     o.tmp_result.assign((size_t)12 * ne, 0.0);
     o.elemmarkers.assign((size_t)ne * params->nmat, 0);
@@ -1994,18 +2562,24 @@ int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, d
     if (bottom_dist >= 0)
         for (int i = 0; i < o.nn; ++i)
             if (o.bcflag[i] & BOUNDZ0) {
-                double z = o.coord[2 * (size_t)o.nn + i];
+                double z = o.coord[(ND-1) * (size_t)o.nn + i];
                 if (std::fabs(z - bottom) > bottom_dist) { out->bottom_node = i; break; }
             }
     double q = 1; int worst = 0;
     for (int e = 0; e < o.ne; e++) {
-        double d[4][3];
+        double d[NPE][ND];
         elem_coords(o, e, d);
+        double vol = o.volume[e];
+#if DES_NDIMS == 3
         double normalization_factor = 216 * std::sqrt(3);
         double area_sum = (triangle_area(d[0], d[1], d[2]) + triangle_area(d[0], d[1], d[3]) +
                            triangle_area(d[2], d[3], d[0]) + triangle_area(d[2], d[3], d[1]));
-        double vol = o.volume[e];
         double quality = normalization_factor * vol * vol / (area_sum * area_sum * area_sum);
+#else
+        double normalization_factor = 4 * std::sqrt(3);
+        double dist2_sum = dist2(d[0], d[1]) + dist2(d[1], d[2]) + dist2(d[0], d[2]);
+        double quality = normalization_factor * vol / dist2_sum;
+#endif
         if (quality < q) { q = quality; worst = e; }
     }
     out->worst_quality = q; out->worst_elem = worst;
@@ -2016,6 +2590,7 @@ int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, d
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global)
 {
     if (owned_begin < 0 || owned_end > h->nn || owned_begin > owned_end) return DES_ERR_INTERNAL;
+    if (ND == 2 && (owned_begin > 0 || owned_end < h->nn)) return DES_ERR_UNSUPPORTED_DIM;   // the decomposition is 3-D only
     if (h->p.has_PT && (owned_begin > 0 || owned_end < h->nn)) return DES_ERR_UNSUPPORTED;   // the loop's residual is global
     h->o0 = owned_begin; h->o1 = owned_end; h->nn_global = nnode_global;
     return DES_OK;
@@ -2029,6 +2604,7 @@ int des_oracle_set_isostasy(des_oracle *h, int on) { h->iso = on != 0; return DE
 // what = 1 {stress, strain, plstrain} of the local elements idx[0..n); buf[i*width + c]
 int des_oracle_halo_pack(des_oracle *h, int what, const int *idx, int n, double *buf)
 {
+    if (ND != 3) return DES_ERR_UNSUPPORTED_DIM;
     const int nn = h->nn, ne = h->ne;
     for (int i = 0; i < n; ++i) {
         const int k = idx[i];
@@ -2047,6 +2623,7 @@ int des_oracle_halo_pack(des_oracle *h, int what, const int *idx, int n, double 
 
 int des_oracle_halo_unpack(des_oracle *h, int what, const int *idx, int n, const double *buf)
 {
+    if (ND != 3) return DES_ERR_UNSUPPORTED_DIM;
     const int nn = h->nn, ne = h->ne;
     for (int i = 0; i < n; ++i) {
         const int k = idx[i];

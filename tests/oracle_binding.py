@@ -11,8 +11,8 @@ ORACLE_DIR = os.path.join(REPO_ROOT, "oracle")
 _libs = {}
 
 
-def load_oracle(omp=False):
-    name = "libdes_oracle_omp.so" if omp else "libdes_oracle.so"
+def load_oracle(omp=False, ndims=3):
+    name = "libdes_oracle2d.so" if ndims == 2 else "libdes_oracle_omp.so" if omp else "libdes_oracle.so"
     if name not in _libs:
         path = os.path.join(ORACLE_DIR, name)
         if not os.path.exists(path):
@@ -47,7 +47,7 @@ class OracleEngine(EngineBase):
     prefix = "des_oracle"
 
     def __init__(self, host, omp=False):
-        lib = load_oracle(omp)
+        lib = load_oracle(omp, getattr(host, "ndims", 3))
         h = lib.des_oracle_create(C.byref(host.params), C.byref(host.mesh))
         if not h:
             raise RuntimeError("des_oracle_create failed")

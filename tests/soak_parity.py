@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--sensitivity", action="store_true")
     ap.add_argument("--portable-libm", action="store_true",
                     help="both sides use csrc/des_libm.hpp instead of ocml / glibc: expect zeros")
-    ap.add_argument("--mesh-file", default=os.path.join(ROOT, "oracle/_ref/test-3d-big-460.desmesh"))
+    ap.add_argument("--mesh-file", default=des.reference_mesh("test-3d-big-460"))
     a = ap.parse_args()
     load_oracle(omp=True).des_oracle_set_threads(a.threads)
     if a.portable_libm:
@@ -49,7 +49,8 @@ def main():
     else:
         other = des.DeviceEngine(host)
         assert other.init_from_host(host) == ref.init_from_host(host)
-        print("# device engine vs oracle" + (", portable libm on both sides" if a.portable_libm else ""))
+        print("# device engine (%s) vs oracle (%s)" % (os.environ.get("DES_LIBM", "des_libm.hpp: pow/exp = glibc's bits"),
+                                                       "des_libm.hpp" if a.portable_libm else "the C library's libm"))
     print("# nnode %d nelem %d" % (host.mesh.nnode, host.mesh.nelem))
     t = time.time()
     for _ in range(a.steps // 100):
