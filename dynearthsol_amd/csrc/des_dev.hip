@@ -41,6 +41,7 @@
 #include <rccl/rccl.h>
 
 #include "des_dev.h"
+#include "des_dev2d.hpp"
 #define DES_LIBM_LDS_TABLES 1     // kernels that call deslibm:: stage its tables in LDS first
 #define DES_LIBM_LDS_WAVES 4      // = DES_BLOCK / 64, one private copy per wavefront
 #include "des_kernels.hpp"
@@ -125,6 +126,7 @@ struct DiagBuf {
 } // namespace
 
 struct des_dev {
+    des2d::Engine *d2;       // a 2-D (triangle) model lives in the engine of des_dev2d.hip; everything below is then unused
     int device;
     int portable_libm;       // DES_LIBM=portable: des_libm.hpp instead of ocml in the stress update
     des_params p;
@@ -250,6 +252,10 @@ namespace des_hip {
 
 using namespace des_hip;
 
+// a handle that holds a 2-D engine forwards the call (and keeps the engine's error text)
+#define D2_FORWARD(h, call) do { if ((h) && (h)->d2) { int rc2_ = des2d::call; if (rc2_) g_last_error = des2d::last_error((h)->d2); return rc2_; } } while (0)
+#define D2_REFUSE(h, what) do { if ((h) && (h)->d2) { g_last_error = what " is offered for 3-D models only"; return DES_ERR_UNSUPPORTED_DIM; } } while (0)
+
 // =====================================================================================
 // C-ABI
 // =====================================================================================
@@ -267,6 +273,7 @@ int des_dev_device_count(void)
 void des_dev_destroy(des_dev *h)
 {
     if (!h) return;
+    if (h->d2) { des2d::destroy(h->d2); delete h; return; }
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm_stream) { hipStreamSynchronize(h->comm_stream); hipStreamDestroy(h->comm_stream); }
@@ -299,7 +306,15 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     int dummy; if (!err) err = &dummy;
     *err = DES_OK;
     if (!params || !mesh) { *err = DES_ERR_INTERNAL; g_last_error = "null argument"; return nullptr; }
-    if (params->ndims != 3) { *err = DES_ERR_UNSUPPORTED_DIM; g_last_error = "only the 3D (THREED) path is offloaded"; return nullptr; }
+    if (params->ndims == 2) {
+        // the reference's 2-D build: its own engine behind the same entry points (des_dev2d.hpp)
+        des2d::Engine *e2 = des2d::create(device, params, mesh, err, g_last_error);
+        if (!e2) return nullptr;
+        des_dev *h2 = new des_dev();
+        h2->d2 = e2; h2->device = device; h2->p = *params; h2->nn = mesh->nnode; h2->ne = mesh->nelem; h2->nmat = params->nmat;
+        return h2;
+    }
+    if (params->ndims != 3) { *err = DES_ERR_UNSUPPORTED_DIM; g_last_error = "ndims must be 2 or 3"; return nullptr; }
     if (params->nmat < 1 || params->nmat > DES_MAX_MAT) { *err = DES_ERR_CONFIG_VALUE; g_last_error = "bad nmat"; return nullptr; }
     switch (params->rheol_type) {
     case DES_RH_ELASTIC: case DES_RH_VISCOUS: case DES_RH_MAXWELL: case DES_RH_EP: case DES_RH_EVP: break;
@@ -601,6 +616,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
 
 long long des_dev_field_count(const des_dev *h, int field)
 {
+    if (h && h->d2) return des2d::field_count(h->d2, field);
     const long long nn = h->nn, ne = h->ne;
     switch (field) {
     case DES_F_COORD: case DES_F_VEL: case DES_F_FORCE: case DES_F_FORCE_RESIDUAL: case DES_F_COORD0: return 3*nn;
@@ -679,6 +695,7 @@ static int packed_io(des_dev *h, int field, void *host, bool upload)
 
 int des_dev_upload(des_dev *h, int field, const void *host, long long count)
 {
+    D2_FORWARD(h, upload(h->d2, field, host, count));
     if (!h || !host) return DES_ERR_INTERNAL;
     if (count != des_dev_field_count(h, field)) { g_last_error = "field size mismatch"; return DES_ERR_INTERNAL; }
     hipSetDevice(h->device);
@@ -703,6 +720,7 @@ int des_dev_upload(des_dev *h, int field, const void *host, long long count)
 
 int des_dev_download(des_dev *h, int field, void *host, long long count)
 {
+    D2_FORWARD(h, download(h->d2, field, host, count));
     if (!h || !host) return DES_ERR_INTERNAL;
     if (count != des_dev_field_count(h, field)) { g_last_error = "field size mismatch"; return DES_ERR_INTERNAL; }
     hipSetDevice(h->device);
@@ -733,6 +751,7 @@ int des_dev_download(des_dev *h, int field, void *host, long long count)
 
 int des_dev_set_clock(des_dev *h, double dt, double time, long long steps)
 {
+    D2_FORWARD(h, set_clock(h->d2, dt, time, steps));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     int rc = sync_clock(h);
@@ -750,6 +769,7 @@ int des_dev_set_clock(des_dev *h, double dt, double time, long long steps)
 // still stores dpressure and compute_mass the thermal mass, as in the reference.)
 int des_dev_set_isostasy(des_dev *h, int on)
 {
+    D2_FORWARD(h, set_isostasy(h->d2, on));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     int rc = sync_clock(h);
@@ -763,6 +783,7 @@ int des_dev_set_isostasy(des_dev *h, int on)
 
 int des_dev_sync(des_dev *h)
 {
+    D2_FORWARD(h, sync(h->d2));
     if (!h) return DES_ERR_INTERNAL;
     HIP_OK(hipStreamSynchronize(h->stream));
     return DES_OK;
@@ -770,6 +791,7 @@ int des_dev_sync(des_dev *h)
 
 int des_dev_init_geometry(des_dev *h)
 {
+    D2_FORWARD(h, init_geometry(h->d2));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     refresh_props(h);
@@ -791,6 +813,7 @@ int des_dev_init_geometry(des_dev *h)
 
 int des_dev_compute_dt(des_dev *h, double *dt)
 {
+    D2_FORWARD(h, compute_dt(h->d2, dt));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     refresh_props(h);
@@ -809,6 +832,7 @@ int des_dev_compute_dt(des_dev *h, double *dt)
 // part) stays fused with the start of step t+1 (A part) whenever another step follows.
 int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
 {
+    D2_FORWARD(h, step(h->d2, nsteps, out));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     refresh_props(h);
@@ -918,6 +942,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
 // ---- domain decomposition ---------------------------------------------------------
 int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
 {
+    D2_REFUSE(h, "the domain decomposition");
     if (!h || !halo) return DES_ERR_INTERNAL;
     if (h->p.has_PT && (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn)) {
         g_last_error = "control.has_PT on a decomposed mesh: the loop's residual test is global";
@@ -996,6 +1021,7 @@ int des_dev_comm_unique_id(unsigned char *id128)
 
 int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128)
 {
+    D2_REFUSE(h, "the domain decomposition");
     if (!h || !id128) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     ncclUniqueId id;
@@ -1008,6 +1034,7 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
 
 int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
 {
+    if (h && h->d2) { if (nranks) *nranks = 0; if (rank) *rank = 0; if (overlapped) *overlapped = 0; return DES_OK; }
     if (!h) return DES_ERR_INTERNAL;
     int n = 1, r = 0;
     if (h->comm) {
@@ -1025,6 +1052,7 @@ int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
 // between the two phases of a step); asynchronous on the engine's stream.
 int des_dev_exchange(des_dev *h)
 {
+    D2_REFUSE(h, "the ghost-region exchange");
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     return exchange(h);
@@ -1035,6 +1063,7 @@ int des_dev_exchange(des_dev *h)
 // engines on one GPU.  Returns 1 after phase 1 when the compute_dt partials are ready.
 int des_dev_phase(des_dev *h, int phase)
 {
+    D2_REFUSE(h, "the two-phase step");
     if (!h) return -DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     switch (phase) {
@@ -1098,16 +1127,19 @@ static int state_io(des_dev *h, int what, const int *idx, int n, double *buf, bo
 
 int des_dev_halo_pack(des_dev *h, int what, const int *idx, int n, double *buf)
 {
+    D2_REFUSE(h, "the ghost-region exchange");
     return state_io(h, what, idx, n, buf, true);
 }
 
 int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const double *buf)
 {
+    D2_REFUSE(h, "the ghost-region exchange");
     return state_io(h, what, idx, n, const_cast<double *>(buf), false);
 }
 
 int des_dev_dt_partials(des_dev *h, double out[6], int recompute)
 {
+    D2_REFUSE(h, "the split compute_dt");
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     if (recompute) { refresh_props(h); launch_e1<MODE_DT>(h); }
@@ -1119,6 +1151,7 @@ int des_dev_dt_partials(des_dev *h, double out[6], int recompute)
 
 int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt)
 {
+    D2_REFUSE(h, "the split compute_dt");
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     HIP_OK(hipMemcpyAsync(h->d_red, in, 48, hipMemcpyHostToDevice, h->stream));
@@ -1195,6 +1228,7 @@ int des_dev_elasto_plastic_eval(int device, int libm, long long n, const double 
 
 int des_dev_check_nan(des_dev *h, long long *n_nan)
 {
+    D2_FORWARD(h, check_nan(h->d2, n_nan));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     unsigned long long *d_count = nullptr;
@@ -1216,6 +1250,7 @@ int des_dev_check_nan(des_dev *h, long long *n_nan)
 
 int des_dev_mesh_quality(des_dev *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out)
 {
+    D2_FORWARD(h, mesh_quality(h->d2, smallest_vol, bottom, bottom_dist, out));
     if (!h || !out) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     struct Slots { double q; int i[4]; } init = { 1.0, { INT_MAX, INT_MAX, INT_MAX, 0 } }, res;
@@ -1324,6 +1359,7 @@ int des_dev_access_bench(int device, int pattern, long long items, int reps, dou
 
 int des_dev_timer_start(des_dev *h)
 {
+    D2_FORWARD(h, timer_start(h->d2));
     if (!h) return DES_ERR_INTERNAL;
     HIP_OK(hipEventRecord(h->ev0, h->stream));
     return DES_OK;
@@ -1331,6 +1367,7 @@ int des_dev_timer_start(des_dev *h)
 
 int des_dev_timer_stop(des_dev *h, float *ms)
 {
+    D2_FORWARD(h, timer_stop(h->d2, ms));
     if (!h) return DES_ERR_INTERNAL;
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     HIP_OK(hipEventSynchronize(h->ev1));
@@ -1342,6 +1379,7 @@ int des_dev_timer_stop(des_dev *h, float *ms)
 
 int des_dev_profile_enable(des_dev *h, int on)
 {
+    if (h && h->d2) return DES_OK;                 // no per-kernel accounting in the 2-D engine
     if (!h) return DES_ERR_INTERNAL;
     hipStreamSynchronize(h->stream);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -1353,6 +1391,7 @@ int des_dev_profile_enable(des_dev *h, int on)
 
 int des_dev_profile_read(des_dev *h, int cap, char (*names)[64], double *ms, long long *calls)
 {
+    if (h && h->d2) return 0;
     if (!h) return 0;
     hipStreamSynchronize(h->stream);
     for (ProfRec &r : h->prof_recs) {
@@ -1375,6 +1414,7 @@ int des_dev_profile_read(des_dev *h, int cap, char (*names)[64], double *ms, lon
 // NMD off -96*ne -28*nn
 double des_dev_algorithmic_bytes_per_step(const des_dev *h)
 {
+    if (h && h->d2) return des2d::algorithmic_bytes_per_step(h->d2);
     double be = 1420, bn = 348;
     if (h->p.rheol_type == DES_RH_EVP) { be += 24; bn += 8; }
     if (!h->p.has_thermal_diffusion) { be -= 88; bn -= 24; }

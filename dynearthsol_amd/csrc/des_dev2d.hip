@@ -1,0 +1,1774 @@
+// des_dev2d.hip -- the 2-D (triangle) build of the explicit time step on gfx950 (des_dev2d.hpp).
+//
+// One kernel per loop of the reference's 2-D build, in the reference's order; node loops sum their
+// element patch through the same Support CSR in the same ascending order (parameters.hpp:585-610),
+// so with -ffp-contract=off every field equals the CPU build's bit for bit, as the 3-D engine's do.
+// Arrays are the reference's own (SoA, caller's numbering): coord / vel / force [2][nnode] =
+// {x, z}; stress / strain / strain_rate [3][nelem] = {XX, ZZ, XZ}; connectivity [3][nelem].
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#define DES_LIBM_LDS_TABLES 1     // the stress kernel stages the libm tables in LDS first
+#define DES_LIBM_LDS_WAVES 4      // = DES_BLOCK / 64
+#include "des_kernels.hpp"
+#include "des_dev2d.hpp"
+
+namespace des2d {
+
+namespace {
+
+const int ND = 2, NPE = 3, NSTR = 3, NPF = 2;
+__device__ const int NODE_OF_FACET_D[3][2] = {{1,2},{2,0},{0,1}};     // constants.hpp:71-75
+const unsigned BOUNDX0 = 1u, BOUNDX1 = 2u, BOUNDZ0 = 1u << 4, BOUNDZ1 = 1u << 5, BOUND_ANY = 0x3ffu;
+const int iboundx0 = 0, iboundz0 = 4, iboundz1 = 5, iboundn0 = 6, iboundn3 = 9;
+#define DES2_YEAR2SEC (365.2422 * 86400)                               /* constants.hpp:76 */
+
+// device-resident clock, reduction slots and the per-step scalars of apply_vbcs
+struct Clock {
+    double dt, time, l2_residual, max_surf_vel, max_global_vel_mag, global_dt_min;
+    double r_minl, r_dt_maxwell, r_dt_diffusion, r_global_dt_min, r_max_vem;   // compute_dt (geometry.cxx:1490-1503)
+    double maxdh, l2_sum;
+    double x0_max, x0_min, zmin;       // bc.cxx:251-290, 350-361
+    double avg_time0;
+    long long steps;
+    int status, iso, n_past, x0_init;
+};
+
+inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
+
+} // namespace
+
+struct Engine {
+    int device = 0;
+    int portable_libm = 1;
+    des_params p;
+    int nn = 0, ne = 0, nmat = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    des_params *d_p = nullptr;
+    desk::ViscTerms *d_vt = nullptr;
+    Clock *d_clk = nullptr, *h_clk = nullptr;
+    // topology
+    int *conn = nullptr, *sup_idx = nullptr, *sup_arr = nullptr, *sup_lidx = nullptr;
+    unsigned *bcflag = nullptr;
+    int nbf[DES_NBDRY] = {0}, nbn[DES_NBDRY] = {0};
+    int *bf_elem[DES_NBDRY] = {nullptr}, *bf_facet[DES_NBDRY] = {nullptr}, *bnodes[DES_NBDRY] = {nullptr};
+    double *bnormals = nullptr, *edge_vec = nullptr; int *edge_slot = nullptr;
+    int ntop = 0, etop = 0, ntop_elems = 0;
+    int *top_nodes = nullptr, *ean = nullptr, *conn_surf = nullptr, *top_elems = nullptr;
+    // nodal
+    double *coord = nullptr, *vel = nullptr, *force = nullptr, *fres = nullptr, *coord0 = nullptr, *temperature = nullptr,
+           *volume_n = nullptr, *mass = nullptr, *tmass = nullptr, *ymass = nullptr, *dhacc = nullptr, *ntmp = nullptr,
+           *total_dx = nullptr, *total_slope = nullptr;
+    // element
+    double *stress = nullptr, *strain = nullptr, *strain_rate = nullptr, *stressyy = nullptr, *plstrain = nullptr,
+           *delta_plstrain = nullptr, *viscosity = nullptr, *volume = nullptr, *volume_old = nullptr, *dpressure = nullptr,
+           *edvoldt = nullptr, *radiogenic = nullptr, *etmp = nullptr, *tmp_result = nullptr /* [6][ne] */, *props = nullptr /* [5][ne] */;
+    int *markers = nullptr, *etmp_int = nullptr;
+    double *dh = nullptr, *edvacc = nullptr;
+    double *stress_avg = nullptr, *dplstrain_avg = nullptr, *strain0 = nullptr, *coord_avg0 = nullptr;
+    double *res_part = nullptr; int res_nb = 0;
+    bool markers_dirty = true, iso = false;
+    long long steps_host = 0;
+    std::vector<void *> allocs;
+    std::string err;
+};
+
+namespace {
+
+#define HIP2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    h->err = std::string(#call) + ": " + hipGetErrorString(e_); return DES_ERR_RESOURCE; } } while (0)
+
+template <typename T>
+int dalloc(Engine *h, T *&ptr, size_t count)
+{
+    void *d = nullptr;
+    HIP2(hipMalloc(&d, std::max<size_t>(count, 1) * sizeof(T)));
+    HIP2(hipMemset(d, 0, std::max<size_t>(count, 1) * sizeof(T)));
+    h->allocs.push_back(d);
+    ptr = (T *)d;
+    return DES_OK;
+}
+
+template <typename T>
+int dcopy(Engine *h, T *&ptr, const T *host, size_t count)
+{
+    int rc = dalloc(h, ptr, count);
+    if (rc) return rc;
+    if (count && host) HIP2(hipMemcpy(ptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return DES_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// device functions: the !THREED branches
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double trace2(const double *s) { return s[0] + s[1]; }                  // utils.hpp:211-219
+__device__ __forceinline__ double second_invariant2_2d(const double *t)                             // utils.hpp:222-231
+{
+    return 0.25*(t[0]-t[1])*(t[0]-t[1]) + t[2]*t[2];
+}
+
+// geometry.cxx:77-93 (!THREED)
+__device__ __forceinline__ double triangle_area(const double *a, const double *b, const double *c)
+{
+    double ab0 = b[0] - a[0], ab1 = b[1] - a[1];
+    double ac0 = c[0] - a[0], ac1 = c[1] - a[1];
+    return fabs(ab0*ac1 - ab1*ac0) / 2;
+}
+
+__device__ __forceinline__ double dist2(const double *a, const double *b)                             // geometry.cxx:16-25
+{
+    double sum = 0;
+    for (int i = 0; i < 2; ++i) { double d = b[i] - a[i]; sum += d * d; }
+    return sum;
+}
+
+__device__ __forceinline__ void elem_coords(const double *coord, const int *conn, int nn, int ne, int e, double d[3][2])
+{
+    for (int i = 0; i < 3; ++i) {
+        const int n = conn[i * ne + e];
+        d[i][0] = coord[n]; d[i][1] = coord[nn + n];
+    }
+}
+
+// fields.cxx:40-53
+__device__ __forceinline__ void shape_fn2(const double d[3][2], double vol, double shpdx[3], double shpdz[3])
+{
+    double iv = 1.0 / (2.0 * vol);
+    shpdx[0] = iv * (d[1][1] - d[2][1]);
+    shpdx[1] = iv * (d[2][1] - d[0][1]);
+    shpdx[2] = iv * (d[0][1] - d[1][1]);
+    shpdz[0] = iv * (d[2][0] - d[1][0]);
+    shpdz[1] = iv * (d[0][0] - d[2][0]);
+    shpdz[2] = iv * (d[1][0] - d[0][0]);
+}
+
+__device__ __forceinline__ double elemT(const double *temperature, const int *conn, int ne, int e)    // matprops.cxx:338-343
+{
+    double T = 0;
+    for (int i = 0; i < 3; ++i) T += temperature[conn[i * ne + e]];
+    T /= 3;
+    return T;
+}
+
+// matprops.cxx:333-377 with the 2-D trace / second invariant
+template <class M>
+__device__ __forceinline__ double mat_visc2(const des_params *p, const desk::ViscTerms *vt, const desk::Mix &mx,
+                                            double T, const double *s, const double *edot3)
+{
+    const double min_strain_rate = 1e-30;
+    double s0 = trace2(s) / 2;
+    double edot = sqrt(second_invariant2_2d(edot3));
+    edot = fmax(edot, min_strain_rate);
+    double result = 0;
+    int n = 0;
+    for (int m = 0; m < p->nmat; m++) {
+        const int marker_count = mx.count(m);
+        if (marker_count == 0) continue;
+        double visc0 = 0.25 * M::pow(edot, vt->pow_edot[m]) * vt->coef_term[m]
+            * M::exp((p->visc_activation_energy[m] + p->visc_activation_volume[m] * s0)
+                  / (vt->nR[m] * T)) * 1e6;
+        result += marker_count / visc0;
+        n += marker_count;
+    }
+    double visc = n / result;
+    visc = fmin(fmax(visc, p->visc_min), p->visc_max);
+    return visc;
+}
+
+// rheology.cxx:248-260
+__device__ __forceinline__ void elastic2(double bulkm, double shearm, const double *de, double *s)
+{
+    double lambda = bulkm - 2. / 3 * shearm;
+    double dev = trace2(de);
+    for (int i = 0; i < 2; ++i) s[i] += 2 * shearm * de[i] + lambda * dev;
+    s[2] += 2 * shearm * de[2];
+}
+
+// rheology.cxx:277-295
+__device__ __forceinline__ void maxwell2(double bulkm, double shearm, double viscosity, double dt, double dv,
+                                         const double *de, double *s)
+{
+    double tmp = 0.5 * dt * shearm / viscosity;
+    double f1 = 1 - tmp;
+    double f2 = 1 / (1 + tmp);
+    double dev = trace2(de) / 2;
+    double s0 = trace2(s) / 2;
+    for (int i = 0; i < 2; ++i)
+        s[i] = ((s[i] - s0) * f1 + 2 * shearm * (de[i] - dev)) * f2 + s0 + bulkm * dv;
+    s[2] = (s[2] * f1 + 2 * shearm * de[2]) * f2;
+}
+
+// rheology.cxx:298-310
+__device__ __forceinline__ void viscous2(double bulkm, double viscosity, double total_dv, const double *edot, double *s)
+{
+    double dev = trace2(edot) / 2;
+    for (int i = 0; i < 2; ++i) s[i] = 2 * viscosity * (edot[i] - dev) + bulkm * total_dv;
+    s[2] = 2 * viscosity * edot[2];
+}
+
+// rheology.cxx:86-119
+__device__ __forceinline__ void principal_stresses2(const double *s, double p[2], double &cos2t, double &sin2t)
+{
+    double s0 = 0.5 * (s[0] + s[1]);
+    double rad = sqrt(second_invariant2_2d(s));
+    p[0] = s0 - rad;
+    p[1] = s0 + rad;
+    const double eps = 1e-15;
+    double a = 0.5 * (s[0] - s[1]);
+    double b = - rad;
+    if (b < -eps) {
+        cos2t = a / b;
+        sin2t = s[2] / b;
+    } else {
+        cos2t = 1;
+        sin2t = 0;
+    }
+}
+
+// rheology.cxx:312-484, the !THREED branches (pure 2-D Mohr-Coulomb)
+__device__ __forceinline__ void elasto_plastic(double bulkm, double shearm, double amc, double anphi, double anpsi,
+                                               double hardn, double ten_max, const double *de, double &depls, double *s)
+{
+    elastic2(bulkm, shearm, de, s);
+    depls = 0;
+    double p[2];
+    double cos2t, sin2t;
+    principal_stresses2(s, p, cos2t, sin2t);
+
+    double fs = p[0] - p[1] * anphi + amc;
+    double ft = p[1] - ten_max;
+    if (fs > 0 && ft < 0) return;
+
+    double pa = sqrt(1 + anphi*anphi) + anphi;
+    double ps = ten_max * anphi - amc;
+    double hh = p[1] - ten_max + pa * (p[0] - ps);
+    double a1 = bulkm + 4. / 3 * shearm;
+    double a2 = bulkm - 2. / 3 * shearm;
+
+    double alam;
+    if (hh < 0) {
+        alam = fs / (a1 - a2*anpsi + a1*anphi*anpsi - a2*anphi + 2*sqrt(anphi)*hardn);
+        p[0] -= alam * (a1 - a2 * anpsi);
+        p[1] -= alam * (a2 - a1 * anpsi);
+        depls = fabs(alam) * sqrt((3 + 2*anpsi + 3*anpsi*anpsi) / 8);
+    } else {
+        alam = ft / a1;
+        p[0] -= alam * a2;
+        p[1] -= alam * a1;
+        depls = fabs(alam) * sqrt(3. / 8);
+    }
+    double dc2 = (p[0] - p[1]) * cos2t;
+    double dss = p[0] + p[1];
+    s[0] = 0.5 * (dss + dc2);
+    s[1] = 0.5 * (dss - dc2);
+    s[2] = 0.5 * (p[0] - p[1]) * sin2t;
+}
+
+// rheology.cxx:486-701 (plane strain)
+__device__ __forceinline__ void elasto_plastic2d(double bulkm, double shearm, double amc, double anphi, double anpsi,
+                                                 double hardn, double ten_max, const double *de, double &depls,
+                                                 double *s, double &syy)
+{
+    depls = 0;
+    double a1 = bulkm + 4. / 3 * shearm;
+    double a2 = bulkm - 2. / 3 * shearm;
+    double sxx = s[0] + de[1]*a2 + de[0]*a1;
+    double szz = s[1] + de[0]*a2 + de[1]*a1;
+    double sxz = s[2] + de[2]*2*shearm;
+    syy += (de[0] + de[1]) * a2;
+
+    // p[n1], p[n2], p[n3] as scalars: which principal stress is the out-of-plane one
+    double p0, p1, p2;
+    double cos2t, sin2t;
+    int order;                       // 0: syy largest, 1: syy smallest, 2: syy intermediate
+    {
+        double s0 = 0.5 * (sxx + szz);
+        double rad = 0.5 * sqrt((sxx-szz)*(sxx-szz) + 4*sxz*sxz);
+        double si = s0 - rad;
+        double sii = s0 + rad;
+        const double eps = 1e-15;
+        if (rad > eps) {
+            cos2t = 0.5 * (szz - sxx) / rad;
+            sin2t = -sxz / rad;
+        } else {
+            cos2t = 1;
+            sin2t = 0;
+        }
+        if (syy > sii)      { order = 0; p0 = si;  p1 = sii; p2 = syy; }
+        else if (syy < si)  { order = 1; p0 = syy; p1 = si;  p2 = sii; }
+        else                { order = 2; p0 = si;  p1 = syy; p2 = sii; }
+    }
+
+    if (p0 >= ten_max) {
+        s[0] = s[1] = syy = ten_max;
+        s[2] = 0.0;
+        return;
+    }
+    if (p1 >= ten_max) { p1 = p2 = ten_max; }
+    else if (p2 >= ten_max) { p2 = ten_max; }
+
+    double fs = p0 - p2 * anphi + amc;
+    if (fs >= 0.0) {
+        s[0] = sxx;
+        s[1] = szz;
+        s[2] = sxz;
+        return;
+    }
+
+    const double alams = fs / (a1 - a2*anpsi + a1*anphi*anpsi - a2*anphi + hardn);
+    p0 -= alams * (a1 - a2 * anpsi);
+    p1 -= alams * (a2 - a2 * anpsi);
+    p2 -= alams * (a2 - a1 * anpsi);
+
+    depls = 0.5 * fabs(alams + alams * anpsi);
+
+    if (p0 >= ten_max) {
+        s[0] = s[1] = syy = ten_max;
+        s[2] = 0.0;
+        return;
+    }
+    if (p1 >= ten_max) { p1 = p2 = ten_max; }
+    else if (p2 >= ten_max) { p2 = ten_max; }
+
+    {
+        // (n1, n2, n3) = (0,1,2) / (1,2,0) / (0,2,1)
+        const double pn1 = (order == 1) ? p1 : p0;
+        const double pn2 = (order == 0) ? p1 : p2;
+        const double pn3 = (order == 0) ? p2 : (order == 1) ? p0 : p1;
+        double dc2 = (pn1 - pn2) * cos2t;
+        double dss = pn1 + pn2;
+        s[0] = 0.5 * (dss + dc2);
+        s[1] = 0.5 * (dss - dc2);
+        s[2] = 0.5 * (pn1 - pn2) * sin2t;
+        syy = pn3;
+    }
+}
+
+// utils.hpp:259-287
+__device__ __forceinline__ double interp1(const double *x, const double *y, int n, double x_new)
+{
+    double dist = DBL_MAX;
+    int idx = -1;
+    for (int i = 0; i < n; ++i) {
+        double newDist = x_new - x[i];
+        if (newDist >= 0 && newDist <= dist) { dist = newDist; idx = i; }
+    }
+    double slope = 0;
+    if (idx < 0) idx = 0;
+    else if (idx < n - 1) slope = (y[idx+1] - y[idx]) / (x[idx+1] - x[idx]);
+    return slope * (x_new - x[idx]) + y[idx];
+}
+
+// bc.cxx:42-50
+__device__ __forceinline__ void normal_vector_of_facet(const double fc[2][2], double *normal, double &zcenter)
+{
+    double v01[2];
+    for (int i = 0; i < 2; ++i) v01[i] = fc[1][i] - fc[0][i];
+    normal[0] = v01[1];
+    normal[1] = -v01[0];
+    zcenter = (fc[0][1] + fc[1][1]) / 2;
+}
+
+// ---------------------------------------------------------------------------------
+// kernels, in the order of a step
+// ---------------------------------------------------------------------------------
+__global__ void k2_clock(Clock *clk)                                  // dynearthsol.cxx:769-770
+{
+    clk->steps++;
+    clk->time += clk->dt;
+}
+
+// MatProps::refresh_elem_cache (matprops.cxx:259-303)
+__global__ void k2_props(const des_params *p, int ne, const int *markers, double *props)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const int *mk = &markers[(size_t)e * p->nmat];
+    props[e]          = desk::harmonic_mean(p->bulk_modulus, mk, p->nmat);
+    props[ne + e]     = desk::harmonic_mean(p->shear_modulus, mk, p->nmat);
+    props[2 * ne + e] = desk::arithmetic_mean(p->porosity, mk, p->nmat);
+    props[3 * ne + e] = desk::arithmetic_mean(p->heat_capacity, mk, p->nmat);
+    props[4 * ne + e] = desk::arithmetic_mean(p->therm_cond, mk, p->nmat);
+}
+
+// update_temperature (fields.cxx:197-278), element part
+__global__ void k2_temp_elem(const des_params *p, int nn, int ne, const int *conn, const double *coord,
+                             const double *temperature, const double *volume, const double *radiogenic,
+                             const double *props, const int *markers, double *tmp_result)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+    double kv = props[4 * ne + e] * volume[e];
+    double rh = radiogenic[e] * volume[e] * desk::mat_rho(p, mx, elemT(temperature, conn, ne, e)) / 3;
+    double d[3][2], shpdx[3], shpdz[3];
+    elem_coords(coord, conn, nn, ne, e, d);
+    shape_fn2(d, volume[e], shpdx, shpdz);
+    for (int i = 0; i < 3; ++i) {
+        double diffusion = 0.;
+        for (int j = 0; j < 3; ++j)
+            diffusion += (shpdx[i] * shpdx[j] + shpdz[i] * shpdz[j]) * temperature[conn[j * ne + e]];
+        tmp_result[i * ne + e] = diffusion * kv - rh;
+    }
+}
+
+__global__ void k2_temp_node(const des_params *p, const Clock *clk, int nn, int ne, const int *sup_idx, const int *sup_arr,
+                             const int *sup_lidx, const unsigned *bcflag, const double *tmp_result, const double *tmass,
+                             double *temperature)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    if (bcflag[n] & BOUNDZ1)
+        temperature[n] = p->surface_temperature;
+    else {
+        double tdot = 0;
+        for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k)
+            tdot += tmp_result[sup_lidx[k] * ne + sup_arr[k]];
+        temperature[n] -= clk->dt * tdot / tmass[n];
+    }
+}
+
+// update_strain_rate (fields.cxx:405-480) + the element part of compute_dvoldt (geometry.cxx:214-224)
+__global__ void k2_strain_rate(int nn, int ne, const int *conn, const double *coord, const double *vel,
+                               const double *volume, double *strain_rate, double *etmp)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    double d[3][2], shpdx[3], shpdz[3], v[3][2];
+    elem_coords(coord, conn, nn, ne, e, d);
+    shape_fn2(d, volume[e], shpdx, shpdz);
+    elem_coords(vel, conn, nn, ne, e, v);
+    double s[3];
+    s[0] = 0; for (int i = 0; i < 3; ++i) s[0] += v[i][0] * shpdx[i];
+    s[1] = 0; for (int i = 0; i < 3; ++i) s[1] += v[i][1] * shpdz[i];
+    s[2] = 0; for (int i = 0; i < 3; ++i) s[2] += 0.5 * (v[i][0] * shpdz[i] + v[i][1] * shpdx[i]);
+    for (int i = 0; i < 3; ++i) strain_rate[i * ne + e] = s[i];
+    double dj = s[0] + s[1];
+    etmp[e] = dj * volume[e];
+}
+
+// nodal gather of compute_dvoldt (geometry.cxx:226-237) and of NMD_stress (geometry.cxx:298-308)
+__global__ void k2_node_avg(int nn, const int *sup_idx, const int *sup_arr, const double *etmp, const double *volume_n, double *ntmp)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    double acc = 0.;
+    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) acc += etmp[sup_arr[k]];
+    ntmp[n] = acc / volume_n[n];
+}
+
+// compute_edvoldt (geometry.cxx:249-279)
+__global__ void k2_edvoldt(int ne, const int *conn, const double *ntmp, double *edvoldt)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    double dj = 0;
+    for (int i = 0; i < 3; ++i) dj += ntmp[conn[i * ne + e]];
+    edvoldt[e] = dj / 3;
+}
+
+// update_stress (rheology.cxx:703-1030, non-RSF, non-hydraulic) + the element part of NMD_stress
+template <class M>
+__global__ void __launch_bounds__(DES_BLOCK)
+k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, const int *conn, const double *temperature,
+          const double *props, const int *markers, const double *edvoldt, const double *volume, const double *volume_old,
+          double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
+          double *viscosity, double *dpressure, double *etmp)
+{
+    M::stage_begin();
+    M::stage_end();
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    const double dt = clk->dt;
+    desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+    const double bulkm = props[e], shearm = props[ne + e];
+    double s[3], es[3], edot[3];
+    for (int i = 0; i < 3; ++i) {
+        s[i] = stress[i * ne + e];
+        es[i] = strain[i * ne + e];
+        edot[i] = strain_rate[i * ne + e];
+    }
+    double old_s = trace2(s);
+    {
+        double div = trace2(edot);
+        for (int i = 0; i < 2; ++i) edot[i] += (edvoldt[e] - div) / 2;
+    }
+    for (int i = 0; i < 3; ++i) strain_rate[i * ne + e] = edot[i];
+    for (int i = 0; i < 3; ++i) es[i] += edot[i] * dt;
+    double de[3];
+    for (int i = 0; i < 3; ++i) de[i] = edot[i] * dt;
+
+    double dpls = 0.;
+    int past = 0;                  // statistics only (des_scalars::n_return_mapping): reached the yield test
+    switch (p->rheol_type) {
+    case DES_RH_ELASTIC:
+        elastic2(bulkm, shearm, de, s);
+        break;
+    case DES_RH_VISCOUS: {
+        double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
+        viscosity[e] = visc;
+        double total_dv = trace2(es);
+        viscous2(bulkm, visc, total_dv, edot, s);
+        break;
+    }
+    case DES_RH_MAXWELL: {
+        double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
+        viscosity[e] = visc;
+        double dv = volume[e] / volume_old[e] - 1;
+        maxwell2(bulkm, shearm, visc, dt, dv, de, s);
+        break;
+    }
+    case DES_RH_EP: {
+        double depls = 0;
+        double amc, anphi, anpsi, hardn, ten_max;
+        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max);
+        if (p->is_plane_strain) {
+            double syy = stressyy[e];
+            elasto_plastic2d(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, s, syy);
+            stressyy[e] = syy;
+        } else {
+            elasto_plastic(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, s);
+            past = 1;
+        }
+        plstrain[e] += depls;
+        dpls = depls;
+        break;
+    }
+    case DES_RH_EVP: {
+        double depls = 0;
+        double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
+        viscosity[e] = visc;
+        double dv = volume[e] / volume_old[e] - 1;
+        double sv[3];
+        for (int i = 0; i < 3; ++i) sv[i] = s[i];
+        maxwell2(bulkm, shearm, visc, dt, dv, de, sv);
+        double svII = second_invariant2_2d(sv);
+
+        double amc, anphi, anpsi, hardn, ten_max;
+        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max);
+        double sp[3], spyy = 0;
+        for (int i = 0; i < 3; ++i) sp[i] = s[i];
+        if (p->is_plane_strain) {
+            spyy = stressyy[e];
+            elasto_plastic2d(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, sp, spyy);
+        } else {
+            elasto_plastic(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, sp);
+            past = 1;
+        }
+        double spII = second_invariant2_2d(sp);
+        if (svII < spII) {
+            for (int i = 0; i < 3; ++i) s[i] = sv[i];
+        } else {
+            for (int i = 0; i < 3; ++i) s[i] = sp[i];
+            plstrain[e] += depls;
+            dpls = depls;
+            if (p->is_plane_strain) stressyy[e] = spyy;
+        }
+        break;
+    }
+    default: break;
+    }
+    delta_plstrain[e] = dpls;
+    {
+        const unsigned long long b = __ballot(past);
+        if (b && (int)(threadIdx.x & 63) == __ffsll((long long)b) - 1) atomicAdd(&clk->n_past, (int)__popcll(b));
+    }
+    if (p->is_using_mixed_stress) {
+        const double dp = trace2(s) - old_s;
+        dpressure[e] = dp;
+        etmp[e] = dp * volume[e];                      // NMD_stress, geometry.cxx:292-296
+    }
+    for (int i = 0; i < 3; ++i) {
+        stress[i * ne + e] = s[i];
+        strain[i * ne + e] = es[i];
+    }
+}
+
+// NMD_stress (geometry.cxx:311-331), element update
+__global__ void k2_nmd_apply(int ne, const int *conn, const double *ntmp, const double *dpressure, double *stress)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    double dp = 0;
+    for (int i = 0; i < 3; ++i) dp += ntmp[conn[i * ne + e]];
+    double dp_el = dp / 3;
+    double dp_orig = dpressure[e];
+    double ddp = (-dp_orig + dp_el) / 2;
+    for (int i = 0; i < 2; ++i) stress[i * ne + e] += ddp;
+}
+
+// update_force (fields.cxx:609-698): element part
+__global__ void k2_force_elem(const des_params *p, int nn, int ne, const int *conn, const double *coord, const double *temperature,
+                              const double *volume, const double *stress, const double *props, const int *markers, double *tmp_result)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    double d[3][2], shpdx[3], shpdz[3];
+    elem_coords(coord, conn, nn, ne, e, d);
+    double vol = volume[e];
+    shape_fn2(d, vol, shpdx, shpdz);
+    double s[3];
+    for (int i = 0; i < 3; ++i) s[i] = stress[i * ne + e];
+    double buoy = 0;
+    if (p->gravity != 0) {
+        desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+        const double phi = props[2 * ne + e];
+        buoy = (desk::mat_rho(p, mx, elemT(temperature, conn, ne, e)) * (1 - phi) + 1000.0 * phi) * p->gravity / 3;
+    }
+    for (int i = 0; i < 3; ++i) {
+        tmp_result[i * ne + e] = (s[0]*shpdx[i] + s[2]*shpdz[i]) * vol;
+        tmp_result[(i + 3) * ne + e] = (s[2]*shpdx[i] + s[1]*shpdz[i] + buoy) * vol;
+    }
+}
+
+// node part
+__global__ void k2_force_node(int nn, int ne, const int *sup_idx, const int *sup_arr, const int *sup_lidx,
+                              const double *tmp_result, double *force, double *fres)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    double f[2] = {0, 0}, fr[2] = {0, 0};
+    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) {
+        const int e = sup_arr[k], i = sup_lidx[k];
+        for (int j = 0; j < 2; j++) {
+            f[j] -= tmp_result[(i + 3*j) * ne + e];
+            fr[j] = tmp_result[(i + 3*j) * ne + e];            // assignment: fields.cxx:673
+        }
+    }
+    for (int j = 0; j < 2; j++) { force[j*nn + n] = f[j]; fres[j*nn + n] = fr[j]; }
+}
+
+// apply_stress_bcs (bc.cxx:661-827) of boundary `ib`: facet part ...
+__global__ void k2_sbc_facet(const des_params *p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
+                             const int *conn, const double *coord, const double *temperature, const int *markers,
+                             double *tmp_result, int *etmp_int)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= bound) return;
+    const int e = bf_elem[n], f = bf_facet[n];
+    double normal[2], zcenter, fc[2][2];
+    for (int j = 0; j < 2; ++j) {
+        const int nd = conn[NODE_OF_FACET_D[f][j] * ne + e];
+        fc[j][0] = coord[nd]; fc[j][1] = coord[nn + nd];
+    }
+    normal_vector_of_facet(fc, normal, zcenter);
+    double pr;
+    if (ib == iboundz0 && p->has_winkler_foundation) {
+        desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+        double rho_effective = desk::mat_rho(p, mx, elemT(temperature, conn, ne, e));
+        pr = p->compensation_pressure - (rho_effective + p->winkler_delta_rho) * p->gravity * (zcenter + p->zlength);
+    } else if (ib == iboundz1 && p->has_water_loading) {
+        pr = 0;
+        if (zcenter < p->surf_base_level)
+            pr = p->sea_water_density * p->gravity * (p->surf_base_level - zcenter);
+    } else {
+        pr = desk::ref_pressure(p, zcenter);
+        if (pr < 0.0) pr = 0.0;
+    }
+    etmp_int[e] = n;
+    for (int j = 0; j < 2; ++j)
+        for (int d = 0; d < 2; ++d)
+            tmp_result[(j*2 + d) * ne + n] = pr * normal[d] / 2;
+}
+
+// ... node part ...
+__global__ void k2_sbc_node(int nbdry_nodes, const int *bnodes, const int *bf_facet, int nn, int ne, const int *conn,
+                            const int *sup_idx, const int *sup_arr, const double *tmp_result, const int *etmp_int, double *force)
+{
+    const int j = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (j >= nbdry_nodes) return;
+    const int n = bnodes[j];
+    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) {
+        int e = sup_arr[k];
+        int ibound = etmp_int[e];
+        if (ibound < 0) continue;
+        int f = bf_facet[ibound];
+        for (int l = 0; l < 2; ++l) {
+            if (n == conn[NODE_OF_FACET_D[f][l] * ne + e]) {
+                for (int d = 0; d < 2; ++d)
+                    force[d * nn + n] -= tmp_result[(l*2 + d) * ne + ibound];
+                break;
+            }
+        }
+    }
+}
+
+// ... and the reset of the facet marks
+__global__ void k2_sbc_reset(int bound, const int *bf_elem, int *etmp_int)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n < bound) etmp_int[bf_elem[n]] = -1;
+}
+
+__global__ void k2_fill_int(int n, int *a, int v)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
+// elastic foundation (bc.cxx:819-825)
+__global__ void k2_elastic_foundation(const des_params *p, int nb, const int *bnodes, int nn, const double *coord,
+                                      const double *coord0, double *force)
+{
+    const int j = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (j >= nb) return;
+    const int n = bnodes[j];
+    force[nn + n] -= p->elastic_foundation_constant * (coord[nn + n] - coord0[nn + n]);
+}
+
+// apply_stress_bcs_neumann (bc.cxx:829-912) of one boundary: a serial loop in the reference, and
+// facets of one boundary share nodes, so one lane walks them in the reference's order
+__global__ void k2_neumann(const des_params *p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
+                           const int *conn, const double *coord, double *force)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int n = 0; n < bound; ++n) {
+        const int e = bf_elem[n], f = bf_facet[n];
+        double normal[2] = {0, 0}, zcenter = 0, fc[2][2];
+        for (int j = 0; j < 2; ++j) {
+            const int nd = conn[NODE_OF_FACET_D[f][j] * ne + e];
+            fc[j][0] = coord[nd]; fc[j][1] = coord[nn + nd];
+        }
+        normal_vector_of_facet(fc, normal, zcenter);
+        double traction[2] = {0, 0};
+        switch (p->stress_bc_types[ib]) {
+        case 1: traction[0] = p->stress_bc_values[ib]; break;
+        case 3: traction[1] = p->stress_bc_values[ib]; break;
+        default: continue;
+        }
+        for (int j = 0; j < 2; ++j) {
+            const int node = conn[NODE_OF_FACET_D[f][j] * ne + e];
+            for (int d = 0; d < 2; ++d)
+                force[d * nn + node] += traction[d] * normal[d] / 2;
+        }
+    }
+}
+
+// apply_damping (fields.cxx:483-579) + update_velocity (fields.cxx:725-742) of a node
+__global__ void k2_damp_vel(const des_params *p, const Clock *clk, int nn, const double *mass, const double *ymass,
+                            double *force, double *vel)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= nn) return;
+    const double small_vel = 1e-13;
+    const double dt = clk->dt;
+    for (int j = 0; j < 2; j++) {
+        double f = force[j*nn + i];
+        const double v = vel[j*nn + i];
+        switch (p->damping_option) {
+        case 1:
+            if (fabs(v) > small_vel) f -= p->damping_factor * copysign(f, v);
+            break;
+        case 2:
+            f -= p->damping_factor * f;
+            break;
+        case 3:
+            if ((f < 0) == (v < 0)) f -= p->damping_factor * f;          // fields.cxx:538: comma operator
+            else f += (1 - p->damping_factor) * f;
+            break;
+        case 4:
+            if (fabs(v) > small_vel) {
+                double critical_coeff = 2.0 * sqrt(mass[i] * ymass[i]);
+                double f_C = p->damping_factor * copysign(f, v);
+                double f_V = critical_coeff * v;
+                double f_damping = (fabs(f_C) < fabs(f_V)) ? f_V : f_C;
+                f -= f_damping;
+            }
+            break;
+        default: break;
+        }
+        force[j*nn + i] = f;
+        vel[j*nn + i] = v + dt * f / mass[i];
+    }
+}
+
+// calculate_residual_force (fields.cxx:700-722): per-block partial sums, then one block adds them
+__global__ void k2_residual_part(int nn, const double *fres, double *part)
+{
+    __shared__ double sm[DES_BLOCK / 64];
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    double v = 0;
+    if (i < nn) {
+        const double num = (double)nn * 2;
+        for (int j = 0; j < 2; ++j) { const double f = fres[j*nn + i]; v += f * f / num; }
+    }
+    v = desk::wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ void k2_residual_fin(int nb, const double *part, Clock *clk)
+{
+    __shared__ double sm[DES_BLOCK / 64];
+    double v = 0;
+    for (int i = threadIdx.x; i < nb; i += DES_BLOCK) v += part[i];
+    v = desk::wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) clk->l2_residual = sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+
+// apply_vbcs, 2-D: vertical extent of the x0 / x1 walls and the lowest node (bc.cxx:251-290, 350-361).
+// min / max: exact whatever the order.  One workgroup.
+__global__ void k2_vbc_extent(int nn, const unsigned *bcflag, const double *coord, Clock *clk)
+{
+    __shared__ double s_max[DES_BLOCK / 64], s_min[DES_BLOCK / 64], s_zmin[DES_BLOCK / 64];
+    __shared__ int s_any[DES_BLOCK / 64];
+    double mx = -DBL_MAX, mn = DBL_MAX, zmin = 0;
+    int any = 0;
+    for (int i = threadIdx.x; i < nn; i += DES_BLOCK) {
+        const double z = coord[nn + i];
+        if (z < zmin) zmin = z;
+        if (bcflag[i] & BOUNDX0) { any = 1; mx = fmax(mx, z); mn = fmin(mn, z); }
+    }
+    mx = desk::wave_max(mx); mn = desk::wave_min(mn); zmin = desk::wave_min(zmin);
+    any = __any(any);
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_max[w] = mx; s_min[w] = mn; s_zmin[w] = zmin; s_any[w] = any; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < DES_BLOCK / 64; ++w) {
+            s_max[0] = fmax(s_max[0], s_max[w]); s_min[0] = fmin(s_min[0], s_min[w]);
+            s_zmin[0] = fmin(s_zmin[0], s_zmin[w]); s_any[0] |= s_any[w];
+        }
+        clk->x0_init = s_any[0];
+        clk->x0_max = s_any[0] ? s_max[0] : 0.;
+        clk->x0_min = s_any[0] ? s_min[0] : 0.;
+        clk->zmin = s_zmin[0];
+    }
+}
+
+// apply_vbcs (bc.cxx:227-659, !THREED) of a node; `hold`: PT_jump (not offered in 2-D: always 0)
+__global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, const unsigned *bcflag, const double *bnormals,
+                              const double *edge_vec, const int *edge_slot, const double *coord, double *vel)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= nn) return;
+    const unsigned flag = bcflag[i];
+    if (!(flag & BOUND_ANY)) return;
+
+    double t_now = clk->time / DES2_YEAR2SEC;
+    double vbc_applied_x0 = p->vbc_values[0] * interp1(p->vbc_period_x0_time_in_yr, p->vbc_period_x0_ratio, p->num_vbc_period_x0, t_now);
+    double vbc_applied_x1 = p->vbc_values[1] * interp1(p->vbc_period_x1_time_in_yr, p->vbc_period_x1_ratio, p->num_vbc_period_x1, t_now);
+    const double BOUNDX0_max = clk->x0_max, BOUNDX0_width = clk->x0_max - clk->x0_min;
+    double div_x0[4], div_x1[4];
+    for (int k = 0; k < 4; k++) {
+        div_x0[k] = - (BOUNDX0_max - p->vbc_vertical_div_x0[k] * BOUNDX0_width);
+        div_x1[k] = - (BOUNDX0_max - p->vbc_vertical_div_x1[k] * BOUNDX0_width);      // x0's extent: bc.cxx:299
+    }
+    const int bc_x0 = p->vbc_types[0], bc_x1 = p->vbc_types[1];
+    const int bc_z0 = p->vbc_types[4];
+    int bc_z1 = p->vbc_types[5];
+    const double bc_vx0 = p->vbc_values[0], bc_vx1 = p->vbc_values[1];
+    const double bc_vz0 = p->vbc_values[4], bc_vz1 = p->vbc_values[5];
+    const double bc_vx0_l = p->vbc_val_l[0], bc_vx1_l = p->vbc_val_l[1];
+    if (clk->time > p->vbc_val_z1_loading_period) bc_z1 = 0;
+    const double zmin = clk->zmin;
+
+    double v[2] = {vel[i], vel[nn + i]};
+    const double x1 = coord[nn + i];
+    double vbc_exact_x0 = vbc_applied_x0 * interp1(div_x0, p->vbc_vertical_ratio_x0, 4, -x1);
+    double vbc_exact_x1 = vbc_applied_x1 * interp1(div_x1, p->vbc_vertical_ratio_x1, 4, -x1);
+
+    if (flag & BOUNDX0) {
+        switch (bc_x0) {
+        case 0: break;
+        case 1: v[0] = vbc_exact_x0; break;
+        case 2: v[1] = 0; break;
+        case 3:
+            v[0] = vbc_exact_x0;
+            if (p->bottom_shear_zone_thickness > 0.) {
+                double dz = x1 - zmin;
+                if (dz < p->bottom_shear_zone_thickness)
+                    v[0] = v[0] * dz / p->bottom_shear_zone_thickness;
+            }
+            v[1] = 0;
+            break;
+        case 4: v[0] = 0; v[1] = bc_vx0; break;
+        case 6: v[0] = vbc_exact_x0; v[1] = bc_vx0_l; break;
+        }
+    }
+    if (flag & BOUNDX1) {
+        switch (bc_x1) {
+        case 0: break;
+        case 1: v[0] = vbc_exact_x1; break;
+        case 2: v[1] = 0; break;
+        case 3: v[0] = vbc_exact_x1; v[1] = 0; break;
+        case 4: v[0] = 0; v[1] = bc_vx1; break;
+        case 6: v[0] = vbc_exact_x1; v[1] = bc_vx1_l; break;
+        }
+    }
+
+    // slanted boundaries n0..n3, bc.cxx:491-585
+    for (int ib = iboundn0; ib <= iboundn3; ib++) {
+        if (!(flag & (1u << ib))) continue;
+        const double n[2] = {bnormals[ib], bnormals[DES_NBDRY + ib]};
+        double fac = 0;
+        switch (p->vbc_types[ib]) {
+        case 1:
+        case 11: {
+            const int nd = (p->vbc_types[ib] == 1) ? 2 : 1;
+            double target = p->vbc_values[ib];
+            if (p->vbc_types[ib] == 11) {
+                fac = 1 / sqrt(1 - n[1]*n[1]);
+                target = p->vbc_values[ib] * fac;
+            }
+            if (flag == (1u << ib)) {
+                double vn = 0;
+                for (int d = 0; d < nd; d++) vn += v[d] * n[d];
+                for (int d = 0; d < nd; d++) v[d] += (target - vn) * n[d];
+            } else {
+                for (int ic = iboundx0; ic < ib; ic++) {
+                    if (!(flag & (1u << ic))) continue;
+                    if (p->vbc_types[ic] == 0) {
+                        double vn = 0;
+                        for (int d = 0; d < nd; d++) vn += v[d] * n[d];
+                        for (int d = 0; d < nd; d++) v[d] += (target - vn) * n[d];
+                    } else if (p->vbc_types[ic] == 1) {
+                        const int slot = edge_slot[ic*DES_NBDRY + ib];
+                        if (slot < 0) continue;
+                        const double *edge = &edge_vec[slot*2];
+                        double ve = 0;
+                        for (int d = 0; d < 2; d++) ve += v[d] * edge[d];
+                        for (int d = 0; d < 2; d++) v[d] = ve * edge[d];
+                    }
+                }
+            }
+            break;
+        }
+        case 3:
+            for (int d = 0; d < 2; d++) v[d] = p->vbc_values[ib] * n[d];
+            break;
+        case 13:
+            fac = 1 / sqrt(1 - n[1]*n[1]);
+            v[0] = p->vbc_values[ib] * fac * n[0];
+            v[1] = 0;
+            break;
+        }
+    }
+
+    // Z last, bc.cxx:587-650
+    if (!(bc_z0 == 0 && bc_z1 == 0)) {
+        if (flag & BOUNDZ0) {
+            switch (bc_z0) {
+            case 0: break;
+            case 1: v[1] = bc_vz0; break;
+            case 2: v[0] = 0; break;
+            case 3: v[0] = 0; v[1] = bc_vz0; break;
+            case 4: v[0] = bc_vz0; v[1] = 0; break;
+            }
+        }
+        if (flag & BOUNDZ1) {
+            switch (bc_z1) {
+            case 0: break;
+            case 1: v[1] = bc_vz1; break;
+            case 2: v[0] = 0; break;
+            case 3: v[0] = 0.0; v[1] = bc_vz1; break;
+            case 4: v[0] = bc_vz1; v[1] = 0; break;
+            }
+        }
+    }
+    vel[i] = v[0]; vel[nn + i] = v[1];
+}
+
+// isostasy_adjustment's velocity filter (dynearthsol.cxx:524-533)
+__global__ void k2_iso_vel(const des_params *p, int nn, const unsigned *bcflag, double *vel)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= nn) return;
+    vel[i] = 0;
+    if (!p->has_winkler_foundation && (bcflag[i] & BOUNDZ0)) vel[nn + i] = 0;
+}
+
+// update_coordinate (fields.cxx:761-784)
+__global__ void k2_update_coord(const Clock *clk, int n2, const double *vel, double *coord)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < n2) coord[i] += vel[i] * clk->dt;
+}
+
+// simple_diffusion (bc.cxx:916-1112, !THREED): segments of the sorted top nodes ...
+__global__ void k2_surf_seg(int etop, int nn, int ne, const int *top_nodes, const double *coord, double *etmp, double *tmp_result)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= etop) return;
+    const int n0 = top_nodes[i], n1 = top_nodes[i+1];
+    double dx = fabs(coord[n1] - coord[n0]);
+    etmp[i] = dx;
+    tmp_result[0 * ne + i] = -(coord[nn + n1] - coord[nn + n0]) / dx;
+    tmp_result[1 * ne + i] = (coord[nn + n1] - coord[nn + n0]) / dx;
+}
+
+// ... then the height change of every top node; surface_processes moves the node and books dhacc
+// (bc.cxx:1773-1786).  dh[] starts from 0 (bc.cxx:1718-1724).
+__global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
+                             const double *etmp, const double *tmp_result, double *total_dx, double *total_slope,
+                             double *coord, double *dhacc, double *dh)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= ntop) return;
+    const int n = top_nodes[i];
+    double d = 0.;
+    if (p->surface_process_option == 1) {
+        double tdx, tsl;
+        if (i == 0) { tdx = etmp[i]; tsl = tmp_result[0 * ne + i]; }
+        else if (i == ntop-1) { tdx = etmp[i-1]; tsl = tmp_result[1 * ne + i-1]; }
+        else { tdx = etmp[i-1] + etmp[i]; tsl = tmp_result[1 * ne + i-1] + tmp_result[0 * ne + i]; }
+        total_dx[n] = tdx; total_slope[n] = tsl;
+        double conv = p->surface_diffusivity * clk->dt * tsl / tdx;
+        const double z = coord[nn + n];
+        if (z > p->surf_base_level && conv > 0.) d -= p->surf_diff_ratio_terrig * conv;
+        else if (z <= p->surf_base_level && conv < 0.) d -= p->surf_diff_ratio_marine * conv;
+        else d -= conv;
+    }
+    dh[i] = d;
+    coord[nn + n] += d;
+    dhacc[n] += d;
+}
+
+// edvacc_surf (bc.cxx:1788-1805)
+__global__ void k2_surf_edv(int etop, int nn, const int *ean, const int *conn_surf, const double *coord, const double *dh, double *edvacc)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= etop) return;
+    double dh_e = 0.;
+    for (int j = 0; j < 2; j++) dh_e += dh[ean[j * etop + i]];
+    const double base = fabs(coord[conn_surf[i]] - coord[conn_surf[etop + i]]);      // compute_area_facet, geometry.cxx:109-121
+    edvacc[i] += dh_e * base / 2;
+}
+
+// max |dh| -> max_surf_vel (bc.cxx:1820-1836).  One workgroup.
+__global__ void k2_surf_maxdh(int ntop, const double *dh, Clock *clk)
+{
+    __shared__ double sm[DES_BLOCK / 64];
+    double m = 0.;
+    for (int i = threadIdx.x; i < ntop; i += DES_BLOCK) m = fmax(m, fabs(dh[i]));
+    m = desk::wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < DES_BLOCK / 64; ++w) sm[0] = fmax(sm[0], sm[w]);
+        clk->maxdh = sm[0];
+        clk->max_surf_vel = sm[0] / clk->dt;
+    }
+}
+
+// correct_surface_element (bc.cxx:1655-1707), element part; surface_plstrain_diffusion (bc.cxx:1633-1653)
+// rides along when `decay` (same elements, applied after the correction as in surface_processes)
+__global__ void k2_cse_elem(const des_params *p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
+                            const int *conn, const double *coord, const int *markers, int decay, double *volume,
+                            double *plstrain, double *stress, double *strain, double *strain_rate)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= ntop_elems) return;
+    const int e = top_elems[i];
+    double d[3][2];
+    elem_coords(coord, conn, nn, ne, e, d);
+    double new_volumes = triangle_area(d[0], d[1], d[2]);
+    double rdv = new_volumes / volume[e];
+    volume[e] = new_volumes;
+    double pls = plstrain[e];
+    if (!(rdv < 1.0)) {
+        pls /= rdv;
+        for (int j = 0; j < 3; j++) {
+            stress[j*ne+e] /= rdv;
+            strain[j*ne+e] /= rdv;
+            strain_rate[j*ne+e] /= rdv;
+        }
+    }
+    if (decay) {
+        const int *a = &markers[(size_t)e * p->nmat];
+        int mat = 0;
+        for (int m = 1; m < p->nmat; ++m) if (a[m] > a[mat]) mat = m;        // std::max_element: first maximum
+        if (mat != p->mattype_oceanic_crust) {
+            double half_life = 1.e2 * DES2_YEAR2SEC;
+            double lambha = 0.69314718056 / half_life;
+            pls -= pls * lambha * clk->dt;
+        }
+    }
+    plstrain[e] = pls;
+}
+
+__global__ void k2_cse_node(int ntop, const int *top_nodes, const int *sup_idx, const int *sup_arr, const double *volume,
+                            double *volume_n, int reset_dhacc, double *dhacc)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= ntop) return;
+    const int nt = top_nodes[i];
+    double acc = 0.;
+    for (int k = sup_idx[nt]; k < sup_idx[nt+1]; ++k) acc += volume[sup_arr[k]];
+    volume_n[nt] = acc;
+    if (reset_dhacc) dhacc[nt] = 0.;                      // bc.cxx:1837-1838
+}
+
+// compute_volume (geometry.cxx:170-201) + the element part of compute_mass (geometry.cxx:1743-1870)
+__global__ void k2_volume_mass_elem(const des_params *p, int nn, int ne, const int *conn, const double *coord,
+                                    const double *temperature, const double *props, const int *markers, int with_mass,
+                                    double *volume, double *tmp_result)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    double d[3][2];
+    elem_coords(coord, conn, nn, ne, e, d);
+    const double vol = triangle_area(d[0], d[1], d[2]);
+    volume[e] = vol;
+    if (!with_mass) return;
+    desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+    const double bulkm = props[e], shearm = props[ne + e];
+    const double mrho = desk::mat_rho(p, mx, elemT(temperature, conn, ne, e));
+    const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+    double rho = p->is_quasi_static ? bulkm / (pseudo_speed * pseudo_speed) : mrho;
+    double m = rho * vol / 3;
+    double tm = mrho * props[3 * ne + e] * vol / 3;
+    double ym = 9 * bulkm * shearm / (3 * bulkm + shearm) / 3;
+    tmp_result[0 * ne + e] = m;
+    tmp_result[1 * ne + e] = tm;
+    tmp_result[2 * ne + e] = ym;
+}
+
+__global__ void k2_mass_node(const des_params *p, int nn, int ne, const int *sup_idx, const int *sup_arr, const double *volume,
+                             const double *tmp_result, double *volume_n, double *mass, double *tmass, double *ymass)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    double vn = 0, ms = 0, tms = 0, yms = 0;
+    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) {
+        const int e = sup_arr[k];
+        vn += volume[e];
+        ms += tmp_result[0 * ne + e];
+        if (p->has_thermal_diffusion) tms += tmp_result[1 * ne + e];
+        yms += tmp_result[2 * ne + e];
+    }
+    volume_n[n] = vn; mass[n] = ms; tmass[n] = tms; ymass[n] = yms;
+}
+
+// rotate_stress (fields.cxx:807-821, 885-900)
+__device__ __forceinline__ void jaumann_rate_2d(double *s, double dt, double w2)
+{
+    double s_inc[3];
+    s_inc[0] = -2.0 * s[2] * w2;
+    s_inc[1] =  2.0 * s[2] * w2;
+    s_inc[2] = s[0] * w2 - s[1] * w2;
+    for (int i = 0; i < 3; ++i) s[i] += dt * s_inc[i];
+}
+
+__global__ void k2_rotate(const Clock *clk, int nn, int ne, const int *conn, const double *coord, const double *vel,
+                          const double *volume, double *stress, double *strain)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    double d[3][2], shpdx[3], shpdz[3], v[3][2];
+    elem_coords(coord, conn, nn, ne, e, d);
+    shape_fn2(d, volume[e], shpdx, shpdz);
+    elem_coords(vel, conn, nn, ne, e, v);
+    double w2 = 0;
+    for (int i = 0; i < 3; ++i) w2 += 0.5 * (v[i][1] * shpdx[i] - v[i][0] * shpdz[i]);
+    double s[3], es[3];
+    for (int i = 0; i < 3; ++i) { s[i] = stress[i*ne+e]; es[i] = strain[i*ne+e]; }
+    jaumann_rate_2d(s, clk->dt, w2);
+    jaumann_rate_2d(es, clk->dt, w2);
+    for (int i = 0; i < 3; ++i) { stress[i*ne+e] = s[i]; strain[i*ne+e] = es[i]; }
+}
+
+// Output::average_fields (output.cxx:327-370)
+__global__ void k2_average(Clock *clk, int first, int nn2, int ne, const double *coord, const double *strain, const double *stress,
+                           const double *delta_plstrain, double *coord_avg0, double *strain0, double *stress_avg, double *dplstrain_avg)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i == 0 && first) clk->avg_time0 = clk->time;
+    if (first) {
+        if (i < nn2) coord_avg0[i] = coord[i];
+        if (i < 3 * ne) { strain0[i] = strain[i]; stress_avg[i] = stress[i]; }
+        if (i < ne) dplstrain_avg[i] = delta_plstrain[i];
+    } else {
+        if (i < 3 * ne) stress_avg[i] += stress[i];
+        if (i < ne) dplstrain_avg[i] += delta_plstrain[i];
+    }
+}
+
+// compute_dt (geometry.cxx:1480-1647): element reduction ...
+__global__ void k2_dt_init(Clock *clk)
+{
+    clk->r_minl = DBL_MAX; clk->r_dt_maxwell = DBL_MAX; clk->r_dt_diffusion = DBL_MAX;
+    clk->r_global_dt_min = DBL_MAX; clk->r_max_vem = 0.0;
+}
+
+__global__ void k2_dt_partials(const des_params *p, Clock *clk, int nn, int ne, const int *conn, const double *coord,
+                               const double *vel, const double *temperature, const double *volume, const double *props,
+                               const int *markers)
+{
+    __shared__ double sm[5][DES_BLOCK / 64];
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    double minl = DBL_MAX, dt_maxwell = DBL_MAX, dt_diffusion = DBL_MAX, gdt = DBL_MAX, vem = 0.0;
+    if (e < ne) {
+        double vx = 0.0, vy = 0.0;
+        double weight = 1.0 / 3;
+        for (int j = 0; j < 3; ++j) {
+            int n = conn[j * ne + e];
+            vx += vel[n] * weight;
+            vy += vel[nn + n] * weight;
+        }
+        vem = sqrt(vx*vx + vy*vy);
+        double d[3][2];
+        elem_coords(coord, conn, nn, ne, e, d);
+        double maxl = sqrt(fmax(fmax(dist2(d[0], d[1]), dist2(d[1], d[2])), dist2(d[0], d[2])));
+        double minh = 2 * volume[e] / maxl;
+        const double shearm = props[ne + e];
+        dt_maxwell = 0.5 * p->visc_min / (1e-40 + shearm);
+        if (p->has_thermal_diffusion) dt_diffusion = 0.5 * minh * minh / p->therm_diff_max;
+        minl = minh;
+        desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+        gdt = minh / sqrt(shearm / desk::mat_rho(p, mx, elemT(temperature, conn, ne, e))) / 5.0;
+    }
+    minl = desk::wave_min(minl); dt_maxwell = desk::wave_min(dt_maxwell); dt_diffusion = desk::wave_min(dt_diffusion);
+    gdt = desk::wave_min(gdt); vem = desk::wave_max(vem);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sm[0][w] = minl; sm[1][w] = dt_maxwell; sm[2][w] = dt_diffusion; sm[3][w] = gdt; sm[4][w] = vem;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < DES_BLOCK / 64; ++w) {
+            for (int q = 0; q < 4; ++q) sm[q][0] = fmin(sm[q][0], sm[q][w]);
+            sm[4][0] = fmax(sm[4][0], sm[4][w]);
+        }
+        desk::atomic_min_double(&clk->r_minl, sm[0][0]);
+        desk::atomic_min_double(&clk->r_dt_maxwell, sm[1][0]);
+        desk::atomic_min_double(&clk->r_dt_diffusion, sm[2][0]);
+        desk::atomic_min_double(&clk->r_global_dt_min, sm[3][0]);
+        desk::atomic_max_double(&clk->r_max_vem, sm[4][0]);
+    }
+}
+
+// ... and its tail (geometry.cxx:1597-1646)
+__global__ void k2_dt_finalize(const des_params *p, Clock *clk)
+{
+    const double minl = clk->r_minl, dt_maxwell = clk->r_dt_maxwell, dt_diffusion = clk->r_dt_diffusion;
+    const double dt_hydro_diffusion = DBL_MAX;
+    double global_max_vem = clk->r_max_vem;
+    double max_vbc_val;
+    if (p->characteristic_speed == 0) {
+        max_vbc_val = p->max_vbc_val;
+        if (p->surface_process_option > 0) max_vbc_val = fmax(max_vbc_val, clk->max_surf_vel * 5e-1);
+    } else
+        max_vbc_val = p->characteristic_speed;
+    global_max_vem = fmax(global_max_vem, p->max_vbc_val);
+    clk->max_global_vel_mag = global_max_vem;
+    clk->global_dt_min = clk->r_global_dt_min;
+    double dt_advection = 0.5 * minl / max_vbc_val;
+    double dt_elastic = p->is_quasi_static
+        ? 0.5 * minl / (max_vbc_val * p->inertial_scaling)
+        : 0.5 * minl / sqrt(p->bulk_modulus[p->mattype_ref] / p->rho0[p->mattype_ref]);
+    double dt = fmin(fmin(fmin(dt_elastic, dt_maxwell), fmin(dt_advection, dt_diffusion)), dt_hydro_diffusion) * p->dt_fraction;
+    if (p->fixed_dt != 0) dt = p->fixed_dt;
+    if (dt <= 0) clk->status = DES_ERR_RUNTIME_NAN;
+    clk->dt = dt;
+}
+
+__global__ void k2_count_nan(long long n, const double *a, unsigned long long *count)
+{
+    const long long i = (long long)blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < n && a[i] != a[i]) atomicAdd(count, 1ull);
+}
+
+// bad_mesh_quality's reductions (remeshing.cxx:2765-2798, 2841-2844) + elem_quality (geometry.cxx:1873-1909, !THREED).
+// One workgroup; "first" = lowest index, as the reference's serial loops find it.
+__global__ void k2_quality(int nn, int ne, const int *conn, const double *coord, const double *volume, const unsigned *bcflag,
+                           double smallest_vol, double bottom, double bottom_dist, des_quality *out)
+{
+    __shared__ int s_small[DES_BLOCK], s_bot[DES_BLOCK], s_worst[DES_BLOCK];
+    __shared__ double s_q[DES_BLOCK];
+    int small = INT_MAX, bot = INT_MAX, worst = 0;
+    double q = 1;
+    for (int e = threadIdx.x; e < ne; e += DES_BLOCK) {
+        if (volume[e] < smallest_vol && e < small) small = e;
+        double d[3][2];
+        elem_coords(coord, conn, nn, ne, e, d);
+        double normalization_factor = 4 * sqrt(3.0);
+        double dist2_sum = dist2(d[0], d[1]) + dist2(d[1], d[2]) + dist2(d[0], d[2]);
+        double quality = normalization_factor * volume[e] / dist2_sum;
+        if (quality < q) { q = quality; worst = e; }
+    }
+    if (bottom_dist >= 0)
+        for (int i = threadIdx.x; i < nn; i += DES_BLOCK)
+            if ((bcflag[i] & BOUNDZ0) && fabs(coord[nn + i] - bottom) > bottom_dist && i < bot) bot = i;
+    s_small[threadIdx.x] = small; s_bot[threadIdx.x] = bot; s_worst[threadIdx.x] = worst; s_q[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the serial loop keeps the first element attaining the strict minimum
+        for (int t = 1; t < DES_BLOCK; ++t) {
+            small = min(small, s_small[t]); bot = min(bot, s_bot[t]);
+            if (s_q[t] < q || (s_q[t] == q && s_q[t] < 1 && s_worst[t] < worst)) { q = s_q[t]; worst = s_worst[t]; }
+        }
+        out->small_elem = small == INT_MAX ? -1 : small;
+        out->bottom_node = bot == INT_MAX ? -1 : bot;
+        out->worst_elem = worst; out->worst_quality = q; out->pad_ = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+struct FieldRef { void *ptr; long long count; int elsize; };
+
+FieldRef field_ref(const Engine *h, int field)
+{
+    const long long nn = h->nn, ne = h->ne;
+    switch (field) {
+    case DES_F_COORD: return {h->coord, 2*nn, 8};
+    case DES_F_VEL: return {h->vel, 2*nn, 8};
+    case DES_F_FORCE: return {h->force, 2*nn, 8};
+    case DES_F_FORCE_RESIDUAL: return {h->fres, 2*nn, 8};
+    case DES_F_COORD0: return {h->coord0, 2*nn, 8};
+    case DES_F_TEMPERATURE: return {h->temperature, nn, 8};
+    case DES_F_VOLUME_N: return {h->volume_n, nn, 8};
+    case DES_F_MASS: return {h->mass, nn, 8};
+    case DES_F_TMASS: return {h->tmass, nn, 8};
+    case DES_F_DHACC: return {h->dhacc, nn, 8};
+    case DES_F_NTMP: return {h->ntmp, nn, 8};
+    case DES_F_STRESS: return {h->stress, 3*ne, 8};
+    case DES_F_STRAIN: return {h->strain, 3*ne, 8};
+    case DES_F_STRAIN_RATE: return {h->strain_rate, 3*ne, 8};
+    case DES_F_PLSTRAIN: return {h->plstrain, ne, 8};
+    case DES_F_DELTA_PLSTRAIN: return {h->delta_plstrain, ne, 8};
+    case DES_F_VISCOSITY: return {h->viscosity, ne, 8};
+    case DES_F_VOLUME: return {h->volume, ne, 8};
+    case DES_F_VOLUME_OLD: return {h->volume_old, ne, 8};
+    case DES_F_DPRESSURE: return {h->dpressure, ne, 8};
+    case DES_F_EDVOLDT: return {h->edvoldt, ne, 8};
+    case DES_F_RADIOGENIC: return {h->radiogenic, ne, 8};
+    case DES_F_ELEMMARKERS: return {h->markers, ne * h->nmat, 4};
+    case DES_F_EDVACC_SURF: return {h->edvacc, (long long)h->etop, 8};
+    case DES_F_DH: return {h->dh, (long long)h->ntop, 8};
+    case DES_F_STRESSYY: return {h->stressyy, ne, 8};
+    case DES_F_STRESS_AVG: return {h->stress_avg, h->stress_avg ? 3*ne : 0, 8};
+    case DES_F_DPLSTRAIN_AVG: return {h->dplstrain_avg, h->dplstrain_avg ? ne : 0, 8};
+    case DES_F_STRAIN0: return {h->strain0, h->strain0 ? 3*ne : 0, 8};
+    case DES_F_COORD_AVG0: return {h->coord_avg0, h->coord_avg0 ? 2*nn : 0, 8};
+    default: return {nullptr, -1, 0};
+    }
+}
+
+#define L2(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, __VA_ARGS__)
+
+void refresh_props(Engine *h)
+{
+    if (!h->markers_dirty) return;
+    L2(k2_props, h->ne, h->d_p, h->ne, h->markers, h->props);
+    h->markers_dirty = false;
+}
+
+void launch_volume_mass(Engine *h, bool with_mass)
+{
+    L2(k2_volume_mass_elem, h->ne, h->d_p, h->nn, h->ne, h->conn, h->coord, h->temperature, h->props, h->markers,
+       with_mass ? 1 : 0, h->volume, h->tmp_result);
+    if (with_mass)
+        L2(k2_mass_node, h->nn, h->d_p, h->nn, h->ne, h->sup_idx, h->sup_arr, h->volume, h->tmp_result, h->volume_n,
+           h->mass, h->tmass, h->ymass);
+}
+
+void launch_vbcs(Engine *h)
+{
+    hipLaunchKernelGGL(k2_vbc_extent, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nn, h->bcflag, h->coord, h->d_clk);
+    L2(k2_apply_vbcs, h->nn, h->d_p, h->d_clk, h->nn, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->coord, h->vel);
+}
+
+template <class M>
+void launch_stress(Engine *h)
+{
+    L2(k2_stress<M>, h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
+       h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
+       h->viscosity, h->dpressure, h->etmp);
+}
+
+// update_force's boundary terms in the reference's order (fields.cxx:682-691)
+void launch_stress_bcs(Engine *h)
+{
+    const des_params &p = h->p;
+    if (p.gravity != 0) {
+        for (int i = 0; i < DES_NBDRY; i++) {
+            if (p.vbc_types[i] != 0 && p.vbc_types[i] != 2 && p.vbc_types[i] != 4) continue;
+            if (i == iboundz0 && !p.has_winkler_foundation) continue;
+            if (i == iboundz1 && !p.has_water_loading) continue;
+            if (h->nbf[i] == 0) continue;
+            L2(k2_sbc_facet, h->nbf[i], h->d_p, i, h->nbf[i], h->bf_elem[i], h->bf_facet[i], h->nn, h->ne, h->conn, h->coord,
+               h->temperature, h->markers, h->tmp_result, h->etmp_int);
+            if (h->nbn[i])
+                L2(k2_sbc_node, h->nbn[i], h->nbn[i], h->bnodes[i], h->bf_facet[i], h->nn, h->ne, h->conn, h->sup_idx, h->sup_arr,
+                   h->tmp_result, h->etmp_int, h->force);
+            L2(k2_sbc_reset, h->nbf[i], h->nbf[i], h->bf_elem[i], h->etmp_int);
+        }
+        if (p.has_elastic_foundation && h->nbn[iboundz0])
+            L2(k2_elastic_foundation, h->nbn[iboundz0], h->d_p, h->nbn[iboundz0], h->bnodes[iboundz0], h->nn, h->coord, h->coord0, h->force);
+    }
+    for (int i = 0; i < 6; ++i) {
+        if (p.stress_bc_types[i] == 0 || h->nbf[i] == 0) continue;
+        hipLaunchKernelGGL(k2_neumann, dim3(1), dim3(64), 0, h->stream, h->d_p, i, h->nbf[i], h->bf_elem[i], h->bf_facet[i],
+                           h->nn, h->ne, h->conn, h->coord, h->force);
+    }
+}
+
+// update_mesh (dynearthsol.cxx:448-493) after update_coordinate
+void launch_update_mesh(Engine *h, long long steps)
+{
+    const des_params &p = h->p;
+    // surface_processes (bc.cxx:1709-1872)
+    if (p.surface_process_option == 1 && h->etop > 0)
+        L2(k2_surf_seg, h->etop, h->etop, h->nn, h->ne, h->top_nodes, h->coord, h->etmp, h->tmp_result);
+    if (h->ntop > 0)
+        L2(k2_surf_node, h->ntop, h->d_p, h->d_clk, h->ntop, h->nn, h->ne, h->top_nodes, h->etmp, h->tmp_result, h->total_dx,
+           h->total_slope, h->coord, h->dhacc, h->dh);
+    if (h->etop > 0)
+        L2(k2_surf_edv, h->etop, h->etop, h->nn, h->ean, h->conn_surf, h->coord, h->dh, h->edvacc);
+    hipLaunchKernelGGL(k2_surf_maxdh, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->ntop, h->dh, h->d_clk);
+    const bool at_interval = steps % p.quality_check_step_interval == 0;
+    const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
+    if (h->ntop_elems > 0)
+        L2(k2_cse_elem, h->ntop_elems, h->d_p, h->d_clk, h->ntop_elems, h->top_elems, h->nn, h->ne, h->conn, h->coord, h->markers,
+           decay, h->volume, h->plstrain, h->stress, h->strain, h->strain_rate);
+    if (h->ntop > 0)
+        L2(k2_cse_node, h->ntop, h->ntop, h->top_nodes, h->sup_idx, h->sup_arr, h->volume, h->volume_n,
+           (steps != 0 && at_interval) ? 1 : 0, h->dhacc);
+    std::swap(h->volume, h->volume_old);
+    refresh_props(h);
+    launch_volume_mass(h, true);
+}
+
+void launch_dt(Engine *h)
+{
+    refresh_props(h);
+    hipLaunchKernelGGL(k2_dt_init, dim3(1), dim3(1), 0, h->stream, h->d_clk);
+    L2(k2_dt_partials, h->ne, h->d_p, h->d_clk, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
+    hipLaunchKernelGGL(k2_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk);
+}
+
+int sync_clock(Engine *h)
+{
+    HIP2(hipMemcpyAsync(h->h_clk, h->d_clk, sizeof(Clock), hipMemcpyDeviceToHost, h->stream));
+    HIP2(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+template <class M>
+void one_step(Engine *h)
+{
+    const des_params &p = h->p;
+    const int nn = h->nn, ne = h->ne;
+    if (!h->iso) {
+        hipLaunchKernelGGL(k2_clock, dim3(1), dim3(1), 0, h->stream, h->d_clk);
+        ++h->steps_host;
+    }
+    refresh_props(h);
+    if (!h->iso && p.has_thermal_diffusion) {
+        L2(k2_temp_elem, ne, h->d_p, nn, ne, h->conn, h->coord, h->temperature, h->volume, h->radiogenic, h->props, h->markers, h->tmp_result);
+        L2(k2_temp_node, nn, h->d_p, h->d_clk, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->bcflag, h->tmp_result, h->tmass, h->temperature);
+    }
+    L2(k2_strain_rate, ne, nn, ne, h->conn, h->coord, h->vel, h->volume, h->strain_rate, h->etmp);
+    L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
+    L2(k2_edvoldt, ne, ne, h->conn, h->ntmp, h->edvoldt);
+    launch_stress<M>(h);
+    if (!h->iso && p.is_using_mixed_stress) {
+        L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
+        L2(k2_nmd_apply, ne, ne, h->conn, h->ntmp, h->dpressure, h->stress);
+    }
+    L2(k2_force_elem, ne, h->d_p, nn, ne, h->conn, h->coord, h->temperature, h->volume, h->stress, h->props, h->markers, h->tmp_result);
+    L2(k2_force_node, nn, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->tmp_result, h->force, h->fres);
+    launch_stress_bcs(h);
+    L2(k2_damp_vel, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->force, h->vel);
+    L2(k2_residual_part, nn, nn, h->fres, h->res_part);
+    hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(nn), h->res_part, h->d_clk);
+    if (h->iso) L2(k2_iso_vel, nn, h->d_p, nn, h->bcflag, h->vel);
+    else launch_vbcs(h);
+    if (p.has_moving_mesh || h->iso) {
+        L2(k2_update_coord, 2 * nn, h->d_clk, 2 * nn, h->vel, h->coord);
+        launch_update_mesh(h, h->steps_host);
+    }
+    if (h->iso) return;
+    if (p.rheol_type & DES_RH_ELASTIC)
+        L2(k2_rotate, ne, h->d_clk, nn, ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
+    if (p.is_outputting_averaged_fields) {
+        const int first = (h->steps_host % p.quality_check_step_interval == 1) ? 1 : 0;
+        L2(k2_average, std::max(3 * ne, 2 * nn), h->d_clk, first, 2 * nn, ne, h->coord, h->strain, h->stress, h->delta_plstrain,
+           h->coord_avg0, h->strain0, h->stress_avg, h->dplstrain_avg);
+    }
+    if (h->steps_host % 10 == 0) launch_dt(h);
+}
+
+} // namespace
+
+const std::string &last_error(const Engine *h) { return h->err; }
+
+void destroy(Engine *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *q : h->allocs) hipFree(q);
+    if (h->h_clk) hipHostFree(h->h_clk);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh)
+{
+    const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
+    HIP2(hipStreamCreate(&h->stream));
+    HIP2(hipEventCreate(&h->ev0));
+    HIP2(hipEventCreate(&h->ev1));
+    HIP2(hipHostMalloc((void **)&h->h_clk, sizeof(Clock)));
+    int rc;
+#define A2(x) do { rc = (x); if (rc) return rc; } while (0)
+    A2(dcopy(h, h->d_p, params, 1));
+    {
+        // matprops.cxx:237-250
+        desk::ViscTerms vt;
+        const double gas_constant = 8.3144;
+        for (int m = 0; m < DES_MAX_MAT; ++m) vt.pow_edot[m] = vt.coef_term[m] = vt.nR[m] = 0;
+        for (int m = 0; m < nmat; ++m) {
+            vt.pow_edot[m] = 1 / params->visc_exponent[m] - 1;
+            const double pow1 = -1 / params->visc_exponent[m];
+            vt.coef_term[m] = std::pow(0.75 * params->visc_coefficient[m], pow1);
+            vt.nR[m] = params->visc_exponent[m] * gas_constant;
+        }
+        A2(dcopy(h, h->d_vt, &vt, 1));
+    }
+    A2(dalloc(h, h->d_clk, 1));
+    A2(dcopy(h, h->conn, mesh->connectivity, (size_t)3 * ne));
+    A2(dcopy(h, h->sup_idx, mesh->support_idx, (size_t)nn + 1));
+    A2(dcopy(h, h->sup_arr, mesh->support_arr, (size_t)3 * ne));
+    A2(dcopy(h, h->sup_lidx, mesh->support_lidx, (size_t)3 * ne));
+    A2(dcopy(h, h->bcflag, mesh->bcflag, (size_t)nn));
+    for (int i = 0; i < DES_NBDRY; ++i) {
+        h->nbf[i] = mesh->nbfacets[i]; h->nbn[i] = mesh->nbnodes[i];
+        A2(dcopy(h, h->bf_elem[i], mesh->bfacet_elem[i], (size_t)h->nbf[i]));
+        A2(dcopy(h, h->bf_facet[i], mesh->bfacet_facet[i], (size_t)h->nbf[i]));
+        A2(dcopy(h, h->bnodes[i], mesh->bnodes[i], (size_t)h->nbn[i]));
+    }
+    A2(dcopy(h, h->bnormals, mesh->bnormals, (size_t)2 * DES_NBDRY));
+    A2(dcopy(h, h->edge_vec, mesh->edge_vec, (size_t)2 * mesh->nedge));
+    A2(dcopy(h, h->edge_slot, mesh->edge_slot, (size_t)DES_NBDRY * DES_NBDRY));
+    h->ntop = mesh->ntop; h->etop = mesh->etop; h->ntop_elems = mesh->ntop_elems;
+    A2(dcopy(h, h->top_nodes, mesh->top_nodes, (size_t)h->ntop));
+    A2(dcopy(h, h->ean, mesh->elem_and_nodes, (size_t)2 * h->etop));
+    A2(dcopy(h, h->conn_surf, mesh->connectivity_surface, (size_t)3 * h->etop));
+    A2(dcopy(h, h->top_elems, mesh->top_elems, (size_t)h->ntop_elems));
+
+    for (double **v : {&h->coord, &h->vel, &h->force, &h->fres, &h->coord0}) A2(dalloc(h, *v, (size_t)2 * nn));
+    for (double **v : {&h->temperature, &h->volume_n, &h->mass, &h->tmass, &h->ymass, &h->dhacc, &h->ntmp, &h->total_dx, &h->total_slope})
+        A2(dalloc(h, *v, (size_t)nn));
+    for (double **v : {&h->stress, &h->strain, &h->strain_rate}) A2(dalloc(h, *v, (size_t)3 * ne));
+    for (double **v : {&h->stressyy, &h->plstrain, &h->delta_plstrain, &h->viscosity, &h->volume, &h->volume_old, &h->dpressure,
+                       &h->edvoldt, &h->radiogenic, &h->etmp})
+        A2(dalloc(h, *v, (size_t)ne));
+    A2(dalloc(h, h->tmp_result, (size_t)6 * ne));
+    A2(dalloc(h, h->props, (size_t)5 * ne));
+    A2(dalloc(h, h->markers, (size_t)ne * nmat));
+    A2(dalloc(h, h->etmp_int, (size_t)ne));
+    A2(dalloc(h, h->dh, (size_t)h->ntop));
+    A2(dalloc(h, h->edvacc, (size_t)h->etop));
+    A2(dalloc(h, h->res_part, (size_t)nblk(nn)));
+    if (params->is_outputting_averaged_fields) {
+        A2(dalloc(h, h->stress_avg, (size_t)3 * ne)); A2(dalloc(h, h->strain0, (size_t)3 * ne));
+        A2(dalloc(h, h->dplstrain_avg, (size_t)ne)); A2(dalloc(h, h->coord_avg0, (size_t)2 * nn));
+    }
+    {
+        std::vector<double> v((size_t)ne, params->visc_max);               // fields.cxx:110
+        HIP2(hipMemcpy(h->viscosity, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    L2(k2_fill_int, ne, ne, h->etmp_int, -1);
+    HIP2(hipStreamSynchronize(h->stream));
+#undef A2
+    return DES_OK;
+}
+
+Engine *create(int device, const des_params *params, const des_mesh *mesh, int *err, std::string &msg)
+{
+    *err = DES_OK;
+    if (params->ndims != 2) { *err = DES_ERR_UNSUPPORTED_DIM; msg = "not a 2-D model"; return nullptr; }
+    if (params->nmat < 1 || params->nmat > DES_MAX_MAT) { *err = DES_ERR_CONFIG_VALUE; msg = "bad nmat"; return nullptr; }
+    switch (params->rheol_type) {
+    case DES_RH_ELASTIC: case DES_RH_VISCOUS: case DES_RH_MAXWELL: case DES_RH_EP: case DES_RH_EVP: break;
+    default: *err = DES_ERR_UNSUPPORTED; msg = "rheology not offloaded"; return nullptr;
+    }
+    if (params->has_PT) { *err = DES_ERR_UNSUPPORTED_DIM; msg = "control.has_PT: the pseudo-transient loop is offloaded for 3-D models only"; return nullptr; }
+    if (params->num_vbc_period_x0 < 1 || params->num_vbc_period_x0 > DES_MAX_PERIOD ||
+        params->num_vbc_period_x1 < 1 || params->num_vbc_period_x1 > DES_MAX_PERIOD) {
+        *err = DES_ERR_CONFIG_VALUE; msg = "bad num_vbc_period_x?"; return nullptr;
+    }
+    if (mesh->nelem < 1 || mesh->nnode < 3) { *err = DES_ERR_RESOURCE; msg = "empty mesh"; return nullptr; }
+    if (mesh->etop > 0 && mesh->etop != mesh->ntop - 1) {
+        // simple_diffusion walks consecutive pairs of the sorted top nodes (bc.cxx:1021-1033)
+        *err = DES_ERR_CONFIG_VALUE; msg = "2-D surface: etop must be ntop - 1"; return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { *err = DES_ERR_UNSUPPORTED; msg = "no such HIP device"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { *err = DES_ERR_UNSUPPORTED; msg = "hipSetDevice failed"; return nullptr; }
+    Engine *h = new Engine();
+    h->device = device;
+    h->p = *params;
+    const char *env = std::getenv("DES_LIBM");
+    h->portable_libm = !env || std::strcmp(env, "portable") == 0;
+    if (env && !h->portable_libm && std::strcmp(env, "ocml") != 0) {
+        *err = DES_ERR_CONFIG_VALUE; msg = "DES_LIBM must be 'ocml' or 'portable'"; delete h; return nullptr;
+    }
+    int rc = create_impl(h, params, mesh);
+    if (rc) { *err = rc; msg = h->err; destroy(h); return nullptr; }
+    return h;
+}
+
+long long field_count(const Engine *h, int field)
+{
+    FieldRef r = field_ref(h, field);
+    return r.count;
+}
+
+int upload(Engine *h, int field, const void *host, long long count)
+{
+    FieldRef r = field_ref(h, field);
+    if (r.count < 0 || count != r.count) { h->err = "upload: field size mismatch"; return DES_ERR_INTERNAL; }
+    HIP2(hipSetDevice(h->device));
+    HIP2(hipStreamSynchronize(h->stream));
+    if (count) HIP2(hipMemcpy(r.ptr, host, (size_t)count * r.elsize, hipMemcpyHostToDevice));
+    if (field == DES_F_ELEMMARKERS) h->markers_dirty = true;
+    return DES_OK;
+}
+
+int download(Engine *h, int field, void *host, long long count)
+{
+    FieldRef r = field_ref(h, field);
+    if (r.count < 0 || count != r.count) { h->err = "download: field size mismatch"; return DES_ERR_INTERNAL; }
+    HIP2(hipSetDevice(h->device));
+    HIP2(hipStreamSynchronize(h->stream));
+    if (count) HIP2(hipMemcpy(host, r.ptr, (size_t)count * r.elsize, hipMemcpyDeviceToHost));
+    return DES_OK;
+}
+
+int set_clock(Engine *h, double dt, double time, long long steps)
+{
+    HIP2(hipSetDevice(h->device));
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    h->h_clk->dt = dt; h->h_clk->time = time; h->h_clk->steps = steps;
+    h->steps_host = steps;
+    HIP2(hipMemcpy(h->d_clk, h->h_clk, sizeof(Clock), hipMemcpyHostToDevice));
+    return DES_OK;
+}
+
+int set_isostasy(Engine *h, int on) { h->iso = on != 0; return DES_OK; }
+
+int sync(Engine *h)
+{
+    HIP2(hipSetDevice(h->device));
+    HIP2(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+// dynearthsol.cxx:184-194 (compute_volume, volume_old = volume, apply_vbcs, compute_mass)
+int init_geometry(Engine *h)
+{
+    HIP2(hipSetDevice(h->device));
+    refresh_props(h);
+    launch_volume_mass(h, false);
+    HIP2(hipMemcpyAsync(h->volume_old, h->volume, (size_t)h->ne * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    launch_vbcs(h);
+    launch_volume_mass(h, true);
+    HIP2(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int compute_dt(Engine *h, double *dt)
+{
+    HIP2(hipSetDevice(h->device));
+    launch_dt(h);
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    if (dt) *dt = h->h_clk->dt;
+    return h->h_clk->dt > 0 ? DES_OK : DES_ERR_RUNTIME_NAN;
+}
+
+int step(Engine *h, int nsteps, des_scalars *out)
+{
+    HIP2(hipSetDevice(h->device));
+    for (int i = 0; i < nsteps; ++i) {
+        if (i == nsteps - 1) {
+            static const int zero = 0;
+            HIP2(hipMemcpyAsync(&h->d_clk->n_past, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        }
+        if (h->portable_libm) one_step<desk::MathPortable>(h);
+        else one_step<desk::MathOcml>(h);
+    }
+    HIP2(hipGetLastError());
+    if (out) {
+        int rc = sync_clock(h);
+        if (rc) return rc;
+        const Clock &c = *h->h_clk;
+        out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
+        out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min; out->steps = c.steps;
+        out->status = c.status; out->n_return_mapping = c.n_past; out->avg_time0 = c.avg_time0; out->n_pt_iterations = 0;
+        return c.status;
+    }
+    return DES_OK;
+}
+
+int check_nan(Engine *h, long long *n_nan)
+{
+    HIP2(hipSetDevice(h->device));
+    unsigned long long *d_count = nullptr;
+    HIP2(hipMalloc((void **)&d_count, sizeof(unsigned long long)));
+    hipMemsetAsync(d_count, 0, sizeof(unsigned long long), h->stream);
+    const long long nn = h->nn, ne = h->ne;
+    struct { const double *a; long long n; } arr[] = {
+        {h->volume, ne}, {h->dpressure, ne}, {h->viscosity, ne}, {h->stress, 3*ne}, {h->temperature, nn},
+        {h->tmass, nn}, {h->force, 2*nn}, {h->vel, 2*nn}, {h->coord, 2*nn} };
+    for (auto &a : arr) L2(k2_count_nan, a.n, a.n, a.a, d_count);
+    unsigned long long c = 0;
+    hipError_t e = hipMemcpyAsync(&c, d_count, sizeof(c), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_count);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return DES_ERR_RESOURCE; }
+    if (n_nan) *n_nan = (long long)c;
+    return c ? DES_ERR_RUNTIME_NAN : DES_OK;
+}
+
+int mesh_quality(Engine *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out)
+{
+    HIP2(hipSetDevice(h->device));
+    des_quality *d_out = nullptr;
+    HIP2(hipMalloc((void **)&d_out, sizeof(des_quality)));
+    hipLaunchKernelGGL(k2_quality, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nn, h->ne, h->conn, h->coord, h->volume, h->bcflag,
+                       smallest_vol, bottom, bottom_dist, d_out);
+    hipError_t e = hipMemcpyAsync(out, d_out, sizeof(des_quality), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_out);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return DES_ERR_RESOURCE; }
+    return DES_OK;
+}
+
+int timer_start(Engine *h) { HIP2(hipSetDevice(h->device)); HIP2(hipEventRecord(h->ev0, h->stream)); return DES_OK; }
+int timer_stop(Engine *h, float *ms)
+{
+    HIP2(hipEventRecord(h->ev1, h->stream));
+    HIP2(hipEventSynchronize(h->ev1));
+    HIP2(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return DES_OK;
+}
+
+// reads + writes of the kernels above per step (8-byte words; gathers counted once per use)
+double algorithmic_bytes_per_step(const Engine *h)
+{
+    return 8.0 * (118.0 * h->ne + 60.0 * h->nn);
+}
+
+} // namespace des2d

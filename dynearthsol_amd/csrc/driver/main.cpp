@@ -1,5 +1,8 @@
-// dynearthsol3d-hip -- the reference's `dynearthsol3d config_file` with the explicit time step
-// on an MI355X: same .cfg in, same <modelname>.save.NNNNNN / .chkpt.NNNNNN / .info out.
+// dynearthsol3d-hip / dynearthsol2d-hip -- the reference's `dynearthsol3d config_file` (built
+// -DTHREED) and `dynearthsol2d config_file` (2-D build, Makefile `ndims = 2`) with the explicit
+// time step on an MI355X: same .cfg in, same <modelname>.save.NNNNNN / .chkpt.NNNNNN / .info out.
+// One program: the dimension comes from the name it is called by ("2d" in it: the 2-D build) or
+// from --ndims.
 // The loop is des_run (include/des_run.h, mirroring dynearthsol.cxx:593-982); this file only
 // binds it to the HIP engine of include/des_dev.h.  There is no CPU fallback: without a GPU
 // the run stops with the reference's exit category 31 (EXIT_UNSUPPORTED_LIB).
@@ -30,8 +33,11 @@ int main(int argc, const char *argv[])
 {
     std::string cfg, mesh, remesher = std::getenv("DES_REMESH_CMD") ? std::getenv("DES_REMESH_CMD") : "";
     int device = 0, quiet = 0;
+    const char *base = std::strrchr(argv[0], '/');
+    int ndims = std::strstr(base ? base + 1 : argv[0], "2d") ? 2 : 3;
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--device") && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--ndims") && i + 1 < argc) ndims = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--mesh") && i + 1 < argc) mesh = argv[++i];
         else if (!std::strcmp(argv[i], "--remesher") && i + 1 < argc) remesher = argv[++i];
         else if (!std::strcmp(argv[i], "--quiet")) quiet = 1;
@@ -39,7 +45,7 @@ int main(int argc, const char *argv[])
         else cfg = argv[i];
     }
     if (cfg.empty()) {
-        std::fprintf(stderr, "Usage: %s config_file [--device N] [--mesh file.desmesh] [--remesher command] [--quiet]\n", argv[0]);
+        std::fprintf(stderr, "Usage: %s config_file [--ndims 2|3] [--device N] [--mesh file.desmesh] [--remesher command] [--quiet]\n", argv[0]);
         return 1;                                                   // EXIT_USAGE
     }
     if (des_dev_device_count() <= device) {
@@ -55,8 +61,8 @@ int main(int argc, const char *argv[])
     int rc = 0;
     for (int round = 0; ; ++round) {
         int err = 0;
-        des_host *host = des_host_create(cfg.c_str(), overrides.empty() ? nullptr : overrides.c_str(),
-                                         (round == 0 && !mesh.empty()) ? mesh.c_str() : nullptr, &err);
+        des_host *host = des_host_create_nd(ndims, cfg.c_str(), nullptr, overrides.empty() ? nullptr : overrides.c_str(),
+                                            (round == 0 && !mesh.empty()) ? mesh.c_str() : nullptr, &err);
         if (!host) {
             std::fprintf(stderr, "%s\n", des_host_last_error());
             return err ? err : DES_ERR_INTERNAL;

@@ -43,13 +43,13 @@ void rename_to_old_backup(const std::string &fpath)
 // binaryio.cxx:64-204
 class FrameFile {
 public:
-    explicit FrameFile(const std::string &filename, bool rename_if_exists = false)
+    explicit FrameFile(const std::string &filename, bool rename_if_exists = false, int ndims = 3)
         : header_(headerlen, '\0'), eof_pos_(headerlen)
     {
         if (rename_if_exists) rename_to_old_backup(filename);
         f_ = std::fopen(filename.c_str(), "wb");
         if (!f_) throw des::Error(20, "Error: cannot open file: " + filename);             // EXIT_IO_OPEN
-        const std::string rev = "# DynEarthSol ndims=3 revision=4\n";
+        const std::string rev = "# DynEarthSol ndims=" + std::to_string(ndims) + " revision=4\n";       // binaryio.cxx:39-40
         std::memcpy(&header_[0], rev.data(), rev.size());
         hd_pos_ = rev.size();
         std::fseek(f_, (long)eof_pos_, SEEK_SET);
@@ -205,10 +205,11 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
 
         char filename[256];
         std::snprintf(filename, 255, "%s.save.%06d", o->modelname.c_str(), o->frame);
-        FrameFile bin(filename, o->may_overwrite && o->frame == o->start_frame);
+        const int nd = m.nd, npe = nd + 1, nstr = nd * (nd + 1) / 2;
+        FrameFile bin(filename, o->may_overwrite && o->frame == o->start_frame, nd);
 
-        bin.array2d(f->coord, 3, "coordinate", nn);
-        bin.array2d(m.conn.data(), 4, "connectivity", ne);
+        bin.array2d(f->coord, nd, "coordinate", nn);
+        bin.array2d(m.conn.data(), npe, "connectivity", ne);
         bin.scalar((int)f->steps, "steps");
         bin.scalar(double(run_time_ns) * 1e-9, "walltime_sec");
         bin.scalar((int)m.nnode, "nnode");
@@ -217,13 +218,13 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
         bin.scalar(dt, "dt_sec");
         bin.scalar((int)m.nseg, "nseg");
 
-        bin.array2d(f->vel, 3, "velocity", nn);
+        bin.array2d(f->vel, nd, "velocity", nn);
         std::vector<double> tmp;
         if (averaged) {
             // average_velocity = displacement / delta_t
-            tmp.resize(3 * nn);
-            for (std::size_t i = 0; i < 3 * nn; ++i) tmp[i] = (f->coord[i] - f->coord_avg0[i]) * inv_dt;
-            bin.array2d(tmp.data(), 3, "velocity averaged", nn);
+            tmp.resize(nd * nn);
+            for (std::size_t i = 0; i < nd * nn; ++i) tmp[i] = (f->coord[i] - f->coord_avg0[i]) * inv_dt;
+            bin.array2d(tmp.data(), nd, "velocity averaged", nn);
         }
         bin.array(f->temperature, "temperature", nn);
         tmp.assign(nn, 0.0);                       // no hydraulic diffusion on the device path
@@ -240,20 +241,20 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
         }
         if (averaged) {
             // average_strain_rate = delta_strain / delta_t
-            tmp.resize(6 * ne);
-            for (std::size_t i = 0; i < 6 * ne; ++i) tmp[i] = (f->strain[i] - f->strain0[i]) * inv_dt;
-            bin.array2d(tmp.data(), 6, "strain-rate", ne);
+            tmp.resize(nstr * ne);
+            for (std::size_t i = 0; i < nstr * ne; ++i) tmp[i] = (f->strain[i] - f->strain0[i]) * inv_dt;
+            bin.array2d(tmp.data(), nstr, "strain-rate", ne);
         } else {
-            bin.array2d(f->strain_rate, 6, "strain-rate", ne);
+            bin.array2d(f->strain_rate, nstr, "strain-rate", ne);
         }
-        bin.array2d(f->strain, 6, "strain", ne);
-        bin.array2d(f->stress, 6, "stress", ne);
+        bin.array2d(f->strain, nstr, "strain", ne);
+        bin.array2d(f->stress, nstr, "stress", ne);
         bin.array(f->viscosity, "viscosity", ne);
         if (averaged) {
             const double w = 1.0 / (o->average_interval + 1);
-            tmp.resize(6 * ne);
-            for (std::size_t i = 0; i < 6 * ne; ++i) tmp[i] = f->stress_avg[i] * w;
-            bin.array2d(tmp.data(), 6, "stress averaged", ne);
+            tmp.resize(nstr * ne);
+            for (std::size_t i = 0; i < nstr * ne; ++i) tmp[i] = f->stress_avg[i] * w;
+            bin.array2d(tmp.data(), nstr, "stress averaged", ne);
         }
 
         tmp.resize(ne);
@@ -263,9 +264,21 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
 
         for (std::size_t e = 0; e < ne; ++e) {
             double c[4][3];
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < npe; ++i) {
                 const std::size_t n = m.conn[(std::size_t)i * ne + e];
-                for (int d = 0; d < 3; ++d) c[i][d] = f->coord[(std::size_t)d * nn + n];
+                for (int d = 0; d < nd; ++d) c[i][d] = f->coord[(std::size_t)d * nn + n];
+            }
+            if (nd == 2) {
+                // elem_quality, geometry.cxx:1901-1906
+                auto dist2 = [](const double *a, const double *b) {
+                    double sum = 0;
+                    for (int i = 0; i < 2; ++i) { double d = b[i] - a[i]; sum += d * d; }
+                    return sum;
+                };
+                const double normalization_factor = 4 * std::sqrt(3);
+                const double dist2_sum = dist2(c[0], c[1]) + dist2(c[1], c[2]) + dist2(c[0], c[2]);
+                tmp[e] = normalization_factor * f->volume[e] / dist2_sum;
+                continue;
             }
             const double normalization_factor = 216 * std::sqrt(3);
             const double area_sum = (tri_area(c[0], c[1], c[2]) + tri_area(c[0], c[1], c[3]) +
@@ -283,8 +296,8 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
         }
         bin.array(tmp.data(), "material", ne);
 
-        bin.array2d(f->force, 3, "force", nn);
-        bin.array2d(f->coord0, 3, "coord0", nn);
+        bin.array2d(f->force, nd, "force", nn);
+        bin.array2d(f->coord0, nd, "coord0", nn);
         bin.array(m.bcflag.data(), "bcflag", nn);
 
         if (o->has_marker_output) {
@@ -293,16 +306,16 @@ int des_output_write(des_output *o, const des_frame *f, int exact)
             const std::size_t nm = (std::size_t)mk.nmarkers;
             const int itmp[1] = { mk.nmarkers };
             bin.array(itmp, "markerset size", 1);
-            tmp.assign(3 * nm, 0.0);                              // calculate_marker_coord (:989-1007)
+            tmp.assign(nd * nm, 0.0);                              // calculate_marker_coord (:989-1007)
             for (std::size_t n = 0; n < nm; ++n)
-                for (int d = 0; d < 3; ++d) {
+                for (int d = 0; d < nd; ++d) {
                     double sum = 0;
-                    for (int k = 0; k < 4; ++k)
+                    for (int k = 0; k < npe; ++k)
                         sum += f->coord[(std::size_t)d * nn + m.conn[(std::size_t)k * ne + mk.elem[n]]] * mk.eta[(std::size_t)k * nm + n];
-                    tmp[n * 3 + d] = sum;
+                    tmp[n * nd + d] = sum;
                 }
-            bin.array(tmp.data(), "markerset.coord", 3 * nm);
-            bin.array2d(mk.eta.data(), 4, "markerset.eta", nm);
+            bin.array(tmp.data(), "markerset.coord", nd * nm);
+            bin.array2d(mk.eta.data(), npe, "markerset.eta", nm);
             bin.array(mk.elem.data(), "markerset.elem", nm);
             bin.array(mk.mattype.data(), "markerset.mattype", nm);
             bin.array(mk.id.data(), "markerset.id", nm);
@@ -344,7 +357,7 @@ int des_output_write_checkpoint(des_output *o, const des_frame *f)
         const des::HostMesh &m = h->mesh;
         char filename[256];
         std::snprintf(filename, 255, "%s.chkpt.%06d", o->modelname.c_str(), o->frame);
-        FrameFile bin(filename, o->may_overwrite && o->frame == o->start_frame);
+        FrameFile bin(filename, o->may_overwrite && o->frame == o->start_frame, m.nd);
         bin.scalar(f->time, "time");
         bin.scalar(f->info_display_next_step, "info_display_next_step");
         bin.scalar(h->fields.compensation_pressure, "compensation_pressure");
@@ -353,11 +366,13 @@ int des_output_write_checkpoint(des_output *o, const des_frame *f)
         bin.scalar(f->max_global_vel_mag, "max_global_vel_mag");
         bin.scalar(f->reference_frame_time, "reference_frame_time");
         bin.scalar(f->last_remesh_time, "last_remesh_time");
-        bin.array2d(m.segment.data(), 3, "segment", (std::size_t)m.nseg);
+        bin.array2d(m.segment.data(), m.nd, "segment", (std::size_t)m.nseg);
         bin.array(m.segflag.data(), "segflag", (std::size_t)m.nseg);
-        bin.array(f->edvacc_surf, "dv surface acc", m.conn_surf.size() / 4);
+        bin.array(f->edvacc_surf, "dv surface acc", m.conn_surf.size() / (m.nd + 1));
         bin.array(f->dhacc, "dhacc", (std::size_t)m.nnode);
         bin.array(f->volume_old, "volume_old", (std::size_t)m.nelem);
+        if (h->params.is_plane_strain && f->stressyy)                      // output.cxx:394-395
+            bin.array(f->stressyy, "stressyy", (std::size_t)m.nelem);
         {   // MarkerSet::write_chkpt_file (markerset.cxx:877-891)
             const des::HostMarkers &mk = h->fields.markers;
             const int itmp[3] = { mk.nmarkers, mk.last_id, mk.reserved_space };

@@ -39,6 +39,7 @@ struct Run {
     des_output *out;
     des_scalars sc;
     bool averaged;
+    bool plane_strain = false;    // mat.is_plane_strain of a 2-D model: stressyy goes into checkpoints
     int info_display_next_step;
     double reference_frame_time, last_remesh_time;
     double restored_vmax;         // max_global_vel_mag of the checkpoint, until compute_dt renews it
@@ -74,7 +75,7 @@ struct Run {
         f.plstrain = pls.data(); f.delta_plstrain = dpls.data(); f.strain_rate = edot.data();
         f.strain = strain.data(); f.stress = stress.data(); f.viscosity = visc.data(); f.volume = vol.data();
         f.force = force.data(); f.coord0 = coord0.data(); f.elemmarkers = markers.data();
-        std::vector<double> c0, s0, savg, davg, vold, edv, dhacc;
+        std::vector<double> c0, s0, savg, davg, vold, edv, dhacc, syy;
         if (averaged && !exact) {
             c0 = get(DES_F_COORD_AVG0); s0 = get(DES_F_STRAIN0); savg = get(DES_F_STRESS_AVG); davg = get(DES_F_DPLSTRAIN_AVG);
             f.coord_avg0 = c0.data(); f.strain0 = s0.data(); f.stress_avg = savg.data(); f.dplstrain_avg = davg.data();
@@ -83,6 +84,7 @@ struct Run {
         if (checkpoint) {
             vold = get(DES_F_VOLUME_OLD); edv = get(DES_F_EDVACC_SURF); dhacc = get(DES_F_DHACC);
             f.volume_old = vold.data(); f.edvacc_surf = edv.data(); f.dhacc = dhacc.data();
+            if (plane_strain) { syy = get(DES_F_STRESSYY); f.stressyy = syy.data(); }
             f.info_display_next_step = info_display_next_step;
             f.reference_frame_time = reference_frame_time; f.last_remesh_time = last_remesh_time;
             int rc = api->no_files ? 0 : des_output_write_checkpoint(out, &f);
@@ -153,6 +155,9 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         r.check(api->upload(r.eng, DES_F_STRAIN, f.strain.data(), (long long)f.strain.size()), "upload strain");
         r.check(api->upload(r.eng, DES_F_PLSTRAIN, f.plstrain.data(), (long long)f.plstrain.size()), "upload plstrain");
         r.check(api->upload(r.eng, DES_F_VISCOSITY, f.viscosity.data(), (long long)f.viscosity.size()), "upload viscosity");
+        if (m.nd == 2)
+            r.check(api->upload(r.eng, DES_F_STRESSYY, f.stressyy.data(), (long long)f.stressyy.size()), "upload stressyy");
+        r.plane_strain = p.is_plane_strain != 0;
         if (!rs.active) {
             double dt0 = 0;
             r.check(api->compute_dt(r.eng, &dt0), "compute_dt");
@@ -219,7 +224,8 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
             std::fflush(stdout);
         }
 
-        const double smallest_vol = cfg.d("mesh.smallest_size") * sizefactor * std::pow(cfg.d("mesh.resolution"), 3);
+        // remeshing.cxx:40-44, 2765: the volume of an equilateral tetrahedron / triangle of unit side
+        const double smallest_vol = cfg.d("mesh.smallest_size") * (m.nd == 3 ? sizefactor : 0.433) * std::pow(cfg.d("mesh.resolution"), m.nd);
         const int remeshing_option = cfg.i("mesh.remeshing_option");
         const bool check_bottom = remeshing_option == 1 || remeshing_option == 2 || remeshing_option == 11 || remeshing_option == 13;
         const double bottom_dist = check_bottom ? cfg.d("mesh.max_boundary_distortion") * cfg.d("mesh.resolution") : -1.0;
@@ -306,7 +312,7 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
                         bad = 2;
                         if (!quiet) std::printf("    Node #%d is too far from the bottm\n", q.bottom_node);
                     } else {
-                        min_quality = std::pow(q.worst_quality, 1.0 / 3);
+                        min_quality = (m.nd == 3) ? std::pow(q.worst_quality, 1.0 / 3) : q.worst_quality;   // remeshing.cxx:2845-2848
                         if (min_quality < cfg.d("mesh.min_quality")) {
                             bad = 1;
                             if (!quiet) std::printf("    Element #%d has mesh quality = %g\n", q.worst_elem, min_quality);

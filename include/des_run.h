@@ -35,6 +35,7 @@ typedef struct des_frame {
     /* Output::average_fields state; all NULL unless sim.is_outputting_averaged_fields */
     const double *coord_avg0, *strain0, *stress_avg, *dplstrain_avg;
     double avg_time0;
+    const double *stressyy;         /* checkpoint only, plane-strain 2-D models (output.cxx:394-395); else NULL */
 } des_frame;
 
 typedef struct des_output des_output;

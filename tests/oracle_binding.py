@@ -78,7 +78,7 @@ class portable_libm:
     the portable libm instead of glibc / ocml."""
 
     def __enter__(self):
-        self._old = [(lib, lib.des_oracle_set_libm(1)) for lib in (load_oracle(False), load_oracle(True))]
+        self._old = [(lib, lib.des_oracle_set_libm(1)) for lib in (load_oracle(False), load_oracle(True), load_oracle(ndims=2))]
         self._env = os.environ.get("DES_LIBM")
         os.environ["DES_LIBM"] = "portable"
         return self
