@@ -41,6 +41,7 @@ struct Clock {
     double avg_time0;
     long long steps;
     int status, iso, n_past, x0_init;
+    int pt, pad;                       // inside the pseudo-transient loop of a step (Param::control.PT_jump)
 };
 
 inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
@@ -79,6 +80,7 @@ struct Engine {
     double *res_part = nullptr; int res_nb = 0;
     bool markers_dirty = true, iso = false;
     long long steps_host = 0;
+    long long n_pt_iterations = 0;   // pseudo-transient iterations of the current step() call
     std::vector<void *> allocs;
     std::string err;
 };
@@ -848,7 +850,7 @@ __global__ void k2_vbc_extent(int nn, const unsigned *bcflag, const double *coor
     }
 }
 
-// apply_vbcs (bc.cxx:227-659, !THREED) of a node; `hold`: PT_jump (not offered in 2-D: always 0)
+// apply_vbcs (bc.cxx:227-659, !THREED) of a node; Clock::pt = PT_jump: boundaries at rest (bc.cxx:330-343)
 __global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, const unsigned *bcflag, const double *bnormals,
                               const double *edge_vec, const int *edge_slot, const double *coord, double *vel)
 {
@@ -869,9 +871,13 @@ __global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, con
     const int bc_x0 = p->vbc_types[0], bc_x1 = p->vbc_types[1];
     const int bc_z0 = p->vbc_types[4];
     int bc_z1 = p->vbc_types[5];
-    const double bc_vx0 = p->vbc_values[0], bc_vx1 = p->vbc_values[1];
-    const double bc_vz0 = p->vbc_values[4], bc_vz1 = p->vbc_values[5];
+    double bc_vx0 = p->vbc_values[0], bc_vx1 = p->vbc_values[1];
+    double bc_vz0 = p->vbc_values[4], bc_vz1 = p->vbc_values[5];
     const double bc_vx0_l = p->vbc_val_l[0], bc_vx1_l = p->vbc_val_l[1];
+    if (clk->pt) {
+        bc_vx0 = 0.0; bc_vx1 = 0.0; bc_vz0 = 0.0; bc_vz1 = 0.0;
+        vbc_applied_x0 = 0.0; vbc_applied_x1 = 0.0;
+    }
     if (clk->time > p->vbc_val_z1_loading_period) bc_z1 = 0;
     const double zmin = clk->zmin;
 
@@ -1459,8 +1465,67 @@ int sync_clock(Engine *h)
     return DES_OK;
 }
 
+// strain rate -> stress -> force -> velocity -> residual: the part of a step the pseudo-transient loop repeats
 template <class M>
-void one_step(Engine *h)
+void launch_mechanics(Engine *h, bool nmd)
+{
+    const int nn = h->nn, ne = h->ne;
+    L2(k2_strain_rate, ne, nn, ne, h->conn, h->coord, h->vel, h->volume, h->strain_rate, h->etmp);
+    L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
+    L2(k2_edvoldt, ne, ne, h->conn, h->ntmp, h->edvoldt);
+    launch_stress<M>(h);
+    if (nmd) {
+        L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
+        L2(k2_nmd_apply, ne, ne, h->conn, h->ntmp, h->dpressure, h->stress);
+    }
+    L2(k2_force_elem, ne, h->d_p, nn, ne, h->conn, h->coord, h->temperature, h->volume, h->stress, h->props, h->markers, h->tmp_result);
+    L2(k2_force_node, nn, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->tmp_result, h->force, h->fres);
+    launch_stress_bcs(h);
+    L2(k2_damp_vel, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->force, h->vel);
+    L2(k2_residual_part, nn, nn, h->fres, h->res_part);
+    hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(nn), h->res_part, h->d_clk);
+}
+
+int set_pt(Engine *h, int on)
+{
+    static const int vals[2] = {0, 1};
+    HIP2(hipMemcpyAsync(&h->d_clk->pt, &vals[on ? 1 : 0], sizeof(int), hipMemcpyHostToDevice, h->stream));
+    return DES_OK;
+}
+
+// The pseudo-transient loop of a step (dynearthsol.cxx:803-864): the quasi-static part of the step repeated
+// with the boundaries at rest (bc.cxx:330-343) and update_mesh without surface processes
+// (dynearthsol.cxx:456-461) until the relative change of the residual drops below the tolerance.  The host
+// joins the stream once per iteration for that decision, as the reference's loop does.
+template <class M>
+int pt_loop(Engine *h)
+{
+    const des_params &p = h->p;
+    int rc;
+    if ((rc = sync_clock(h))) return rc;
+    double residual_old = h->h_clk->l2_residual;
+    if ((rc = set_pt(h, 1))) return rc;
+    for (int pt_step = 0; pt_step < p.PT_max_iter; ++pt_step) {
+        launch_vbcs(h);
+        if (p.has_moving_mesh) {
+            L2(k2_update_coord, 2 * h->nn, h->d_clk, 2 * h->nn, h->vel, h->coord);
+            std::swap(h->volume, h->volume_old);
+            refresh_props(h);
+            launch_volume_mass(h, true);
+        }
+        launch_mechanics<M>(h, false);
+        if ((rc = sync_clock(h))) return rc;
+        ++h->n_pt_iterations;
+        const double l2 = h->h_clk->l2_residual;
+        const double relative_change = std::fabs((l2 - residual_old) / residual_old);
+        if (relative_change < p.PT_relative_tolerance) break;
+        residual_old = l2;
+    }
+    return set_pt(h, 0);
+}
+
+template <class M>
+int one_step(Engine *h)
 {
     const des_params &p = h->p;
     const int nn = h->nn, ne = h->ne;
@@ -1473,27 +1538,15 @@ void one_step(Engine *h)
         L2(k2_temp_elem, ne, h->d_p, nn, ne, h->conn, h->coord, h->temperature, h->volume, h->radiogenic, h->props, h->markers, h->tmp_result);
         L2(k2_temp_node, nn, h->d_p, h->d_clk, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->bcflag, h->tmp_result, h->tmass, h->temperature);
     }
-    L2(k2_strain_rate, ne, nn, ne, h->conn, h->coord, h->vel, h->volume, h->strain_rate, h->etmp);
-    L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
-    L2(k2_edvoldt, ne, ne, h->conn, h->ntmp, h->edvoldt);
-    launch_stress<M>(h);
-    if (!h->iso && p.is_using_mixed_stress) {
-        L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
-        L2(k2_nmd_apply, ne, ne, h->conn, h->ntmp, h->dpressure, h->stress);
-    }
-    L2(k2_force_elem, ne, h->d_p, nn, ne, h->conn, h->coord, h->temperature, h->volume, h->stress, h->props, h->markers, h->tmp_result);
-    L2(k2_force_node, nn, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->tmp_result, h->force, h->fres);
-    launch_stress_bcs(h);
-    L2(k2_damp_vel, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->force, h->vel);
-    L2(k2_residual_part, nn, nn, h->fres, h->res_part);
-    hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(nn), h->res_part, h->d_clk);
+    launch_mechanics<M>(h, !h->iso && p.is_using_mixed_stress);
+    if (!h->iso && p.has_PT) { int rc = pt_loop<M>(h); if (rc) return rc; }
     if (h->iso) L2(k2_iso_vel, nn, h->d_p, nn, h->bcflag, h->vel);
     else launch_vbcs(h);
     if (p.has_moving_mesh || h->iso) {
         L2(k2_update_coord, 2 * nn, h->d_clk, 2 * nn, h->vel, h->coord);
         launch_update_mesh(h, h->steps_host);
     }
-    if (h->iso) return;
+    if (h->iso) return DES_OK;
     if (p.rheol_type & DES_RH_ELASTIC)
         L2(k2_rotate, ne, h->d_clk, nn, ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
     if (p.is_outputting_averaged_fields) {
@@ -1502,6 +1555,7 @@ void one_step(Engine *h)
            h->coord_avg0, h->strain0, h->stress_avg, h->dplstrain_avg);
     }
     if (h->steps_host % 10 == 0) launch_dt(h);
+    return DES_OK;
 }
 
 } // namespace
@@ -1602,7 +1656,6 @@ Engine *create(int device, const des_params *params, const des_mesh *mesh, int *
     case DES_RH_ELASTIC: case DES_RH_VISCOUS: case DES_RH_MAXWELL: case DES_RH_EP: case DES_RH_EVP: break;
     default: *err = DES_ERR_UNSUPPORTED; msg = "rheology not offloaded"; return nullptr;
     }
-    if (params->has_PT) { *err = DES_ERR_UNSUPPORTED_DIM; msg = "control.has_PT: the pseudo-transient loop is offloaded for 3-D models only"; return nullptr; }
     if (params->num_vbc_period_x0 < 1 || params->num_vbc_period_x0 > DES_MAX_PERIOD ||
         params->num_vbc_period_x1 < 1 || params->num_vbc_period_x1 > DES_MAX_PERIOD) {
         *err = DES_ERR_CONFIG_VALUE; msg = "bad num_vbc_period_x?"; return nullptr;
@@ -1701,13 +1754,14 @@ int compute_dt(Engine *h, double *dt)
 int step(Engine *h, int nsteps, des_scalars *out)
 {
     HIP2(hipSetDevice(h->device));
+    h->n_pt_iterations = 0;
     for (int i = 0; i < nsteps; ++i) {
         if (i == nsteps - 1) {
             static const int zero = 0;
             HIP2(hipMemcpyAsync(&h->d_clk->n_past, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
         }
-        if (h->portable_libm) one_step<desk::MathPortable>(h);
-        else one_step<desk::MathOcml>(h);
+        const int rc = h->portable_libm ? one_step<desk::MathPortable>(h) : one_step<desk::MathOcml>(h);
+        if (rc) return rc;
     }
     HIP2(hipGetLastError());
     if (out) {
@@ -1716,7 +1770,7 @@ int step(Engine *h, int nsteps, des_scalars *out)
         const Clock &c = *h->h_clk;
         out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
         out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min; out->steps = c.steps;
-        out->status = c.status; out->n_return_mapping = c.n_past; out->avg_time0 = c.avg_time0; out->n_pt_iterations = 0;
+        out->status = c.status; out->n_return_mapping = c.n_past; out->avg_time0 = c.avg_time0; out->n_pt_iterations = h->n_pt_iterations;
         return c.status;
     }
     return DES_OK;

@@ -7,8 +7,8 @@
 // the 2-D apply_vbcs (bc.cxx:227-400, 425-481), 1-D surface diffusion (bc.cxx:1021-1033,
 // 1067-1106), jaumann_rate_2d (fields.cxx:807-821), the 2-D compute_dt / elem_quality
 // (geometry.cxx:1566-1576, 1901-1906).  Every des_dev_* entry point dispatches here when the
-// handle holds a 2-D engine; what a 2-D model cannot have (domain decomposition, the
-// pseudo-transient loop) returns DES_ERR_UNSUPPORTED_DIM.
+// handle holds a 2-D engine; what a 2-D model cannot have (the domain decomposition and its
+// exchange / two-phase entry points) returns DES_ERR_UNSUPPORTED_DIM.
 //
 // Arrays stay in the reference's own SoA layout and the caller's numbering: the 2-D configs of
 // BASELINE.json are the CPU-runnable plumbing case (configs[0]), bit-for-bit parity with the

@@ -18,8 +18,6 @@ des_host *create_impl(int ndims, const char *path, const char *text, const char 
         else      h->cfg.load_string(text ? text : "", ov);
         des::build_params(h->cfg, h->params, ndims);
         h->mesh.nd = ndims;
-        if (ndims == 2 && h->cfg.b("sim.is_restarting"))
-            throw des::Error(31, "sim.is_restarting: restart files are read by the 3-D host only");
         if (h->cfg.b("sim.is_restarting")) {
             des::restart_from_files(h->cfg, h->params, h->mesh, h->fields);
             des::build_topology(h->mesh, h->params.vbc_types);

@@ -18,14 +18,15 @@ const std::size_t headerlen = 4096;
 // BinaryInput (binaryio.cxx:206-330)
 class FrameReader {
 public:
-    explicit FrameReader(const std::string &filename) : name_(filename)
+    explicit FrameReader(const std::string &filename, int ndims = 3) : name_(filename)
     {
         f_ = std::fopen(filename.c_str(), "rb");
         if (!f_) throw Error(20, "Error: cannot open file: " + filename);                 // EXIT_IO_OPEN
         std::vector<char> header(headerlen + 1, '\0');
         if (std::fread(header.data(), 1, headerlen, f_) != headerlen)
             throw Error(21, "error reading file header");                                   // EXIT_IO_RW
-        const char *rev = "# DynEarthSol ndims=3 revision=4";
+        const std::string revs = "# DynEarthSol ndims=" + std::to_string(ndims) + " revision=4";   // binaryio.cxx:39-40, 230-238
+        const char *rev = revs.c_str();
         char *line = std::strtok(header.data(), "\n");
         if (!line || std::strncmp(line, rev, std::strlen(rev)) != 0)
             throw Error(22, std::string("Error: mismatching revision string in header\n  Expect: ") + rev +
@@ -96,7 +97,8 @@ void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostField
     RestartState &rs = f.restart;
     rs.active = true; rs.frame = frame;
 
-    FrameReader save(frame_name(model, "save", frame));
+    const int nd = m.nd, npe = nd + 1, nstr = nd * (nd + 1) / 2;
+    FrameReader save(frame_name(model, "save", frame), nd);
 
     // frame metadata: the .info row, else the scalars embedded in the frame (:246-288)
     bool got_meta = false;
@@ -114,13 +116,13 @@ void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostField
         save.scalar(rs.steps, "steps"); save.scalar(nnode, "nnode"); save.scalar(nelem, "nelem"); save.scalar(nseg, "nseg");
     }
 
-    FrameReader chk(frame_name(model, "chkpt", frame));
+    FrameReader chk(frame_name(model, "chkpt", frame), nd);
 
     // mesh (replacing create_new_mesh, :304-317)
     m.nnode = nnode; m.nelem = nelem; m.nseg = nseg;
-    save.array2d(m.coord, 3, "coordinate", (std::size_t)nnode);
-    save.array2d(m.conn, 4, "connectivity", (std::size_t)nelem);
-    chk.array2d(m.segment, 3, "segment", (std::size_t)nseg);
+    save.array2d(m.coord, nd, "coordinate", (std::size_t)nnode);
+    save.array2d(m.conn, npe, "connectivity", (std::size_t)nelem);
+    chk.array2d(m.segment, nd, "segment", (std::size_t)nseg);
     chk.array(m.segflag, "segflag", (std::size_t)nseg);
     m.regattr.assign((std::size_t)nelem, 0.0);
 
@@ -130,7 +132,7 @@ void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostField
     chk.array(itmp, "markerset size", 3);
     mk.nmarkers = itmp[0]; mk.last_id = itmp[1]; mk.reserved_space = itmp[2];
     const std::size_t nm = (std::size_t)mk.nmarkers;
-    save.array2d(mk.eta, 4, "markerset.eta", nm);
+    save.array2d(mk.eta, npe, "markerset.eta", nm);
     save.array(mk.elem, "markerset.elem", nm);
     save.array(mk.mattype, "markerset.mattype", nm);
     save.array(mk.id, "markerset.id", nm);
@@ -146,7 +148,7 @@ void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostField
         ++f.elemmarkers[(std::size_t)mk.elem[i] * p.nmat + mk.mattype[i]];
     }
 
-    save.array2d(rs.coord0, 3, "coord0", (std::size_t)nnode);
+    save.array2d(rs.coord0, nd, "coord0", (std::size_t)nnode);
 
     // misc. items (:343-352)
     chk.scalar(rs.time, "time");
@@ -160,18 +162,22 @@ void restart_from_files(const Config &cfg, des_params &p, HostMesh &m, HostField
     p.compensation_pressure = f.compensation_pressure;
 
     // fields (:359-392)
-    save.array2d(f.vel, 3, "velocity", (std::size_t)nnode);
+    save.array2d(f.vel, nd, "velocity", (std::size_t)nnode);
     save.array(f.temperature, "temperature", (std::size_t)nnode);
-    save.array2d(f.strain, 6, "strain", (std::size_t)nelem);
-    save.array2d(f.stress, 6, "stress", (std::size_t)nelem);
+    save.array2d(f.strain, nstr, "strain", (std::size_t)nelem);
+    save.array2d(f.stress, nstr, "stress", (std::size_t)nelem);
+    if (nd == 2) {
+        f.stressyy.assign((std::size_t)nelem, 0.0);
+        if (p.is_plane_strain) chk.array(f.stressyy, "stressyy", (std::size_t)nelem);        // dynearthsol.cxx:380-381
+    }
     save.array(f.plstrain, "plastic strain", (std::size_t)nelem);
     save.array(f.radiogenic, "radiogenic source", (std::size_t)nelem);
     chk.array(rs.volume_old, "volume_old", (std::size_t)nelem);
     chk.array(rs.edvacc_surf, "dv surface acc", chk.bytes("dv surface acc") / sizeof(double));   // one per top facet
     chk.array(rs.dhacc, "dhacc", (std::size_t)nnode);
-    save.array2d(rs.strain_rate, 6, "strain-rate", (std::size_t)nelem);
+    save.array2d(rs.strain_rate, nstr, "strain-rate", (std::size_t)nelem);
     save.array(f.viscosity, "viscosity", (std::size_t)nelem);
-    save.array2d(rs.force, 3, "force", (std::size_t)nnode);
+    save.array2d(rs.force, nd, "force", (std::size_t)nnode);
     save.array(rs.delta_plstrain, "plastic strain-rate", (std::size_t)nelem);
 
     if (cfg.b("ic.is_restarting_weakzone"))

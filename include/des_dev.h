@@ -24,6 +24,15 @@
  *
  * All arrays crossing this boundary are host pointers in the reference's SoA layout
  * (des_params.h).  No torch / HIP types appear in any signature.
+ *
+ * Dimension.  The reference is compiled for tets (-DTHREED) or triangles (constants.hpp:12-25); here
+ * des_params::ndims says which build a model is, and des_dev_create returns an engine for it behind the
+ * same entry points.  ndims = 2: coordinates / velocities / forces [2][nnode] = {x, z}, tensors [3][nelem] =
+ * {XX, ZZ, XZ}, connectivity [3][nelem], DES_F_STRESSYY [nelem]; the step runs the !THREED branches --
+ * get_local_shape_fn (fields.cxx:40-53), principal_stresses2 / elasto_plastic / elasto_plastic2d
+ * (rheology.cxx:86-119, 364-483, 486-701), the 2-D apply_vbcs (bc.cxx:247-300, 425-481), the 1-D surface
+ * diffusion (bc.cxx:1021-1033, 1067-1106), jaumann_rate_2d (fields.cxx:807-821).  A 2-D engine has no domain
+ * decomposition and no pseudo-transient loop: those entry points return DES_ERR_UNSUPPORTED_DIM.
  */
 #ifndef DES_DEV_H
 #define DES_DEV_H
@@ -44,6 +53,7 @@ int des_dev_device_count(void);
  * uploads an OpenACC build does implicitly.  With mesh->coord (initial coordinates, a layout
  * hint) the engine keeps its arrays in a Morton order of its own; everything crossing this
  * interface stays in the caller's numbering and list order (des_params.h, des_mesh).
+ * params->ndims = 2 creates the 2-D (triangle) engine (see the header above).
  * Returns NULL on failure and stores a DES_ERR_* code in *err (may be NULL). */
 des_dev *des_dev_create(int device, const des_params *params, const des_mesh *mesh, int *err);
 

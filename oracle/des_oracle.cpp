@@ -2765,6 +2765,19 @@ double des_oracle_elasto_plastic(double bulkm, double shearm, double amc, double
     return depls;
 }
 
+#if DES_NDIMS == 2
+// rheology.cxx:486-701 on one stress state {XX, ZZ, XZ} + the out-of-plane stress
+double des_oracle_elasto_plastic2d(double bulkm, double shearm, double amc, double anphi,
+                                   double anpsi, double hardn, double ten_max,
+                                   const double de[3], double s[3], double *syy, int *failure_mode)
+{
+    double depls = 0; int fm = 0;
+    elasto_plastic2d(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, s, *syy, fm);
+    if (failure_mode) *failure_mode = fm;
+    return depls;
+}
+#endif
+
 void des_oracle_maxwell(double bulkm, double shearm, double viscosity, double dt, double dv,
                         const double de[6], double s[6])
 {

@@ -23,8 +23,8 @@ YEAR2SEC = 365.2422 * 86400
 REF = "/root/reference"
 
 
-def oracle_api():
-    lib = load_oracle()
+def oracle_api(ndims=3):
+    lib = load_oracle(ndims=ndims)
     lib.des_oracle_create.restype = C.c_void_p
 
     @driver.CREATE_T
@@ -35,11 +35,11 @@ def oracle_api():
     return api
 
 
-def read_frame(fname):
+def read_frame(fname, ndims=3):
     """binaryio.cxx:18-36: 4096-byte text header, 'name<TAB>offset' lines, raw data."""
     with open(fname, "rb") as f:
         head = f.read(4096).split(b"\0")[0].decode().splitlines()
-    assert head[0] == "# DynEarthSol ndims=3 revision=4"
+    assert head[0] == "# DynEarthSol ndims=%d revision=4" % ndims
     pos = {}
     for line in head[1:]:
         name, off = line.split("\t")

@@ -174,14 +174,85 @@ def test_mesh_quality_reductions_match():
     assert out[0] == out[1] and out[0][0] >= 0 and 0 < out[0][3] < 1
 
 
+@pytest.mark.parametrize("tol,moving", [("1e-2", "yes"), ("1e-4", "yes"), ("1e-4", "no")])
+def test_pseudo_transient_loop_bit_exact(tol, moving):
+    """control.has_PT (dynearthsol.cxx:803-864) in the 2-D build: the quasi-static part of every step iterated
+    with the boundaries at rest (bc.cxx:330-343) until the residual settles.  Same iteration counts, same bits."""
+    ov = ("control.has_PT = yes\ncontrol.PT_max_iter = 40\ncontrol.PT_relative_tolerance = %s\n"
+          "control.has_moving_mesh = %s\n" % (tol, moving))
+    host, dev, ora = pair(dict(cfgs.EP, res=1e3), overrides=ov)
+    total = 0
+    for n in (1, 4, 8):                                     # crosses step 10 (compute_dt)
+        sd, so = dev.step(n), ora.step(n)
+        assert sd.n_pt_iterations == so.n_pt_iterations > 0 and (sd.dt, sd.steps) == (so.dt, so.steps)
+        assert abs(sd.l2_residual - so.l2_residual) <= 1e-12 * so.l2_residual
+        total += so.n_pt_iterations
+        assert_bit_exact(dev, ora)
+    assert total >= 13
+
+
 def test_what_a_2d_model_cannot_have_is_refused_with_the_dimension_code():
     host = des.Host(cfg_text=cfgs.make(**cfgs.EP), ndims=2)
     dev = des.DeviceEngine(host)
-    import ctypes as C
     assert dev._lib.des_dev_phase(dev._h, 0) == 30 and dev._lib.des_dev_exchange(dev._h) == 30
-    with pytest.raises(des.DesError) as ei:
-        des.DeviceEngine(des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides="control.has_PT = yes\n", ndims=2))
-    assert ei.value.code == 30
-    # a 3-D handle still refuses a 2-D model's arrays by size
+    # an upload with the 3-D size of the field is refused
     with pytest.raises(des.DesError):
         dev.upload("COORD", np.zeros(3 * host.nnode))
+
+
+# ---- the reference's own 2-D case: benchmarks-cores/test-tiny.cfg (BASELINE configs[0]) -------------
+import os
+import subprocess
+
+from dynearthsol_amd import driver
+from test_driver_output import oracle_api, read_frame, in_tmp  # noqa: E402,F401
+
+TINY_MESH = os.path.join(des.REPO_ROOT, "tests", "golden", "test-tiny.desmesh")
+EXE2D = os.path.join(des.REPO_ROOT, "dynearthsol_amd", "bin", "dynearthsol2d-hip")
+
+
+def test_reference_test_tiny_is_bit_exact_on_its_triangle_mesh():
+    """Eight materials, evp, Gaussian weak zone, continental geotherm, surface diffusion, PREM reference
+    pressure, on the 97-node mesh the reference's Triangle makes from cube.poly: the four steps of the
+    benchmark, then 404 with yielding."""
+    host = des.Host(cfg_text=cfgs.TEST_TINY, mesh_file=TINY_MESH, ndims=2)
+    dev, ora = des.DeviceEngine(host), OracleEngine(host)
+    assert dev.init_from_host(host) == ora.init_from_host(host)
+    run(dev, ora, 4, 1)                          # the benchmark itself, against the oracle on glibc
+    with portable_libm():                        # later elements of the weak zone yield now and then: one libm on both sides
+        dev, ora = des.DeviceEngine(host), OracleEngine(host)
+        assert dev.init_from_host(host) == ora.init_from_host(host)
+        run(dev, ora, 4, 101)
+
+
+def test_dynearthsol2d_executable_writes_the_frames_the_oracle_loop_writes(in_tmp):
+    with open("tiny.cfg", "w") as f:
+        f.write(cfgs.apply_overrides(cfgs.TEST_TINY, "sim.modelname = gpu\nsim.has_initial_checkpoint = yes\n"))
+    out = subprocess.run([EXE2D, "tiny.cfg", "--mesh", TINY_MESH], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "Output # 4" in out.stdout and "Ending simulation." in out.stdout
+    host = des.Host(cfg_path="tiny.cfg", mesh_file=TINY_MESH, ndims=2, overrides="sim.modelname = cpu\n")
+    st = driver.run(host, api=oracle_api(2))
+    assert st.frames == 5
+    for frame in range(5):
+        a, b = read_frame("gpu.save.%06d" % frame, ndims=2), read_frame("cpu.save.%06d" % frame, ndims=2)
+        assert sorted(a) == sorted(b)
+        for name in a:
+            if name != "walltime_sec":
+                assert np.array_equal(a[name], b[name]), (frame, name)
+    # the same program under its 3-D name refuses the 2-D mesh file
+    out3 = subprocess.run([EXE2D.replace("2d", "3d"), "tiny.cfg", "--mesh", TINY_MESH], capture_output=True, text=True, timeout=300)
+    assert out3.returncode == 30
+    # ... and takes the dimension as an option
+    out2 = subprocess.run([EXE2D.replace("2d", "3d"), "tiny.cfg", "--ndims", "2", "--mesh", TINY_MESH, "--quiet"],
+                          capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr
+
+
+def test_python_driver_runs_a_2d_model_on_the_device(in_tmp):
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, nmat=2, res=1e3)), ndims=2,
+                    overrides="sim.max_steps = 60\nsim.output_step_interval = 30\nsim.modelname = py2d\nmesh.quality_check_step_interval = 10\n")
+    st = driver.run(host)
+    assert (st.steps, st.frames, st.exit_code) == (60, 3, 0)
+    fr = read_frame("py2d.save.000002", ndims=2)
+    assert fr["steps"].view(np.int32)[0] == 60 and fr["stress"].size == 3 * host.nelem * 8
