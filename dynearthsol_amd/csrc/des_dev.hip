@@ -87,10 +87,13 @@ struct DevClock {
     double avg_time0;        // Output::time0 (output.cxx:332)
     int n_defer;             // elements the first stress pass of this step handed to E2_return_mapping
     int pad;
+    double dt_prev;          // the dt k_dt_finalize replaced: what a deferred rotate_stress of the step before ran with
 };
 
 // INIT: C part without rotate_stress; AVG: Output::average_fields on the final stress of the step
-enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_NOREC = 16 };
+// DEFER (with C | A): rotate_stress of this step (and the pending NMD increment) is left to the next
+// step's stress update, which reads stress / strain anyway -- E1 stores the three spin components only
+enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_NOREC = 16, MODE_DEFER = 32 };
 
 enum KernelId { K_E1, K_N1, K_E2, K_E2R, K_N2, K_E3, K_N3, K_S2, K_S3,
                 K_DTFIN, K_MISC, K_EXCH, K_EN3, K_EN1, K_EN2, K_COUNT };
@@ -177,6 +180,11 @@ struct des_dev {
     ushort4 *pe_ln;
     short4 *pe_slot;
     double *ddp;                          // [ne] NMD increment of the stress diagonal, applied by the next E1
+    double *spin;                         // [3][ne] w3, w4, w5 of a deferred rotate_stress (E1<DEFER> -> next E2)
+    bool defer_rot;                       // DES_DEFER_ROT != 0 (default on): fused end-of-step passes defer the rotation
+    bool rot_pending, rot_prev_dt;        // the next E2 applies it; with the dt of before the last k_dt_finalize
+    bool en1x_next;                       // the next EN1 writes the element outputs of the skipped end-of-step pass
+    int *top_elist;                       // [ntop_elems] Variables::top_elems in the engine's order
     d4 *xt_alt;                           // the other buffer of the {x,y,z,T} pair (EN3 writes it, then they swap)
     // stress-bc lists
     int nbcf;                             // facets with a stress bc (incl. neumann)
@@ -282,7 +290,7 @@ void des_dev_destroy(des_dev *h)
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
-    void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_ln, h->pe_slot, h->ddp, h->xt_alt,
+    void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_ln, h->pe_slot, h->ddp, h->xt_alt, h->spin, h->top_elist,
         h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->d_esend_idx, h->d_erecv_idx, h->d_send_noff,
@@ -470,6 +478,12 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->radiogenic, (size_t)ne)); CK(dev_alloc(h->markers, (size_t)ne * nmat));
     CK(dev_alloc(h->mono, (size_t)ne));
     CK(dev_alloc(h->defer_list, (size_t)ne));
+    {
+        // deferred rotate_stress (MODE_DEFER, passes/e1.hpp): on by default, DES_DEFER_ROT=0 keeps rotate_stress in E1
+        const char *dr = std::getenv("DES_DEFER_ROT");
+        h->defer_rot = !(dr && dr[0] == '0');
+        if (h->defer_rot) { CK(dev_alloc(h->spin, (size_t)3*ne)); HK(hipMemsetAsync(h->spin, 0, 24*(size_t)ne, h->stream)); }
+    }
     if (nmat > 1) {
         CK(dev_alloc(h->props, (size_t)5*ne));
         CK(dev_alloc(h->ptab, (size_t)nmat * DES_PTAB_CNT * 5));
@@ -599,6 +613,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             std::vector<unsigned char> flag((size_t)ne, 0);
             for (int i = 0; i < h->ntop_elems; ++i) flag[mesh->top_elems[i]] = 1;
             CK(dev_alloc(h->topflag, (size_t)ne)); CK(dev_upload(h->topflag, flag.data(), (size_t)ne, h->stream));
+            CK(dev_alloc(h->top_elist, (size_t)h->ntop_elems));
+            CK(dev_upload(h->top_elist, mesh->top_elems, (size_t)h->ntop_elems, h->stream));
         }
         CK(dev_alloc(h->dh, ntop)); CK(dev_alloc(h->edvacc, etop)); CK(dev_alloc(h->znew, ntop));
         HK(hipMemsetAsync(h->dh, 0, 8*std::max<size_t>(ntop, 1), h->stream));

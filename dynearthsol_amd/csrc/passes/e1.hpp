@@ -52,14 +52,16 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
      const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
      double *__restrict__ stress, const double *__restrict__ ddp, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
-     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp)
+     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp, double *__restrict__ spin,
+     const int *__restrict__ elist)
 {
     // this launch covers the elements [b0, b0 + c0) and [b1, b1 + c1) (the whole mesh: 0, ne, 0, 0;
     // the overlapped multi-GPU schedule runs the interior elements while the ghost region is
     // still on its way, then the two groups that touch it); ne stays the SoA plane stride
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     const bool active = el < c0 + c1;
-    const int e = el < c0 ? b0 + el : b1 + (el - c0);
+    // (elist: the first c0 entries of a list instead of a range -- the top elements, engine/launch.hpp)
+    const int e = elist ? (active ? elist[el] : 0) : (el < c0 ? b0 + el : b1 + (el - c0));
 
     double r_minl = DBL_MAX, r_maxw = DBL_MAX, r_diff = DBL_MAX, r_gdt = DBL_MAX, r_vem = 0.0;
 
@@ -113,7 +115,16 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
         double sx[4], sy[4], sz[4];
         desk::shape_fn(c, vol, sx, sy, sz);
 
-        if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
+        if ((MODE & MODE_DEFER) && !topflag[e]) {
+            // rotate_stress of this element happens in the next step's stress update (passes/e2.hpp), which
+            // has its stress and strain in registers anyway: 24 B written here instead of 192 B moved.  The
+            // top elements (correct_surface_element may rescale them first) are finished here as usual.
+            double w3 = 0, w4 = 0, w5 = 0;
+            for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
+            for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
+            for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
+            spin[e] = w3; spin[(size_t)ne + e] = w4; spin[(size_t)2*ne + e] = w5;
+        } else if ((MODE & MODE_C) && !(MODE & MODE_INIT)) {
             const bool rescale = rdv >= 1.0;                         // bc.cxx:1677
             const bool rotate = (p->rheol_type & DES_RH_ELASTIC) != 0 && !clk->iso && !clk->pt;   // not in the isostasy / PT loops
             // NMD_stress' increment of the diagonal (geometry.cxx:316-331), left here by EN3 -- the
@@ -232,6 +243,7 @@ __global__ void k_dt_finalize(const des_params *p, DevClock *clk, const double *
                 * p->dt_fraction;
     if (p->fixed_dt != 0) dt = p->fixed_dt;
     if (!(dt > 0)) clk->status = DES_ERR_RUNTIME_NAN;
+    clk->dt_prev = clk->dt;
     clk->dt = dt;
     clk->r_minl = DBL_MAX; clk->r_dt_maxwell = DBL_MAX; clk->r_dt_diffusion = DBL_MAX;
     clk->r_global_dt_min = DBL_MAX; clk->r_max_vem = 0.0;

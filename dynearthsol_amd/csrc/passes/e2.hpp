@@ -14,6 +14,9 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 // The stress update of element e.  DEFER = 1 (first pass): returns true WITHOUT having stored
 // anything but viscosity[e] when the element needs the Mohr-Coulomb return mapping; the second
 // pass then runs the same code with DEFER = 0 for exactly those elements.
+// what E1<MODE_DEFER> left for this pass to finish (all null / 0: nothing)
+struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; };
+
 template <class M, int DEFER>
 __device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
      const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
@@ -21,7 +24,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
      const double *__restrict__ volume, const double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
-     double *__restrict__ dpressure, double *__restrict__ etmp2)
+     double *__restrict__ dpressure, double *__restrict__ etmp2, const RotPending rp)
 {
     const double dt = clk->dt;
     const int4 cn = conn[e];
@@ -38,6 +41,17 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         s[i] = stress[(size_t)i*ne + e];
         es[i] = strain[(size_t)i*ne + e];
         edot[i] = strain_rate[(size_t)i*ne + e];
+    }
+    if (rp.spin && !rp.topflag[e]) {
+        // the end of the step before, left here by E1<MODE_DEFER>: NMD_stress' increment of the diagonal
+        // (geometry.cxx:316-331), then rotate_stress (fields.cxx:827-902) with that step's dt -- the same
+        // operations in the same order as E1 does them in place
+        const double dd = rp.ddp ? rp.ddp[e] : 0.0;
+        if (dd != 0.0) for (int i = 0; i < 3; ++i) s[i] += dd;
+        const double dtr = rp.prev_dt ? clk->dt_prev : dt;
+        const double w3 = rp.spin[e], w4 = rp.spin[(size_t)ne + e], w5 = rp.spin[(size_t)2*ne + e];
+        desk::jaumann_rate_3d(s, dtr, w3, w4, w5);
+        desk::jaumann_rate_3d(es, dtr, w3, w4, w5);
     }
     const double old_s = desk::trace3(s);
     {
@@ -135,7 +149,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ list, int *__restrict__ count,
      int nblocks8, int nbcf, const int *__restrict__ f_elem, const int *__restrict__ f_facet,
-     const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp)
+     const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp, const RotPending rp)
 {
     if ((int)blockIdx.x >= nblocks8) {
         // workgroups past the element range: the stress-bc facet terms (passes/e3.hpp, bc_facet_work).
@@ -150,7 +164,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     if (el >= e_count) return;
     const int e = e_begin + el;
     const bool defer = e2_element<M, DEFER>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
-                                            plstrain, delta_plstrain, viscosity, dpressure, etmp2);
+                                            plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);
     // one atomic per wavefront that has such elements; without DEFER only the count is kept
     // (des_scalars::n_return_mapping, and what the host picks the next call's mode from)
     const unsigned long long mask = __ballot(defer);
@@ -176,12 +190,13 @@ E2_return_mapping(const des_params *__restrict__ p, const desk::ViscTerms *__res
      const double *__restrict__ volume, const double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
-     double *__restrict__ dpressure, double *__restrict__ etmp2, const int *__restrict__ list, const int *__restrict__ count)
+     double *__restrict__ dpressure, double *__restrict__ etmp2, const int *__restrict__ list, const int *__restrict__ count,
+     const RotPending rp)
 {
     M::stage_begin();
     M::stage_end();
     const int n = *count;
     for (int i = blockIdx.x * DES_BLOCK + threadIdx.x; i < n; i += gridDim.x * DES_BLOCK)
         e2_element<M, 0>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
-                         plstrain, delta_plstrain, viscosity, dpressure, etmp2);
+                         plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);
 }
