@@ -110,7 +110,16 @@ KERNEL_BYTES = {
     "EN3_force_nodes":            (260 + 160, 40 + 160),
     "EN1_mass_temperature_dvoldt": (224, 64),
     "EN2_nmd_gather":             (48, 20),
+    # E2<GEO> (csrc/passes/e2.hpp): the stress update that also does the end-of-step pass of the step before
+    # and this step's strain rate.  It stands for SURVEY's E1 and E2 rows (728 B per element) but moves less
+    # than half of that -- no stress / strain round trip for rotate_stress, no strain_rate round trip, no
+    # mrec / ttmp -- so it is credited with ITS OWN minimum, counted by SURVEY 8(d)'s rules: read conn 16,
+    # stress 48, strain 48, plstrain 8, volume 8, ddp 8, markers 4, top flag 1; write stress 48, strain 48,
+    # strain_rate 48, delta_plstrain 8, dpressure 8, etmp 8, volume 8, volume_old 8 (evp: + viscosity 8 W,
+    # T gathered anyway); nodes once each: coord 24, vel 24, T 8, ntmp 8.  KERNEL_ROWS has the rows' figure.
+    "E2G_geom_rotate_update_stress": (325, 64),
 }
+KERNEL_ROWS = {"E2G_geom_rotate_update_stress": (364 + 364, 56 + 8)}
 
 
 def main():
@@ -363,6 +372,8 @@ def main():
                 be, bn = KERNEL_BYTES[dom]
                 if dom == "E2_update_stress" and args.rheology == "elasto-visco-plastic":
                     be, bn = be + 24, bn + 8
+                if dom == "E2G_geom_rotate_update_stress" and args.rheology == "elasto-visco-plastic":
+                    be += 8
                 kbytes = be * ne_local + bn * (nn if world == 1 else part.nnode)     # rank 0's launch
                 achieved = kbytes / (ms / calls * 1e-3) / 1e9
                 # HBM bytes from the PMC counters cannot be collected inside the timed run (separate
@@ -386,6 +397,13 @@ def main():
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                         "ceiling_GBs": ceiling, "frac_of_ceiling": (achieved / ceiling) if ceiling else None,
                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": ms / calls}
+                if dom in KERNEL_ROWS:
+                    # the same launch priced with the SURVEY rows it replaces (E1 + E2; evp + 24 / + 8)
+                    re_, rn_ = KERNEL_ROWS[dom]
+                    if args.rheology == "elasto-visco-plastic":
+                        re_, rn_ = re_ + 24, rn_ + 8
+                    rows_bytes = re_ * ne_local + rn_ * (nn if world == 1 else part.nnode)
+                    roof["frac_of_replaced_survey_rows"] = rows_bytes / (ms / calls * 1e-3) / 1e9 / HBM_PEAK_GBS
         result["roofline"] = roof
 
         cpu = None

@@ -93,14 +93,17 @@ struct DevClock {
 // INIT: C part without rotate_stress; AVG: Output::average_fields on the final stress of the step
 // DEFER (with C | A): rotate_stress of this step (and the pending NMD increment) is left to the next
 // step's stress update, which reads stress / strain anyway -- E1 stores the three spin components only
-enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_NOREC = 16, MODE_DEFER = 32 };
+// VOLX (with DT alone): the element's volume is formed from the coordinates instead of read -- the compute_dt
+// reduction of a step whose end-of-step pass the next stress update does (E2<GEO>)
+enum { MODE_A = 1, MODE_C = 2, MODE_DT = 4, MODE_INIT = 8, MODE_NOREC = 16, MODE_DEFER = 32, MODE_VOLX = 64 };
 
 enum KernelId { K_E1, K_N1, K_E2, K_E2R, K_N2, K_E3, K_N3, K_S2, K_S3,
-                K_DTFIN, K_MISC, K_EXCH, K_EN3, K_EN1, K_EN2, K_COUNT };
+                K_DTFIN, K_MISC, K_EXCH, K_EN3, K_EN1, K_EN2, K_E2G, K_COUNT };
 const char *kKernelNames[K_COUNT] = {
     "E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "E2_return_mapping", "N2_nmd_gather",
     "E3_nmd_force", "N3_force_velocity_coord", "S2_surface_diffusion",
-    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange", "EN3_force_nodes", "EN1_mass_temperature_dvoldt", "EN2_nmd_gather" };
+    "S3_edvacc_step_finalize", "dt_finalize", "misc", "ghost_exchange", "EN3_force_nodes", "EN1_mass_temperature_dvoldt", "EN2_nmd_gather",
+    "E2G_geom_rotate_update_stress" };
 
 struct ProfRec { int k; hipEvent_t a, b; };
 
@@ -183,8 +186,7 @@ struct des_dev {
     double *spin;                         // [3][ne] w3, w4, w5 of a deferred rotate_stress (E1<DEFER> -> next E2)
     bool defer_rot;                       // DES_DEFER_ROT != 0 (default on): fused end-of-step passes defer the rotation
     bool rot_pending, rot_prev_dt;        // the next E2 applies it; with the dt of before the last k_dt_finalize
-    bool en1x_next;                       // the next EN1 writes the element outputs of the skipped end-of-step pass
-    int *top_elist;                       // [ntop_elems] Variables::top_elems in the engine's order
+    bool e2geo_next;                      // the next E2 does what the skipped end-of-step pass would have done (E2<GEO>)
     d4 *xt_alt;                           // the other buffer of the {x,y,z,T} pair (EN3 writes it, then they swap)
     // stress-bc lists
     int nbcf;                             // facets with a stress bc (incl. neumann)
@@ -290,7 +292,7 @@ void des_dev_destroy(des_dev *h)
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
-    void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_ln, h->pe_slot, h->ddp, h->xt_alt, h->spin, h->top_elist,
+    void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_ln, h->pe_slot, h->ddp, h->xt_alt, h->spin,
         h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->d_esend_idx, h->d_erecv_idx, h->d_send_noff,
@@ -613,8 +615,6 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             std::vector<unsigned char> flag((size_t)ne, 0);
             for (int i = 0; i < h->ntop_elems; ++i) flag[mesh->top_elems[i]] = 1;
             CK(dev_alloc(h->topflag, (size_t)ne)); CK(dev_upload(h->topflag, flag.data(), (size_t)ne, h->stream));
-            CK(dev_alloc(h->top_elist, (size_t)h->ntop_elems));
-            CK(dev_upload(h->top_elist, mesh->top_elems, (size_t)h->ntop_elems, h->stream));
         }
         CK(dev_alloc(h->dh, ntop)); CK(dev_alloc(h->edvacc, etop)); CK(dev_alloc(h->znew, ntop));
         HK(hipMemsetAsync(h->dh, 0, 8*std::max<size_t>(ntop, 1), h->stream));

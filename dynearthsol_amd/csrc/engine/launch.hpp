@@ -56,22 +56,20 @@ void refresh_props(des_dev *h)
 
 // which elements an E1 launch covers: everything, the interior ones (every node owned), or the two
 // groups that touch the ghost nodes (first and last in the engine's order, engine/order.hpp)
-enum { E1_ALL = 0, E1_INTERIOR = 1, E1_GHOST_SIDE = 2, E1_TOP_LIST = 3 };
+enum { E1_ALL = 0, E1_INTERIOR = 1, E1_GHOST_SIDE = 2 };
 
 template <int MODE>
 void launch_e1(des_dev *h, int part = E1_ALL)
 {
     int b0 = 0, c0 = h->ne, b1 = 0, c1 = 0;
-    const int *elist = nullptr;
     if (part == E1_INTERIOR)   { b0 = h->e_int0; c0 = h->e_int1 - h->e_int0; }
     if (part == E1_GHOST_SIDE) { b0 = 0; c0 = h->e_int0; b1 = h->e_int1; c1 = h->ne - h->e_int1; }
-    if (part == E1_TOP_LIST)   { c0 = h->ntop_elems; elist = h->top_elist; }
     if (c0 + c1 == 0) return;
     Launch l(h, K_E1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(c0 + c1)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, h->ne, nblk(c0 + c1), b0, c0, b1, c1, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
                        h->topflag, h->stress, h->patch ? h->ddp : nullptr, h->strain, h->plstrain, h->volume, h->volume_old,
-                       h->strain_rate, h->mrec, h->ttmp, h->spin, elist);
+                       h->strain_rate, h->mrec, h->ttmp, h->spin);
     if (MODE & MODE_DEFER) { h->rot_pending = true; h->rot_prev_dt = (MODE & MODE_DT) != 0; }
 }
 
@@ -118,25 +116,30 @@ inline bool en1_ok(const des_dev *h)
     return h->patch && h->patch_n1 && h->p.has_moving_mesh && !h->iso && h->p.damping_option != 4;
 }
 
-// EN1 can also stand in for the fused end-of-step pass itself (passes/en1.hpp, EOUT): the block that owns
-// an element writes its new volume, strain rate and the spin of the deferred rotate_stress.  What remains
-// of the end-of-step pass is the handful of top elements (correct_surface_element) -- E1<C> over their
-// list -- and, every 10th step, the compute_dt reduction: those steps keep the full fused pass.
-inline bool en1x_ok(const des_dev *h)
+// The next stress update can do the end-of-step pass of this step itself: E2<GEO> (passes/e2.hpp) forms
+// volume, strain rate and spin from the nodal records and finishes the top elements in registers -- no
+// end-of-step launch at all between two plain steps of a call (every 10th step: the compute_dt reduction
+// alone, E1<DT | VOLX>).
+inline bool e2geo_ok(const des_dev *h)
 {
-    static const char *env = std::getenv("DES_EN1X");
-    return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h) && h->top_elist && !h->overlap;
+    static const char *env = std::getenv("DES_E2GEO");
+    return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h) && h->topflag && !h->overlap;
 }
 
 // end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
 void launch_e1_end(des_dev *h, long long step_no, bool with_next, int part = E1_ALL)
 {
     const bool do_dt = (step_no % 10 == 0);
-    if (with_next && !do_dt && part == E1_ALL && en1x_ok(h)) {
-        launch_e1<MODE_C>(h, E1_TOP_LIST);
-        h->en1x_next = true;                            // the next step's EN1 writes the element outputs
+    if (with_next && part == E1_ALL && e2geo_ok(h)) {
+        // nothing to launch, the next E2 does it -- but for the compute_dt reduction of every 10th step, which
+        // then runs alone (on the new volume, formed from the coordinates); the rotation of this step uses
+        // the dt k_dt_finalize is about to replace
+        if (do_dt) launch_e1<MODE_DT | MODE_VOLX>(h, part);
+        h->e2geo_next = true;
+        h->rot_prev_dt = do_dt;
         return;
     }
+
     const int sel = (with_next ? 1 : 0) | (do_dt ? 2 : 0);
     const bool norec = with_next && en1_ok(h);       // the next step's N1 is EN1: no mrec / ttmp needed
     const bool dfr = with_next && defer_rot_ok(h);
@@ -256,15 +259,19 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     const bool defer = h->e2_two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
-    RotPending rp = {nullptr, nullptr, nullptr, 0};
-    if (h->rot_pending) {
-        rp.spin = h->spin; rp.topflag = h->topflag; rp.prev_dt = h->rot_prev_dt ? 1 : 0;
+    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr};
+    const bool geo = h->e2geo_next;
+    if (h->rot_pending || geo) {
+        rp.spin = h->spin; rp.topflag = h->topflag; rp.prev_dt = h->rot_prev_dt ? 1 : 0; rp.vm = h->vm;
         rp.ddp = (h->patch && h->p.is_using_mixed_stress && !h->iso) ? h->ddp : nullptr;
     }
     {
-        Launch l(h, K_E2);
-        auto k = h->portable_libm ? (defer ? E2_update_stress<desk::MathPortable, 1> : E2_update_stress<desk::MathPortable, 0>)
-                                  : (defer ? E2_update_stress<desk::MathOcml, 1> : E2_update_stress<desk::MathOcml, 0>);
+        Launch l(h, geo ? K_E2G : K_E2);
+        auto k = h->portable_libm
+            ? (geo ? (defer ? E2_update_stress<desk::MathPortable, 1, 1> : E2_update_stress<desk::MathPortable, 0, 1>)
+                   : (defer ? E2_update_stress<desk::MathPortable, 1, 0> : E2_update_stress<desk::MathPortable, 0, 0>))
+            : (geo ? (defer ? E2_update_stress<desk::MathOcml, 1, 1> : E2_update_stress<desk::MathOcml, 0, 1>)
+                   : (defer ? E2_update_stress<desk::MathOcml, 1, 0> : E2_update_stress<desk::MathOcml, 0, 0>));
         // with EN3 the stress-bc facet workgroups ride here (with the classic pair: in E3's launch)
         const int nbf = (h->patch && e_begin == 0 && e_count == h->ne) ? nblk(h->nbcf) : 0;
         hipLaunchKernelGGL(k, dim3(nblk8(e_count) + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
@@ -275,13 +282,14 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     }
     if (defer && !exp_skip("e2r")) {
         Launch l(h, K_E2R);
-        auto k = h->portable_libm ? E2_return_mapping<desk::MathPortable> : E2_return_mapping<desk::MathOcml>;
+        auto k = h->portable_libm ? (geo ? E2_return_mapping<desk::MathPortable, 1> : E2_return_mapping<desk::MathPortable, 0>)
+                                  : (geo ? E2_return_mapping<desk::MathOcml, 1> : E2_return_mapping<desk::MathOcml, 0>);
         hipLaunchKernelGGL(k, dim3(std::min(nblk(e_count), DES_E2R_GRID)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                            h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                            h->etmp2, h->defer_list, count, rp);
     }
-    if (e_begin + e_count == h->ne) h->rot_pending = false;      // (sub-range launches: the last one ends at ne)
+    if (e_begin + e_count == h->ne) { h->rot_pending = false; h->e2geo_next = false; }   // (sub-range launches: the last one ends at ne)
 }
 
 void launch_n2(des_dev *h)
@@ -340,22 +348,18 @@ void launch_en1(des_dev *h)
         Launch l(h, K_EN1);
         void (*k)(const des_params *, DevClock *, int, int, int, int, const int *, const int *, const ushort4 *, const short4 *,
                   const int *, const int *, const int *, const unsigned *, const MatData, const double *, const d4 *, d4 *, d4 *,
-                  double *, double *, double *, const En1Out);
+                  double *, double *, double *);
         const bool cm = h->const_mass;
-        const bool eout = h->en1x_next;
         static const char *tenv = std::getenv("DES_EN1_THREADS");
         const int T = (tenv && std::atoi(tenv) == 512) ? 512 : 256;
         const bool fit = h->patch_max_inc <= 1600 && h->patch_max_pn <= 296 && h->patch_max_pe <= 872;
-#define DES_EN1_PICK(TT, II, NN, EE) (eout ? (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1, 1> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0, 1>) \
-                                           : (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1, 0> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0, 0>))
+#define DES_EN1_PICK(TT, II, NN, EE) (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0>)
         if (fit) k = T == 512 ? DES_EN1_PICK(512, 1600, 296, 872) : DES_EN1_PICK(256, 1600, 296, 872);
         else     k = T == 512 ? DES_EN1_PICK(512, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE) : DES_EN1_PICK(256, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE);
 #undef DES_EN1_PICK
-        const En1Out eo = { h->topflag, h->volume, h->volume_old, h->strain_rate, h->spin };
         hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, h->patch_nb,
                            h->patch_npb, h->pe_ptr, h->pe_elem, h->pe_ln, h->pe_slot, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
-                           mat_data(h), h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n, h->tmass, h->ntmp, eo);
-        if (eout) { h->rot_pending = true; h->rot_prev_dt = false; h->en1x_next = false; }
+                           mat_data(h), h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n, h->tmass, h->ntmp);
     }
     std::swap(h->xt, h->xt_alt);               // EN1 wrote the records with the new temperatures there
 }

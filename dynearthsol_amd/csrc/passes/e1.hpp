@@ -52,16 +52,14 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
      const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
      double *__restrict__ stress, const double *__restrict__ ddp, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
-     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp, double *__restrict__ spin,
-     const int *__restrict__ elist)
+     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp, double *__restrict__ spin)
 {
     // this launch covers the elements [b0, b0 + c0) and [b1, b1 + c1) (the whole mesh: 0, ne, 0, 0;
     // the overlapped multi-GPU schedule runs the interior elements while the ghost region is
     // still on its way, then the two groups that touch it); ne stays the SoA plane stride
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     const bool active = el < c0 + c1;
-    // (elist: the first c0 entries of a list instead of a range -- the top elements, engine/launch.hpp)
-    const int e = elist ? (active ? elist[el] : 0) : (el < c0 ? b0 + el : b1 + (el - c0));
+    const int e = el < c0 ? b0 + el : b1 + (el - c0);
 
     double r_minl = DBL_MAX, r_maxw = DBL_MAX, r_diff = DBL_MAX, r_gdt = DBL_MAX, r_vem = 0.0;
 
@@ -105,7 +103,7 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
             rec.x = vol;
             e1_mass_terms(p, pr, rho, vol, rec.y, rec.z);
         } else {
-            vol = volume[e];
+            vol = (MODE & MODE_VOLX) ? desk::tet_volume(c) : volume[e];
             if (MODE & MODE_A) {
                 const d4 old = mrec[e];
                 rec.x = old.x; rec.y = old.y; rec.z = old.z;

@@ -15,13 +15,21 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 // anything but viscosity[e] when the element needs the Mohr-Coulomb return mapping; the second
 // pass then runs the same code with DEFER = 0 for exactly those elements.
 // what E1<MODE_DEFER> left for this pass to finish (all null / 0: nothing)
-struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; };
+struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; const d4 *vm; };
 
-template <class M, int DEFER>
+// GEO = 1: this pass also does what is left of the end-of-step pass of the step before AND the strain
+// rate of this step, from the nodal records it gathers anyway: compute_volume after the volume swap
+// (geometry.cxx:170-201, dynearthsol.cxx:466-470), correct_surface_element for the elements of the top
+// surface (bc.cxx:1670-1687), NMD_stress' pending increment, rotate_stress (fields.cxx:827-902),
+// update_strain_rate (fields.cxx:415-476) -- in the reference's order, on the stress it holds in
+// registers.  No E1 launch between two such steps (engine/launch.hpp: e2geo_ok); the coordinates,
+// velocities and dt it uses are the ones that pass would have seen (nothing but the temperature moves
+// in between, and steps with a compute_dt keep the fused E1).
+template <class M, int DEFER, int GEO>
 __device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
      const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData &md,
-     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2, const RotPending rp)
@@ -37,12 +45,58 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     const double edvoldt = dj / 4;
 
     double s[6], es[6], edot[6];
+    double g_vol = 0, g_vol_old = 0, g_pls = 0, g_T = 0;
+    bool g_rescaled = false, g_top = false;
+    if (GEO) {
+        d4 c[4], v[4];
+        c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
+        v[0] = rp.vm[cn.x]; v[1] = rp.vm[cn.y]; v[2] = rp.vm[cn.z]; v[3] = rp.vm[cn.w];
+        g_T += c[0].w; g_T += c[1].w; g_T += c[2].w; g_T += c[3].w;
+        g_T /= 4;
+        const double vol_prev = volume[e];
+        g_vol = desk::tet_volume(c);
+        double rdv = 0.0;
+        g_top = rp.topflag[e] != 0;
+        if (g_top) { rdv = g_vol / vol_prev; g_vol_old = g_vol; }     // correct_surface_element stored the new volume before the swap
+        else g_vol_old = vol_prev;
+        double sx[4], sy[4], sz[4];
+        desk::shape_fn(c, g_vol, sx, sy, sz);
+        e1_strain_rate_diag(v, sx, sy, sz, edot[0], edot[1], edot[2]);
+        edot[3] = 0; for (int i = 0; i < 4; ++i) edot[3] += 0.5 * (v[i].x * sy[i] + v[i].y * sx[i]);
+        edot[4] = 0; for (int i = 0; i < 4; ++i) edot[4] += 0.5 * (v[i].x * sz[i] + v[i].z * sx[i]);
+        edot[5] = 0; for (int i = 0; i < 4; ++i) edot[5] += 0.5 * (v[i].y * sz[i] + v[i].z * sy[i]);
+        // the shear components are final (only the diagonal is corrected below): out now, not held to the end
+        // (the return-mapping pass recomputes and rewrites the same values for the elements set aside)
+        for (int i = 3; i < 6; ++i) strain_rate[(size_t)i*ne + e] = edot[i];
+        double w3 = 0, w4 = 0, w5 = 0;
+        for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
+        for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
+        for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
+        for (int i = 0; i < 6; ++i) {
+            s[i] = stress[(size_t)i*ne + e];
+            es[i] = strain[(size_t)i*ne + e];
+        }
+        g_pls = plstrain[e];
+        const double dd = rp.ddp ? rp.ddp[e] : 0.0;
+        if (dd != 0.0) for (int i = 0; i < 3; ++i) s[i] += dd;
+        if (rdv >= 1.0) {                                                      // bc.cxx:1677
+            g_pls /= rdv;
+            for (int i = 0; i < 6; ++i) { s[i] /= rdv; es[i] /= rdv; }
+            g_rescaled = true;
+        }
+        if (rheol & DES_RH_ELASTIC) {
+            const double dtr = rp.prev_dt ? clk->dt_prev : dt;             // the dt of the step being finished
+            desk::jaumann_rate_3d(s, dtr, w3, w4, w5);
+            desk::jaumann_rate_3d(es, dtr, w3, w4, w5);
+        }
+    } else {
     for (int i = 0; i < 6; ++i) {
         s[i] = stress[(size_t)i*ne + e];
         es[i] = strain[(size_t)i*ne + e];
         edot[i] = strain_rate[(size_t)i*ne + e];
     }
-    if (rp.spin && !rp.topflag[e]) {
+    }
+    if (!GEO && rp.spin && !rp.topflag[e]) {
         // the end of the step before, left here by E1<MODE_DEFER>: NMD_stress' increment of the diagonal
         // (geometry.cxx:316-331), then rotate_stress (fields.cxx:827-902) with that step's dt -- the same
         // operations in the same order as E1 does them in place
@@ -63,14 +117,18 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     for (int i = 0; i < 6; ++i) de[i] = edot[i] * dt;
     double dpl = 0.;
     bool defer = false;
-    const double vol = volume[e];
+    const double vol = GEO ? g_vol : volume[e];
+    const double vol_old = GEO ? g_vol_old : ((rheol == DES_RH_MAXWELL || rheol == DES_RH_EVP) ? volume_old[e] : 0.0);   // (dies at dv)
 
     M::stage_end();
     double visc = 0;
     if (rheol & DES_RH_VISCOUS) {
         double T = 0;
-        T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
-        T /= 4;
+        if (GEO) T = g_T;
+        else {
+            T += xt[cn.x].w; T += xt[cn.y].w; T += xt[cn.z].w; T += xt[cn.w].w;
+            T /= 4;
+        }
         visc = desk::mat_visc<M>(p, vt, mx, T, s, edot);
         viscosity[e] = visc;
     }
@@ -83,28 +141,29 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         desk::viscous(pr.bulkm, visc, desk::trace3(es), edot, s);
         break;
     case DES_RH_MAXWELL: {
-        double dv = vol / volume_old[e] - 1;
+        double dv = vol / vol_old - 1;
         desk::maxwell(pr.bulkm, pr.shearm, visc, dt, dv, de, s);
         break;
     }
     case DES_RH_EP: {
         double amc, anphi, anpsi, hardn, ten_max;
-        double pls = plstrain[e];
+        double pls = GEO ? g_pls : plstrain[e];
         desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s, &defer);
         if (DEFER && defer) return true;
-        if (depls != 0) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
+        if (depls != 0 || g_rescaled) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
+        g_rescaled = false;
         dpl = depls;
         break;
     }
     case DES_RH_EVP: {
-        double dv = vol / volume_old[e] - 1;
+        double dv = vol / vol_old - 1;
         double sv[6];
         for (int i = 0; i < 6; ++i) sv[i] = s[i];
         desk::maxwell(pr.bulkm, pr.shearm, visc, dt, dv, de, sv);
         double svII = desk::second_invariant2(sv);
         double amc, anphi, anpsi, hardn, ten_max;
-        double pls = plstrain[e];
+        double pls = GEO ? g_pls : plstrain[e];
         desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double sp[6];
         for (int i = 0; i < 6; ++i) sp[i] = s[i];
@@ -117,17 +176,23 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
             for (int i = 0; i < 6; ++i) s[i] = sp[i];
             plstrain[e] = pls + depls;
             dpl = depls;
+            g_rescaled = false;
         }
         break;
     }
     default: break;
+    }
+    if (GEO) {
+        if (g_rescaled) plstrain[e] = g_pls;                 // rescaled by correct_surface_element, not changed by the law
+        volume_old[e] = g_top ? vol : volume[e];             // (re-read rather than held in registers through the update)
+        volume[e] = vol;
     }
     delta_plstrain[e] = dpl;
     for (int i = 0; i < 6; ++i) {
         stress[(size_t)i*ne + e] = s[i];
         strain[(size_t)i*ne + e] = es[i];
     }
-    for (int i = 0; i < 3; ++i) strain_rate[(size_t)i*ne + e] = edot[i];   // only the diagonal changed
+    for (int i = 0; i < 3; ++i) strain_rate[(size_t)i*ne + e] = edot[i];   // only the diagonal changed (GEO: all six are new)
     if (p->is_using_mixed_stress) {
         double dp = desk::trace3(s) - old_s;
         dpressure[e] = dp;
@@ -139,12 +204,17 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
 // First pass: every element [e_begin, e_begin + e_count) (the whole local mesh, or a sub-range:
 // ne stays the SoA plane stride).  DEFER = 1: elements that need the return mapping are appended
 // to `list` (wave-aggregated: one atomic per wavefront) for E2_return_mapping.
-template <class M, int DEFER>
-__global__ void __launch_bounds__(DES_BLOCK, DEFER ? DES_E2_WAVES_FAST : DES_E2_WAVES)
+// first pass with the geometry part: 206 VGPRs; held to the 168 of three waves per SIMD it spills 150 B per
+// lane and takes 137 us instead of 89 (1M tets)
+#ifndef DES_E2GEO_WAVES
+#define DES_E2GEO_WAVES DES_E2_WAVES
+#endif
+template <class M, int DEFER, int GEO>
+__global__ void __launch_bounds__(DES_BLOCK, DEFER ? (GEO ? DES_E2GEO_WAVES : DES_E2_WAVES_FAST) : DES_E2_WAVES)
 E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData md,
-     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ list, int *__restrict__ count,
@@ -163,7 +233,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     if (el >= e_count) return;
     const int e = e_begin + el;
-    const bool defer = e2_element<M, DEFER>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+    const bool defer = e2_element<M, DEFER, GEO>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
                                             plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);
     // one atomic per wavefront that has such elements; without DEFER only the count is kept
     // (des_scalars::n_return_mapping, and what the host picks the next call's mode from)
@@ -182,12 +252,12 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
 
 // Second pass: the elements the first pass set aside, full stress update with the return mapping
 // (same code, same arithmetic; the order of the list does not matter, every element is its own).
-template <class M>
+template <class M, int GEO>
 __global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
 E2_return_mapping(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData md,
-     const double *__restrict__ volume, const double *__restrict__ volume_old,
+     double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2, const int *__restrict__ list, const int *__restrict__ count,
@@ -197,6 +267,6 @@ E2_return_mapping(const des_params *__restrict__ p, const desk::ViscTerms *__res
     M::stage_end();
     const int n = *count;
     for (int i = blockIdx.x * DES_BLOCK + threadIdx.x; i < n; i += gridDim.x * DES_BLOCK)
-        e2_element<M, 0>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+        e2_element<M, 0, GEO>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
                          plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);
 }

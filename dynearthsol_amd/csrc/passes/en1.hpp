@@ -16,28 +16,19 @@
 // Valid when nothing but the nodal records has changed since the end-of-step pass (engine/launch.hpp,
 // en1_ok): inside a multi-step call.  The new temperatures go to the other buffer of the
 // {x,y,z,T} pair (another block may still be reading this block's nodes); the host swaps.
-//
-// EOUT: the block that owns an element (holds its lowest node) also writes what the fused end-of-step
-// pass E1<C | A | NOREC | DEFER> of the step before would have written for it -- the volume swap +
-// compute_volume (dynearthsol.cxx:466-470, geometry.cxx:170-201), update_strain_rate (fields.cxx:415-476)
-// and the spin of the deferred rotate_stress -- from the very records, volume and shape functions it has
-// in hand, so that pass is not launched at all (engine/launch.hpp: en1x).  Elements of the top surface
-// were finished by E1 over the top list (correct_surface_element may rescale them): only their strain
-// rate is written here.
+
 #ifndef DES_PATCH_PE
 #define DES_PATCH_PE 1280         // elements of a patch (LDS records)
 #endif
 
-struct En1Out { const unsigned char *topflag; double *volume, *volume_old, *strain_rate, *spin; };
-
-template <int THREADS, int INC, int PN, int PE, int CONSTM, int EOUT>
+template <int THREADS, int INC, int PN, int PE, int CONSTM>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 3)
 EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int ne, int nblocks, int npb,
      const int *__restrict__ pe_ptr, const int *__restrict__ pe_elem, const ushort4 *__restrict__ pe_ln,
      const short4 *__restrict__ pe_slot, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag, const MatData md,
      const double *__restrict__ radiogenic, const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm,
-     double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp, const En1Out eo)
+     double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp)
 {
     __shared__ d4 lxt[PN];
     __shared__ double lvx[PN], lvy[PN], lvz[PN];
@@ -82,8 +73,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     __syncthreads();
     // the patch's elements: E1's element terms, recomputed
     for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) {
-        const int ew = pe_elem[i];
-        const int e = ew & 0x3fffffff;
+        const int e = pe_elem[i] & 0x3fffffff;
         const ushort4 ln = pe_ln[i];
         const short4 sl = pe_slot[i];
         const int q = i - e_begin;                          // position in the patch
@@ -109,24 +99,6 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         double s0, s1, s2;
         e1_strain_rate_diag(v, sx, sy, sz, s0, s1, s2);
         double dj = s0 + s1 + s2;
-        if (EOUT && (ew & 0x40000000)) {
-            // the element's own outputs of the end-of-step pass (same expressions as E1)
-            double s3 = 0, s4 = 0, s5 = 0;
-            for (int k = 0; k < 4; ++k) s3 += 0.5 * (v[k].x * sy[k] + v[k].y * sx[k]);
-            for (int k = 0; k < 4; ++k) s4 += 0.5 * (v[k].x * sz[k] + v[k].z * sx[k]);
-            for (int k = 0; k < 4; ++k) s5 += 0.5 * (v[k].y * sz[k] + v[k].z * sy[k]);
-            double *sr = eo.strain_rate + e;
-            sr[0] = s0; sr[(size_t)ne] = s1; sr[(size_t)2*ne] = s2; sr[(size_t)3*ne] = s3; sr[(size_t)4*ne] = s4; sr[(size_t)5*ne] = s5;
-            if (!eo.topflag[e]) {
-                double w3 = 0, w4 = 0, w5 = 0;
-                for (int k = 0; k < 4; ++k) w3 += 0.5 * (v[k].x * sy[k] - v[k].y * sx[k]);
-                for (int k = 0; k < 4; ++k) w4 += 0.5 * (v[k].x * sz[k] - v[k].z * sx[k]);
-                for (int k = 0; k < 4; ++k) w5 += 0.5 * (v[k].y * sz[k] - v[k].z * sy[k]);
-                eo.spin[e] = w3; eo.spin[(size_t)ne + e] = w4; eo.spin[(size_t)2*ne + e] = w5;
-                eo.volume_old[e] = eo.volume[e];             // pointer swap of dynearthsol.cxx:466-470
-                eo.volume[e] = vol;
-            }
-        }
         lvol[q] = vol; ltm[q] = tm; ldv[q] = dj * vol;
         if (!CONSTM) lm[q] = m;
         if (sl.x >= 0) { ltd[sl.x] = tr[0]; lidx[sl.x] = (unsigned short)q; }
