@@ -452,6 +452,10 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             }
             if (h->patch) {
                 h->patch_npb = P.npb; h->patch_nb = P.nb; h->patch_max_inc = P.max_inc; h->patch_max_pn = P.max_pn; h->patch_max_pe = P.max_pe;
+                if (std::getenv("DES_PATCH_VERBOSE"))
+                    std::fprintf(stderr, "patches: %d nodes per block, %d blocks, max incidences %d, patch nodes %d, patch elements %d, "
+                                 "elements listed %zu (%.2f x nelem)\n", P.npb, P.nb, P.max_inc, P.max_pn, P.max_pe, P.pe_elem.size(),
+                                 (double)P.pe_elem.size() / ne);
                 const char *pn1 = std::getenv("DES_PATCH_N1");
                 h->patch_n1 = !(pn1 && pn1[0] == '0') && P.max_pe <= DES_PATCH_PE;
                 const char *pt = std::getenv("DES_PATCH_THREADS");

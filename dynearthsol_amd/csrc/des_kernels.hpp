@@ -82,6 +82,17 @@ __device__ __forceinline__ double tri_area(const d4 &a, const d4 &b, const d4 &c
     double d2 = ab0*ac1 - ab1*ac0;
     return sqrt(d0*d0 + d1*d1 + d2*d2) / 2;
 }
+// the radicand alone: sqrt is monotone and correctly rounded, so max_i sqrt(x_i) = sqrt(max_i x_i) to the bit --
+// the largest of several areas costs one square root
+__device__ __forceinline__ double tri_area_sq4(const d4 &a, const d4 &b, const d4 &c)
+{
+    double ab0 = b.x - a.x, ab1 = b.y - a.y, ab2 = b.z - a.z;
+    double ac0 = c.x - a.x, ac1 = c.y - a.y, ac2 = c.z - a.z;
+    double d0 = ab1*ac2 - ab2*ac1;
+    double d1 = ab2*ac0 - ab0*ac2;
+    double d2 = ab0*ac1 - ab1*ac0;
+    return d0*d0 + d1*d1 + d2*d2;
+}
 
 __device__ __forceinline__ double trace3(const double *s) { return s[0] + s[1] + s[2]; }
 

@@ -159,9 +159,10 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
             double vx = 0.0, vy = 0.0, vz = 0.0;
             const double weight = 1.0 / 4;
             for (int j = 0; j < 4; ++j) { vx += v[j].x * weight; vy += v[j].y * weight; vz += v[j].z * weight; }
-            r_vem = sqrt(vx*vx + vy*vy + vz*vz);
-            double maxa = fmax(fmax(desk::tri_area(c[0], c[1], c[2]), desk::tri_area(c[0], c[1], c[3])),
-                               fmax(desk::tri_area(c[2], c[3], c[0]), desk::tri_area(c[2], c[3], c[1])));
+            r_vem = vx*vx + vy*vy + vz*vz;           // its square root is taken after the maximum over the block (monotone)
+            // max of the four facet areas = sqrt(max of the radicands) / 2, to the bit
+            double maxa = sqrt(fmax(fmax(desk::tri_area_sq4(c[0], c[1], c[2]), desk::tri_area_sq4(c[0], c[1], c[3])),
+                                    fmax(desk::tri_area_sq4(c[2], c[3], c[0]), desk::tri_area_sq4(c[2], c[3], c[1])))) / 2;
             double minh = 3 * vol / maxa;
             r_maxw = 0.5 * p->visc_min / (1e-40 + pr.shearm);
             if (p->has_thermal_diffusion) r_diff = 0.5 * minh * minh / p->therm_diff_max;
@@ -208,7 +209,7 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
             desk::atomic_min_double(&clk->r_dt_maxwell, red[1][0]);
             desk::atomic_min_double(&clk->r_dt_diffusion, red[2][0]);
             desk::atomic_min_double(&clk->r_global_dt_min, red[3][0]);
-            desk::atomic_max_double(&clk->r_max_vem, red[4][0]);
+            desk::atomic_max_double(&clk->r_max_vem, sqrt(red[4][0]));
         }
     }
 }
