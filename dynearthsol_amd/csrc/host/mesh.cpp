@@ -99,6 +99,94 @@ void new_mesh_regular2d(const Config &cfg, HostMesh &m)
     m.regattr.assign((size_t)nelem, 0.0);     // mesh.cxx:570-575
 }
 
+// meshing_elem_shape = 2 (2-D only): rows of near-equilateral triangles (new_mesh_regular_equilateral,
+// mesh.cxx:578-684, 2513-2596).  Rows alternate between nx nodes ("even" rows, the top one first) and
+// nx + 1 nodes shifted by half a spacing ("odd" rows); the side walls stay at x = 0 and xlength, the last
+// row sits at -zlength.  Node numbering: all even rows first, then all odd rows; each strip between two
+// rows carries nx - 1 triangles with their base on the even row and nx with their base on the odd row,
+// the family whose base is on the strip's upper row first; connectivity counter-clockwise.
+void new_mesh_equilateral2d(const Config &cfg, HostMesh &m)
+{
+    const double Lx = cfg.d("mesh.xlength"), Lz = cfg.d("mesh.zlength"), res = cfg.d("mesh.resolution");
+    const double sqrt3_to_2 = 2. / std::sqrt(3.0);
+    const double x_mid = Lx / 2;
+    const int nx = int((x_mid - 0.5*res) / res) * 2 + 2;
+    const int nz = int(Lz * sqrt3_to_2 / res) + 1;
+    if (nx < 2 || nz < 2) throw Error(11, "regular mesh needs at least one cell per direction");
+    const int n_even_rows = (nz + 1) / 2, n_odd_rows = nz / 2;
+    const int nnode = nx * n_even_rows + (nx + 1) * n_odd_rows;
+    const int nelem = (2*nx - 1) * (nz - 1);
+    const int nseg = (nx - 1) + (nx - nz % 2) + 2 * (nz - 1);
+    const int odd_base = nx * n_even_rows;
+    // first node of row j and its node count
+    auto row_start = [&](int j) { return (j % 2 == 0) ? nx * (j / 2) : odd_base + (nx + 1) * (j / 2); };
+    auto row_count = [&](int j) { return (j % 2 == 0) ? nx : nx + 1; };
+
+    m.nd = 2;
+    m.nnode = nnode; m.nelem = nelem; m.nseg = nseg;
+    m.coord.assign((size_t)2*nnode, 0.0);
+    const double dx = res, dz = -res * std::sqrt(3.0) / 2.;
+    const double bdy_dx = (Lx - (nx-1)*dx) / 2.;
+    for (int j = 0; j < nz; ++j) {
+        const int s0 = row_start(j), cnt = row_count(j);
+        const double z = (j == nz-1) ? -Lz : j * dz;
+        for (int i = 0; i < cnt; ++i) {
+            double x;
+            if (i == 0) x = 0.;
+            else if (i == cnt-1) x = Lx;
+            else x = (j % 2 == 0) ? i * dx + bdy_dx : ((i-1) + 0.5) * dx + bdy_dx;
+            m.coord[(size_t)s0 + i] = x;
+            m.coord[(size_t)nnode + s0 + i] = z;
+        }
+    }
+
+    m.conn.assign((size_t)3*nelem, 0);
+    int e = 0;
+    auto tri = [&](int a, int b, int c) {
+        m.conn[e] = a; m.conn[(size_t)nelem + e] = b; m.conn[(size_t)2*nelem + e] = c; ++e;
+    };
+    for (int j = 0; j < nz-1; ++j) {
+        const bool even_on_top = (j % 2 == 0);
+        const int ev = row_start(even_on_top ? j : j+1), od = row_start(even_on_top ? j+1 : j);
+        // base on the even row: (even i, even i+1) + the odd node between them
+        auto even_based = [&]() {
+            for (int i = 0; i < nx-1; ++i) {
+                if (even_on_top) tri(ev + i, od + i + 1, ev + i + 1);
+                else             tri(ev + i, ev + i + 1, od + i + 1);
+            }
+        };
+        // base on the odd row: (odd i, odd i+1) + the even node between them
+        auto odd_based = [&]() {
+            for (int i = 0; i < nx; ++i) {
+                if (even_on_top) tri(od + i, od + i + 1, ev + i);
+                else             tri(od + i, ev + i, od + i + 1);
+            }
+        };
+        if (even_on_top) { even_based(); odd_based(); }
+        else             { odd_based(); even_based(); }
+    }
+    if (e != nelem) throw Error(60, "equilateral mesh: element count mismatch");
+
+    std::vector<int> seg, flag;
+    auto add = [&](int a, int b, unsigned f) { seg.push_back(a); seg.push_back(b); flag.push_back((int)f); };
+    for (int i = 0; i < nx-1; ++i) add(i, i + 1, BOUNDZ1);
+    {
+        const int b0 = row_start(nz-1), nb = row_count(nz-1) - 1;
+        for (int i = 0; i < nb; ++i) add(b0 + i, b0 + i + 1, BOUNDZ0);
+    }
+    for (int j = 0; j < nz-1; ++j) {
+        // side walls, upper node first
+        add(row_start(j), row_start(j+1), BOUNDX0);
+        add(row_start(j) + row_count(j) - 1, row_start(j+1) + row_count(j+1) - 1, BOUNDX1);
+    }
+    if ((int)flag.size() != nseg) throw Error(60, "equilateral mesh: segment count mismatch");
+    m.segment.resize((size_t)2*nseg);
+    for (int q = 0; q < nseg; ++q)
+        for (int d = 0; d < 2; ++d) m.segment[(size_t)d*nseg + q] = seg[(size_t)q*2 + d];
+    m.segflag = flag;
+    m.regattr.assign((size_t)nelem, 0.0);
+}
+
 // The regular mesher writes AoS scratch arrays first (as the reference's
 // create_rect_node / create_elem_from_cell / create_regular_segments do) and converts to SoA.
 void new_mesh_regular(const Config &cfg, HostMesh &m)
@@ -386,9 +474,9 @@ void create_new_mesh(const Config &cfg, HostMesh &m, const std::string &mesh_fil
         throw Error(30, "mesh.meshing_elem_shape >= 1 is only for mesh.meshing_option == 1.");
     if (shape == 2 && m.nd == 3)
         throw Error(30, "mesh.meshing_elem_shape == 2 is not available in 3D.");
-    if (shape == 2)
-        throw Error(31, "mesh.meshing_elem_shape == 2 (equilateral triangles, mesh.cxx:577-760) is not built by this host");
-    if (opt == 1 && shape == 1) {
+    if (opt == 1 && shape == 2) {
+        new_mesh_equilateral2d(cfg, m);
+    } else if (opt == 1 && shape == 1) {
         new_mesh_regular(cfg, m);
     } else if (opt == 1 || opt == 2 || opt == 90 || opt == 91) {
         throw Error(31, "this meshing_option needs TetGen / Triangle, host-side libraries of the "

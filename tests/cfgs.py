@@ -506,3 +506,14 @@ dilation_angle1 = [ 0 ]
 max_viscosity = 1e24
 min_viscosity = 1e19
 """
+
+
+# benchmarks-cores/test-rect-tiny.cfg = test-tiny.cfg on the 2-D build's own mesh of near-equilateral
+# triangles (meshing_option = 1 with meshing_elem_shape = 2: no Triangle needed), a 50-km-deep box
+TEST_RECT_TINY_OVERRIDES = ("mesh.meshing_option = 1\nmesh.meshing_elem_shape = 2\nmesh.meshing_verbosity = -1\n"
+                            "mesh.zlength = 50e3\nmesh.min_angle = 10.\nmesh.max_boundary_distortion = 1e1\n")
+
+# benchmarks-cores/test-topo.cfg = test-tiny.cfg with topo.poly (10 km of relief on the top boundary) at 5 km,
+# strong surface diffusion, 2000 steps; mesh: tests/golden/test-topo.desmesh (361 nodes / 653 triangles)
+TEST_TOPO_OVERRIDES = ("mesh.poly_filename = topo.poly\nmesh.resolution = 5e3\ncontrol.surface_diffusivity = 1e-2\n"
+                       "sim.max_steps = 2000\nsim.output_step_interval = 500\nsim.checkpoint_frame_interval = 4\n")

@@ -104,8 +104,8 @@ def test_2d_initial_conditions_have_2d_shapes():
 
 def test_what_the_2d_host_does_not_build_is_refused():
     with pytest.raises(des.DesError) as ei:
-        des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides="mesh.meshing_elem_shape = 2\n", ndims=2)
-    assert ei.value.code == 31
+        des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides="mesh.meshing_elem_shape = 2\n")        # 2-D only (input.cxx:1072-1076)
+    assert ei.value.code == 30
     with pytest.raises(des.DesError) as ei:
         des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides="mesh.meshing_elem_shape = 0\n", ndims=2)   # needs Triangle
     assert ei.value.code == 31
@@ -363,3 +363,35 @@ def test_reference_reader_reads_our_2d_frames(in_tmp):
     coord, conn = d.read_field(4, "coordinate"), d.read_field(4, "connectivity")
     expect = np.einsum("mkd,mk->md", coord[conn[mk["markerset.elem"]]], mk["markerset.eta"])
     assert np.allclose(mk["markerset.coord"], expect, rtol=1e-14, atol=1e-6)
+
+
+def test_equilateral_2d_mesher_of_test_rect_tiny():
+    """mesh.meshing_elem_shape = 2 (new_mesh_regular_equilateral, mesh.cxx:578-684): benchmarks-cores/test-rect-tiny.cfg
+    is meshed by the host itself -- the reference's counts, counter-clockwise triangles that tile the box, flat
+    boundaries, equilateral interior rows; then four steps of the oracle."""
+    h = des.Host(cfg_text=cfgs.TEST_TINY, overrides=cfgs.TEST_RECT_TINY_OVERRIDES, ndims=2)
+    Lx, Lz, res = 150e3, 50e3, 1e4
+    nx = int((Lx / 2 - 0.5 * res) / res) * 2 + 2                       # mesh.cxx:660-665
+    nz = int(Lz * 2 / np.sqrt(3.0) / res) + 1
+    assert (nx, nz) == (16, 6)
+    assert h.nnode == nx * ((nz + 1) // 2) + (nx + 1) * (nz // 2) == 99
+    assert h.nelem == (2 * nx - 1) * (nz - 1) == 155
+    m = h.mesh
+    assert [m.nbfacets[i] for i in range(10)] == [nz - 1, nz - 1, 0, 0, nx, nx - 1, 0, 0, 0, 0]     # nz even: the last row has nx + 1 nodes
+    assert (m.ntop, m.etop) == (nx, nx - 1)
+    coord = h.array("coord").reshape(2, -1)
+    conn = h.array("connectivity").reshape(3, -1)
+    a, b, c = (coord[:, conn[i]] for i in range(3))
+    area = 0.5 * ((b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]))
+    assert (area > 0).all() and area.sum() == pytest.approx(Lx * Lz, rel=1e-13)
+    bc = np.ctypeslib.as_array(m.bcflag, shape=(h.nnode,))
+    assert (coord[0][(bc & 1) != 0] == 0).all() and (coord[0][(bc & 2) != 0] == Lx).all()
+    assert (coord[1][(bc & 32) != 0] == 0).all() and (coord[1][(bc & 16) != 0] == -Lz).all()
+    # interior triangles of the upper strips are equilateral with side = resolution
+    side = np.stack([np.hypot(*(b - a)), np.hypot(*(c - b)), np.hypot(*(a - c))])
+    equil = np.isclose(side, res, rtol=1e-12).all(axis=0)
+    assert equil.sum() > 0.5 * h.nelem
+    o = OracleEngine(h)
+    o.init_from_host(h)
+    sc = o.step(4)
+    assert sc.steps == 4 and sc.status == 0 and o.check_nan() == 0
