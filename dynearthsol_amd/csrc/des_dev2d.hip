@@ -78,7 +78,9 @@ struct Engine {
     double *dh = nullptr, *edvacc = nullptr;
     double *stress_avg = nullptr, *dplstrain_avg = nullptr, *strain0 = nullptr, *coord_avg0 = nullptr;
     double *res_part = nullptr; int res_nb = 0;
+    double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
     bool markers_dirty = true, iso = false;
+    bool count_past = false;           // this step feeds des_scalars::n_return_mapping (the last one of a call)
     long long steps_host = 0;
     long long n_pt_iterations = 0;   // pseudo-transient iterations of the current step() call
     std::vector<void *> allocs;
@@ -485,7 +487,7 @@ __global__ void __launch_bounds__(DES_BLOCK)
 k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, const int *conn, const double *temperature,
           const double *props, const int *markers, const double *edvoldt, const double *volume, const double *volume_old,
           double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
-          double *viscosity, double *dpressure, double *etmp)
+          double *viscosity, double *dpressure, double *etmp, int count_past)
 {
     M::stage_begin();
     M::stage_end();
@@ -581,7 +583,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     default: break;
     }
     delta_plstrain[e] = dpls;
-    {
+    if (count_past) {                  // (the last step of a call only: one address, thousands of wavefronts)
         const unsigned long long b = __ballot(past);
         if (b && (int)(threadIdx.x & 63) == __ffsll((long long)b) - 1) atomicAdd(&clk->n_past, (int)__popcll(b));
     }
@@ -821,34 +823,45 @@ __global__ void k2_residual_fin(int nb, const double *part, Clock *clk)
     if (threadIdx.x == 0) clk->l2_residual = sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
-// apply_vbcs, 2-D: vertical extent of the x0 / x1 walls and the lowest node (bc.cxx:251-290, 350-361).
-// min / max: exact whatever the order.  One workgroup.
-__global__ void k2_vbc_extent(int nn, const unsigned *bcflag, const double *coord, Clock *clk)
+// apply_vbcs, 2-D: vertical extent of the x0 wall (bc.cxx:251-290; only x0's is used, :292-300) over the list of
+// its nodes.  min / max: exact whatever the order.  One workgroup.
+__global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double *coord, Clock *clk)
 {
-    __shared__ double s_max[DES_BLOCK / 64], s_min[DES_BLOCK / 64], s_zmin[DES_BLOCK / 64];
-    __shared__ int s_any[DES_BLOCK / 64];
-    double mx = -DBL_MAX, mn = DBL_MAX, zmin = 0;
-    int any = 0;
-    for (int i = threadIdx.x; i < nn; i += DES_BLOCK) {
-        const double z = coord[nn + i];
-        if (z < zmin) zmin = z;
-        if (bcflag[i] & BOUNDX0) { any = 1; mx = fmax(mx, z); mn = fmin(mn, z); }
+    __shared__ double s_max[DES_BLOCK / 64], s_min[DES_BLOCK / 64];
+    double mx = -DBL_MAX, mn = DBL_MAX;
+    for (int j = threadIdx.x; j < nb; j += DES_BLOCK) {
+        const double z = coord[nn + bnodes_x0[j]];
+        mx = fmax(mx, z); mn = fmin(mn, z);
     }
-    mx = desk::wave_max(mx); mn = desk::wave_min(mn); zmin = desk::wave_min(zmin);
-    any = __any(any);
-    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_max[w] = mx; s_min[w] = mn; s_zmin[w] = zmin; s_any[w] = any; }
+    mx = desk::wave_max(mx); mn = desk::wave_min(mn);
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_max[w] = mx; s_min[w] = mn; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < DES_BLOCK / 64; ++w) {
-            s_max[0] = fmax(s_max[0], s_max[w]); s_min[0] = fmin(s_min[0], s_min[w]);
-            s_zmin[0] = fmin(s_zmin[0], s_zmin[w]); s_any[0] |= s_any[w];
-        }
-        clk->x0_init = s_any[0];
-        clk->x0_max = s_any[0] ? s_max[0] : 0.;
-        clk->x0_min = s_any[0] ? s_min[0] : 0.;
-        clk->zmin = s_zmin[0];
+        for (int w = 1; w < DES_BLOCK / 64; ++w) { s_max[0] = fmax(s_max[0], s_max[w]); s_min[0] = fmin(s_min[0], s_min[w]); }
+        clk->x0_init = nb > 0;
+        clk->x0_max = nb > 0 ? s_max[0] : 0.;
+        clk->x0_min = nb > 0 ? s_min[0] : 0.;
+        clk->zmin = 0;                       // k2_vbc_zmin lowers it when the sheared bottom zone needs it
     }
 }
+
+// ... and the lowest node of the mesh, zmin = min(0, min z) (bc.cxx:350-361): read only by vbc_x0 = 3 with a
+// bottom shear zone (bc.cxx:446-451), so only launched then.  -zmin = max(0, max(-z)): a maximum of
+// non-negative doubles, one native 64-bit integer atomic per workgroup.
+__global__ void k2_vbc_zmin(int nn, const double *coord, double *neg_zmin)
+{
+    __shared__ double sm[DES_BLOCK / 64];
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    double m = (i < nn) ? fmax(0.0, -coord[nn + i]) : 0.0;
+    m = desk::wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < DES_BLOCK / 64; ++w) sm[0] = fmax(sm[0], sm[w]);
+        desk::atomic_max_double(neg_zmin, sm[0]);
+    }
+}
+__global__ void k2_vbc_zmin_fin(Clock *clk, double *neg_zmin) { clk->zmin = -(*neg_zmin); *neg_zmin = 0.0; }
 
 // apply_vbcs (bc.cxx:227-659, !THREED) of a node; Clock::pt = PT_jump: boundaries at rest (bc.cxx:330-343)
 __global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, const unsigned *bcflag, const double *bnormals,
@@ -1385,16 +1398,21 @@ void launch_volume_mass(Engine *h, bool with_mass)
 
 void launch_vbcs(Engine *h)
 {
-    hipLaunchKernelGGL(k2_vbc_extent, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nn, h->bcflag, h->coord, h->d_clk);
+    hipLaunchKernelGGL(k2_vbc_extent, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord, h->d_clk);
+    if (h->p.vbc_types[0] == 3 && h->p.bottom_shear_zone_thickness > 0.) {
+        L2(k2_vbc_zmin, h->nn, h->nn, h->coord, h->neg_zmin);
+        hipLaunchKernelGGL(k2_vbc_zmin_fin, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->neg_zmin);
+    }
     L2(k2_apply_vbcs, h->nn, h->d_p, h->d_clk, h->nn, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->coord, h->vel);
 }
 
 template <class M>
 void launch_stress(Engine *h)
 {
+    if (h->count_past) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
     L2(k2_stress<M>, h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
        h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-       h->viscosity, h->dpressure, h->etmp);
+       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0);
 }
 
 // update_force's boundary terms in the reference's order (fields.cxx:682-691)
@@ -1633,6 +1651,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->dh, (size_t)h->ntop));
     A2(dalloc(h, h->edvacc, (size_t)h->etop));
     A2(dalloc(h, h->res_part, (size_t)nblk(nn)));
+    A2(dalloc(h, h->neg_zmin, 1));
     if (params->is_outputting_averaged_fields) {
         A2(dalloc(h, h->stress_avg, (size_t)3 * ne)); A2(dalloc(h, h->strain0, (size_t)3 * ne));
         A2(dalloc(h, h->dplstrain_avg, (size_t)ne)); A2(dalloc(h, h->coord_avg0, (size_t)2 * nn));
@@ -1756,10 +1775,7 @@ int step(Engine *h, int nsteps, des_scalars *out)
     HIP2(hipSetDevice(h->device));
     h->n_pt_iterations = 0;
     for (int i = 0; i < nsteps; ++i) {
-        if (i == nsteps - 1) {
-            static const int zero = 0;
-            HIP2(hipMemcpyAsync(&h->d_clk->n_past, &zero, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        }
+        h->count_past = (i == nsteps - 1);
         const int rc = h->portable_libm ? one_step<desk::MathPortable>(h) : one_step<desk::MathOcml>(h);
         if (rc) return rc;
     }
