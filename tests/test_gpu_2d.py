@@ -136,6 +136,28 @@ def test_2d_boundary_conditions_are_bit_exact(bc):
         run(dev, ora, 3, 20)
 
 
+OPTIONS = [
+    "control.has_moving_mesh = no\n",
+    "control.gravity = 0\n",
+    "control.is_using_mixed_stress = no\n",
+    "control.has_thermal_diffusion = no\n",
+    "control.fixed_dt = 1e7\n",
+    "control.is_quasi_static = no\ncontrol.dt_fraction = 0.5\n",
+    "control.surface_process_option = 0\n",
+    "control.ref_pressure_option = 2\nbc.has_winkler_foundation = no\nbc.vbc_z0 = 1\n",
+    "control.characteristic_speed = 2e-9\nbc.winkler_delta_rho = 100\n",
+    "mesh.meshing_elem_shape = 2\n",
+]
+
+
+@pytest.mark.parametrize("ov", OPTIONS)
+def test_2d_option_matrix_is_bit_exact(ov):
+    # the switches of the step one at a time, on two materials with a geotherm (evp)
+    with portable_libm():
+        host, dev, ora = pair(dict(cfgs.EVP, nmat=2, res=1e3), overrides=ov)
+        run(dev, ora, 3, 15)
+
+
 @pytest.mark.parametrize("opt", [1, 2, 3, 4])
 def test_damping_options_are_bit_exact(opt):
     host, dev, ora = pair(dict(cfgs.EP, res=1e3, control="damping_option = %d\n" % opt))
