@@ -162,6 +162,8 @@ struct des_dev {
     bool use_graph;                       // DES_GRAPH=1
     hipGraphExec_t graph_exec[2];
     bool graph_two_pass[2];
+    hipGraphExec_t pgraph_exec[6];        // the fused (patch) step: plain, with compute_dt, after compute_dt;
+    bool pgraph_two_pass[6];              // x which of the two coordinate buffers is the current one
     int e2_defer;                         // DES_E2_DEFER: 0 one pass, 1 two passes, 2 (default) chosen per call
     bool e2_two_pass;                     // the current choice
     int *mono;                            // [ne] (material << 16) | count of single-material elements, else -1
@@ -186,6 +188,8 @@ struct des_dev {
     double *spin;                         // [3][ne] w3, w4, w5 of a deferred rotate_stress (E1<DEFER> -> next E2)
     bool defer_rot;                       // DES_DEFER_ROT != 0 (default on): fused end-of-step passes defer the rotation
     bool rot_pending, rot_prev_dt;        // the next E2 applies it; with the dt of before the last k_dt_finalize
+    bool elide_ok;                        // DES_E2_ELIDE != 0
+    bool e2_elide;                        // this step is not the last of its call: E2<GEO> skips the output-only stores
     bool e2geo_next;                      // the next E2 does what the skipped end-of-step pass would have done (E2<GEO>)
     d4 *xt_alt;                           // the other buffer of the {x,y,z,T} pair (EN3 writes it, then they swap)
     // stress-bc lists
@@ -292,6 +296,7 @@ void des_dev_destroy(des_dev *h)
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
+    for (hipGraphExec_t g : h->pgraph_exec) if (g) hipGraphExecDestroy(g);
     void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_ln, h->pe_slot, h->ddp, h->xt_alt, h->spin,
         h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
@@ -486,6 +491,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->defer_list, (size_t)ne));
     {
         // deferred rotate_stress (MODE_DEFER, passes/e1.hpp): on by default, DES_DEFER_ROT=0 keeps rotate_stress in E1
+        const char *el = std::getenv("DES_E2_ELIDE");      // =0: every step stores every field
+        h->elide_ok = !(el && el[0] == '0');
         const char *dr = std::getenv("DES_DEFER_ROT");
         h->defer_rot = !(dr && dr[0] == '0');
         if (h->defer_rot) { CK(dev_alloc(h->spin, (size_t)3*ne)); HK(hipMemsetAsync(h->spin, 0, 24*(size_t)ne, h->stream)); }
@@ -864,6 +871,11 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     const bool graphs = h->use_graph && !multi && !iso && !h->prof && !h->p.is_outputting_averaged_fields
                         && !h->patch           // EN3 swaps the two coordinate buffers every step: nothing to replay
                         && !h->p.has_PT;
+    // ... and of the fused step (EN1 .. S3 with E2<GEO>): EN1 and EN3 each swap the two coordinate
+    // buffers, so the steps inside a call all start on the same one (the first step of a call swaps
+    // once, N1 + EN3); three graphs per buffer, because the E2 after a compute_dt step rotates with
+    // the dt of before it and a compute_dt step ends with the reduction
+    const bool pgraphs = h->use_graph && h->patch && !multi && !h->prof && e2geo_ok(h);
     const long long qcsi = h->p.quality_check_step_interval;
     int rc;
     h->n_pt_iterations = 0;
@@ -887,6 +899,30 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
                 h->graph_two_pass[which] = h->e2_two_pass;
             }
             HIP_OK(hipGraphLaunch(h->graph_exec[which], h->stream));
+            continue;
+        }
+        h->e2_elide = h->elide_ok && i < nsteps - 1;
+        if (pgraphs && i > 0 && i < nsteps - 1 && step_no % qcsi != 0 && h->e2geo_next) {
+            const bool do_dt = (step_no % 10 == 0);
+            const int which = 2 * (do_dt ? 1 : (h->rot_prev_dt ? 2 : 0)) + (h->xt < h->xt_alt ? 0 : 1);
+            if (!h->pgraph_exec[which] || h->pgraph_two_pass[which] != h->e2_two_pass) {
+                if (h->pgraph_exec[which]) { hipGraphExecDestroy(h->pgraph_exec[which]); h->pgraph_exec[which] = nullptr; }
+                hipGraph_t g = nullptr;
+                d4 *const xt0 = h->xt;
+                HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+                launch_en1(h); launch_e2(h); if (nmd) launch_n2(h); launch_force_pass(h);
+                launch_s2(h, 1);
+                launch_s3(h, true, true, true);
+                launch_e1_end(h, do_dt ? 10 : 1, true);
+                if (do_dt) launch_dt_finalize(h, nullptr);
+                HIP_OK(hipStreamEndCapture(h->stream, &g));
+                if (h->xt != xt0) { hipGraphDestroy(g); g_last_error = "graph capture: the coordinate buffers did not swap back"; return DES_ERR_INTERNAL; }
+                HIP_OK(hipGraphInstantiate(&h->pgraph_exec[which], g, nullptr, nullptr, 0));
+                hipGraphDestroy(g);
+                h->pgraph_two_pass[which] = h->e2_two_pass;
+            }
+            HIP_OK(hipGraphLaunch(h->pgraph_exec[which], h->stream));
+            h->rot_pending = false; h->e2geo_next = true; h->rot_prev_dt = do_dt;     // as the launches leave them
             continue;
         }
         // inside a multi-step call the step before ended with the fused E1<C | A | NOREC>, and EN1

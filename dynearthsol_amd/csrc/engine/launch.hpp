@@ -75,12 +75,12 @@ void launch_e1(des_dev *h, int part = E1_ALL)
 
 // A fused end-of-step pass may leave rotate_stress to the next stress update when nothing reads the
 // stress in between: rotation on (an elastic part in the rheology), a plain time step (not the
-// isostasy / pseudo-transient loops), no per-step averaging pass, no hipGraph replay (its E2 node is
-// captured once, with or without the pending pointers).
+// isostasy / pseudo-transient loops), no per-step averaging pass, no hipGraph replay of the classic passes (that E2 node
+// is captured once, without the pending pointers; the fused step has graphs of its own, des_dev_step).
 inline bool defer_rot_ok(const des_dev *h)
 {
     return h->defer_rot && h->spin && (h->p.rheol_type & DES_RH_ELASTIC) && !h->iso && !h->p.has_PT
-           && !h->p.is_outputting_averaged_fields && !h->use_graph;
+           && !h->p.is_outputting_averaged_fields && !(h->use_graph && !h->patch);
 }
 
 // Output::average_fields (output.cxx:327-370) on the end-of-step fields, i.e. after the C part
@@ -259,11 +259,12 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     const bool defer = h->e2_two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
-    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr};
+    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1};
     const bool geo = h->e2geo_next;
     if (h->rot_pending || geo) {
         rp.spin = h->spin; rp.topflag = h->topflag; rp.prev_dt = h->rot_prev_dt ? 1 : 0; rp.vm = h->vm;
         rp.ddp = (h->patch && h->p.is_using_mixed_stress && !h->iso) ? h->ddp : nullptr;
+        rp.outputs = (geo && h->e2_elide) ? 0 : 1;
     }
     {
         Launch l(h, geo ? K_E2G : K_E2);

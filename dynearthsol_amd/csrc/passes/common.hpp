@@ -7,6 +7,49 @@
 // =====================================================================================
 struct ElemProps { double bulkm, shearm, phi, cp, k; };
 
+// Element e of plane i of an SoA array [planes][ne], addressed as a UNIFORM plane base (a scalar register
+// pair) + a 32-bit byte offset eo = 8 e that every plane shares: the lane holds one offset register instead
+// of a 64-bit address per plane it loads and later stores (18 planes in the stress update = 36 VGPRs).
+// ne < 2^29 (des_dev_create), so 8 e fits.
+#define DES_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ double pl_ld(const double *__restrict__ a, int i, int ne, unsigned eo)
+{
+    const DES_GLOBAL char *b = (const DES_GLOBAL char *)(a + (size_t)i * ne);
+    asm("" : "+s"(b));                 // the base stays a scalar pair of its own (not folded into a per-lane address chain)
+    return *(const DES_GLOBAL double *)(b + eo);
+}
+// record `id` of a nodal / element array addressed the same way (gathers: uniform base + 32-bit byte
+// offset; nn < 2^27, des_dev_create)
+typedef double des_dv4 __attribute__((ext_vector_type(4)));
+typedef int des_iv4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double rec_ld(const double *__restrict__ a, int id)
+{
+    const DES_GLOBAL char *b = (const DES_GLOBAL char *)a;
+    asm("" : "+s"(b));
+    return *(const DES_GLOBAL double *)(b + (unsigned)id * 8u);
+}
+__device__ __forceinline__ d4 rec_ld(const d4 *__restrict__ a, int id)
+{
+    const DES_GLOBAL char *b = (const DES_GLOBAL char *)a;
+    asm("" : "+s"(b));
+    const des_dv4 v = *(const DES_GLOBAL des_dv4 *)(b + (unsigned)id * 32u);
+    d4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+}
+__device__ __forceinline__ int4 rec_ld(const int4 *__restrict__ a, int id)
+{
+    const DES_GLOBAL char *b = (const DES_GLOBAL char *)a;
+    asm("" : "+s"(b));
+    const des_iv4 v = *(const DES_GLOBAL des_iv4 *)(b + (unsigned)id * 16u);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void pl_st(double *__restrict__ a, int i, int ne, unsigned eo, double v)
+{
+    DES_GLOBAL char *b = (DES_GLOBAL char *)(a + (size_t)i * ne);
+    asm("" : "+s"(b));
+    *(DES_GLOBAL double *)(b + eo) = v;
+}
+
 // What the kernels know about the materials of an element (refresh_elem_cache,
 // matprops.cxx:259-303, redone whenever the marker counts change):
 //   markers [ne][nmat]  the counts themselves

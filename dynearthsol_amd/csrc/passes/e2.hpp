@@ -15,7 +15,7 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 // anything but viscosity[e] when the element needs the Mohr-Coulomb return mapping; the second
 // pass then runs the same code with DEFER = 0 for exactly those elements.
 // what E1<MODE_DEFER> left for this pass to finish (all null / 0: nothing)
-struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; const d4 *vm; };
+struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; const d4 *vm; int outputs; };
 
 // GEO = 1: this pass also does what is left of the end-of-step pass of the step before AND the strain
 // rate of this step, from the nodal records it gathers anyway: compute_volume after the volume swap
@@ -25,7 +25,14 @@ struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int 
 // registers.  No E1 launch between two such steps (engine/launch.hpp: e2geo_ok); the coordinates,
 // velocities and dt it uses are the ones that pass would have seen (nothing but the temperature moves
 // in between, and steps with a compute_dt keep the fused E1).
-template <class M, int DEFER, int GEO>
+// RotPending::outputs = 0 (a step of a call that is not its last one, engine/launch.hpp): what no pass reads
+// before the next E2<GEO> overwrites it -- strain_rate (recomputed from the nodal records every step),
+// viscosity, delta_plstrain, volume_old -- is not stored: 72 of the pass's 192 B of stores per element.
+// The last step of every call stores them all, so what a caller can download is what the reference holds.
+// With GEO the first pass of two (DEFER = 1) stores the strain and the corrected strain-rate diagonal as
+// soon as they are final -- before the constitutive law, whose registers they would otherwise sit next to --
+// also for the elements it sets aside; the return-mapping pass (RM = 1) then leaves the strain alone.
+template <class M, int DEFER, int GEO, int RM = 0>
 __device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
      const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData &md,
@@ -35,25 +42,29 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
      double *__restrict__ dpressure, double *__restrict__ etmp2, const RotPending rp)
 {
     const double dt = clk->dt;
-    const int4 cn = conn[e];
+    const unsigned eo = (unsigned)e * 8u;
+    const int4 cn = rec_ld(conn, e);
     const int rheol = p->rheol_type;
     const desk::Mix mx = mix_of(md, p->nmat, e);
     const ElemProps pr = load_props(p, md, mx, ne, e);
 
     double dj = 0;
-    dj += ntmp[cn.x]; dj += ntmp[cn.y]; dj += ntmp[cn.z]; dj += ntmp[cn.w];
+    dj += rec_ld(ntmp, cn.x); dj += rec_ld(ntmp, cn.y); dj += rec_ld(ntmp, cn.z); dj += rec_ld(ntmp, cn.w);
     const double edvoldt = dj / 4;
 
-    double s[6], es[6], edot[6];
+    const bool outs = !GEO || rp.outputs;
+    constexpr bool ES_EARLY = GEO && DEFER;          // strain / strain-rate diagonal stored before the law
+    constexpr bool ES_DONE = GEO && RM;              // ... by the first pass: not touched here
+    double s[6], es[6] = {0, 0, 0, 0, 0, 0}, edot[6];
     double g_vol = 0, g_vol_old = 0, g_pls = 0, g_T = 0;
     bool g_rescaled = false, g_top = false;
     if (GEO) {
         d4 c[4], v[4];
-        c[0] = xt[cn.x]; c[1] = xt[cn.y]; c[2] = xt[cn.z]; c[3] = xt[cn.w];
-        v[0] = rp.vm[cn.x]; v[1] = rp.vm[cn.y]; v[2] = rp.vm[cn.z]; v[3] = rp.vm[cn.w];
+        c[0] = rec_ld(xt, cn.x); c[1] = rec_ld(xt, cn.y); c[2] = rec_ld(xt, cn.z); c[3] = rec_ld(xt, cn.w);
+        v[0] = rec_ld(rp.vm, cn.x); v[1] = rec_ld(rp.vm, cn.y); v[2] = rec_ld(rp.vm, cn.z); v[3] = rec_ld(rp.vm, cn.w);
         g_T += c[0].w; g_T += c[1].w; g_T += c[2].w; g_T += c[3].w;
         g_T /= 4;
-        const double vol_prev = volume[e];
+        const double vol_prev = pl_ld(volume, 0, ne, eo);
         g_vol = desk::tet_volume(c);
         double rdv = 0.0;
         g_top = rp.topflag[e] != 0;
@@ -67,33 +78,36 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         edot[5] = 0; for (int i = 0; i < 4; ++i) edot[5] += 0.5 * (v[i].y * sz[i] + v[i].z * sy[i]);
         // the shear components are final (only the diagonal is corrected below): out now, not held to the end
         // (the return-mapping pass recomputes and rewrites the same values for the elements set aside)
-        for (int i = 3; i < 6; ++i) strain_rate[(size_t)i*ne + e] = edot[i];
+        if (outs) for (int i = 3; i < 6; ++i) pl_st(strain_rate, i, ne, eo, edot[i]);
         double w3 = 0, w4 = 0, w5 = 0;
         for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
         for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
         for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
+#ifdef DES_E2G_PHASED
+        asm volatile("" ::: "memory");          // the stress / strain loads below are not hoisted over the gathers above
+#endif
         for (int i = 0; i < 6; ++i) {
-            s[i] = stress[(size_t)i*ne + e];
-            es[i] = strain[(size_t)i*ne + e];
+            s[i] = pl_ld(stress, i, ne, eo);
+            if (!ES_DONE) es[i] = pl_ld(strain, i, ne, eo);
         }
-        g_pls = plstrain[e];
+        g_pls = pl_ld(plstrain, 0, ne, eo);
         const double dd = rp.ddp ? rp.ddp[e] : 0.0;
         if (dd != 0.0) for (int i = 0; i < 3; ++i) s[i] += dd;
         if (rdv >= 1.0) {                                                      // bc.cxx:1677
             g_pls /= rdv;
-            for (int i = 0; i < 6; ++i) { s[i] /= rdv; es[i] /= rdv; }
+            for (int i = 0; i < 6; ++i) { s[i] /= rdv; if (!ES_DONE) es[i] /= rdv; }
             g_rescaled = true;
         }
         if (rheol & DES_RH_ELASTIC) {
             const double dtr = rp.prev_dt ? clk->dt_prev : dt;             // the dt of the step being finished
             desk::jaumann_rate_3d(s, dtr, w3, w4, w5);
-            desk::jaumann_rate_3d(es, dtr, w3, w4, w5);
+            if (!ES_DONE) desk::jaumann_rate_3d(es, dtr, w3, w4, w5);
         }
     } else {
     for (int i = 0; i < 6; ++i) {
-        s[i] = stress[(size_t)i*ne + e];
-        es[i] = strain[(size_t)i*ne + e];
-        edot[i] = strain_rate[(size_t)i*ne + e];
+        s[i] = pl_ld(stress, i, ne, eo);
+        es[i] = pl_ld(strain, i, ne, eo);
+        edot[i] = pl_ld(strain_rate, i, ne, eo);
     }
     }
     if (!GEO && rp.spin && !rp.topflag[e]) {
@@ -112,13 +126,17 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         double div = desk::trace3(edot);
         for (int i = 0; i < 3; ++i) edot[i] += (edvoldt - div) / 3;
     }
-    for (int i = 0; i < 6; ++i) es[i] += edot[i] * dt;
+    if (!ES_DONE) for (int i = 0; i < 6; ++i) es[i] += edot[i] * dt;
+    if (ES_EARLY) {
+        for (int i = 0; i < 6; ++i) pl_st(strain, i, ne, eo, es[i]);
+        if (outs) for (int i = 0; i < 3; ++i) pl_st(strain_rate, i, ne, eo, edot[i]);
+    }
     double de[6];
     for (int i = 0; i < 6; ++i) de[i] = edot[i] * dt;
     double dpl = 0.;
     bool defer = false;
-    const double vol = GEO ? g_vol : volume[e];
-    const double vol_old = GEO ? g_vol_old : ((rheol == DES_RH_MAXWELL || rheol == DES_RH_EVP) ? volume_old[e] : 0.0);   // (dies at dv)
+    const double vol = GEO ? g_vol : pl_ld(volume, 0, ne, eo);
+    const double vol_old = GEO ? g_vol_old : ((rheol == DES_RH_MAXWELL || rheol == DES_RH_EVP) ? pl_ld(volume_old, 0, ne, eo) : 0.0);   // (dies at dv)
 
     M::stage_end();
     double visc = 0;
@@ -130,7 +148,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
             T /= 4;
         }
         visc = desk::mat_visc<M>(p, vt, mx, T, s, edot);
-        viscosity[e] = visc;
+        if (outs) pl_st(viscosity, 0, ne, eo, visc);
     }
 
     switch (rheol) {
@@ -147,11 +165,11 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     }
     case DES_RH_EP: {
         double amc, anphi, anpsi, hardn, ten_max;
-        double pls = GEO ? g_pls : plstrain[e];
+        double pls = GEO ? g_pls : pl_ld(plstrain, 0, ne, eo);
         desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s, &defer);
         if (DEFER && defer) return true;
-        if (depls != 0 || g_rescaled) plstrain[e] = pls + depls;       // plstrain += 0 is the identity
+        if (depls != 0 || g_rescaled) pl_st(plstrain, 0, ne, eo, pls + depls);       // plstrain += 0 is the identity
         g_rescaled = false;
         dpl = depls;
         break;
@@ -163,7 +181,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         desk::maxwell(pr.bulkm, pr.shearm, visc, dt, dv, de, sv);
         double svII = desk::second_invariant2(sv);
         double amc, anphi, anpsi, hardn, ten_max;
-        double pls = GEO ? g_pls : plstrain[e];
+        double pls = GEO ? g_pls : pl_ld(plstrain, 0, ne, eo);
         desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
         double sp[6];
         for (int i = 0; i < 6; ++i) sp[i] = s[i];
@@ -174,7 +192,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
             for (int i = 0; i < 6; ++i) s[i] = sv[i];
         } else {
             for (int i = 0; i < 6; ++i) s[i] = sp[i];
-            plstrain[e] = pls + depls;
+            pl_st(plstrain, 0, ne, eo, pls + depls);
             dpl = depls;
             g_rescaled = false;
         }
@@ -183,20 +201,21 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     default: break;
     }
     if (GEO) {
-        if (g_rescaled) plstrain[e] = g_pls;                 // rescaled by correct_surface_element, not changed by the law
-        volume_old[e] = g_top ? vol : volume[e];             // (re-read rather than held in registers through the update)
-        volume[e] = vol;
+        if (g_rescaled) pl_st(plstrain, 0, ne, eo, g_pls);                 // rescaled by correct_surface_element, not changed by the law
+        if (outs) pl_st(volume_old, 0, ne, eo, g_top ? vol : pl_ld(volume, 0, ne, eo));             // (re-read rather than held in registers through the update)
+        pl_st(volume, 0, ne, eo, vol);
     }
-    delta_plstrain[e] = dpl;
+    if (outs) pl_st(delta_plstrain, 0, ne, eo, dpl);
     for (int i = 0; i < 6; ++i) {
-        stress[(size_t)i*ne + e] = s[i];
-        strain[(size_t)i*ne + e] = es[i];
+        pl_st(stress, i, ne, eo, s[i]);
+        if (!ES_EARLY && !ES_DONE) pl_st(strain, i, ne, eo, es[i]);
     }
-    for (int i = 0; i < 3; ++i) strain_rate[(size_t)i*ne + e] = edot[i];   // only the diagonal changed (GEO: all six are new)
+    if (!ES_EARLY && !ES_DONE && outs)
+        for (int i = 0; i < 3; ++i) pl_st(strain_rate, i, ne, eo, edot[i]);   // only the diagonal changed (GEO: all six are new)
     if (p->is_using_mixed_stress) {
         double dp = desk::trace3(s) - old_s;
-        dpressure[e] = dp;
-        etmp2[e] = dp * vol;
+        pl_st(dpressure, 0, ne, eo, dp);
+        pl_st(etmp2, 0, ne, eo, dp * vol);
     }
     return defer;                  // went past the yield pre-filter
 }
@@ -267,6 +286,6 @@ E2_return_mapping(const des_params *__restrict__ p, const desk::ViscTerms *__res
     M::stage_end();
     const int n = *count;
     for (int i = blockIdx.x * DES_BLOCK + threadIdx.x; i < n; i += gridDim.x * DES_BLOCK)
-        e2_element<M, 0, GEO>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+        e2_element<M, 0, GEO, 1>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
                          plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);
 }

@@ -81,6 +81,24 @@ def test_hipgraph_replay_of_interior_steps_gives_the_same_bits(monkeypatch):
         assert_bit_exact(dev, devg)
 
 
+def test_interior_steps_leave_out_output_only_stores_same_bits(monkeypatch):
+    """Inside a multi-step call E2<GEO> does not store strain_rate / viscosity / delta_plstrain / volume_old
+    (nothing reads them before the next launch overwrites them); the last step of every call does.  Every
+    downloadable field must equal the oracle's and the DES_E2_ELIDE=0 engine's after calls of any length,
+    a compute_dt step (10, 20, ...) and a quality-check step (15, 30, ...) being the last or not."""
+    ov = "mesh.quality_check_step_interval = 15\n"
+    host, dev, ora = pair(cfgs.EVP, overrides=ov)
+    monkeypatch.setenv("DES_E2_ELIDE", "0")
+    host2 = des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=ov)
+    dev0 = des.DeviceEngine(host2)
+    dev0.init_from_host(host2)
+    for n in (2, 8, 1, 4, 15, 11, 9):
+        sd, s0, so = dev.step(n), dev0.step(n), ora.step(n)
+        assert (sd.dt, sd.time, sd.steps) == (s0.dt, s0.time, s0.steps) == (so.dt, so.time, so.steps)
+        assert_bit_exact(dev, dev0)
+        assert_bit_exact(dev, ora)                 # STATE holds those four fields
+
+
 def test_step_splitting_is_invisible_on_the_device():
     # E1 fuses the end of step t with the start of step t+1; the API boundary must not show
     host, dev, ora = pair(cfgs.EP)
