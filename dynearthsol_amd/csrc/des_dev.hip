@@ -188,6 +188,8 @@ struct des_dev {
     double *spin;                         // [3][ne] w3, w4, w5 of a deferred rotate_stress (E1<DEFER> -> next E2)
     bool defer_rot;                       // DES_DEFER_ROT != 0 (default on): fused end-of-step passes defer the rotation
     bool rot_pending, rot_prev_dt;        // the next E2 applies it; with the dt of before the last k_dt_finalize
+    double *dt_part;                      // compute_dt partials, [5][dt_part_cap]: one slot per E1<MODE_DT> workgroup
+    int dt_part_cap, dt_parts_used;       // ... slots filled since the last reduction (k_dt_finalize / k_dt_pack)
     bool elide_ok;                        // DES_E2_ELIDE != 0
     bool e2_elide;                        // this step is not the last of its call: E2<GEO> skips the output-only stores
     bool e2geo_next;                      // the next E2 does what the skipped end-of-step pass would have done (E2<GEO>)
@@ -299,7 +301,7 @@ void des_dev_destroy(des_dev *h)
     for (hipGraphExec_t g : h->pgraph_exec) if (g) hipGraphExecDestroy(g);
     void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_ln, h->pe_slot, h->ddp, h->xt_alt, h->spin,
         h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
-        h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->d_n_new2old, h->d_e_new2old,
+        h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->dt_part, h->d_n_new2old, h->d_e_new2old,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->d_esend_idx, h->d_erecv_idx, h->d_send_noff,
         h->d_send_eoff, h->d_recv_noff, h->d_recv_eoff, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
@@ -483,6 +485,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->ymass, (size_t)nn)); CK(dev_alloc(h->force, (size_t)3*nn)); CK(dev_alloc(h->fres, (size_t)3*nn));
     CK(dev_alloc(h->coord0, (size_t)3*nn)); CK(dev_alloc(h->dhacc, (size_t)nn)); CK(dev_alloc(h->dh_n, (size_t)nn));
     CK(dev_alloc(h->d_red, 8));
+    h->dt_part_cap = 2 * (((ne + DES_BLOCK - 1) / DES_BLOCK + 7) / 8 * 8) + 64;
+    CK(dev_alloc(h->dt_part, (size_t)5 * h->dt_part_cap));
     CK(dev_alloc(h->stress, (size_t)6*ne)); CK(dev_alloc(h->strain, (size_t)6*ne)); CK(dev_alloc(h->strain_rate, (size_t)6*ne));
     CK(dev_alloc(h->plstrain, (size_t)ne)); CK(dev_alloc(h->delta_plstrain, (size_t)ne)); CK(dev_alloc(h->viscosity, (size_t)ne));
     CK(dev_alloc(h->volume, (size_t)ne)); CK(dev_alloc(h->volume_old, (size_t)ne)); CK(dev_alloc(h->dpressure, (size_t)ne));
@@ -1199,7 +1203,9 @@ int des_dev_dt_partials(des_dev *h, double out[6], int recompute)
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     if (recompute) { refresh_props(h); launch_e1<MODE_DT>(h); }
-    hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->d_red, h->dt_part, h->dt_part_cap,
+                       h->dt_parts_used);
+    h->dt_parts_used = 0;
     HIP_OK(hipMemcpyAsync(out, h->d_red, 48, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     return DES_OK;

@@ -63,7 +63,9 @@ int exchange_join(des_dev *h)
 int reduce_dt(des_dev *h)
 {
     if (h->comm_size <= 1) { launch_dt_finalize(h, nullptr); return DES_OK; }
-    hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->d_red, h->dt_part, h->dt_part_cap,
+                       h->dt_parts_used);
+    h->dt_parts_used = 0;
     ncclResult_t r = ncclAllReduce(h->d_red, h->d_red, 6, ncclDouble, ncclMin, h->comm, h->stream);
     if (r != ncclSuccess) { g_last_error = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
     launch_dt_finalize(h, h->d_red);

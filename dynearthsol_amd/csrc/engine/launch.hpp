@@ -66,10 +66,17 @@ void launch_e1(des_dev *h, int part = E1_ALL)
     if (part == E1_GHOST_SIDE) { b0 = 0; c0 = h->e_int0; b1 = h->e_int1; c1 = h->ne - h->e_int1; }
     if (c0 + c1 == 0) return;
     Launch l(h, K_E1);
+    // MODE_DT: one slot of compute_dt partials per workgroup, after those of an earlier part of the same pass
+    if ((MODE & MODE_DT) && h->dt_parts_used + nblk8(c0 + c1) > h->dt_part_cap) {
+        hipLaunchKernelGGL(k_dt_fold, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->dt_part, h->dt_part_cap, h->dt_parts_used);
+        h->dt_parts_used = 0;
+    }
+    const int dt_base = h->dt_parts_used;
+    if (MODE & MODE_DT) h->dt_parts_used += nblk8(c0 + c1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(c0 + c1)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, h->ne, nblk(c0 + c1), b0, c0, b1, c1, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
                        h->topflag, h->stress, h->patch ? h->ddp : nullptr, h->strain, h->plstrain, h->volume, h->volume_old,
-                       h->strain_rate, h->mrec, h->ttmp, h->spin);
+                       h->strain_rate, h->mrec, h->ttmp, h->spin, h->dt_part, h->dt_part_cap, dt_base);
     if (MODE & MODE_DEFER) { h->rot_pending = true; h->rot_prev_dt = (MODE & MODE_DT) != 0; }
 }
 
@@ -212,7 +219,10 @@ void launch_dt_finalize(des_dev *h, const double *red)
 {
     if (exp_skip("dt")) return;
     Launch l(h, K_DTFIN);
-    hipLaunchKernelGGL(k_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk, red);
+    // (after the cross-rank reduction k_dt_pack has already folded the partials in: dt_parts_used is 0 then)
+    hipLaunchKernelGGL(k_dt_finalize, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, red, h->dt_part, h->dt_part_cap,
+                       h->dt_parts_used);
+    h->dt_parts_used = 0;
 }
 
 inline bool surface_diffusion_on(const des_dev *h)

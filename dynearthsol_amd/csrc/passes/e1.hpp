@@ -52,7 +52,8 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
      const double *__restrict__ radiogenic, const unsigned char *__restrict__ topflag,
      double *__restrict__ stress, const double *__restrict__ ddp, double *__restrict__ strain, double *__restrict__ plstrain,
      double *__restrict__ volume, double *__restrict__ volume_old,
-     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp, double *__restrict__ spin)
+     double *__restrict__ strain_rate, d4 *__restrict__ mrec, d4 *__restrict__ ttmp, double *__restrict__ spin,
+     double *__restrict__ dt_part, int dt_cap, int dt_base)
 {
     // this launch covers the elements [b0, b0 + c0) and [b1, b1 + c1) (the whole mesh: 0, ne, 0, 0;
     // the overlapped multi-GPU schedule runs the interior elements while the ghost region is
@@ -205,18 +206,48 @@ E1_geom_rotate_strainrate(const des_params *__restrict__ p, DevClock *__restrict
                 red[2][0] = fmin(red[2][0], red[2][i]); red[3][0] = fmin(red[3][0], red[3][i]);
                 red[4][0] = fmax(red[4][0], red[4][i]);
             }
-            desk::atomic_min_double(&clk->r_minl, red[0][0]);
-            desk::atomic_min_double(&clk->r_dt_maxwell, red[1][0]);
-            desk::atomic_min_double(&clk->r_dt_diffusion, red[2][0]);
-            desk::atomic_min_double(&clk->r_global_dt_min, red[3][0]);
-            desk::atomic_max_double(&clk->r_max_vem, sqrt(red[4][0]));
+            // one slot per workgroup, reduced by the next k_dt_finalize / k_dt_pack (dt_reduce_partials): thousands
+            // of atomics on the five words of one cache line took longer than the pass itself
+            double *q = dt_part + dt_base + blockIdx.x;
+            q[0] = red[0][0]; q[dt_cap] = red[1][0]; q[2 * (size_t)dt_cap] = red[2][0]; q[3 * (size_t)dt_cap] = red[3][0];
+            q[4 * (size_t)dt_cap] = sqrt(red[4][0]);
         }
     }
 }
 
-// compute_dt tail (geometry.cxx:1597-1646); one thread
-__global__ void k_dt_finalize(const des_params *p, DevClock *clk, const double *red)
+// the per-workgroup compute_dt partials of the E1<MODE_DT> launches since the last reduction -> clk->r_*
+// (min / max are order-independent); one workgroup of DES_BLOCK lanes, ends with a barrier
+__device__ void dt_reduce_partials(DevClock *clk, const double *__restrict__ dt_part, int dt_cap, int count)
 {
+    __shared__ double red[5][DES_BLOCK / 64];
+    if (count <= 0) return;                      // (uniform)
+    double r[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, 0.0};
+    for (int i = threadIdx.x; i < count; i += DES_BLOCK) {
+        for (int k = 0; k < 4; ++k) r[k] = fmin(r[k], dt_part[(size_t)k * dt_cap + i]);
+        r[4] = fmax(r[4], dt_part[(size_t)4 * dt_cap + i]);
+    }
+    for (int k = 0; k < 4; ++k) r[k] = desk::wave_min(r[k]);
+    r[4] = desk::wave_max(r[4]);
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 5; ++k) red[k][threadIdx.x >> 6] = r[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < DES_BLOCK / 64; ++i) {
+            for (int k = 0; k < 4; ++k) red[k][0] = fmin(red[k][0], red[k][i]);
+            red[4][0] = fmax(red[4][0], red[4][i]);
+        }
+        clk->r_minl = fmin(clk->r_minl, red[0][0]); clk->r_dt_maxwell = fmin(clk->r_dt_maxwell, red[1][0]);
+        clk->r_dt_diffusion = fmin(clk->r_dt_diffusion, red[2][0]); clk->r_global_dt_min = fmin(clk->r_global_dt_min, red[3][0]);
+        clk->r_max_vem = fmax(clk->r_max_vem, red[4][0]);
+    }
+    __syncthreads();
+}
+
+// compute_dt tail (geometry.cxx:1597-1646); one workgroup: the reduction of the partials, then one thread
+__global__ void __launch_bounds__(DES_BLOCK)
+k_dt_finalize(const des_params *p, DevClock *clk, const double *red, const double *__restrict__ dt_part, int dt_cap, int dt_count)
+{
+    dt_reduce_partials(clk, dt_part, dt_cap, dt_count);
+    if (threadIdx.x != 0) return;
     if (red) {          // partials min-reduced over the ranks (k_dt_pack layout)
         clk->r_minl = red[0]; clk->r_dt_maxwell = red[1]; clk->r_dt_diffusion = red[2];
         clk->r_global_dt_min = red[3]; clk->r_max_vem = -red[4]; clk->max_surf_vel = -red[5];

@@ -55,8 +55,18 @@ k_state_unpack(int nnodes, const int *__restrict__ nidx, const int *__restrict__
 }
 
 // compute_dt partials of this rank, all arranged for a MIN reduction across ranks
-__global__ void k_dt_pack(const DevClock *clk, double *red)
+// (the partial slots are about to run out: fold what is there into clk->r_*)
+__global__ void __launch_bounds__(DES_BLOCK)
+k_dt_fold(DevClock *clk, const double *__restrict__ dt_part, int dt_cap, int dt_count)
 {
+    dt_reduce_partials(clk, dt_part, dt_cap, dt_count);
+}
+
+__global__ void __launch_bounds__(DES_BLOCK)
+k_dt_pack(DevClock *clk, double *red, const double *__restrict__ dt_part, int dt_cap, int dt_count)
+{
+    dt_reduce_partials(clk, dt_part, dt_cap, dt_count);
+    if (threadIdx.x != 0) return;
     red[0] = clk->r_minl; red[1] = clk->r_dt_maxwell; red[2] = clk->r_dt_diffusion;
     red[3] = clk->r_global_dt_min; red[4] = -clk->r_max_vem; red[5] = -clk->max_surf_vel;
 }
