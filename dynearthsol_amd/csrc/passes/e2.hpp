@@ -282,9 +282,10 @@ E2_return_mapping(const des_params *__restrict__ p, const desk::ViscTerms *__res
      double *__restrict__ dpressure, double *__restrict__ etmp2, const int *__restrict__ list, const int *__restrict__ count,
      const RotPending rp)
 {
+    const int n = *count;
+    if (n == 0) return;                 // (uniform) nothing was set aside: not even the libm tables are staged
     M::stage_begin();
     M::stage_end();
-    const int n = *count;
     for (int i = blockIdx.x * DES_BLOCK + threadIdx.x; i < n; i += gridDim.x * DES_BLOCK)
         e2_element<M, 0, GEO, 1>(list[i], p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
                          plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);

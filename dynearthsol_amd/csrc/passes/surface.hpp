@@ -8,6 +8,9 @@
 // facet's local node) are recomputed by every node that touches the facet -- ~6x redundant
 // work on O(surface) data, in exchange for one launch and no facet temporaries; the values are
 // the same deterministic expressions, so the sums are bit-identical.
+#ifndef DES_S2_BATCH
+#define DES_S2_BATCH 4
+#endif
 __global__ void __launch_bounds__(DES_BLOCK)
 k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int diffuse,
      const int *__restrict__ top_nodes, const int *__restrict__ ssup_idx, const int *__restrict__ ssup_nodes,
@@ -20,25 +23,25 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
     if (n >= 0) {                               // every local surface node; [o0, o1) = the owned ones
         if (diffuse) {
             double total_dx = 0., total_slope = 0.;
-            // facets in batches of four: all facet ids, then all node ids, then all node records are
+            // facets in batches of DES_S2_BATCH = 4 (8: more registers, no faster): all facet ids, then all node ids, then all node records are
             // requested before the first is used, so a batch costs three memory latencies instead
             // of three per facet; the sums below still run in list order
             const int jb = ssup_idx[i], je = ssup_idx[i+1];
-            for (int j0 = jb; j0 < je; j0 += 4) {
-                int kf[4], nd[4][3];
-                d4 cf[4][3];
+            for (int j0 = jb; j0 < je; j0 += DES_S2_BATCH) {
+                int kf[DES_S2_BATCH], nd[DES_S2_BATCH][3];
+                d4 cf[DES_S2_BATCH][3];
                 // ssup_nodes[3k + m] = conn_surf[m*etop + ssup_arr[k]], flattened once at create
                 // (one dependent look-up less on this latency-bound kernel)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kf[u] = (j0 + u < je) ? 0 : -1;
+                for (int u = 0; u < DES_S2_BATCH; ++u) kf[u] = (j0 + u < je) ? 0 : -1;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < DES_S2_BATCH; ++u)
                     for (int m = 0; m < 3; ++m) nd[u][m] = (kf[u] >= 0) ? ssup_nodes[3 * (size_t)(j0 + u) + m] : n;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < DES_S2_BATCH; ++u)
                     for (int m = 0; m < 3; ++m) cf[u][m] = xt_in[nd[u][m]];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < DES_S2_BATCH; ++u) {
                     if (kf[u] < 0) continue;
                     const d4 *c = cf[u];
                     double x01 = c[1].x - c[0].x, y01 = c[1].y - c[0].y;
