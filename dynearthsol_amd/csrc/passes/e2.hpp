@@ -83,9 +83,6 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         for (int i = 0; i < 4; ++i) w3 += 0.5 * (v[i].x * sy[i] - v[i].y * sx[i]);
         for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
         for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
-#ifdef DES_E2G_PHASED
-        asm volatile("" ::: "memory");          // the stress / strain loads below are not hoisted over the gathers above
-#endif
         for (int i = 0; i < 6; ++i) {
             s[i] = pl_ld(stress, i, ne, eo);
             if (!ES_DONE) es[i] = pl_ld(strain, i, ne, eo);
