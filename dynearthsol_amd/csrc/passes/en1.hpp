@@ -17,6 +17,9 @@
 // en1_ok): inside a multi-step call.  The new temperatures go to the other buffer of the
 // {x,y,z,T} pair (another block may still be reading this block's nodes); the host swaps.
 
+#ifndef DES_EN1_NB
+#define DES_EN1_NB 8              // incidences per batch of LDS requests in the node phase
+#endif
 #ifndef DES_PATCH_PE
 #define DES_PATCH_PE 1280         // elements of a patch (LDS records)
 #endif
@@ -56,12 +59,10 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     const bool has_node = (int)threadIdx.x < nown;
     int r0 = 0, r1 = 0;
     unsigned flag = 0;
-    d4 m4 = {0, 0, 0, 0};
     if (has_node) {
         const int kb = sup_idx[n0];
         r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
         flag = bcflag[n];
-        m4 = vm[n];
     }
     // the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
@@ -112,7 +113,34 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
     const double rho_m = p->bulk_modulus[0] / (pseudo_speed * pseudo_speed);
     double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0;
-    for (int k = r0; k < r1; ++k) {
+    // DES_EN1_NB incidences at a time: their indices, then every term they point at, are requested from LDS
+    // before the first is used (one lane walks its list alone; a dependent look-up per incidence made this
+    // phase a third of the workgroup's life); the sums themselves stay in list order
+    constexpr int NB = DES_EN1_NB;
+    int k = r0;
+    for (; k + NB <= r1; k += NB) {
+        int q[NB];
+        double vol[NB], mq[NB], tq[NB], td[NB], dv[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) q[u] = lidx[k + u];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            vol[u] = lvol[q[u]];
+            mq[u] = CONSTM ? 0.0 : lm[q[u]];
+            tq[u] = thermal ? ltm[q[u]] : 0.0;
+            td[u] = thermal ? ltd[k + u] : 0.0;
+            dv[u] = ldv[q[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            vn += vol[u];
+            if (CONSTM) ms += rho_m * vol[u] / 4;
+            else        ms += mq[u];
+            if (thermal) { tms += tq[u]; tdot += td[u]; }
+            acc += dv[u];
+        }
+    }
+    for (; k < r1; ++k) {
         const int q = lidx[k];
         const double vol = lvol[q];
         vn += vol;
@@ -123,7 +151,8 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     }
     volume_n[n] = vn;
     tmass[n] = tms;
-    m4.w = ms;
+    d4 m4;                                                   // the velocity is the staged one (own node: local id = lane)
+    m4.x = lvx[threadIdx.x]; m4.y = lvy[threadIdx.x]; m4.z = lvz[threadIdx.x]; m4.w = ms;
     vm[n] = m4;
     d4 x4 = lxt[threadIdx.x];
     if (thermal) {

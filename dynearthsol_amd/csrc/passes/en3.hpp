@@ -69,9 +69,10 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     auto load_elem = [&](int i, Elem &E) {
         E.ew = pe_elem[i]; E.ln = pe_ln[i]; E.sl = pe_slot[i];
         const int e = E.ew & 0x3fffffff;
-        for (int k = 0; k < 6; ++k) E.s[k] = stress[(size_t)k*ne + e];
-        E.vol = volume[e];
-        E.dpo = nmd ? dpressure[e] : 0.0;
+        const unsigned eo = (unsigned)e * 8u;               // scalar plane base + one 32-bit offset (passes/common.hpp)
+        for (int k = 0; k < 6; ++k) E.s[k] = pl_ld(stress, k, ne, eo);
+        E.vol = pl_ld(volume, 0, ne, eo);
+        E.dpo = nmd ? pl_ld(dpressure, 0, ne, eo) : 0.0;
         E.mono = gravity != 0 ? md.mono[e] : 0;
     };
     // (a) this lane's first patch element: list entry, then stress / volume / dpressure (holding a
@@ -149,7 +150,16 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     double l2 = 0.0;
     if (has_node) {
         double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
-        for (int k = r0; k < r1; ++k) {
+        int k = r0;
+        for (; k + 4 <= r1; k += 4) {                       // four slots requested from LDS before the first is used
+            double t[3][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { t[0][u] = lf[0][k + u]; t[1][u] = lf[1][k + u]; t[2][u] = lf[2][k + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { f[0] -= t[0][u]; f[1] -= t[1][u]; f[2] -= t[2][u]; }
+            fr[0] = t[0][3]; fr[1] = t[1][3]; fr[2] = t[2][3];
+        }
+        for (; k < r1; ++k) {
             const double t0v = lf[0][k], t1v = lf[1][k], t2v = lf[2][k];
             f[0] -= t0v; f[1] -= t1v; f[2] -= t2v;
             fr[0] = t0v; fr[1] = t1v; fr[2] = t2v;          // assignment: fields.cxx:673
