@@ -151,7 +151,15 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     if (has_node) {
         double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
         int k = r0;
-        for (; k + 4 <= r1; k += 4) {                       // four slots requested from LDS before the first is used
+        for (; k + 8 <= r1; k += 8) {                       // eight slots requested from LDS before the first is used
+            double t[3][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t[0][u] = lf[0][k + u]; t[1][u] = lf[1][k + u]; t[2][u] = lf[2][k + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { f[0] -= t[0][u]; f[1] -= t[1][u]; f[2] -= t[2][u]; }
+            fr[0] = t[0][7]; fr[1] = t[1][7]; fr[2] = t[2][7];
+        }
+        for (; k + 4 <= r1; k += 4) {
             double t[3][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { t[0][u] = lf[0][k + u]; t[1][u] = lf[1][k + u]; t[2][u] = lf[2][k + u]; }
