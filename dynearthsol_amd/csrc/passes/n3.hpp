@@ -136,20 +136,35 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
     double l2 = 0.0;
     const double dt = clk->dt;
     if (flag & bc_mask) {
+        // the node's facet terms: first the ones apply_stress_bcs subtracts, then the elastic-foundation term,
+        // then (entries with bit 0 set) the ones apply_stress_bcs_neumann adds -- in list order.  Four entries
+        // at a time, every entry and every term of a batch requested before the first is used: a boundary
+        // node's lane walks its list alone, two dependent look-ups per entry
         const int b0 = bcn_idx[n], b1 = bcn_idx[n+1];
-        int b = b0;
-        for (; b < b1; ++b) {
-            const int ent = bcn_ent[b];
-            if (ent & 1) break;
-            const double *t = bcf_tmp + (size_t)(ent >> 1) * 3;
-            f[0] -= t[0]; f[1] -= t[1]; f[2] -= t[2];
+        bool plus = false;
+        auto foundation = [&]() {
+            if (p->has_elastic_foundation && (flag & (1u << 4)))
+                f[2] -= p->elastic_foundation_constant * (x4.z - coord0[(size_t)2*nn + n]);
+        };
+        for (int b = b0; b < b1; b += 4) {
+            int ent[4];
+            double t[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ent[u] = (b + u < b1) ? bcn_ent[b + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double *q = bcf_tmp + (size_t)(ent[u] >> 1) * 3;       // (entry 0 for the padding: a valid row)
+                t[u][0] = q[0]; t[u][1] = q[1]; t[u][2] = q[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (b + u >= b1) break;
+                if (!plus && (ent[u] & 1)) { plus = true; foundation(); }
+                if (plus) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
+                else      { f[0] -= t[u][0]; f[1] -= t[u][1]; f[2] -= t[u][2]; }
+            }
         }
-        if (p->has_elastic_foundation && (flag & (1u << 4)))
-            f[2] -= p->elastic_foundation_constant * (x4.z - coord0[(size_t)2*nn + n]);
-        for (; b < b1; ++b) {
-            const double *t = bcf_tmp + (size_t)(bcn_ent[b] >> 1) * 3;
-            f[0] += t[0]; f[1] += t[1]; f[2] += t[2];
-        }
+        if (!plus) foundation();
     }
     double v[3] = {m4.x, m4.y, m4.z};
     const double small_vel = 1e-13;
