@@ -85,12 +85,10 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     const bool has_node = (int)threadIdx.x < nown;
     int r0 = 0, r1 = 0;
     unsigned flag = 0;
-    d4 m4 = {0, 0, 0, 0};
     if (has_node) {
         const int kb = sup_idx[n0];
         r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
         flag = bcflag[n];
-        m4 = vm[n];
     }
     // (c) the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
@@ -149,6 +147,9 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     // the block's nodes: force sums in CSR order, then the rest of the nodal update
     double l2 = 0.0;
     if (has_node) {
+        // {vx,vy,vz,mass}: requested here, behind the force sums, not ahead of the element phase -- held across it
+        // the record went to scratch (at 80 VGPRs), 24 MB of stores per launch for 2901 workgroups
+        const d4 m4 = vm[n];
         double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
         int k = r0;
         for (; k + 8 <= r1; k += 8) {                       // eight slots requested from LDS before the first is used
