@@ -39,7 +39,10 @@ def child(a):
         done += a.steps
         sc = dev.step(0)
         out["points"].append({"step": done, "yielding_fraction": frac, "n_defer_fraction": sc.n_return_mapping / host.nelem,
-                              "E2_us": 1e3 * prof.get("E2_update_stress", 0), "E2R_us": 1e3 * prof.get("E2_return_mapping", 0),
+                              # (inside a multi-step call the first pass is E2<GEO>, profile name E2G_...; the
+                              #  plain E2 only runs in the first step of the call)
+                              "E2_us": 1e3 * prof.get("E2G_geom_rotate_update_stress", prof.get("E2_update_stress", 0)),
+                              "E2R_us": 1e3 * prof.get("E2_return_mapping", 0),
                               "checksum": float(np.abs(dev.download("STRESS")).sum())})
     print(json.dumps(out))
 
@@ -48,7 +51,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--res", type=float, default=800.0)
     ap.add_argument("--march", type=int, nargs="+", default=[5, 12, 20, 35, 60, 120])
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--rheology", default="elasto-plastic")
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
