@@ -291,10 +291,15 @@ __device__ __forceinline__ void dsyevc3(const double *a, double w[3])
 
 // 3x3-C/dsytrd3.c:379-455 + dsyevq3.c:245-350: Householder tridiagonalisation, then QL
 // with implicit shifts.  Q columns are returned in q[r][col].  Rarely taken (degenerate
-// or near-degenerate tensors), so it is kept out of line.
-__device__ __noinline__ int dsyevq3(const double *a, double Q[3][3], double w[3])
+// or near-degenerate tensors), so it is kept out of line -- and takes / returns everything BY VALUE:
+// with pointer arguments the caller's eigenvector matrix had to live in memory, and the Mohr-Coulomb
+// return (which calls this once in a blue moon) kept it in scratch for every element it handles
+// (~40 scratch accesses of 16 B per call).  The run-time indexed copies below are this function's own.
+struct Eig3 { double q[3][3]; double w[3]; int rc; };
+__device__ __noinline__ Eig3 dsyevq3_core(double A00, double A11, double A22, double A01, double A02, double A12)
 {
-    const double A00 = a[0], A11 = a[1], A22 = a[2], A01 = a[3], A02 = a[4], A12 = a[5];
+    Eig3 R;
+    double *w = R.w;
     double e0, e1, e2 = 0;
     double Q11 = 1, Q12 = 0, Q21 = 0, Q22 = 1;     // Q00 = 1, Q01 = Q02 = Q10 = Q20 = 0
     {
@@ -344,7 +349,7 @@ __device__ __noinline__ int dsyevq3(const double *a, double Q[3][3], double w[3]
                 if (fabs(e[m]) + g == g) break;
             }
             if (m == l) break;
-            if (nIter++ >= 30) return -1;
+            if (nIter++ >= 30) { R.rc = -1; return R; }
 
             g = (w[l+1] - w[l]) / (e[l] + e[l]);
             r = sqrt(sqr(g) + 1.0);
@@ -379,7 +384,18 @@ __device__ __noinline__ int dsyevq3(const double *a, double Q[3][3], double w[3]
             e[m]  = 0.0;
         }
     }
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Q[i][j] = q[i][j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R.q[i][j] = q[i][j];
+    R.rc = 0;
+    return R;
+}
+__device__ __forceinline__ int dsyevq3(const double *a, double Q[3][3], double w[3])
+{
+    const Eig3 R = dsyevq3_core(a[0], a[1], a[2], a[3], a[4], a[5]);
+    w[0] = R.w[0]; w[1] = R.w[1]; w[2] = R.w[2];           // (the QL sweep works on w in place, converged or not)
+    if (R.rc != 0) return R.rc;                          // no convergence: Q is not written (dsyevq3.c:283)
+    Q[0][0] = R.q[0][0]; Q[0][1] = R.q[0][1]; Q[0][2] = R.q[0][2];
+    Q[1][0] = R.q[1][0]; Q[1][1] = R.q[1][1]; Q[1][2] = R.q[1][2];
+    Q[2][0] = R.q[2][0]; Q[2][1] = R.q[2][1]; Q[2][2] = R.q[2][2];
     return 0;
 }
 

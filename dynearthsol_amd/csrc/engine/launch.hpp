@@ -248,13 +248,13 @@ void launch_n1(des_dev *h)
 // update_stress in two passes when the rheology has a yield surface: the first pass (3 waves
 // per SIMD) sets the few elements that need the return mapping aside, the second one (the same
 // code with the return mapping, 2 waves per SIMD) works that list off.  The list is sparse, so
-// the second pass pays ~8x per element; above DES_E2_DEFER_MAX of the mesh one pass is cheaper.
+// the second pass pays ~6x per element; above DES_E2_DEFER_MAX of the mesh one pass is cheaper.
 // Both give the same bits.  DES_E2_DEFER=0 / 1 pins the mode; default: choose_e2_mode().
 #ifndef DES_E2R_GRID
 #define DES_E2R_GRID 512          // workgroups of the second pass (grid-stride loop): two per CU, all resident
 #endif
 #ifndef DES_E2_DEFER_MAX
-#define DES_E2_DEFER_MAX 0.02
+#define DES_E2_DEFER_MAX 0.01      // (1.6M tets, ep: two passes 119 / 134 / 152 us at 0 / 2.5 / 10 % set aside, one pass ~121 / 127 / 138)
 #endif
 // called whenever the host copy of the clock is fresh (end of des_dev_step / des_dev_phase calls)
 void choose_e2_mode(des_dev *h)
