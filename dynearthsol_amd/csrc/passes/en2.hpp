@@ -41,6 +41,17 @@ EN2_nmd_gather(int nn, int nblocks, int npb, const int *__restrict__ pe_ptr, con
     __syncthreads();
     if (!has_node) return;
     double acc = 0;
-    for (int k = r0; k < r1; ++k) acc += lv[lidx[k]];
+    int k = r0;
+    for (; k + 8 <= r1; k += 8) {                           // eight indices, then eight terms, then the sums in list order
+        int q[8];
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = lidx[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = lv[q[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; k < r1; ++k) acc += lv[lidx[k]];
     ntmp[n] = acc / vn;
 }
