@@ -21,6 +21,8 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
     double d = 0.;
     const int n = (i < ntop) ? top_nodes[i] : -1;
     if (n >= 0) {                               // every local surface node; [o0, o1) = the owned ones
+        // (requested with the first batch of facets, not behind the last one)
+        const double z_old = xt_in[n].z, dhacc_old = dhacc[n];
         if (diffuse) {
             double total_dx = 0., total_slope = 0.;
             // facets in batches of DES_S2_BATCH = 4 (8: more registers, no faster): all facet ids, then all node ids, then all node records are
@@ -74,8 +76,8 @@ k_s2(const des_params *__restrict__ p, DevClock *__restrict__ clk, int ntop, int
         dh[i] = d;
         // neighbours still need this node's OLD height: the new one goes to a side buffer and
         // is committed by the next launch (k_s3_finalize)
-        znew[i] = xt_in[n].z + d;
-        dhacc[n] += d;
+        znew[i] = z_old + d;
+        dhacc[n] = dhacc_old + d;
         dh_n[n] = d;
     }
     // max |dh| (bc.cxx:1811-1821); max is order-independent
