@@ -18,6 +18,20 @@ __device__ __forceinline__ double pl_ld(const double *__restrict__ a, int i, int
     asm("" : "+s"(b));                 // the base stays a scalar pair of its own (not folded into a per-lane address chain)
     return *(const DES_GLOBAL double *)(b + eo);
 }
+// the same, non-temporal: planes that are read once and written once per step (nothing reads them again before
+// ~0.6 GB of other traffic has passed) should not evict what the next pass is about to read
+__device__ __forceinline__ double pl_ld_nt(const double *__restrict__ a, int i, int ne, unsigned eo)
+{
+    const DES_GLOBAL char *b = (const DES_GLOBAL char *)(a + (size_t)i * ne);
+    asm("" : "+s"(b));
+    return __builtin_nontemporal_load((const DES_GLOBAL double *)(b + eo));
+}
+__device__ __forceinline__ void pl_st_nt(double *__restrict__ a, int i, int ne, unsigned eo, double v)
+{
+    DES_GLOBAL char *b = (DES_GLOBAL char *)(a + (size_t)i * ne);
+    asm("" : "+s"(b));
+    __builtin_nontemporal_store(v, (DES_GLOBAL double *)(b + eo));
+}
 // record `id` of a nodal / element array addressed the same way (gathers: uniform base + 32-bit byte
 // offset; nn < 2^27, des_dev_create)
 typedef double des_dv4 __attribute__((ext_vector_type(4)));
