@@ -232,6 +232,7 @@ struct des_dev {
     std::vector<int> n_new2old, n_old2new, e_new2old, e_old2new;
     int *d_n_new2old, *d_e_new2old;
     bool markers_dirty;
+    bool radiogenic_zero;                 // every heat source is +0.0 (the default): EN1 does not fetch them
     bool const_mass;                      // quasi-static, one material: nodal mass from volumes alone
     bool pending_c;                       // C part of the last step has been run (always true outside step())
     long long steps_host;
@@ -380,6 +381,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     }
     const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
     h->markers_dirty = true;
+    h->radiogenic_zero = true;            // (the array starts zeroed; des_dev_upload looks at what it is given)
     h->pending_c = true;
     h->const_mass = params->is_quasi_static && params->nmat == 1;
     h->o0 = 0; h->o1 = nn; h->nn_global = nn; h->nnbr = 0; h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
@@ -741,6 +743,13 @@ int des_dev_upload(des_dev *h, int field, const void *host, long long count)
     }
     double *dst = plain_field(h, field);
     if (!dst) return DES_ERR_INTERNAL;
+    if (field == DES_F_RADIOGENIC) {
+        // +0.0 everywhere (bit pattern 0): 0.0 * vol * rho / 4 is formed without the 8 B per listed patch element
+        const unsigned long long *u = (const unsigned long long *)host;
+        bool z = true;
+        for (long long i = 0; i < count && z; ++i) z = u[i] == 0ull;
+        h->radiogenic_zero = z;
+    }
     const int space = field_space(field);
     if (space == 0 || h->n_new2old.empty()) return dev_upload(dst, (const double *)host, (size_t)count, h->stream);
     const size_t n = space == 1 ? (size_t)h->nn : (size_t)h->ne;

@@ -370,7 +370,8 @@ void launch_en1(des_dev *h)
 #undef DES_EN1_PICK
         hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, h->patch_nb,
                            h->patch_npb, h->pe_ptr, h->pe_elem, h->pe_ln, h->pe_slot, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
-                           mat_data(h), h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n, h->tmass, h->ntmp);
+                           mat_data(h), h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n,
+                           h->tmass, h->ntmp);
     }
     std::swap(h->xt, h->xt_alt);               // EN1 wrote the records with the new temperatures there
 }

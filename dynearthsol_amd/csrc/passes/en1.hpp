@@ -96,7 +96,8 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         double sx[4], sy[4], sz[4];
         desk::shape_fn(c, vol, sx, sy, sz);
         double tr[4] = {0, 0, 0, 0};
-        if (thermal) e1_thermal_terms(c, sx, sy, sz, pr.k, vol, radiogenic[e], rho, tr);
+        // (radiogenic == nullptr: every heat source is +0.0, engine/launch.hpp -- the same arithmetic without the fetch)
+        if (thermal) e1_thermal_terms(c, sx, sy, sz, pr.k, vol, radiogenic ? radiogenic[e] : 0.0, rho, tr);
         double s0, s1, s2;
         e1_strain_rate_diag(v, sx, sy, sz, s0, s1, s2);
         double dj = s0 + s1 + s2;
