@@ -341,9 +341,10 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     if (des_dev_device_count() <= device) { *err = DES_ERR_UNSUPPORTED; g_last_error = "no such HIP device"; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { *err = DES_ERR_UNSUPPORTED; g_last_error = "hipSetDevice failed"; return nullptr; }
 
-    if (mesh->nelem < 1 || mesh->nnode < 4 || mesh->nelem >= (1 << 29)) {
-        // incidences are packed as elem*4 + local node in 32 bits (and 4*nelem indexes the CSR arrays)
-        *err = DES_ERR_RESOURCE; g_last_error = "mesh size outside 1 <= nelem < 2^29"; return nullptr;
+    if (mesh->nelem < 1 || mesh->nnode < 4 || mesh->nelem >= (1 << 29) || mesh->nnode >= (1 << 27)) {
+        // incidences are packed as elem*4 + local node in 32 bits (and 4*nelem indexes the CSR arrays); the stress
+        // update addresses planes and 32-byte nodal records by 32-bit byte offsets (passes/common.hpp: pl_ld, rec_ld)
+        *err = DES_ERR_RESOURCE; g_last_error = "mesh size outside 1 <= nelem < 2^29, nnode < 2^27"; return nullptr;
     }
     des_dev *h = new des_dev();       // value-initialised: every pointer/scalar member starts at 0
     h->device = device;
