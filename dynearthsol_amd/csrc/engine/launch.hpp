@@ -357,7 +357,7 @@ void launch_en1(des_dev *h)
 {
     {
         Launch l(h, K_EN1);
-        void (*k)(const des_params *, DevClock *, int, int, int, int, const int *, const int *, const ushort4 *, const short4 *,
+        void (*k)(const des_params *, DevClock *, int, int, int, int, const int *, const ulonglong2 *,
                   const int *, const int *, const int *, const unsigned *, const MatData, const double *, const d4 *, d4 *, d4 *,
                   double *, double *, double *);
         const bool cm = h->const_mass;
@@ -369,7 +369,7 @@ void launch_en1(des_dev *h)
         else     k = T == 512 ? DES_EN1_PICK(512, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE) : DES_EN1_PICK(256, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE);
 #undef DES_EN1_PICK
         hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, h->patch_nb,
-                           h->patch_npb, h->pe_ptr, h->pe_elem, h->pe_ln, h->pe_slot, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
+                           h->patch_npb, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
                            mat_data(h), h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n,
                            h->tmass, h->ntmp);
     }
@@ -384,8 +384,7 @@ void launch_en3(des_dev *h)
     {
         Launch l(h, K_EN3);
         // the smallest LDS shape that holds this mesh's largest block -> most workgroups per CU
-        void (*k)(const des_params *, const DevClock *, int, int, int, int, int, int, int, int, const int *, const int *, const ushort4 *,
-                  const short4 *, const int *, const int *, const int *, const unsigned *, const double *, const MatData, const double *,
+        void (*k)(const des_params *, const DevClock *, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *, const int *, const int *, const int *, const unsigned *, const double *, const MatData, const double *,
                   const double *, const double *, double *, unsigned, const int *, const int *, const double *, const double *, const double *,
                   const double *, const double *, const int *, const d4 *, d4 *, d4 *, double *, double *, double *);
         const int T = h->patch_threads;
@@ -394,7 +393,7 @@ void launch_en3(des_dev *h)
         else k = T == 512 ? EN3_force_nodes<512, DES_PATCH_INC, DES_PATCH_PN> : EN3_force_nodes<256, DES_PATCH_INC, DES_PATCH_PN>;
         hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk,
                            (int)(h->p.is_using_mixed_stress && !h->iso), h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb,
-                           h->pe_ptr, h->pe_elem, h->pe_ln, h->pe_slot, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag, h->ntmp, mat_data(h),
+                           h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag, h->ntmp, mat_data(h),
                            h->volume, h->dpressure, h->stress, h->ddp, h->bc_mask, h->bcn_idx, h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass,
                            h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part);
     }

@@ -6,15 +6,19 @@
 //   pn_id  [pn_ptr[b] .. pn_ptr[b+1])   the nodes of its elements that are NOT its own, ascending
 //   pe_*   [pe_ptr[b] .. pe_ptr[b+1])   its patch = every element touching one of its nodes, ascending:
 //          pe_elem  element id | 1 << 30 if this block owns the element (holds its lowest node)
-//          pe_ln    local id of the element's four nodes in connectivity order: n - n0 for the
-//                   block's own nodes, nown + position in pn_id for the others
+//          (ln)     local id of the element's four nodes in connectivity order: n - n0 for the
+//                   block's own nodes, nown + position in pn_id for the others -- in pe_pack only
 //          pe_slot  for each of the four nodes: position of that incidence in the block's slice of the
 //                   CSR support list (k - sup_idx[n0]) if the node is the block's own, else -1
+//   pe_pack  the three of them in ONE 16-byte record (EN1 / EN3: one request per listed element instead of three;
+//            EN2 reads pe_elem / pe_slot):
+//            .x = elem (31 bits incl. the owner flag) | ln0 << 31 | ln1 << 40 | ln2 << 49
+//            .y = ln3 | slot0 << 9 | slot1 << 21 | slot2 << 33 | slot3 << 45      (9-bit local ids, 12-bit slots, 0xfff = none)
 struct PatchLists {
     int npb = 0, nb = 0, max_inc = 0, max_pn = 0, max_pe = 0;
     std::vector<int> pe_ptr, pe_elem, pn_ptr, pn_id;
-    std::vector<ushort4> pe_ln;
     std::vector<short4> pe_slot;
+    std::vector<ulonglong2> pe_pack;
 };
 
 // false: a block exceeds the LDS caps of the kernel (cap_inc incidences, cap_pn patch nodes)
@@ -30,7 +34,7 @@ bool build_patches(const des_mesh *m, int npb, int cap_inc, int cap_pn, PatchLis
     for (int b = 0; b < P.nb; ++b) {
         const int n0 = b * npb, n1 = std::min(nn, n0 + npb), nown = n1 - n0;
         const int kb = sidx[n0], ke = sidx[n1];
-        if (ke - kb > cap_inc || ke - kb > 32767) return false;
+        if (ke - kb > cap_inc || ke - kb > 4094) return false;                               // (12-bit slots in pe_pack)
         elems.clear(); halo.clear();
         for (int k = kb; k < ke; ++k) if (emark[sarr[k]] != b) { emark[sarr[k]] = b; elems.push_back(sarr[k]); }
         std::sort(elems.begin(), elems.end());
@@ -42,7 +46,7 @@ bool build_patches(const des_mesh *m, int npb, int cap_inc, int cap_pn, PatchLis
             }
         }
         std::sort(halo.begin(), halo.end());
-        if (nown + (int)halo.size() > cap_pn || nown + halo.size() > 65535) return false;
+        if (nown + (int)halo.size() > cap_pn || nown + halo.size() > 511) return false;      // (9-bit local ids in pe_pack)
         // position of each element in the sorted patch, then the slots from the CSR slice
         for (size_t q = 0; q < elems.size(); ++q) emark[elems[q]] = -2 - (int)q;       // (restored to b below)
         slots.assign(4 * elems.size(), (short)-1);
@@ -59,8 +63,16 @@ bool build_patches(const des_mesh *m, int npb, int cap_inc, int cap_pn, PatchLis
                 else ln[i] = (unsigned short)(nown + (std::lower_bound(halo.begin(), halo.end(), n) - halo.begin()));
             }
             P.pe_elem.push_back(e | ((nmin >= n0 && nmin < n1) ? 0x40000000 : 0));
-            P.pe_ln.push_back(make_ushort4(ln[0], ln[1], ln[2], ln[3]));
             P.pe_slot.push_back(make_short4(slots[4*q], slots[4*q + 1], slots[4*q + 2], slots[4*q + 3]));
+            {
+                ulonglong2 r;
+                r.x = (unsigned long long)(unsigned)P.pe_elem.back() | ((unsigned long long)ln[0] << 31) | ((unsigned long long)ln[1] << 40)
+                      | ((unsigned long long)ln[2] << 49);
+                r.y = (unsigned long long)ln[3];
+                for (int k = 0; k < 4; ++k)
+                    r.y |= (unsigned long long)(slots[4*q + k] < 0 ? 0xfff : slots[4*q + k]) << (9 + 12 * k);
+                P.pe_pack.push_back(r);
+            }
         }
         P.pn_id.insert(P.pn_id.end(), halo.begin(), halo.end());
         P.pe_ptr.push_back((int)P.pe_elem.size());

@@ -64,6 +64,25 @@ __device__ __forceinline__ void pl_st(double *__restrict__ a, int i, int ne, uns
     *(DES_GLOBAL double *)(b + eo) = v;
 }
 
+// One listed patch element as EN1 / EN3 read it: engine/patch.hpp packs (element | owner flag, four local node ids,
+// four CSR slots) into 16 bytes -- .x = elem (31 bits) | ln0 << 31 | ln1 << 40 | ln2 << 49, .y = ln3 | slot_k << (9 + 12 k),
+// 0xfff = no slot.
+struct PatchElem { int ew; unsigned short ln[4]; short sl[4]; };
+__device__ __forceinline__ PatchElem patch_elem_unpack(const ulonglong2 r)
+{
+    PatchElem E;
+    E.ew = (int)(r.x & 0x7fffffffull);
+    E.ln[0] = (unsigned short)((r.x >> 31) & 0x1ff); E.ln[1] = (unsigned short)((r.x >> 40) & 0x1ff);
+    E.ln[2] = (unsigned short)((r.x >> 49) & 0x1ff); E.ln[3] = (unsigned short)(r.y & 0x1ff);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = (int)((r.y >> (9 + 12 * k)) & 0xfff);
+        E.sl[k] = (short)(s == 0xfff ? -1 : s);
+    }
+    return E;
+}
+
+
 // What the kernels know about the materials of an element (refresh_elem_cache,
 // matprops.cxx:259-303, redone whenever the marker counts change):
 //   markers [ne][nmat]  the counts themselves

@@ -27,8 +27,7 @@
 template <int THREADS, int INC, int PN, int PE, int CONSTM>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 3)
 EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int ne, int nblocks, int npb,
-     const int *__restrict__ pe_ptr, const int *__restrict__ pe_elem, const ushort4 *__restrict__ pe_ln,
-     const short4 *__restrict__ pe_slot, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
+     const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag, const MatData md,
      const double *__restrict__ radiogenic, const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm,
      double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp)
@@ -74,9 +73,10 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     __syncthreads();
     // the patch's elements: E1's element terms, recomputed
     for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) {
-        const int e = pe_elem[i] & 0x3fffffff;
-        const ushort4 ln = pe_ln[i];
-        const short4 sl = pe_slot[i];
+        const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
+        const int e = PE_.ew & 0x3fffffff;
+        const ushort4 ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
+        const short4 sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
         const int q = i - e_begin;                          // position in the patch
         d4 c[4], v[4];
         c[0] = lxt[ln.x]; c[1] = lxt[ln.y]; c[2] = lxt[ln.z]; c[3] = lxt[ln.w];

@@ -35,8 +35,7 @@ template <int THREADS, int INC, int PN>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 6 : 3)
 EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nmd, int o0, int nn_own_end,
      int nn, int nn_global, int ne, int nblocks, int npb,
-     const int *__restrict__ pe_ptr, const int *__restrict__ pe_elem, const ushort4 *__restrict__ pe_ln,
-     const short4 *__restrict__ pe_slot, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
+     const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag,
      const double *__restrict__ ntmp, const MatData md, const double *__restrict__ volume,
      const double *__restrict__ dpressure, const double *__restrict__ stress, double *__restrict__ ddp_out,
@@ -67,7 +66,9 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     // not one per phase -- with three workgroups per CU there is little else to hide them behind.
     struct Elem { int ew, mono; ushort4 ln; short4 sl; double s[6], vol, dpo; };
     auto load_elem = [&](int i, Elem &E) {
-        E.ew = pe_elem[i]; E.ln = pe_ln[i]; E.sl = pe_slot[i];
+        const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
+        E.ew = PE_.ew; E.ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
+        E.sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
         const int e = E.ew & 0x3fffffff;
         const unsigned eo = (unsigned)e * 8u;               // scalar plane base + one 32-bit offset (passes/common.hpp)
         for (int k = 0; k < 6; ++k) E.s[k] = pl_ld(stress, k, ne, eo);
