@@ -181,8 +181,7 @@ struct des_dev {
     bool patch;
     int patch_npb, patch_nb, patch_max_inc, patch_max_pn, patch_max_pe, patch_threads;
     bool patch_n1;                        // EN1 replaces N1 inside multi-step calls (passes/en1.hpp)
-    int *pe_ptr, *pe_elem, *pn_ptr, *pn_id;
-    short4 *pe_slot;
+    int *pe_ptr, *pn_ptr, *pn_id;
     ulonglong2 *pe_pack;                  // (elem, local ids, slots) in one 16-byte record, engine/patch.hpp
     double *ddp;                          // [ne] NMD increment of the stress diagonal, applied by the next E1
     double *spin;                         // [3][ne] w3, w4, w5 of a deferred rotate_stress (E1<DEFER> -> next E2)
@@ -300,7 +299,7 @@ void des_dev_destroy(des_dev *h)
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
     for (hipGraphExec_t g : h->pgraph_exec) if (g) hipGraphExecDestroy(g);
-    void *ptrs[] = { h->pe_ptr, h->pe_elem, h->pn_ptr, h->pn_id, h->pe_pack, h->pe_slot, h->ddp, h->xt_alt, h->spin,
+    void *ptrs[] = { h->pe_ptr, h->pn_ptr, h->pn_id, h->pe_pack, h->ddp, h->xt_alt, h->spin,
         h->d_p, h->d_vt, h->d_clk, h->conn, h->sup_idx, h->sup_pack, h->bcflag, h->xt, h->vm,
         h->ntmp, h->volume_n, h->tmass, h->ymass, h->force, h->fres, h->coord0, h->dhacc, h->dh_n, h->d_red, h->dt_part, h->d_n_new2old, h->d_e_new2old,
         h->d_send_idx, h->d_recv_idx, h->d_sendbuf, h->d_recvbuf, h->d_esend_idx, h->d_erecv_idx, h->d_send_noff,
@@ -471,9 +470,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
                 const char *pt = std::getenv("DES_PATCH_THREADS");
                 h->patch_threads = (pt && std::atoi(pt) == 256) ? 256 : 512;
                 CK(dev_alloc(h->pe_ptr, P.pe_ptr.size())); CK(dev_upload(h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size(), h->stream));
-                CK(dev_alloc(h->pe_elem, P.pe_elem.size())); CK(dev_upload(h->pe_elem, P.pe_elem.data(), P.pe_elem.size(), h->stream));
                 CK(dev_alloc(h->pe_pack, P.pe_pack.size())); CK(dev_upload(h->pe_pack, P.pe_pack.data(), P.pe_pack.size(), h->stream));
-                CK(dev_alloc(h->pe_slot, P.pe_slot.size())); CK(dev_upload(h->pe_slot, P.pe_slot.data(), P.pe_slot.size(), h->stream));
                 CK(dev_alloc(h->pn_ptr, P.pn_ptr.size())); CK(dev_upload(h->pn_ptr, P.pn_ptr.data(), P.pn_ptr.size(), h->stream));
                 CK(dev_alloc(h->pn_id, P.pn_id.size())); CK(dev_upload(h->pn_id, P.pn_id.data(), P.pn_id.size(), h->stream));
                 CK(dev_alloc(h->ddp, (size_t)ne)); CK(dev_alloc(h->xt_alt, (size_t)nn));

@@ -312,10 +312,10 @@ void launch_n2(des_dev *h)
         const dim3 grid((h->patch_nb + 7) / 8 * 8);
         if (h->patch_max_inc <= 1664 && h->patch_max_pe <= 896)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(EN2_nmd_gather<1664, 896>), grid, dim3(256), 0, h->stream, h->nn, h->patch_nb, h->patch_npb,
-                               h->pe_ptr, h->pe_elem, h->pe_slot, h->sup_idx, h->etmp2, h->volume_n, h->ntmp);
+                               h->pe_ptr, h->pe_pack, h->sup_idx, h->etmp2, h->volume_n, h->ntmp);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(EN2_nmd_gather<DES_PATCH_INC, DES_PATCH_PE>), grid, dim3(256), 0, h->stream, h->nn, h->patch_nb,
-                               h->patch_npb, h->pe_ptr, h->pe_elem, h->pe_slot, h->sup_idx, h->etmp2, h->volume_n, h->ntmp);
+                               h->patch_npb, h->pe_ptr, h->pe_pack, h->sup_idx, h->etmp2, h->volume_n, h->ntmp);
         return;
     }
     Launch l(h, K_N2);

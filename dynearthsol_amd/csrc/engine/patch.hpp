@@ -10,14 +10,13 @@
 //                   block's own nodes, nown + position in pn_id for the others -- in pe_pack only
 //          pe_slot  for each of the four nodes: position of that incidence in the block's slice of the
 //                   CSR support list (k - sup_idx[n0]) if the node is the block's own, else -1
-//   pe_pack  the three of them in ONE 16-byte record (EN1 / EN3: one request per listed element instead of three;
-//            EN2 reads pe_elem / pe_slot):
+//   pe_pack  the three of them in ONE 16-byte record, the only form that goes to the device (one request per listed
+//            element instead of three; EN2 reads the same records just ahead of EN3, which then finds them cached):
 //            .x = elem (31 bits incl. the owner flag) | ln0 << 31 | ln1 << 40 | ln2 << 49
 //            .y = ln3 | slot0 << 9 | slot1 << 21 | slot2 << 33 | slot3 << 45      (9-bit local ids, 12-bit slots, 0xfff = none)
 struct PatchLists {
     int npb = 0, nb = 0, max_inc = 0, max_pn = 0, max_pe = 0;
     std::vector<int> pe_ptr, pe_elem, pn_ptr, pn_id;
-    std::vector<short4> pe_slot;
     std::vector<ulonglong2> pe_pack;
 };
 
@@ -63,7 +62,6 @@ bool build_patches(const des_mesh *m, int npb, int cap_inc, int cap_pn, PatchLis
                 else ln[i] = (unsigned short)(nown + (std::lower_bound(halo.begin(), halo.end(), n) - halo.begin()));
             }
             P.pe_elem.push_back(e | ((nmin >= n0 && nmin < n1) ? 0x40000000 : 0));
-            P.pe_slot.push_back(make_short4(slots[4*q], slots[4*q + 1], slots[4*q + 2], slots[4*q + 3]));
             {
                 ulonglong2 r;
                 r.x = (unsigned long long)(unsigned)P.pe_elem.back() | ((unsigned long long)ln[0] << 31) | ((unsigned long long)ln[1] << 40)

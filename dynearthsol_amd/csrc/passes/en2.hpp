@@ -9,8 +9,8 @@
 // and the nodes sum their incidences from there, in CSR order (same association, same bits).
 template <int INC, int PE>
 __global__ void __launch_bounds__(256)
-EN2_nmd_gather(int nn, int nblocks, int npb, const int *__restrict__ pe_ptr, const int *__restrict__ pe_elem,
-               const short4 *__restrict__ pe_slot, const int *__restrict__ sup_idx,
+EN2_nmd_gather(int nn, int nblocks, int npb, const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack,
+               const int *__restrict__ sup_idx,
                const double *__restrict__ etmp2, const double *__restrict__ volume_n, double *__restrict__ ntmp)
 {
     __shared__ double lv[PE];
@@ -31,12 +31,12 @@ EN2_nmd_gather(int nn, int nblocks, int npb, const int *__restrict__ pe_ptr, con
     }
     for (int i = e_begin + threadIdx.x; i < e_end; i += 256) {
         const int q = i - e_begin;
-        const short4 sl = pe_slot[i];
-        lv[q] = etmp2[pe_elem[i] & 0x3fffffff];
-        if (sl.x >= 0) lidx[sl.x] = (unsigned short)q;
-        if (sl.y >= 0) lidx[sl.y] = (unsigned short)q;
-        if (sl.z >= 0) lidx[sl.z] = (unsigned short)q;
-        if (sl.w >= 0) lidx[sl.w] = (unsigned short)q;
+        const PatchElem E = patch_elem_unpack(pe_pack[i]);    // (the record EN3 streams next: it finds it in the caches)
+        lv[q] = etmp2[E.ew & 0x3fffffff];
+        if (E.sl[0] >= 0) lidx[E.sl[0]] = (unsigned short)q;
+        if (E.sl[1] >= 0) lidx[E.sl[1]] = (unsigned short)q;
+        if (E.sl[2] >= 0) lidx[E.sl[2]] = (unsigned short)q;
+        if (E.sl[3] >= 0) lidx[E.sl[3]] = (unsigned short)q;
     }
     __syncthreads();
     if (!has_node) return;
