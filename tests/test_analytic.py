@@ -1,5 +1,5 @@
 """Known answers from OUTSIDE the code: the two analytic benchmarks the reference ships with a closed-form
-solution it compares its own output with.
+solution it compares its own output with, plus the Maxwell / Newtonian laws themselves on a cell in pure shear.
 
 * oedometer test (benchmarks/oedometer-2d.cfg, the closed form in benchmarks/oedometer-2d-plot.py:13-44):
   a confined block compressed at a constant rate, elastic up to step ~641, then yielding on the Mohr-Coulomb
@@ -182,6 +182,58 @@ def run_cooling(make_engine, until_myr=10.0):
     # 2-km cells: 4.4 K of 1327 at 1 Myr, 8.7 K at 10 Myr (9.6 K at 60 Myr)
     assert worst < 1e-2
     return eng
+
+
+# benchmarks/maxwell.cfg's material and strain rate (K 1e12, G 1e10, viscosity pinned at 1e22, 1e-14 per second) as
+# a pure shear of ONE cell -- that file's own boundary condition (type 100: velocity proportional to the far
+# corner's coordinate) is a patch to bc.cxx it ships as maxwell.diff, not part of the reference
+PURE_SHEAR = (OEDOMETER % "").replace("rheology_type = elasto-plastic", "rheology_type = %s") \
+    .replace("fixed_dt = 1.0", "fixed_dt = 1e10") \
+    .replace("inertial_scaling = 1e5", "inertial_scaling = 1e6\ncharacteristic_speed = 1e-14\nhas_thermal_diffusion = no") \
+    .replace("vbc_val_x1 = -1e-5", "vbc_val_x1 = -1e-14").replace("vbc_val_z1 = 0", "vbc_val_z1 = 1e-14") \
+    .replace("bulk_modulus = [ 200.0e6 ]", "bulk_modulus = [ 1e12 ]") \
+    .replace("shear_modulus = [ 200.0e6 ]", "shear_modulus = [ 1e10 ]\nmax_viscosity = 1e22\nmin_viscosity = 1e22")
+
+
+def run_pure_shear(make_engine, rheology):
+    """(sxx - szz) / 2 of a cell shortened along x and stretched along z at 1e-14 per second for five relaxation
+    times, against the EXACT integral of the Maxwell law s' = 2 G e' - (G / eta) s over each step with the strain
+    rate of that step's geometry (maxwell, rheology.cxx:277-295: a trapezoidal step, second order in G dt / eta =
+    0.01), or against 2 eta e' (viscous, rheology.cxx:298-310)."""
+    host = des.Host(cfg_text=PURE_SHEAR % rheology)
+    assert (host.nnode, host.nelem) == (8, 5)
+    eng = make_engine(host)
+    eng.init_from_host(host)
+    g, eta, dt, v = 1e10, 1e22, 1e10, 1e-14
+    lx = lz = 1.0
+    sd, decay = 0.0, math.exp(-g * dt / eta)
+    for n in range(1, 501):
+        ed = (-v / lx - v / lz) / 2                          # (exx - ezz) / 2 on the geometry the step starts from
+        sd = sd * decay + 2 * eta * ed * (1 - decay) if rheology == "maxwell" else 2 * eta * ed
+        lx -= v * dt
+        lz += v * dt
+        if n % 100 == 0:
+            sc = eng.step(100)
+            assert sc.time == pytest.approx(n * dt, rel=1e-12)
+            s = eng.download("STRESS").reshape(6, -1)
+            assert np.ptp(s[0]) <= 1e-9 * abs(s[0]).max()   # uniform
+            # maxwell: 4.8e-6 after one relaxation time, 2.9e-7 after five
+            assert (s[0] - s[2]).mean() / 2 == pytest.approx(sd, rel=2e-5), "step %d" % n
+    return eng
+
+
+@pytest.mark.parametrize("rheology", ["maxwell", "viscous"])
+def test_oracle_pure_shear_against_the_maxwell_and_newtonian_laws(rheology):
+    run_pure_shear(OracleEngine, rheology)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rheology", ["maxwell", "viscous"])
+def test_device_pure_shear_against_the_maxwell_and_newtonian_laws(rheology):
+    dev = run_pure_shear(des.DeviceEngine, rheology)
+    ora = run_pure_shear(OracleEngine, rheology)
+    for f in ("COORD", "STRESS", "STRAIN", "VISCOSITY"):
+        assert np.array_equal(dev.download(f), ora.download(f)), f
 
 
 @pytest.mark.parametrize("ndims", [2, 3])
