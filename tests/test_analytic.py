@@ -236,6 +236,43 @@ def test_device_pure_shear_against_the_maxwell_and_newtonian_laws(rheology):
         assert np.array_equal(dev.download(f), ora.download(f)), f
 
 
+def run_uniform_heating(make_engine):
+    """A uniform heat source H in a body at uniform temperature: the conduction terms vanish, update_temperature
+    (fields.cxx:211-262) reduces to dT = dt H / cp -- away from the surface, whose temperature is held."""
+    host = des.Host(cfg_text=DIFFUSION.replace("oceanic_plate_age_in_yr = 1e6", "oceanic_plate_age_in_yr = 1e6\n")
+                    .replace("[bc]", "[bc]\nsurface_temperature = 273\nmantle_temperature = 273")
+                    .replace("rho0 = [ 3000 ]", "rho0 = [ 3000 ]\nalpha = [ 0 ]"))   # (rho(T) enters the source and the thermal mass a step apart)
+    eng = make_engine(host)
+    eng.init_from_host(host)
+    t0 = eng.download("TEMPERATURE")
+    assert np.all(t0 == 273.0)
+    h_src, cp = 2e-9, 1000.0                                  # W/kg
+    eng.upload("RADIOGENIC", np.full(host.nelem, h_src))
+    sc = eng.step(200)
+    z = eng.download("COORD").reshape(3, -1)[2]
+    t = eng.download("TEMPERATURE")
+    deep = z < -100e3                                        # ~6 conduction lengths below the surface after 200 steps
+    assert deep.sum() > 1000
+    assert np.abs(t[deep] - (273.0 + h_src * sc.time / cp)).max() <= 1e-9 * (h_src * sc.time / cp)
+    assert t[z == z.max()].max() == 273.0                    # the surface is held
+    # and switching the sources off again (all +0.0: the engine then skips the fetch) freezes the deep temperature
+    eng.upload("RADIOGENIC", np.zeros(host.nelem))
+    eng.step(50)
+    assert np.abs(eng.download("TEMPERATURE")[z < -200e3] - t[z < -200e3]).max() < 1e-9     # (rounding of the conduction sums)
+    return eng
+
+
+def test_oracle_uniform_heating():
+    run_uniform_heating(OracleEngine)
+
+
+@pytest.mark.gpu
+def test_device_uniform_heating():
+    dev = run_uniform_heating(des.DeviceEngine)
+    ora = run_uniform_heating(OracleEngine)
+    assert np.array_equal(dev.download("TEMPERATURE"), ora.download("TEMPERATURE"))
+
+
 @pytest.mark.parametrize("ndims", [2, 3])
 def test_oracle_oedometer_against_the_closed_form(ndims):
     run_oedometer(OracleEngine, ndims)
