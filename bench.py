@@ -317,6 +317,10 @@ def main():
             "hip_event_ms_per_step": ev_ms / args.steps,
             "nan_entries": nan, "status": sc.status,
             "libm": os.environ.get("DES_LIBM", "portable (pow/exp = glibc's bits)"),
+            # inside the one des_dev_step call of the timed region only the LAST step stores strain_rate, viscosity,
+            # delta_plstrain and volume_old (nothing reads them before the next step overwrites them; every field a
+            # caller can download after the call is the reference's).  DES_E2_ELIDE=0: every step stores them
+            "interior_step_store_elision": os.environ.get("DES_E2_ELIDE", "1") != "0",
         },
     }
     if world > 1:
