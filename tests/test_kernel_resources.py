@@ -1,0 +1,51 @@
+"""Register / scratch budget of the kernels of the fused step (cross-compiled for gfx950: no GPU needed).
+
+Scratch is HBM traffic (a 16-byte spill in EN3 was 24 MB of stores per launch, a stack slot in
+EN1 doubled what it writes) and the patch passes only hold three workgroups per CU at their register caps, so the
+hot kernels must stay scratch-free and inside the budgets their launch bounds assume."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def table():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = []
+    for line in out.stdout.splitlines()[1:]:
+        f = line.split()
+        if len(f) < 6:
+            continue
+        rows.append((" ".join(f[:-5]), dict(vgpr=int(f[-5]), sgpr=int(f[-4]), scratch=int(f[-3]), lds=int(f[-2]), waves=int(f[-1]))))
+    assert len(rows) > 40
+    return rows
+
+
+def pick(table, prefix):
+    # (the tool cuts names at 44 characters: variants that only differ in a later template argument -- EN1 with the
+    #  constant quasi-static mass or a per-element one -- share a name; the bench model runs the smaller one)
+    hits = [v for k, v in table if k.startswith(prefix)]
+    assert hits, prefix
+    return min(hits, key=lambda r: r["lds"])
+
+
+@pytest.mark.parametrize("kernel,max_vgpr,min_waves,max_lds", [
+    ("E2_update_stress<desk::MathPortable, 1, 1>", 256, 2, 20480),      # E2<GEO>, first pass of two (the default)
+    ("E2_update_stress<desk::MathOcml, 1, 1>", 256, 2, 0),
+    ("E2_update_stress<desk::MathPortable, 1, 0>", 168, 3, 20480),      # first step of a call
+    ("EN1_mass_temperature_dvoldt<256, 1600, 296,", 168, 3, 54613),     # three workgroups per CU: LDS <= 160 KiB / 3
+    ("EN3_force_nodes<512, 1664, 320>", 80, 6, 54613),
+    ("EN2_nmd_gather<1664, 896>", 64, 8, 20480),
+    ("k_s2", 256, 2, 1024),
+    ("k_s3_finalize", 64, 8, 4096),
+    ("E1_geom_rotate_strainrate<68>", 96, 5, 1024),                      # the compute_dt reduction of every 10th step
+])
+def test_hot_kernels_stay_scratch_free_and_inside_their_budgets(table, kernel, max_vgpr, min_waves, max_lds):
+    r = pick(table, kernel)
+    assert r["scratch"] == 0, r
+    assert r["vgpr"] <= max_vgpr and r["waves"] >= min_waves and r["lds"] <= max_lds, r
