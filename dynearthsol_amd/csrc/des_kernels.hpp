@@ -291,12 +291,16 @@ __device__ __forceinline__ void dsyevc3(const double *a, double w[3])
 
 // 3x3-C/dsytrd3.c:379-455 + dsyevq3.c:245-350: Householder tridiagonalisation, then QL
 // with implicit shifts.  Q columns are returned in q[r][col].  Rarely taken (degenerate
-// or near-degenerate tensors), so it is kept out of line -- and takes / returns everything BY VALUE:
-// with pointer arguments the caller's eigenvector matrix had to live in memory, and the Mohr-Coulomb
-// return (which calls this once in a blue moon) kept it in scratch for every element it handles
-// (~40 scratch accesses of 16 B per call).  The run-time indexed copies below are this function's own.
+// or near-degenerate tensors).  It takes / returns everything BY VALUE -- with pointer arguments the caller's
+// eigenvector matrix had to live in memory, and the Mohr-Coulomb return (which calls this once in a blue moon)
+// kept it in scratch for every element it handles (~40 scratch accesses of 16 B per call) -- and indexes
+// nothing at run time (below), so it and the return mapping are inlined into the stress update without a
+// scratch frame anywhere: the one-pass update went 127-138 -> 115-119 us with 2-10 % of 1.6M tets yielding.
+#ifndef DES_RM_INLINE
+#define DES_RM_INLINE __forceinline__
+#endif
 struct Eig3 { double q[3][3]; double w[3]; int rc; };
-__device__ __noinline__ Eig3 dsyevq3_core(double A00, double A11, double A22, double A01, double A02, double A12)
+__device__ DES_RM_INLINE Eig3 dsyevq3_core(double A00, double A11, double A22, double A01, double A02, double A12)
 {
     Eig3 R;
     double *w = R.w;
@@ -336,56 +340,70 @@ __device__ __noinline__ Eig3 dsyevq3_core(double A00, double A11, double A22, do
             e1 = A12;
         }
     }
-    double q[3][3] = {{1, 0, 0}, {0, Q11, Q12}, {0, Q21, Q22}};
-    double e[3] = {e0, e1, e2};
-
+    // Everything below is indexed by l, m, i in {0, 1, 2} that depend on the data: w, e and the columns of q live
+    // in scalars and are picked by selects (DES_G3 / DES_P3), so that nothing is addressed at run time -- no
+    // scratch frame, and the whole solver can be inlined into the stress update.
+    double w0 = w[0], w1 = w[1], w2 = w[2];
+    double q00 = 1, q01 = 0, q02 = 0, q10 = 0, q11 = Q11, q12 = Q12, q20 = 0, q21 = Q21, q22 = Q22;
+#define DES_G3(a, i) ((i) == 0 ? a##0 : ((i) == 1 ? a##1 : a##2))
+#define DES_P3(a, i, v) { const double v_ = (v); if ((i) == 0) a##0 = v_; else if ((i) == 1) a##1 = v_; else a##2 = v_; }
     double g, r, p, f, b, s, c, t;
+    int rc = 0;
+#pragma unroll
     for (int l = 0; l < 2; l++) {
         int nIter = 0;
-        while (1) {
+        while (rc == 0) {
             int m;
             for (m = l; m <= 1; m++) {
-                g = fabs(w[m]) + fabs(w[m+1]);
-                if (fabs(e[m]) + g == g) break;
+                g = fabs(DES_G3(w, m)) + fabs(DES_G3(w, m + 1));
+                if (fabs(DES_G3(e, m)) + g == g) break;
             }
             if (m == l) break;
-            if (nIter++ >= 30) { R.rc = -1; return R; }
+            if (nIter++ >= 30) { rc = -1; break; }
 
-            g = (w[l+1] - w[l]) / (e[l] + e[l]);
+            const double wl = DES_G3(w, l), el = DES_G3(e, l);
+            g = (DES_G3(w, l + 1) - wl) / (el + el);
             r = sqrt(sqr(g) + 1.0);
-            if (g > 0) g = w[m] - w[l] + e[l]/(g + r);
-            else       g = w[m] - w[l] + e[l]/(g - r);
+            if (g > 0) g = DES_G3(w, m) - wl + el/(g + r);
+            else       g = DES_G3(w, m) - wl + el/(g - r);
 
             s = c = 1.0;
             p = 0.0;
             for (int i = m-1; i >= l; i--) {
-                f = s * e[i];
-                b = c * e[i];
+                const double ei = DES_G3(e, i);
+                f = s * ei;
+                b = c * ei;
                 if (fabs(f) > fabs(g)) {
                     c      = g / f;
                     r      = sqrt(sqr(c) + 1.0);
-                    e[i+1] = f * r;
+                    DES_P3(e, i + 1, f * r);
                     c     *= (s = 1.0/r);
                 } else {
                     s      = f / g;
                     r      = sqrt(sqr(s) + 1.0);
-                    e[i+1] = g * r;
+                    DES_P3(e, i + 1, g * r);
                     s     *= (c = 1.0/r);
                 }
-                g = w[i+1] - p;
-                r = (w[i] - g)*s + 2.0*c*b;
+                g = DES_G3(w, i + 1) - p;
+                r = (DES_G3(w, i) - g)*s + 2.0*c*b;
                 p = s * r;
-                w[i+1] = g + p;
+                DES_P3(w, i + 1, g + p);
                 g = c*r - b;
-                for (int k = 0; k < 3; k++) DES_QL_ROT(q[k][i], q[k][i+1]);
+                if (i == 0) { DES_QL_ROT(q00, q01); DES_QL_ROT(q10, q11); DES_QL_ROT(q20, q21); }
+                else        { DES_QL_ROT(q01, q02); DES_QL_ROT(q11, q12); DES_QL_ROT(q21, q22); }
             }
-            w[l] -= p;
-            e[l]  = g;
-            e[m]  = 0.0;
+            DES_P3(w, l, DES_G3(w, l) - p);
+            DES_P3(e, l, g);
+            DES_P3(e, m, 0.0);
         }
     }
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R.q[i][j] = q[i][j];
-    R.rc = 0;
+#undef DES_G3
+#undef DES_P3
+    w[0] = w0; w[1] = w1; w[2] = w2;
+    R.q[0][0] = q00; R.q[0][1] = q01; R.q[0][2] = q02;
+    R.q[1][0] = q10; R.q[1][1] = q11; R.q[1][2] = q12;
+    R.q[2][0] = q20; R.q[2][1] = q21; R.q[2][2] = q22;
+    R.rc = rc;
     return R;
 }
 __device__ __forceinline__ int dsyevq3(const double *a, double Q[3][3], double w[3])
@@ -495,15 +513,15 @@ __device__ __forceinline__ void viscous(double bulkm, double viscosity, double t
 }
 
 // The Mohr-Coulomb return after the pre-filter said "maybe yielding" (rheology.cxx:363-475).
-// ~0.2 % of the elements get here, so it is out of line to keep the common path lean.  The
-// stress travels BY VALUE (in registers): passing a pointer to the caller's array would force
-// that array -- the stress every element works on -- into scratch memory for all elements.
+// ~0.2 % of the elements get here.  Inlined (DES_RM_INLINE; round 1 kept it out of line, which cost every
+// caller a scratch frame for the call); the stress travels BY VALUE (in registers): passing a pointer to
+// the caller's array would force that array -- the stress every element works on -- into scratch memory.
 // mode: the reference's failure_mode (0 none, 1 tensile, 10 shear; a local there, rheology.cxx:322)
 // + 100 when dsyevh3 fell back to dsyevq3 -- only read by des_dev_elasto_plastic_eval.
 struct Stress7 { double s0, s1, s2, s3, s4, s5, depls; int mode; };
 
 template <class M>
-__device__ __noinline__ Stress7 mohr_coulomb_return(double bulkm, double shearm, double amc, double anphi,
+__device__ DES_RM_INLINE Stress7 mohr_coulomb_return(double bulkm, double shearm, double amc, double anphi,
                                                     double anpsi, double hardn, double ten_max, Stress7 io)
 {
     double s[6] = {io.s0, io.s1, io.s2, io.s3, io.s4, io.s5};

@@ -254,7 +254,7 @@ void launch_n1(des_dev *h)
 #define DES_E2R_GRID 512          // workgroups of the second pass (grid-stride loop): two per CU, all resident
 #endif
 #ifndef DES_E2_DEFER_MAX
-#define DES_E2_DEFER_MAX 0.01      // (1.6M tets, ep: two passes 119 / 134 / 152 us at 0 / 2.5 / 10 % set aside, one pass ~121 / 127 / 138)
+#define DES_E2_DEFER_MAX 0.002     // (1.6M tets, ep: two passes 111 + 17 / 112 + 28 us at 2.5 / 10 % set aside, one pass 115 / 119; nothing set aside, evp 1M: 73 + 5 against 77)
 #endif
 // called whenever the host copy of the clock is fresh (end of des_dev_step / des_dev_phase calls)
 void choose_e2_mode(des_dev *h)

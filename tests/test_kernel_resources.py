@@ -38,6 +38,8 @@ def pick(table, prefix):
     ("E2_update_stress<desk::MathPortable, 1, 1>", 256, 2, 20480),      # E2<GEO>, first pass of two (the default)
     ("E2_update_stress<desk::MathOcml, 1, 1>", 256, 2, 0),
     ("E2_update_stress<desk::MathPortable, 1, 0>", 168, 3, 20480),      # first step of a call
+    ("E2_update_stress<desk::MathPortable, 0, 1>", 256, 2, 20480),      # one pass (return mapping inline): the mode when elements yield
+    ("E2_return_mapping<desk::MathPortable, 1>", 256, 2, 20480),        # second pass
     ("EN1_mass_temperature_dvoldt<256, 1600, 296,", 168, 3, 54613),     # three workgroups per CU: LDS <= 160 KiB / 3
     ("EN3_force_nodes<512, 1664, 320>", 80, 6, 54613),
     ("EN2_nmd_gather<1664, 896>", 64, 8, 20480),
