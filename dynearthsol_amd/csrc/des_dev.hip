@@ -890,6 +890,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     const long long qcsi = h->p.quality_check_step_interval;
     int rc;
     h->n_pt_iterations = 0;
+    if (h->e2_defer == 2 && e2geo_ok(h)) h->e2_two_pass = false;      // (choose_e2_mode: the fused step runs one pass)
     for (int i = 0; i < nsteps; ++i) {
         const long long step_no = iso ? h->steps_host : ++h->steps_host;
         if (i == 0) launch_e1<MODE_A>(h);

@@ -250,16 +250,19 @@ void launch_n1(des_dev *h)
 // code with the return mapping, 2 waves per SIMD) works that list off.  The list is sparse, so
 // the second pass pays ~6x per element; above DES_E2_DEFER_MAX of the mesh one pass is cheaper.
 // Both give the same bits.  DES_E2_DEFER=0 / 1 pins the mode; default: choose_e2_mode().
+// With E2<GEO> (two waves per SIMD either way, and the return mapping inlined without a scratch frame) one pass
+// is never slower -- 200.9 against 201.6 us per step with nothing set aside (1M tets), 115 against 128 us for
+// the pass at 2.5 % --, so the fused step runs ONE pass and the second launch is gone from it.
 #ifndef DES_E2R_GRID
 #define DES_E2R_GRID 512          // workgroups of the second pass (grid-stride loop): two per CU, all resident
 #endif
 #ifndef DES_E2_DEFER_MAX
-#define DES_E2_DEFER_MAX 0.002     // (1.6M tets, ep: two passes 111 + 17 / 112 + 28 us at 2.5 / 10 % set aside, one pass 115 / 119; nothing set aside, evp 1M: 73 + 5 against 77)
+#define DES_E2_DEFER_MAX 0.01      // (the classic first pass runs three waves per SIMD: 70 + 5 us against 81 in one pass with nothing set aside)
 #endif
 // called whenever the host copy of the clock is fresh (end of des_dev_step / des_dev_phase calls)
 void choose_e2_mode(des_dev *h)
 {
-    if (h->e2_defer == 2) h->e2_two_pass = h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
+    if (h->e2_defer == 2) h->e2_two_pass = e2geo_ok(h) ? false : h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
 }
 
 void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)

@@ -59,7 +59,9 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     const double edvoldt = dj / 4;
 
     const bool outs = !GEO || rp.outputs;
-    constexpr bool ES_EARLY = GEO && DEFER;          // strain / strain-rate diagonal stored before the law
+    // strain / strain-rate diagonal stored before the law: by the only pass (nothing re-reads them), and by the first
+    // of two passes when the second can tell (GEO: it recomputes the strain rate and skips the strain, ES_DONE)
+    constexpr bool ES_EARLY = !RM && (GEO || !DEFER);
     constexpr bool ES_DONE = GEO && RM;              // ... by the first pass: not touched here
     double s[6], es[6] = {0, 0, 0, 0, 0, 0}, edot[6];
     double g_vol = 0, g_vol_old = 0, g_pls = 0, g_T = 0;
