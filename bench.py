@@ -386,6 +386,8 @@ def main():
                     # the profiled leg is ONE des_dev_step call: its last launch stores every field, the others
                     # are interior launches -- the average launch is credited with the average of the two
                     be = (E2G_INTERIOR[0] * (calls - 1) + be) / calls
+                if dom == "E2G_geom_rotate_update_stress" and args.averaged_fields:
+                    be += 112           # Output::average_fields rides in the pass: stress_avg 48 R + 48 W, dplstrain_avg 8 R + 8 W
                 kbytes = be * ne_local + bn * (nn if world == 1 else part.nnode)     # rank 0's launch
                 achieved = kbytes / (ms / calls * 1e-3) / 1e9
                 # HBM bytes from the PMC counters cannot be collected inside the timed run (separate

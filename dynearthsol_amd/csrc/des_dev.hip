@@ -190,6 +190,7 @@ struct des_dev {
     double *dt_part;                      // compute_dt partials, [5][dt_part_cap]: one slot per E1<MODE_DT> workgroup
     int dt_part_cap, dt_parts_used;       // ... slots filled since the last reduction (k_dt_finalize / k_dt_pack)
     bool elide_ok;                        // DES_E2_ELIDE != 0
+    bool e2_not_last;                     // this step is not the last of its call (its end-of-step pass rides in the next stress update)
     bool e2_elide;                        // this step is not the last of its call: E2<GEO> skips the output-only stores
     bool e2geo_next;                      // the next E2 does what the skipped end-of-step pass would have done (E2<GEO>)
     d4 *xt_alt;                           // the other buffer of the {x,y,z,T} pair (EN3 writes it, then they swap)
@@ -886,7 +887,8 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     // buffers, so the steps inside a call all start on the same one (the first step of a call swaps
     // once, N1 + EN3); three graphs per buffer, because the E2 after a compute_dt step rotates with
     // the dt of before it and a compute_dt step ends with the reduction
-    const bool pgraphs = h->use_graph && h->patch && !multi && !h->prof && e2geo_ok(h);
+    const bool pgraphs = h->use_graph && h->patch && !multi && !h->prof && e2geo_ok(h)
+                         && !h->p.is_outputting_averaged_fields;       // (k_avg_coord0 rides on some steps)
     const long long qcsi = h->p.quality_check_step_interval;
     int rc;
     h->n_pt_iterations = 0;
@@ -914,6 +916,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
             continue;
         }
         h->e2_elide = h->elide_ok && i < nsteps - 1;
+        h->e2_not_last = i < nsteps - 1;
         if (pgraphs && i > 0 && i < nsteps - 1 && step_no % qcsi != 0 && h->e2geo_next) {
             const bool do_dt = (step_no % 10 == 0);
             const int which = 2 * (do_dt ? 1 : (h->rot_prev_dt ? 2 : 0)) + (h->xt < h->xt_alt ? 0 : 1);

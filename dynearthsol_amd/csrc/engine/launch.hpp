@@ -84,10 +84,12 @@ void launch_e1(des_dev *h, int part = E1_ALL)
 // stress in between: rotation on (an elastic part in the rheology), a plain time step (not the
 // isostasy / pseudo-transient loops), no per-step averaging pass, no hipGraph replay of the classic passes (that E2 node
 // is captured once, without the pending pointers; the fused step has graphs of its own, des_dev_step).
-inline bool defer_rot_ok(const des_dev *h)
+// (geo: the deferral into E2<GEO>, which folds Output::average_fields in; the E1<MODE_DEFER> route does not: the
+//  averaging pass behind it would see the stress before its rotation)
+inline bool defer_rot_ok(const des_dev *h, bool geo = false)
 {
     return h->defer_rot && h->spin && (h->p.rheol_type & DES_RH_ELASTIC) && !h->iso && !h->p.has_PT
-           && !h->p.is_outputting_averaged_fields && !(h->use_graph && !h->patch);
+           && (geo || !h->p.is_outputting_averaged_fields) && !(h->use_graph && !h->patch);
 }
 
 // Output::average_fields (output.cxx:327-370) on the end-of-step fields, i.e. after the C part
@@ -130,7 +132,7 @@ inline bool en1_ok(const des_dev *h)
 inline bool e2geo_ok(const des_dev *h)
 {
     static const char *env = std::getenv("DES_E2GEO");
-    return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h) && h->topflag && !h->overlap;
+    return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h, true) && h->topflag && !h->overlap;
 }
 
 // end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
@@ -272,12 +274,18 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     const bool defer = h->e2_two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
-    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1};
+    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, 0, 1};
+    if (h->p.is_outputting_averaged_fields && e2geo_ok(h) && e_begin == 0 && e_count == h->ne) {
+        rp.dplstrain_avg = h->dplstrain_avg;
+        rp.avg_dpl = h->e2_not_last ? 1 : 0;            // the last step of a call ends with E1 + k_average_fields
+        rp.qcsi = (int)h->p.quality_check_step_interval;
+    }
     const bool geo = h->e2geo_next;
     if (h->rot_pending || geo) {
         rp.spin = h->spin; rp.topflag = h->topflag; rp.prev_dt = h->rot_prev_dt ? 1 : 0; rp.vm = h->vm;
         rp.ddp = (h->patch && h->p.is_using_mixed_stress && !h->iso) ? h->ddp : nullptr;
         rp.outputs = (geo && h->e2_elide) ? 0 : 1;
+        if (geo && h->p.is_outputting_averaged_fields) { rp.stress_avg = h->stress_avg; rp.strain0 = h->strain0; }
     }
     {
         Launch l(h, geo ? K_E2G : K_E2);

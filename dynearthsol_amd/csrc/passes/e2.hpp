@@ -21,7 +21,12 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 // loads and on the output-only stores: no further gain, EN3 a little slower.)
 #define DES_STRAIN_LD pl_ld_nt
 #define DES_STRAIN_ST pl_st_nt
-struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; const d4 *vm; int outputs; };
+// avg_*: Output::average_fields (output.cxx:327-370) folded into this pass when the end-of-step pass is (engine/launch.hpp):
+// stress_avg / strain0 take the end-of-step stress / strain of the step BEFORE, which this pass holds in registers right
+// after the pending rotation; dplstrain_avg takes this step's delta_plstrain where it is formed (avg_dpl: unless the
+// classic end-of-step pass + k_average_fields follow this step, i.e. the last step of a call).  Null: not averaging.
+struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; const d4 *vm; int outputs;
+                    double *stress_avg, *strain0, *dplstrain_avg; int avg_dpl, qcsi; };
 
 // GEO = 1: this pass also does what is left of the end-of-step pass of the step before AND the strain
 // rate of this step, from the nodal records it gathers anyway: compute_volume after the volume swap
@@ -107,6 +112,12 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
             const double dtr = rp.prev_dt ? clk->dt_prev : dt;             // the dt of the step being finished
             desk::jaumann_rate_3d(s, dtr, w3, w4, w5);
             if (!ES_DONE) desk::jaumann_rate_3d(es, dtr, w3, w4, w5);
+        }
+        if (rp.stress_avg && !RM) {
+            // average_fields of the step this block has just finished (number clk->steps - 1: EN1 has counted on)
+            const bool first = (clk->steps - 1) % rp.qcsi == 1;
+            for (int i = 0; i < 6; ++i) pl_st(rp.stress_avg, i, ne, eo, first ? s[i] : pl_ld(rp.stress_avg, i, ne, eo) + s[i]);
+            if (first) for (int i = 0; i < 6; ++i) pl_st(rp.strain0, i, ne, eo, es[i]);
         }
     } else {
     for (int i = 0; i < 6; ++i) {
@@ -211,6 +222,10 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         pl_st(volume, 0, ne, eo, vol);
     }
     if (outs) pl_st(delta_plstrain, 0, ne, eo, dpl);
+    if (rp.dplstrain_avg && rp.avg_dpl) {
+        const bool first = clk->steps % rp.qcsi == 1;
+        pl_st(rp.dplstrain_avg, 0, ne, eo, first ? dpl : pl_ld(rp.dplstrain_avg, 0, ne, eo) + dpl);
+    }
     for (int i = 0; i < 6; ++i) {
         pl_st(stress, i, ne, eo, s[i]);
         if (!ES_EARLY && !ES_DONE) DES_STRAIN_ST(strain, i, ne, eo, es[i]);

@@ -42,6 +42,9 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     const int n0 = lb * npb;
     const double dt = clk->dt;
     if (blockIdx.x == 0 && threadIdx.x == 0) {             // never in the isostasy loop (en1_ok)
+        // Output::average_fields' time0 (output.cxx:332) of the step that has just ended, when its end-of-step pass
+        // (and with it k_average_fields) was left to the next stress update
+        if (p->is_outputting_averaged_fields && clk->steps % p->quality_check_step_interval == 1) clk->avg_time0 = clk->time;
         clk->steps += 1;
         clk->time += dt;
         clk->maxdh = 0.0;
