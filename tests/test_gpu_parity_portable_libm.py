@@ -123,6 +123,25 @@ def test_one_pass_and_two_pass_stress_update_give_the_same_bits(mode, monkeypatc
             assert so.n_return_mapping > 0
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_averaged_fields_ride_in_the_stress_update_while_elements_yield(mode, monkeypatch):
+    """Output::average_fields folded into E2<GEO> (the end-of-step stress / strain of the step before, this step's
+    delta_plstrain): with half of the mesh yielding, in one pass and in two (the elements set aside add their
+    delta_plstrain in the return-mapping pass, everything else exactly once in the first), across interval
+    boundaries and call boundaries, the running sums and snapshots equal the oracle's to the bit."""
+    monkeypatch.setenv("DES_E2_DEFER", mode)
+    ov = "sim.is_outputting_averaged_fields = yes\nsim.output_step_interval = 100\n"
+    with portable_libm():
+        host = des.Host(cfg_text=cfgs.make(**dict(cfgs.YIELD, qcsi=10)), overrides=ov)
+        dev, ora = pair(host)
+        for n in (1, 4, 5, 7, 10, 3, 30):
+            sd, so = dev.step(n), ora.step(n)
+            assert (sd.dt, sd.time, sd.steps, sd.avg_time0) == (so.dt, so.time, so.steps, so.avg_time0)
+            for f in ("STRESS_AVG", "DPLSTRAIN_AVG", "STRAIN0", "COORD_AVG0", "STRESS", "STRAIN", "PLSTRAIN", "DELTA_PLSTRAIN"):
+                assert np.array_equal(dev.download(f), ora.download(f)), "%s, mode %s, after %d steps" % (f, mode, sd.steps)
+        assert so.n_return_mapping > host.nelem // 10 and np.abs(ora.download("DPLSTRAIN_AVG")).max() > 0
+
+
 def test_yield_heavy_chaotic_run_bit_exact():
     """Half of the mesh yielding every step: in default mode only statistics can be compared
     (test_yield_heavy_run_stays_statistically_identical); with one libm the 300-step trajectories
