@@ -271,7 +271,11 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
 {
     if (e_count < 0) e_count = h->ne;
     if (e_count == 0) return;
-    const bool defer = h->e2_two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
+    // (the first step of a call in the fused flow is a classic stress update: three waves per SIMD in the first of two
+    //  passes against two in one pass -- it keeps the classic rule when the mode is not pinned)
+    bool two_pass = h->e2_two_pass;
+    if (h->e2_defer == 2 && !h->e2geo_next && !h->use_graph) two_pass = h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
+    const bool defer = two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
     RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, 0, 1};
