@@ -2,8 +2,8 @@
 """Yield-heavy parity at scale (not part of the suite: a minute of 16 CPU threads): the fast-loading
 elasto-plastic model of tests/cfgs.py (YIELD) on a 1.6M-tet regular mesh, device against oracle with the
 portable libm on both sides (sin / cos / tan / atan2 are in play once elements yield), every field compared
-every few steps while the yielding fraction grows to ~10 % -- the stress update switches from two passes to one
-on the way (engine/launch.hpp: choose_e2_mode).
+every few steps while the yielding fraction grows to ~10 % (the fused step runs its stress update in one pass, the
+Mohr-Coulomb return and the QL fall-back inlined; DES_E2_DEFER=1 pins the two-pass variant).
 
   python tests/soak_yield.py [--res 800] [--steps 126] [--threads 16]
 """
