@@ -239,6 +239,12 @@ struct des_dev {
     bool iso;                 // des_dev_set_isostasy
     long long n_pt_iterations; // pseudo-transient iterations of the current des_dev_step call
     bool in_pt;                // host side of DevClock::pt
+    // engines of ONE process as each other's neighbours (des_dev_step_group): the ghost state moves by
+    // device-to-device copies between the message buffers instead of RCCL messages
+    des_dev **group;           // [group_n], indexed by rank (des_halo::nbr_rank); null: no group
+    int group_n, group_rank;
+    hipEvent_t ev_packed, ev_taken;   // messages packed (my stream) / the neighbours' messages copied out and unpacked
+    bool ddp_live;             // EN3 has left NMD increments in ddp[] that no pass has folded into the stress yet
     // profiling
     bool prof;
     std::vector<ProfRec> prof_recs;
@@ -296,6 +302,9 @@ void des_dev_destroy(des_dev *h)
     if (h->comm_stream) { hipStreamSynchronize(h->comm_stream); hipStreamDestroy(h->comm_stream); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->ev_packed) hipEventDestroy(h->ev_packed);
+    if (h->ev_taken) hipEventDestroy(h->ev_taken);
+    delete[] h->group;
     if (h->comm) ncclCommDestroy(h->comm);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (hipGraphExec_t g : h->graph_exec) if (g) hipGraphExecDestroy(g);
@@ -869,116 +878,173 @@ int des_dev_compute_dt(des_dev *h, double *dt)
 // local mesh alone (redundantly on the ghost region), then ONE exchange refreshes the ghost
 // region (des_halo, des_params.h), then the end-of-step geometry pass; the end of step t (E1's C
 // part) stays fused with the start of step t+1 (A part) whenever another step follows.
-int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
+//
+// The step is issued in three pieces -- step_front (everything up to the committed surface heights),
+// the exchange of the ghost region, step_back (the rest of the surface bookkeeping and the end-of-step
+// pass) -- so that the same launches serve des_dev_step (RCCL between the pieces) and
+// des_dev_step_group (several engines of one process, device-to-device copies between them).
+namespace {
+struct StepPlan {
+    bool multi, iso, nmd, graphs, pgraphs;
+    long long qcsi;
+    int nsteps;
+};
+
+void step_plan(des_dev *h, int nsteps, StepPlan &c)
 {
-    D2_FORWARD(h, step(h->d2, nsteps, out));
-    if (!h) return DES_ERR_INTERNAL;
-    hipSetDevice(h->device);
-    refresh_props(h);
-    const bool multi = h->nnbr > 0;
-    const bool iso = h->iso;
-    const bool nmd = h->p.is_using_mixed_stress && !iso;
+    c.nsteps = nsteps;
+    c.multi = h->nnbr > 0;
+    c.iso = h->iso;
+    c.nmd = h->p.is_using_mixed_stress && !c.iso;
     // DES_GRAPH=1: the launches of an interior step of a single-GPU call are replayed from a
     // hipGraph captured once (two graphs: with and without the compute_dt variant of E1)
-    const bool graphs = h->use_graph && !multi && !iso && !h->prof && !h->p.is_outputting_averaged_fields
-                        && !h->patch           // EN3 swaps the two coordinate buffers every step: nothing to replay
-                        && !h->p.has_PT;
+    c.graphs = h->use_graph && !c.multi && !c.iso && !h->prof && !h->p.is_outputting_averaged_fields
+               && !h->patch           // EN3 swaps the two coordinate buffers every step: nothing to replay
+               && !h->p.has_PT;
     // ... and of the fused step (EN1 .. S3 with E2<GEO>): EN1 and EN3 each swap the two coordinate
     // buffers, so the steps inside a call all start on the same one (the first step of a call swaps
     // once, N1 + EN3); three graphs per buffer, because the E2 after a compute_dt step rotates with
     // the dt of before it and a compute_dt step ends with the reduction
-    const bool pgraphs = h->use_graph && h->patch && !multi && !h->prof && e2geo_ok(h)
-                         && !h->p.is_outputting_averaged_fields;       // (k_avg_coord0 rides on some steps)
-    const long long qcsi = h->p.quality_check_step_interval;
-    int rc;
+    c.pgraphs = h->use_graph && h->patch && !c.multi && !h->prof && e2geo_ok(h)
+                && !h->p.is_outputting_averaged_fields;       // (k_avg_coord0 rides on some steps)
+    c.qcsi = h->p.quality_check_step_interval;
     h->n_pt_iterations = 0;
     if (h->e2_defer == 2 && e2geo_ok(h)) h->e2_two_pass = false;      // (choose_e2_mode: the fused step runs one pass)
-    for (int i = 0; i < nsteps; ++i) {
-        const long long step_no = iso ? h->steps_host : ++h->steps_host;
-        if (i == 0) launch_e1<MODE_A>(h);
-        if (graphs && i < nsteps - 1 && step_no % qcsi != 0) {
-            const int which = (step_no % 10 == 0) ? 1 : 0;
-            if (!h->graph_exec[which] || h->graph_two_pass[which] != h->e2_two_pass) {
-                if (h->graph_exec[which]) { hipGraphExecDestroy(h->graph_exec[which]); h->graph_exec[which] = nullptr; }
-                hipGraph_t g = nullptr;
-                HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                launch_n1(h); launch_e2(h); if (nmd) launch_n2(h); launch_force_pass(h);
-                launch_s2(h, 1);                                   // (no dhacc reset: those steps are not replayed)
-                launch_s3(h, true, true, true);
-                launch_e1_end(h, which ? 10 : 1, true);
-                if (which) launch_dt_finalize(h, nullptr);
-                HIP_OK(hipStreamEndCapture(h->stream, &g));
-                HIP_OK(hipGraphInstantiate(&h->graph_exec[which], g, nullptr, nullptr, 0));
-                hipGraphDestroy(g);
-                h->graph_two_pass[which] = h->e2_two_pass;
-            }
-            HIP_OK(hipGraphLaunch(h->graph_exec[which], h->stream));
-            continue;
-        }
-        h->e2_elide = h->elide_ok && i < nsteps - 1;
-        h->e2_not_last = i < nsteps - 1;
-        if (pgraphs && i > 0 && i < nsteps - 1 && step_no % qcsi != 0 && h->e2geo_next) {
-            const bool do_dt = (step_no % 10 == 0);
-            const int which = 2 * (do_dt ? 1 : (h->rot_prev_dt ? 2 : 0)) + (h->xt < h->xt_alt ? 0 : 1);
-            if (!h->pgraph_exec[which] || h->pgraph_two_pass[which] != h->e2_two_pass) {
-                if (h->pgraph_exec[which]) { hipGraphExecDestroy(h->pgraph_exec[which]); h->pgraph_exec[which] = nullptr; }
-                hipGraph_t g = nullptr;
-                d4 *const xt0 = h->xt;
-                HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                launch_en1(h); launch_e2(h); if (nmd) launch_n2(h); launch_force_pass(h);
-                launch_s2(h, 1);
-                launch_s3(h, true, true, true);
-                launch_e1_end(h, do_dt ? 10 : 1, true);
-                if (do_dt) launch_dt_finalize(h, nullptr);
-                HIP_OK(hipStreamEndCapture(h->stream, &g));
-                if (h->xt != xt0) { hipGraphDestroy(g); g_last_error = "graph capture: the coordinate buffers did not swap back"; return DES_ERR_INTERNAL; }
-                HIP_OK(hipGraphInstantiate(&h->pgraph_exec[which], g, nullptr, nullptr, 0));
-                hipGraphDestroy(g);
-                h->pgraph_two_pass[which] = h->e2_two_pass;
-            }
-            HIP_OK(hipGraphLaunch(h->pgraph_exec[which], h->stream));
-            h->rot_pending = false; h->e2geo_next = true; h->rot_prev_dt = do_dt;     // as the launches leave them
-            continue;
-        }
-        // inside a multi-step call the step before ended with the fused E1<C | A | NOREC>, and EN1
-        // forms the element terms itself; the first step of a call gathers what E1 stored (the
-        // caller may have uploaded fields in between)
-        if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h);
-        launch_e2(h);
-        if (nmd) launch_n2(h);
-        launch_force_pass(h);
-        if (h->p.has_PT && !iso && (rc = pt_loop(h))) return rc;
-        launch_s2(h, step_no);
-        const bool last = (i == nsteps - 1);
-        const bool overlapped = multi && h->overlap && !iso && h->e_int1 > h->e_int0;
-        if (overlapped) {
-            // exchange on the side stream || end-of-step pass of the interior elements; then the
-            // rest of the surface bookkeeping (it reads the ghost nodes' dh) and the two element
-            // groups that touch the ghost region
-            launch_s3(h, true, false, false);
-            if ((rc = exchange_begin(h))) return rc;
-            launch_e1_end(h, step_no, !last, E1_INTERIOR);
-            if ((rc = exchange_join(h))) return rc;
-            launch_avg_coord0(h, step_no);                 // owned and ghost coordinates alike: after the join
-            launch_s3(h, false, true, true);
-            launch_e1_end(h, step_no, !last, E1_GHOST_SIDE);
-            if (step_no % 10 == 0 && (rc = reduce_dt(h))) return rc;
-            continue;
-        }
-        if (multi) {
-            launch_s3(h, true, false, false);                      // commit the surface heights
-            if ((rc = exchange(h))) return rc;
-            launch_s3(h, false, true, true);
-        } else {
+}
+
+inline bool step_overlapped(const des_dev *h, const StepPlan &c)
+{
+    return c.multi && h->overlap && !c.iso && h->e_int1 > h->e_int0;
+}
+
+// Step i of the call up to the committed surface heights.  *whole = true: the step was replayed from a
+// hipGraph, end-of-step pass and compute_dt included (single GPU only) -- nothing is left to do for it.
+int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, bool *whole)
+{
+    int rc;
+    const int nsteps = c.nsteps;
+    const long long step_no = c.iso ? h->steps_host : ++h->steps_host;
+    *step_no_out = step_no;
+    *whole = false;
+    if (i == 0) launch_e1<MODE_A>(h);
+    if (c.graphs && i < nsteps - 1 && step_no % c.qcsi != 0) {
+        const int which = (step_no % 10 == 0) ? 1 : 0;
+        if (!h->graph_exec[which] || h->graph_two_pass[which] != h->e2_two_pass) {
+            if (h->graph_exec[which]) { hipGraphExecDestroy(h->graph_exec[which]); h->graph_exec[which] = nullptr; }
+            hipGraph_t g = nullptr;
+            HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            launch_n1(h); launch_e2(h); if (c.nmd) launch_n2(h); launch_force_pass(h);
+            launch_s2(h, 1);                                   // (no dhacc reset: those steps are not replayed)
             launch_s3(h, true, true, true);
+            launch_e1_end(h, which ? 10 : 1, true);
+            if (which) launch_dt_finalize(h, nullptr);
+            HIP_OK(hipStreamEndCapture(h->stream, &g));
+            HIP_OK(hipGraphInstantiate(&h->graph_exec[which], g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            h->graph_two_pass[which] = h->e2_two_pass;
         }
-        if (iso) {                                         // no averaging, no compute_dt in that loop
-            if (last) launch_e1<MODE_C>(h); else launch_e1<MODE_C | MODE_A>(h);
-            continue;
-        }
+        HIP_OK(hipGraphLaunch(h->graph_exec[which], h->stream));
+        *whole = true;
+        return DES_OK;
+    }
+    h->e2_elide = h->elide_ok && i < nsteps - 1;
+    h->e2_not_last = i < nsteps - 1;
+    if (c.pgraphs && i > 0 && i < nsteps - 1 && step_no % c.qcsi != 0 && h->e2geo_next) {
         const bool do_dt = (step_no % 10 == 0);
-        launch_avg_coord0(h, step_no);
-        launch_e1_end(h, step_no, !last);
+        const int which = 2 * (do_dt ? 1 : (h->rot_prev_dt ? 2 : 0)) + (h->xt < h->xt_alt ? 0 : 1);
+        if (!h->pgraph_exec[which] || h->pgraph_two_pass[which] != h->e2_two_pass) {
+            if (h->pgraph_exec[which]) { hipGraphExecDestroy(h->pgraph_exec[which]); h->pgraph_exec[which] = nullptr; }
+            hipGraph_t g = nullptr;
+            d4 *const xt0 = h->xt;
+            HIP_OK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            launch_en1(h); launch_e2(h); if (c.nmd) launch_n2(h); launch_force_pass(h);
+            launch_s2(h, 1);
+            launch_s3(h, true, true, true);
+            launch_e1_end(h, do_dt ? 10 : 1, true);
+            if (do_dt) launch_dt_finalize(h, nullptr);
+            HIP_OK(hipStreamEndCapture(h->stream, &g));
+            if (h->xt != xt0) { hipGraphDestroy(g); g_last_error = "graph capture: the coordinate buffers did not swap back"; return DES_ERR_INTERNAL; }
+            HIP_OK(hipGraphInstantiate(&h->pgraph_exec[which], g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            h->pgraph_two_pass[which] = h->e2_two_pass;
+        }
+        HIP_OK(hipGraphLaunch(h->pgraph_exec[which], h->stream));
+        h->rot_pending = false; h->e2geo_next = true; h->rot_prev_dt = do_dt;     // as the launches leave them
+        *whole = true;
+        return DES_OK;
+    }
+    // inside a multi-step call the step before ended with the fused E1<C | A | NOREC>, and EN1
+    // forms the element terms itself; the first step of a call gathers what E1 stored (the
+    // caller may have uploaded fields in between)
+    if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h);
+    launch_e2(h);
+    if (c.nmd) launch_n2(h);
+    launch_force_pass(h);
+    if (h->p.has_PT && !c.iso && (rc = pt_loop(h))) return rc;
+    launch_s2(h, step_no);
+    // decomposed: only the commit of the surface heights -- the rest of S3 reads the ghost nodes' dh
+    if (c.multi) launch_s3(h, true, false, false);
+    else         launch_s3(h, true, true, true);
+    return DES_OK;
+}
+
+// The rest of step i, once the exchange has been issued (decomposed meshes).  Returns through *do_dt
+// whether the compute_dt partials of this step are waiting for their reduction.
+int step_back(des_dev *h, const StepPlan &c, int i, long long step_no, bool *do_dt)
+{
+    int rc;
+    const bool last = (i == c.nsteps - 1);
+    *do_dt = false;
+    if (step_overlapped(h, c)) {
+        // the exchange runs on the side stream || end-of-step pass of the interior elements; then the
+        // rest of the surface bookkeeping (it reads the ghost nodes' dh) and the two element
+        // groups that touch the ghost region
+        launch_e1_end(h, step_no, !last, E1_INTERIOR);
+        if ((rc = exchange_join(h))) return rc;
+        launch_avg_coord0(h, step_no);                 // owned and ghost coordinates alike: after the join
+        launch_s3(h, false, true, true);
+        launch_e1_end(h, step_no, !last, E1_GHOST_SIDE);
+        *do_dt = (step_no % 10 == 0);
+        return DES_OK;
+    }
+    if (c.multi) launch_s3(h, false, true, true);
+    if (c.iso) {                                       // no averaging, no compute_dt in that loop
+        if (last) launch_e1<MODE_C>(h); else launch_e1<MODE_C | MODE_A>(h);
+        return DES_OK;
+    }
+    launch_avg_coord0(h, step_no);
+    launch_e1_end(h, step_no, !last);
+    *do_dt = (step_no % 10 == 0);
+    return DES_OK;
+}
+
+// after the last step of a call: the scalars of des_scalars from the (synchronised) clock
+void fill_scalars(const des_dev *h, des_scalars *out)
+{
+    const DevClock &c = *h->h_clk;
+    out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
+    out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min;
+    out->steps = c.steps; out->status = c.status; out->n_return_mapping = c.n_defer; out->avg_time0 = c.avg_time0;
+    out->n_pt_iterations = h->n_pt_iterations;
+}
+} // namespace
+
+int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
+{
+    D2_FORWARD(h, step(h->d2, nsteps, out));
+    if (!h) return DES_ERR_INTERNAL;
+    if (h->group) { g_last_error = "this engine belongs to a group: step it with des_dev_step_group"; return DES_ERR_INTERNAL; }
+    hipSetDevice(h->device);
+    refresh_props(h);
+    StepPlan c;
+    step_plan(h, nsteps, c);
+    int rc;
+    for (int i = 0; i < nsteps; ++i) {
+        long long step_no; bool whole, do_dt;
+        if ((rc = step_front(h, c, i, &step_no, &whole))) return rc;
+        if (whole) continue;
+        if (c.multi && (rc = step_overlapped(h, c) ? exchange_begin(h) : exchange(h))) return rc;
+        if ((rc = step_back(h, c, i, step_no, &do_dt))) return rc;
         if (do_dt && (rc = reduce_dt(h))) return rc;
     }
     // compute_mass gather of the last update_mesh, so that volume_n / mass / tmass hold the
@@ -995,19 +1061,122 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
         rc = sync_clock(h);
         if (rc) return rc;
         choose_e2_mode(h);
-        const DevClock &c = *h->h_clk;
-        out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
+        fill_scalars(h, out);
         if (h->comm_size > 1) {
             double l2sum = 0;
             HIP_OK(hipMemcpy(&l2sum, h->d_red + 6, 8, hipMemcpyDeviceToHost));
             out->l2_residual = std::sqrt(l2sum);
         }
-        out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min;
-        out->steps = c.steps; out->status = c.status; out->n_return_mapping = c.n_defer; out->avg_time0 = c.avg_time0;
-        out->n_pt_iterations = h->n_pt_iterations;
-        return c.status;
+        return h->h_clk->status;
     }
     return DES_OK;
+}
+
+// ---- several engines of one process as one decomposed model -------------------------------
+int des_dev_group_attach(des_dev **engines, int n)
+{
+    if (!engines || n < 1) return DES_ERR_INTERNAL;
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = engines[k];
+        D2_REFUSE(h, "the domain decomposition");
+        if (!h) return DES_ERR_INTERNAL;
+        if (h->comm) { g_last_error = "an engine with an RCCL communicator cannot join a group"; return DES_ERR_INTERNAL; }
+        for (int q = 0; q < h->nnbr; ++q)
+            if (h->nbr_rank[q] < 0 || h->nbr_rank[q] >= n || h->nbr_rank[q] == k) {
+                g_last_error = "des_halo::nbr_rank outside the group"; return DES_ERR_INTERNAL;
+            }
+    }
+    // every message must have its counterpart of the same length on the other side
+    for (int k = 0; k < n; ++k)
+        for (int q = 0; q < engines[k]->nnbr; ++q) {
+            const des_dev *h = engines[k], *o = engines[h->nbr_rank[q]];
+            int qo = -1;
+            for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
+            if (qo < 0 || o->send_off[qo + 1] - o->send_off[qo] != h->recv_off[q + 1] - h->recv_off[q]) {
+                g_last_error = "group: the exchange lists of two neighbours do not match"; return DES_ERR_INTERNAL;
+            }
+        }
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = engines[k];
+        hipSetDevice(h->device);
+        delete[] h->group;
+        h->group = new des_dev *[n];
+        for (int j = 0; j < n; ++j) h->group[j] = engines[j];
+        h->group_n = n; h->group_rank = k;
+        if (!h->ev_packed) HIP_OK(hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
+        if (!h->ev_taken) HIP_OK(hipEventCreateWithFlags(&h->ev_taken, hipEventDisableTiming));
+    }
+    return DES_OK;
+}
+
+int des_dev_group_detach(des_dev **engines, int n)
+{
+    if (!engines || n < 0) return DES_ERR_INTERNAL;
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = engines[k];
+        if (!h || h->d2) continue;
+        hipSetDevice(h->device);
+        hipStreamSynchronize(h->stream);
+        if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
+        delete[] h->group;
+        h->group = nullptr; h->group_n = 0; h->group_rank = 0;
+    }
+    return DES_OK;
+}
+
+int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
+{
+    if (!engines || n < 1 || nsteps < 0) return DES_ERR_INTERNAL;
+    for (int k = 0; k < n; ++k)
+        if (!engines[k] || engines[k]->d2 || engines[k]->group_n != n || engines[k]->group_rank != k || engines[k]->group[k] != engines[k]) {
+            g_last_error = "des_dev_step_group: not the group des_dev_group_attach was given"; return DES_ERR_INTERNAL;
+        }
+    std::vector<StepPlan> plan((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = engines[k];
+        hipSetDevice(h->device);
+        refresh_props(h);
+        step_plan(h, nsteps, plan[k]);
+        if (plan[k].graphs || plan[k].pgraphs || h->p.has_PT) { g_last_error = "des_dev_step_group: decomposed engines only (no hipGraph replay, no PT loop)"; return DES_ERR_UNSUPPORTED; }
+    }
+    int rc;
+    std::vector<long long> step_no((size_t)n);
+    for (int i = 0; i < nsteps; ++i) {
+        bool any_dt = false;
+        for (int k = 0; k < n; ++k) {                  // every engine's step up to its packed messages
+            des_dev *h = engines[k];
+            bool whole;
+            hipSetDevice(h->device);
+            if ((rc = step_front(h, plan[k], i, &step_no[k], &whole))) return rc;
+            if (plan[k].multi && (rc = exchange_local_pack(h))) return rc;
+        }
+        for (int k = 0; k < n; ++k) {                  // the messages change hands; the rest of the step
+            des_dev *h = engines[k];
+            bool do_dt;
+            hipSetDevice(h->device);
+            if (plan[k].multi && (rc = exchange_local_take(h, step_overlapped(h, plan[k]) ? h->comm_stream : h->stream))) return rc;
+            if ((rc = step_back(h, plan[k], i, step_no[k], &do_dt))) return rc;
+            any_dt = any_dt || do_dt;
+        }
+        if (any_dt && (rc = reduce_dt_group(engines, n))) return rc;
+    }
+    double l2sum = 0;
+    int status = DES_OK;
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = engines[k];
+        hipSetDevice(h->device);
+        if (nsteps > 0) launch_mass_gather(h);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
+        if (!out) continue;
+        if ((rc = sync_clock(h))) return rc;
+        choose_e2_mode(h);
+        fill_scalars(h, &out[k]);
+        l2sum += h->h_clk->l2_sum;                     // owned nodes only: every node counts once
+        if (h->h_clk->status) status = h->h_clk->status;
+    }
+    if (out) for (int k = 0; k < n; ++k) out[k].l2_residual = std::sqrt(l2sum);
+    return status;
 }
 
 // ---- domain decomposition ---------------------------------------------------------

@@ -6,6 +6,7 @@
 // The loop is des_run (include/des_run.h, mirroring dynearthsol.cxx:593-982); this file only
 // binds it to the HIP engine of include/des_dev.h.  There is no CPU fallback: without a GPU
 // the run stops with the reference's exit category 31 (EXIT_UNSUPPORTED_LIB).
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,7 +60,12 @@ int main(int argc, const char *argv[])
     // saved; with a remesher command (include/des_run.h) the run goes on from the remeshed pair.
     std::string overrides;
     int rc = 0;
+    const int max_rounds = 100;                    // (dynearthsol_amd/driver.py: run_with_remesher has the same cap)
     for (int round = 0; ; ++round) {
+        if (round >= max_rounds) {
+            std::fprintf(stderr, "Error: the mesh needed remeshing more than %d times\n", max_rounds);
+            return DES_ERR_UNSUPPORTED;
+        }
         int err = 0;
         des_host *host = des_host_create_nd(ndims, cfg.c_str(), nullptr, overrides.empty() ? nullptr : overrides.c_str(),
                                             (round == 0 && !mesh.empty()) ? mesh.c_str() : nullptr, &err);
@@ -73,7 +79,13 @@ int main(int argc, const char *argv[])
         rc = des_run(host, &api, device, quiet, &st);
         des_host_destroy(host);
         if (!st.remesh_needed || remesher.empty()) break;
-        const std::string cmd = remesher + " " + model + " " + std::to_string(st.last_frame);
+        // the model name goes into a shell command line: letters, digits and . _ - / + only
+        for (const char *q = model; *q; ++q)
+            if (!std::isalnum((unsigned char)*q) && !std::strchr("._-/+", *q)) {
+                std::fprintf(stderr, "Error: sim.modelname '%s' cannot be handed to a remesher command (character '%c')\n", model, *q);
+                return DES_ERR_UNSUPPORTED;
+            }
+        const std::string cmd = remesher + " '" + model + "' " + std::to_string(st.last_frame);
         if (!quiet) { std::printf("  Remeshing: %s\n", cmd.c_str()); std::fflush(stdout); }
         if (std::system(cmd.c_str()) != 0) {
             std::fprintf(stderr, "Error: the remesher command failed: %s\n", cmd.c_str());

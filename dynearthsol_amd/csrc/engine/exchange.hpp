@@ -59,6 +59,50 @@ int exchange_join(des_dev *h)
     return DES_OK;
 }
 
+// ---- the same exchange between engines of ONE process (des_dev_step_group) ---------------------
+// No communicator: a neighbour's message buffer is plain device memory of this process, so the
+// transfer is one device-to-device copy per neighbour, ordered by events instead of RCCL's
+// rendezvous -- ev_packed (my messages are complete) and ev_taken (I have copied my neighbours'
+// messages out: they may pack the next step's).  Same lists, same pack / unpack kernels, same
+// place in the step as the RCCL path; the group issues every engine's pack before any take.
+int exchange_local_pack(des_dev *h)
+{
+    if (h->nnbr == 0) return DES_OK;
+    const int ns = h->send_ptr[h->nnbr], nes = h->esend_ptr[h->nnbr];
+    for (int q = 0; q < h->nnbr; ++q)                      // (first step: never recorded, no wait)
+        HIP_OK(hipStreamWaitEvent(h->stream, h->group[h->nbr_rank[q]]->ev_taken, 0));
+    Launch l(h, K_EXCH);
+    hipLaunchKernelGGL(k_state_pack, dim3(nblk(ns + nes)), dim3(DES_BLOCK), 0, h->stream, ns, h->d_send_idx, h->d_send_noff,
+                       nes, h->d_esend_idx, h->d_send_eoff, h->xt, h->vm, h->dh_n, h->stress, pending_ddp(h), h->strain, h->plstrain,
+                       h->ne, h->d_sendbuf);
+    HIP_OK(hipEventRecord(h->ev_packed, h->stream));
+    return DES_OK;
+}
+
+// `xs`: the engine's stream, or its side stream (overlapped schedule: exchange_join follows)
+int exchange_local_take(des_dev *h, hipStream_t xs)
+{
+    if (h->nnbr == 0) return DES_OK;
+    const int nr = h->recv_ptr[h->nnbr], ner = h->erecv_ptr[h->nnbr];
+    const bool side = xs != h->stream;
+    if (side) HIP_OK(hipStreamWaitEvent(xs, h->ev_packed, 0));          // fork: behind everything this engine has issued
+    Launch l(h, K_EXCH, xs);
+    for (int q = 0; q < h->nnbr; ++q) {
+        des_dev *o = h->group[h->nbr_rank[q]];
+        int qo = 0;
+        while (o->nbr_rank[qo] != h->group_rank) ++qo;                  // (checked by des_dev_group_attach)
+        HIP_OK(hipStreamWaitEvent(xs, o->ev_packed, 0));
+        HIP_OK(hipMemcpyAsync(h->d_recvbuf + h->recv_off[q], o->d_sendbuf + o->send_off[qo],
+                              (size_t)(h->recv_off[q+1] - h->recv_off[q]) * sizeof(double), hipMemcpyDeviceToDevice, xs));
+    }
+    hipLaunchKernelGGL(k_state_unpack, dim3(nblk(nr + ner)), dim3(DES_BLOCK), 0, xs, nr, h->d_recv_idx, h->d_recv_noff,
+                       ner, h->d_erecv_idx, h->d_recv_eoff, h->xt, h->vm, h->dh_n, h->stress, pending_ddp(h), h->strain, h->plstrain,
+                       h->ne, h->d_recvbuf);
+    HIP_OK(hipEventRecord(h->ev_taken, xs));
+    if (side) HIP_OK(hipEventRecord(h->ev_join, xs));
+    return DES_OK;
+}
+
 // compute_dt across ranks: pack the six partials, MIN-allreduce, finalize
 int reduce_dt(des_dev *h)
 {
@@ -125,5 +169,30 @@ int pt_loop(des_dev *h)
     }
     if ((rc = set_pt(h, 0))) return rc;
     launch_vbcs_coord(h);                                  // apply_vbcs + update_coordinate of the step itself
+    return DES_OK;
+}
+
+// compute_dt across the engines of a group: the six partials of each, their minimum on the host (this
+// path serves tests and rehearsals; every 10th step), finalize on each
+int reduce_dt_group(des_dev **g, int n)
+{
+    double red[6], mine[6];
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = g[k];
+        hipSetDevice(h->device);
+        hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->d_red, h->dt_part, h->dt_part_cap,
+                           h->dt_parts_used);
+        h->dt_parts_used = 0;
+        HIP_OK(hipMemcpyAsync(mine, h->d_red, 48, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        for (int j = 0; j < 6; ++j) red[j] = k == 0 ? mine[j] : std::min(red[j], mine[j]);
+    }
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = g[k];
+        hipSetDevice(h->device);
+        HIP_OK(hipMemcpyAsync(h->d_red, red, 48, hipMemcpyHostToDevice, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));             // (red[] is a stack buffer)
+        launch_dt_finalize(h, h->d_red);
+    }
     return DES_OK;
 }

@@ -37,12 +37,17 @@ struct Launch {
 };
 
 // Timing experiments only (tools/launch_cost.py): DES_EXP_SKIP=e2r,s2,s3,dt leaves those launches
-// out, which makes the results WRONG wherever they had work -- never set outside that tool.
+// out, which makes the results WRONG wherever they had work.  Compiled into experiment builds alone
+// (make HIPFLAGS+=-DDES_EXPERIMENTS): the shipped library has no such switch.
+#ifdef DES_EXPERIMENTS
 inline bool exp_skip(const char *what)
 {
     static const char *env = std::getenv("DES_EXP_SKIP");
     return env && std::strstr(env, what) != nullptr;
 }
+#else
+inline bool exp_skip(const char *) { return false; }
+#endif
 
 inline MatData mat_data(const des_dev *h) { return MatData{ h->markers, h->mono, h->props, h->ptab }; }
 
@@ -75,9 +80,13 @@ void launch_e1(des_dev *h, int part = E1_ALL)
     if (MODE & MODE_DT) h->dt_parts_used += nblk8(c0 + c1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(E1_geom_rotate_strainrate<MODE>), dim3(nblk8(c0 + c1)), dim3(DES_BLOCK), 0, h->stream,
                        h->d_p, h->d_clk, h->ne, nblk(c0 + c1), b0, c0, b1, c1, h->conn, h->xt, h->vm, mat_data(h), h->radiogenic,
-                       h->topflag, h->stress, h->patch ? h->ddp : nullptr, h->strain, h->plstrain, h->volume, h->volume_old,
+                       h->topflag, h->stress, (h->patch && h->ddp_live) ? h->ddp : nullptr, h->strain, h->plstrain, h->volume, h->volume_old,
                        h->strain_rate, h->mrec, h->ttmp, h->spin, h->dt_part, h->dt_part_cap, dt_base);
     if (MODE & MODE_DEFER) { h->rot_pending = true; h->rot_prev_dt = (MODE & MODE_DT) != 0; }
+    // a C pass folds EN3's pending NMD increments into the stress (passes/e1.hpp): they are spent once its last part is
+    // launched -- a second end-of-step pass without a force pass in between then gets no ddp pointer and adds nothing
+    // (with MODE_DEFER the elements off the top surface are folded by the next stress update, launch_e2)
+    if ((MODE & MODE_C) && !(MODE & (MODE_INIT | MODE_DEFER)) && part != E1_INTERIOR) h->ddp_live = false;
 }
 
 // A fused end-of-step pass may leave rotate_stress to the next stress update when nothing reads the
@@ -196,7 +205,7 @@ inline int node_grid(const des_dev *h) { return (node_blocks(h) + 7) / 8 * 8; }
 inline int res_part_size(const des_dev *h) { return std::max(node_grid(h), h->patch ? (h->patch_nb + 7) / 8 * 8 : 0); }
 // EN3's NMD increments that E1 has not folded into the stress yet (between the force pass and the
 // end-of-step pass of a step outside the isostasy loop): what the ghost-region pack must add
-inline double *pending_ddp(const des_dev *h) { return (h->patch && h->p.is_using_mixed_stress && !h->iso) ? h->ddp : nullptr; }
+inline double *pending_ddp(const des_dev *h) { return (h->patch && h->ddp_live && h->p.is_using_mixed_stress && !h->iso) ? h->ddp : nullptr; }
 
 // nodes per node-kernel workgroup: 256, or 64 while that leaves fewer than two workgroups per CU
 // (a 137k-tet mesh has 31k nodes = 120 workgroups of 256 on 256 CUs, each walking 4-5 incidence
@@ -287,7 +296,7 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     const bool geo = h->e2geo_next;
     if (h->rot_pending || geo) {
         rp.spin = h->spin; rp.topflag = h->topflag; rp.prev_dt = h->rot_prev_dt ? 1 : 0; rp.vm = h->vm;
-        rp.ddp = (h->patch && h->p.is_using_mixed_stress && !h->iso) ? h->ddp : nullptr;
+        rp.ddp = pending_ddp(h);
         rp.outputs = (geo && h->e2_elide) ? 0 : 1;
         if (geo && h->p.is_outputting_averaged_fields) { rp.stress_avg = h->stress_avg; rp.strain0 = h->strain0; }
     }
@@ -315,7 +324,10 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                            h->etmp2, h->defer_list, count, rp);
     }
-    if (e_begin + e_count == h->ne) { h->rot_pending = false; h->e2geo_next = false; }   // (sub-range launches: the last one ends at ne)
+    if (e_begin + e_count == h->ne) {                      // (sub-range launches: the last one ends at ne)
+        if (h->rot_pending || geo) h->ddp_live = false;    // ... and has folded the pending NMD increments in
+        h->rot_pending = false; h->e2geo_next = false;
+    }
 }
 
 void launch_n2(des_dev *h)
@@ -413,6 +425,7 @@ void launch_en3(des_dev *h)
                            h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part);
     }
     std::swap(h->xt, h->xt_alt);               // the records EN3 wrote are the current ones from here on
+    if (h->p.is_using_mixed_stress && !h->iso) h->ddp_live = true;      // ddp[] now holds this step's NMD increments
 }
 
 // update_force + everything nodal that follows it in a step

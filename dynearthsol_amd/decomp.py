@@ -190,6 +190,72 @@ class TorchComm:
         return engine.dt_finalize(t.numpy())
 
 
+class DeviceGroup:
+    """`nranks` device engines of THIS process as the ranks of one decomposed model, stepped in lockstep by
+    des_dev_step_group: every rank runs des_dev_step's own launches (the fused multi-step path included) and
+    the ghost region changes hands by device-to-device copies -- the multi-GPU step at its real partition,
+    rehearsed on one GPU.  (A production run has one process per GPU and RCCL in the same place.)"""
+
+    def __init__(self, host, nranks, device=0):
+        from . import DeviceEngine, DesScalars, load_hip_lib
+        self.host, self.nranks = host, nranks
+        self.parts = [Partition(host, nranks, r) for r in range(nranks)]
+        self.engines = [DeviceEngine(p, device=device) for p in self.parts]
+        self._lib = load_hip_lib()
+        self._scalars = DesScalars
+        for e, p in zip(self.engines, self.parts):
+            e.set_halo(p)
+        self._arr = (C.c_void_p * nranks)(*[e._h for e in self.engines])
+        self._lib.des_dev_group_attach.argtypes = [C.c_void_p, C.c_int]
+        self._lib.des_dev_group_detach.argtypes = [C.c_void_p, C.c_int]
+        self._lib.des_dev_step_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        rc = self._lib.des_dev_group_attach(self._arr, nranks)
+        if rc:
+            raise DesError(rc, self._lib.des_dev_last_error().decode())
+        self._attached = True
+
+    def init_from_host(self):
+        """init() + the first compute_dt on every rank; returns the (common) dt."""
+        steppers = [PhasedStepper(e, p, None) for e, p in zip(self.engines, self.parts)]
+        comm = LoopbackComm(steppers)
+
+        class _NoReduce:
+            def reduce_dt(self, engine, recompute):
+                return None
+        for e, p in zip(self.engines, self.parts):
+            init_rank(e, p, _NoReduce())
+        dts = comm.reduce_dt_all(recompute=True)
+        assert all(d == dts[0] for d in dts)
+        return dts[0]
+
+    def step(self, nsteps):
+        out = (self._scalars * self.nranks)()
+        rc = self._lib.des_dev_step_group(self._arr, self.nranks, nsteps, out)
+        if rc:
+            raise DesError(rc, self._lib.des_dev_last_error().decode())
+        return list(out)
+
+    def download(self, field, ncomp, kind):
+        """the global SoA array of `field`, assembled from every rank's owned nodes / elements"""
+        n = self.host.nnode if kind == "node" else self.host.nelem
+        return assemble(self.parts, [e.download(field) for e in self.engines], ncomp, n, kind)
+
+    def close(self):
+        if self._attached:
+            self._lib.des_dev_group_detach(self._arr, self.nranks)
+            self._attached = False
+        for e in self.engines:
+            e.close()
+        for p in self.parts:
+            p.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def assemble(parts, locals_, ncomp, nglobal, kind):
     """Global SoA array from per-rank local arrays: owned nodes / owned elements (every node and
     every element of the global mesh has exactly one owner)."""

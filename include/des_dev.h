@@ -183,6 +183,19 @@ int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const doubl
 int des_dev_dt_partials(des_dev *h, double out[6], int recompute);
 int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt);
 
+/* Several engines of ONE process as the ranks of one decomposed model -- engines[r] is rank r of the
+ * des_halo lists (several engines on one GPU: tests and rehearsals of the multi-GPU step at its real
+ * partition; engines on several GPUs of one process where peer access is on).  des_dev_step_group is
+ * des_dev_step for all of them in lockstep: the same launches in the same order on every engine's own
+ * stream, the ghost region refreshed once per step by device-to-device copies between the engines'
+ * message buffers (events order them; no communicator, no host synchronisation but for the six
+ * compute_dt partials every 10th step).  `out`: NULL or n entries (l2_residual = over all ranks' owned
+ * nodes).  An attached engine refuses des_dev_step; des_dev_group_detach before destroying any member.
+ * New: the reference is single-process (dynearthsol.cxx:768-894 is what every rank runs). */
+int des_dev_group_attach(des_dev **engines, int n);
+int des_dev_group_detach(des_dev **engines, int n);
+int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out);
+
 const char *des_dev_last_error(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,115 @@
+"""BASELINE configs[3] at its real size, before hardware does it: the headline mesh (test-3d-big.cfg's
+box, the reference's TetGen at 460 m: 1,001,310 tets / 185,637 nodes, elasto-visco-plastic) cut 2, 4 and
+8 ways into node slabs (host/partition.cpp; the slab order is the reference's own renumbering,
+mesh.cxx:2742-2792), one device engine per slab -- all on the ONE GPU of this box -- stepped in lockstep by
+des_dev_step_group: every rank runs des_dev_step's own launch sequence (the fused step with E2<GEO>, the
+store elision, EN1 / EN3) and the ghost region changes hands once per step through the engines' message
+buffers, where a multi-GPU run has RCCL.  The result must be the single engine's, bit for bit, in every
+nodal and elemental field and in dt -- across three compute_dt steps.
+
+Also here: the resolution-scaled variant of examples/oblique-rift-3d.cfg SURVEY.md 8(d)-5 asks for (the
+file as written meshes to 2,991 tets), 8 ways, 1000 steps."""
+import os
+
+import numpy as np
+import pytest
+
+import cfgs
+import dynearthsol_amd as des
+from dynearthsol_amd.decomp import DeviceGroup
+
+pytestmark = pytest.mark.gpu
+
+MESH = des.reference_mesh("test-3d-big-460")
+OBLIQUE_MESH = des.reference_mesh("oblique-rift-3d-1250")
+
+NODE_FIELDS = (("COORD", 3), ("VEL", 3), ("TEMPERATURE", 1), ("MASS", 1), ("VOLUME_N", 1), ("FORCE", 3), ("DHACC", 1))
+ELEM_FIELDS = (("STRESS", 6), ("STRAIN", 6), ("STRAIN_RATE", 6), ("PLSTRAIN", 1), ("DELTA_PLSTRAIN", 1), ("VISCOSITY", 1),
+               ("VOLUME", 1), ("VOLUME_OLD", 1), ("DPRESSURE", 1))
+
+
+def _headline_host():
+    import bench
+    ov = "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\nmat.rheology_type = elasto-visco-plastic\n"
+    host = des.Host(cfg_text=bench.BENCH_CFG.format(res="460.0", xlen="400e3"), overrides=ov, mesh_file=MESH)
+    assert (host.nnode, host.nelem) == (185637, 1001310)
+    return host
+
+
+def _compare(group, ref, calls):
+    """`calls`: the step counts of successive calls, the same on both sides"""
+    for e in group.engines:
+        e.profile_enable(True)
+    for n in calls:
+        sref = ref.step(n)
+        sg = group.step(n)
+        for s in sg:
+            assert (s.dt, s.time, s.steps, s.status) == (sref.dt, sref.time, sref.steps, 0)
+    for f, c in NODE_FIELDS:
+        assert np.array_equal(group.download(f, c, "node"), ref.download(f)), f
+    for f, c in ELEM_FIELDS:
+        assert np.array_equal(group.download(f, c, "elem"), ref.download(f)), f
+    return [dict((name, calls_) for name, _, calls_ in e.profile_read()) for e in group.engines]
+
+
+@pytest.mark.skipif(MESH is None, reason="data/test-3d-big-460.desmesh.xz is missing")
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_headline_mesh_cut_n_ways_is_the_single_engine_bit_for_bit(nranks):
+    host = _headline_host()
+    ref = des.DeviceEngine(host)
+    dt_ref = ref.init_from_host(host)
+    group = DeviceGroup(host, nranks)
+    try:
+        assert group.init_from_host() == dt_ref
+        owned = sum(p.owned[1] - p.owned[0] for p in group.parts)
+        assert owned == host.nnode and sum(int(p.elem_owned.sum()) for p in group.parts) == host.nelem
+        ghost_share = sum(p.nelem for p in group.parts) / host.nelem - 1
+        print("%d ranks: %.1f %% ghost-region elements" % (nranks, 100 * ghost_share))
+        # 34 steps in calls of 33 + 1: compute_dt at steps 10, 20, 30; the first and the last step of a call take the
+        # classic passes, everything in between is the fused step
+        kern = _compare(group, ref, (33, 1))
+        for k in kern:
+            assert k.get("E2G_geom_rotate_update_stress", 0) >= 28, k       # the fused step ran on every rank
+            assert k.get("EN1_mass_temperature_dvoldt", 0) >= 28 and k.get("EN3_force_nodes", 0) == 34, k
+            assert k.get("ghost_exchange", 0) >= 34, k
+    finally:
+        group.close()
+
+
+@pytest.mark.skipif(MESH is None, reason="data/test-3d-big-460.desmesh.xz is missing")
+def test_headline_mesh_overlapped_schedule_across_real_neighbours(monkeypatch):
+    """DES_OVERLAP=1 on four real slabs of the headline mesh: transfer + unpack on every rank's side stream
+    while its main stream works, joined before anything reads the ghost region -- against the single engine."""
+    host = _headline_host()
+    ref = des.DeviceEngine(host)
+    dt_ref = ref.init_from_host(host)
+    monkeypatch.setenv("DES_OVERLAP", "1")
+    group = DeviceGroup(host, 4)
+    monkeypatch.delenv("DES_OVERLAP")
+    try:
+        assert all(e.comm_info()["overlapped"] for e in group.engines)
+        assert group.init_from_host() == dt_ref
+        _compare(group, ref, (23,))
+    finally:
+        group.close()
+
+
+@pytest.mark.skipif(OBLIQUE_MESH is None, reason="data/oblique-rift-3d-1250.desmesh.xz is missing")
+def test_oblique_rift_resolution_scaled_8_ways_1000_steps():
+    """examples/oblique-rift-3d.cfg (Mohr-Coulomb weak zone, two materials, vbc type 6, PREM reference
+    pressure) on the reference's TetGen mesh of its box at resolution = 1250 m instead of 5000: 8 slabs
+    against one engine for 1000 steps, yielding elements included (same device libm on both sides, so the
+    comparison is exact whatever the model does)."""
+    host = des.Host(cfg_text=cfgs.OBLIQUE, overrides="mesh.resolution = 1250\n", mesh_file=OBLIQUE_MESH)
+    assert host.nelem > 100000
+    ref = des.DeviceEngine(host)
+    dt_ref = ref.init_from_host(host)
+    group = DeviceGroup(host, 8)
+    try:
+        assert group.init_from_host() == dt_ref
+        _compare(group, ref, (400, 599, 1))
+        n_yield = int((ref.download("PLSTRAIN") > host.array("plstrain")).sum())
+        print("oblique rift at 1250 m: %d tets, %d elements have yielded in 1000 steps" % (host.nelem, n_yield))
+        assert n_yield > 0
+    finally:
+        group.close()
