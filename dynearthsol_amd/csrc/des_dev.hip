@@ -244,6 +244,12 @@ struct des_dev {
     des_dev **group;           // [group_n], indexed by rank (des_halo::nbr_rank); null: no group
     int group_n, group_rank;
     hipEvent_t ev_packed, ev_taken;   // messages packed (my stream) / the neighbours' messages copied out and unpacked
+    unsigned char *pb_top;     // [patch_nb] the block's patch holds a surface node
+    int2 *tfan;                // [nn] {position in top_nodes | fan size << 27, start of the fan in ssup_nodes}, {-1, 0} below the surface (passes/en1.hpp)
+    bool s2_defer;             // DES_S2_DEFER != 0 (read at create)
+    bool s2_pending;           // the surface step of the last step has not run: the next EN1 does it (s2_defer_ok)
+    bool edv_pending;
+    bool s2_skipped;           // this step's S2 / S3 launches were left out (step_front -> step_back)          // ... and the next stress update its edvacc_surf part
     bool ddp_live;             // EN3 has left NMD increments in ddp[] that no pass has folded into the stress yet
     // profiling
     bool prof;
@@ -254,6 +260,7 @@ struct des_dev {
 namespace des_hip {
 
 #include "passes/common.hpp"
+#include "passes/surface.hpp"
 #include "passes/e1.hpp"
 #include "passes/node_gather.hpp"
 #include "passes/n1.hpp"
@@ -264,7 +271,6 @@ namespace des_hip {
 #include "passes/en3.hpp"
 #include "passes/en1.hpp"
 #include "passes/en2.hpp"
-#include "passes/surface.hpp"
 #include "passes/small_kernels.hpp"
 #include "engine/patch.hpp"
 #include "engine/launch.hpp"
@@ -318,7 +324,7 @@ void des_dev_destroy(des_dev *h)
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
         h->radiogenic, h->markers, h->props, h->mono, h->defer_list, h->ptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
-        h->conn_surf, h->ssup_idx, h->ssup_arr, h->ssup_nodes, h->topflag, h->dh, h->edvacc,
+        h->conn_surf, h->ssup_idx, h->ssup_arr, h->ssup_nodes, h->topflag, h->tfan, h->pb_top, h->dh, h->edvacc,
         h->znew, h->bnormals, h->edge_vec, h->edge_slot };
     for (void *q : ptrs) if (q) hipFree(q);
     if (h->h_clk) hipHostFree(h->h_clk);
@@ -482,6 +488,18 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
                 CK(dev_alloc(h->pe_ptr, P.pe_ptr.size())); CK(dev_upload(h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size(), h->stream));
                 CK(dev_alloc(h->pe_pack, P.pe_pack.size())); CK(dev_upload(h->pe_pack, P.pe_pack.data(), P.pe_pack.size(), h->stream));
                 CK(dev_alloc(h->pn_ptr, P.pn_ptr.size())); CK(dev_upload(h->pn_ptr, P.pn_ptr.data(), P.pn_ptr.size(), h->stream));
+                {
+                    // surface nodes among a patch's foreign nodes: bit 31 of their pn_id entry; blocks whose patch has any
+                    // (EN1's deferred surface step, passes/en1.hpp)
+                    std::vector<unsigned char> is_top((size_t)nn, 0), pbt((size_t)P.nb, 0);
+                    for (int i = 0; i < mesh->ntop; ++i) is_top[mesh->top_nodes[i]] = 1;
+                    for (int b = 0; b < P.nb; ++b) {
+                        for (int n = b * P.npb; n < std::min(nn, (b + 1) * P.npb); ++n) pbt[b] |= is_top[n];
+                        for (int k = P.pn_ptr[b]; k < P.pn_ptr[b + 1]; ++k)
+                            if (is_top[P.pn_id[k]]) { P.pn_id[k] |= (int)0x80000000u; pbt[b] = 1; }
+                    }
+                    CK(dev_alloc(h->pb_top, pbt.size())); CK(dev_upload(h->pb_top, pbt.data(), pbt.size(), h->stream));
+                }
                 CK(dev_alloc(h->pn_id, P.pn_id.size())); CK(dev_upload(h->pn_id, P.pn_id.data(), P.pn_id.size(), h->stream));
                 CK(dev_alloc(h->ddp, (size_t)ne)); CK(dev_alloc(h->xt_alt, (size_t)nn));
                 HK(hipMemsetAsync(h->ddp, 0, 8*(size_t)ne, h->stream));
@@ -507,6 +525,8 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         // deferred rotate_stress (MODE_DEFER, passes/e1.hpp): on by default, DES_DEFER_ROT=0 keeps rotate_stress in E1
         const char *el = std::getenv("DES_E2_ELIDE");      // =0: every step stores every field
         h->elide_ok = !(el && el[0] == '0');
+        const char *sd = std::getenv("DES_S2_DEFER");      // =0: every step launches its own S2 / S3
+        h->s2_defer = !(sd && sd[0] == '0');
         const char *dr = std::getenv("DES_DEFER_ROT");
         h->defer_rot = !(dr && dr[0] == '0');
         if (h->defer_rot) { CK(dev_alloc(h->spin, (size_t)3*ne)); HK(hipMemsetAsync(h->spin, 0, 24*(size_t)ne, h->stream)); }
@@ -640,6 +660,16 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             std::vector<unsigned char> flag((size_t)ne, 0);
             for (int i = 0; i < h->ntop_elems; ++i) flag[mesh->top_elems[i]] = 1;
             CK(dev_alloc(h->topflag, (size_t)ne)); CK(dev_upload(h->topflag, flag.data(), (size_t)ne, h->stream));
+        }
+        if (h->patch && ntop) {
+            std::vector<int2> tf((size_t)nn, make_int2(-1, 0));
+            bool fits = true;                      // 4 bits for the fan size (a surface node of a tet mesh has ~6 facets)
+            for (int i = 0; i < h->ntop; ++i) {
+                const int jb = mesh->support_surf_idx[i], nf = mesh->support_surf_idx[i + 1] - jb;
+                fits = fits && nf >= 0 && nf <= 15;
+                tf[mesh->top_nodes[i]] = make_int2(i | (nf << 27), jb);
+            }
+            if (fits) { CK(dev_alloc(h->tfan, (size_t)nn)); CK(dev_upload(h->tfan, tf.data(), (size_t)nn, h->stream)); }
         }
         CK(dev_alloc(h->dh, ntop)); CK(dev_alloc(h->edvacc, etop)); CK(dev_alloc(h->znew, ntop));
         HK(hipMemsetAsync(h->dh, 0, 8*std::max<size_t>(ntop, 1), h->stream));
@@ -981,6 +1011,14 @@ int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, boo
     if (c.nmd) launch_n2(h);
     launch_force_pass(h);
     if (h->p.has_PT && !c.iso && (rc = pt_loop(h))) return rc;
+    if (s2_defer_ok(h, i < nsteps - 1, step_no)) {
+        // no S2 / S3 launch: the next step's EN1 and E2 do the surface step of this one; with diffusion switched off
+        // there is nothing to do at all (dh = 0: heights, dhacc and edvacc_surf keep their values)
+        h->s2_pending = surface_diffusion_on(h);
+        h->s2_skipped = true;
+        return DES_OK;
+    }
+    h->s2_skipped = false;
     launch_s2(h, step_no);
     // decomposed: only the commit of the surface heights -- the rest of S3 reads the ghost nodes' dh
     if (c.multi) launch_s3(h, true, false, false);
@@ -1002,12 +1040,12 @@ int step_back(des_dev *h, const StepPlan &c, int i, long long step_no, bool *do_
         launch_e1_end(h, step_no, !last, E1_INTERIOR);
         if ((rc = exchange_join(h))) return rc;
         launch_avg_coord0(h, step_no);                 // owned and ghost coordinates alike: after the join
-        launch_s3(h, false, true, true);
+        if (!h->s2_skipped) launch_s3(h, false, true, true);
         launch_e1_end(h, step_no, !last, E1_GHOST_SIDE);
         *do_dt = (step_no % 10 == 0);
         return DES_OK;
     }
-    if (c.multi) launch_s3(h, false, true, true);
+    if (c.multi && !h->s2_skipped) launch_s3(h, false, true, true);
     if (c.iso) {                                       // no averaging, no compute_dt in that loop
         if (last) launch_e1<MODE_C>(h); else launch_e1<MODE_C | MODE_A>(h);
         return DES_OK;

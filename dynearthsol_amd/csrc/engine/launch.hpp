@@ -144,6 +144,25 @@ inline bool e2geo_ok(const des_dev *h)
     return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h, true) && h->topflag && !h->overlap;
 }
 
+// The surface step (surface_processes, bc.cxx:1709-1872: S2 + S3 here) of a step can be left to the passes of the
+// NEXT step: its two launches do O(surface) work and cost ~5 us each whatever the mesh size -- 12 of a 57-us step on
+// a 137k-tet shard, 14 of 201 at 1M tets.  EN1 redoes the diffusion for the surface nodes of each patch while it
+// stages their records (passes/en1.hpp: SurfPending), writes the committed heights with its own nodes' records, and
+// the next stress update's tail workgroups add the edvacc_surf terms.  When: the next step starts with EN1 and runs
+// E2<GEO> (so nothing else reads coordinates in between), the step is a plain one -- no compute_dt (its finalize
+// reads max_surf_vel, and EN1 would see the new dt), no quality-check step (the dhacc reset follows the surface
+// step), no first step of an averaging interval (its coordinate snapshot wants the committed surface) -- and nobody
+// needs the step's scalars (l2 residual, max_surf_vel: the last step of a call never defers).  DES_S2_DEFER=0: off.
+inline bool s2_defer_ok(const des_dev *h, bool with_next, long long step_no)
+{
+    if (!h->s2_defer || !with_next || !e2geo_ok(h) || h->use_graph || !h->tfan) return false;
+    if (!(h->p.has_moving_mesh && h->ntop > 0)) return false;
+    const long long qcsi = h->p.quality_check_step_interval;
+    if (step_no % 10 == 0 || step_no % qcsi == 0) return false;
+    if (h->p.is_outputting_averaged_fields && step_no % qcsi == 1) return false;
+    return true;
+}
+
 // end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
 void launch_e1_end(des_dev *h, long long step_no, bool with_next, int part = E1_ALL)
 {
@@ -287,7 +306,7 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     const bool defer = two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
-    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, 0, 1};
+    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, nullptr, nullptr};
     if (h->p.is_outputting_averaged_fields && e2geo_ok(h) && e_begin == 0 && e_count == h->ne) {
         rp.dplstrain_avg = h->dplstrain_avg;
         rp.avg_dpl = h->e2_not_last ? 1 : 0;            // the last step of a call ends with E1 + k_average_fields
@@ -309,11 +328,18 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
                    : (defer ? E2_update_stress<desk::MathOcml, 1, 0> : E2_update_stress<desk::MathOcml, 0, 0>));
         // with EN3 the stress-bc facet workgroups ride here (with the classic pair: in E3's launch)
         const int nbf = (h->patch && e_begin == 0 && e_count == h->ne) ? nblk(h->nbcf) : 0;
-        hipLaunchKernelGGL(k, dim3(nblk8(e_count) + nbf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+        // ... and so does the edvacc_surf update of a surface step EN1 has just done for the step before (s2_defer_ok)
+        int nsf = 0;
+        if (h->edv_pending && h->patch && e_begin == 0 && e_count == h->ne) {
+            rp.edv_etop = h->etop; rp.edv_conn_surf = h->conn_surf; rp.edv_dh_n = h->dh_n; rp.edv_edvacc = h->edvacc;
+            nsf = nblk(h->etop);
+            h->edv_pending = false;
+        }
+        hipLaunchKernelGGL(k, dim3(nblk8(e_count) + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                            e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                            h->etmp2, h->defer_list, count,
-                           nblk8(e_count), nbf ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
+                           nblk8(e_count), (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
     }
     if (defer && !exp_skip("e2r")) {
         Launch l(h, K_E2R);
@@ -386,7 +412,15 @@ void launch_en1(des_dev *h)
         Launch l(h, K_EN1);
         void (*k)(const des_params *, DevClock *, int, int, int, int, const int *, const ulonglong2 *,
                   const int *, const int *, const int *, const unsigned *, const MatData, const double *, const d4 *, d4 *, d4 *,
-                  double *, double *, double *);
+                  double *, double *, double *, const SurfPending);
+        // the surface step of the step before, if its S2 / S3 launches were left out (s2_defer_ok)
+        SurfPending sp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (h->s2_pending) {
+            sp.tfan = h->tfan; sp.pb_top = h->pb_top; sp.ssup_nodes = h->ssup_nodes;
+            sp.dh = h->dh; sp.dhacc = h->dhacc; sp.dh_n = h->dh_n;
+            h->s2_pending = false;
+            h->edv_pending = true;                  // the edvacc_surf part rides in the next stress update
+        }
         const bool cm = h->const_mass;
         static const char *tenv = std::getenv("DES_EN1_THREADS");
         const int T = (tenv && std::atoi(tenv) == 512) ? 512 : 256;
@@ -398,7 +432,7 @@ void launch_en1(des_dev *h)
         hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, h->patch_nb,
                            h->patch_npb, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
                            mat_data(h), h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n,
-                           h->tmass, h->ntmp);
+                           h->tmass, h->ntmp, sp);
     }
     std::swap(h->xt, h->xt_alt);               // EN1 wrote the records with the new temperatures there
 }

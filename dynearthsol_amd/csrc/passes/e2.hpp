@@ -25,8 +25,11 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 // stress_avg / strain0 take the end-of-step stress / strain of the step BEFORE, which this pass holds in registers right
 // after the pending rotation; dplstrain_avg takes this step's delta_plstrain where it is formed (avg_dpl: unless the
 // classic end-of-step pass + k_average_fields follow this step, i.e. the last step of a call).  Null: not averaging.
+// edv_*: the edvacc_surf update of a surface step whose S2 / S3 launches were left out and whose diffusion EN1 has
+// just done (passes/en1.hpp: SurfPending): extra workgroups behind the stress-bc facet ones.  edv_etop = 0: none.
 struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; const d4 *vm; int outputs;
-                    double *stress_avg, *strain0, *dplstrain_avg; int avg_dpl, qcsi; };
+                    double *stress_avg, *strain0, *dplstrain_avg; int avg_dpl, qcsi;
+                    int edv_etop; const int *edv_conn_surf; const double *edv_dh_n; double *edv_edvacc; };
 
 // GEO = 1: this pass also does what is left of the end-of-step pass of the step before AND the strain
 // rate of this step, from the nodal records it gathers anyway: compute_volume after the volume swap
@@ -265,7 +268,10 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         // They need the temperature N1 has just updated and the coordinates of this step, and the
         // force pass consumes them; with EN3 there is no E3 launch for them to ride in.
         const int g = ((int)blockIdx.x - nblocks8) * DES_BLOCK + threadIdx.x;
+        const int nbcf_pad = (nbcf + DES_BLOCK - 1) / DES_BLOCK * DES_BLOCK;
         if (g < nbcf) bc_facet_work(p, g, conn, xt, md, f_elem, f_facet, f_kind, f_val, f_tmp);
+        else if (g >= nbcf_pad && g - nbcf_pad < rp.edv_etop)
+            edvacc_facet(g - nbcf_pad, rp.edv_etop, rp.edv_conn_surf, xt, rp.edv_dh_n, rp.edv_edvacc);
         return;
     }
     M::stage_begin();

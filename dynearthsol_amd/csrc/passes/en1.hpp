@@ -17,6 +17,22 @@
 // en1_ok): inside a multi-step call.  The new temperatures go to the other buffer of the
 // {x,y,z,T} pair (another block may still be reading this block's nodes); the host swaps.
 
+// The surface step of the step BEFORE, when its S2 / S3 launches were left out (engine/launch.hpp: s2_defer_ok):
+// simple_diffusion of every surface node of the patch (passes/surface.hpp: s2_node_dh, from the coordinates
+// update_coordinate left -- the buffer this pass only reads), the new height applied to the staged record, so that
+// every element term below and the record this block stores for its own nodes hold the committed surface, as
+// after k_s2 + k_s3_finalize; dh / dhacc / the nodal dh are stored for the block's own nodes.  Surface nodes of
+// the patch that belong to other blocks are recomputed here (their owners store them): a few tens of nodes per
+// block, against two launches of ~5 us each.  topidx == nullptr: nothing pending.
+// tfan[node] = {position in top_nodes | facets in its fan << 27, first entry of its fan in ssup_nodes}, {-1, 0} for
+// the nodes below the surface: one look-up instead of topidx -> ssup_idx.
+// pb_top[block] != 0: the block's patch holds a surface node at all (the others never touch tfan); the surface nodes
+// among a patch's foreign nodes carry bit 31 in pn_id (engine/patch.hpp), so only they cost a look-up.
+struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *ssup_nodes; double *dh, *dhacc, *dh_n; };
+#ifndef DES_EN1_S2_BATCH
+#define DES_EN1_S2_BATCH 2
+#endif
+
 #ifndef DES_EN1_NB
 #define DES_EN1_NB 8              // incidences per batch of LDS requests in the node phase
 #endif
@@ -30,7 +46,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
      const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag, const MatData md,
      const double *__restrict__ radiogenic, const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm,
-     double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp)
+     double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp, const SurfPending sp)
 {
     __shared__ d4 lxt[PN];
     __shared__ double lvx[PN], lvy[PN], lvz[PN];
@@ -67,11 +83,39 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         flag = bcflag[n];
     }
     // the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
-    for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
-        const int id = j < nown ? n0 + j : pn_id[h0 + j - nown];
-        lxt[j] = xt[id];
-        const d4 v = vm[id];
-        lvx[j] = v.x; lvy[j] = v.y; lvz[j] = v.z;
+    // (every record of the patch is requested before anything waits: the surface nodes, which need more, come after)
+    constexpr int ROUNDS = (PN + THREADS - 1) / THREADS;
+    int2 tf[ROUNDS];
+    int ids[ROUNDS];
+    const bool blk_top = sp.tfan && sp.pb_top[lb];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int j = threadIdx.x + r * THREADS;
+        tf[r] = make_int2(-1, 0);
+        ids[r] = 0;
+        if (j < nown + nh) {
+            const int raw = j < nown ? n0 + j : pn_id[h0 + j - nown];
+            const int id = raw & 0x7fffffff;
+            ids[r] = id;
+            lxt[j] = xt[id];
+            const d4 v = vm[id];
+            lvx[j] = v.x; lvy[j] = v.y; lvz[j] = v.z;
+            if (blk_top && (j < nown || raw < 0)) tf[r] = sp.tfan[id];
+        }
+    }
+    if (blk_top) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (tf[r].x < 0) continue;
+            const int j = threadIdx.x + r * THREADS;
+            const int id = ids[r];
+            const int ti = tf[r].x & 0x7ffffff, nf = tf[r].x >> 27;
+            // (dt: the step before ran with it too -- a step with a compute_dt keeps its own S2 / S3 launches)
+            const double dhacc_old = j < nown ? sp.dhacc[id] : 0.0;
+            const double d = s2_node_dh_range<DES_EN1_S2_BATCH>(id, tf[r].y, tf[r].y + nf, sp.ssup_nodes, xt, p->surface_diffusivity, dt);
+            lxt[j].z = lxt[j].z + d;                    // (this lane staged the record itself)
+            if (j < nown) { sp.dh[ti] = d; sp.dhacc[id] = dhacc_old + d; sp.dh_n[id] = d; }
+        }
     }
     __syncthreads();
     // the patch's elements: E1's element terms, recomputed

@@ -93,7 +93,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     }
     // (c) the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
-        const int id = j < nown ? n0 + j : pn_id[h0 + j - nown];
+        const int id = j < nown ? n0 + j : (pn_id[h0 + j - nown] & 0x7fffffff);      // (bit 31: a surface node, for EN1)
         lxt[j] = xt[id];
         if (nmd) lnt[j] = ntmp[id];
     }

@@ -99,6 +99,37 @@ def test_interior_steps_leave_out_output_only_stores_same_bits(monkeypatch):
         assert_bit_exact(dev, ora)                 # STATE holds those four fields
 
 
+@pytest.mark.parametrize("ov", ["mesh.quality_check_step_interval = 25\n",
+                                "mesh.quality_check_step_interval = 4\nsim.is_outputting_averaged_fields = yes\n",
+                                "control.surface_process_option = 0\n"])
+def test_surface_step_left_to_the_next_steps_passes_same_bits(monkeypatch, ov):
+    """Inside a multi-step call a plain step launches no S2 / S3: the next step's EN1 redoes the surface diffusion
+    for the surface nodes of each patch and commits the heights with its own records, the next stress update adds
+    the edvacc_surf terms (engine/launch.hpp: s2_defer_ok).  Every downloadable field -- DH, DHACC, EDVACC_SURF and
+    the averaged fields among them -- must equal the oracle's and the DES_S2_DEFER=0 engine's after calls of any
+    length, compute_dt (10, 20, ...) and quality-check steps falling first, last or in between; and the launches
+    must really be gone."""
+    host, dev, ora = pair(cfgs.EVP, overrides=ov)
+    monkeypatch.setenv("DES_S2_DEFER", "0")
+    host2 = des.Host(cfg_text=cfgs.make(**cfgs.EVP), overrides=ov)
+    dev0 = des.DeviceEngine(host2)
+    dev0.init_from_host(host2)
+    monkeypatch.delenv("DES_S2_DEFER")
+    dev.profile_enable(True); dev0.profile_enable(True)
+    fields = STATE + (("STRESS_AVG", "DPLSTRAIN_AVG", "STRAIN0", "COORD_AVG0") if "averaged" in ov else ())
+    total = 0
+    for n in (2, 8, 1, 4, 15, 11, 9, 3):
+        sd, s0, so = dev.step(n), dev0.step(n), ora.step(n)
+        total += n
+        assert (sd.dt, sd.time, sd.steps, sd.l2_residual, sd.max_surf_vel) == (s0.dt, s0.time, s0.steps, s0.l2_residual, s0.max_surf_vel)
+        assert (sd.dt, sd.time, sd.steps, sd.max_surf_vel) == (so.dt, so.time, so.steps, so.max_surf_vel)
+        assert_bit_exact(dev, dev0, fields)
+        assert_bit_exact(dev, ora, fields)
+    k, k0 = (dict((name, calls) for name, _, calls in d.profile_read()) for d in (dev, dev0))
+    assert k0["S3_edvacc_step_finalize"] == total and k["S3_edvacc_step_finalize"] < total - 15, (k, k0)
+    assert k.get("S2_surface_diffusion", 0) < k0.get("S2_surface_diffusion", 0) or "surface_process_option = 0" in ov
+
+
 def test_step_splitting_is_invisible_on_the_device():
     # E1 fuses the end of step t with the start of step t+1; the API boundary must not show
     host, dev, ora = pair(cfgs.EP)
