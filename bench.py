@@ -104,12 +104,18 @@ KERNEL_BYTES = {
     "N2_nmd_gather":              (48, 20),
     "E3_nmd_force":               (260, 40),
     "N3_force_velocity_coord":    (160, 160),
-    # E3 + N3 as one pass over node-block patches (csrc/passes/en3.hpp): credited with the
-    # algorithmic bytes of the two rows it replaces, although it no longer moves the 96 + 96 B
-    # per element of force temporaries that figure contains
-    "EN3_force_nodes":            (260 + 160, 40 + 160),
-    "EN1_mass_temperature_dvoldt": (224, 64),
-    "EN2_nmd_gather":             (48, 20),
+    # The node-block patch passes (csrc/passes/en1.hpp, en2.hpp, en3.hpp) are priced with THEIR OWN minimum, by
+    # SURVEY 8(d)'s rules (every array once per pass, nodal records once per node) -- not with the rows of the
+    # passes they replace, whose stored temporaries (ftmp 192 B, mrec / ttmp 64 B per element) they no longer move;
+    # KERNEL_ROWS keeps the rows' figures for `frac_of_replaced_survey_rows`.
+    # EN3: per element stress 48, volume 8, dpressure 8, marker word 4, ddp 8 W, patch record 16; per node {x,y,z,T} 32 R
+    #      + 32 W, {v,m} 32 R + 32 W, ntmp 8, force 24 W, force_residual 24 W, bcflag 4, CSR offset 4
+    "EN3_force_nodes":            (92, 192),
+    # EN1: per element marker word 4, patch record 16; per node {x,y,z,T} 32 R + 32 W, {v,m} 32 R + 32 W, volume_n 8 W,
+    #      tmass 8 W, ntmp 8 W, bcflag 4, CSR offset 4
+    "EN1_mass_temperature_dvoldt": (20, 160),
+    # EN2: per element etmp2 8, patch record 16; per node volume_n 8, ntmp 8 W, CSR offset 4
+    "EN2_nmd_gather":             (24, 20),
     # E2<GEO> (csrc/passes/e2.hpp): the stress update that also does the end-of-step pass of the step before
     # and this step's strain rate.  It stands for SURVEY's E1 and E2 rows (728 B per element) but moves less
     # than half of that -- no stress / strain round trip for rotate_stress, no strain_rate round trip, no
@@ -123,7 +129,8 @@ KERNEL_BYTES = {
     "E2G_geom_rotate_update_stress": (325, 64),
 }
 E2G_INTERIOR = (261, 64)          # read 141 (as above) + write stress 48, strain 48, dpressure 8, etmp 8, volume 8
-KERNEL_ROWS = {"E2G_geom_rotate_update_stress": (364 + 364, 56 + 8)}
+KERNEL_ROWS = {"E2G_geom_rotate_update_stress": (364 + 364, 56 + 8), "EN3_force_nodes": (260 + 160, 40 + 160),
+               "EN1_mass_temperature_dvoldt": (224, 64), "EN2_nmd_gather": (48, 20)}
 
 
 def main():
@@ -321,6 +328,12 @@ def main():
             # delta_plstrain and volume_old (nothing reads them before the next step overwrites them; every field a
             # caller can download after the call is the reference's).  DES_E2_ELIDE=0: every step stores them
             "interior_step_store_elision": os.environ.get("DES_E2_ELIDE", "1") != "0",
+            # the whole timed region is ONE des_dev_step call of `steps` steps: its first and last step take the classic
+            # passes, every 10th step carries a compute_dt, the others are the fused step (EN1, E2<GEO>, EN2, EN3; the
+            # surface step rides in the next step's EN1 / E2 unless DES_S2_DEFER=0) -- a shorter call has a larger share
+            # of the slower first / last steps
+            "steps_per_call": args.steps,
+            "surface_step_in_next_steps_passes": os.environ.get("DES_S2_DEFER", "1") != "0",
         },
     }
     if world > 1:
@@ -394,7 +407,7 @@ def main():
                 # rocprofv3 passes, MI355X_MICROARCH.md): tools/measure_traffic.py makes them for a
                 # named workload and commits the summary; it is quoted only for that very workload
                 traffic, tsrc = None, None
-                for tname in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+                for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
                     tpath = os.path.join(ROOT, "profiles", tname)
                     if not os.path.exists(tpath):
                         continue
@@ -414,7 +427,7 @@ def main():
                 if dom in KERNEL_ROWS:
                     # the same launch priced with the SURVEY rows it replaces (E1 + E2; evp + 24 / + 8)
                     re_, rn_ = KERNEL_ROWS[dom]
-                    if args.rheology == "elasto-visco-plastic":
+                    if args.rheology == "elasto-visco-plastic" and dom == "E2G_geom_rotate_update_stress":
                         re_, rn_ = re_ + 24, rn_ + 8
                     rows_bytes = re_ * ne_local + rn_ * (nn if world == 1 else part.nnode)
                     roof["frac_of_replaced_survey_rows"] = rows_bytes / (ms / calls * 1e-3) / 1e9 / HBM_PEAK_GBS

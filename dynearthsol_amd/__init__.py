@@ -127,7 +127,7 @@ def load_hip_lib():
     return _hip_lib
 
 
-LIBM_FN = {"pow": 0, "exp": 1, "sin": 2, "cos": 3, "tan": 4, "atan2": 5}       # DES_LIBM_* (des_dev.h)
+LIBM_FN = {"pow": 0, "exp": 1, "sin": 2, "cos": 3, "tan": 4, "atan2": 5, "sincos_s": 6, "sincos_c": 7}       # DES_LIBM_* (des_dev.h)
 
 
 def copy_ceiling(nbytes=1 << 30, reps=20, device=0):

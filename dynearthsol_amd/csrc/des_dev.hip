@@ -1444,7 +1444,7 @@ int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt)
 
 int des_dev_libm_eval(int device, int fn, long long n, const double *x, const double *y, double *out)
 {
-    if (fn < DES_LIBM_POW || fn > DES_LIBM_ATAN2 || n < 0 || !x || !out) return DES_ERR_INTERNAL;
+    if (fn < DES_LIBM_POW || fn > DES_LIBM_SINCOS_C || n < 0 || !x || !out) return DES_ERR_INTERNAL;
     if ((fn == DES_LIBM_POW || fn == DES_LIBM_ATAN2) && !y) return DES_ERR_INTERNAL;
     if (des_dev_device_count() <= device) { g_last_error = "no such HIP device"; return DES_ERR_UNSUPPORTED; }
     if (n == 0) return DES_OK;
@@ -1566,12 +1566,14 @@ int des_dev_copy_ceiling(int device, long long bytes, int reps, double *gbs)
     auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == DES_OK) { rc = DES_ERR_RESOURCE; g_last_error = hipGetErrorString(e); } return e == hipSuccess; };
     if (ok(hipMalloc((void **)&a, n * 16)) && ok(hipMalloc((void **)&b, n * 16)) && ok(hipMemset(a, 1, n * 16)) && ok(hipMemset(b, 0, n * 16))
         && ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1))) {
-        for (int variant = 0; variant < 6 && rc == DES_OK; ++variant) {
+        for (int variant = 0; variant < 7 && rc == DES_OK; ++variant) {
             const unsigned per_cu[3] = {4, 8, 16};
             const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * per_cu[variant % 3]);
+            if (variant == 6 && (n + 255) / 256 > 0x7fffffffull) break;
             auto launch = [&]() {
-                if (variant < 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_copy16<4, false>), dim3(grid), dim3(256), 0, 0, a, b, n);
-                else             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_copy16<4, true>), dim3(grid), dim3(256), 0, 0, a, b, n);
+                if (variant < 3)      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_copy16<4, false>), dim3(grid), dim3(256), 0, 0, a, b, n);
+                else if (variant < 6) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_copy16<4, true>), dim3(grid), dim3(256), 0, 0, a, b, n);
+                else                  hipLaunchKernelGGL(k_copy16_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a, b, n);   // one item per lane
             };
             launch();                                                                     // warm-up
             ok(hipEventRecord(e0, 0));

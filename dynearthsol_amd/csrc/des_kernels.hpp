@@ -163,6 +163,7 @@ struct MathOcml {
     static __device__ __forceinline__ double exp(double a) { return ::exp(a); }
     static __device__ __forceinline__ double sin(double a) { return ::sin(a); }
     static __device__ __forceinline__ double cos(double a) { return ::cos(a); }
+    static __device__ __forceinline__ double tan(double a) { return ::tan(a); }
     static __device__ __forceinline__ void sincos(double a, double *s, double *c) { ::sincos(a, s, c); }
     static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
 };
@@ -173,6 +174,7 @@ struct MathPortable {
     static __device__ __forceinline__ double exp(double a) { return deslibm::exp(a); }
     static __device__ __forceinline__ double sin(double a) { return deslibm::sin(a); }
     static __device__ __forceinline__ double cos(double a) { return deslibm::cos(a); }
+    static __device__ __forceinline__ double tan(double a) { return deslibm::tan(a); }
     static __device__ __forceinline__ void sincos(double a, double *s, double *c) { deslibm::sincos(a, s, c); }
     static __device__ __forceinline__ double atan2(double y, double x) { return deslibm::atan2(y, x); }
 };
@@ -238,15 +240,15 @@ __device__ __forceinline__ void plastic_props(const des_params *p, const Mix &mx
     hardn = h / n;
 
     const double DEG2RAD = M_PI / 180;
-    // one argument reduction for sin(phi) and tan(phi) = sin/cos (tan only enters the tension
-    // cut-off); sin(0) is exactly 0, so the usual zero dilation angle needs no call at all
-    double sphi, cphi;
-    M::sincos(phi * DEG2RAD, &sphi, &cphi);
+    // the reference's own calls: sin of both angles, tan of the friction angle (matprops.cxx:598-605) -- with the
+    // portable libm they return the C library's bits (des_libm_trig.hpp); sin(0) is exactly 0 there, so the usual
+    // zero dilation angle needs no call at all
+    double sphi = M::sin(phi * DEG2RAD);
     double spsi = (psi == 0) ? 0.0 : M::sin(psi * DEG2RAD);
     anphi = (1 + sphi) / (1 - sphi);
     anpsi = (1 + spsi) / (1 - spsi);
     amc = 2 * cohesion * sqrt(anphi);
-    ten_max = (phi == 0) ? p->tension_max : fmin(p->tension_max, cohesion / (sphi / cphi));
+    ten_max = (phi == 0) ? p->tension_max : fmin(p->tension_max, cohesion / M::tan(phi * DEG2RAD));
 }
 
 // ---------------------------------------------------------------------------------
@@ -277,8 +279,13 @@ __device__ __forceinline__ void dsyevc3(const double *a, double w[3])
     double phi = 27.0 * (0.25*sqr(c1)*(p - c1) + c0*(q + 27.0/4.0*c0));
     phi = (1.0/3.0) * M::atan2(sqrt(fabs(phi)), q);
 
-    double c = sqrt_p*M::cos(phi);
-    double s = (1.0/sqrt3)*sqrt_p*M::sin(phi);
+    // cos(phi) and sin(phi) of ONE argument reach the C library as one sincos call in any optimised build of the
+    // reference (gcc turns the pair into it from -O1 on; 3x3-C/Makefile: -O3 -ffast-math), and glibc's sincos is not
+    // bit for bit its sin and cos (des_libm_trig.hpp: g_sincos)
+    double sn_phi, cs_phi;
+    M::sincos(phi, &sn_phi, &cs_phi);
+    double c = sqrt_p*cs_phi;
+    double s = (1.0/sqrt3)*sqrt_p*sn_phi;
 
     w[1]  = (1.0/3.0)*(m - c);
     w[2]  = w[1] + s;

@@ -312,7 +312,7 @@ DES_LIBM_FN double cos_kernel(double x, double t)
     return w + (((1.0 - w) - hz) + (z * p - x * t));
 }
 
-DES_LIBM_FN void sincos(double x, double *s, double *c)
+DES_LIBM_FN void sincos_own(double x, double *s, double *c)
 {
     double r, t;                                     // inf / NaN turn into NaN on their own (inf - inf)
     const int n = rem_pio2(x, &r, &t);
@@ -322,9 +322,9 @@ DES_LIBM_FN void sincos(double x, double *s, double *c)
     *c = ((n + 1) & 2) ? -cv : cv;
 }
 
-DES_LIBM_FN double sin(double x) { double s, c; sincos(x, &s, &c); return s; }
-DES_LIBM_FN double cos(double x) { double s, c; sincos(x, &s, &c); return c; }
-DES_LIBM_FN double tan(double x) { double s, c; sincos(x, &s, &c); return s / c; }
+DES_LIBM_FN double sin_own(double x) { double s, c; sincos_own(x, &s, &c); return s; }
+DES_LIBM_FN double cos_own(double x) { double s, c; sincos_own(x, &s, &c); return c; }
+DES_LIBM_FN double tan_own(double x) { double s, c; sincos_own(x, &s, &c); return s / c; }
 
 // ---- atan2 ----------------------------------------------------------------------------
 DES_LIBM_FN double atan_pos(double x)              // x >= 0 (inf allowed)
@@ -344,7 +344,7 @@ DES_LIBM_FN double atan_pos(double x)              // x >= 0 (inf allowed)
     return hi + ((t * q + lo) + t);
 }
 
-DES_LIBM_FN double atan2(double y, double x)
+DES_LIBM_FN double atan2_own(double y, double x)
 {
     const bool sy = (bits(y) >> 63) != 0, sx = (bits(x) >> 63) != 0;
     const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
@@ -357,4 +357,15 @@ DES_LIBM_FN double atan2(double y, double x)
     return sy ? -r : r;
 }
 
+}  // namespace deslibm
+
+// sin / cos / tan / atan2 with the C library's bits (glibc 2.35), where its own range reduction applies
+#include "des_libm_trig.hpp"
+
+namespace deslibm {
+DES_LIBM_FN double sin(double x) { return g_sincos_in_range(x) ? g_sin(x) : sin_own(x); }
+DES_LIBM_FN double cos(double x) { return g_sincos_in_range(x) ? g_cos(x) : cos_own(x); }
+DES_LIBM_FN void sincos(double x, double *s, double *c) { if (g_sincos_in_range(x)) g_sincos(x, s, c); else sincos_own(x, s, c); }
+DES_LIBM_FN double tan(double x) { return g_tan_in_range(x) ? g_tan(x) : tan_own(x); }
+DES_LIBM_FN double atan2(double y, double x) { return g_atan2_in_range(y, x) ? g_atan2(y, x) : atan2_own(y, x); }
 }  // namespace deslibm

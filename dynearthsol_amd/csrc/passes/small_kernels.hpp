@@ -93,6 +93,8 @@ __global__ void k_libm_eval(int fn, long long n, const double *__restrict__ x, c
     case DES_LIBM_SIN:   r = deslibm::sin(a); break;
     case DES_LIBM_COS:   r = deslibm::cos(a); break;
     case DES_LIBM_TAN:   r = deslibm::tan(a); break;
+    case DES_LIBM_SINCOS_S: { double c_; deslibm::sincos(a, &r, &c_); break; }
+    case DES_LIBM_SINCOS_C: { double s_; deslibm::sincos(a, &s_, &r); break; }
     default:             r = deslibm::atan2(a, b); break;
     }
     out[i] = r;
@@ -163,6 +165,15 @@ __global__ void __launch_bounds__(256) k_copy16(const double2 *__restrict__ src,
         }
     }
     for (; i < n; i += stride) dst[i] = src[i];
+}
+
+// The same copy with ONE 16-byte item per lane and as many workgroups as it takes (no grid-stride loop): the launch
+// shape that reaches the guide's 6.2-6.3 TB/s from HBM on this machine (tools/plane_stream_bench.hip measured 6.19 with it
+// where the grid-stride shapes above stop at 4.6-4.9).
+__global__ void __launch_bounds__(256) k_copy16_flat(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 // des_dev_access_bench: the engine's memory access shapes on a KNOWN byte count, to calibrate the

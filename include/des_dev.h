@@ -105,7 +105,10 @@ int des_dev_check_nan(des_dev *h, long long *n_nan);
  * (y only for pow / atan2, else NULL).  Host pointers.  A CPU build of the same header must
  * give the same bits; no reference counterpart (the reference calls the C library:
  * rheology.cxx:260-300, matprops.cxx:380-418, 3x3-C/dsyevc3.c:60-70). */
-enum { DES_LIBM_POW = 0, DES_LIBM_EXP = 1, DES_LIBM_SIN = 2, DES_LIBM_COS = 3, DES_LIBM_TAN = 4, DES_LIBM_ATAN2 = 5 };
+/* (DES_LIBM_SINCOS_S / _C: the sine / the cosine as the C library's sincos(x, &s, &c) returns them -- what a compiler makes
+ * of sin(x), cos(x) of one argument, 3x3-C/dsyevc3.c:66-67 -- which are not bit for bit its sin(x) and cos(x)) */
+enum { DES_LIBM_POW = 0, DES_LIBM_EXP = 1, DES_LIBM_SIN = 2, DES_LIBM_COS = 3, DES_LIBM_TAN = 4, DES_LIBM_ATAN2 = 5,
+       DES_LIBM_SINCOS_S = 6, DES_LIBM_SINCOS_C = 7 };
 int des_dev_libm_eval(int device, int fn, long long n, const double *x, const double *y, double *out);
 
 /* Diagnostic: the device build of the reference's 3x3 symmetric eigen-solvers over n tensors, so

@@ -44,6 +44,9 @@ inline double m_exp(double a) { return g_portable_libm ? deslibm::exp(a) : std::
 inline double m_sin(double a) { return g_portable_libm ? deslibm::sin(a) : std::sin(a); }
 inline double m_cos(double a) { return g_portable_libm ? deslibm::cos(a) : std::cos(a); }
 inline double m_tan(double a) { return g_portable_libm ? deslibm::tan(a) : std::tan(a); }
+// cos and sin of one argument: ONE sincos call, as an optimised build of 3x3-C/dsyevc3.c:66-67 makes it (gcc's
+// sincos transformation, -O1 and up) -- written out so that it does not depend on this file's optimisation level
+inline void m_sincos(double a, double *s, double *c) { if (g_portable_libm) deslibm::sincos(a, s, c); else ::sincos(a, s, c); }
 inline double m_atan2(double y, double x) { return g_portable_libm ? deslibm::atan2(y, x) : std::atan2(y, x); }
 
 #ifndef DES_NDIMS
@@ -143,8 +146,10 @@ int dsyevc3(const double A[3][3], double w[3])
     double phi = 27.0 * (0.25*sqr(c1)*(p - c1) + c0*(q + 27.0/4.0*c0));
     phi = (1.0/3.0) * m_atan2(std::sqrt(std::fabs(phi)), q);
 
-    double c = sqrt_p*m_cos(phi);
-    double s = (1.0/sqrt3)*sqrt_p*m_sin(phi);
+    double sn_phi, cs_phi;
+    m_sincos(phi, &sn_phi, &cs_phi);
+    double c = sqrt_p*cs_phi;
+    double s = (1.0/sqrt3)*sqrt_p*sn_phi;
 
     w[1]  = (1.0/3.0)*(m - c);
     w[2]  = w[1] + s;
@@ -2669,6 +2674,8 @@ void des_oracle_libm_eval(int fn, long long n, const double *x, const double *y,
         case 2:  out[i] = deslibm::sin(a); break;
         case 3:  out[i] = deslibm::cos(a); break;
         case 4:  out[i] = deslibm::tan(a); break;
+        case 6:  { double c_; deslibm::sincos(a, &out[i], &c_); break; }
+        case 7:  { double s_; deslibm::sincos(a, &s_, &out[i]); break; }
         default: out[i] = deslibm::atan2(a, b); break;
         }
     }
@@ -2687,6 +2694,8 @@ void des_oracle_clib_eval(int fn, long long n, const double *x, const double *y,
         case 2:  out[i] = std::sin(a); break;
         case 3:  out[i] = std::cos(a); break;
         case 4:  out[i] = std::tan(a); break;
+        case 6:  { double c_; ::sincos(a, &out[i], &c_); break; }
+        case 7:  { double s_; ::sincos(a, &s_, &out[i]); break; }
         default: out[i] = std::atan2(a, b); break;
         }
     }

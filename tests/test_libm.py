@@ -39,13 +39,13 @@ def _samples(rng, n):
         "pow subnormal": (lu(5e-324, 2.2e-308), rng.uniform(-1, 1, n), "pow", 0.8),
         "exp": (rng.uniform(-700, 700, n), None, "exp", 0.52),
         "exp small": (lu(1e-20, 1) * rng.choice([-1, 1], n), None, "exp", 0.52),
-        "sin": (rng.uniform(-3.2, 3.2, n), None, "sin", 0.9),
-        "cos": (rng.uniform(-3.2, 3.2, n), None, "cos", 0.9),
-        "sin far": (rng.uniform(-1e5, 1e5, n), None, "sin", 0.9),
-        "cos far": (rng.uniform(-1e5, 1e5, n), None, "cos", 0.9),
-        "tan": (rng.uniform(0, 1.5533, n), None, "tan", 2.5),
-        "atan2": (rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), "atan2", 1.7),
-        "atan2 wide": (lu(1e-30, 1e30), lu(1e-30, 1e30) * rng.choice([-1, 1], n), "atan2", 1.7),
+        "sin": (rng.uniform(-3.2, 3.2, n), None, "sin", 0.56),
+        "cos": (rng.uniform(-3.2, 3.2, n), None, "cos", 0.56),
+        "sin far": (rng.uniform(-1e5, 1e5, n), None, "sin", 0.56),
+        "cos far": (rng.uniform(-1e5, 1e5, n), None, "cos", 0.56),
+        "tan": (rng.uniform(0, 1.5533, n), None, "tan", 0.65),
+        "atan2": (rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), "atan2", 0.6),
+        "atan2 wide": (lu(1e-30, 1e30), lu(1e-30, 1e30) * rng.choice([-1, 1], n), "atan2", 0.6),
     }
 
 
@@ -134,6 +134,34 @@ def _c_library_cases(rng, n):
     }
 
 
+def _c_library_trig_cases(rng, n):
+    """Arguments of the trigonometric calls on the path -- plastic_props (matprops.cxx:598-605: sin, tan of angles in
+    degrees x pi/180) and the Kopp solver (3x3-C/dsyevc3.c:64-67: atan2(sqrt|.|, q), then cos / sin of a third of it,
+    which a compiler turns into one sincos) -- and far beyond: every branch of s_sin.c / s_tan.c / e_atan2.c the
+    restatement covers (des_libm_trig.hpp)."""
+    lu = lambda a, b: np.exp(rng.uniform(np.log(a), np.log(b), n))
+    sgn = lambda: rng.choice([-1.0, 1.0], n)
+    cases = {}
+    for fn in ("sin", "cos", "sincos_s", "sincos_c"):
+        cases[fn + " angles of the path"] = (fn, rng.uniform(0, 1.6, n), None)
+        cases[fn + " |x| < 3.2"] = (fn, rng.uniform(-3.2, 3.2, n), None)
+        cases[fn + " |x| < 1e5"] = (fn, rng.uniform(-1e5, 1e5, n), None)
+        cases[fn + " |x| < 1.05e8"] = (fn, rng.uniform(-1.05e8, 1.05e8, n), None)
+        cases[fn + " tiny"] = (fn, lu(1e-320, 1) * sgn(), None)
+    cases["tan angles of the path"] = ("tan", rng.uniform(0, 1.5707, n), None)
+    cases["tan |x| < 25"] = ("tan", rng.uniform(-25, 25, n), None)
+    cases["tan |x| < 1e8"] = ("tan", rng.uniform(-1e8, 1e8, n), None)
+    cases["tan tiny"] = ("tan", lu(1e-320, 1) * sgn(), None)
+    cases["tan near pi/2"] = ("tan", (np.pi / 2 + rng.integers(-3, 4, n) * np.pi) + lu(1e-12, 1e-2) * sgn(), None)
+    q = lu(1e-40, 1e80)
+    cases["atan2 Cardano"] = ("atan2", q * lu(1e-9, 1e9), q * sgn())
+    cases["atan2 |.| < 10"] = ("atan2", rng.uniform(-10, 10, n), rng.uniform(-10, 10, n))
+    cases["atan2 wide"] = ("atan2", lu(1e-300, 1e300) * sgn(), lu(1e-300, 1e300) * sgn())
+    cases["atan2 extreme ratios"] = ("atan2", lu(1e-30, 1e30) * sgn(), lu(1e-30, 1e30) * lu(1e-20, 1e20) * sgn())
+    cases["atan2 near the axes and the diagonals"] = ("atan2", 1.0 + lu(1e-16, 1e-1) * sgn(), sgn() * (1.0 + lu(1e-16, 1e-1) * sgn()))
+    return cases
+
+
 def _mismatches(a, b):
     return int(((a.view(np.uint64) != b.view(np.uint64)) & ~(np.isnan(a) & np.isnan(b))).sum())
 
@@ -160,6 +188,61 @@ def test_pow_exp_return_the_c_librarys_bits():
     assert _mismatches(oracle_libm_eval("exp", e), oracle_libm_eval("exp", e, clib=True)) == 0
     xs, ys = rng.uniform(1e-3, 1e-1, 200000), rng.uniform(100, 160, 200000)
     assert _mismatches(oracle_libm_eval("pow", xs, ys), oracle_libm_eval("pow", xs, ys, clib=True)) == 0
+
+
+@needs_glibc_fma
+def test_trig_return_the_c_librarys_bits():
+    """CPU build of deslibm::sin / cos / sincos / tan / atan2 against the host's C library: 3.4e7 arguments, special
+    values included -- no mismatch.  (sincos is compared with ::sincos, which in glibc 2.35 has no FMA variant and is
+    not bit for bit sin and cos.)"""
+    rng = np.random.default_rng(2031)
+    total = 0
+    for name, (fn, x, y) in _c_library_trig_cases(rng, 1_000_000).items():
+        ours, libc = oracle_libm_eval(fn, x, y, omp=True), oracle_libm_eval(fn, x, y, clib=True, omp=True)
+        assert _mismatches(ours, libc) == 0, (name, _mismatches(ours, libc))
+        total += x.size
+    assert total >= 30_000_000
+    inf, nan = np.inf, np.nan
+    v = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0, -2.0, 3.0, inf, -inf, nan, 5e-324, -5e-324, 1e-310, 1e308, -1e308,
+                  2.2250738585072014e-308, 0.126, 0.855469, 2.426265, 0.0608, 0.787, 25.0, 1e8, 105414350.0, 0.0625, 1e300, 1e-300])
+    for fn in ("sin", "cos", "sincos_s", "sincos_c", "tan"):
+        w = v[~(np.abs(v) > 1e8) | ~np.isfinite(v)]          # (beyond its own reduction glibc calls __branred: not restated)
+        assert _mismatches(oracle_libm_eval(fn, w), oracle_libm_eval(fn, w, clib=True)) == 0, fn
+    Y, X = [a.ravel().copy() for a in np.meshgrid(v, v)]
+    assert _mismatches(oracle_libm_eval("atan2", Y, X), oracle_libm_eval("atan2", Y, X, clib=True)) == 0
+    # the neighbourhoods of the branch points of the three routines
+    for fn, pts in (("sin", (0.126, 0.855469, 2.426265)), ("cos", (0.855469, 2.426265)), ("tan", (1.259e-8, 0.0608, 0.787, 25.0))):
+        for p0 in pts:
+            x = np.nextafter(p0, 0) + np.arange(-2000, 2000) * np.spacing(p0)
+            x = np.concatenate([x, -x])
+            assert _mismatches(oracle_libm_eval(fn, x), oracle_libm_eval(fn, x, clib=True)) == 0, (fn, p0)
+    u = np.concatenate([0.0625 + np.arange(-2000, 2000) * np.spacing(0.0625), 1.0 + np.arange(-2000, 2000) * np.spacing(0.5)])
+    for sx in (1.0, -1.0):
+        one = np.full(u.size, sx)
+        assert _mismatches(oracle_libm_eval("atan2", u, one), oracle_libm_eval("atan2", u, one, clib=True)) == 0
+        assert _mismatches(oracle_libm_eval("atan2", np.abs(one), sx * u), oracle_libm_eval("atan2", np.abs(one), sx * u, clib=True)) == 0
+
+
+def test_trig_tables_equal_the_c_librarys():
+    """des_libm_trig_tables.hpp against the tables of this image's static libm (tools/gen_libm_trig_tables.py reads
+    them out of it: they cannot be recomputed, the library's low words are not the correctly rounded remainders)."""
+    import glob
+    import re
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if not glob.glob("/usr/lib/x86_64-linux-gnu/libm-2.35.a"):
+        pytest.skip("no static libm of glibc 2.35 to read the tables from")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_libm_trig_tables", os.path.join(sys_path, "gen_libm_trig_tables.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "dynearthsol_amd", "csrc", "des_libm_trig_tables.hpp")) as f:
+        src = f.read()
+    for name, member, sym in (("des_sincostab", "sincostab.o", "__sincostab"), ("des_tan_xfg", "s_tan-fma.o", "xfg.12"),
+                              ("des_atan_cij", "e_atan2-fma.o", "cij")):
+        m = re.search(r"double %s\[\d+\] = \{(.*?)\};" % name, src, re.S)
+        ours = np.array([float(t) for t in m.group(1).replace("\n", " ").split(",") if t.strip()])
+        assert np.array_equal(ours.view(np.uint64), np.array(gen.table(member, sym)).view(np.uint64)), name
 
 
 def test_tables_equal_the_c_librarys():
@@ -226,6 +309,21 @@ def test_device_pow_exp_return_the_c_librarys_bits():
         assert _mismatches(dev, libc) == 0, (name, _mismatches(dev, libc))
         total += x.size
     assert total >= 20_000_000
+
+
+@pytest.mark.gpu
+@needs_glibc_fma
+def test_device_trig_return_the_c_librarys_bits():
+    """The gfx950 build of sin / cos / sincos / tan / atan2 against the C library of the GPU box's host: 3.4e7
+    arguments, no mismatch."""
+    import dynearthsol_amd as des
+    rng = np.random.default_rng(2032)
+    total = 0
+    for name, (fn, x, y) in _c_library_trig_cases(rng, 1_000_000).items():
+        dev, libc = des.libm_eval(fn, x, y), oracle_libm_eval(fn, x, y, clib=True, omp=True)
+        assert _mismatches(dev, libc) == 0, (name, _mismatches(dev, libc))
+        total += x.size
+    assert total >= 30_000_000
 
 
 @pytest.mark.gpu

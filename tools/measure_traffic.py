@@ -78,7 +78,7 @@ def main():
                   "traffic_bytes_per_launch": (fv / cal["fetch"] + wv / cal["write"]) * 1024}
         print("%-28s FETCH %.1f MiB raw, WRITE %.1f MiB -> traffic %.1f MB/launch" % (k, fv / 1024, wv / 1024, res[k]["traffic_bytes_per_launch"] / 1e6))
     # (on the GPU box only gpurun_out/ travels back: DES_PROFILE_OUT=gpurun_out/<dir>, then copy to profiles/)
-    json.dump(res, open(os.path.join(os.environ.get("DES_PROFILE_OUT", os.path.join(ROOT, "profiles")), "r02_pmc_traffic.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(os.environ.get("DES_PROFILE_OUT", os.path.join(ROOT, "profiles")), os.environ.get("DES_TRAFFIC_NAME", "r03_pmc_traffic.json")), "w"), indent=1)
 
 
 if __name__ == "__main__":
