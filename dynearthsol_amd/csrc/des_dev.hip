@@ -168,6 +168,7 @@ struct des_dev {
     bool e2_two_pass;                     // the current choice
     int *mono;                            // [ne] (material << 16) | count of single-material elements, else -1
     double *ptab;                         // [nmat][DES_PTAB_CNT][5] property means of single-material elements
+    double *pptab;                        // [nmat][DES_PPTAB_CNT][3][5] plastic_props of single-material elements by weakening regime
     unsigned char *topflag;               // element touches the top surface (Variables::top_elems)
     double *props;                        // [5][ne] bulkm, shearm, phi, cp, k  (nmat > 1 only)
     // temporaries
@@ -322,7 +323,7 @@ void des_dev_destroy(des_dev *h)
         h->d_send_eoff, h->d_recv_noff, h->d_recv_eoff, h->stress, h->strain,
         h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->volume, h->volume_old, h->dpressure,
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
-        h->radiogenic, h->markers, h->props, h->mono, h->defer_list, h->ptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
+        h->radiogenic, h->markers, h->props, h->mono, h->defer_list, h->ptab, h->pptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
         h->conn_surf, h->ssup_idx, h->ssup_arr, h->ssup_nodes, h->topflag, h->tfan, h->pb_top, h->dh, h->edvacc,
         h->znew, h->bnormals, h->edge_vec, h->edge_slot };
@@ -535,6 +536,16 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         CK(dev_alloc(h->props, (size_t)5*ne));
         CK(dev_alloc(h->ptab, (size_t)nmat * DES_PTAB_CNT * 5));
         hipLaunchKernelGGL(k_ptab, dim3((nmat * DES_PTAB_CNT + 63) / 64), dim3(64), 0, h->stream, h->d_p, h->ptab);
+    }
+    if (params->rheol_type == DES_RH_EP || params->rheol_type == DES_RH_EVP) {
+        // plastic_props outside the linear weakening range, by (material, marker count, regime): DES_PPTAB=0 switches it off
+        const char *pp = std::getenv("DES_PPTAB");
+        if (!(pp && pp[0] == '0')) {
+            const int n = nmat * DES_PPTAB_CNT * 3;
+            CK(dev_alloc(h->pptab, (size_t)n * 5));
+            if (h->portable_libm) hipLaunchKernelGGL(k_pptab<desk::MathPortable>, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_p, h->pptab);
+            else                  hipLaunchKernelGGL(k_pptab<desk::MathOcml>, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_p, h->pptab);
+        }
     }
     CK(dev_alloc(h->mrec, (size_t)ne)); CK(dev_alloc(h->ttmp, (size_t)ne)); CK(dev_alloc(h->etmp2, (size_t)ne));
     CK(dev_alloc(h->ftmp, (size_t)12*ne));

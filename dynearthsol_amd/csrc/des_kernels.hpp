@@ -207,11 +207,26 @@ __device__ __forceinline__ double mat_visc(const des_params *p, const ViscTerms 
 }
 
 // matprops.cxx:380-418 + 589-606
+// pptab (may be null): the five results for a single-material element by (material, marker count, weakening regime),
+// [nmat][DES_PPTAB_CNT][3][5], filled once per engine by THIS function (des_dev.hip: k_pptab) -- outside the linear
+// weakening range the results depend on nothing else, so every such element reads five doubles instead of running
+// sin, tan, a square root and five divisions.  Regimes: 0 pls < pls0; 1 pls == pls0 (the interpolation at q = 0:
+// the values of regime 0, but its hardening modulus); 2 pls >= pls1.  Anything else is computed below.
+#define DES_PPTAB_CNT 64
 template <class M>
 __device__ __forceinline__ void plastic_props(const des_params *p, const Mix &mx, double pls,
                                               double &amc, double &anphi, double &anpsi,
-                                              double &hardn, double &ten_max)
+                                              double &hardn, double &ten_max, const double *__restrict__ pptab = nullptr)
 {
+    if (pptab && !mx.mk && mx.cnt > 0 && mx.cnt < DES_PPTAB_CNT) {
+        const double p0 = p->pls0[mx.mat], p1 = p->pls1[mx.mat];
+        const int regime = (pls < p0) ? 0 : ((pls < p1) ? ((pls == p0) ? 1 : -1) : 2);
+        if (regime >= 0) {
+            const double *t = pptab + (((size_t)mx.mat * DES_PPTAB_CNT + mx.cnt) * 3 + regime) * 5;
+            amc = t[0]; anphi = t[1]; anpsi = t[2]; hardn = t[3]; ten_max = t[4];
+            return;
+        }
+    }
     double c = 0, f = 0, d = 0, h = 0;
     int n = 0;
     for (int m = 0; m < p->nmat; m++) {

@@ -49,7 +49,7 @@ inline bool exp_skip(const char *what)
 inline bool exp_skip(const char *) { return false; }
 #endif
 
-inline MatData mat_data(const des_dev *h) { return MatData{ h->markers, h->mono, h->props, h->ptab }; }
+inline MatData mat_data(const des_dev *h) { return MatData{ h->markers, h->mono, h->props, h->ptab, h->pptab }; }
 
 void refresh_props(des_dev *h)
 {

@@ -93,7 +93,7 @@ __device__ __forceinline__ PatchElem patch_elem_unpack(const ulonglong2 r)
 //                       `count` markers (the means are count-dependent in the last bit:
 //                       count / (count / s)), so those elements read a cached table row
 #define DES_PTAB_CNT 64
-struct MatData { const int *markers; const int *mono; const double *props; const double *ptab; };
+struct MatData { const int *markers; const int *mono; const double *props; const double *ptab; const double *pptab; };
 
 __device__ __forceinline__ desk::Mix mix_of(const MatData &md, int nmat, int e)
 {
@@ -153,6 +153,22 @@ k_props(const des_params *p, const int *markers, double *props, int *mono, int n
     props[(size_t)2*ne + e] = desk::arithmetic_mean(p->porosity, mk, nmat);
     props[(size_t)3*ne + e] = desk::arithmetic_mean(p->heat_capacity, mk, nmat);
     props[(size_t)4*ne + e] = desk::arithmetic_mean(p->therm_cond, mk, nmat);
+}
+
+// plastic_props of a single-material element by (material, marker count, weakening regime): desk::plastic_props itself,
+// run once per entry with a plastic strain of that regime (des_kernels.hpp)
+template <class M>
+__global__ void k_pptab(const des_params *p, double *pptab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nmat = p->nmat;
+    if (i >= nmat * DES_PPTAB_CNT * 3) return;
+    const int regime = i % 3, cnt = (i / 3) % DES_PPTAB_CNT, mat = i / (3 * DES_PPTAB_CNT);
+    desk::Mix mx;
+    mx.mk = nullptr; mx.mat = mat; mx.cnt = cnt > 0 ? cnt : 1;           // entry 0 is never read
+    const double pls = regime == 0 ? p->pls0[mat] - 1.0 : (regime == 1 ? p->pls0[mat] : p->pls1[mat]);
+    double *t = pptab + (size_t)i * 5;
+    desk::plastic_props<M>(p, mx, pls, t[0], t[1], t[2], t[3], t[4]);
 }
 
 // the five means of a single-material element, by (material, marker count)

@@ -185,7 +185,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     case DES_RH_EP: {
         double amc, anphi, anpsi, hardn, ten_max;
         double pls = GEO ? g_pls : pl_ld(plstrain, 0, ne, eo);
-        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
+        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max, md.pptab);
         double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, s, &defer);
         if (DEFER && defer) return true;
         if (depls != 0 || g_rescaled) pl_st(plstrain, 0, ne, eo, pls + depls);       // plstrain += 0 is the identity
@@ -201,7 +201,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         double svII = desk::second_invariant2(sv);
         double amc, anphi, anpsi, hardn, ten_max;
         double pls = GEO ? g_pls : pl_ld(plstrain, 0, ne, eo);
-        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max);
+        desk::plastic_props<M>(p, mx, pls, amc, anphi, anpsi, hardn, ten_max, md.pptab);
         double sp[6];
         for (int i = 0; i < 6; ++i) sp[i] = s[i];
         double depls = desk::elasto_plastic<M, DEFER>(pr.bulkm, pr.shearm, amc, anphi, anpsi, hardn, ten_max, de, sp, &defer);
