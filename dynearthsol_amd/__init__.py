@@ -296,6 +296,14 @@ class EngineBase:
         """isostasy_adjustment mode: step() runs that loop's body instead of a time step."""
         self._check(self._f("set_isostasy")(self._h, int(bool(on))), "set_isostasy")
 
+    def body_force_adjustment(self):
+        """initial_body_force_adjustment (dynearthsol.cxx:546-591); returns the scalars afterwards."""
+        sc = DesScalars()
+        f = self._f("body_force_adjustment")
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(f(self._h, C.byref(sc)), "body_force_adjustment")
+        return sc
+
     def set_clock(self, dt, time=0.0, steps=0):
         self._check(self._f("set_clock")(self._h, dt, time, steps), "set_clock")
 

@@ -83,7 +83,7 @@ struct DevClock {
     int status;
     int iso;                 // inside isostasy_adjustment (des_dev_set_isostasy)
     int pt;                  // inside the pseudo-transient loop of a step (Param::control.PT_jump)
-    int pad2;
+    int no_neumann;          // inside initial_body_force_adjustment: apply_stress_bcs_neumann is held back (fields.cxx:690)
     double avg_time0;        // Output::time0 (output.cxx:332)
     int n_defer;             // elements the first stress pass of this step handed to E2_return_mapping
     int pad;
@@ -1226,6 +1226,35 @@ int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
     }
     if (out) for (int k = 0; k < n; ++k) out[k].l2_residual = std::sqrt(l2sum);
     return status;
+}
+
+// initial_body_force_adjustment (dynearthsol.cxx:546-591; main() calls it once before the time loop when
+// ic.has_body_force_adjustment): the pseudo-transient loop on the initial state with the Neumann tractions held back
+// (fields.cxx:690: apply_stress_bcs_neumann is skipped while Param::ic.has_body_force_adjustment is set).  Without
+// control.has_PT the reference only forms the residual of the force_residual it holds; so does this.
+int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
+{
+    D2_REFUSE(h, "the initial body-force adjustment");
+    if (!h) return DES_ERR_INTERNAL;
+    if (h->nnbr > 0 || h->group) { g_last_error = "the initial body-force adjustment's residual test is global: single domain only"; return DES_ERR_UNSUPPORTED; }
+    hipSetDevice(h->device);
+    refresh_props(h);
+    h->n_pt_iterations = 0;
+    int rc;
+    if (h->p.has_PT) {
+        static const int on = 1, off = 0;
+        HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &on, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        rc = pt_loop(h, false);
+        HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &off, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (rc) return rc;
+        // (the loop leaves the masses of its last update_mesh in the element records: gathered as after a step)
+        launch_mass_gather(h);
+    } else {
+        launch_s3(h, false, false, true);
+    }
+    if ((rc = sync_clock(h))) return rc;
+    if (out) { fill_scalars(h, out); }
+    return h->h_clk->status;
 }
 
 // ---- domain decomposition ---------------------------------------------------------

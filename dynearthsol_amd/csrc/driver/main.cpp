@@ -27,6 +27,7 @@ int eng_compute_dt(void *h, double *dt) { return des_dev_compute_dt((des_dev *)h
 int eng_step(void *h, int n, des_scalars *s) { return des_dev_step((des_dev *)h, n, s); }
 int eng_check_nan(void *h, long long *n) { return des_dev_check_nan((des_dev *)h, n); }
 int eng_set_isostasy(void *h, int on) { return des_dev_set_isostasy((des_dev *)h, on); }
+int eng_bfa(void *h, des_scalars *s) { return des_dev_body_force_adjustment((des_dev *)h, s); }
 int eng_quality(void *h, double sv, double b, double bd, des_quality *q) { return des_dev_mesh_quality((des_dev *)h, sv, b, bd, q); }
 }
 
@@ -55,7 +56,7 @@ int main(int argc, const char *argv[])
     }
     const des_engine_api api = { eng_create, eng_destroy, eng_upload, eng_download, eng_field_count,
                                  eng_set_clock, eng_init_geometry, eng_compute_dt, eng_step, eng_check_nan, eng_quality,
-                                 des_dev_last_error, eng_set_isostasy, 0 };
+                                 des_dev_last_error, eng_set_isostasy, 0, eng_bfa };
     // One des_run per mesh: where the reference would call remesh() the loop returns with the state
     // saved; with a remesher command (include/des_run.h) the run goes on from the remeshed pair.
     std::string overrides;

@@ -145,7 +145,9 @@ void launch_vbcs_coord(des_dev *h)
                        h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm, h->xt);
 }
 
-int pt_loop(des_dev *h)
+// in_step = false: initial_body_force_adjustment's loop (dynearthsol.cxx:546-591) -- the same iterations on the state
+// as it stands, no step around them (so no apply_vbcs + update_coordinate of a step behind the loop)
+int pt_loop(des_dev *h, bool in_step = true)
 {
     int rc;
     launch_s3(h, false, false, true);                      // l2 of the step's own update_force
@@ -168,7 +170,7 @@ int pt_loop(des_dev *h)
         residual_old = l2;
     }
     if ((rc = set_pt(h, 0))) return rc;
-    launch_vbcs_coord(h);                                  // apply_vbcs + update_coordinate of the step itself
+    if (in_step) launch_vbcs_coord(h);                     // apply_vbcs + update_coordinate of the step itself
     return DES_OK;
 }
 

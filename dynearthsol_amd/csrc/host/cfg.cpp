@@ -285,9 +285,10 @@ void build_params(const Config &c, des_params &p, int ndims)
     if (p.surface_process_option != 0 && p.surface_process_option != 1)
         throw Error(31, "surface_process_option other than 0/1 is host-coupled in the reference and not offloaded");
     if (c.b("control.has_hydraulic_diffusion") ||
-        c.b("control.use_global_velocity_scaling") || c.b("control.has_hydration_processes") ||
-        c.b("ic.has_body_force_adjustment"))
-        throw Error(31, "hydraulic diffusion / global velocity scaling / hydration / initial body-force adjustment are outside the offloaded hot path");
+        c.b("control.use_global_velocity_scaling") || c.b("control.has_hydration_processes"))
+        throw Error(31, "hydraulic diffusion / global velocity scaling / hydration are outside the offloaded hot path");
+    // (ic.has_body_force_adjustment: the loop calls the engine's initial_body_force_adjustment before the first step,
+    //  host/run.cpp)
     // the pseudo-transient loop of a step (dynearthsol.cxx:803-864) runs inside des_dev_step
     p.has_PT = c.b("control.has_PT");
     p.PT_max_iter = c.i("control.PT_max_iter");

@@ -40,6 +40,7 @@ struct Run {
     des_scalars sc;
     bool averaged;
     bool plane_strain = false;    // mat.is_plane_strain of a 2-D model: stressyy goes into checkpoints
+    bool body_force_adjustment = false;   // ic.has_body_force_adjustment: the engine's PT loop runs once before the first step
     int info_display_next_step;
     double reference_frame_time, last_remesh_time;
     double restored_vmax;         // max_global_vel_mag of the checkpoint, until compute_dt renews it
@@ -195,6 +196,9 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         r.check(api->step(r.eng, 0, &r.sc), "clock");
 
         r.out = des_output_create(host, rs.active ? rs.frame : 0);
+        r.body_force_adjustment = cfg.b("ic.has_body_force_adjustment");
+        if (r.body_force_adjustment && !api->body_force_adjustment)
+            throw des::Error(31, "this engine does not offload the initial body-force adjustment");
         if (api->no_files) quiet = 1;
         des::output_set_quiet(r.out, quiet != 0);
 
@@ -219,6 +223,11 @@ extern "C" int des_run(des_host *host, const des_engine_api *api, int device, in
         const long long starting_step = r.sc.steps;
         int next_regular_frame = 1;
 
+        if (r.body_force_adjustment) {
+            // initial_body_force_adjustment (dynearthsol.cxx:753-761): right before the time loop, also after a restart
+            r.check(api->body_force_adjustment(r.eng, &r.sc), "body_force_adjustment");
+            r.body_force_adjustment = false;
+        }
         if (!quiet) {
             std::printf("Starting simulation...\n  Showing model progress every %d steps.\n", info_display_step_interval);
             std::fflush(stdout);

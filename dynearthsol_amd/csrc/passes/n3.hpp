@@ -159,6 +159,7 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (b + u >= b1) break;
+                if ((ent[u] & 1) && clk->no_neumann) continue;        // initial_body_force_adjustment: fields.cxx:690
                 if (!plus && (ent[u] & 1)) { plus = true; foundation(); }
                 if (plus) { f[0] += t[u][0]; f[1] += t[u][1]; f[2] += t[u][2]; }
                 else      { f[0] -= t[u][0]; f[1] -= t[u][1]; f[2] -= t[u][2]; }

@@ -27,13 +27,15 @@ NAN_T = C.CFUNCTYPE(_i, _vp, C.POINTER(_ll))
 QUALITY_T = C.CFUNCTYPE(_i, _vp, _d, _d, _d, C.POINTER(DesQuality))
 ERR_T = C.CFUNCTYPE(C.c_char_p)
 ISO_T = C.CFUNCTYPE(_i, _vp, _i)
+BFA_T = C.CFUNCTYPE(_i, _vp, C.POINTER(DesScalars))
 
 
 class EngineApi(C.Structure):
     """des_engine_api"""
     _fields_ = [("create", CREATE_T), ("destroy", DESTROY_T), ("upload", UPLOAD_T), ("download", DOWNLOAD_T),
                 ("field_count", COUNT_T), ("set_clock", CLOCK_T), ("init_geometry", INITGEOM_T), ("compute_dt", DT_T), ("step", STEP_T),
-                ("check_nan", NAN_T), ("mesh_quality", QUALITY_T), ("last_error", ERR_T), ("set_isostasy", ISO_T), ("no_files", _i)]
+                ("check_nan", NAN_T), ("mesh_quality", QUALITY_T), ("last_error", ERR_T), ("set_isostasy", ISO_T), ("no_files", _i),
+                ("body_force_adjustment", BFA_T)]
 
 
 class RunStats(C.Structure):
@@ -59,6 +61,8 @@ def api_from_lib(lib, prefix, create=None):
     api.check_nan = g("check_nan", NAN_T)
     api.mesh_quality = g("mesh_quality", QUALITY_T)
     api.set_isostasy = g("set_isostasy", ISO_T)
+    if hasattr(lib, prefix + "_body_force_adjustment"):
+        api.body_force_adjustment = g("body_force_adjustment", BFA_T)
     if hasattr(lib, prefix + "_last_error"):
         api.last_error = g("last_error", ERR_T)
     return api

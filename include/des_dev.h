@@ -74,6 +74,12 @@ long long des_dev_field_count(const des_dev *h, int field);
  * step(iso_steps); set_isostasy(0); dt = compute_dt. */
 int des_dev_set_isostasy(des_dev *h, int on);
 
+/* initial_body_force_adjustment (dynearthsol.cxx:546-591; main() calls it once before the time loop when
+ * ic.has_body_force_adjustment is set, :753-761): the pseudo-transient loop of control.has_PT on the initial state,
+ * apply_stress_bcs_neumann held back meanwhile (fields.cxx:690).  out (may be NULL): the scalars afterwards,
+ * n_pt_iterations = the loop's iterations.  3-D, single domain. */
+int des_dev_body_force_adjustment(des_dev *h, des_scalars *out);
+
 /* Set time-step scalars: dt (Variables::dt), time, steps.  compute_dt semantics: if
  * fixed_dt != 0 it always wins (geometry.cxx:1487). */
 int des_dev_set_clock(des_dev *h, double dt, double time, long long steps);

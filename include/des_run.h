@@ -73,6 +73,9 @@ typedef struct des_engine_api {
      * mesh_quality / check_nan reduce across ranks: dynearthsol_amd/distributed.py); ranks with
      * no_files != 0 take part in every gather but write no frame, checkpoint or progress line. */
     int no_files;
+    /* initial_body_force_adjustment (des_dev_body_force_adjustment; dynearthsol.cxx:753-761); may be NULL, in which
+     * case a config with ic.has_body_force_adjustment is refused with code 31 */
+    int (*body_force_adjustment)(void *h, des_scalars *out);
 } des_engine_api;
 
 /* What the loop did, for callers that do not parse stdout. */

@@ -78,6 +78,7 @@ struct des_oracle {
     int nn, ne;
     int iso = 0;                        // inside isostasy_adjustment (dynearthsol.cxx:496-544)
     bool pt_jump = false;               // Param::control.PT_jump while the pseudo-transient loop runs
+    bool body_force_adjustment = false; // Param::ic.has_body_force_adjustment while initial_body_force_adjustment runs (fields.cxx:690)
     long long n_pt_iterations = 0;      // iterations taken since the last des_oracle_step call began
     int n_return_mapping = 0;           // elements past the yield pre-filter in the last update_stress
     // topology
@@ -1465,7 +1466,7 @@ void update_force(des_oracle &o)
         }
     }
     apply_stress_bcs(o);
-    apply_stress_bcs_neumann(o);     // has_body_force_adjustment is off (fields.cxx:690)
+    if (!o.body_force_adjustment) apply_stress_bcs_neumann(o);     // fields.cxx:690
     apply_damping(o);
 }
 
@@ -2604,6 +2605,27 @@ int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode
 int des_oracle_phase(des_oracle *h, int phase) { return step_phase(*h, phase); }
 
 int des_oracle_set_isostasy(des_oracle *h, int on) { h->iso = on != 0; return DES_OK; }
+
+// initial_body_force_adjustment (dynearthsol.cxx:546-591, called once before the time loop when
+// ic.has_body_force_adjustment): the pseudo-transient loop on the initial state, Neumann tractions held back
+// (fields.cxx:690).  Without control.has_PT it only forms the residual, as the reference does.
+int des_oracle_body_force_adjustment(des_oracle *h, des_scalars *out)
+{
+    des_oracle &o = *h;
+    o.n_pt_iterations = 0;
+    o.l2_residual = calculate_residual_force(o);
+    if (o.p.has_PT) {
+        o.body_force_adjustment = true;
+        pt_loop(o);
+        o.body_force_adjustment = false;
+    }
+    if (out) {
+        const long long it = o.n_pt_iterations;
+        des_oracle_step(h, 0, out);
+        out->n_pt_iterations = it;
+    }
+    return DES_OK;
+}
 
 // the exchange of a step: what = 0 nodal {x,y,z,vx,vy,vz,T,dh} of the local nodes idx[0..n),
 // what = 1 {stress, strain, plstrain} of the local elements idx[0..n); buf[i*width + c]

@@ -34,6 +34,9 @@ int des_oracle_phase(des_oracle *h, int phase);
 /* 1: des_oracle_step / des_oracle_phase run the body of isostasy_adjustment's loop
  * (dynearthsol.cxx:506-539) instead of a time step; 0: back to time steps. */
 int des_oracle_set_isostasy(des_oracle *h, int on);
+/* initial_body_force_adjustment (dynearthsol.cxx:546-591): the pseudo-transient loop on the initial state without
+ * the Neumann tractions (fields.cxx:690); out->n_pt_iterations = its iterations */
+int des_oracle_body_force_adjustment(des_oracle *h, des_scalars *out);
 int des_oracle_halo_pack(des_oracle *h, int kind, const int *idx, int n, double *buf);
 int des_oracle_halo_unpack(des_oracle *h, int kind, const int *idx, int n, const double *buf);
 int des_oracle_dt_partials(des_oracle *h, double out[6], int recompute);

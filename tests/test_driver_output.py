@@ -349,3 +349,30 @@ def test_remeshing_round_trip_through_an_external_remesher(in_tmp):
     # the run went on from the repaired state: time keeps counting, the state keeps evolving
     last = read_frame("rt.save.000009")
     assert not np.array_equal(last["stress"], after["stress"])
+
+
+def test_initial_body_force_adjustment_runs_before_the_first_step(in_tmp):
+    """ic.has_body_force_adjustment (dynearthsol.cxx:753-761): des_run calls the engine's adjustment once, right before
+    the time loop; the frames are those of adjustment + straight steps; an engine table without the entry refuses (31)."""
+    ov = ("sim.modelname = bfa\nsim.max_steps = 6\nsim.output_step_interval = 6\nic.has_body_force_adjustment = yes\n"
+          "control.has_PT = yes\ncontrol.PT_max_iter = 5\ncontrol.PT_relative_tolerance = 0\nbc.stress_bc_z1 = 3\nbc.stress_val_z1 = 2e6\n")
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=ov)
+    st = driver.run(host, api=oracle_api())
+    assert (st.steps, st.exit_code) == (6, 0)
+    h2 = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=ov)
+    ora = OracleEngine(h2)
+    ora.init_from_host(h2)
+    assert ora.body_force_adjustment().n_pt_iterations == 5
+    ora.step(6)
+    fr = read_frame("bfa.save.000001")
+    assert np.array_equal(as_f64(fr["velocity"], host.nnode, 3).T.ravel(), ora.download("VEL"))
+    assert np.array_equal(as_f64(fr["stress"], host.nelem, 6).T.ravel(), ora.download("STRESS"))
+    skipped = OracleEngine(h2)
+    skipped.init_from_host(h2)
+    skipped.step(6)
+    assert not np.array_equal(skipped.download("VEL"), ora.download("VEL"))
+    api = oracle_api()
+    api.body_force_adjustment = driver.BFA_T()
+    with pytest.raises(des.DesError) as e:
+        driver.run(des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=ov), api=api)
+    assert e.value.code == 31

@@ -431,3 +431,31 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
         total += so.n_pt_iterations
         assert_bit_exact(dev, ora)
     assert total >= (13 if tol == "1e-2" else 30)
+
+
+@pytest.mark.parametrize("moving", ["yes", "no"])
+def test_initial_body_force_adjustment_bit_exact(moving):
+    """ic.has_body_force_adjustment (dynearthsol.cxx:546-591, 753-761): before the first step the pseudo-transient loop
+    runs on the initial state with apply_stress_bcs_neumann held back (fields.cxx:690).  Same iteration count and bits
+    as the oracle, the steps that follow included -- and the tractions were really held back."""
+    ov = ("control.has_PT = yes\ncontrol.PT_max_iter = 25\ncontrol.PT_relative_tolerance = 1e-4\n"
+          "control.has_moving_mesh = %s\nbc.stress_bc_z1 = 3\nbc.stress_val_z1 = 2e6\nbc.stress_bc_x0 = 1\nbc.stress_val_x0 = -1e6\n" % moving)
+    host, dev, ora = pair(cfgs.EP, overrides=ov)
+    ref = OracleEngine(host)
+    ref.init_from_host(host)
+    # (the lithostatic start is in equilibrium: the loop would stop after two idle iterations -- push it out of balance)
+    pushed = ora.download("STRESS") * 1.03
+    for eng in (dev, ora, ref):
+        eng.upload("STRESS", pushed)
+    sd, so = dev.body_force_adjustment(), ora.body_force_adjustment()
+    assert sd.n_pt_iterations == so.n_pt_iterations > 3 and (sd.dt, sd.steps, sd.time) == (so.dt, so.steps, so.time) == (so.dt, 0, 0.0)
+    assert abs(sd.l2_residual - so.l2_residual) <= 1e-12 * so.l2_residual
+    assert_bit_exact(dev, ora)
+    for n in (1, 3, 8):
+        sd, so = dev.step(n), ora.step(n)
+        assert sd.n_pt_iterations == so.n_pt_iterations > 0 and (sd.dt, sd.steps) == (so.dt, so.steps)
+        assert_bit_exact(dev, ora)
+    # the loop on its own, tractions applied, is another model: the step's PT loop of an oracle that skipped the
+    # adjustment leaves other forces on the traction boundaries
+    ref.step(12)
+    assert not np.array_equal(ref.download("VEL"), ora.download("VEL"))

@@ -65,7 +65,7 @@ def test_features_outside_the_offloaded_path_are_refused_not_ignored():
     """Options that would change the results or the files written, but are not built: code 31,
     never a silent no-op."""
     base = cfgs.make(**cfgs.EP)
-    for ov in ("ic.has_body_force_adjustment = yes\n", "control.has_hydraulic_diffusion = yes\n", "control.surface_process_option = 101\n",
+    for ov in ("control.has_hydraulic_diffusion = yes\n", "control.surface_process_option = 101\n",
                "control.has_hydration_processes = yes\n", "monitor.enabled = yes\nmonitor.num_points = 1\n",
                "ic.temperature_option = 90\n", "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n",
                "mesh.meshing_option = 95\nmesh.meshing_elem_shape = 0\n"):
