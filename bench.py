@@ -278,6 +278,30 @@ def main():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         dev.sync()
 
+    # N > 1, RCCL transport: which schedule -- everything in order on the engine's stream, or the exchange on a side
+    # stream beside the next step's passes on the deep part of the slab (engine/launch.hpp: deep_split_ok)?  Neither has
+    # run on two physical GPUs in the build container, so the untimed part of the run measures both (40 steps each,
+    # MAX over ranks) and the timed region takes the faster; DES_OVERLAP=0 / 1 pins it.  Both give the same bits
+    # (tests/test_gpu_headline_decomp.py).
+    schedule_probe = None
+    if world > 1 and transport.startswith("RCCL") and os.environ.get("DES_OVERLAP") is None:
+        probe = {}
+        for on in (0, 1):
+            dev.set_overlap(on)
+            dev.step(10, want_scalars=False)
+            barrier()
+            t1 = time.perf_counter()
+            dev.step(40, want_scalars=False)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            probe[on] = float(tt.item()) / 40
+        pick = 1 if probe[1] < probe[0] else 0
+        dev.set_overlap(pick)
+        dev.step(10, want_scalars=False)
+        dev.sync()
+        schedule_probe = {"in_order_ms_per_step": 1e3 * probe[0], "overlapped_ms_per_step": 1e3 * probe[1], "picked": "overlapped" if pick else "in order"}
+
     note("timed region")
     barrier()
     t0 = time.perf_counter()
@@ -348,6 +372,7 @@ def main():
             "rccl_ranks": info["rccl_ranks"],
             "rccl_ranks_sum_over_ranks": int(counts[1].item()),          # = world^2 when every rank is in one communicator
             "overlapped_schedule": info["overlapped"],
+            "schedule_probe": schedule_probe,
             "ghost_work_share": (ne_sum - ne) / ne_sum,                    # elements computed redundantly / all computed
             "nelem_local_sum": int(ne_sum),
         })

@@ -455,6 +455,11 @@ class DeviceEngine(EngineBase):
         self._check(self._lib.des_dev_comm_info(self._h, C.byref(n), C.byref(r), C.byref(o)), "comm_info")
         return {"rccl_ranks": n.value, "rank": r.value, "overlapped": bool(o.value)}
 
+    def set_overlap(self, on):
+        """in-order / overlapped multi-GPU schedule from the next step() call on (the same on every rank)"""
+        self._lib.des_dev_set_overlap.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._lib.des_dev_set_overlap(self._h, int(bool(on))), "set_overlap")
+
     def comm_init(self, dist, rank, world):
         """Attach an RCCL communicator: rank 0 creates the ncclUniqueId, torch.distributed only
         carries those 128 bytes; all halo traffic then stays inside the engine."""

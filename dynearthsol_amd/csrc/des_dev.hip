@@ -225,6 +225,10 @@ struct des_dev {
     hipStream_t comm_stream;
     hipEvent_t ev_fork, ev_join;
     int e_int0, e_int1;
+    // ... and the part of them (and of the node blocks) that lies deep inside the slab: what the passes compute there reads
+    // nothing the exchange writes (engine/order.hpp: DES_DEEP_DIST).  Empty ranges: the slab is too thin.
+    int e_deep0, e_deep1, n_deep0, n_deep1;
+    bool join_pending;         // the exchange of the last step is still running on the side stream (step_front joins)
     // element part of the exchange lists and the record offsets inside the message buffers
     std::vector<int> esend_ptr, erecv_ptr;
     std::vector<long long> send_off, recv_off;             // [nnbr+1] message offsets (doubles) per neighbour
@@ -257,6 +261,12 @@ struct des_dev {
     std::vector<ProfRec> prof_recs;
     double prof_ms[K_COUNT]; long long prof_calls[K_COUNT];
 };
+
+// engine/order.hpp: how far from every ghost node a "deep" node lies (its patch = ring 1 and the surface fans of its
+// patch nodes = ring 2 are then owned), and the id margin that keeps every node block (<= 128 nodes, DES_PATCH) holding
+// a node of a deep element inside the deep range
+#define DES_DEEP_DIST 3
+#define DES_DEEP_MARGIN 128
 
 namespace des_hip {
 
@@ -391,9 +401,11 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             h->n_new2old.swap(pm.n_new2old); h->n_old2new.swap(pm.n_old2new);
             h->e_new2old.swap(pm.e_new2old); h->e_old2new.swap(pm.e_old2new);
             h->e_int0 = pm.e_int0; h->e_int1 = pm.e_int1;
+            h->e_deep0 = pm.e_deep0; h->e_deep1 = pm.e_deep1; h->n_deep0 = pm.n_deep0; h->n_deep1 = pm.n_deep1;
             mesh = &pm.view;             // everything below builds the device state in the internal order
         } else {
             h->e_int0 = 0; h->e_int1 = 0;      // caller's order kept: no interior range known, no overlap
+            h->e_deep0 = h->e_deep1 = h->n_deep0 = h->n_deep1 = 0;
         }
     }
     const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
@@ -408,11 +420,11 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
                    *err = DES_ERR_RESOURCE; des_dev_destroy(h); return nullptr; } } while (0)
     HK(hipStreamCreate(&h->stream));
     HK(hipEventCreate(&h->ev0)); HK(hipEventCreate(&h->ev1));
-    if (h->overlap) {
-        HK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-        HK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
+    // (side stream + fork / join events of the overlapped schedule: always there, so that des_dev_set_overlap can switch
+    //  schedules on a live engine)
+    HK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HK(hipHostMalloc((void **)&h->h_clk, sizeof(DevClock)));
 
     CK(dev_alloc(h->d_p, 1)); CK(dev_alloc(h->d_vt, 1)); CK(dev_alloc(h->d_clk, 1));
@@ -1017,8 +1029,19 @@ int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, boo
     // inside a multi-step call the step before ended with the fused E1<C | A | NOREC>, and EN1
     // forms the element terms itself; the first step of a call gathers what E1 stored (the
     // caller may have uploaded fields in between)
-    if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h);
-    launch_e2(h);
+    if (h->join_pending) {
+        // the exchange of the step before is still on the side stream (step_back): EN1 and E2<GEO> of the deep part of
+        // the slab run beside it, the rest behind the join
+        const bool split = i > 0 && en1_ok(h) && h->e2geo_next && deep_split_ok(h);
+        if (split) { launch_en1(h, PART_DEEP); launch_e2(h, PART_DEEP); }
+        if ((rc = exchange_join(h))) return rc;
+        h->join_pending = false;
+        if (split) { launch_en1(h, PART_REST); launch_e2(h, PART_REST); }
+        else { if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h); launch_e2(h); }
+    } else {
+        if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h);
+        launch_e2(h);
+    }
     if (c.nmd) launch_n2(h);
     launch_force_pass(h);
     if (h->p.has_PT && !c.iso && (rc = pt_loop(h))) return rc;
@@ -1044,9 +1067,18 @@ int step_back(des_dev *h, const StepPlan &c, int i, long long step_no, bool *do_
     int rc;
     const bool last = (i == c.nsteps - 1);
     *do_dt = false;
-    if (step_overlapped(h, c)) {
-        // the exchange runs on the side stream || end-of-step pass of the interior elements; then the
-        // rest of the surface bookkeeping (it reads the ghost nodes' dh) and the two element
+    if (step_overlapped(h, c) && e2geo_ok(h)) {
+        if (h->s2_skipped && !last && deep_split_ok(h)) {
+            // the fused step: nothing left of this step reads the ghost region -- the join waits for the next step's
+            // front, which has work for the meantime (deep_split_ok)
+            launch_e1_end(h, step_no, true);           // (a plain step: no launch, the next stress update does it)
+            h->join_pending = true;
+            return DES_OK;
+        }
+        if ((rc = exchange_join(h))) return rc;        // a step that needs the ghost region now: in order from here
+    } else if (step_overlapped(h, c)) {
+        // (classic passes, DES_E2GEO=0) the exchange runs on the side stream || end-of-step pass of the interior
+        // elements; then the rest of the surface bookkeeping (it reads the ghost nodes' dh) and the two element
         // groups that touch the ghost region
         launch_e1_end(h, step_no, !last, E1_INTERIOR);
         if ((rc = exchange_join(h))) return rc;
@@ -1363,6 +1395,20 @@ int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
     if (nranks) *nranks = h->comm ? n : 0;
     if (rank) *rank = r;
     if (overlapped) *overlapped = h->overlap && h->nnbr > 0 && h->e_int1 > h->e_int0;
+    return DES_OK;
+}
+
+// Switches between the in-order schedule (everything on the engine's stream) and the overlapped one (DES_OVERLAP=1 at
+// create selects it from the start) between two des_dev_step calls.
+int des_dev_set_overlap(des_dev *h, int on)
+{
+    D2_REFUSE(h, "the domain decomposition");
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipStreamSynchronize(h->comm_stream));
+    if (h->join_pending) { g_last_error = "des_dev_set_overlap inside a step"; return DES_ERR_INTERNAL; }
+    h->overlap = on != 0;
     return DES_OK;
 }
 

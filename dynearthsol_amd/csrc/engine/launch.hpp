@@ -141,7 +141,7 @@ inline bool en1_ok(const des_dev *h)
 inline bool e2geo_ok(const des_dev *h)
 {
     static const char *env = std::getenv("DES_E2GEO");
-    return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h, true) && h->topflag && !h->overlap;
+    return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h, true) && h->topflag;
 }
 
 // The surface step (surface_processes, bc.cxx:1709-1872: S2 + S3 here) of a step can be left to the passes of the
@@ -161,6 +161,18 @@ inline bool s2_defer_ok(const des_dev *h, bool with_next, long long step_no)
     if (step_no % 10 == 0 || step_no % qcsi == 0) return false;
     if (h->p.is_outputting_averaged_fields && step_no % qcsi == 1) return false;
     return true;
+}
+
+// Overlapped multi-GPU schedule on the fused step (DES_OVERLAP=1): a plain step whose surface step is left to the next
+// step's passes ends with EN3 -- nothing of it reads the ghost region after the exchange has been issued.  So the
+// transfer + unpack run on the side stream while the NEXT step's EN1 and E2<GEO> work through the node blocks /
+// elements deep inside the slab (engine/order.hpp: nothing they read is written by the unpack); step_front joins, then
+// runs the two passes on the rest.  Needs a slab thick enough to have a deep part.
+inline bool deep_split_ok(const des_dev *h)
+{
+    if (!h->patch || h->e_deep1 <= h->e_deep0) return false;
+    const int npb = h->patch_npb, d0 = (h->n_deep0 + npb - 1) / npb, d1 = h->n_deep1 / npb;
+    return d1 > d0 && npb <= DES_DEEP_MARGIN && !h->p.is_outputting_averaged_fields;
 }
 
 // end-of-step E1 (C part) of step `step_no`, optionally fused with the A part of the next step
@@ -295,10 +307,21 @@ void choose_e2_mode(des_dev *h)
     if (h->e2_defer == 2) h->e2_two_pass = e2geo_ok(h) ? false : h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
 }
 
-void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
+// which elements / node blocks a launch of the fused step covers (overlapped multi-GPU schedule, step_front): everything,
+// the part deep inside the slab (nothing it reads is written by the ghost-region exchange, engine/order.hpp), or the
+// rest around it
+enum { PART_ALL = 0, PART_DEEP = 1, PART_REST = 2 };
+
+void launch_e2(des_dev *h, int part = PART_ALL)
 {
-    if (e_count < 0) e_count = h->ne;
-    if (e_count == 0) return;
+    int e_begin = 0, e_count = h->ne, e_begin2 = 0, e_count2 = 0;
+    if (part == PART_DEEP) { e_begin = h->e_deep0; e_count = h->e_deep1 - h->e_deep0; }
+    if (part == PART_REST) { e_count = h->e_deep0; e_begin2 = h->e_deep1; e_count2 = h->ne - h->e_deep1; }
+    const bool whole = part != PART_DEEP;                  // the launch that carries the facet workgroups and ends the pass
+    if (e_count + e_count2 == 0 && !whole) return;
+    // (PART_DEEP runs between the two EN1 launches of the step, before the coordinate buffers swap: the records of
+    //  the deep nodes are the ones EN1 has just written to the other buffer)
+    const d4 *const xt_now = part == PART_DEEP ? h->xt_alt : h->xt;
     // (the first step of a call in the fused flow is a classic stress update: three waves per SIMD in the first of two
     //  passes against two in one pass -- it keeps the classic rule when the mode is not pinned)
     bool two_pass = h->e2_two_pass;
@@ -307,7 +330,7 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
     RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, nullptr, nullptr};
-    if (h->p.is_outputting_averaged_fields && e2geo_ok(h) && e_begin == 0 && e_count == h->ne) {
+    if (h->p.is_outputting_averaged_fields && e2geo_ok(h) && part == PART_ALL) {
         rp.dplstrain_avg = h->dplstrain_avg;
         rp.avg_dpl = h->e2_not_last ? 1 : 0;            // the last step of a call ends with E1 + k_average_fields
         rp.qcsi = (int)h->p.quality_check_step_interval;
@@ -327,30 +350,31 @@ void launch_e2(des_dev *h, int e_begin = 0, int e_count = -1)
             : (geo ? (defer ? E2_update_stress<desk::MathOcml, 1, 1> : E2_update_stress<desk::MathOcml, 0, 1>)
                    : (defer ? E2_update_stress<desk::MathOcml, 1, 0> : E2_update_stress<desk::MathOcml, 0, 0>));
         // with EN3 the stress-bc facet workgroups ride here (with the classic pair: in E3's launch)
-        const int nbf = (h->patch && e_begin == 0 && e_count == h->ne) ? nblk(h->nbcf) : 0;
+        const int nbf = (h->patch && whole) ? nblk(h->nbcf) : 0;
         // ... and so does the edvacc_surf update of a surface step EN1 has just done for the step before (s2_defer_ok)
         int nsf = 0;
-        if (h->edv_pending && h->patch && e_begin == 0 && e_count == h->ne) {
+        if (h->edv_pending && h->patch && whole) {
             rp.edv_etop = h->etop; rp.edv_conn_surf = h->conn_surf; rp.edv_dh_n = h->dh_n; rp.edv_edvacc = h->edvacc;
             nsf = nblk(h->etop);
             h->edv_pending = false;
         }
-        hipLaunchKernelGGL(k, dim3(nblk8(e_count) + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
-                           e_begin, e_count, nblk(e_count), h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
+        const int e_all = e_count + e_count2;
+        hipLaunchKernelGGL(k, dim3(nblk8(e_all) + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                           e_begin, e_count, e_begin2, e_count2, nblk(e_all), h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                            h->etmp2, h->defer_list, count,
-                           nblk8(e_count), (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
+                           nblk8(e_all), (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
     }
     if (defer && !exp_skip("e2r")) {
         Launch l(h, K_E2R);
         auto k = h->portable_libm ? (geo ? E2_return_mapping<desk::MathPortable, 1> : E2_return_mapping<desk::MathPortable, 0>)
                                   : (geo ? E2_return_mapping<desk::MathOcml, 1> : E2_return_mapping<desk::MathOcml, 0>);
-        hipLaunchKernelGGL(k, dim3(std::min(nblk(e_count), DES_E2R_GRID)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
-                           h->conn, h->xt, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
+        hipLaunchKernelGGL(k, dim3(std::min(nblk(e_count + e_count2), DES_E2R_GRID)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                           h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                            h->etmp2, h->defer_list, count, rp);
     }
-    if (e_begin + e_count == h->ne) {                      // (sub-range launches: the last one ends at ne)
+    if (whole) {                                           // (PART_DEEP is followed by PART_REST)
         if (h->rot_pending || geo) h->ddp_live = false;    // ... and has folded the pending NMD increments in
         h->rot_pending = false; h->e2geo_next = false;
     }
@@ -406,11 +430,19 @@ void launch_n3(des_dev *h)
 
 // N1 as a pass over node-block patches (passes/en1.hpp): the element terms are recomputed from the
 // nodal records instead of being stored by E1 and gathered
-void launch_en1(des_dev *h)
+void launch_en1(des_dev *h, int part = PART_ALL)
 {
-    {
+    // node blocks of this launch: all, the ones made of deep nodes only, or the rest around them
+    const int nb = h->patch_nb, npb = h->patch_npb;
+    int b0 = 0, c0 = nb, b1 = 0, c1 = 0;
+    if (part != PART_ALL) {
+        const int d0 = std::min(nb, (h->n_deep0 + npb - 1) / npb), d1 = std::max(d0, h->n_deep1 / npb);
+        if (part == PART_DEEP) { b0 = d0; c0 = d1 - d0; }
+        else                   { c0 = d0; b1 = d1; c1 = nb - d1; }
+    }
+    if (c0 + c1 > 0) {
         Launch l(h, K_EN1);
-        void (*k)(const des_params *, DevClock *, int, int, int, int, const int *, const ulonglong2 *,
+        void (*k)(const des_params *, DevClock *, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *,
                   const int *, const int *, const int *, const unsigned *, const MatData, const double *, const d4 *, d4 *, d4 *,
                   double *, double *, double *, const SurfPending);
         // the surface step of the step before, if its S2 / S3 launches were left out (s2_defer_ok)
@@ -418,8 +450,10 @@ void launch_en1(des_dev *h)
         if (h->s2_pending) {
             sp.tfan = h->tfan; sp.pb_top = h->pb_top; sp.ssup_nodes = h->ssup_nodes;
             sp.dh = h->dh; sp.dhacc = h->dhacc; sp.dh_n = h->dh_n;
-            h->s2_pending = false;
-            h->edv_pending = true;                  // the edvacc_surf part rides in the next stress update
+            if (part != PART_DEEP) {                // (PART_DEEP is followed by PART_REST, which needs it too)
+                h->s2_pending = false;
+                h->edv_pending = true;              // the edvacc_surf part rides in the next stress update
+            }
         }
         const bool cm = h->const_mass;
         static const char *tenv = std::getenv("DES_EN1_THREADS");
@@ -429,12 +463,12 @@ void launch_en1(des_dev *h)
         if (fit) k = T == 512 ? DES_EN1_PICK(512, 1600, 296, 872) : DES_EN1_PICK(256, 1600, 296, 872);
         else     k = T == 512 ? DES_EN1_PICK(512, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE) : DES_EN1_PICK(256, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE);
 #undef DES_EN1_PICK
-        hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, h->patch_nb,
-                           h->patch_npb, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
+        hipLaunchKernelGGL(k, dim3((c0 + c1 + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, b0, c0, b1, c1,
+                           (int)(part != PART_REST), h->patch_npb, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
                            mat_data(h), h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n,
                            h->tmass, h->ntmp, sp);
     }
-    std::swap(h->xt, h->xt_alt);               // EN1 wrote the records with the new temperatures there
+    if (part != PART_DEEP) std::swap(h->xt, h->xt_alt);      // EN1 wrote the records with the new temperatures there
 }
 
 // E3 + N3 as one pass over node-block patches (passes/en3.hpp); the stress-bc facet terms, which

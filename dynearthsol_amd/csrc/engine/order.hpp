@@ -20,7 +20,14 @@ struct PermMesh {
     std::vector<int> bf_elem[DES_NBDRY], bnodes[DES_NBDRY];
     des_mesh view;
     int e_int0, e_int1;        // [e_int0, e_int1): elements whose four nodes are all owned
+    // Decomposed meshes: the owned nodes are ordered [near the low cut | deep | near the high cut], "deep" = at least
+    // DES_DEEP_DIST element layers from every ghost node; [n_deep0, n_deep1) is that middle range (engine numbering)
+    // and [e_deep0, e_deep1) the elements whose four nodes lie DES_DEEP_MARGIN ids inside it -- so that any node block
+    // of up to that many nodes which holds one of their nodes is made of deep nodes only.  What the passes of a step
+    // compute on deep blocks / elements reads nothing the ghost-region exchange writes (engine/launch.hpp: overlap).
+    int n_deep0, n_deep1, e_deep0, e_deep1;
 };
+
 
 inline unsigned long long morton3(unsigned x, unsigned y, unsigned z)
 {
@@ -51,15 +58,48 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
         return morton3((unsigned)((x - lo[0]) * scale), (unsigned)((y - lo[1]) * scale), (unsigned)((z - lo[2]) * scale));
     };
     const int ob = in->owned_begin, oe = in->owned_end > 0 ? in->owned_end : nn;
+    // element layers between a node and the nearest ghost node of the low / the high range (capped at DES_DEEP_DIST)
+    std::vector<unsigned char> dlo((size_t)nn, DES_DEEP_DIST), dhi((size_t)nn, DES_DEEP_DIST);
+    if (ob > 0 || oe < nn) {
+        auto spread = [&](std::vector<unsigned char> &d, int g0, int g1) {
+            std::vector<int> front, next;
+            for (int n = g0; n < g1; ++n) { d[n] = 0; front.push_back(n); }
+            for (int layer = 1; layer < DES_DEEP_DIST && !front.empty(); ++layer) {
+                next.clear();
+                for (int n : front)
+                    for (int k = in->support_idx[n]; k < in->support_idx[n + 1]; ++k) {
+                        const int e = in->support_arr[k];
+                        for (int i = 0; i < 4; ++i) {
+                            const int m = in->connectivity[(size_t)i*ne + e];
+                            if (d[m] > layer) { d[m] = (unsigned char)layer; next.push_back(m); }
+                        }
+                    }
+                front.swap(next);
+            }
+        };
+        spread(dlo, 0, ob);
+        spread(dhi, oe, nn);
+    }
+    pm.n_deep0 = ob; pm.n_deep1 = oe;
     {
         std::vector<std::pair<unsigned long long, int> > key((size_t)nn);
-        for (int n = 0; n < nn; ++n) key[n] = std::make_pair(code(X[n], X[(size_t)nn + n], X[(size_t)2*nn + n]), n);
-        // Morton order inside each of the three id ranges (the pairs break ties by caller id)
+        for (int n = 0; n < nn; ++n) {
+            // owned nodes: near the low cut, deep, near the high cut -- Morton order inside each group
+            unsigned long long grp = 0;
+            if (n >= ob && n < oe) grp = dlo[n] < DES_DEEP_DIST ? 0 : (dhi[n] < DES_DEEP_DIST ? 2 : 1);
+            key[n] = std::make_pair(grp << 62 | code(X[n], X[(size_t)nn + n], X[(size_t)2*nn + n]) >> 2, n);
+        }
+        // ... inside each of the three id ranges (the pairs break ties by caller id)
         std::sort(key.begin(), key.begin() + ob);
         std::sort(key.begin() + ob, key.begin() + oe);
         std::sort(key.begin() + oe, key.end());
         pm.n_new2old.resize((size_t)nn); pm.n_old2new.resize((size_t)nn);
         for (int i = 0; i < nn; ++i) { pm.n_new2old[i] = key[i].second; pm.n_old2new[key[i].second] = i; }
+        for (int i = ob; i < oe; ++i) {
+            const unsigned long long grp = key[i].first >> 62;
+            if (grp == 0) pm.n_deep0 = i + 1;
+            if (grp == 2) { pm.n_deep1 = i; break; }
+        }
     }
     {
         std::vector<std::pair<unsigned long long, int> > key((size_t)ne);
@@ -72,16 +112,32 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
                 for (int d = 0; d < 3; ++d) c[d] += X[(size_t)d*nn + n] / 4;
                 touches_lo |= n < ob; touches_hi |= n >= oe;
             }
-            if (touches_lo) grp = 0; else if (touches_hi) grp = 2;
-            key[e] = std::make_pair(grp << 62 | code(c[0], c[1], c[2]) >> 2, e);      // group, then Morton
+            // groups: 0 touches the low ghost range, 1 owned but not deep (low side), 2 deep, 3 owned but not deep (high
+            // side), 4 touches the high ghost range
+            const bool cut = ob > 0 || oe < nn;            // (one domain: every element is deep, the order is the plain Morton one)
+            const int d0 = cut ? pm.n_deep0 + DES_DEEP_MARGIN : 0, d1 = cut ? pm.n_deep1 - DES_DEEP_MARGIN : nn;
+            bool deep = true, lowside = false;
+            for (int i = 0; i < 4; ++i) {
+                const int m = pm.n_old2new[in->connectivity[(size_t)i*ne + e]];
+                deep = deep && m >= d0 && m < d1;
+                lowside = lowside || m < d0;
+            }
+            grp = deep ? 2 : (lowside ? 1 : 3);
+            if (touches_lo) grp = 0; else if (touches_hi) grp = 4;
+            key[e] = std::make_pair(grp << 61 | code(c[0], c[1], c[2]) >> 3, e);      // group, then Morton
         }
         std::sort(key.begin(), key.end());
-        pm.e_int0 = 0; pm.e_int1 = ne;
+        pm.e_int0 = 0; pm.e_int1 = ne; pm.e_deep0 = 0; pm.e_deep1 = ne;
+        bool seen_deep = false;
         for (int i = 0; i < ne; ++i) {
-            const unsigned long long grp = key[i].first >> 62;
+            const unsigned long long grp = key[i].first >> 61;
             if (grp == 0) pm.e_int0 = i + 1;
-            if (grp == 2) { pm.e_int1 = i; break; }
+            if (grp <= 1) pm.e_deep0 = i + 1;
+            if (grp == 2) seen_deep = true;
+            if (grp >= 3 && pm.e_deep1 == ne) pm.e_deep1 = i;
+            if (grp == 4) { pm.e_int1 = i; break; }
         }
+        if (!seen_deep) pm.e_deep1 = pm.e_deep0;
         pm.e_new2old.resize((size_t)ne); pm.e_old2new.resize((size_t)ne);
         for (int i = 0; i < ne; ++i) { pm.e_new2old[i] = key[i].second; pm.e_old2new[key[i].second] = i; }
     }

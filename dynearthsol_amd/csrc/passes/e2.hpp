@@ -254,7 +254,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
 template <class M, int DEFER, int GEO>
 __global__ void __launch_bounds__(DES_BLOCK, DEFER ? (GEO ? DES_E2GEO_WAVES : DES_E2_WAVES_FAST) : DES_E2_WAVES)
 E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
-     int ne, int e_begin, int e_count, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     int ne, int e_begin, int e_count, int e_begin2, int e_count2, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData md,
      double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
@@ -275,9 +275,10 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
         return;
     }
     M::stage_begin();
+    // (two element ranges: the overlapped multi-GPU schedule runs the deep elements first, then the two groups around them)
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
-    if (el >= e_count) return;
-    const int e = e_begin + el;
+    if (el >= e_count + e_count2) return;
+    const int e = el < e_count ? e_begin + el : e_begin2 + (el - e_count);
     const bool defer = e2_element<M, DEFER, GEO>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
                                             plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);
     // one atomic per wavefront that has such elements; without DEFER only the count is kept

@@ -42,7 +42,7 @@ struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *s
 
 template <int THREADS, int INC, int PN, int PE, int CONSTM>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 3)
-EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int ne, int nblocks, int npb,
+EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int ne, int b0, int c0, int b1, int c1, int do_clock, int npb,
      const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag, const MatData md,
      const double *__restrict__ radiogenic, const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm,
@@ -54,10 +54,13 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     __shared__ double lm[CONSTM ? 1 : PE];
     __shared__ double ltd[INC];
     __shared__ unsigned short lidx[INC];
-    const int lb = desk::logical_block(nblocks);
+    // this launch covers the node blocks [b0, b0 + c0) and [b1, b1 + c1): all of them (0, nb, 0, 0), or -- overlapped
+    // multi-GPU schedule -- first the blocks deep inside the slab, later the ones near its cuts (engine/launch.hpp)
+    const int L = desk::logical_block(c0 + c1);
+    const int lb = L < c0 ? b0 + L : b1 + (L - c0);
     const int n0 = lb * npb;
     const double dt = clk->dt;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {             // never in the isostasy loop (en1_ok)
+    if (do_clock && blockIdx.x == 0 && threadIdx.x == 0) { // never in the isostasy loop (en1_ok); once per step
         // Output::average_fields' time0 (output.cxx:332) of the step that has just ended, when its end-of-step pass
         // (and with it k_average_fields) was left to the next stress update
         if (p->is_outputting_averaged_fields && clk->steps % p->quality_check_step_interval == 1) clk->avg_time0 = clk->time;
@@ -66,7 +69,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         clk->maxdh = 0.0;
         clk->n_defer = 0;
     }
-    if (n0 >= nn) return;                                  // grid padding
+    if (L >= c0 + c1 || n0 >= nn) return;                  // grid padding
     const int nown = min(npb, nn - n0);
     const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
     const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];

@@ -177,6 +177,8 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
  * side stream while the end-of-step pass of the interior elements runs; default: everything
  * in order on the engine's stream) */
 int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped);
+/* in-order (0) or overlapped (1) schedule from the next des_dev_step call on; every rank must choose the same */
+int des_dev_set_overlap(des_dev *h, int on);
 /* the ghost-region exchange through the attached communicator, asynchronous on the engine's
  * stream: what des_dev_step issues between the two phases of a step */
 int des_dev_exchange(des_dev *h);
