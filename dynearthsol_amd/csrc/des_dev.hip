@@ -471,7 +471,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     {
         const char *env = std::getenv("DES_PATCH");
         h->patch = false;
-        if (!(env && env[0] == '0') && !params->has_PT) {      // (the PT loop re-enters the passes mid-step: classic pairs)
+        if (!(env && env[0] == '0')) {
             PatchLists P;
             // DES_PATCH=<n>: n nodes per block; default: the largest of 64, 56, 48, 40, 32 whose biggest
             // block fits the three-workgroups-per-CU LDS shapes of both patch kernels (valence-32 nodes of

@@ -159,8 +159,7 @@ int pt_loop(des_dev *h, bool in_step = true)
         launch_e1<MODE_C | MODE_A>(h);
         launch_n1(h);
         launch_e2(h);
-        launch_e3(h);
-        launch_n3(h);
+        launch_force_pass(h);                              // E3 + N3, or EN3 (the facet terms then ride in E2's launch)
         launch_s3(h, false, false, true);
         if ((rc = sync_clock(h))) return rc;
         ++h->n_pt_iterations;

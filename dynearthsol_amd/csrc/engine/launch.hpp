@@ -131,7 +131,8 @@ k_average_fields(const des_params *__restrict__ p, DevClock *__restrict__ clk, i
 // multi-GPU schedule (which cuts the end-of-step pass in two)
 inline bool en1_ok(const des_dev *h)
 {
-    return h->patch && h->patch_n1 && h->p.has_moving_mesh && !h->iso && h->p.damping_option != 4;
+    // (nor with the pseudo-transient loop: its iterations re-enter the passes without a clock or temperature update)
+    return h->patch && h->patch_n1 && h->p.has_moving_mesh && !h->iso && h->p.damping_option != 4 && !h->p.has_PT;
 }
 
 // The next stress update can do the end-of-step pass of this step itself: E2<GEO> (passes/e2.hpp) forms
@@ -487,13 +488,13 @@ void launch_en3(des_dev *h)
         else if (h->patch_max_inc <= 1664 && h->patch_max_pn <= 320) k = T == 512 ? EN3_force_nodes<512, 1664, 320> : EN3_force_nodes<256, 1664, 320>;
         else k = T == 512 ? EN3_force_nodes<512, DES_PATCH_INC, DES_PATCH_PN> : EN3_force_nodes<256, DES_PATCH_INC, DES_PATCH_PN>;
         hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk,
-                           (int)(h->p.is_using_mixed_stress && !h->iso), h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb,
+                           (int)(h->p.is_using_mixed_stress && !h->iso && !h->in_pt), h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb,
                            h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag, h->ntmp, mat_data(h),
                            h->volume, h->dpressure, h->stress, h->ddp, h->bc_mask, h->bcn_idx, h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass,
                            h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part);
     }
     std::swap(h->xt, h->xt_alt);               // the records EN3 wrote are the current ones from here on
-    if (h->p.is_using_mixed_stress && !h->iso) h->ddp_live = true;      // ddp[] now holds this step's NMD increments
+    if (h->p.is_using_mixed_stress && !h->iso && !h->in_pt) h->ddp_live = true;      // ddp[] now holds this step's NMD increments
 }
 
 // update_force + everything nodal that follows it in a step

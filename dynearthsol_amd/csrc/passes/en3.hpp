@@ -69,7 +69,10 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
         E.ew = PE_.ew; E.ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
         E.sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
-        const int e = E.ew & 0x3fffffff;
+        int e = E.ew & 0x3fffffff;
+#ifdef DES_EXP_EN3_FAKE_ELEM
+        e = (e & 1023) + (lb & 7) * 1024; // timing experiment only (wrong results): the element loads hit a few hot lines
+#endif
         const unsigned eo = (unsigned)e * 8u;               // scalar plane base + one 32-bit offset (passes/common.hpp)
         for (int k = 0; k < 6; ++k) E.s[k] = pl_ld(stress, k, ne, eo);
         E.vol = pl_ld(volume, 0, ne, eo);
@@ -93,7 +96,10 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     }
     // (c) the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
-        const int id = j < nown ? n0 + j : (pn_id[h0 + j - nown] & 0x7fffffff);      // (bit 31: a surface node, for EN1)
+        int id = j < nown ? n0 + j : (pn_id[h0 + j - nown] & 0x7fffffff);      // (bit 31: a surface node, for EN1)
+#ifdef DES_EXP_EN3_FAKE_STAGE
+        id = n0 + (j & 63);              // timing experiment only (wrong results): the staging gathers hit lines already on their way
+#endif
         lxt[j] = xt[id];
         if (nmd) lnt[j] = ntmp[id];
     }

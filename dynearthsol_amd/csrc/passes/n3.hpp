@@ -213,6 +213,7 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
         // update_coordinate (dynearthsol.cxx:798-872): those two follow in k_apply_vbcs
         m4.x = v[0]; m4.y = v[1]; m4.z = v[2];
         vm[n] = m4;
+        if (always_store_xt) xt_out[n] = x4;           // (EN3: the record goes to the other buffer of the pair, moved or not)
         return l2;
     }
     if (clk->iso) {
