@@ -356,6 +356,19 @@ class EngineBase:
         buf = np.ascontiguousarray(buf, dtype=np.float64)
         self._check(f(self._h, kind, idx.ctypes.data_as(C.c_void_p), len(idx), buf.ctypes.data_as(C.c_void_p)), "halo_unpack")
 
+    def wall_get(self):
+        f = self._f("wall_get")
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        out = np.empty(3)
+        self._check(f(self._h, out.ctypes.data_as(C.c_void_p)), "wall_get")
+        return out
+
+    def wall_set(self, red):
+        f = self._f("wall_set")
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        red = np.ascontiguousarray(red, dtype=np.float64)
+        self._check(f(self._h, red.ctypes.data_as(C.c_void_p)), "wall_set")
+
     def dt_partials(self, recompute):
         f = self._f("dt_partials")
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]

@@ -1157,9 +1157,14 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
 int des_dev_group_attach(des_dev **engines, int n)
 {
     if (!engines || n < 1) return DES_ERR_INTERNAL;
+    {
+        int n2 = 0;
+        for (int k = 0; k < n; ++k) if (engines[k] && engines[k]->d2) ++n2;
+        if (n2 == n) return DES_OK;                 // 2-D engines: des2d::step_group checks the lists each call
+        if (n2) { g_last_error = "a group mixes 2-D and 3-D engines"; return DES_ERR_UNSUPPORTED_DIM; }
+    }
     for (int k = 0; k < n; ++k) {
         des_dev *h = engines[k];
-        D2_REFUSE(h, "the domain decomposition");
         if (!h) return DES_ERR_INTERNAL;
         if (h->comm) { g_last_error = "an engine with an RCCL communicator cannot join a group"; return DES_ERR_INTERNAL; }
         for (int q = 0; q < h->nnbr; ++q)
@@ -1208,6 +1213,16 @@ int des_dev_group_detach(des_dev **engines, int n)
 int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
 {
     if (!engines || n < 1 || nsteps < 0) return DES_ERR_INTERNAL;
+    if (engines[0] && engines[0]->d2) {
+        std::vector<des2d::Engine *> g2((size_t)n);
+        for (int k = 0; k < n; ++k) {
+            if (!engines[k] || !engines[k]->d2) { g_last_error = "a group mixes 2-D and 3-D engines"; return DES_ERR_UNSUPPORTED_DIM; }
+            g2[k] = engines[k]->d2;
+        }
+        const int rc2 = des2d::step_group(g2.data(), n, nsteps, out);
+        if (rc2) for (int k = 0; k < n; ++k) if (!des2d::last_error(g2[k]).empty()) { g_last_error = des2d::last_error(g2[k]); break; }
+        return rc2;
+    }
     for (int k = 0; k < n; ++k)
         if (!engines[k] || engines[k]->d2 || engines[k]->group_n != n || engines[k]->group_rank != k || engines[k]->group[k] != engines[k]) {
             g_last_error = "des_dev_step_group: not the group des_dev_group_attach was given"; return DES_ERR_INTERNAL;
@@ -1292,8 +1307,8 @@ int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
 // ---- domain decomposition ---------------------------------------------------------
 int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
 {
-    D2_REFUSE(h, "the domain decomposition");
     if (!h || !halo) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, set_halo(h->d2, halo, nnode_global));
     if (h->p.has_PT && (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn)) {
         g_last_error = "control.has_PT on a decomposed mesh: the loop's residual test is global";
         return DES_ERR_UNSUPPORTED;
@@ -1371,7 +1386,7 @@ int des_dev_comm_unique_id(unsigned char *id128)
 
 int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128)
 {
-    D2_REFUSE(h, "the domain decomposition");
+    D2_REFUSE(h, "the RCCL communicator inside des_dev_step");
     if (!h || !id128) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     ncclUniqueId id;
@@ -1402,7 +1417,7 @@ int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
 // create selects it from the start) between two des_dev_step calls.
 int des_dev_set_overlap(des_dev *h, int on)
 {
-    D2_REFUSE(h, "the domain decomposition");
+    D2_REFUSE(h, "the overlapped schedule");
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -1416,7 +1431,7 @@ int des_dev_set_overlap(des_dev *h, int on)
 // between the two phases of a step); asynchronous on the engine's stream.
 int des_dev_exchange(des_dev *h)
 {
-    D2_REFUSE(h, "the ghost-region exchange");
+    D2_REFUSE(h, "the RCCL communicator inside des_dev_step");
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     return exchange(h);
@@ -1427,7 +1442,11 @@ int des_dev_exchange(des_dev *h)
 // engines on one GPU.  Returns 1 after phase 1 when the compute_dt partials are ready.
 int des_dev_phase(des_dev *h, int phase)
 {
-    D2_REFUSE(h, "the two-phase step");
+    if (h && h->d2) {
+        const int r = des2d::phase(h->d2, phase);
+        if (r < 0) g_last_error = des2d::last_error(h->d2);
+        return r;
+    }
     if (!h) return -DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     switch (phase) {
@@ -1491,20 +1510,38 @@ static int state_io(des_dev *h, int what, const int *idx, int n, double *buf, bo
 
 int des_dev_halo_pack(des_dev *h, int what, const int *idx, int n, double *buf)
 {
-    D2_REFUSE(h, "the ghost-region exchange");
+    D2_FORWARD(h, halo_pack(h->d2, what, idx, n, buf));
     return state_io(h, what, idx, n, buf, true);
 }
 
 int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const double *buf)
 {
-    D2_REFUSE(h, "the ghost-region exchange");
+    D2_FORWARD(h, halo_unpack(h->d2, what, idx, n, buf));
     return state_io(h, what, idx, n, const_cast<double *>(buf), false);
+}
+
+// What apply_vbcs reads off the WHOLE mesh in a 2-D model (bc.cxx:251-290, 350-361: the x0 wall's vertical extent, the
+// lowest node), as this rank's mesh has it / as the cross-rank MAX gave it -- once after every exchange and before
+// des_dev_init_geometry.  A 3-D model has nothing of the kind: zeros out, nothing in.
+int des_dev_wall_get(des_dev *h, double out[3])
+{
+    if (!h || !out) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, wall_get(h->d2, out));
+    out[0] = out[1] = out[2] = 0.0;
+    return DES_OK;
+}
+
+int des_dev_wall_set(des_dev *h, const double in[3])
+{
+    if (!h || !in) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, wall_set(h->d2, in));
+    return DES_OK;
 }
 
 int des_dev_dt_partials(des_dev *h, double out[6], int recompute)
 {
-    D2_REFUSE(h, "the split compute_dt");
     if (!h) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, dt_partials(h->d2, out, recompute));
     hipSetDevice(h->device);
     if (recompute) { refresh_props(h); launch_e1<MODE_DT>(h); }
     hipLaunchKernelGGL(k_dt_pack, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->d_red, h->dt_part, h->dt_part_cap,
@@ -1517,8 +1554,8 @@ int des_dev_dt_partials(des_dev *h, double out[6], int recompute)
 
 int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt)
 {
-    D2_REFUSE(h, "the split compute_dt");
     if (!h) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, dt_finalize(h->d2, in, dt));
     hipSetDevice(h->device);
     HIP_OK(hipMemcpyAsync(h->d_red, in, 48, hipMemcpyHostToDevice, h->stream));
     launch_dt_finalize(h, h->d_red);

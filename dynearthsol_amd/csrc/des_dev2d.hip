@@ -79,6 +79,18 @@ struct Engine {
     double *stress_avg = nullptr, *dplstrain_avg = nullptr, *strain0 = nullptr, *coord_avg0 = nullptr;
     double *res_part = nullptr; int res_nb = 0;
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
+    // domain decomposition (set_halo): this engine holds one node slab + its ghost region
+    bool halo = false, halo_set = false;       // halo: the mesh has neighbours (set_halo with nnbr > 0)
+    int o0 = 0, o1 = 0, nn_global = 0;         // owned nodes [o0, o1) of nn; the residual's divisor is global
+    int *top_pos = nullptr;                    // [nn] position of a node in top_nodes, -1 below the surface
+    int nnbr = 0;
+    std::vector<int> nbr_rank, send_ptr, recv_ptr, esend_ptr, erecv_ptr;
+    std::vector<long long> send_off, recv_off; // [nnbr + 1] doubles: a message = node records, then element records
+    int *d_send_idx = nullptr, *d_send_noff = nullptr, *d_esend_idx = nullptr, *d_send_eoff = nullptr;
+    int *d_recv_idx = nullptr, *d_recv_noff = nullptr, *d_erecv_idx = nullptr, *d_recv_eoff = nullptr;
+    double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+    double *d_red = nullptr;                   // [8] scratch of the cross-rank reductions
+    double *h_red = nullptr;                   // pinned copy
     bool markers_dirty = true, iso = false;
     bool count_past = false;           // this step feeds des_scalars::n_return_mapping (the last one of a call)
     long long steps_host = 0;
@@ -797,13 +809,14 @@ __global__ void k2_damp_vel(const des_params *p, const Clock *clk, int nn, const
 }
 
 // calculate_residual_force (fields.cxx:700-722): per-block partial sums, then one block adds them
-__global__ void k2_residual_part(int nn, const double *fres, double *part)
+// (a decomposed mesh: over the rank's owned nodes [o0, o1), divisor = the global node count)
+__global__ void k2_residual_part(int nn, int o0, int o1, int nn_global, const double *fres, double *part)
 {
     __shared__ double sm[DES_BLOCK / 64];
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    const int i = o0 + blockIdx.x * DES_BLOCK + threadIdx.x;
     double v = 0;
-    if (i < nn) {
-        const double num = (double)nn * 2;
+    if (i < o1) {
+        const double num = (double)nn_global * 2;
         for (int j = 0; j < 2; ++j) { const double f = fres[j*nn + i]; v += f * f / num; }
     }
     v = desk::wave_sum(v);
@@ -1067,11 +1080,14 @@ __global__ void k2_surf_edv(int etop, int nn, const int *ean, const int *conn_su
 }
 
 // max |dh| -> max_surf_vel (bc.cxx:1820-1836).  One workgroup.
-__global__ void k2_surf_maxdh(int ntop, const double *dh, Clock *clk)
+__global__ void k2_surf_maxdh(int ntop, const int *top_nodes, int o0, int o1, const double *dh, Clock *clk)
 {
     __shared__ double sm[DES_BLOCK / 64];
     double m = 0.;
-    for (int i = threadIdx.x; i < ntop; i += DES_BLOCK) m = fmax(m, fabs(dh[i]));
+    for (int i = threadIdx.x; i < ntop; i += DES_BLOCK) {
+        const int n = top_nodes[i];
+        if (n >= o0 && n < o1) m = fmax(m, fabs(dh[i]));
+    }
     m = desk::wave_max(m);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -1338,6 +1354,94 @@ __global__ void k2_quality(int nn, int ne, const int *conn, const double *coord,
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
+
+// ---- domain decomposition: the ghost-region records, the wall extent, the split compute_dt ----------
+// A node record = x, z, vx, vz, T, dh (DES_X_NODE_WIDTH_2D); an element record = stress[3], strain[3],
+// plstrain, stressyy (DES_X_ELEM_WIDTH_2D).  dh[] is indexed by position in top_nodes: top_pos maps a node there.
+__global__ void k2_state_pack(int n_nodes, const int *nidx, const int *noff, int n_elems, const int *eidx, const int *eoff,
+                              int nn, int ne, const double *coord, const double *vel, const double *temperature,
+                              const int *top_pos, const double *dh, const double *stress, const double *strain,
+                              const double *plstrain, const double *stressyy, double *buf)
+{
+    const int k = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (k < n_nodes) {
+        const int n = nidx[k];
+        double *r = buf + noff[k];
+        r[0] = coord[n]; r[1] = coord[nn + n]; r[2] = vel[n]; r[3] = vel[nn + n]; r[4] = temperature[n];
+        const int t = top_pos[n];
+        r[5] = t >= 0 ? dh[t] : 0.0;
+    } else if (k - n_nodes < n_elems) {
+        const int e = eidx[k - n_nodes];
+        double *r = buf + eoff[k - n_nodes];
+        for (int j = 0; j < 3; ++j) { r[j] = stress[j*ne + e]; r[3 + j] = strain[j*ne + e]; }
+        r[6] = plstrain[e]; r[7] = stressyy[e];
+    }
+}
+
+__global__ void k2_state_unpack(int n_nodes, const int *nidx, const int *noff, int n_elems, const int *eidx, const int *eoff,
+                                int nn, int ne, double *coord, double *vel, double *temperature, const int *top_pos, double *dh,
+                                double *stress, double *strain, double *plstrain, double *stressyy, const double *buf)
+{
+    const int k = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (k < n_nodes) {
+        const int n = nidx[k];
+        const double *r = buf + noff[k];
+        coord[n] = r[0]; coord[nn + n] = r[1]; vel[n] = r[2]; vel[nn + n] = r[3]; temperature[n] = r[4];
+        const int t = top_pos[n];
+        if (t >= 0) dh[t] = r[5];
+    } else if (k - n_nodes < n_elems) {
+        const int e = eidx[k - n_nodes];
+        const double *r = buf + eoff[k - n_nodes];
+        for (int j = 0; j < 3; ++j) { stress[j*ne + e] = r[j]; strain[j*ne + e] = r[3 + j]; }
+        plstrain[e] = r[6]; stressyy[e] = r[7];
+    }
+}
+
+// What apply_vbcs reads off the whole mesh (bc.cxx:251-290, 350-361), as this rank sees it: out = {max z of the x0
+// wall, max -z of it, max(0, max -z) of every node}, -DBL_MAX where the rank holds no wall node -- three maxima, so the
+// cross-rank reduction (MAX) is exact whatever the order.  One workgroup.
+__global__ void k2_wall_local(int nb, const int *bnodes_x0, int nn, const double *coord, int with_zmin, double *out)
+{
+    __shared__ double sm[3][DES_BLOCK / 64];
+    double mx = -DBL_MAX, mn = -DBL_MAX, nz = 0.0;
+    for (int j = threadIdx.x; j < nb; j += DES_BLOCK) {
+        const double z = coord[nn + bnodes_x0[j]];
+        mx = fmax(mx, z); mn = fmax(mn, -z);
+    }
+    if (with_zmin) for (int i = threadIdx.x; i < nn; i += DES_BLOCK) nz = fmax(nz, -coord[nn + i]);
+    mx = desk::wave_max(mx); mn = desk::wave_max(mn); nz = desk::wave_max(nz);
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sm[0][w] = mx; sm[1][w] = mn; sm[2][w] = nz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < DES_BLOCK / 64; ++w) for (int q = 0; q < 3; ++q) sm[q][0] = fmax(sm[q][0], sm[q][w]);
+        out[0] = sm[0][0]; out[1] = sm[1][0]; out[2] = sm[2][0];
+    }
+}
+
+// ... and the reduced values into the clock, where k2_vbc_extent / k2_vbc_zmin put them on an undivided mesh
+__global__ void k2_wall_set(Clock *clk, double x0_max, double neg_x0_min, double neg_zmin, int with_zmin)
+{
+    const bool any = x0_max != -DBL_MAX;
+    clk->x0_init = any;
+    clk->x0_max = any ? x0_max : 0.;
+    clk->x0_min = any ? -neg_x0_min : 0.;
+    clk->zmin = with_zmin ? -neg_zmin : 0.;
+}
+
+// compute_dt across ranks: the element reduction's result out (six minima: the two maxima negated) ...
+__global__ void k2_dt_pack(const Clock *clk, double *red)
+{
+    red[0] = clk->r_minl; red[1] = clk->r_dt_maxwell; red[2] = clk->r_dt_diffusion;
+    red[3] = clk->r_global_dt_min; red[4] = -clk->r_max_vem; red[5] = -clk->max_surf_vel;
+}
+
+// ... and the reduced six back in, ahead of k2_dt_finalize
+__global__ void k2_dt_unpack(Clock *clk, const double *red)
+{
+    clk->r_minl = red[0]; clk->r_dt_maxwell = red[1]; clk->r_dt_diffusion = red[2];
+    clk->r_global_dt_min = red[3]; clk->r_max_vem = -red[4]; clk->max_surf_vel = -red[5];
+}
+
 struct FieldRef { void *ptr; long long count; int elsize; };
 
 FieldRef field_ref(const Engine *h, int field)
@@ -1396,12 +1500,18 @@ void launch_volume_mass(Engine *h, bool with_mass)
            h->mass, h->tmass, h->ymass);
 }
 
+inline bool wall_needs_zmin(const Engine *h) { return h->p.vbc_types[0] == 3 && h->p.bottom_shear_zone_thickness > 0.; }
+
 void launch_vbcs(Engine *h)
 {
-    hipLaunchKernelGGL(k2_vbc_extent, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord, h->d_clk);
-    if (h->p.vbc_types[0] == 3 && h->p.bottom_shear_zone_thickness > 0.) {
-        L2(k2_vbc_zmin, h->nn, h->nn, h->coord, h->neg_zmin);
-        hipLaunchKernelGGL(k2_vbc_zmin_fin, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->neg_zmin);
+    // (a decomposed mesh: the wall's extent is the cross-rank maximum wall_set left in the clock -- the coordinates
+    // have not moved since it was taken, update_coordinate comes after apply_vbcs)
+    if (!h->halo) {
+        hipLaunchKernelGGL(k2_vbc_extent, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord, h->d_clk);
+        if (wall_needs_zmin(h)) {
+            L2(k2_vbc_zmin, h->nn, h->nn, h->coord, h->neg_zmin);
+            hipLaunchKernelGGL(k2_vbc_zmin_fin, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->neg_zmin);
+        }
     }
     L2(k2_apply_vbcs, h->nn, h->d_p, h->d_clk, h->nn, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->coord, h->vel);
 }
@@ -1442,8 +1552,9 @@ void launch_stress_bcs(Engine *h)
     }
 }
 
-// update_mesh (dynearthsol.cxx:448-493) after update_coordinate
-void launch_update_mesh(Engine *h, long long steps)
+// update_mesh (dynearthsol.cxx:448-493) after update_coordinate, in two parts: up to the committed surface heights
+// (where a decomposed mesh refreshes its ghost region) ...
+void launch_surface_commit(Engine *h)
 {
     const des_params &p = h->p;
     // surface_processes (bc.cxx:1709-1872)
@@ -1452,9 +1563,15 @@ void launch_update_mesh(Engine *h, long long steps)
     if (h->ntop > 0)
         L2(k2_surf_node, h->ntop, h->d_p, h->d_clk, h->ntop, h->nn, h->ne, h->top_nodes, h->etmp, h->tmp_result, h->total_dx,
            h->total_slope, h->coord, h->dhacc, h->dh);
+}
+
+// ... and the rest
+void launch_update_mesh_rest(Engine *h, long long steps)
+{
+    const des_params &p = h->p;
     if (h->etop > 0)
         L2(k2_surf_edv, h->etop, h->etop, h->nn, h->ean, h->conn_surf, h->coord, h->dh, h->edvacc);
-    hipLaunchKernelGGL(k2_surf_maxdh, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->ntop, h->dh, h->d_clk);
+    hipLaunchKernelGGL(k2_surf_maxdh, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->ntop, h->top_nodes, h->o0, h->o1, h->dh, h->d_clk);
     const bool at_interval = steps % p.quality_check_step_interval == 0;
     const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
     if (h->ntop_elems > 0)
@@ -1500,8 +1617,8 @@ void launch_mechanics(Engine *h, bool nmd)
     L2(k2_force_node, nn, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->tmp_result, h->force, h->fres);
     launch_stress_bcs(h);
     L2(k2_damp_vel, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->force, h->vel);
-    L2(k2_residual_part, nn, nn, h->fres, h->res_part);
-    hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(nn), h->res_part, h->d_clk);
+    L2(k2_residual_part, h->o1 - h->o0, nn, h->o0, h->o1, h->nn_global, h->fres, h->res_part);
+    hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
 }
 
 int set_pt(Engine *h, int on)
@@ -1542,8 +1659,9 @@ int pt_loop(Engine *h)
     return set_pt(h, 0);
 }
 
+// A step up to the committed surface heights ...
 template <class M>
-int one_step(Engine *h)
+int step_front(Engine *h)
 {
     const des_params &p = h->p;
     const int nn = h->nn, ne = h->ne;
@@ -1562,9 +1680,18 @@ int one_step(Engine *h)
     else launch_vbcs(h);
     if (p.has_moving_mesh || h->iso) {
         L2(k2_update_coord, 2 * nn, h->d_clk, 2 * nn, h->vel, h->coord);
-        launch_update_mesh(h, h->steps_host);
+        launch_surface_commit(h);
     }
-    if (h->iso) return DES_OK;
+    return DES_OK;
+}
+
+// ... and from there on (a decomposed mesh has refreshed its ghost region in between); compute_dt excluded
+void step_back(Engine *h)
+{
+    const des_params &p = h->p;
+    const int nn = h->nn, ne = h->ne;
+    if (p.has_moving_mesh || h->iso) launch_update_mesh_rest(h, h->steps_host);
+    if (h->iso) return;
     if (p.rheol_type & DES_RH_ELASTIC)
         L2(k2_rotate, ne, h->d_clk, nn, ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
     if (p.is_outputting_averaged_fields) {
@@ -1572,8 +1699,50 @@ int one_step(Engine *h)
         L2(k2_average, std::max(3 * ne, 2 * nn), h->d_clk, first, 2 * nn, ne, h->coord, h->strain, h->stress, h->delta_plstrain,
            h->coord_avg0, h->strain0, h->stress_avg, h->dplstrain_avg);
     }
-    if (h->steps_host % 10 == 0) launch_dt(h);
+}
+
+template <class M>
+int one_step(Engine *h)
+{
+    int rc = step_front<M>(h);
+    if (rc) return rc;
+    step_back(h);
+    if (!h->iso && h->steps_host % 10 == 0) launch_dt(h);
     return DES_OK;
+}
+
+void launch_dt_partials(Engine *h)
+{
+    refresh_props(h);
+    hipLaunchKernelGGL(k2_dt_init, dim3(1), dim3(1), 0, h->stream, h->d_clk);
+    L2(k2_dt_partials, h->ne, h->d_p, h->d_clk, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
+}
+
+void launch_pack(Engine *h)
+{
+    const int nq = h->nnbr, n = h->send_ptr[nq], m = h->esend_ptr[nq];
+    if (n + m == 0) return;
+    L2(k2_state_pack, n + m, n, h->d_send_idx, h->d_send_noff, m, h->d_esend_idx, h->d_send_eoff, h->nn, h->ne, h->coord, h->vel,
+       h->temperature, h->top_pos, h->dh, h->stress, h->strain, h->plstrain, h->stressyy, h->d_sendbuf);
+}
+
+void launch_unpack(Engine *h)
+{
+    const int nq = h->nnbr, n = h->recv_ptr[nq], m = h->erecv_ptr[nq];
+    if (n + m == 0) return;
+    L2(k2_state_unpack, n + m, n, h->d_recv_idx, h->d_recv_noff, m, h->d_erecv_idx, h->d_recv_eoff, h->nn, h->ne, h->coord, h->vel,
+       h->temperature, h->top_pos, h->dh, h->stress, h->strain, h->plstrain, h->stressyy, h->d_recvbuf);
+}
+
+void launch_wall_local(Engine *h)
+{
+    hipLaunchKernelGGL(k2_wall_local, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord,
+                       wall_needs_zmin(h) ? 1 : 0, h->d_red);
+}
+
+void launch_wall_set(Engine *h, const double in[3])
+{
+    hipLaunchKernelGGL(k2_wall_set, dim3(1), dim3(1), 0, h->stream, h->d_clk, in[0], in[1], in[2], wall_needs_zmin(h) ? 1 : 0);
 }
 
 } // namespace
@@ -1587,6 +1756,7 @@ void destroy(Engine *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *q : h->allocs) hipFree(q);
     if (h->h_clk) hipHostFree(h->h_clk);
+    if (h->h_red) hipHostFree(h->h_red);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1596,6 +1766,7 @@ void destroy(Engine *h)
 static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh)
 {
     const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
+    h->o0 = 0; h->o1 = nn; h->nn_global = nn;
     HIP2(hipStreamCreate(&h->stream));
     HIP2(hipEventCreate(&h->ev0));
     HIP2(hipEventCreate(&h->ev1));
@@ -1652,6 +1823,8 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->edvacc, (size_t)h->etop));
     A2(dalloc(h, h->res_part, (size_t)nblk(nn)));
     A2(dalloc(h, h->neg_zmin, 1));
+    A2(dalloc(h, h->d_red, 8));
+    HIP2(hipHostMalloc((void **)&h->h_red, 8 * sizeof(double)));
     if (params->is_outputting_averaged_fields) {
         A2(dalloc(h, h->stress_avg, (size_t)3 * ne)); A2(dalloc(h, h->strain0, (size_t)3 * ne));
         A2(dalloc(h, h->dplstrain_avg, (size_t)ne)); A2(dalloc(h, h->coord_avg0, (size_t)2 * nn));
@@ -1770,9 +1943,24 @@ int compute_dt(Engine *h, double *dt)
     return h->h_clk->dt > 0 ? DES_OK : DES_ERR_RUNTIME_NAN;
 }
 
+static int fill_scalars(Engine *h, des_scalars *out)
+{
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    const Clock &c = *h->h_clk;
+    out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
+    out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min; out->steps = c.steps;
+    out->status = c.status; out->n_return_mapping = c.n_past; out->avg_time0 = c.avg_time0; out->n_pt_iterations = h->n_pt_iterations;
+    return c.status;
+}
+
 int step(Engine *h, int nsteps, des_scalars *out)
 {
     HIP2(hipSetDevice(h->device));
+    if (h->halo && nsteps > 0) {
+        h->err = "a decomposed 2-D engine steps through des_dev_step_group or des_dev_phase + the exchange entry points";
+        return DES_ERR_UNSUPPORTED;
+    }
     h->n_pt_iterations = 0;
     for (int i = 0; i < nsteps; ++i) {
         h->count_past = (i == nsteps - 1);
@@ -1780,16 +1968,239 @@ int step(Engine *h, int nsteps, des_scalars *out)
         if (rc) return rc;
     }
     HIP2(hipGetLastError());
-    if (out) {
-        int rc = sync_clock(h);
-        if (rc) return rc;
-        const Clock &c = *h->h_clk;
-        out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
-        out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min; out->steps = c.steps;
-        out->status = c.status; out->n_return_mapping = c.n_past; out->avg_time0 = c.avg_time0; out->n_pt_iterations = h->n_pt_iterations;
-        return c.status;
-    }
+    if (out) return fill_scalars(h, out);
     return DES_OK;
+}
+
+// ---- domain decomposition (des_dev.h: des_dev_set_halo ... des_dev_step_group) ------------------------------------
+// The 2-D model is cut like the 3-D one (host/partition.cpp: node slabs along x in the reference's renumbered
+// order + four element layers of ghost region); one exchange per step after the surface heights are committed.
+// Beside the ghost records two small reductions cross the ranks: the x0 wall's vertical extent apply_vbcs scales its
+// velocity profiles with (every step, MAX of three), and compute_dt's minima (every 10th step).
+int set_halo(Engine *h, const des_halo *halo, int nn_global)
+{
+    HIP2(hipSetDevice(h->device));
+    if (h->p.has_PT && (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn)) {
+        h->err = "control.has_PT on a decomposed mesh: the loop's residual test is global";
+        return DES_ERR_UNSUPPORTED;
+    }
+    if (halo->owned_begin < 0 || halo->owned_end > h->nn || halo->owned_begin >= halo->owned_end) return DES_ERR_INTERNAL;
+    h->o0 = halo->owned_begin; h->o1 = halo->owned_end; h->nn_global = nn_global;
+    const int nq = h->nnbr = halo->nnbr;
+    h->halo_set = true; h->halo = nq > 0;
+    h->nbr_rank.assign(halo->nbr_rank, halo->nbr_rank + nq);
+    h->send_ptr.assign(halo->send_ptr, halo->send_ptr + nq + 1);
+    h->recv_ptr.assign(halo->recv_ptr, halo->recv_ptr + nq + 1);
+    h->esend_ptr.assign(halo->esend_ptr, halo->esend_ptr + nq + 1);
+    h->erecv_ptr.assign(halo->erecv_ptr, halo->erecv_ptr + nq + 1);
+    auto layout = [&](const std::vector<int> &np, const std::vector<int> &ep, std::vector<long long> &off,
+                      std::vector<int> &noff, std::vector<int> &eoff) {
+        off.assign((size_t)nq + 1, 0);
+        noff.resize((size_t)np[nq]); eoff.resize((size_t)ep[nq]);
+        for (int q = 0; q < nq; ++q) {
+            long long base = off[q];
+            for (int k = np[q]; k < np[q+1]; ++k) noff[k] = (int)(base + (long long)(k - np[q]) * DES_X_NODE_WIDTH_2D);
+            base += (long long)(np[q+1] - np[q]) * DES_X_NODE_WIDTH_2D;
+            for (int k = ep[q]; k < ep[q+1]; ++k) eoff[k] = (int)(base + (long long)(k - ep[q]) * DES_X_ELEM_WIDTH_2D);
+            off[q+1] = base + (long long)(ep[q+1] - ep[q]) * DES_X_ELEM_WIDTH_2D;
+        }
+    };
+    std::vector<int> snoff, seoff, rnoff, reoff;
+    layout(h->send_ptr, h->esend_ptr, h->send_off, snoff, seoff);
+    layout(h->recv_ptr, h->erecv_ptr, h->recv_off, rnoff, reoff);
+    int rc;
+#define A2(x) do { rc = (x); if (rc) return rc; } while (0)
+    A2(dcopy(h, h->d_send_idx, halo->send_idx, (size_t)h->send_ptr[nq]));
+    A2(dcopy(h, h->d_recv_idx, halo->recv_idx, (size_t)h->recv_ptr[nq]));
+    A2(dcopy(h, h->d_esend_idx, halo->esend_idx, (size_t)h->esend_ptr[nq]));
+    A2(dcopy(h, h->d_erecv_idx, halo->erecv_idx, (size_t)h->erecv_ptr[nq]));
+    A2(dcopy(h, h->d_send_noff, snoff.data(), snoff.size()));
+    A2(dcopy(h, h->d_send_eoff, seoff.data(), seoff.size()));
+    A2(dcopy(h, h->d_recv_noff, rnoff.data(), rnoff.size()));
+    A2(dcopy(h, h->d_recv_eoff, reoff.data(), reoff.size()));
+    A2(dalloc(h, h->d_sendbuf, (size_t)h->send_off[nq]));
+    A2(dalloc(h, h->d_recvbuf, (size_t)h->recv_off[nq]));
+    {
+        std::vector<int> top((size_t)h->ntop), pos((size_t)h->nn, -1);
+        if (h->ntop) HIP2(hipMemcpy(top.data(), h->top_nodes, top.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < h->ntop; ++i) pos[top[i]] = i;
+        A2(dcopy(h, h->top_pos, pos.data(), pos.size()));
+    }
+#undef A2
+    return DES_OK;
+}
+
+// One phase of a step without any communication (the caller moves the ghost records and reduces the wall extent in
+// between).  Returns 1 after phase 1 when this is a compute_dt step (the partials are in the clock), < 0: -error.
+int phase(Engine *h, int ph)
+{
+    if (hipSetDevice(h->device) != hipSuccess) return -DES_ERR_RESOURCE;
+    if (ph == 0) {
+        h->count_past = true;
+        const int rc = h->portable_libm ? step_front<desk::MathPortable>(h) : step_front<desk::MathOcml>(h);
+        return rc ? -rc : 0;
+    }
+    if (ph != 1) return -DES_ERR_INTERNAL;
+    step_back(h);
+    if (h->iso || h->steps_host % 10 != 0) return 0;
+    launch_dt_partials(h);
+    return 1;
+}
+
+// state records of the listed local ids to / from a host buffer (what = 0: nodes, 1: elements)
+static int state_io(Engine *h, int what, const int *idx, int n, double *buf, bool pack)
+{
+    if (what < 0 || what > 1) return DES_ERR_INTERNAL;
+    HIP2(hipSetDevice(h->device));
+    if (n == 0) return DES_OK;
+    if (!h->top_pos) { h->err = "des_dev_halo_pack / unpack before des_dev_set_halo"; return DES_ERR_INTERNAL; }
+    const size_t w = what == 0 ? DES_X_NODE_WIDTH_2D : DES_X_ELEM_WIDTH_2D;
+    std::vector<int> off((size_t)n);
+    for (int k = 0; k < n; ++k) off[k] = (int)(k * w);
+    int *d_idx = nullptr, *d_off = nullptr; double *d_buf = nullptr;
+    HIP2(hipMalloc((void **)&d_idx, (size_t)n * sizeof(int)));
+    HIP2(hipMalloc((void **)&d_off, (size_t)n * sizeof(int)));
+    HIP2(hipMalloc((void **)&d_buf, (size_t)n * w * sizeof(double)));
+    HIP2(hipMemcpyAsync(d_idx, idx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP2(hipMemcpyAsync(d_off, off.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const int n_nodes = what == 0 ? n : 0, n_elems = what == 0 ? 0 : n;
+    if (pack) {
+        L2(k2_state_pack, n, n_nodes, d_idx, d_off, n_elems, d_idx, d_off, h->nn, h->ne, h->coord, h->vel, h->temperature,
+           h->top_pos, h->dh, h->stress, h->strain, h->plstrain, h->stressyy, d_buf);
+        HIP2(hipMemcpyAsync(buf, d_buf, (size_t)n * w * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        HIP2(hipMemcpyAsync(d_buf, buf, (size_t)n * w * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        L2(k2_state_unpack, n, n_nodes, d_idx, d_off, n_elems, d_idx, d_off, h->nn, h->ne, h->coord, h->vel, h->temperature,
+           h->top_pos, h->dh, h->stress, h->strain, h->plstrain, h->stressyy, d_buf);
+    }
+    HIP2(hipStreamSynchronize(h->stream));
+    hipFree(d_idx); hipFree(d_off); hipFree(d_buf);
+    return DES_OK;
+}
+
+int halo_pack(Engine *h, int what, const int *idx, int n, double *buf) { return state_io(h, what, idx, n, buf, true); }
+int halo_unpack(Engine *h, int what, const int *idx, int n, const double *buf) { return state_io(h, what, idx, n, const_cast<double *>(buf), false); }
+
+int wall_get(Engine *h, double out[3])
+{
+    HIP2(hipSetDevice(h->device));
+    launch_wall_local(h);
+    HIP2(hipMemcpyAsync(out, h->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP2(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int wall_set(Engine *h, const double in[3])
+{
+    HIP2(hipSetDevice(h->device));
+    launch_wall_set(h, in);
+    return DES_OK;
+}
+
+int dt_partials(Engine *h, double out[6], int recompute)
+{
+    HIP2(hipSetDevice(h->device));
+    if (recompute) launch_dt_partials(h);
+    hipLaunchKernelGGL(k2_dt_pack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    HIP2(hipMemcpyAsync(out, h->d_red, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP2(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int dt_finalize(Engine *h, const double in[6], double *dt)
+{
+    HIP2(hipSetDevice(h->device));
+    HIP2(hipMemcpyAsync(h->d_red, in, 6 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k2_dt_unpack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    hipLaunchKernelGGL(k2_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk);
+    int rc = sync_clock(h);
+    if (rc) return rc;
+    if (dt) *dt = h->h_clk->dt;
+    return h->h_clk->status;
+}
+
+// Several engines of ONE process as the ranks of one decomposed model (des_dev_step_group): ghost records by
+// device-to-device copies between the message buffers; the two reductions through the host, which joins every
+// engine's stream for them (the 2-D models are the small ones: simplicity over overlap here).
+int step_group(Engine **g, int n, int nsteps, des_scalars *out)
+{
+    for (int k = 0; k < n; ++k) {
+        Engine *h = g[k];
+        if (!h->halo_set) { h->err = "des_dev_step_group: des_dev_set_halo first"; return DES_ERR_INTERNAL; }
+        for (int q = 0; q < h->nnbr; ++q) {
+            const int r = h->nbr_rank[q];
+            int qo = -1;
+            if (r >= 0 && r < n && r != k) for (int j = 0; j < g[r]->nnbr; ++j) if (g[r]->nbr_rank[j] == k) qo = j;
+            if (qo < 0 || g[r]->send_off[qo + 1] - g[r]->send_off[qo] != h->recv_off[q + 1] - h->recv_off[q]) {
+                h->err = "group: the exchange lists of two neighbours do not match"; return DES_ERR_INTERNAL;
+            }
+        }
+        h->n_pt_iterations = 0;
+    }
+    Engine *h = g[0];                               // (HIP2 books errors on rank 0)
+    HIP2(hipSetDevice(h->device));
+    for (int i = 0; i < nsteps; ++i) {
+        for (int k = 0; k < n; ++k) {
+            g[k]->count_past = (i == nsteps - 1);
+            const int rc = g[k]->portable_libm ? step_front<desk::MathPortable>(g[k]) : step_front<desk::MathOcml>(g[k]);
+            if (rc) return rc;
+            launch_pack(g[k]);
+        }
+        for (int k = 0; k < n; ++k) HIP2(hipStreamSynchronize(g[k]->stream));
+        for (int k = 0; k < n; ++k) {
+            Engine *e = g[k];
+            for (int q = 0; q < e->nnbr; ++q) {
+                Engine *o = g[e->nbr_rank[q]];
+                int qo = 0;
+                for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
+                const long long len = e->recv_off[q + 1] - e->recv_off[q];
+                if (len) HIP2(hipMemcpyAsync(e->d_recvbuf + e->recv_off[q], o->d_sendbuf + o->send_off[qo], (size_t)len * sizeof(double),
+                                             hipMemcpyDeviceToDevice, e->stream));
+            }
+            launch_unpack(e);
+            launch_wall_local(e);
+            HIP2(hipMemcpyAsync(e->h_red, e->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        }
+        double wall[3] = {-DBL_MAX, -DBL_MAX, 0.0};
+        for (int k = 0; k < n; ++k) {
+            HIP2(hipStreamSynchronize(g[k]->stream));
+            for (int q = 0; q < 3; ++q) wall[q] = std::max(wall[q], g[k]->h_red[q]);
+        }
+        bool do_dt = false;
+        for (int k = 0; k < n; ++k) {
+            Engine *e = g[k];
+            launch_wall_set(e, wall);
+            step_back(e);
+            if (!e->iso && e->steps_host % 10 == 0) {
+                do_dt = true;
+                launch_dt_partials(e);
+                hipLaunchKernelGGL(k2_dt_pack, dim3(1), dim3(1), 0, e->stream, e->d_clk, e->d_red);
+                HIP2(hipMemcpyAsync(e->h_red, e->d_red, 6 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            }
+        }
+        if (do_dt) {
+            double red[6];
+            for (int q = 0; q < 6; ++q) red[q] = DBL_MAX;
+            for (int k = 0; k < n; ++k) {
+                HIP2(hipStreamSynchronize(g[k]->stream));
+                for (int q = 0; q < 6; ++q) red[q] = std::min(red[q], g[k]->h_red[q]);
+            }
+            for (int k = 0; k < n; ++k) {
+                Engine *e = g[k];
+                for (int q = 0; q < 6; ++q) e->h_red[q] = red[q];
+                HIP2(hipMemcpyAsync(e->d_red, e->h_red, 6 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+                hipLaunchKernelGGL(k2_dt_unpack, dim3(1), dim3(1), 0, e->stream, e->d_clk, e->d_red);
+                hipLaunchKernelGGL(k2_dt_finalize, dim3(1), dim3(1), 0, e->stream, e->d_p, e->d_clk);
+            }
+        }
+    }
+    HIP2(hipGetLastError());
+    int worst = DES_OK;
+    for (int k = 0; k < n; ++k) {
+        if (out) { const int rc = fill_scalars(g[k], &out[k]); if (rc && !worst) worst = rc; }
+        else HIP2(hipStreamSynchronize(g[k]->stream));
+    }
+    return worst;
 }
 
 int check_nan(Engine *h, long long *n_nan)

@@ -7,8 +7,9 @@
 // the 2-D apply_vbcs (bc.cxx:227-400, 425-481), 1-D surface diffusion (bc.cxx:1021-1033,
 // 1067-1106), jaumann_rate_2d (fields.cxx:807-821), the 2-D compute_dt / elem_quality
 // (geometry.cxx:1566-1576, 1901-1906).  Every des_dev_* entry point dispatches here when the
-// handle holds a 2-D engine; what a 2-D model cannot have (the domain decomposition and its
-// exchange / two-phase entry points) returns DES_ERR_UNSUPPORTED_DIM.
+// handle holds a 2-D engine, the domain decomposition included (node slabs along x, the two-phase
+// step with the caller's exchange, des_dev_step_group); what it does not offer (the RCCL
+// communicator inside des_dev_step, the overlapped schedule) returns DES_ERR_UNSUPPORTED_DIM.
 //
 // Arrays stay in the reference's own SoA layout and the caller's numbering: the 2-D configs of
 // BASELINE.json are the CPU-runnable plumbing case (configs[0]), bit-for-bit parity with the
@@ -42,6 +43,16 @@ int mesh_quality(Engine *h, double smallest_vol, double bottom, double bottom_di
 int timer_start(Engine *h);
 int timer_stop(Engine *h, float *ms);
 double algorithmic_bytes_per_step(const Engine *h);
+// domain decomposition
+int set_halo(Engine *h, const des_halo *halo, int nn_global);
+int phase(Engine *h, int ph);
+int halo_pack(Engine *h, int what, const int *idx, int n, double *buf);
+int halo_unpack(Engine *h, int what, const int *idx, int n, const double *buf);
+int wall_get(Engine *h, double out[3]);
+int wall_set(Engine *h, const double in[3]);
+int dt_partials(Engine *h, double out[6], int recompute);
+int dt_finalize(Engine *h, const double in[6], double *dt);
+int step_group(Engine **g, int n, int nsteps, des_scalars *out);
 
 } // namespace des2d
 

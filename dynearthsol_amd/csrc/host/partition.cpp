@@ -17,7 +17,9 @@
 #include <unordered_map>
 
 namespace {
-const int NODE_OF_FACET[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};
+const int NODE_OF_FACET3[4][3] = {{1,2,3},{0,3,2},{0,1,3},{0,2,1}};   // constants.hpp:64-69
+const int NODE_OF_FACET2[3][2] = {{1,2},{2,0},{0,1}};                  // constants.hpp:71-75
+inline int node_of_facet(int nd, int f, int j) { return nd == 3 ? NODE_OF_FACET3[f][j] : NODE_OF_FACET2[f % 3][j & 1]; }
 }
 
 #define DES_GHOST_LAYERS 4
@@ -64,7 +66,7 @@ struct Reach {
 
 static void grow(const HostMesh &g, int a, int b, int nlayers, Reach &R)
 {
-    const int ne = g.nelem, nn = g.nnode;
+    const int ne = g.nelem, nn = g.nnode, npe = g.nd + 1;
     R.elem_layer.assign((size_t)ne, -1);
     R.node_depth.assign((size_t)nn, -1);
     std::vector<int> frontier;
@@ -76,7 +78,7 @@ static void grow(const HostMesh &g, int a, int b, int nlayers, Reach &R)
                 const int e = g.sup_arr[q];
                 if (R.elem_layer[e] >= 0) continue;
                 R.elem_layer[e] = (signed char)k;
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < npe; ++i) {
                     const int m = g.conn[(size_t)i*ne + e];
                     if (R.node_depth[m] < 0) { R.node_depth[m] = (signed char)(k + 1); next.push_back(m); }
                 }
@@ -89,6 +91,7 @@ void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
 {
     if (nranks < 1 || rank < 0 || rank >= nranks) throw Error(60, "bad rank / nranks");
     const int ne = g.nelem, nn = g.nnode;
+    const int nd = g.nd, npe = nd + 1, npf = nd;           // tets / triangles (the 2-D build: constants.hpp:12-25)
     const int nlayers = DES_GHOST_LAYERS;
     P.node_start = split_nodes(g, nranks);
     const int a = P.node_start[rank], b = P.node_start[rank + 1];
@@ -108,13 +111,14 @@ void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
 
     HostMesh &m = P.local;
     m = HostMesh();
+    m.nd = nd;
     m.nnode = lnn; m.nelem = lne; m.nseg = 0;
-    m.coord.resize((size_t)3*lnn);
+    m.coord.resize((size_t)nd*lnn);
     for (int n = 0; n < lnn; ++n)
-        for (int d = 0; d < 3; ++d) m.coord[(size_t)d*lnn + n] = g.coord[(size_t)d*nn + P.l2g_node[n]];
-    m.conn.resize((size_t)4*lne);
+        for (int d = 0; d < nd; ++d) m.coord[(size_t)d*lnn + n] = g.coord[(size_t)d*nn + P.l2g_node[n]];
+    m.conn.resize((size_t)npe*lne);
     for (int e = 0; e < lne; ++e)
-        for (int i = 0; i < 4; ++i) m.conn[(size_t)i*lne + e] = g2l[g.conn[(size_t)i*ne + P.l2g_elem[e]]];
+        for (int i = 0; i < npe; ++i) m.conn[(size_t)i*lne + e] = g2l[g.conn[(size_t)i*ne + P.l2g_elem[e]]];
     m.regattr.resize((size_t)lne);
     for (int e = 0; e < lne; ++e) m.regattr[e] = g.regattr[P.l2g_elem[e]];
     m.bcflag.resize((size_t)lnn);
@@ -133,13 +137,13 @@ void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
     // support of the local mesh (complete up to ghost depth nlayers-1, partial for the outermost nodes)
     m.sup_idx.assign((size_t)lnn + 1, 0);
     for (int e = 0; e < lne; ++e)
-        for (int i = 0; i < 4; ++i) m.sup_idx[m.conn[(size_t)i*lne + e] + 1]++;
+        for (int i = 0; i < npe; ++i) m.sup_idx[m.conn[(size_t)i*lne + e] + 1]++;
     for (int n = 1; n <= lnn; ++n) m.sup_idx[n] += m.sup_idx[n-1];
     m.sup_arr.resize((size_t)m.sup_idx[lnn]); m.sup_lidx.resize((size_t)m.sup_idx[lnn]);
     {
         std::vector<int> cursor(m.sup_idx.begin(), m.sup_idx.end() - 1);
         for (int e = 0; e < lne; ++e)
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < npe; ++i) {
                 int slot = cursor[m.conn[(size_t)i*lne + e]]++;
                 m.sup_arr[slot] = e; m.sup_lidx[slot] = i;
             }
@@ -148,24 +152,24 @@ void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
     m.top_nodes.clear();
     for (size_t i = 0; i < g.top_nodes.size(); ++i) { int l = g2l[g.top_nodes[i]]; if (l >= 0) m.top_nodes.push_back(l); }
     const int etop = (int)m.bfacet_elem[5].size(), ntop = (int)m.top_nodes.size();
-    m.conn_surf.assign((size_t)4*etop, 0);
+    m.conn_surf.assign((size_t)npe*etop, 0);
     for (int i = 0; i < etop; ++i)
-        for (int j = 0; j < 3; ++j)
-            m.conn_surf[(size_t)j*etop + i] = m.conn[(size_t)NODE_OF_FACET[m.bfacet_facet[5][i]][j]*lne + m.bfacet_elem[5][i]];
+        for (int j = 0; j < npf; ++j)
+            m.conn_surf[(size_t)j*etop + i] = m.conn[(size_t)node_of_facet(nd, m.bfacet_facet[5][i], j)*lne + m.bfacet_elem[5][i]];
     std::unordered_map<int,int> arctop;
     for (int i = 0; i < ntop; ++i) arctop[m.top_nodes[i]] = i;
-    m.elem_and_nodes.assign((size_t)3*etop, 0);
+    m.elem_and_nodes.assign((size_t)npf*etop, 0);
     for (int i = 0; i < etop; ++i)
-        for (int k = 0; k < 3; ++k) m.elem_and_nodes[(size_t)k*etop + i] = arctop[m.conn_surf[(size_t)k*etop + i]];
+        for (int k = 0; k < npf; ++k) m.elem_and_nodes[(size_t)k*etop + i] = arctop[m.conn_surf[(size_t)k*etop + i]];
     m.ssup_idx.assign((size_t)ntop + 1, 0);
     for (int i = 0; i < etop; ++i)
-        for (int k = 0; k < 3; ++k) m.ssup_idx[m.elem_and_nodes[(size_t)k*etop + i] + 1]++;
+        for (int k = 0; k < npf; ++k) m.ssup_idx[m.elem_and_nodes[(size_t)k*etop + i] + 1]++;
     for (int n = 1; n <= ntop; ++n) m.ssup_idx[n] += m.ssup_idx[n-1];
     m.ssup_arr.resize((size_t)m.ssup_idx[ntop]);
     {
         std::vector<int> cursor(m.ssup_idx.begin(), m.ssup_idx.end() - 1);
         for (int i = 0; i < etop; ++i)
-            for (int k = 0; k < 3; ++k) m.ssup_arr[cursor[m.elem_and_nodes[(size_t)k*etop + i]]++] = i;
+            for (int k = 0; k < npf; ++k) m.ssup_arr[cursor[m.elem_and_nodes[(size_t)k*etop + i]]++] = i;
     }
     m.top_elems.clear();
     for (size_t i = 0; i < g.top_elems.size(); ++i) { int le = g2l_elem[g.top_elems[i]]; if (le >= 0) m.top_elems.push_back(le); }
@@ -180,7 +184,7 @@ void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
     // receiver's growth).
     auto elem_owner = [&](int e) {
         int lo = g.conn[e];
-        for (int i = 1; i < 4; ++i) lo = std::min(lo, g.conn[(size_t)i*ne + e]);
+        for (int i = 1; i < npe; ++i) lo = std::min(lo, g.conn[(size_t)i*ne + e]);
         return owner_of(P.node_start, lo);
     };
     P.elem_owned.assign((size_t)lne, 0);
@@ -246,8 +250,6 @@ des_part *des_host_partition(const des_host *h, int nranks, int rank, int *err)
 {
     des_part *P = new des_part();
     try {
-        if (des_host_mesh_internal(h)->nd != 3)
-            throw des::Error(DES_ERR_UNSUPPORTED_DIM, "the slab decomposition is built for 3-D meshes only");
         des::build_partition(*des_host_mesh_internal(h), nranks, rank, *P);
         if (err) *err = DES_OK;
         return P;

@@ -18,8 +18,11 @@ from . import load_host_lib, DesError, DesMesh, F
 from ._structs import DesHalo
 
 NODE_WIDTH, ELEM_WIDTH = 8, 13     # DES_X_NODE_WIDTH, DES_X_ELEM_WIDTH (des_params.h)
+WIDTHS = {3: (NODE_WIDTH, ELEM_WIDTH), 2: (6, 8)}      # ... and DES_X_NODE_WIDTH_2D, DES_X_ELEM_WIDTH_2D
 NODAL = {"coord": 3, "vel": 3, "temperature": 1}
 ELEMENTAL = {"stress": 6, "strain": 6, "plstrain": 1, "viscosity": 1, "radiogenic": 1}
+NODAL_2D = {"coord": 2, "vel": 2, "temperature": 1}
+ELEMENTAL_2D = {"stress": 3, "strain": 3, "plstrain": 1, "viscosity": 1, "radiogenic": 1, "stressyy": 1}
 
 
 class Partition:
@@ -46,6 +49,8 @@ class Partition:
         self.mesh = lib.des_part_mesh(self._p).contents
         self.halo = lib.des_part_halo(self._p).contents
         self.params = host.params
+        self.ndims = int(host.params.ndims)
+        self.node_width, self.elem_width = WIDTHS[self.ndims]
         self.nnode, self.nelem = self.mesh.nnode, self.mesh.nelem
 
         def ints(fn):
@@ -71,11 +76,12 @@ class Partition:
     def local(self, name):
         """This rank's slice of a global host array, in the reference's SoA layout."""
         a = self.host.array(name)
-        if name in NODAL:
-            c = NODAL[name]
+        nodal, elemental = (NODAL_2D, ELEMENTAL_2D) if self.ndims == 2 else (NODAL, ELEMENTAL)
+        if name in nodal:
+            c = nodal[name]
             return np.ascontiguousarray(a.reshape(c, -1)[:, self.l2g_node]).ravel()
-        if name in ELEMENTAL:
-            c = ELEMENTAL[name]
+        if name in elemental:
+            c = elemental[name]
             return np.ascontiguousarray(a.reshape(c, -1)[:, self.l2g_elem]).ravel()
         if name == "elemmarkers":
             nmat = self.params.nmat
@@ -94,18 +100,30 @@ class Partition:
             pass
 
 
-def init_rank(engine, part, comm):
-    """init() + first compute_dt of main() for one rank (dynearthsol.cxx:175-221, 643)."""
+def init_rank_mesh(engine, part):
     engine.set_halo(part)
     coord = part.local("coord")
     engine.upload("COORD", coord)
     engine.upload("COORD0", coord)
     engine.upload("ELEMMARKERS", part.local("elemmarkers"))
     engine.upload("VEL", part.local("vel"))
+
+
+def init_rank_fields(engine, part):
     engine.init_geometry()
     for f, name in (("TEMPERATURE", "temperature"), ("RADIOGENIC", "radiogenic"), ("STRESS", "stress"),
                     ("STRAIN", "strain"), ("PLSTRAIN", "plstrain"), ("VISCOSITY", "viscosity")):
         engine.upload(f, part.local(name))
+    if part.ndims == 2:
+        engine.upload("STRESSYY", part.local("stressyy"))
+
+
+def init_rank(engine, part, comm):
+    """init() + first compute_dt of main() for one rank (dynearthsol.cxx:175-221, 643)."""
+    init_rank_mesh(engine, part)
+    if part.ndims == 2:
+        comm.reduce_wall(engine)        # apply_vbcs inside init_geometry reads the whole mesh's x0 wall (des_dev.h)
+    init_rank_fields(engine, part)
     return comm.reduce_dt(engine, recompute=True)
 
 
@@ -120,6 +138,8 @@ class PhasedStepper:
         for _ in range(nsteps):
             e.phase(0)
             self.comm.exchange(self)
+            if self.part.ndims == 2:
+                self.comm.reduce_wall(e)
             if e.phase(1):
                 self.comm.reduce_dt(e, recompute=False)
 
@@ -136,13 +156,18 @@ class LoopbackComm:
         for st in self.steppers:
             p = st.part
             for q, idx, eidx in zip(p.nbr_rank, p.send_idx, p.esend_idx):
-                boxes[(p.rank, q)] = (st.engine.halo_pack(0, idx, NODE_WIDTH), st.engine.halo_pack(1, eidx, ELEM_WIDTH))
+                boxes[(p.rank, q)] = (st.engine.halo_pack(0, idx, p.node_width), st.engine.halo_pack(1, eidx, p.elem_width))
         for st in self.steppers:
             p = st.part
             for q, idx, eidx in zip(p.nbr_rank, p.recv_idx, p.erecv_idx):
                 nbuf, ebuf = boxes[(q, p.rank)]
                 st.engine.halo_unpack(0, idx, nbuf)
                 st.engine.halo_unpack(1, eidx, ebuf)
+
+    def reduce_wall_all(self):
+        red = np.array([st.engine.wall_get() for st in self.steppers]).max(axis=0)
+        for st in self.steppers:
+            st.engine.wall_set(red)
 
     def reduce_dt_all(self, recompute):
         parts = np.array([st.engine.dt_partials(recompute) for st in self.steppers])
@@ -155,6 +180,8 @@ def run_loopback(steppers, nsteps):
     for _ in range(nsteps):
         for st in steppers: st.engine.phase(0)
         comm.exchange_all()
+        if steppers[0].part.ndims == 2:
+            comm.reduce_wall_all()
         flags = [st.engine.phase(1) for st in steppers]
         if any(flags):
             comm.reduce_dt_all(recompute=False)
@@ -172,8 +199,8 @@ class TorchComm:
         p, e = stepper.part, stepper.engine
         reqs, recvs = [], []
         for q, sidx, ridx, seidx, reidx in zip(p.nbr_rank, p.send_idx, p.recv_idx, p.esend_idx, p.erecv_idx):
-            sbuf = torch.from_numpy(np.concatenate([e.halo_pack(0, sidx, NODE_WIDTH), e.halo_pack(1, seidx, ELEM_WIDTH)]))
-            rbuf = torch.empty(len(ridx) * NODE_WIDTH + len(reidx) * ELEM_WIDTH, dtype=torch.float64)
+            sbuf = torch.from_numpy(np.concatenate([e.halo_pack(0, sidx, p.node_width), e.halo_pack(1, seidx, p.elem_width)]))
+            rbuf = torch.empty(len(ridx) * p.node_width + len(reidx) * p.elem_width, dtype=torch.float64)
             reqs.append(dist.isend(sbuf, dst=q, group=self.group))
             reqs.append(dist.irecv(rbuf, src=q, group=self.group))
             recvs.append((ridx, reidx, rbuf, sbuf))
@@ -181,8 +208,13 @@ class TorchComm:
             r.wait()
         for ridx, reidx, rbuf, _ in recvs:
             a = rbuf.numpy()
-            e.halo_unpack(0, ridx, a[:len(ridx) * NODE_WIDTH])
-            e.halo_unpack(1, reidx, a[len(ridx) * NODE_WIDTH:])
+            e.halo_unpack(0, ridx, a[:len(ridx) * p.node_width])
+            e.halo_unpack(1, reidx, a[len(ridx) * p.node_width:])
+
+    def reduce_wall(self, engine):
+        t = self.torch.from_numpy(engine.wall_get())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        engine.wall_set(t.numpy())
 
     def reduce_dt(self, engine, recompute):
         t = self.torch.from_numpy(engine.dt_partials(recompute))
@@ -219,11 +251,12 @@ class DeviceGroup:
         steppers = [PhasedStepper(e, p, None) for e, p in zip(self.engines, self.parts)]
         comm = LoopbackComm(steppers)
 
-        class _NoReduce:
-            def reduce_dt(self, engine, recompute):
-                return None
         for e, p in zip(self.engines, self.parts):
-            init_rank(e, p, _NoReduce())
+            init_rank_mesh(e, p)
+        if self.parts[0].ndims == 2:
+            comm.reduce_wall_all()
+        for e, p in zip(self.engines, self.parts):
+            init_rank_fields(e, p)
         dts = comm.reduce_dt_all(recompute=True)
         assert all(d == dts[0] for d in dts)
         return dts[0]

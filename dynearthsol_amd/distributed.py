@@ -30,7 +30,7 @@ _NODE3 = {"COORD", "VEL", "FORCE", "FORCE_RESIDUAL", "COORD0", "COORD_AVG0"}
 _NODE1 = {"TEMPERATURE", "VOLUME_N", "MASS", "TMASS", "DHACC", "NTMP"}
 _ELEM6 = {"STRESS", "STRAIN", "STRAIN_RATE", "STRESS_AVG", "STRAIN0"}
 _ELEM1 = {"PLSTRAIN", "DELTA_PLSTRAIN", "VISCOSITY", "VOLUME", "VOLUME_OLD", "DPRESSURE", "EDVOLDT", "RADIOGENIC",
-          "DPLSTRAIN_AVG"}
+          "DPLSTRAIN_AVG", "STRESSYY"}
 
 
 class CollectiveEngine:
@@ -43,6 +43,8 @@ class CollectiveEngine:
         # host-side gathers / reductions of numpy data go over gloo whatever the main backend is
         self.group = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
         self.host = host
+        self.ndims = int(host.params.ndims)
+        self.nvec, self.nsym = (3, 6) if self.ndims == 3 else (2, 3)       # components of a nodal vector / a symmetric tensor
         self.part = Partition(host, self.world, self.rank)
         self.engine = engine_factory(self.part)
         self.engine.set_halo(self.part)
@@ -93,11 +95,11 @@ class CollectiveEngine:
     def upload(self, name, glob):
         p = self.part
         if name in _NODE3:
-            loc = glob.reshape(3, -1)[:, p.l2g_node]
+            loc = glob.reshape(self.nvec, -1)[:, p.l2g_node]
         elif name in _NODE1:
             loc = glob[p.l2g_node]
         elif name in _ELEM6:
-            loc = glob.reshape(6, -1)[:, p.l2g_elem]
+            loc = glob.reshape(self.nsym, -1)[:, p.l2g_elem]
         elif name in _ELEM1:
             loc = glob[p.l2g_elem]
         elif name == "ELEMMARKERS":
@@ -111,10 +113,10 @@ class CollectiveEngine:
     def download(self, name):
         a = self.engine.download(name)
         if name in _NODE3 or name in _NODE1:
-            c = 3 if name in _NODE3 else 1
+            c = self.nvec if name in _NODE3 else 1
             return self._gather_rows(a.reshape(c, -1)[:, self.own_nodes_l], self.g_nodes, self.nn).ravel()
         if name in _ELEM6 or name in _ELEM1:
-            c = 6 if name in _ELEM6 else 1
+            c = self.nsym if name in _ELEM6 else 1
             return self._gather_rows(a.reshape(c, -1)[:, self.own_elems_l], self.g_elems, self.ne).ravel()
         if name == "ELEMMARKERS":
             rows = a.reshape(self.part.nelem, -1)[self.own_elems_l].T
@@ -211,9 +213,9 @@ def collective_api(ce):
     @driver.COUNT_T
     def field_count(h, field):
         name = FIELDS[field]
-        if name in _NODE3: return 3 * ce.nn
+        if name in _NODE3: return ce.nvec * ce.nn
         if name in _NODE1: return ce.nn
-        if name in _ELEM6: return 6 * ce.ne
+        if name in _ELEM6: return ce.nsym * ce.ne
         if name in _ELEM1: return ce.ne
         if name == "ELEMMARKERS": return ce.ne * ce.host.params.nmat
         if name == "DH": return ce.ntop_global
@@ -229,6 +231,8 @@ def collective_api(ce):
     @driver.INITGEOM_T
     @guard
     def init_geometry(h):
+        if ce.ndims == 2 and ce.stepper is not None:
+            ce.stepper.comm.reduce_wall(ce.engine)         # apply_vbcs reads the whole mesh's x0 wall (des_dev.h)
         ce.engine.init_geometry()
         return 0
 
@@ -288,8 +292,15 @@ def run_distributed(host, dist, engine_factory=None, stepper=None, quiet=True):
         def engine_factory(part):
             eng = DeviceEngine(part, device=local)
             return eng
+    two_d = int(host.params.ndims) == 2
+    if two_d and stepper is None:
+        # the 2-D engine has no communicator of its own: the two-phase step, ghost records and the two small reductions
+        # moved by torch.distributed (host-staged; the 2-D models are the small ones)
+        gloo = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+        comm = TorchComm(dist, group=gloo)
+        stepper = lambda e, p: PhasedStepper(e, p, comm)
     ce = CollectiveEngine(host, dist, engine_factory, stepper)
-    if isinstance(ce.engine, DeviceEngine):
+    if isinstance(ce.engine, DeviceEngine) and not two_d:
         ce.engine.comm_init(dist, ce.rank, ce.world)
     api = collective_api(ce)
     return driver.run(host, quiet=quiet or ce.rank != 0, api=api)
@@ -300,14 +311,17 @@ def main(argv=None):
     import torch.distributed as dist
     argv = sys.argv[1:] if argv is None else argv
     if not argv:
-        sys.stderr.write("usage: torchrun --nproc-per-node N -m dynearthsol_amd.distributed config.cfg [mesh.desmesh]\n")
+        sys.stderr.write("usage: torchrun --nproc-per-node N -m dynearthsol_amd.distributed [--ndims 2|3] config.cfg [mesh.desmesh]\n")
         return 1
+    ndims = 3
+    if argv[0] == "--ndims":
+        ndims, argv = int(argv[1]), argv[2:]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
     try:
-        host = Host(cfg_path=argv[0], mesh_file=argv[1] if len(argv) > 1 else None)
+        host = Host(cfg_path=argv[0], mesh_file=argv[1] if len(argv) > 1 else None, ndims=ndims)
         st = run_distributed(host, dist, quiet=False)
         return st.exit_code
     finally:

@@ -193,6 +193,14 @@ int des_dev_halo_pack(des_dev *h, int what, const int *idx, int n, double *buf);
 int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const double *buf);
 int des_dev_dt_partials(des_dev *h, double out[6], int recompute);
 int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt);
+/* 2-D models (des_params::ndims = 2; widths DES_X_NODE_WIDTH_2D / DES_X_ELEM_WIDTH_2D) cut the same way have one more
+ * thing to share: apply_vbcs scales its velocity profiles with the vertical extent of the x0 wall and, for vbc_x0 = 3
+ * with a bottom shear zone, the lowest node of the mesh (bc.cxx:251-300, 350-361).  out = {max z of the wall, max -z of
+ * it, max(0, max -z) over all nodes} on this rank's mesh (-DBL_MAX without a wall node); the caller reduces with MAX
+ * across ranks and hands the result back: after every exchange (between phase 0 and phase 1) and once before
+ * des_dev_init_geometry.  des_dev_step_group does it itself.  A 3-D engine: zeros out, nothing in. */
+int des_dev_wall_get(des_dev *h, double out[3]);
+int des_dev_wall_set(des_dev *h, const double in[3]);
 
 /* Several engines of ONE process as the ranks of one decomposed model -- engines[r] is rank r of the
  * des_halo lists (several engines on one GPU: tests and rehearsals of the multi-GPU step at its real

@@ -197,6 +197,8 @@ typedef struct des_halo {
  * geometry pass): widths in doubles per node / per element. */
 #define DES_X_NODE_WIDTH 8           /* x, y, z, vx, vy, vz, T, dh                                  */
 #define DES_X_ELEM_WIDTH 13          /* stress[6], strain[6], plstrain                              */
+#define DES_X_NODE_WIDTH_2D 6        /* 2-D models: x, z, vx, vz, T, dh                             */
+#define DES_X_ELEM_WIDTH_2D 8        /* stress[3], strain[3], plstrain, stressyy                    */
 
 /* Field ids for upload/download.  "E" = per element, "N" = per node. */
 enum des_field {

@@ -119,10 +119,25 @@ def test_what_the_2d_host_does_not_build_is_refused():
     with pytest.raises(des.DesError) as ei:                               # a 3-D mesh file is not a 2-D mesh
         des.Host(cfg_text=cfgs.TEST_TINY, mesh_file=os.path.join(HERE, "golden", "test-3d.desmesh"), ndims=2)
     assert ei.value.code == 30
-    with pytest.raises(des.DesError) as ei:                               # the slab decomposition is 3-D only
-        import dynearthsol_amd.decomp as decomp
-        decomp.Partition(host2d(), 2, 0)
-    assert ei.value.code == 30
+
+
+def test_2d_mesh_is_cut_into_node_slabs_like_the_3d_one():
+    """host/partition.cpp on triangles: owned node ranges tile the mesh, every element is owned once, the local top
+    nodes stay a run of the sorted surface (simple_diffusion walks consecutive pairs, bc.cxx:1021-1033)."""
+    import dynearthsol_amd.decomp as decomp
+    h = host2d()
+    parts = [decomp.Partition(h, 3, r) for r in range(3)]
+    assert sum(p.owned[1] - p.owned[0] for p in parts) == h.nnode
+    assert sum(int(p.elem_owned.sum()) for p in parts) == h.nelem
+    gx = h.array("coord").reshape(2, -1)[0]
+    for p in parts:
+        assert (p.ndims, p.node_width, p.elem_width) == (2, 6, 8)
+        assert p.mesh.etop == p.mesh.ntop - 1
+        top = np.ctypeslib.as_array(p.mesh.top_nodes, shape=(p.mesh.ntop,))
+        x = gx[p.l2g_node[top]]
+        assert (np.diff(x) > 0).all()
+        assert p.local("coord").size == 2 * p.nnode and p.local("stressyy").size == p.nelem
+        assert [q for q in p.nbr_rank] == [r for r in (p.rank - 1, p.rank + 1) if 0 <= r < 3]
 
 
 # ---- oracle: the 2-D constitutive formulas ----------------------------------------------------

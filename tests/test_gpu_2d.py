@@ -216,7 +216,7 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
 def test_what_a_2d_model_cannot_have_is_refused_with_the_dimension_code():
     host = des.Host(cfg_text=cfgs.make(**cfgs.EP), ndims=2)
     dev = des.DeviceEngine(host)
-    assert dev._lib.des_dev_phase(dev._h, 0) == 30 and dev._lib.des_dev_exchange(dev._h) == 30
+    assert dev._lib.des_dev_exchange(dev._h) == 30 and dev._lib.des_dev_set_overlap(dev._h, 1) == 30      # (RCCL inside des_dev_step)
     # an upload with the 3-D size of the field is refused
     with pytest.raises(des.DesError):
         dev.upload("COORD", np.zeros(3 * host.nnode))

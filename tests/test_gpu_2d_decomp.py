@@ -1,0 +1,183 @@
+"""The 2-D build cut into node slabs (host/partition.cpp on triangles: slabs along x in the reference's renumbered
+order + four element layers of ghost region), one device engine per slab on the ONE GPU of this box, against the
+single 2-D engine: every nodal and elemental field and dt, bit for bit.  Two ways of stepping: des_dev_step_group
+(ghost records by device-to-device copies) and the two-phase entry points with the exchange done by the caller
+(des_dev_phase / des_dev_halo_pack / des_dev_halo_unpack / des_dev_wall_get / des_dev_wall_set: what a multi-process
+run over torch.distributed uses).  Beside the ghost records a 2-D model shares the x0 wall's vertical extent
+(apply_vbcs scales its depth profiles with it, bc.cxx:251-300) and, with a sheared bottom zone, the lowest node."""
+import os
+
+import numpy as np
+import pytest
+
+import cfgs
+import dynearthsol_amd as des
+from dynearthsol_amd.decomp import DeviceGroup, PhasedStepper, run_loopback
+from test_gpu_2d import BCS, bc_overrides
+
+pytestmark = pytest.mark.gpu
+
+NODE_FIELDS = (("COORD", 2), ("VEL", 2), ("TEMPERATURE", 1), ("MASS", 1), ("TMASS", 1), ("VOLUME_N", 1), ("FORCE", 2), ("DHACC", 1))
+ELEM_FIELDS = (("STRESS", 3), ("STRAIN", 3), ("STRAIN_RATE", 3), ("PLSTRAIN", 1), ("DELTA_PLSTRAIN", 1), ("VISCOSITY", 1),
+               ("VOLUME", 1), ("VOLUME_OLD", 1), ("DPRESSURE", 1), ("STRESSYY", 1), ("EDVOLDT", 1))
+
+
+def _compare(group, ref, calls, phased=False):
+    steppers = [PhasedStepper(e, p, None) for e, p in zip(group.engines, group.parts)]
+    for n in calls:
+        sref = ref.step(n)
+        if phased:
+            run_loopback(steppers, n)
+            for e in group.engines:
+                s = e.step(0)
+                assert (s.dt, s.time, s.steps, s.status) == (sref.dt, sref.time, sref.steps, 0)
+        else:
+            for s in group.step(n):
+                assert (s.dt, s.time, s.steps, s.status) == (sref.dt, sref.time, sref.steps, 0)
+        for f, c in NODE_FIELDS:
+            assert np.array_equal(group.download(f, c, "node"), ref.download(f)), f
+        for f, c in ELEM_FIELDS:
+            assert np.array_equal(group.download(f, c, "elem"), ref.download(f)), f
+
+
+def _pair(host, nranks):
+    ref = des.DeviceEngine(host)
+    dt_ref = ref.init_from_host(host)
+    group = DeviceGroup(host, nranks)
+    assert group.init_from_host() == dt_ref
+    assert sum(p.owned[1] - p.owned[0] for p in group.parts) == host.nnode
+    assert sum(int(p.elem_owned.sum()) for p in group.parts) == host.nelem
+    return ref, group
+
+
+@pytest.mark.parametrize("nranks,phased", [(2, False), (3, True), (4, False)])
+def test_2d_model_cut_n_ways_is_the_single_engine_bit_for_bit(nranks, phased):
+    # two materials with a geotherm (evp), water load, surface diffusion with its marine branch, dhacc reset + top-element
+    # rescaling every 7th step; compute_dt every 10th
+    kw = dict(cfgs.EVP, nmat=2, res=1e3, qcsi=7, water="yes", control="surf_base_level = -100\nsurf_diff_ratio_marine = 0.5\n")
+    host = des.Host(cfg_text=cfgs.make(**kw), ndims=2)
+    ref, group = _pair(host, nranks)
+    try:
+        _compare(group, ref, (33, 1, 26), phased)
+        assert np.abs(ref.download("DHACC")).max() > 0
+    finally:
+        group.close()
+
+
+@pytest.mark.parametrize("bc", BCS)
+def test_2d_boundary_conditions_on_a_cut_mesh(bc):
+    # depth-dependent side velocities scaled by the x0 wall's extent on BOTH walls (the x1 wall lies on the last rank,
+    # the x0 wall on the first), the sheared bottom zone (lowest node of the whole mesh), Neumann tractions
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EP, res=1e3)), overrides=bc_overrides(bc), ndims=2)
+    ref, group = _pair(host, 3)
+    try:
+        _compare(group, ref, (20, 20, 20))
+    finally:
+        group.close()
+
+
+def test_x1_wall_profile_uses_the_x0_walls_extent_across_ranks():
+    # bc.cxx:299: the x1 wall's depth profile is laid out over the x0 wall's extent; x1 = 1 with a profile
+    ov = ("bc.vbc_x1 = 1\nbc.vbc_val_x1 = 1e-9\nbc.vbc_val_division_x1_min = 0.25\nbc.vbc_val_division_x1_max = 0.7\n"
+          "bc.vbc_val_x1_ratio0 = 1\nbc.vbc_val_x1_ratio1 = 0.6\nbc.vbc_val_x1_ratio2 = 0.3\nbc.vbc_val_x1_ratio3 = 0.1\n")
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, res=1e3)), overrides=ov, ndims=2)
+    ref, group = _pair(host, 4)
+    try:
+        _compare(group, ref, (25, 25))
+    finally:
+        group.close()
+
+
+def test_reference_test_topo_cut_3_ways_2000_steps():
+    """benchmarks-cores/test-topo.cfg on the reference's Triangle mesh of topo.poly (10 km ridge, surface diffusivity
+    1e-2, eight materials, evp with a weak zone): 3 slabs against one engine for the benchmark's 2000 steps."""
+    host = des.Host(cfg_text=cfgs.TEST_TINY, overrides=cfgs.TEST_TOPO_OVERRIDES, ndims=2,
+                    mesh_file=os.path.join(des.REPO_ROOT, "tests", "golden", "test-topo.desmesh"))
+    ref, group = _pair(host, 3)
+    try:
+        _compare(group, ref, (500, 500, 999, 1))
+    finally:
+        group.close()
+
+
+def test_a_million_triangles_cut_8_ways():
+    kw = dict(cfgs.EVP, lx=400e3, lz=100e3, res=250.0)
+    host = des.Host(cfg_text=cfgs.make(**kw), ndims=2)
+    assert host.nelem == 2 * 1600 * 400
+    ref, group = _pair(host, 8)
+    try:
+        ghost_share = sum(p.nelem for p in group.parts) / host.nelem - 1
+        print("8 ranks: %.2f %% ghost-region elements" % (100 * ghost_share))
+        _compare(group, ref, (21, 1))
+    finally:
+        group.close()
+
+
+def test_a_cut_2d_engine_refuses_what_it_does_not_offer():
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EP), ndims=2)
+    group = DeviceGroup(host, 2)
+    try:
+        e = group.engines[0]
+        with pytest.raises(des.DesError) as ei:
+            e.step(1)                                   # des_dev_step on its own: no communicator for 2-D engines
+        assert ei.value.code == 31
+        assert e._lib.des_dev_exchange(e._h) == 30
+    finally:
+        group.close()
+    with pytest.raises(des.DesError):                   # the PT loop's residual test is global
+        DeviceGroup(des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides="control.has_PT = yes\n", ndims=2), 2)
+
+
+# ---- the whole 2-D program on several ranks (dynearthsol_amd/distributed.py) -----------------------------------
+RUN_OV = ("sim.max_steps = 60\nsim.output_step_interval = 20\nsim.checkpoint_frame_interval = 2\n"
+          "mesh.quality_check_step_interval = 10\nsim.is_outputting_averaged_fields = yes\n")
+RUN_KW = dict(cfgs.EVP, nmat=2, res=1e3)
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    from dynearthsol_amd.distributed import run_distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"                # every rank on the one GPU of this box
+    os.chdir(out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host = des.Host(cfg_text=cfgs.make(**RUN_KW), overrides=RUN_OV + "sim.modelname = multi\n", ndims=2)
+    st = run_distributed(host, dist)              # 2-D: the two-phase step, ghost records over torch.distributed
+    assert (st.steps, st.frames, st.exit_code) == (60, 4, 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_2d_program_on_three_ranks_writes_the_frames_of_one(tmp_path):
+    """des_run() on three processes (one device engine each, all on this box's GPU), the 2-D model cut three ways:
+    rank 0's frames, checkpoints and .info equal those of the plain one-engine run, bit for bit."""
+    import torch.multiprocessing as mp
+    from dynearthsol_amd import driver
+    from test_driver_output import read_frame
+    world = 3
+    mp.spawn(_worker, args=(world, 29300 + os.getpid() % 500, str(tmp_path)), nprocs=world, join=True)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        host = des.Host(cfg_text=cfgs.make(**RUN_KW), overrides=RUN_OV + "sim.modelname = single\n", ndims=2)
+        st = driver.run(host)
+        assert (st.steps, st.frames) == (60, 4)
+        files = sorted(f for f in os.listdir(tmp_path) if f.startswith("multi."))
+        assert files == ["multi.chkpt.000000", "multi.chkpt.000002", "multi.info", "multi.save.000000",
+                         "multi.save.000001", "multi.save.000002", "multi.save.000003"]
+        for name in files:
+            if name.endswith(".info"):
+                a, b = np.loadtxt(name).reshape(-1, 8), np.loadtxt(name.replace("multi", "single")).reshape(-1, 8)
+                assert np.array_equal(np.delete(a, 4, axis=1), np.delete(b, 4, axis=1))
+                continue
+            a, b = read_frame(name, ndims=2), read_frame(name.replace("multi", "single"), ndims=2)
+            assert sorted(a) == sorted(b)
+            for k in a:
+                if k != "walltime_sec":
+                    assert np.array_equal(a[k], b[k]), (name, k)
+    finally:
+        os.chdir(cwd)
