@@ -79,6 +79,13 @@ struct Engine {
     double *stress_avg = nullptr, *dplstrain_avg = nullptr, *strain0 = nullptr, *coord_avg0 = nullptr;
     double *res_part = nullptr; int res_nb = 0;
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
+    // node-block patch passes (des_dev2d_patch.hpp); DES2D_PATCH=0 or a mesh outside their LDS caps: the plain kernels
+    bool patch = false, res_fin_pending = false, tick_pending = false;
+    int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0;
+    int *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
+    ulonglong2 *pe_pack = nullptr;
+    double *temperature_alt = nullptr;         // the other buffer of the temperature pair (k2p_temp_dvoldt)
+    double *stress_pre = nullptr;              // the stress between update_stress and NMD_stress (k2p_force)
     // domain decomposition (set_halo): this engine holds one node slab + its ghost region
     bool halo = false, halo_set = false;       // halo: the mesh has neighbours (set_halo with nnbr > 0)
     int o0 = 0, o1 = 0, nn_global = 0;         // owned nodes [o0, o1) of nn; the residual's divisor is global
@@ -494,12 +501,15 @@ __global__ void k2_edvoldt(int ne, const int *conn, const double *ntmp, double *
 }
 
 // update_stress (rheology.cxx:703-1030, non-RSF, non-hydraulic) + the element part of NMD_stress
-template <class M>
+// FUSED = 1 (the patch path, des_dev2d_patch.hpp): edvoldt (compute_edvoldt, geometry.cxx:249-279) is formed here from the
+// nodal values with k2_edvoldt's statements instead of being read back, and the new stress goes to stress_out (another
+// buffer when NMD_stress follows).
+template <class M, int FUSED = 0>
 __global__ void __launch_bounds__(DES_BLOCK)
 k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, const int *conn, const double *temperature,
-          const double *props, const int *markers, const double *edvoldt, const double *volume, const double *volume_old,
-          double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
-          double *viscosity, double *dpressure, double *etmp, int count_past)
+          const double *props, const int *markers, double *edvoldt, const double *volume, const double *volume_old,
+          const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
+          double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out)
 {
     M::stage_begin();
     M::stage_end();
@@ -514,10 +524,18 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         es[i] = strain[i * ne + e];
         edot[i] = strain_rate[i * ne + e];
     }
+    double edv;
+    if (FUSED) {
+        double dj = 0;
+        for (int i = 0; i < 3; ++i) dj += ntmp[conn[i * ne + e]];
+        edv = dj / 3;
+        edvoldt[e] = edv;
+    } else
+        edv = edvoldt[e];
     double old_s = trace2(s);
     {
         double div = trace2(edot);
-        for (int i = 0; i < 2; ++i) edot[i] += (edvoldt[e] - div) / 2;
+        for (int i = 0; i < 2; ++i) edot[i] += (edv - div) / 2;
     }
     for (int i = 0; i < 3; ++i) strain_rate[i * ne + e] = edot[i];
     for (int i = 0; i < 3; ++i) es[i] += edot[i] * dt;
@@ -605,7 +623,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         etmp[e] = dp * volume[e];                      // NMD_stress, geometry.cxx:292-296
     }
     for (int i = 0; i < 3; ++i) {
-        stress[i * ne + e] = s[i];
+        stress_out[i * ne + e] = s[i];
         strain[i * ne + e] = es[i];
     }
 }
@@ -771,11 +789,9 @@ __global__ void k2_neumann(const des_params *p, int ib, int bound, const int *bf
 }
 
 // apply_damping (fields.cxx:483-579) + update_velocity (fields.cxx:725-742) of a node
-__global__ void k2_damp_vel(const des_params *p, const Clock *clk, int nn, const double *mass, const double *ymass,
-                            double *force, double *vel)
+__device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *clk, int i, int nn, const double *mass,
+                                              const double *ymass, double *force, double *vel)
 {
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= nn) return;
     const double small_vel = 1e-13;
     const double dt = clk->dt;
     for (int j = 0; j < 2; j++) {
@@ -808,6 +824,13 @@ __global__ void k2_damp_vel(const des_params *p, const Clock *clk, int nn, const
     }
 }
 
+__global__ void k2_damp_vel(const des_params *p, const Clock *clk, int nn, const double *mass, const double *ymass,
+                            double *force, double *vel)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < nn) damp_vel_node(p, clk, i, nn, mass, ymass, force, vel);
+}
+
 // calculate_residual_force (fields.cxx:700-722): per-block partial sums, then one block adds them
 // (a decomposed mesh: over the rank's owned nodes [o0, o1), divisor = the global node count)
 __global__ void k2_residual_part(int nn, int o0, int o1, int nn_global, const double *fres, double *part)
@@ -825,7 +848,7 @@ __global__ void k2_residual_part(int nn, int o0, int o1, int nn_global, const do
     if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-__global__ void k2_residual_fin(int nb, const double *part, Clock *clk)
+__device__ __forceinline__ void residual_fin_block(int nb, const double *part, Clock *clk)
 {
     __shared__ double sm[DES_BLOCK / 64];
     double v = 0;
@@ -836,9 +859,13 @@ __global__ void k2_residual_fin(int nb, const double *part, Clock *clk)
     if (threadIdx.x == 0) clk->l2_residual = sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
 }
 
+__global__ void k2_residual_fin(int nb, const double *part, Clock *clk) { residual_fin_block(nb, part, clk); }
+
 // apply_vbcs, 2-D: vertical extent of the x0 wall (bc.cxx:251-290; only x0's is used, :292-300) over the list of
 // its nodes.  min / max: exact whatever the order.  One workgroup.
-__global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double *coord, Clock *clk)
+// (tick: the step counter and the model time move on here, k2_clock's two statements -- the patch path's plain step, where
+//  nothing before this launch reads them)
+__global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double *coord, Clock *clk, int tick = 0)
 {
     __shared__ double s_max[DES_BLOCK / 64], s_min[DES_BLOCK / 64];
     double mx = -DBL_MAX, mn = DBL_MAX;
@@ -855,6 +882,7 @@ __global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double
         clk->x0_max = nb > 0 ? s_max[0] : 0.;
         clk->x0_min = nb > 0 ? s_min[0] : 0.;
         clk->zmin = 0;                       // k2_vbc_zmin lowers it when the sheared bottom zone needs it
+        if (tick) { clk->steps++; clk->time += clk->dt; }
     }
 }
 
@@ -877,11 +905,10 @@ __global__ void k2_vbc_zmin(int nn, const double *coord, double *neg_zmin)
 __global__ void k2_vbc_zmin_fin(Clock *clk, double *neg_zmin) { clk->zmin = -(*neg_zmin); *neg_zmin = 0.0; }
 
 // apply_vbcs (bc.cxx:227-659, !THREED) of a node; Clock::pt = PT_jump: boundaries at rest (bc.cxx:330-343)
-__global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, const unsigned *bcflag, const double *bnormals,
-                              const double *edge_vec, const int *edge_slot, const double *coord, double *vel)
+__device__ __forceinline__ void vbcs_node(const des_params *p, const Clock *clk, int i, int nn, const unsigned *bcflag,
+                                          const double *bnormals, const double *edge_vec, const int *edge_slot,
+                                          const double *coord, double *vel)
 {
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= nn) return;
     const unsigned flag = bcflag[i];
     if (!(flag & BOUND_ANY)) return;
 
@@ -1013,6 +1040,27 @@ __global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, con
     vel[i] = v[0]; vel[nn + i] = v[1];
 }
 
+__global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, const unsigned *bcflag, const double *bnormals,
+                              const double *edge_vec, const int *edge_slot, const double *coord, double *vel)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < nn) vbcs_node(p, clk, i, nn, bcflag, bnormals, edge_vec, edge_slot, coord, vel);
+}
+
+// apply_damping + update_velocity, apply_vbcs and update_coordinate of a node in one launch: each touches the node's own
+// entries only (apply_vbcs reads the wall extent the clock already holds and the node's own z before it moves)
+__global__ void k2_node_final(const des_params *p, const Clock *clk, int nn, const double *mass, const double *ymass,
+                              const unsigned *bcflag, const double *bnormals, const double *edge_vec, const int *edge_slot,
+                              double *force, double *vel, double *coord)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= nn) return;
+    damp_vel_node(p, clk, i, nn, mass, ymass, force, vel);
+    vbcs_node(p, clk, i, nn, bcflag, bnormals, edge_vec, edge_slot, coord, vel);
+    coord[i] += vel[i] * clk->dt;
+    coord[nn + i] += vel[nn + i] * clk->dt;
+}
+
 // isostasy_adjustment's velocity filter (dynearthsol.cxx:524-533)
 __global__ void k2_iso_vel(const des_params *p, int nn, const unsigned *bcflag, double *vel)
 {
@@ -1030,10 +1078,8 @@ __global__ void k2_update_coord(const Clock *clk, int n2, const double *vel, dou
 }
 
 // simple_diffusion (bc.cxx:916-1112, !THREED): segments of the sorted top nodes ...
-__global__ void k2_surf_seg(int etop, int nn, int ne, const int *top_nodes, const double *coord, double *etmp, double *tmp_result)
+__device__ __forceinline__ void surf_seg_at(int i, int etop, int nn, int ne, const int *top_nodes, const double *coord, double *etmp, double *tmp_result)
 {
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= etop) return;
     const int n0 = top_nodes[i], n1 = top_nodes[i+1];
     double dx = fabs(coord[n1] - coord[n0]);
     etmp[i] = dx;
@@ -1041,14 +1087,18 @@ __global__ void k2_surf_seg(int etop, int nn, int ne, const int *top_nodes, cons
     tmp_result[1 * ne + i] = (coord[nn + n1] - coord[nn + n0]) / dx;
 }
 
+__global__ void k2_surf_seg(int etop, int nn, int ne, const int *top_nodes, const double *coord, double *etmp, double *tmp_result)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < etop) surf_seg_at(i, etop, nn, ne, top_nodes, coord, etmp, tmp_result);
+}
+
 // ... then the height change of every top node; surface_processes moves the node and books dhacc
 // (bc.cxx:1773-1786).  dh[] starts from 0 (bc.cxx:1718-1724).
-__global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
+__device__ __forceinline__ void surf_node_at(int i, const des_params *p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
                              const double *etmp, const double *tmp_result, double *total_dx, double *total_slope,
                              double *coord, double *dhacc, double *dh)
 {
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= ntop) return;
     const int n = top_nodes[i];
     double d = 0.;
     if (p->surface_process_option == 1) {
@@ -1068,19 +1118,31 @@ __global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, in
     dhacc[n] += d;
 }
 
-// edvacc_surf (bc.cxx:1788-1805)
-__global__ void k2_surf_edv(int etop, int nn, const int *ean, const int *conn_surf, const double *coord, const double *dh, double *edvacc)
+__global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
+                             const double *etmp, const double *tmp_result, double *total_dx, double *total_slope,
+                             double *coord, double *dhacc, double *dh)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= etop) return;
+    if (i < ntop) surf_node_at(i, p, clk, ntop, nn, ne, top_nodes, etmp, tmp_result, total_dx, total_slope, coord, dhacc, dh);
+}
+
+// edvacc_surf (bc.cxx:1788-1805)
+__device__ __forceinline__ void surf_edv_at(int i, int etop, int nn, const int *ean, const int *conn_surf, const double *coord, const double *dh, double *edvacc)
+{
     double dh_e = 0.;
     for (int j = 0; j < 2; j++) dh_e += dh[ean[j * etop + i]];
     const double base = fabs(coord[conn_surf[i]] - coord[conn_surf[etop + i]]);      // compute_area_facet, geometry.cxx:109-121
     edvacc[i] += dh_e * base / 2;
 }
 
+__global__ void k2_surf_edv(int etop, int nn, const int *ean, const int *conn_surf, const double *coord, const double *dh, double *edvacc)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < etop) surf_edv_at(i, etop, nn, ean, conn_surf, coord, dh, edvacc);
+}
+
 // max |dh| -> max_surf_vel (bc.cxx:1820-1836).  One workgroup.
-__global__ void k2_surf_maxdh(int ntop, const int *top_nodes, int o0, int o1, const double *dh, Clock *clk)
+__device__ __forceinline__ void surf_maxdh_block(int ntop, const int *top_nodes, int o0, int o1, const double *dh, Clock *clk)
 {
     __shared__ double sm[DES_BLOCK / 64];
     double m = 0.;
@@ -1098,14 +1160,17 @@ __global__ void k2_surf_maxdh(int ntop, const int *top_nodes, int o0, int o1, co
     }
 }
 
+__global__ void k2_surf_maxdh(int ntop, const int *top_nodes, int o0, int o1, const double *dh, Clock *clk)
+{
+    surf_maxdh_block(ntop, top_nodes, o0, o1, dh, clk);
+}
+
 // correct_surface_element (bc.cxx:1655-1707), element part; surface_plstrain_diffusion (bc.cxx:1633-1653)
 // rides along when `decay` (same elements, applied after the correction as in surface_processes)
-__global__ void k2_cse_elem(const des_params *p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
+__device__ __forceinline__ void cse_elem_at(int i, const des_params *p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
                             const int *conn, const double *coord, const int *markers, int decay, double *volume,
                             double *plstrain, double *stress, double *strain, double *strain_rate)
 {
-    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= ntop_elems) return;
     const int e = top_elems[i];
     double d[3][2];
     elem_coords(coord, conn, nn, ne, e, d);
@@ -1134,16 +1199,62 @@ __global__ void k2_cse_elem(const des_params *p, const Clock *clk, int ntop_elem
     plstrain[e] = pls;
 }
 
-__global__ void k2_cse_node(int ntop, const int *top_nodes, const int *sup_idx, const int *sup_arr, const double *volume,
-                            double *volume_n, int reset_dhacc, double *dhacc)
+__global__ void k2_cse_elem(const des_params *p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
+                            const int *conn, const double *coord, const int *markers, int decay, double *volume,
+                            double *plstrain, double *stress, double *strain, double *strain_rate)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (i >= ntop) return;
+    if (i < ntop_elems) cse_elem_at(i, p, clk, ntop_elems, top_elems, nn, ne, conn, coord, markers, decay, volume, plstrain, stress, strain, strain_rate);
+}
+
+__device__ __forceinline__ void cse_node_at(int i, int ntop, const int *top_nodes, const int *sup_idx, const int *sup_arr, const double *volume,
+                            double *volume_n, int reset_dhacc, double *dhacc)
+{
     const int nt = top_nodes[i];
     double acc = 0.;
     for (int k = sup_idx[nt]; k < sup_idx[nt+1]; ++k) acc += volume[sup_arr[k]];
     volume_n[nt] = acc;
     if (reset_dhacc) dhacc[nt] = 0.;                      // bc.cxx:1837-1838
+}
+
+__global__ void k2_cse_node(int ntop, const int *top_nodes, const int *sup_idx, const int *sup_arr, const double *volume,
+                            double *volume_n, int reset_dhacc, double *dhacc)
+{
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < ntop) cse_node_at(i, ntop, top_nodes, sup_idx, sup_arr, volume, volume_n, reset_dhacc, dhacc);
+}
+
+// The independent loops of surface_processes share launches on the patch path: the segments of simple_diffusion with the
+// final sum of calculate_residual_force (one extra workgroup); edvacc_surf with correct_surface_element's element part;
+// the nodal part with the max |dh| reduction (one extra workgroup).
+__global__ void k2_surf_seg_resfin(int etop, int nn, int ne, const int *top_nodes, const double *coord, double *etmp, double *tmp_result,
+                                   int nb_seg, int res_nb, const double *res_part, Clock *clk)
+{
+    if ((int)blockIdx.x >= nb_seg) { residual_fin_block(res_nb, res_part, clk); return; }
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < etop) surf_seg_at(i, etop, nn, ne, top_nodes, coord, etmp, tmp_result);
+}
+
+__global__ void k2_surf_edv_cse_elem(const des_params *p, const Clock *clk, int etop, int ntop_elems, int nb_edv, int nn, int ne,
+                                     const int *ean, const int *conn_surf, const int *top_elems, const int *conn, const int *markers,
+                                     int decay, const double *coord, const double *dh, double *edvacc, double *volume, double *plstrain,
+                                     double *stress, double *strain, double *strain_rate)
+{
+    if ((int)blockIdx.x < nb_edv) {
+        const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+        if (i < etop) surf_edv_at(i, etop, nn, ean, conn_surf, coord, dh, edvacc);
+        return;
+    }
+    const int i = ((int)blockIdx.x - nb_edv) * DES_BLOCK + threadIdx.x;
+    if (i < ntop_elems) cse_elem_at(i, p, clk, ntop_elems, top_elems, nn, ne, conn, coord, markers, decay, volume, plstrain, stress, strain, strain_rate);
+}
+
+__global__ void k2_cse_node_maxdh(int ntop, int nb_node, const int *top_nodes, const int *sup_idx, const int *sup_arr, const double *volume,
+                                  double *volume_n, int reset_dhacc, double *dhacc, int o0, int o1, const double *dh, Clock *clk)
+{
+    if ((int)blockIdx.x >= nb_node) { surf_maxdh_block(ntop, top_nodes, o0, o1, dh, clk); return; }
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i < ntop) cse_node_at(i, ntop, top_nodes, sup_idx, sup_arr, volume, volume_n, reset_dhacc, dhacc);
 }
 
 // compute_volume (geometry.cxx:170-201) + the element part of compute_mass (geometry.cxx:1743-1870)
@@ -1442,6 +1553,8 @@ __global__ void k2_dt_unpack(Clock *clk, const double *red)
     clk->r_global_dt_min = red[3]; clk->r_max_vem = -red[4]; clk->max_surf_vel = -red[5];
 }
 
+#include "des_dev2d_patch.hpp"
+
 struct FieldRef { void *ptr; long long count; int elsize; };
 
 FieldRef field_ref(const Engine *h, int field)
@@ -1502,27 +1615,40 @@ void launch_volume_mass(Engine *h, bool with_mass)
 
 inline bool wall_needs_zmin(const Engine *h) { return h->p.vbc_types[0] == 3 && h->p.bottom_shear_zone_thickness > 0.; }
 
-void launch_vbcs(Engine *h)
+inline PatchArgs patch_args(const Engine *h)
+{
+    PatchArgs a = {h->nn, h->ne, h->p_npb, h->p_nb, h->p_pn_cap, h->p_inc_cap, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx};
+    return a;
+}
+
+void launch_vbcs(Engine *h, bool apply = true, bool tick = false)
 {
     // (a decomposed mesh: the wall's extent is the cross-rank maximum wall_set left in the clock -- the coordinates
     // have not moved since it was taken, update_coordinate comes after apply_vbcs)
     if (!h->halo) {
-        hipLaunchKernelGGL(k2_vbc_extent, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord, h->d_clk);
+        hipLaunchKernelGGL(k2_vbc_extent, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord, h->d_clk,
+                           tick ? 1 : 0);
         if (wall_needs_zmin(h)) {
             L2(k2_vbc_zmin, h->nn, h->nn, h->coord, h->neg_zmin);
             hipLaunchKernelGGL(k2_vbc_zmin_fin, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->neg_zmin);
         }
     }
-    L2(k2_apply_vbcs, h->nn, h->d_p, h->d_clk, h->nn, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->coord, h->vel);
+    if (apply) L2(k2_apply_vbcs, h->nn, h->d_p, h->d_clk, h->nn, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->coord, h->vel);
 }
 
 template <class M>
-void launch_stress(Engine *h)
+void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr)
 {
     if (h->count_past) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
-    L2(k2_stress<M>, h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
+    if (fused) {
+        L2((k2_stress<M, 1>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
+           h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
+           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out);
+        return;
+    }
+    L2((k2_stress<M, 0>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
        h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0);
+       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, h->stress);
 }
 
 // update_force's boundary terms in the reference's order (fields.cxx:682-691)
@@ -1557,6 +1683,12 @@ void launch_stress_bcs(Engine *h)
 void launch_surface_commit(Engine *h)
 {
     const des_params &p = h->p;
+    if (h->res_fin_pending && p.surface_process_option == 1 && h->etop > 0) {
+        const int nbs = nblk(h->etop);
+        hipLaunchKernelGGL(k2_surf_seg_resfin, dim3(nbs + 1), dim3(DES_BLOCK), 0, h->stream, h->etop, h->nn, h->ne, h->top_nodes, h->coord,
+                           h->etmp, h->tmp_result, nbs, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
+        h->res_fin_pending = false;
+    } else
     // surface_processes (bc.cxx:1709-1872)
     if (p.surface_process_option == 1 && h->etop > 0)
         L2(k2_surf_seg, h->etop, h->etop, h->nn, h->ne, h->top_nodes, h->coord, h->etmp, h->tmp_result);
@@ -1566,22 +1698,39 @@ void launch_surface_commit(Engine *h)
 }
 
 // ... and the rest
-void launch_update_mesh_rest(Engine *h, long long steps)
+void launch_update_mesh_rest(Engine *h, long long steps, bool rotate)
 {
     const des_params &p = h->p;
+    const bool at_interval = steps % p.quality_check_step_interval == 0;
+    const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
+    if (h->patch && h->ntop > 0) {
+        const int nbe = nblk(h->etop), nbc = nblk(h->ntop_elems), nbn = nblk(h->ntop);
+        if (nbe + nbc > 0)
+            hipLaunchKernelGGL(k2_surf_edv_cse_elem, dim3(nbe + nbc), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->etop, h->ntop_elems,
+                               nbe, h->nn, h->ne, h->ean, h->conn_surf, h->top_elems, h->conn, h->markers, decay, h->coord, h->dh,
+                               h->edvacc, h->volume, h->plstrain, h->stress, h->strain, h->strain_rate);
+        hipLaunchKernelGGL(k2_cse_node_maxdh, dim3(nbn + 1), dim3(DES_BLOCK), 0, h->stream, h->ntop, nbn, h->top_nodes, h->sup_idx, h->sup_arr,
+                           h->volume, h->volume_n, (steps != 0 && at_interval) ? 1 : 0, h->dhacc, h->o0, h->o1, h->dh, h->d_clk);
+    } else {
     if (h->etop > 0)
         L2(k2_surf_edv, h->etop, h->etop, h->nn, h->ean, h->conn_surf, h->coord, h->dh, h->edvacc);
     hipLaunchKernelGGL(k2_surf_maxdh, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->ntop, h->top_nodes, h->o0, h->o1, h->dh, h->d_clk);
-    const bool at_interval = steps % p.quality_check_step_interval == 0;
-    const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
     if (h->ntop_elems > 0)
         L2(k2_cse_elem, h->ntop_elems, h->d_p, h->d_clk, h->ntop_elems, h->top_elems, h->nn, h->ne, h->conn, h->coord, h->markers,
            decay, h->volume, h->plstrain, h->stress, h->strain, h->strain_rate);
     if (h->ntop > 0)
         L2(k2_cse_node, h->ntop, h->ntop, h->top_nodes, h->sup_idx, h->sup_arr, h->volume, h->volume_n,
            (steps != 0 && at_interval) ? 1 : 0, h->dhacc);
+    }
     std::swap(h->volume, h->volume_old);
     refresh_props(h);
+    if (h->patch) {
+        // compute_volume + rotate_stress in one element pass, compute_mass over the node-block patches
+        L2(k2_rotate_vol, h->ne, h->d_clk, rotate ? 1 : 0, h->nn, h->ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
+        hipLaunchKernelGGL(k2p_mass, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (3 * (size_t)h->p_pn_cap + 4 * (size_t)h->p_inc_cap), h->stream, h->d_p, patch_args(h), h->coord,
+                           h->temperature, h->props, h->markers, h->volume_n, h->mass, h->tmass, h->ymass);
+        return;
+    }
     launch_volume_mass(h, true);
 }
 
@@ -1601,10 +1750,36 @@ int sync_clock(Engine *h)
 }
 
 // strain rate -> stress -> force -> velocity -> residual: the part of a step the pseudo-transient loop repeats
+// Patch path: `thermal` -- update_temperature rides in the first patch pass; `tail` -- apply_vbcs and update_coordinate
+// follow in the velocity kernel (a plain step with a moving mesh), the residual's final sum is left to the surface kernel.
 template <class M>
-void launch_mechanics(Engine *h, bool nmd)
+void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = false)
 {
     const int nn = h->nn, ne = h->ne;
+    if (h->patch) {
+        const PatchArgs a = patch_args(h);
+        hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0, a,
+                           h->bcflag, h->coord, h->vel, h->temperature, h->temperature_alt, h->volume, h->radiogenic, h->props,
+                           h->markers, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
+        if (thermal) std::swap(h->temperature, h->temperature_alt);
+        double *const s_law = nmd ? h->stress_pre : h->stress;
+        launch_stress<M>(h, true, s_law);
+        if (nmd) L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
+        hipLaunchKernelGGL(k2p_force, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+                           h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->force, h->fres);
+        launch_stress_bcs(h);
+        if (tail) {
+            launch_vbcs(h, false, h->tick_pending);     // the wall's extent into the clock (the coordinates have not moved yet)
+            h->tick_pending = false;
+            L2(k2_node_final, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot,
+               h->force, h->vel, h->coord);
+        } else
+            L2(k2_damp_vel, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->force, h->vel);
+        L2(k2_residual_part, h->o1 - h->o0, nn, h->o0, h->o1, h->nn_global, h->fres, h->res_part);
+        if (tail && h->p.surface_process_option == 1 && h->etop > 0) h->res_fin_pending = true;
+        else hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
+        return;
+    }
     L2(k2_strain_rate, ne, nn, ne, h->conn, h->coord, h->vel, h->volume, h->strain_rate, h->etmp);
     L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
     L2(k2_edvoldt, ne, ne, h->conn, h->ntmp, h->edvoldt);
@@ -1665,22 +1840,29 @@ int step_front(Engine *h)
 {
     const des_params &p = h->p;
     const int nn = h->nn, ne = h->ne;
+    const bool tail = h->patch && !h->iso && !p.has_PT && p.has_moving_mesh;
     if (!h->iso) {
-        hipLaunchKernelGGL(k2_clock, dim3(1), dim3(1), 0, h->stream, h->d_clk);
+        if (tail && !h->halo) h->tick_pending = true;      // (k2_vbc_extent counts the step)
+        else hipLaunchKernelGGL(k2_clock, dim3(1), dim3(1), 0, h->stream, h->d_clk);
         ++h->steps_host;
     }
     refresh_props(h);
-    if (!h->iso && p.has_thermal_diffusion) {
+    const bool thermal = !h->iso && p.has_thermal_diffusion;
+    if (thermal && !h->patch) {
         L2(k2_temp_elem, ne, h->d_p, nn, ne, h->conn, h->coord, h->temperature, h->volume, h->radiogenic, h->props, h->markers, h->tmp_result);
         L2(k2_temp_node, nn, h->d_p, h->d_clk, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->bcflag, h->tmp_result, h->tmass, h->temperature);
     }
-    launch_mechanics<M>(h, !h->iso && p.is_using_mixed_stress);
+    launch_mechanics<M>(h, !h->iso && p.is_using_mixed_stress, thermal, tail);
     if (!h->iso && p.has_PT) { int rc = pt_loop<M>(h); if (rc) return rc; }
     if (h->iso) L2(k2_iso_vel, nn, h->d_p, nn, h->bcflag, h->vel);
-    else launch_vbcs(h);
+    else if (!tail) launch_vbcs(h);
     if (p.has_moving_mesh || h->iso) {
-        L2(k2_update_coord, 2 * nn, h->d_clk, 2 * nn, h->vel, h->coord);
+        if (!tail) L2(k2_update_coord, 2 * nn, h->d_clk, 2 * nn, h->vel, h->coord);
         launch_surface_commit(h);
+    }
+    if (h->res_fin_pending) {
+        hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
+        h->res_fin_pending = false;
     }
     return DES_OK;
 }
@@ -1690,9 +1872,11 @@ void step_back(Engine *h)
 {
     const des_params &p = h->p;
     const int nn = h->nn, ne = h->ne;
-    if (p.has_moving_mesh || h->iso) launch_update_mesh_rest(h, h->steps_host);
+    const bool rotate = !h->iso && (p.rheol_type & DES_RH_ELASTIC);
+    const bool moved = p.has_moving_mesh || h->iso;
+    if (moved) launch_update_mesh_rest(h, h->steps_host, rotate);
     if (h->iso) return;
-    if (p.rheol_type & DES_RH_ELASTIC)
+    if (rotate && !(h->patch && moved))
         L2(k2_rotate, ne, h->d_clk, nn, ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
     if (p.is_outputting_averaged_fields) {
         const int first = (h->steps_host % p.quality_check_step_interval == 1) ? 1 : 0;
@@ -1824,6 +2008,31 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->res_part, (size_t)nblk(nn)));
     A2(dalloc(h, h->neg_zmin, 1));
     A2(dalloc(h, h->d_red, 8));
+    {
+        // node-block patches (des_dev2d_patch.hpp): blocks of 128 nodes, of 64 where 128 would not fit the LDS caps
+        const char *env = std::getenv("DES2D_PATCH");
+        Patch2 P;
+        bool ok = false;
+        if (!(env && env[0] == '0')) {
+            const int want = env ? std::atoi(env) : 0;
+            if (want >= 16 && want <= DES2_PATCH_THREADS) ok = build_patches2(mesh, want, P);
+            else ok = build_patches2(mesh, 128, P) || build_patches2(mesh, 64, P);
+        }
+        if (ok) {
+            h->patch = true; h->p_npb = P.npb; h->p_nb = P.nb;
+            h->p_pn_cap = (P.max_pn + 7) / 8 * 8; h->p_inc_cap = (P.max_inc + 7) / 8 * 8;
+            if (std::getenv("DES_PATCH_VERBOSE"))
+                std::fprintf(stderr, "2-D patches: %d nodes per block, %d blocks, max incidences %d, patch nodes %d, patch elements %d, "
+                             "elements listed %zu (%.2f x nelem)\n", P.npb, P.nb, P.max_inc, P.max_pn, P.max_pe, P.pe_pack.size(),
+                             (double)P.pe_pack.size() / ne);
+            A2(dcopy(h, h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size()));
+            A2(dcopy(h, h->pe_pack, P.pe_pack.data(), P.pe_pack.size()));
+            A2(dcopy(h, h->pn_ptr, P.pn_ptr.data(), P.pn_ptr.size()));
+            A2(dcopy(h, h->pn_id, P.pn_id.data(), P.pn_id.size()));
+            A2(dalloc(h, h->temperature_alt, (size_t)nn));
+            A2(dalloc(h, h->stress_pre, (size_t)3 * ne));
+        }
+    }
     HIP2(hipHostMalloc((void **)&h->h_red, 8 * sizeof(double)));
     if (params->is_outputting_averaged_fields) {
         A2(dalloc(h, h->stress_avg, (size_t)3 * ne)); A2(dalloc(h, h->strain0, (size_t)3 * ne));

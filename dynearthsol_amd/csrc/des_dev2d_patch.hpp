@@ -1,0 +1,387 @@
+// des_dev2d_patch.hpp -- the node-block patch passes of the 2-D (triangle) engine.
+// Part of the translation unit des_dev2d.hip (included inside its anonymous namespace, after the
+// device functions and the one-kernel-per-loop kernels); not a stand-alone header.
+//
+// The plain 2-D step runs every element -> node sum of the reference as a pair of launches: an element
+// kernel stores its terms (three to six doubles per element), a node kernel gathers them per incidence
+// through the support list -- scattered 8-byte reads, the slowest traffic the device has.  Here, as in
+// the 3-D engine (passes/en1.hpp, passes/en3.hpp), a workgroup takes a block of `npb` consecutive nodes
+// and RECOMPUTES the terms of the block's patch (every element touching one of its nodes, listed once
+// per mesh): the nodal records of the patch are staged in LDS (one gather per node instead of one per
+// incidence), each lane takes patch elements and drops the terms of the element's nodes that belong
+// to the block into the LDS slot of that incidence = its position in the block's slice of the CSR
+// support list; after a barrier each node's lane adds its slots in CSR order, i.e. in the reference's
+// ascending element order: same association, same bits as the gather.  Three such passes:
+//   k2p_temp_dvoldt   update_temperature (fields.cxx:197-278) + compute_dvoldt (geometry.cxx:214-237)
+//   k2p_force         NMD_stress' element update (geometry.cxx:311-331) + update_force (fields.cxx:609-698)
+//   k2p_mass          compute_mass (geometry.cxx:1743-1870) with its volumes
+// and the element kernels that remain do more per visit (k2_stress forms edvoldt from the nodal values;
+// k2_rotate_vol = compute_volume + rotate_stress).
+
+// For every block of `npb` consecutive nodes:
+//   pn_id   [pn_ptr[b] .. pn_ptr[b+1])   the nodes of its patch that are NOT its own, ascending
+//   pe_pack [pe_ptr[b] .. pe_ptr[b+1])   its patch elements, ascending, one 16-byte record each:
+//           .x = element (bits 0..29) | 1 << 30 if this block owns it (holds its lowest node) | ln0 << 31 | ln1 << 40 | ln2 << 49
+//           .y = slot0 | slot1 << 12 | slot2 << 24
+//           ln  = local id of the element's nodes in connectivity order (own: n - n0, others: nown + position in pn_id)
+//           slot = position of that incidence in the block's slice of the support list, 0xfff: not this block's node
+struct Patch2 {
+    int npb = 0, nb = 0, max_inc = 0, max_pn = 0, max_pe = 0;
+    std::vector<int> pe_ptr, pn_ptr, pn_id;
+    std::vector<ulonglong2> pe_pack;
+};
+
+#define DES2_PATCH_INC 1024         // LDS slots of a block (incidences of its nodes)
+#define DES2_PATCH_PN 448           // ... and nodes of its patch
+#define DES2_PATCH_THREADS 256
+#define DES2_PATCH_IT 3             // patch elements per lane at most: their list entries and element data are loaded up front
+
+// false: a block exceeds the caps (the engine then keeps the plain kernels)
+static bool build_patches2(const des_mesh *m, int npb, Patch2 &P)
+{
+    const int nn = m->nnode, ne = m->nelem;
+    const int *conn = m->connectivity, *sidx = m->support_idx, *sarr = m->support_arr, *slid = m->support_lidx;
+    P = Patch2();
+    P.npb = npb; P.nb = (nn + npb - 1) / npb;
+    P.pe_ptr.assign(1, 0); P.pn_ptr.assign(1, 0);
+    std::vector<int> emark((size_t)ne, -1), nmark((size_t)nn, -1), elems, others;
+    std::vector<int> slots;
+    for (int b = 0; b < P.nb; ++b) {
+        const int n0 = b * npb, n1 = std::min(nn, n0 + npb), nown = n1 - n0;
+        const int kb = sidx[n0], ke = sidx[n1];
+        if (ke - kb > DES2_PATCH_INC) return false;
+        elems.clear(); others.clear();
+        for (int k = kb; k < ke; ++k) if (emark[sarr[k]] != b) { emark[sarr[k]] = b; elems.push_back(sarr[k]); }
+        std::sort(elems.begin(), elems.end());
+        for (int e : elems)
+            for (int i = 0; i < 3; ++i) {
+                const int n = conn[(size_t)i * ne + e];
+                if ((n < n0 || n >= n1) && nmark[n] != b) { nmark[n] = b; others.push_back(n); }
+            }
+        std::sort(others.begin(), others.end());
+        if (nown + (int)others.size() > DES2_PATCH_PN) return false;
+        slots.assign(3 * elems.size(), 0xfff);
+        for (int k = kb; k < ke; ++k) {
+            const size_t q = std::lower_bound(elems.begin(), elems.end(), sarr[k]) - elems.begin();
+            slots[3 * q + slid[k]] = k - kb;
+        }
+        for (size_t q = 0; q < elems.size(); ++q) {
+            const int e = elems[q];
+            int nmin = nn;
+            unsigned long long ln[3];
+            for (int i = 0; i < 3; ++i) {
+                const int n = conn[(size_t)i * ne + e];
+                nmin = std::min(nmin, n);
+                ln[i] = (n >= n0 && n < n1) ? (unsigned long long)(n - n0)
+                                            : (unsigned long long)(nown + (std::lower_bound(others.begin(), others.end(), n) - others.begin()));
+            }
+            ulonglong2 r;
+            r.x = (unsigned long long)(unsigned)e | ((nmin >= n0 && nmin < n1) ? 0x40000000ull : 0ull) | (ln[0] << 31) | (ln[1] << 40) | (ln[2] << 49);
+            r.y = (unsigned long long)slots[3*q] | ((unsigned long long)slots[3*q + 1] << 12) | ((unsigned long long)slots[3*q + 2] << 24);
+            P.pe_pack.push_back(r);
+        }
+        P.pn_id.insert(P.pn_id.end(), others.begin(), others.end());
+        P.pe_ptr.push_back((int)P.pe_pack.size());
+        P.pn_ptr.push_back((int)P.pn_id.size());
+        P.max_inc = std::max(P.max_inc, ke - kb);
+        P.max_pn = std::max(P.max_pn, nown + (int)others.size());
+        P.max_pe = std::max(P.max_pe, (int)elems.size());
+        if (P.max_pe > DES2_PATCH_IT * DES2_PATCH_THREADS) return false;
+    }
+    return true;
+}
+
+struct PatchElem2 { int e; bool owner; int ln[3]; int sl[3]; };
+__device__ __forceinline__ PatchElem2 patch_elem2(const ulonglong2 r)
+{
+    PatchElem2 E;
+    E.e = (int)(r.x & 0x3fffffffull);
+    E.owner = (r.x >> 30) & 1ull;
+    E.ln[0] = (int)((r.x >> 31) & 0x1ffull); E.ln[1] = (int)((r.x >> 40) & 0x1ffull); E.ln[2] = (int)((r.x >> 49) & 0x1ffull);
+    E.sl[0] = (int)(r.y & 0xfffull); E.sl[1] = (int)((r.y >> 12) & 0xfffull); E.sl[2] = (int)((r.y >> 24) & 0xfffull);
+    return E;
+}
+
+// pn_cap / inc_cap: LDS entries per nodal array / per slot array = the mesh's largest block, rounded up (dynamic LDS: a
+// workgroup takes what the mesh needs, not the caps, so that more of them fit a CU)
+struct PatchArgs { int nn, ne, npb, nb, pn_cap, inc_cap; const int *pe_ptr; const ulonglong2 *pe_pack; const int *pn_ptr, *pn_id, *sup_idx; };
+
+// ---- update_temperature + compute_dvoldt ------------------------------------------------------------
+// thermal = 0: the temperature stands (isostasy loop, pseudo-transient iterations, has_thermal_diffusion = no).
+// T_in / T_out: a block must not move a temperature another block may still be reading -- the host swaps the two.
+__global__ void __launch_bounds__(DES2_PATCH_THREADS)
+k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, const PatchArgs a, const unsigned *bcflag,
+                const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
+                const double *radiogenic, const double *props, const int *markers, const double *tmass, const double *volume_n,
+                double *ntmp, double *strain_rate)
+{
+    extern __shared__ double lds[];
+    double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
+    double *const lf0 = lT + a.pn_cap, *const lf1 = lf0 + a.inc_cap;
+    // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
+    const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
+    if (b >= a.nb) return;
+    const int n0 = b * a.npb, nown = min(a.npb, nn - n0);
+    const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
+    // everything that does not depend on the staged records is loaded first, so that a workgroup's trips to memory overlap:
+    // this lane's list entries, then the element data they name, beside the nodal records
+    ulonglong2 rec[DES2_PATCH_IT];
+    double g_vol[DES2_PATCH_IT], g_kc[DES2_PATCH_IT], g_rad[DES2_PATCH_IT];
+    const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k)
+        if (q0 + k * DES2_PATCH_THREADS < qe) rec[k] = a.pe_pack[q0 + k * DES2_PATCH_THREADS];
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k)
+        if (q0 + k * DES2_PATCH_THREADS < qe) {
+            const int e = (int)(rec[k].x & 0x3fffffffull);
+            g_vol[k] = volume[e];
+            if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; }
+        }
+    for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
+        const int id = j < nown ? n0 + j : a.pn_id[h0 + j - nown];
+        lx[j] = coord[id]; lz[j] = coord[nn + id]; lvx[j] = vel[id]; lvz[j] = vel[nn + id]; lT[j] = T_in[id];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k) {
+        if (q0 + k * DES2_PATCH_THREADS >= qe) break;
+        const PatchElem2 E = patch_elem2(rec[k]);
+        const int e = E.e;
+        double d[3][2], v[3][2], shpdx[3], shpdz[3], T[3];
+        for (int i = 0; i < 3; ++i) {
+            d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; v[i][0] = lvx[E.ln[i]]; v[i][1] = lvz[E.ln[i]]; T[i] = lT[E.ln[i]];
+        }
+        const double vol = g_vol[k];
+        shape_fn2(d, vol, shpdx, shpdz);
+        if (thermal) {
+            // k2_temp_elem's statements
+            desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+            double kv = g_kc[k] * vol;
+            double Te = 0;
+            for (int i = 0; i < 3; ++i) Te += T[i];
+            Te /= 3;
+            double rh = g_rad[k] * vol * desk::mat_rho(p, mx, Te) / 3;
+            for (int i = 0; i < 3; ++i) {
+                if (E.sl[i] == 0xfff) continue;
+                double diffusion = 0.;
+                for (int j = 0; j < 3; ++j)
+                    diffusion += (shpdx[i] * shpdx[j] + shpdz[i] * shpdz[j]) * T[j];
+                lf0[E.sl[i]] = diffusion * kv - rh;
+            }
+        }
+        // k2_strain_rate's statements; the block that owns the element stores the strain rate
+        double s0 = 0, s1 = 0;
+        for (int i = 0; i < 3; ++i) s0 += v[i][0] * shpdx[i];
+        for (int i = 0; i < 3; ++i) s1 += v[i][1] * shpdz[i];
+        if (E.owner) {
+            double s2 = 0;
+            for (int i = 0; i < 3; ++i) s2 += 0.5 * (v[i][0] * shpdz[i] + v[i][1] * shpdx[i]);
+            strain_rate[e] = s0; strain_rate[ne + e] = s1; strain_rate[2 * ne + e] = s2;
+        }
+        double dj = s0 + s1;
+        const double et = dj * vol;
+        for (int i = 0; i < 3; ++i) if (E.sl[i] != 0xfff) lf1[E.sl[i]] = et;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nown) {
+        const int n = n0 + threadIdx.x;
+        const int kb = a.sup_idx[n0], r0 = a.sup_idx[n] - kb, r1 = a.sup_idx[n + 1] - kb;
+        double acc = 0.;
+        for (int k = r0; k < r1; ++k) acc += lf1[k];
+        ntmp[n] = acc / volume_n[n];
+        if (thermal) {
+            if (bcflag[n] & BOUNDZ1)
+                T_out[n] = p->surface_temperature;
+            else {
+                double tdot = 0;
+                for (int k = r0; k < r1; ++k) tdot += lf0[k];
+                T_out[n] = lT[threadIdx.x] - clk->dt * tdot / tmass[n];
+            }
+        }
+    }
+}
+
+// ---- NMD_stress (element update) + update_force ---------------------------------------------------------
+// nmd: the stress k2_stress left in stress_in gets its diagonal corrected here; the block that owns the element stores the
+// result to stress_out (another buffer: a neighbouring block may still be reading stress_in).  nmd = 0: stress_in is read only.
+__global__ void __launch_bounds__(DES2_PATCH_THREADS)
+k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
+          const double *volume, const double *dpressure, const double *stress_in, double *stress_out, const double *props,
+          const int *markers, double *force, double *fres)
+{
+    extern __shared__ double lds[];
+    double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap, *const lnt = lT + a.pn_cap;
+    double *const lf0 = lnt + a.pn_cap, *const lf1 = lf0 + a.inc_cap;
+    // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
+    const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
+    if (b >= a.nb) return;
+    const int n0 = b * a.npb, nown = min(a.npb, nn - n0);
+    const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
+    const double gravity = p->gravity;
+    ulonglong2 rec[DES2_PATCH_IT];
+    double g_vol[DES2_PATCH_IT], g_s[DES2_PATCH_IT][3], g_dp[DES2_PATCH_IT], g_phi[DES2_PATCH_IT];
+    const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k)
+        if (q0 + k * DES2_PATCH_THREADS < qe) rec[k] = a.pe_pack[q0 + k * DES2_PATCH_THREADS];
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k)
+        if (q0 + k * DES2_PATCH_THREADS < qe) {
+            const int e = (int)(rec[k].x & 0x3fffffffull);
+            g_vol[k] = volume[e];
+            for (int i = 0; i < 3; ++i) g_s[k][i] = stress_in[i * ne + e];
+            g_dp[k] = nmd ? dpressure[e] : 0.0;
+            g_phi[k] = gravity != 0 ? props[2 * ne + e] : 0.0;
+        }
+    for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
+        const int id = j < nown ? n0 + j : a.pn_id[h0 + j - nown];
+        lx[j] = coord[id]; lz[j] = coord[nn + id];
+        if (gravity != 0) lT[j] = temperature[id];
+        if (nmd) lnt[j] = ntmp[id];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k) {
+        if (q0 + k * DES2_PATCH_THREADS >= qe) break;
+        const PatchElem2 E = patch_elem2(rec[k]);
+        const int e = E.e;
+        double d[3][2], shpdx[3], shpdz[3];
+        for (int i = 0; i < 3; ++i) { d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; }
+        double vol = g_vol[k];
+        shape_fn2(d, vol, shpdx, shpdz);
+        double s[3];
+        for (int i = 0; i < 3; ++i) s[i] = g_s[k][i];
+        if (nmd) {
+            // k2_nmd_apply's statements
+            double dp = 0;
+            for (int i = 0; i < 3; ++i) dp += lnt[E.ln[i]];
+            double dp_el = dp / 3;
+            double dp_orig = g_dp[k];
+            double ddp = (-dp_orig + dp_el) / 2;
+            for (int i = 0; i < 2; ++i) s[i] += ddp;
+            if (E.owner) for (int i = 0; i < 3; ++i) stress_out[i * ne + e] = s[i];
+        }
+        double buoy = 0;
+        if (gravity != 0) {
+            desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+            const double phi = g_phi[k];
+            double Te = 0;
+            for (int i = 0; i < 3; ++i) Te += lT[E.ln[i]];
+            Te /= 3;
+            buoy = (desk::mat_rho(p, mx, Te) * (1 - phi) + 1000.0 * phi) * gravity / 3;
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (E.sl[i] == 0xfff) continue;
+            lf0[E.sl[i]] = (s[0]*shpdx[i] + s[2]*shpdz[i]) * vol;
+            lf1[E.sl[i]] = (s[2]*shpdx[i] + s[1]*shpdz[i] + buoy) * vol;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nown) {
+        const int n = n0 + threadIdx.x;
+        const int kb = a.sup_idx[n0], r0 = a.sup_idx[n] - kb, r1 = a.sup_idx[n + 1] - kb;
+        double f[2] = {0, 0}, fr[2] = {0, 0};
+        for (int k = r0; k < r1; ++k) {
+            f[0] -= lf0[k]; fr[0] = lf0[k];            // assignment: fields.cxx:673
+            f[1] -= lf1[k]; fr[1] = lf1[k];
+        }
+        for (int j = 0; j < 2; j++) { force[j*nn + n] = f[j]; fres[j*nn + n] = fr[j]; }
+    }
+}
+
+// ---- compute_mass (with the volumes it sums) ----------------------------------------------------------------
+// The element volumes are recomputed from the staged coordinates with compute_volume's own expression (k2_rotate_vol
+// stores the same value to volume[]).
+__global__ void __launch_bounds__(DES2_PATCH_THREADS)
+k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const double *temperature, const double *props,
+         const int *markers, double *volume_n, double *mass, double *tmass, double *ymass)
+{
+    extern __shared__ double lds[];
+    double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap;
+    double *const lf0 = lT + a.pn_cap, *const lf1 = lf0 + a.inc_cap, *const lf2 = lf1 + a.inc_cap, *const lf3 = lf2 + a.inc_cap;
+    // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
+    const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
+    if (b >= a.nb) return;
+    const int n0 = b * a.npb, nown = min(a.npb, nn - n0);
+    const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
+    ulonglong2 rec[DES2_PATCH_IT];
+    double g_bulk[DES2_PATCH_IT], g_shear[DES2_PATCH_IT], g_cp[DES2_PATCH_IT];
+    const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k)
+        if (q0 + k * DES2_PATCH_THREADS < qe) rec[k] = a.pe_pack[q0 + k * DES2_PATCH_THREADS];
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k)
+        if (q0 + k * DES2_PATCH_THREADS < qe) {
+            const int e = (int)(rec[k].x & 0x3fffffffull);
+            g_bulk[k] = props[e]; g_shear[k] = props[ne + e]; g_cp[k] = props[3 * ne + e];
+        }
+    for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
+        const int id = j < nown ? n0 + j : a.pn_id[h0 + j - nown];
+        lx[j] = coord[id]; lz[j] = coord[nn + id]; lT[j] = temperature[id];
+    }
+    __syncthreads();
+    const int thermal = p->has_thermal_diffusion;
+#pragma unroll
+    for (int k = 0; k < DES2_PATCH_IT; ++k) {
+        if (q0 + k * DES2_PATCH_THREADS >= qe) break;
+        const PatchElem2 E = patch_elem2(rec[k]);
+        const int e = E.e;
+        double d[3][2];
+        for (int i = 0; i < 3; ++i) { d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; }
+        const double vol = triangle_area(d[0], d[1], d[2]);
+        // k2_volume_mass_elem's statements
+        desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+        const double bulkm = g_bulk[k], shearm = g_shear[k];
+        double Te = 0;
+        for (int i = 0; i < 3; ++i) Te += lT[E.ln[i]];
+        Te /= 3;
+        const double mrho = desk::mat_rho(p, mx, Te);
+        const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+        double rho = p->is_quasi_static ? bulkm / (pseudo_speed * pseudo_speed) : mrho;
+        double m = rho * vol / 3;
+        double tm = mrho * g_cp[k] * vol / 3;
+        double ym = 9 * bulkm * shearm / (3 * bulkm + shearm) / 3;
+        for (int i = 0; i < 3; ++i) {
+            if (E.sl[i] == 0xfff) continue;
+            lf0[E.sl[i]] = vol; lf1[E.sl[i]] = m; lf2[E.sl[i]] = tm; lf3[E.sl[i]] = ym;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nown) {
+        const int n = n0 + threadIdx.x;
+        const int kb = a.sup_idx[n0], r0 = a.sup_idx[n] - kb, r1 = a.sup_idx[n + 1] - kb;
+        double vn = 0, ms = 0, tms = 0, yms = 0;
+        for (int k = r0; k < r1; ++k) {
+            vn += lf0[k];
+            ms += lf1[k];
+            if (thermal) tms += lf2[k];
+            yms += lf3[k];
+        }
+        volume_n[n] = vn; mass[n] = ms; tmass[n] = tms; ymass[n] = yms;
+    }
+}
+
+// compute_volume (geometry.cxx:170-201) after the volume swap + rotate_stress (fields.cxx:807-821, 885-900) of an element
+__global__ void k2_rotate_vol(const Clock *clk, int rotate, int nn, int ne, const int *conn, const double *coord, const double *vel,
+                              double *volume, double *stress, double *strain)
+{
+    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (e >= ne) return;
+    double d[3][2];
+    elem_coords(coord, conn, nn, ne, e, d);
+    const double vol = triangle_area(d[0], d[1], d[2]);
+    volume[e] = vol;
+    if (!rotate) return;
+    double shpdx[3], shpdz[3], v[3][2];
+    shape_fn2(d, vol, shpdx, shpdz);
+    elem_coords(vel, conn, nn, ne, e, v);
+    double w2 = 0;
+    for (int i = 0; i < 3; ++i) w2 += 0.5 * (v[i][1] * shpdx[i] - v[i][0] * shpdz[i]);
+    double s[3], es[3];
+    for (int i = 0; i < 3; ++i) { s[i] = stress[i*ne+e]; es[i] = strain[i*ne+e]; }
+    jaumann_rate_2d(s, clk->dt, w2);
+    jaumann_rate_2d(es, clk->dt, w2);
+    for (int i = 0; i < 3; ++i) { stress[i*ne+e] = s[i]; strain[i*ne+e] = es[i]; }
+}

@@ -213,6 +213,25 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
     assert total >= 13
 
 
+@pytest.mark.parametrize("knob", ["0", "64", "40"])
+def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
+    """The node-block patch passes (des_dev2d_patch.hpp: temperature + dvoldt, NMD + force, mass; the default) against the
+    one-kernel-per-loop path (DES2D_PATCH=0) and against other block sizes: every field equal, and equal to the oracle's."""
+    kw = dict(cfgs.EVP, nmat=2, res=1e3, qcsi=7, water="yes", control="surf_base_level = -100\nsurf_diff_ratio_marine = 0.5\n")
+    with portable_libm():
+        host, dev, ora = pair(kw)
+        monkeypatch.setenv("DES2D_PATCH", knob)
+        other = des.DeviceEngine(host)
+        monkeypatch.delenv("DES2D_PATCH")
+        other.init_from_host(host)
+        for _ in range(3):
+            sd, so = dev.step(23), other.step(23)
+            ora.step(23)
+            assert (sd.dt, sd.time, sd.steps, sd.l2_residual, sd.max_surf_vel) == (so.dt, so.time, so.steps, so.l2_residual, so.max_surf_vel)
+            assert_bit_exact(dev, other)
+            assert_bit_exact(dev, ora)
+
+
 def test_what_a_2d_model_cannot_have_is_refused_with_the_dimension_code():
     host = des.Host(cfg_text=cfgs.make(**cfgs.EP), ndims=2)
     dev = des.DeviceEngine(host)
