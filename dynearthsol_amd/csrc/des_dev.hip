@@ -313,7 +313,7 @@ int des_dev_device_count(void)
 void des_dev_destroy(des_dev *h)
 {
     if (!h) return;
-    if (h->d2) { des2d::destroy(h->d2); delete h; return; }
+    if (h->d2) { des2d::destroy(h->d2); if (h->comm) ncclCommDestroy(h->comm); delete h; return; }
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm_stream) { hipStreamSynchronize(h->comm_stream); hipStreamDestroy(h->comm_stream); }
@@ -1386,7 +1386,6 @@ int des_dev_comm_unique_id(unsigned char *id128)
 
 int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id128)
 {
-    D2_REFUSE(h, "the RCCL communicator inside des_dev_step");
     if (!h || !id128) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     ncclUniqueId id;
@@ -1394,12 +1393,12 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
     if (r != ncclSuccess) { g_last_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); h->comm = nullptr; return DES_ERR_RESOURCE; }
     h->comm_rank = rank; h->comm_size = nranks;
+    D2_FORWARD(h, set_comm(h->d2, (void *)h->comm));         // a 2-D engine: the same communicator inside its own step
     return DES_OK;
 }
 
 int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
 {
-    if (h && h->d2) { if (nranks) *nranks = 0; if (rank) *rank = 0; if (overlapped) *overlapped = 0; return DES_OK; }
     if (!h) return DES_ERR_INTERNAL;
     int n = 1, r = 0;
     if (h->comm) {
@@ -1409,7 +1408,7 @@ int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
     }
     if (nranks) *nranks = h->comm ? n : 0;
     if (rank) *rank = r;
-    if (overlapped) *overlapped = h->overlap && h->nnbr > 0 && h->e_int1 > h->e_int0;
+    if (overlapped) *overlapped = !h->d2 && h->overlap && h->nnbr > 0 && h->e_int1 > h->e_int0;
     return DES_OK;
 }
 

@@ -6,6 +6,7 @@
 // Arrays are the reference's own (SoA, caller's numbering): coord / vel / force [2][nnode] =
 // {x, z}; stress / strain / strain_rate [3][nelem] = {XX, ZZ, XZ}; connectivity [3][nelem].
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -98,6 +99,7 @@ struct Engine {
     double *d_sendbuf = nullptr, *d_recvbuf = nullptr;
     double *d_red = nullptr;                   // [8] scratch of the cross-rank reductions
     double *h_red = nullptr;                   // pinned copy
+    ncclComm_t comm = nullptr;                 // set_comm: the exchange and the two reductions run inside step() on RCCL (not owned)
     bool markers_dirty = true, iso = false;
     bool count_past = false;           // this step feeds des_scalars::n_return_mapping (the last one of a call)
     long long steps_host = 0;
@@ -1539,6 +1541,15 @@ __global__ void k2_wall_set(Clock *clk, double x0_max, double neg_x0_min, double
     clk->zmin = with_zmin ? -neg_zmin : 0.;
 }
 
+__global__ void k2_wall_set_from(Clock *clk, const double *red, int with_zmin)
+{
+    const bool any = red[0] != -DBL_MAX;
+    clk->x0_init = any;
+    clk->x0_max = any ? red[0] : 0.;
+    clk->x0_min = any ? -red[1] : 0.;
+    clk->zmin = with_zmin ? -red[2] : 0.;
+}
+
 // compute_dt across ranks: the element reduction's result out (six minima: the two maxima negated) ...
 __global__ void k2_dt_pack(const Clock *clk, double *red)
 {
@@ -2129,11 +2140,15 @@ int sync(Engine *h)
     return DES_OK;
 }
 
+static int wall_allreduce(Engine *h);
+static int dt_allreduce(Engine *h, bool recompute);
+
 // dynearthsol.cxx:184-194 (compute_volume, volume_old = volume, apply_vbcs, compute_mass)
 int init_geometry(Engine *h)
 {
     HIP2(hipSetDevice(h->device));
     refresh_props(h);
+    if (h->comm && h->halo_set) { int rc = wall_allreduce(h); if (rc) return rc; }     // apply_vbcs below reads the whole mesh's wall
     launch_volume_mass(h, false);
     HIP2(hipMemcpyAsync(h->volume_old, h->volume, (size_t)h->ne * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     launch_vbcs(h);
@@ -2145,7 +2160,8 @@ int init_geometry(Engine *h)
 int compute_dt(Engine *h, double *dt)
 {
     HIP2(hipSetDevice(h->device));
-    launch_dt(h);
+    if (h->comm && h->halo_set) { int rcd = dt_allreduce(h, true); if (rcd) return rcd; }
+    else launch_dt(h);
     int rc = sync_clock(h);
     if (rc) return rc;
     if (dt) *dt = h->h_clk->dt;
@@ -2163,11 +2179,67 @@ static int fill_scalars(Engine *h, des_scalars *out)
     return c.status;
 }
 
+// ---- the decomposed step on RCCL (set_comm): everything on the engine's stream, no host synchronisation ----------------
+#define NCCL2(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { \
+    h->err = std::string("RCCL: ") + ncclGetErrorString(r_); return DES_ERR_RESOURCE; } } while (0)
+
+// the x0 wall's extent / the lowest node across ranks into the clock (bc.cxx:251-300, 350-361)
+static int wall_allreduce(Engine *h)
+{
+    launch_wall_local(h);
+    NCCL2(ncclAllReduce(h->d_red, h->d_red, 3, ncclDouble, ncclMax, h->comm, h->stream));
+    hipLaunchKernelGGL(k2_wall_set_from, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red, wall_needs_zmin(h) ? 1 : 0);
+    return DES_OK;
+}
+
+// one grouped send / recv per neighbour between the pack and the unpack launch, then the wall reduction
+static int exchange_rccl(Engine *h)
+{
+    launch_pack(h);
+    NCCL2(ncclGroupStart());
+    for (int q = 0; q < h->nnbr; ++q) {
+        NCCL2(ncclSend(h->d_sendbuf + h->send_off[q], (size_t)(h->send_off[q+1] - h->send_off[q]), ncclDouble, h->nbr_rank[q], h->comm, h->stream));
+        NCCL2(ncclRecv(h->d_recvbuf + h->recv_off[q], (size_t)(h->recv_off[q+1] - h->recv_off[q]), ncclDouble, h->nbr_rank[q], h->comm, h->stream));
+    }
+    NCCL2(ncclGroupEnd());
+    launch_unpack(h);
+    return wall_allreduce(h);
+}
+
+static int dt_allreduce(Engine *h, bool recompute)
+{
+    if (recompute) launch_dt_partials(h);
+    hipLaunchKernelGGL(k2_dt_pack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    NCCL2(ncclAllReduce(h->d_red, h->d_red, 6, ncclDouble, ncclMin, h->comm, h->stream));
+    hipLaunchKernelGGL(k2_dt_unpack, dim3(1), dim3(1), 0, h->stream, h->d_clk, h->d_red);
+    hipLaunchKernelGGL(k2_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk);
+    return DES_OK;
+}
+
+int set_comm(Engine *h, void *comm)
+{
+    if (comm && h->p.has_PT) { h->err = "control.has_PT on a decomposed mesh: the loop's residual test is global"; return DES_ERR_UNSUPPORTED; }
+    h->comm = (ncclComm_t)comm;
+    return DES_OK;
+}
+
 int step(Engine *h, int nsteps, des_scalars *out)
 {
     HIP2(hipSetDevice(h->device));
+    if (h->comm && h->halo_set) {
+        h->n_pt_iterations = 0;
+        for (int i = 0; i < nsteps; ++i) {
+            h->count_past = (i == nsteps - 1);
+            int rc = h->portable_libm ? step_front<desk::MathPortable>(h) : step_front<desk::MathOcml>(h);
+            if (rc || (rc = exchange_rccl(h))) return rc;
+            step_back(h);
+            if (!h->iso && h->steps_host % 10 == 0 && (rc = dt_allreduce(h, true))) return rc;
+        }
+        HIP2(hipGetLastError());
+        return out ? fill_scalars(h, out) : DES_OK;
+    }
     if (h->halo && nsteps > 0) {
-        h->err = "a decomposed 2-D engine steps through des_dev_step_group or des_dev_phase + the exchange entry points";
+        h->err = "a decomposed 2-D engine steps through des_dev_step (after des_dev_comm_init), des_dev_step_group, or des_dev_phase + the exchange entry points";
         return DES_ERR_UNSUPPORTED;
     }
     h->n_pt_iterations = 0;

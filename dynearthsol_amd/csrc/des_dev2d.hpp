@@ -8,8 +8,8 @@
 // 1067-1106), jaumann_rate_2d (fields.cxx:807-821), the 2-D compute_dt / elem_quality
 // (geometry.cxx:1566-1576, 1901-1906).  Every des_dev_* entry point dispatches here when the
 // handle holds a 2-D engine, the domain decomposition included (node slabs along x, the two-phase
-// step with the caller's exchange, des_dev_step_group); what it does not offer (the RCCL
-// communicator inside des_dev_step, the overlapped schedule) returns DES_ERR_UNSUPPORTED_DIM.
+// step with the caller's exchange, des_dev_step_group, des_dev_step on an RCCL communicator);
+// what it does not offer (the overlapped schedule) returns DES_ERR_UNSUPPORTED_DIM.
 //
 // Arrays stay in the reference's own SoA layout and the caller's numbering: the 2-D configs of
 // BASELINE.json are the CPU-runnable plumbing case (configs[0]), bit-for-bit parity with the
@@ -53,6 +53,8 @@ int wall_set(Engine *h, const double in[3]);
 int dt_partials(Engine *h, double out[6], int recompute);
 int dt_finalize(Engine *h, const double in[6], double *dt);
 int step_group(Engine **g, int n, int nsteps, des_scalars *out);
+// the RCCL communicator (an ncclComm_t the caller owns) des_dev_step / init_geometry / compute_dt of a decomposed engine use
+int set_comm(Engine *h, void *comm);
 
 } // namespace des2d
 

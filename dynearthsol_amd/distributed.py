@@ -293,14 +293,14 @@ def run_distributed(host, dist, engine_factory=None, stepper=None, quiet=True):
             eng = DeviceEngine(part, device=local)
             return eng
     two_d = int(host.params.ndims) == 2
-    if two_d and stepper is None:
-        # the 2-D engine has no communicator of its own: the two-phase step, ghost records and the two small reductions
-        # moved by torch.distributed (host-staged; the 2-D models are the small ones)
-        gloo = None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
-        comm = TorchComm(dist, group=gloo)
+    # RCCL wants one device per rank: several 2-D ranks on ONE GPU (tests, rehearsals; DES_2D_TRANSPORT=host) step in two
+    # phases with the ghost records and the two small reductions moved by torch.distributed instead
+    staged = two_d and stepper is None and os.environ.get("DES_2D_TRANSPORT", "rccl" if dist.get_backend() == "nccl" else "host") == "host"
+    if staged:
+        comm = TorchComm(dist, group=None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo"))
         stepper = lambda e, p: PhasedStepper(e, p, comm)
     ce = CollectiveEngine(host, dist, engine_factory, stepper)
-    if isinstance(ce.engine, DeviceEngine) and not two_d:
+    if isinstance(ce.engine, DeviceEngine) and not staged:
         ce.engine.comm_init(dist, ce.rank, ce.world)
     api = collective_api(ce)
     return driver.run(host, quiet=quiet or ce.rank != 0, api=api)

@@ -113,15 +113,91 @@ def test_a_million_triangles_cut_8_ways():
         group.close()
 
 
+def test_2d_step_on_rccl_equals_the_two_phase_step():
+    """des_dev_step of a decomposed 2-D engine with a communicator attached (des_dev_comm_init): pack -> one grouped
+    ncclSend / ncclRecv per neighbour -> unpack -> ncclAllReduce(MAX) of the wall extent, compute_dt's ncclAllReduce(MIN),
+    all on the engine's stream.  RCCL refuses two ranks on this box's one GPU, so the middle slab of a three-way cut is
+    its own neighbour (lists cut to equal lengths): the physics of that is meaningless, but the two-phase entry points
+    driven the same way -- every message unpacked where RCCL delivers it -- must leave the same bits in every field."""
+    import ctypes as C
+    import types
+    import torch.distributed as dist
+    from dynearthsol_amd._structs import DesHalo
+    from dynearthsol_amd.decomp import Partition
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 90))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, nmat=2, res=1e3)), ndims=2)
+        part = Partition(host, 3, 1)
+        assert len(part.nbr_rank) == 2
+        pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        cut = lambda s_, r_: [(a[:min(len(a), len(b))], b[:min(len(a), len(b))]) for a, b in zip(s_, r_)]
+        nodes, elems = cut(part.send_idx, part.recv_idx), cut(part.esend_idx, part.erecv_idx)
+        ptr = np.cumsum([0] + [len(a) for a, _ in nodes]).astype(np.int32)
+        eptr = np.cumsum([0] + [len(a) for a, _ in elems]).astype(np.int32)
+        send, recv = [np.ascontiguousarray(np.concatenate([p[i] for p in nodes]), dtype=np.int32) for i in (0, 1)]
+        esend, erecv = [np.ascontiguousarray(np.concatenate([p[i] for p in elems]), dtype=np.int32) for i in (0, 1)]
+        assert ptr[-1] > 20 and eptr[-1] > 20
+        nbr = np.zeros(2, np.int32)
+        halo = DesHalo(part.owned[0], part.owned[1], 4, 2, pi(nbr), pi(ptr), pi(send), pi(ptr), pi(recv),
+                       pi(eptr), pi(esend), pi(eptr), pi(erecv))
+        fake = types.SimpleNamespace(halo=halo, owned=part.owned, host=host)
+        fields = ("COORD", "VEL", "STRESS", "STRAIN", "TEMPERATURE", "PLSTRAIN", "VOLUME", "MASS", "STRAIN_RATE", "STRESSYY", "DHACC")
+        results = []
+        for rccl in (True, False):
+            eng = des.DeviceEngine(part)
+            eng.set_halo(fake)
+            if rccl:
+                eng.comm_init(dist, 0, 1)
+                assert eng.comm_info()["rccl_ranks"] == 1
+            for f, name in (("COORD", "coord"), ("COORD0", "coord"), ("ELEMMARKERS", "elemmarkers"), ("VEL", "vel")):
+                eng.upload(f, part.local(name))
+            if not rccl:
+                eng.wall_set(eng.wall_get())
+            eng.init_geometry()
+            for f, name in (("TEMPERATURE", "temperature"), ("RADIOGENIC", "radiogenic"), ("STRESS", "stress"), ("STRAIN", "strain"),
+                            ("PLSTRAIN", "plstrain"), ("VISCOSITY", "viscosity"), ("STRESSYY", "stressyy")):
+                eng.upload(f, part.local(name))
+            dt0 = eng.compute_dt() if rccl else eng.dt_finalize(eng.dt_partials(True))
+            snaps = []
+            for n in (2, 7, 4):                        # the last call crosses step 10: compute_dt inside it
+                if rccl:
+                    eng.step(n)
+                else:
+                    for _ in range(n):
+                        eng.phase(0)
+                        bufs = [(eng.halo_pack(0, a, part.node_width), eng.halo_pack(1, ea, part.elem_width))
+                                for (a, _), (ea, _) in zip(nodes, elems)]
+                        for (nb, eb), (_, b), (_, eb_idx) in zip(bufs, nodes, elems):
+                            eng.halo_unpack(0, b, nb)
+                            eng.halo_unpack(1, eb_idx, eb)
+                        eng.wall_set(eng.wall_get())
+                        if eng.phase(1):
+                            eng.dt_finalize(eng.dt_partials(False))
+                snaps.append({f: eng.download(f) for f in fields})
+            results.append((dt0, eng.step(0).dt, snaps))
+            eng.close()
+        assert results[0][0] == results[1][0]
+        assert results[0][1] == results[1][1] or (np.isnan(results[0][1]) and np.isnan(results[1][1]))
+        o0, o1 = part.owned
+        assert np.isfinite(results[0][2][0]["VEL"].reshape(2, -1)[:, o0:o1]).mean() > 0.5, "nothing left to compare"
+        for a, b in zip(results[0][2], results[1][2]):
+            for f in fields:
+                assert np.array_equal(a[f], b[f], equal_nan=True), f
+    finally:
+        dist.destroy_process_group()
+
+
 def test_a_cut_2d_engine_refuses_what_it_does_not_offer():
     host = des.Host(cfg_text=cfgs.make(**cfgs.EP), ndims=2)
     group = DeviceGroup(host, 2)
     try:
         e = group.engines[0]
         with pytest.raises(des.DesError) as ei:
-            e.step(1)                                   # des_dev_step on its own: no communicator for 2-D engines
+            e.step(1)                                   # des_dev_step on its own, without a communicator
         assert ei.value.code == 31
-        assert e._lib.des_dev_exchange(e._h) == 30
+        assert e._lib.des_dev_exchange(e._h) == 30 and e._lib.des_dev_set_overlap(e._h, 1) == 30
     finally:
         group.close()
     with pytest.raises(des.DesError):                   # the PT loop's residual test is global
