@@ -99,6 +99,7 @@ struct des_oracle {
          volume_old, dpressure, edvoldt, radiogenic, etmp, tmp_result;
     ivec elemmarkers, etmp_int;
     dvec dh, edvacc_surf, dh_n;
+    bool wall_given = false; double wall[3] = {0, 0, 0};   // des_oracle_wall_set: the x0 wall's extent / the lowest node of the WHOLE mesh (2-D, decomposed)
     // Output::average_fields state (output.hpp:30-36)
     dvec stress_avg, dplstrain_avg, strain0, coord_avg0;
     double avg_time0;
@@ -1539,6 +1540,11 @@ void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
             else { if (z > BOUNDX1_max) BOUNDX1_max = z; if (z < BOUNDX1_min) BOUNDX1_min = z; }
         }
     }
+    if (o.wall_given) {                              // a rank of a decomposed mesh: the cross-rank maxima
+        const bool any = o.wall[0] != -DBL_MAX;
+        BOUNDX0_max = any ? o.wall[0] : 0.;
+        BOUNDX0_min = any ? -o.wall[1] : 0.;
+    }
     double BOUNDX0_width = BOUNDX0_max - BOUNDX0_min;
     (void)BOUNDX1_max; (void)BOUNDX1_min;
     double div_x0[4], div_x1[4];
@@ -1561,6 +1567,7 @@ void apply_vbcs(des_oracle &o, bool all_local_nodes = false)
     double zmin = 0;
     for (int k = 0; k < nn; ++k)
         if (o.coord[nn + k] < zmin) zmin = o.coord[nn + k];
+    if (o.wall_given) zmin = -o.wall[2];
 
     #pragma omp parallel for
     for (int i = 0; i < nn; ++i) {
@@ -2596,7 +2603,6 @@ int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, d
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global)
 {
     if (owned_begin < 0 || owned_end > h->nn || owned_begin > owned_end) return DES_ERR_INTERNAL;
-    if (ND == 2 && (owned_begin > 0 || owned_end < h->nn)) return DES_ERR_UNSUPPORTED_DIM;   // the decomposition is 3-D only
     if (h->p.has_PT && (owned_begin > 0 || owned_end < h->nn)) return DES_ERR_UNSUPPORTED;   // the loop's residual is global
     h->o0 = owned_begin; h->o1 = owned_end; h->nn_global = nnode_global;
     return DES_OK;
@@ -2627,22 +2633,26 @@ int des_oracle_body_force_adjustment(des_oracle *h, des_scalars *out)
     return DES_OK;
 }
 
-// the exchange of a step: what = 0 nodal {x,y,z,vx,vy,vz,T,dh} of the local nodes idx[0..n),
-// what = 1 {stress, strain, plstrain} of the local elements idx[0..n); buf[i*width + c]
+// the exchange of a step: what = 0 nodal {coord[ND], vel[ND], T, dh} of the local nodes idx[0..n),
+// what = 1 {stress[NSTR], strain[NSTR], plstrain (, stressyy in 2-D)} of the local elements idx[0..n); buf[i*width + c]
+// (DES_X_NODE_WIDTH / DES_X_ELEM_WIDTH, and their _2D values)
+static const int X_NODE_W = 2 * ND + 2, X_ELEM_W = 2 * NSTR + 1 + (ND == 2 ? 1 : 0);
 int des_oracle_halo_pack(des_oracle *h, int what, const int *idx, int n, double *buf)
 {
-    if (ND != 3) return DES_ERR_UNSUPPORTED_DIM;
     const int nn = h->nn, ne = h->ne;
     for (int i = 0; i < n; ++i) {
         const int k = idx[i];
         if (what == 0) {
-            double *b = buf + (size_t)i * DES_X_NODE_WIDTH;
-            for (int d = 0; d < 3; ++d) { b[d] = h->coord[d*nn+k]; b[3+d] = h->vel[d*nn+k]; }
-            b[6] = h->temperature[k]; b[7] = h->dh_n[k];
+            double *b = buf + (size_t)i * X_NODE_W;
+            for (int d = 0; d < ND; ++d) { b[d] = h->coord[d*nn+k]; b[ND+d] = h->vel[d*nn+k]; }
+            b[2*ND] = h->temperature[k]; b[2*ND+1] = h->dh_n[k];
         } else {
-            double *b = buf + (size_t)i * DES_X_ELEM_WIDTH;
-            for (int c = 0; c < 6; ++c) { b[c] = h->stress[c*ne+k]; b[6+c] = h->strain[c*ne+k]; }
-            b[12] = h->plstrain[k];
+            double *b = buf + (size_t)i * X_ELEM_W;
+            for (int c = 0; c < NSTR; ++c) { b[c] = h->stress[c*ne+k]; b[NSTR+c] = h->strain[c*ne+k]; }
+            b[2*NSTR] = h->plstrain[k];
+#if DES_NDIMS == 2
+            b[2*NSTR+1] = h->stressyy[k];
+#endif
         }
     }
     return DES_OK;
@@ -2650,20 +2660,49 @@ int des_oracle_halo_pack(des_oracle *h, int what, const int *idx, int n, double 
 
 int des_oracle_halo_unpack(des_oracle *h, int what, const int *idx, int n, const double *buf)
 {
-    if (ND != 3) return DES_ERR_UNSUPPORTED_DIM;
     const int nn = h->nn, ne = h->ne;
     for (int i = 0; i < n; ++i) {
         const int k = idx[i];
         if (what == 0) {
-            const double *b = buf + (size_t)i * DES_X_NODE_WIDTH;
-            for (int d = 0; d < 3; ++d) { h->coord[d*nn+k] = b[d]; h->vel[d*nn+k] = b[3+d]; }
-            h->temperature[k] = b[6]; h->dh_n[k] = b[7];
+            const double *b = buf + (size_t)i * X_NODE_W;
+            for (int d = 0; d < ND; ++d) { h->coord[d*nn+k] = b[d]; h->vel[d*nn+k] = b[ND+d]; }
+            h->temperature[k] = b[2*ND]; h->dh_n[k] = b[2*ND+1];
         } else {
-            const double *b = buf + (size_t)i * DES_X_ELEM_WIDTH;
-            for (int c = 0; c < 6; ++c) { h->stress[c*ne+k] = b[c]; h->strain[c*ne+k] = b[6+c]; }
-            h->plstrain[k] = b[12];
+            const double *b = buf + (size_t)i * X_ELEM_W;
+            for (int c = 0; c < NSTR; ++c) { h->stress[c*ne+k] = b[c]; h->strain[c*ne+k] = b[NSTR+c]; }
+            h->plstrain[k] = b[2*NSTR];
+#if DES_NDIMS == 2
+            h->stressyy[k] = b[2*NSTR+1];
+#endif
         }
     }
+    return DES_OK;
+}
+
+// What the 2-D apply_vbcs reads off the whole mesh (bc.cxx:251-300, 350-361), on this rank's mesh: {max z of the x0 wall,
+// max -z of it, max(0, max -z) of all nodes}, -DBL_MAX without a wall node; the caller MAX-reduces across ranks and hands
+// the result back (des_dev.h: des_dev_wall_get / des_dev_wall_set).  3-D: nothing of the kind.
+int des_oracle_wall_get(des_oracle *h, double out[3])
+{
+    out[0] = out[1] = out[2] = 0.0;
+#if DES_NDIMS == 2
+    const int nn = h->nn;
+    out[0] = out[1] = -DBL_MAX;
+    for (int i = 0; i < nn; ++i) {
+        const double z = h->coord[nn + i];
+        if (h->bcflag[i] & 1u) { out[0] = std::max(out[0], z); out[1] = std::max(out[1], -z); }
+        out[2] = std::max(out[2], -z);
+    }
+#endif
+    return DES_OK;
+}
+
+int des_oracle_wall_set(des_oracle *h, const double in[3])
+{
+#if DES_NDIMS == 2
+    h->wall_given = true;
+    for (int i = 0; i < 3; ++i) h->wall[i] = in[i];
+#endif
     return DES_OK;
 }
 

@@ -39,6 +39,8 @@ int des_oracle_set_isostasy(des_oracle *h, int on);
 int des_oracle_body_force_adjustment(des_oracle *h, des_scalars *out);
 int des_oracle_halo_pack(des_oracle *h, int kind, const int *idx, int n, double *buf);
 int des_oracle_halo_unpack(des_oracle *h, int kind, const int *idx, int n, const double *buf);
+int des_oracle_wall_get(des_oracle *h, double out[3]);
+int des_oracle_wall_set(des_oracle *h, const double in[3]);
 int des_oracle_dt_partials(des_oracle *h, double out[6], int recompute);
 int des_oracle_dt_finalize(des_oracle *h, const double in[6], double *dt);
 double des_oracle_l2_partial(des_oracle *h);

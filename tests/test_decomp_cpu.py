@@ -21,6 +21,7 @@ class _LocalMeshHost:
     """Duck-typed host for OracleEngine(host): the engine only needs .params and .mesh."""
     def __init__(self, part):
         self.params, self.mesh, self._keep = part.params, part.mesh, part
+        self.ndims = getattr(part, "ndims", 3)
 
 
 def build(kw, nranks, overrides=None):
@@ -154,6 +155,90 @@ def test_two_ranks_over_gloo_match_one_rank(tmp_path):
     dt0 = ref.init_from_host(host)
     sc = ref.step(nsteps)
     vel, T, stress = ref.download("VEL").reshape(3, -1), ref.download("TEMPERATURE"), ref.download("STRESS").reshape(6, -1)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert d["dt0"] == dt0 and d["dt"] == sc.dt
+        assert np.array_equal(d["vel"], vel[:, d["nodes"]])
+        assert np.array_equal(d["T"], T[d["nodes"]])
+        assert np.array_equal(d["stress"], stress[:, d["elems"]])
+
+
+# ---- the 2-D build on the slab decomposition (host/partition.cpp on triangles, decomp.py's 2-D record widths, the
+#      wall-extent reduction of des_dev.h) with the 2-D oracle as every rank's engine ----------------------------------
+NODE_FIELDS_2D = (("COORD", 2), ("VEL", 2), ("TEMPERATURE", 1), ("MASS", 1), ("VOLUME_N", 1), ("FORCE", 2), ("DHACC", 1))
+ELEM_FIELDS_2D = (("STRESS", 3), ("STRAIN", 3), ("STRAIN_RATE", 3), ("PLSTRAIN", 1), ("VISCOSITY", 1), ("VOLUME", 1),
+                  ("VOLUME_OLD", 1), ("DPRESSURE", 1), ("STRESSYY", 1))
+# a depth profile on the x1 wall, laid out over the x0 wall's extent (bc.cxx:299): the last rank needs the first rank's wall
+X1_PROFILE = ("bc.vbc_x1 = 1\nbc.vbc_val_x1 = 1e-9\nbc.vbc_val_division_x1_min = 0.25\nbc.vbc_val_division_x1_max = 0.7\n"
+              "bc.vbc_val_x1_ratio0 = 1\nbc.vbc_val_x1_ratio1 = 0.6\nbc.vbc_val_x1_ratio2 = 0.3\nbc.vbc_val_x1_ratio3 = 0.1\n")
+SHEAR_ZONE = "bc.vbc_x0 = 3\nbc.vbc_x1 = 2\nbc.bottom_shear_zone_thickness = 3e3\n"
+
+
+@pytest.mark.parametrize("name,kw,ov,nranks", [
+    ("evp_2mat_water_3", dict(cfgs.EVP, nmat=2, res=1e3, qcsi=7, water="yes"), None, 3),
+    ("x1_profile_4", dict(cfgs.EVP, res=1e3), X1_PROFILE, 4),
+    ("shear_zone_2", dict(cfgs.EP, res=1e3), SHEAR_ZONE, 2),
+])
+def test_decomposed_2d_oracle_is_bit_identical_to_one_rank(name, kw, ov, nranks):
+    host = des.Host(cfg_text=cfgs.make(**kw), overrides=ov, ndims=2)
+    parts = [Partition(host, nranks, r) for r in range(nranks)]
+    ref = OracleEngine(host)
+    dt_ref = ref.init_from_host(host)
+    engines = [OracleEngine(_LocalMeshHost(p)) for p in parts]
+    steppers = [PhasedStepper(e, p, None) for e, p in zip(engines, parts)]
+    comm = LoopbackComm(steppers)
+    from dynearthsol_amd.decomp import init_rank_mesh, init_rank_fields
+    for e, p in zip(engines, parts):
+        init_rank_mesh(e, p)
+    comm.reduce_wall_all()
+    for e, p in zip(engines, parts):
+        init_rank_fields(e, p)
+    dts = comm.reduce_dt_all(recompute=True)
+    assert all(d == dt_ref for d in dts)
+    nsteps = 32
+    ref.step(nsteps)
+    run_loopback(steppers, nsteps)
+    for f, c in NODE_FIELDS_2D:
+        got = assemble(parts, [e.download(f) for e in engines], c, host.nnode, "node")
+        assert np.array_equal(got, ref.download(f)), f
+    for f, c in ELEM_FIELDS_2D:
+        got = assemble(parts, [e.download(f) for e in engines], c, host.nelem, "elem")
+        assert np.array_equal(got, ref.download(f)), f
+    assert all(e.step(0).dt == ref.step(0).dt for e in engines)
+
+
+def _gloo_worker_2d(rank, world, port, nsteps, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, res=1e3)), overrides=X1_PROFILE, ndims=2)
+    part = Partition(host, world, rank)
+    eng = OracleEngine(_LocalMeshHost(part))
+    comm = TorchComm(dist)
+    dt = init_rank(eng, part, comm)
+    PhasedStepper(eng, part, comm).step(nsteps)
+    o0, o1 = part.owned
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dt0=dt, dt=eng.step(0).dt,
+             nodes=part.l2g_node[o0:o1], elems=part.l2g_elem[part.elem_owned],
+             vel=eng.download("VEL").reshape(2, -1)[:, o0:o1],
+             T=eng.download("TEMPERATURE")[o0:o1], stress=eng.download("STRESS").reshape(3, -1)[:, part.elem_owned])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_gloo_match_one_rank_2d(tmp_path):
+    import torch.multiprocessing as mp
+    nsteps, world = 25, 2
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_gloo_worker_2d, args=(world, port, nsteps, str(tmp_path)), nprocs=world, join=True)
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, res=1e3)), overrides=X1_PROFILE, ndims=2)
+    ref = OracleEngine(host)
+    dt0 = ref.init_from_host(host)
+    sc = ref.step(nsteps)
+    vel, T, stress = ref.download("VEL").reshape(2, -1), ref.download("TEMPERATURE"), ref.download("STRESS").reshape(3, -1)
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert d["dt0"] == dt0 and d["dt"] == sc.dt
