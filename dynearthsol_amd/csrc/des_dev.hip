@@ -1281,8 +1281,8 @@ int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
 // control.has_PT the reference only forms the residual of the force_residual it holds; so does this.
 int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
 {
-    D2_REFUSE(h, "the initial body-force adjustment");
     if (!h) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, body_force_adjustment(h->d2, out));
     if (h->nnbr > 0 || h->group) { g_last_error = "the initial body-force adjustment's residual test is global: single domain only"; return DES_ERR_UNSUPPORTED; }
     hipSetDevice(h->device);
     refresh_props(h);

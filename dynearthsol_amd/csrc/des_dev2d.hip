@@ -82,6 +82,7 @@ struct Engine {
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
     // node-block patch passes (des_dev2d_patch.hpp); DES2D_PATCH=0 or a mesh outside their LDS caps: the plain kernels
     bool patch = false, res_fin_pending = false, tick_pending = false;
+    bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
     int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0;
     int *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
     ulonglong2 *pe_pack = nullptr;
@@ -1682,7 +1683,7 @@ void launch_stress_bcs(Engine *h)
         if (p.has_elastic_foundation && h->nbn[iboundz0])
             L2(k2_elastic_foundation, h->nbn[iboundz0], h->d_p, h->nbn[iboundz0], h->bnodes[iboundz0], h->nn, h->coord, h->coord0, h->force);
     }
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 6 && !h->no_neumann; ++i) {
         if (p.stress_bc_types[i] == 0 || h->nbf[i] == 0) continue;
         hipLaunchKernelGGL(k2_neumann, dim3(1), dim3(64), 0, h->stream, h->d_p, i, h->nbf[i], h->bf_elem[i], h->bf_facet[i],
                            h->nn, h->ne, h->conn, h->coord, h->force);
@@ -2251,6 +2252,28 @@ int step(Engine *h, int nsteps, des_scalars *out)
     HIP2(hipGetLastError());
     if (out) return fill_scalars(h, out);
     return DES_OK;
+}
+
+// initial_body_force_adjustment (dynearthsol.cxx:546-591; main() calls it once before the time loop when
+// ic.has_body_force_adjustment): the residual of the force_residual the engine holds, then -- with control.has_PT -- the
+// pseudo-transient loop on the initial state with the Neumann tractions held back (fields.cxx:690).
+int body_force_adjustment(Engine *h, des_scalars *out)
+{
+    HIP2(hipSetDevice(h->device));
+    if (h->halo) { h->err = "the initial body-force adjustment's residual test is global: single domain only"; return DES_ERR_UNSUPPORTED; }
+    refresh_props(h);
+    h->n_pt_iterations = 0;
+    L2(k2_residual_part, h->o1 - h->o0, h->nn, h->o0, h->o1, h->nn_global, h->fres, h->res_part);
+    hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
+    if (h->p.has_PT) {
+        h->no_neumann = true;
+        const int rc = h->portable_libm ? pt_loop<desk::MathPortable>(h) : pt_loop<desk::MathOcml>(h);
+        h->no_neumann = false;
+        if (rc) return rc;
+    }
+    HIP2(hipGetLastError());
+    if (out) return fill_scalars(h, out);
+    return sync_clock(h);
 }
 
 // ---- domain decomposition (des_dev.h: des_dev_set_halo ... des_dev_step_group) ------------------------------------

@@ -43,6 +43,7 @@ int mesh_quality(Engine *h, double smallest_vol, double bottom, double bottom_di
 int timer_start(Engine *h);
 int timer_stop(Engine *h, float *ms);
 double algorithmic_bytes_per_step(const Engine *h);
+int body_force_adjustment(Engine *h, des_scalars *out);
 // domain decomposition
 int set_halo(Engine *h, const des_halo *halo, int nn_global);
 int phase(Engine *h, int ph);

@@ -232,6 +232,27 @@ def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
             assert_bit_exact(dev, ora)
 
 
+@pytest.mark.parametrize("moving", ["yes", "no"])
+def test_initial_body_force_adjustment_2d_bit_exact(moving):
+    """ic.has_body_force_adjustment in the 2-D build (dynearthsol.cxx:546-591): the pseudo-transient loop on the initial
+    state, Neumann tractions held back (fields.cxx:690); same iteration count and bits as the 2-D oracle, the steps that
+    follow included."""
+    ov = ("control.has_PT = yes\ncontrol.PT_max_iter = 25\ncontrol.PT_relative_tolerance = 1e-4\n"
+          "control.has_moving_mesh = %s\nbc.stress_bc_z1 = 3\nbc.stress_val_z1 = 2e6\nbc.stress_bc_x1 = 1\nbc.stress_val_x1 = -1e6\nbc.vbc_x1 = 0\n" % moving)
+    host, dev, ora = pair(dict(cfgs.EP, res=1e3), overrides=ov)
+    pushed = ora.download("STRESS") * 1.03           # (the lithostatic start is in equilibrium: push it out of balance)
+    for eng in (dev, ora):
+        eng.upload("STRESS", pushed)
+    sd, so = dev.body_force_adjustment(), ora.body_force_adjustment()
+    assert sd.n_pt_iterations == so.n_pt_iterations > 3 and (sd.dt, sd.steps, sd.time) == (so.dt, 0, 0.0)
+    assert abs(sd.l2_residual - so.l2_residual) <= 1e-12 * so.l2_residual
+    assert_bit_exact(dev, ora)
+    for n in (1, 3, 8):
+        sd, so = dev.step(n), ora.step(n)
+        assert sd.n_pt_iterations == so.n_pt_iterations > 0 and (sd.dt, sd.steps) == (so.dt, so.steps)
+        assert_bit_exact(dev, ora)
+
+
 def test_what_a_2d_model_cannot_have_is_refused_with_the_dimension_code():
     host = des.Host(cfg_text=cfgs.make(**cfgs.EP), ndims=2)
     dev = des.DeviceEngine(host)
