@@ -282,3 +282,65 @@ def test_overlapped_schedule_gives_the_same_bits():
         else:
             os.environ["DES_S2_DEFER"] = old_defer
         dist.destroy_process_group()
+
+
+def test_switching_schedules_between_calls_keeps_the_bits():
+    """des_dev_set_overlap between two des_dev_step calls -- what bench.py's schedule probe does on N > 1 GPUs before its timed
+    region -- on an engine with an RCCL communicator (the middle slab of a three-way cut as its own neighbour, as above):
+    in order / overlapped / in order again must leave what the in-order schedule alone leaves."""
+    import ctypes as C
+    import os
+    import types
+    import torch.distributed as dist
+    from dynearthsol_amd._structs import DesHalo
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 90))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    old_defer = os.environ.get("DES_S2_DEFER")
+    os.environ["DES_S2_DEFER"] = "0"                   # (see the test above: the slab as its own neighbour)
+    try:
+        host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, lx=90e3)))
+        part = Partition(host, 3, 1)
+        pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        cut = lambda s, r: [(a[:min(len(a), len(b))], b[:min(len(a), len(b))]) for a, b in zip(s, r)]
+        nodes, elems = cut(part.send_idx, part.recv_idx), cut(part.esend_idx, part.erecv_idx)
+        ptr = np.cumsum([0] + [len(a) for a, _ in nodes]).astype(np.int32)
+        eptr = np.cumsum([0] + [len(a) for a, _ in elems]).astype(np.int32)
+        send, recv = [np.ascontiguousarray(np.concatenate([p[i] for p in nodes]), dtype=np.int32) for i in (0, 1)]
+        esend, erecv = [np.ascontiguousarray(np.concatenate([p[i] for p in elems]), dtype=np.int32) for i in (0, 1)]
+        nbr = np.zeros(2, np.int32)
+        halo = DesHalo(part.owned[0], part.owned[1], 4, 2, pi(nbr), pi(ptr), pi(send), pi(ptr), pi(recv),
+                       pi(eptr), pi(esend), pi(eptr), pi(erecv))
+        fields = ("COORD", "VEL", "STRESS", "STRAIN", "TEMPERATURE", "PLSTRAIN", "VOLUME", "MASS")
+        out = []
+        for switching in (False, True):
+            eng = des.DeviceEngine(part)
+            eng.set_halo(types.SimpleNamespace(halo=halo, owned=part.owned, host=host))
+            eng.comm_init(dist, 0, 1)
+            for f, name in (("COORD", "coord"), ("COORD0", "coord"), ("ELEMMARKERS", "elemmarkers"), ("VEL", "vel")):
+                eng.upload(f, part.local(name))
+            eng.init_geometry()
+            for f, name in (("TEMPERATURE", "temperature"), ("RADIOGENIC", "radiogenic"), ("STRESS", "stress"), ("STRAIN", "strain"),
+                            ("PLSTRAIN", "plstrain"), ("VISCOSITY", "viscosity")):
+                eng.upload(f, part.local(name))
+            snaps = []
+            eng.set_clock(eng.compute_dt(), 0.0, 6)        # (the ghost region is scrambled: NaNs creep inwards a layer per step --
+            for k, n in enumerate((2, 3, 2)):          #  few steps, started at step 6 so that the second call crosses compute_dt)
+                if switching:
+                    eng.set_overlap(k == 1)
+                    assert eng.comm_info()["overlapped"] == (k == 1)
+                eng.step(n, want_scalars=False)
+                snaps.append({f: eng.download(f) for f in fields})
+            out.append(snaps)
+            eng.close()
+        o0, o1 = part.owned
+        assert np.isfinite(out[0][0]["VEL"].reshape(3, -1)[:, o0:o1]).mean() > 0.5, "nothing left to compare"
+        for a, b in zip(out[0], out[1]):               # (after the compute_dt of a scrambled mesh: NaN == NaN)
+            for f in fields:
+                assert np.array_equal(a[f], b[f], equal_nan=True), f
+    finally:
+        if old_defer is None:
+            os.environ.pop("DES_S2_DEFER", None)
+        else:
+            os.environ["DES_S2_DEFER"] = old_defer
+        dist.destroy_process_group()
