@@ -84,7 +84,7 @@ struct Engine {
     bool patch = false, res_fin_pending = false, tick_pending = false;
     bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
     int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0;
-    int *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
+    int *po_ptr = nullptr, *po_id = nullptr, *po_slot = nullptr, *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
     ulonglong2 *pe_pack = nullptr;
     double *temperature_alt = nullptr;         // the other buffer of the temperature pair (k2p_temp_dvoldt)
     double *stress_pre = nullptr;              // the stress between update_stress and NMD_stress (k2p_force)
@@ -1629,7 +1629,8 @@ inline bool wall_needs_zmin(const Engine *h) { return h->p.vbc_types[0] == 3 && 
 
 inline PatchArgs patch_args(const Engine *h)
 {
-    PatchArgs a = {h->nn, h->ne, h->p_npb, h->p_nb, h->p_pn_cap, h->p_inc_cap, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx};
+    PatchArgs a = {h->nn, h->ne, h->p_npb, h->p_nb, h->p_pn_cap, h->p_inc_cap, h->po_ptr, h->po_id, h->po_slot, h->pe_ptr, h->pe_pack, h->pn_ptr,
+                   h->pn_id, h->sup_idx};
     return a;
 }
 
@@ -2021,14 +2022,18 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->neg_zmin, 1));
     A2(dalloc(h, h->d_red, 8));
     {
-        // node-block patches (des_dev2d_patch.hpp): blocks of 128 nodes, of 64 where 128 would not fit the LDS caps
+        // node-block patches (des_dev2d_patch.hpp): clusters of 128 nodes along a Morton curve (of 64 where 128 do not fit the
+        // LDS caps; runs of consecutive ids without coordinates or with DES2D_CLUSTER=0); DES2D_PATCH=<n>: n nodes per block
         const char *env = std::getenv("DES2D_PATCH");
+        const char *cl = std::getenv("DES2D_CLUSTER");
+        const bool cluster = !(cl && cl[0] == '0');
         Patch2 P;
         bool ok = false;
         if (!(env && env[0] == '0')) {
             const int want = env ? std::atoi(env) : 0;
-            if (want >= 16 && want <= DES2_PATCH_THREADS) ok = build_patches2(mesh, want, P);
-            else ok = build_patches2(mesh, 128, P) || build_patches2(mesh, 64, P);
+            if (want >= 16 && want <= DES2_PATCH_THREADS) ok = build_patches2(mesh, want, cluster, P);
+            else ok = build_patches2(mesh, 128, cluster, P) || build_patches2(mesh, 64, cluster, P)
+                      || (cluster && (build_patches2(mesh, 128, false, P) || build_patches2(mesh, 64, false, P)));
         }
         if (ok) {
             h->patch = true; h->p_npb = P.npb; h->p_nb = P.nb;
@@ -2037,6 +2042,9 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                 std::fprintf(stderr, "2-D patches: %d nodes per block, %d blocks, max incidences %d, patch nodes %d, patch elements %d, "
                              "elements listed %zu (%.2f x nelem)\n", P.npb, P.nb, P.max_inc, P.max_pn, P.max_pe, P.pe_pack.size(),
                              (double)P.pe_pack.size() / ne);
+            A2(dcopy(h, h->po_ptr, P.po_ptr.data(), P.po_ptr.size()));
+            A2(dcopy(h, h->po_id, P.po_id.data(), P.po_id.size()));
+            A2(dcopy(h, h->po_slot, P.po_slot.data(), P.po_slot.size()));
             A2(dcopy(h, h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size()));
             A2(dcopy(h, h->pe_pack, P.pe_pack.data(), P.pe_pack.size()));
             A2(dcopy(h, h->pn_ptr, P.pn_ptr.data(), P.pn_ptr.size()));

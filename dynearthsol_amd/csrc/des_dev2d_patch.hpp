@@ -5,8 +5,8 @@
 // The plain 2-D step runs every element -> node sum of the reference as a pair of launches: an element
 // kernel stores its terms (three to six doubles per element), a node kernel gathers them per incidence
 // through the support list -- scattered 8-byte reads, the slowest traffic the device has.  Here, as in
-// the 3-D engine (passes/en1.hpp, passes/en3.hpp), a workgroup takes a block of `npb` consecutive nodes
-// and RECOMPUTES the terms of the block's patch (every element touching one of its nodes, listed once
+// the 3-D engine (passes/en1.hpp, passes/en3.hpp), a workgroup takes a block of `npb` nodes (a compact
+// cluster of the mesh, below) and RECOMPUTES the terms of the block's patch (every element touching one of its nodes, listed once
 // per mesh): the nodal records of the patch are staged in LDS (one gather per node instead of one per
 // incidence), each lane takes patch elements and drops the terms of the element's nodes that belong
 // to the block into the LDS slot of that incidence = its position in the block's slice of the CSR
@@ -18,16 +18,21 @@
 // and the element kernels that remain do more per visit (k2_stress forms edvoldt from the nodal values;
 // k2_rotate_vol = compute_volume + rotate_stress).
 
-// For every block of `npb` consecutive nodes:
+// A block is a list of up to `npb` nodes (po_id [po_ptr[b] .. po_ptr[b+1])): with the mesh's coordinates at hand
+// (des_mesh::coord, the layout hint) the nodes are sorted along a Morton curve and cut into blocks, i.e. compact clusters
+// -- an 11 x 11 cluster of a regular mesh touches 1.2 x its share of the elements, a strip of consecutive node ids (the
+// renumbered mesh is sorted along x) 2.0 x; without coordinates the blocks are runs of consecutive ids.  The arrays stay
+// in the caller's numbering: only the grouping of the work changes.  For every block:
+//   po_slot [po_ptr[b] .. po_ptr[b+1])   where each of its nodes' incidences start in the block's LDS slots
 //   pn_id   [pn_ptr[b] .. pn_ptr[b+1])   the nodes of its patch that are NOT its own, ascending
 //   pe_pack [pe_ptr[b] .. pe_ptr[b+1])   its patch elements, ascending, one 16-byte record each:
 //           .x = element (bits 0..29) | 1 << 30 if this block owns it (holds its lowest node) | ln0 << 31 | ln1 << 40 | ln2 << 49
 //           .y = slot0 | slot1 << 12 | slot2 << 24
-//           ln  = local id of the element's nodes in connectivity order (own: n - n0, others: nown + position in pn_id)
-//           slot = position of that incidence in the block's slice of the support list, 0xfff: not this block's node
+//           ln  = local id of the element's nodes in connectivity order (own: position in the block, others: nown + position in pn_id)
+//           slot = po_slot of that node + the position of the incidence in the node's support list, 0xfff: not this block's node
 struct Patch2 {
     int npb = 0, nb = 0, max_inc = 0, max_pn = 0, max_pe = 0;
-    std::vector<int> pe_ptr, pn_ptr, pn_id;
+    std::vector<int> po_ptr, po_id, po_slot, pe_ptr, pn_ptr, pn_id;
     std::vector<ulonglong2> pe_pack;
 };
 
@@ -36,34 +41,63 @@ struct Patch2 {
 #define DES2_PATCH_THREADS 256
 #define DES2_PATCH_IT 3             // patch elements per lane at most: their list entries and element data are loaded up front
 
-// false: a block exceeds the caps (the engine then keeps the plain kernels)
-static bool build_patches2(const des_mesh *m, int npb, Patch2 &P)
+// false: a block exceeds the caps (the engine then tries smaller blocks, then keeps the plain kernels)
+static bool build_patches2(const des_mesh *m, int npb, bool cluster, Patch2 &P)
 {
     const int nn = m->nnode, ne = m->nelem;
     const int *conn = m->connectivity, *sidx = m->support_idx, *sarr = m->support_arr, *slid = m->support_lidx;
     P = Patch2();
     P.npb = npb; P.nb = (nn + npb - 1) / npb;
-    P.pe_ptr.assign(1, 0); P.pn_ptr.assign(1, 0);
-    std::vector<int> emark((size_t)ne, -1), nmark((size_t)nn, -1), elems, others;
+    std::vector<int> order((size_t)nn);
+    for (int n = 0; n < nn; ++n) order[n] = n;
+    if (cluster && m->coord) {
+        // Morton order of the nodes on an isotropic 16-bit grid over the bounding box
+        const double *X = m->coord, *Z = m->coord + nn;
+        double x0 = X[0], x1 = X[0], z0 = Z[0], z1 = Z[0];
+        for (int n = 1; n < nn; ++n) { x0 = std::min(x0, X[n]); x1 = std::max(x1, X[n]); z0 = std::min(z0, Z[n]); z1 = std::max(z1, Z[n]); }
+        const double ext = std::max(x1 - x0, z1 - z0);
+        const double sc = ext > 0 ? 65535.0 / ext : 0.0;
+        auto spread = [](unsigned v) { unsigned long long r = v; r = (r | (r << 8)) & 0x00ff00ffull; r = (r | (r << 4)) & 0x0f0f0f0full;
+                                       r = (r | (r << 2)) & 0x33333333ull; r = (r | (r << 1)) & 0x55555555ull; return r; };
+        std::vector<unsigned long long> key((size_t)nn);
+        for (int n = 0; n < nn; ++n)
+            key[n] = ((spread((unsigned)((X[n] - x0) * sc)) | (spread((unsigned)((Z[n] - z0) * sc)) << 1)) << 32) | (unsigned)n;
+        std::sort(key.begin(), key.end());
+        for (int n = 0; n < nn; ++n) order[n] = (int)(key[n] & 0xffffffffull);
+    }
+    std::vector<int> blk_of((size_t)nn);
+    for (int q = 0; q < nn; ++q) blk_of[order[q]] = q / npb;
+    P.po_ptr.assign(1, 0); P.pe_ptr.assign(1, 0); P.pn_ptr.assign(1, 0);
+    std::vector<int> emark((size_t)ne, -1), nmark((size_t)nn, -1), elems, others, own, pos((size_t)nn, -1), base;
     std::vector<int> slots;
     for (int b = 0; b < P.nb; ++b) {
-        const int n0 = b * npb, n1 = std::min(nn, n0 + npb), nown = n1 - n0;
-        const int kb = sidx[n0], ke = sidx[n1];
-        if (ke - kb > DES2_PATCH_INC) return false;
+        own.assign(order.begin() + (size_t)b * npb, order.begin() + std::min((size_t)nn, (size_t)(b + 1) * npb));
+        std::sort(own.begin(), own.end());
+        const int nown = (int)own.size();
+        base.assign((size_t)nown, 0);
+        int ninc = 0;
         elems.clear(); others.clear();
-        for (int k = kb; k < ke; ++k) if (emark[sarr[k]] != b) { emark[sarr[k]] = b; elems.push_back(sarr[k]); }
+        for (int t = 0; t < nown; ++t) {
+            const int n = own[t];
+            pos[n] = t; base[t] = ninc; ninc += sidx[n + 1] - sidx[n];
+            for (int k = sidx[n]; k < sidx[n + 1]; ++k) if (emark[sarr[k]] != b) { emark[sarr[k]] = b; elems.push_back(sarr[k]); }
+        }
+        if (ninc > DES2_PATCH_INC) return false;
         std::sort(elems.begin(), elems.end());
         for (int e : elems)
             for (int i = 0; i < 3; ++i) {
                 const int n = conn[(size_t)i * ne + e];
-                if ((n < n0 || n >= n1) && nmark[n] != b) { nmark[n] = b; others.push_back(n); }
+                if (blk_of[n] != b && nmark[n] != b) { nmark[n] = b; others.push_back(n); }
             }
         std::sort(others.begin(), others.end());
         if (nown + (int)others.size() > DES2_PATCH_PN) return false;
         slots.assign(3 * elems.size(), 0xfff);
-        for (int k = kb; k < ke; ++k) {
-            const size_t q = std::lower_bound(elems.begin(), elems.end(), sarr[k]) - elems.begin();
-            slots[3 * q + slid[k]] = k - kb;
+        for (int t = 0; t < nown; ++t) {
+            const int n = own[t];
+            for (int k = sidx[n]; k < sidx[n + 1]; ++k) {
+                const size_t q = std::lower_bound(elems.begin(), elems.end(), sarr[k]) - elems.begin();
+                slots[3 * q + slid[k]] = base[t] + (k - sidx[n]);
+            }
         }
         for (size_t q = 0; q < elems.size(); ++q) {
             const int e = elems[q];
@@ -72,18 +106,21 @@ static bool build_patches2(const des_mesh *m, int npb, Patch2 &P)
             for (int i = 0; i < 3; ++i) {
                 const int n = conn[(size_t)i * ne + e];
                 nmin = std::min(nmin, n);
-                ln[i] = (n >= n0 && n < n1) ? (unsigned long long)(n - n0)
-                                            : (unsigned long long)(nown + (std::lower_bound(others.begin(), others.end(), n) - others.begin()));
+                ln[i] = blk_of[n] == b ? (unsigned long long)pos[n]
+                                       : (unsigned long long)(nown + (std::lower_bound(others.begin(), others.end(), n) - others.begin()));
             }
             ulonglong2 r;
-            r.x = (unsigned long long)(unsigned)e | ((nmin >= n0 && nmin < n1) ? 0x40000000ull : 0ull) | (ln[0] << 31) | (ln[1] << 40) | (ln[2] << 49);
+            r.x = (unsigned long long)(unsigned)e | (blk_of[nmin] == b ? 0x40000000ull : 0ull) | (ln[0] << 31) | (ln[1] << 40) | (ln[2] << 49);
             r.y = (unsigned long long)slots[3*q] | ((unsigned long long)slots[3*q + 1] << 12) | ((unsigned long long)slots[3*q + 2] << 24);
             P.pe_pack.push_back(r);
         }
+        P.po_id.insert(P.po_id.end(), own.begin(), own.end());
+        P.po_slot.insert(P.po_slot.end(), base.begin(), base.end());
         P.pn_id.insert(P.pn_id.end(), others.begin(), others.end());
+        P.po_ptr.push_back((int)P.po_id.size());
         P.pe_ptr.push_back((int)P.pe_pack.size());
         P.pn_ptr.push_back((int)P.pn_id.size());
-        P.max_inc = std::max(P.max_inc, ke - kb);
+        P.max_inc = std::max(P.max_inc, ninc);
         P.max_pn = std::max(P.max_pn, nown + (int)others.size());
         P.max_pe = std::max(P.max_pe, (int)elems.size());
         if (P.max_pe > DES2_PATCH_IT * DES2_PATCH_THREADS) return false;
@@ -104,7 +141,7 @@ __device__ __forceinline__ PatchElem2 patch_elem2(const ulonglong2 r)
 
 // pn_cap / inc_cap: LDS entries per nodal array / per slot array = the mesh's largest block, rounded up (dynamic LDS: a
 // workgroup takes what the mesh needs, not the caps, so that more of them fit a CU)
-struct PatchArgs { int nn, ne, npb, nb, pn_cap, inc_cap; const int *pe_ptr; const ulonglong2 *pe_pack; const int *pn_ptr, *pn_id, *sup_idx; };
+struct PatchArgs { int nn, ne, npb, nb, pn_cap, inc_cap; const int *po_ptr, *po_id, *po_slot, *pe_ptr; const ulonglong2 *pe_pack; const int *pn_ptr, *pn_id, *sup_idx; };
 
 // ---- update_temperature + compute_dvoldt ------------------------------------------------------------
 // thermal = 0: the temperature stands (isostasy loop, pseudo-transient iterations, has_thermal_diffusion = no).
@@ -121,7 +158,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, const PatchA
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
     const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
     if (b >= a.nb) return;
-    const int n0 = b * a.npb, nown = min(a.npb, nn - n0);
+    const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     // everything that does not depend on the staged records is loaded first, so that a workgroup's trips to memory overlap:
     // this lane's list entries, then the element data they name, beside the nodal records
@@ -139,7 +176,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, const PatchA
             if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; }
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
-        const int id = j < nown ? n0 + j : a.pn_id[h0 + j - nown];
+        const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
         lx[j] = coord[id]; lz[j] = coord[nn + id]; lvx[j] = vel[id]; lvz[j] = vel[nn + id]; lT[j] = T_in[id];
     }
     __syncthreads();
@@ -185,8 +222,8 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, const PatchA
     }
     __syncthreads();
     if ((int)threadIdx.x < nown) {
-        const int n = n0 + threadIdx.x;
-        const int kb = a.sup_idx[n0], r0 = a.sup_idx[n] - kb, r1 = a.sup_idx[n + 1] - kb;
+        const int n = a.po_id[o0 + threadIdx.x];
+        const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
         double acc = 0.;
         for (int k = r0; k < r1; ++k) acc += lf1[k];
         ntmp[n] = acc / volume_n[n];
@@ -216,7 +253,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
     const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
     if (b >= a.nb) return;
-    const int n0 = b * a.npb, nown = min(a.npb, nn - n0);
+    const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     const double gravity = p->gravity;
     ulonglong2 rec[DES2_PATCH_IT];
@@ -235,7 +272,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
             g_phi[k] = gravity != 0 ? props[2 * ne + e] : 0.0;
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
-        const int id = j < nown ? n0 + j : a.pn_id[h0 + j - nown];
+        const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
         lx[j] = coord[id]; lz[j] = coord[nn + id];
         if (gravity != 0) lT[j] = temperature[id];
         if (nmd) lnt[j] = ntmp[id];
@@ -279,8 +316,8 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
     }
     __syncthreads();
     if ((int)threadIdx.x < nown) {
-        const int n = n0 + threadIdx.x;
-        const int kb = a.sup_idx[n0], r0 = a.sup_idx[n] - kb, r1 = a.sup_idx[n + 1] - kb;
+        const int n = a.po_id[o0 + threadIdx.x];
+        const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
         double f[2] = {0, 0}, fr[2] = {0, 0};
         for (int k = r0; k < r1; ++k) {
             f[0] -= lf0[k]; fr[0] = lf0[k];            // assignment: fields.cxx:673
@@ -303,7 +340,7 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
     const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
     if (b >= a.nb) return;
-    const int n0 = b * a.npb, nown = min(a.npb, nn - n0);
+    const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     ulonglong2 rec[DES2_PATCH_IT];
     double g_bulk[DES2_PATCH_IT], g_shear[DES2_PATCH_IT], g_cp[DES2_PATCH_IT];
@@ -318,7 +355,7 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
             g_bulk[k] = props[e]; g_shear[k] = props[ne + e]; g_cp[k] = props[3 * ne + e];
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
-        const int id = j < nown ? n0 + j : a.pn_id[h0 + j - nown];
+        const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
         lx[j] = coord[id]; lz[j] = coord[nn + id]; lT[j] = temperature[id];
     }
     __syncthreads();
@@ -350,8 +387,8 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
     }
     __syncthreads();
     if ((int)threadIdx.x < nown) {
-        const int n = n0 + threadIdx.x;
-        const int kb = a.sup_idx[n0], r0 = a.sup_idx[n] - kb, r1 = a.sup_idx[n + 1] - kb;
+        const int n = a.po_id[o0 + threadIdx.x];
+        const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
         double vn = 0, ms = 0, tms = 0, yms = 0;
         for (int k = r0; k < r1; ++k) {
             vn += lf0[k];
