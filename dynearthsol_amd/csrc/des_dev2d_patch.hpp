@@ -55,13 +55,18 @@ static bool build_patches2(const des_mesh *m, int npb, bool cluster, Patch2 &P)
         const double *X = m->coord, *Z = m->coord + nn;
         double x0 = X[0], x1 = X[0], z0 = Z[0], z1 = Z[0];
         for (int n = 1; n < nn; ++n) { x0 = std::min(x0, X[n]); x1 = std::max(x1, X[n]); z0 = std::min(z0, Z[n]); z1 = std::max(z1, Z[n]); }
-        const double ext = std::max(x1 - x0, z1 - z0);
-        const double sc = ext > 0 ? 65535.0 / ext : 0.0;
+        // clusters `aspect` times as tall (z) as wide (x): the renumbered mesh is sorted along x, so the ids -- of nodes and of
+        // elements -- inside a thin x-strip are contiguous, and a cluster that is a few columns wide reads longer runs of
+        // the element planes than a square one (DES2D_CLUSTER_ASPECT, default 4)
+        const char *ae = std::getenv("DES2D_CLUSTER_ASPECT");
+        const double aspect = ae && std::atof(ae) > 0 ? std::atof(ae) : 4.0;
+        const double ext = std::max(x1 - x0, (z1 - z0) / aspect);
+        const double sc = ext > 0 ? 65535.0 / ext : 0.0, scz = sc / aspect;
         auto spread = [](unsigned v) { unsigned long long r = v; r = (r | (r << 8)) & 0x00ff00ffull; r = (r | (r << 4)) & 0x0f0f0f0full;
                                        r = (r | (r << 2)) & 0x33333333ull; r = (r | (r << 1)) & 0x55555555ull; return r; };
         std::vector<unsigned long long> key((size_t)nn);
         for (int n = 0; n < nn; ++n)
-            key[n] = ((spread((unsigned)((X[n] - x0) * sc)) | (spread((unsigned)((Z[n] - z0) * sc)) << 1)) << 32) | (unsigned)n;
+            key[n] = ((spread((unsigned)((X[n] - x0) * sc)) | (spread((unsigned)((Z[n] - z0) * scz)) << 1)) << 32) | (unsigned)n;
         std::sort(key.begin(), key.end());
         for (int n = 0; n < nn; ++n) order[n] = (int)(key[n] & 0xffffffffull);
     }
