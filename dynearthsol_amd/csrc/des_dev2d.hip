@@ -82,6 +82,7 @@ struct Engine {
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
     // node-block patch passes (des_dev2d_patch.hpp); DES2D_PATCH=0 or a mesh outside their LDS caps: the plain kernels
     bool patch = false, res_fin_pending = false, tick_pending = false;
+    bool geo_pending = false;                  // compute_volume + rotate_stress of the last step left to the next k2_stress<M, 2>
     bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
     int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0;
     int *po_ptr = nullptr, *po_id = nullptr, *po_slot = nullptr, *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
@@ -507,12 +508,21 @@ __global__ void k2_edvoldt(int ne, const int *conn, const double *ntmp, double *
 // FUSED = 1 (the patch path, des_dev2d_patch.hpp): edvoldt (compute_edvoldt, geometry.cxx:249-279) is formed here from the
 // nodal values with k2_edvoldt's statements instead of being read back, and the new stress goes to stress_out (another
 // buffer when NMD_stress follows).
+// FUSED = 2: this pass also finishes the step BEFORE, whose end-of-step element pass was left out (step_back: geo_pending):
+// compute_volume after the volume swap (geometry.cxx:170-201) and rotate_stress (fields.cxx:807-900) with k2_rotate_vol's
+// statements, from the coordinates and velocities that pass would have seen (nothing but the temperature has moved since)
+// -- on the stress it is about to update anyway: one read and one write of stress and strain per step instead of two.
+// volume[] still holds the volumes of the step before (the top elements' already corrected, bc.cxx:1670-1687): they are
+// this step's volume_old.  The dt is the one that step ran with (a compute_dt step never leaves its rotation behind).
+__device__ __forceinline__ void jaumann_rate_2d(double *s, double dt, double w2);
+
 template <class M, int FUSED = 0>
 __global__ void __launch_bounds__(DES_BLOCK)
 k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, const int *conn, const double *temperature,
-          const double *props, const int *markers, double *edvoldt, const double *volume, const double *volume_old,
+          const double *props, const int *markers, double *edvoldt, double *volume, double *volume_old,
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
-          double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out)
+          double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
+          int nn, const double *coord, const double *vel, int rotate, int store_volume_old)
 {
     M::stage_begin();
     M::stage_end();
@@ -526,6 +536,27 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         s[i] = stress[i * ne + e];
         es[i] = strain[i * ne + e];
         edot[i] = strain_rate[i * ne + e];
+    }
+    double vol, vol_old;
+    if (FUSED == 2) {
+        vol_old = volume[e];
+        double d[3][2];
+        elem_coords(coord, conn, nn, ne, e, d);
+        vol = triangle_area(d[0], d[1], d[2]);
+        volume[e] = vol;
+        if (store_volume_old) volume_old[e] = vol_old;
+        if (rotate) {
+            double shpdx[3], shpdz[3], v[3][2];
+            shape_fn2(d, vol, shpdx, shpdz);
+            elem_coords(vel, conn, nn, ne, e, v);
+            double w2 = 0;
+            for (int i = 0; i < 3; ++i) w2 += 0.5 * (v[i][1] * shpdx[i] - v[i][0] * shpdz[i]);
+            jaumann_rate_2d(s, dt, w2);
+            jaumann_rate_2d(es, dt, w2);
+        }
+    } else {
+        vol = volume[e];
+        vol_old = volume_old[e];
     }
     double edv;
     if (FUSED) {
@@ -561,7 +592,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     case DES_RH_MAXWELL: {
         double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
         viscosity[e] = visc;
-        double dv = volume[e] / volume_old[e] - 1;
+        double dv = vol / vol_old - 1;
         maxwell2(bulkm, shearm, visc, dt, dv, de, s);
         break;
     }
@@ -585,7 +616,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         double depls = 0;
         double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
         viscosity[e] = visc;
-        double dv = volume[e] / volume_old[e] - 1;
+        double dv = vol / vol_old - 1;
         double sv[3];
         for (int i = 0; i < 3; ++i) sv[i] = s[i];
         maxwell2(bulkm, shearm, visc, dt, dv, de, sv);
@@ -623,7 +654,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     if (p->is_using_mixed_stress) {
         const double dp = trace2(s) - old_s;
         dpressure[e] = dp;
-        etmp[e] = dp * volume[e];                      // NMD_stress, geometry.cxx:292-296
+        etmp[e] = dp * vol;                      // NMD_stress, geometry.cxx:292-296
     }
     for (int i = 0; i < 3; ++i) {
         stress_out[i * ne + e] = s[i];
@@ -1653,15 +1684,23 @@ template <class M>
 void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr)
 {
     if (h->count_past) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
+    const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? 1 : 0;
+    if (fused && h->geo_pending) {
+        L2((k2_stress<M, 2>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
+           h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
+           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, 1);
+        h->geo_pending = false;
+        return;
+    }
     if (fused) {
         L2((k2_stress<M, 1>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
            h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out);
+           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, 0);
         return;
     }
     L2((k2_stress<M, 0>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
        h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, h->stress);
+       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, h->stress, h->nn, h->coord, h->vel, rot, 0);
 }
 
 // update_force's boundary terms in the reference's order (fields.cxx:682-691)
@@ -1711,7 +1750,7 @@ void launch_surface_commit(Engine *h)
 }
 
 // ... and the rest
-void launch_update_mesh_rest(Engine *h, long long steps, bool rotate)
+void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer = false)
 {
     const des_params &p = h->p;
     const bool at_interval = steps % p.quality_check_step_interval == 0;
@@ -1735,11 +1774,14 @@ void launch_update_mesh_rest(Engine *h, long long steps, bool rotate)
         L2(k2_cse_node, h->ntop, h->ntop, h->top_nodes, h->sup_idx, h->sup_arr, h->volume, h->volume_n,
            (steps != 0 && at_interval) ? 1 : 0, h->dhacc);
     }
-    std::swap(h->volume, h->volume_old);
+    if (!defer) std::swap(h->volume, h->volume_old);
     refresh_props(h);
     if (h->patch) {
-        // compute_volume + rotate_stress in one element pass, compute_mass over the node-block patches
-        L2(k2_rotate_vol, h->ne, h->d_clk, rotate ? 1 : 0, h->nn, h->ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
+        // compute_volume + rotate_stress in one element pass -- or, inside a multi-step call, left to the next step's stress
+        // update (k2_stress<M, 2>), which reads and writes the same stress and strain anyway; compute_mass over the
+        // node-block patches (it forms the volumes it sums from the coordinates)
+        if (defer) h->geo_pending = true;
+        else L2(k2_rotate_vol, h->ne, h->d_clk, rotate ? 1 : 0, h->nn, h->ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
         hipLaunchKernelGGL(k2p_mass, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (3 * (size_t)h->p_pn_cap + 4 * (size_t)h->p_inc_cap), h->stream, h->d_p, patch_args(h), h->coord,
                            h->temperature, h->props, h->markers, h->volume_n, h->mass, h->tmass, h->ymass);
         return;
@@ -1771,7 +1813,8 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
     const int nn = h->nn, ne = h->ne;
     if (h->patch) {
         const PatchArgs a = patch_args(h);
-        hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0, a,
+        hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0,
+                           h->geo_pending ? 1 : 0, a,
                            h->bcflag, h->coord, h->vel, h->temperature, h->temperature_alt, h->volume, h->radiogenic, h->props,
                            h->markers, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
         if (thermal) std::swap(h->temperature, h->temperature_alt);
@@ -1881,13 +1924,19 @@ int step_front(Engine *h)
 }
 
 // ... and from there on (a decomposed mesh has refreshed its ghost region in between); compute_dt excluded
-void step_back(Engine *h)
+// `more`: another step of the same call follows at once (nothing reads the element fields in between)
+void step_back(Engine *h, bool more = false)
 {
     const des_params &p = h->p;
     const int nn = h->nn, ne = h->ne;
     const bool rotate = !h->iso && (p.rheol_type & DES_RH_ELASTIC);
     const bool moved = p.has_moving_mesh || h->iso;
-    if (moved) launch_update_mesh_rest(h, h->steps_host, rotate);
+    static const char *geo_env = std::getenv("DES2D_GEO");
+    // the end-of-step element pass rides in the next stress update: a plain step (no compute_dt, which wants this step's
+    // volumes; no averaging, which wants its rotated stress; no PT loop, which re-enters the passes)
+    const bool defer = more && h->patch && moved && rotate && !p.is_outputting_averaged_fields && !p.has_PT
+                       && h->steps_host % 10 != 0 && !(geo_env && geo_env[0] == '0');
+    if (moved) launch_update_mesh_rest(h, h->steps_host, rotate, defer);
     if (h->iso) return;
     if (rotate && !(h->patch && moved))
         L2(k2_rotate, ne, h->d_clk, nn, ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
@@ -1899,11 +1948,11 @@ void step_back(Engine *h)
 }
 
 template <class M>
-int one_step(Engine *h)
+int one_step(Engine *h, bool more = false)
 {
     int rc = step_front<M>(h);
     if (rc) return rc;
-    step_back(h);
+    step_back(h, more);
     if (!h->iso && h->steps_host % 10 == 0) launch_dt(h);
     return DES_OK;
 }
@@ -2241,7 +2290,7 @@ int step(Engine *h, int nsteps, des_scalars *out)
             h->count_past = (i == nsteps - 1);
             int rc = h->portable_libm ? step_front<desk::MathPortable>(h) : step_front<desk::MathOcml>(h);
             if (rc || (rc = exchange_rccl(h))) return rc;
-            step_back(h);
+            step_back(h, i < nsteps - 1);
             if (!h->iso && h->steps_host % 10 == 0 && (rc = dt_allreduce(h, true))) return rc;
         }
         HIP2(hipGetLastError());
@@ -2254,7 +2303,7 @@ int step(Engine *h, int nsteps, des_scalars *out)
     h->n_pt_iterations = 0;
     for (int i = 0; i < nsteps; ++i) {
         h->count_past = (i == nsteps - 1);
-        const int rc = h->portable_libm ? one_step<desk::MathPortable>(h) : one_step<desk::MathOcml>(h);
+        const int rc = h->portable_libm ? one_step<desk::MathPortable>(h, i < nsteps - 1) : one_step<desk::MathOcml>(h, i < nsteps - 1);
         if (rc) return rc;
     }
     HIP2(hipGetLastError());
@@ -2482,7 +2531,7 @@ int step_group(Engine **g, int n, int nsteps, des_scalars *out)
         for (int k = 0; k < n; ++k) {
             Engine *e = g[k];
             launch_wall_set(e, wall);
-            step_back(e);
+            step_back(e, i < nsteps - 1);
             if (!e->iso && e->steps_host % 10 == 0) {
                 do_dt = true;
                 launch_dt_partials(e);

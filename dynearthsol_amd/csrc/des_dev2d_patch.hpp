@@ -152,7 +152,7 @@ struct PatchArgs { int nn, ne, npb, nb, pn_cap, inc_cap; const int *po_ptr, *po_
 // thermal = 0: the temperature stands (isostasy loop, pseudo-transient iterations, has_thermal_diffusion = no).
 // T_in / T_out: a block must not move a temperature another block may still be reading -- the host swaps the two.
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
-k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, const PatchArgs a, const unsigned *bcflag,
+k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from_coords, const PatchArgs a, const unsigned *bcflag,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
                 const double *radiogenic, const double *props, const int *markers, const double *tmass, const double *volume_n,
                 double *ntmp, double *strain_rate)
@@ -177,7 +177,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, const PatchA
     for (int k = 0; k < DES2_PATCH_IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
-            g_vol[k] = volume[e];
+            g_vol[k] = vol_from_coords ? 0.0 : volume[e];
             if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; }
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
@@ -194,7 +194,9 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, const PatchA
         for (int i = 0; i < 3; ++i) {
             d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; v[i][0] = lvx[E.ln[i]]; v[i][1] = lvz[E.ln[i]]; T[i] = lT[E.ln[i]];
         }
-        const double vol = g_vol[k];
+        // (vol_from_coords: the end-of-step element pass of the step before was left to the coming stress update, volume[]
+        //  is a step old -- compute_volume's own expression on the staged coordinates gives the value it will store)
+        const double vol = vol_from_coords ? triangle_area(d[0], d[1], d[2]) : g_vol[k];
         shape_fn2(d, vol, shpdx, shpdz);
         if (thermal) {
             // k2_temp_elem's statements
