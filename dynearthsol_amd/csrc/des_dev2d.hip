@@ -82,6 +82,7 @@ struct Engine {
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
     // node-block patch passes (des_dev2d_patch.hpp); DES2D_PATCH=0 or a mesh outside their LDS caps: the plain kernels
     bool patch = false, res_fin_pending = false, tick_pending = false;
+    bool elide = false;                        // this step's output-only element stores can go (a later step of the same call rewrites them)
     bool geo_pending = false;                  // compute_volume + rotate_stress of the last step left to the next k2_stress<M, 2>
     bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
     int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0;
@@ -514,6 +515,9 @@ __global__ void k2_edvoldt(int ne, const int *conn, const double *ntmp, double *
 // -- on the stress it is about to update anyway: one read and one write of stress and strain per step instead of two.
 // volume[] still holds the volumes of the step before (the top elements' already corrected, bc.cxx:1670-1687): they are
 // this step's volume_old.  The dt is the one that step ran with (a compute_dt step never leaves its rotation behind).
+// outs = 0 (a step of a multi-step call that is not its last one): what no pass reads before the next update overwrites it --
+// the corrected strain rate (the next k2p_temp_dvoldt stores a new one), edvoldt, viscosity, delta_plstrain, volume_old --
+// is not stored: 56 of the pass's 128 B of stores per element.  The last step of every call stores them all.
 __device__ __forceinline__ void jaumann_rate_2d(double *s, double dt, double w2);
 
 template <class M, int FUSED = 0>
@@ -522,7 +526,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
           const double *props, const int *markers, double *edvoldt, double *volume, double *volume_old,
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
           double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
-          int nn, const double *coord, const double *vel, int rotate, int store_volume_old)
+          int nn, const double *coord, const double *vel, int rotate, int outs)
 {
     M::stage_begin();
     M::stage_end();
@@ -544,7 +548,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         elem_coords(coord, conn, nn, ne, e, d);
         vol = triangle_area(d[0], d[1], d[2]);
         volume[e] = vol;
-        if (store_volume_old) volume_old[e] = vol_old;
+        if (outs) volume_old[e] = vol_old;
         if (rotate) {
             double shpdx[3], shpdz[3], v[3][2];
             shape_fn2(d, vol, shpdx, shpdz);
@@ -563,7 +567,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         double dj = 0;
         for (int i = 0; i < 3; ++i) dj += ntmp[conn[i * ne + e]];
         edv = dj / 3;
-        edvoldt[e] = edv;
+        if (outs) edvoldt[e] = edv;
     } else
         edv = edvoldt[e];
     double old_s = trace2(s);
@@ -571,7 +575,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         double div = trace2(edot);
         for (int i = 0; i < 2; ++i) edot[i] += (edv - div) / 2;
     }
-    for (int i = 0; i < 3; ++i) strain_rate[i * ne + e] = edot[i];
+    if (outs) for (int i = 0; i < 3; ++i) strain_rate[i * ne + e] = edot[i];
     for (int i = 0; i < 3; ++i) es[i] += edot[i] * dt;
     double de[3];
     for (int i = 0; i < 3; ++i) de[i] = edot[i] * dt;
@@ -584,14 +588,14 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         break;
     case DES_RH_VISCOUS: {
         double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
-        viscosity[e] = visc;
+        if (outs) viscosity[e] = visc;
         double total_dv = trace2(es);
         viscous2(bulkm, visc, total_dv, edot, s);
         break;
     }
     case DES_RH_MAXWELL: {
         double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
-        viscosity[e] = visc;
+        if (outs) viscosity[e] = visc;
         double dv = vol / vol_old - 1;
         maxwell2(bulkm, shearm, visc, dt, dv, de, s);
         break;
@@ -615,7 +619,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     case DES_RH_EVP: {
         double depls = 0;
         double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
-        viscosity[e] = visc;
+        if (outs) viscosity[e] = visc;
         double dv = vol / vol_old - 1;
         double sv[3];
         for (int i = 0; i < 3; ++i) sv[i] = s[i];
@@ -646,7 +650,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     }
     default: break;
     }
-    delta_plstrain[e] = dpls;
+    if (outs) delta_plstrain[e] = dpls;
     if (count_past) {                  // (the last step of a call only: one address, thousands of wavefronts)
         const unsigned long long b = __ballot(past);
         if (b && (int)(threadIdx.x & 63) == __ffsll((long long)b) - 1) atomicAdd(&clk->n_past, (int)__popcll(b));
@@ -1688,19 +1692,19 @@ void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr)
     if (fused && h->geo_pending) {
         L2((k2_stress<M, 2>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
            h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, 1);
+           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
         h->geo_pending = false;
         return;
     }
     if (fused) {
         L2((k2_stress<M, 1>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
            h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, 0);
+           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
         return;
     }
     L2((k2_stress<M, 0>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
        h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, h->stress, h->nn, h->coord, h->vel, rot, 0);
+       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, h->stress, h->nn, h->coord, h->vel, rot, 1);
 }
 
 // update_force's boundary terms in the reference's order (fields.cxx:682-691)
@@ -1947,9 +1951,16 @@ void step_back(Engine *h, bool more = false)
     }
 }
 
+inline bool elide_ok(const Engine *h, bool more)
+{
+    static const char *env = std::getenv("DES2D_ELIDE");
+    return more && h->patch && !h->iso && !h->p.has_PT && !h->p.is_outputting_averaged_fields && !(env && env[0] == '0');
+}
+
 template <class M>
 int one_step(Engine *h, bool more = false)
 {
+    h->elide = elide_ok(h, more);
     int rc = step_front<M>(h);
     if (rc) return rc;
     step_back(h, more);
@@ -2288,6 +2299,7 @@ int step(Engine *h, int nsteps, des_scalars *out)
         h->n_pt_iterations = 0;
         for (int i = 0; i < nsteps; ++i) {
             h->count_past = (i == nsteps - 1);
+            h->elide = elide_ok(h, i < nsteps - 1);
             int rc = h->portable_libm ? step_front<desk::MathPortable>(h) : step_front<desk::MathOcml>(h);
             if (rc || (rc = exchange_rccl(h))) return rc;
             step_back(h, i < nsteps - 1);
@@ -2398,6 +2410,7 @@ int phase(Engine *h, int ph)
     if (hipSetDevice(h->device) != hipSuccess) return -DES_ERR_RESOURCE;
     if (ph == 0) {
         h->count_past = true;
+        h->elide = false;
         const int rc = h->portable_libm ? step_front<desk::MathPortable>(h) : step_front<desk::MathOcml>(h);
         return rc ? -rc : 0;
     }
@@ -2503,6 +2516,7 @@ int step_group(Engine **g, int n, int nsteps, des_scalars *out)
     for (int i = 0; i < nsteps; ++i) {
         for (int k = 0; k < n; ++k) {
             g[k]->count_past = (i == nsteps - 1);
+            g[k]->elide = elide_ok(g[k], i < nsteps - 1);
             const int rc = g[k]->portable_libm ? step_front<desk::MathPortable>(g[k]) : step_front<desk::MathOcml>(g[k]);
             if (rc) return rc;
             launch_pack(g[k]);
