@@ -64,6 +64,7 @@ struct Engine {
     unsigned *bcflag = nullptr;
     int nbf[DES_NBDRY] = {0}, nbn[DES_NBDRY] = {0};
     int *bf_elem[DES_NBDRY] = {nullptr}, *bf_facet[DES_NBDRY] = {nullptr}, *bnodes[DES_NBDRY] = {nullptr};
+    int4 *binc[DES_NBDRY] = {nullptr};         // [2 * nbn] per boundary with facets: the boundary-facet incidences of its nodes (k2_sbc_direct)
     double *bnormals = nullptr, *edge_vec = nullptr; int *edge_slot = nullptr;
     int ntop = 0, etop = 0, ntop_elems = 0;
     int *top_nodes = nullptr, *ean = nullptr, *conn_surf = nullptr, *top_elems = nullptr;
@@ -721,14 +722,11 @@ __global__ void k2_force_node(int nn, int ne, const int *sup_idx, const int *sup
 }
 
 // apply_stress_bcs (bc.cxx:661-827) of boundary `ib`: facet part ...
-__global__ void k2_sbc_facet(const des_params *p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
-                             const int *conn, const double *coord, const double *temperature, const int *markers,
-                             double *tmp_result, int *etmp_int)
+// the pressure on a boundary facet and its (unnormalised) outward normal
+__device__ __forceinline__ double sbc_facet_pressure(const des_params *p, int ib, int e, int f, int nn, int ne, const int *conn,
+                                                     const double *coord, const double *temperature, const int *markers, double normal[2])
 {
-    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (n >= bound) return;
-    const int e = bf_elem[n], f = bf_facet[n];
-    double normal[2], zcenter, fc[2][2];
+    double zcenter, fc[2][2];
     for (int j = 0; j < 2; ++j) {
         const int nd = conn[NODE_OF_FACET_D[f][j] * ne + e];
         fc[j][0] = coord[nd]; fc[j][1] = coord[nn + nd];
@@ -747,10 +745,46 @@ __global__ void k2_sbc_facet(const des_params *p, int ib, int bound, const int *
         pr = desk::ref_pressure(p, zcenter);
         if (pr < 0.0) pr = 0.0;
     }
+    return pr;
+}
+
+__global__ void k2_sbc_facet(const des_params *p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
+                             const int *conn, const double *coord, const double *temperature, const int *markers,
+                             double *tmp_result, int *etmp_int)
+{
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= bound) return;
+    const int e = bf_elem[n], f = bf_facet[n];
+    double normal[2];
+    const double pr = sbc_facet_pressure(p, ib, e, f, nn, ne, conn, coord, temperature, markers, normal);
     etmp_int[e] = n;
     for (int j = 0; j < 2; ++j)
         for (int d = 0; d < 2; ++d)
             tmp_result[(j*2 + d) * ne + n] = pr * normal[d] / 2;
+}
+
+// The same in ONE launch (the patch path): every boundary node forms the terms of its boundary facets itself -- the same
+// expressions, subtracted in the order of its support list as k2_sbc_node does -- from a list built once per mesh:
+// binc[(2*j + q)] = {element, facet, which of the facet's two nodes} of the q-th such incidence of boundary node j, element -1: none.
+#define DES2_SBC_INC 2
+__global__ void k2_sbc_direct(const des_params *p, int ib, int nbdry_nodes, const int *bnodes, const int4 *binc,
+                              int nn, int ne, const int *conn, const double *coord, const double *temperature, const int *markers,
+                              double *force)
+{
+    const int j = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (j >= nbdry_nodes) return;
+    const int n = bnodes[j];
+    int4 inc[DES2_SBC_INC];
+    for (int q = 0; q < DES2_SBC_INC; ++q) inc[q] = binc[DES2_SBC_INC * j + q];
+    double f0 = force[n], f1 = force[nn + n];
+    for (int q = 0; q < DES2_SBC_INC; ++q) {
+        if (inc[q].x < 0) break;
+        double normal[2];
+        const double pr = sbc_facet_pressure(p, ib, inc[q].x, inc[q].y, nn, ne, conn, coord, temperature, markers, normal);
+        f0 -= pr * normal[0] / 2;
+        f1 -= pr * normal[1] / 2;
+    }
+    force[n] = f0; force[nn + n] = f1;
 }
 
 // ... node part ...
@@ -1717,6 +1751,12 @@ void launch_stress_bcs(Engine *h)
             if (i == iboundz0 && !p.has_winkler_foundation) continue;
             if (i == iboundz1 && !p.has_water_loading) continue;
             if (h->nbf[i] == 0) continue;
+            if (h->patch && h->binc[i]) {
+                if (h->nbn[i])
+                    L2(k2_sbc_direct, h->nbn[i], h->d_p, i, h->nbn[i], h->bnodes[i], h->binc[i], h->nn, h->ne, h->conn, h->coord,
+                       h->temperature, h->markers, h->force);
+                continue;
+            }
             L2(k2_sbc_facet, h->nbf[i], h->d_p, i, h->nbf[i], h->bf_elem[i], h->bf_facet[i], h->nn, h->ne, h->conn, h->coord,
                h->temperature, h->markers, h->tmp_result, h->etmp_int);
             if (h->nbn[i])
@@ -2110,6 +2150,32 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
             A2(dcopy(h, h->pn_ptr, P.pn_ptr.data(), P.pn_ptr.size()));
             A2(dcopy(h, h->pn_id, P.pn_id.data(), P.pn_id.size()));
             A2(dalloc(h, h->temperature_alt, (size_t)nn));
+            for (int i = 0; i < DES_NBDRY; ++i) {
+                if (h->nbf[i] == 0 || h->nbn[i] == 0) continue;
+                // k2_sbc_node's walk, once: the marks k2_sbc_facet leaves (the last facet of an element wins), then for every
+                // boundary node the elements of its support list that carry a marked facet holding the node
+                static const int nof[3][2] = {{1,2},{2,0},{0,1}};
+                std::vector<int> bm((size_t)ne, -1);
+                for (int f = 0; f < h->nbf[i]; ++f) bm[mesh->bfacet_elem[i][f]] = f;
+                std::vector<int4> inc((size_t)DES2_SBC_INC * h->nbn[i], make_int4(-1, 0, 0, 0));
+                bool fits = true;
+                for (int j = 0; j < h->nbn[i] && fits; ++j) {
+                    const int n = mesh->bnodes[i][j];
+                    int q = 0;
+                    for (int k = mesh->support_idx[n]; k < mesh->support_idx[n + 1]; ++k) {
+                        const int e = mesh->support_arr[k], ib = bm[e];
+                        if (ib < 0) continue;
+                        const int f = mesh->bfacet_facet[i][ib];
+                        for (int l = 0; l < 2; ++l)
+                            if (n == mesh->connectivity[(size_t)nof[f][l] * ne + e]) {
+                                if (q == DES2_SBC_INC) { fits = false; break; }
+                                inc[(size_t)DES2_SBC_INC * j + q++] = make_int4(e, f, l, 0);
+                                break;
+                            }
+                    }
+                }
+                if (fits) A2(dcopy(h, h->binc[i], inc.data(), inc.size()));      // (else: the three-launch form for this boundary)
+            }
             A2(dalloc(h, h->stress_pre, (size_t)3 * ne));
         }
     }
