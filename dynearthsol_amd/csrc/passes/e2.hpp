@@ -46,7 +46,7 @@ struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int 
 // With GEO the first pass of two (DEFER = 1) stores the strain and the corrected strain-rate diagonal as
 // soon as they are final -- before the constitutive law, whose registers they would otherwise sit next to --
 // also for the elements it sets aside; the return-mapping pass (RM = 1) then leaves the strain alone.
-template <class M, int DEFER, int GEO, int RM = 0>
+template <class M, int DEFER, int GEO, int RM = 0, int RH = 0>
 __device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
      const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData &md,
@@ -58,7 +58,8 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     const double dt = clk->dt;
     const unsigned eo = (unsigned)e * 8u;
     const int4 cn = rec_ld(conn, e);
-    const int rheol = p->rheol_type;
+    // (RH != 0: the rheology is known at compile time -- the kernel holds that law only: -2.5 us of 78 at 1M tets for evp)
+    const int rheol = RH ? RH : p->rheol_type;
     const desk::Mix mx = mix_of(md, p->nmat, e);
     const ElemProps pr = load_props(p, md, mx, ne, e);
 
@@ -251,7 +252,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
 #ifndef DES_E2GEO_WAVES
 #define DES_E2GEO_WAVES DES_E2_WAVES
 #endif
-template <class M, int DEFER, int GEO>
+template <class M, int DEFER, int GEO, int RH = 0>
 __global__ void __launch_bounds__(DES_BLOCK, DEFER ? (GEO ? DES_E2GEO_WAVES : DES_E2_WAVES_FAST) : DES_E2_WAVES)
 E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, int e_begin, int e_count, int e_begin2, int e_count2, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
@@ -279,7 +280,7 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
     const int el = desk::logical_block(nblocks) * DES_BLOCK + threadIdx.x;
     if (el >= e_count + e_count2) return;
     const int e = el < e_count ? e_begin + el : e_begin2 + (el - e_count);
-    const bool defer = e2_element<M, DEFER, GEO>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+    const bool defer = e2_element<M, DEFER, GEO, 0, RH>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
                                             plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp);
     // one atomic per wavefront that has such elements; without DEFER only the count is kept
     // (des_scalars::n_return_mapping, and what the host picks the next call's mode from)

@@ -27,7 +27,7 @@ def table():
 
 
 def pick(table, prefix):
-    # (the tool cuts names at 44 characters: variants that only differ in a later template argument -- EN1 with the
+    # (the tool cuts names at 48 characters: variants that only differ in a later template argument -- EN1 with the
     #  constant quasi-static mass or a per-element one -- share a name; the bench model runs the smaller one)
     hits = [v for k, v in table if k.startswith(prefix)]
     assert hits, prefix
@@ -35,10 +35,11 @@ def pick(table, prefix):
 
 
 @pytest.mark.parametrize("kernel,max_vgpr,min_waves,max_lds", [
-    ("E2_update_stress<desk::MathPortable, 1, 1>", 256, 2, 20480),      # E2<GEO>, first pass of two (the default)
-    ("E2_update_stress<desk::MathOcml, 1, 1>", 256, 2, 0),
-    ("E2_update_stress<desk::MathPortable, 1, 0>", 168, 3, 20480),      # first step of a call
-    ("E2_update_stress<desk::MathPortable, 0, 1>", 256, 2, 20480),      # one pass (return mapping inline): the mode when elements yield
+    ("E2_update_stress<desk::MathPortable, 1, 1, 0>", 256, 2, 20480),   # E2<GEO>, first pass of two
+    ("E2_update_stress<desk::MathOcml, 1, 1, 0>", 256, 2, 0),
+    ("E2_update_stress<desk::MathPortable, 1, 0, 0>", 168, 3, 20480),   # first step of a call
+    ("E2_update_stress<desk::MathPortable, 0, 1, 0>", 256, 2, 20480),   # one pass (return mapping inline): the fused step's mode
+    ("E2_update_stress<desk::MathPortable, 0, 1, 7>", 256, 2, 20480),   # ... with the evp law known at compile time (the headline)
     ("E2_return_mapping<desk::MathPortable, 1>", 256, 2, 20480),        # second pass
     ("EN1_mass_temperature_dvoldt<256, 1600, 296,", 168, 3, 54613),     # three workgroups per CU: LDS <= 160 KiB / 3
     ("EN3_force_nodes<512, 1664, 320>", 80, 6, 54613),

@@ -19,7 +19,7 @@ for line in out.splitlines():
         rows.append(cur)
     elif cur is not None:
         cur[k] = v
-print("%-44s %5s %5s %7s %6s %5s" % ("kernel", "VGPR", "SGPR", "scratch", "LDS", "occ"))
+print("%-48s %5s %5s %7s %6s %5s" % ("kernel", "VGPR", "SGPR", "scratch", "LDS", "occ"))
 for r in rows:
-    print("%-44s %5s %5s %7s %6s %5s" % (r["name"][:44], r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"),
+    print("%-48s %5s %5s %7s %6s %5s" % (r["name"][:48], r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"),
                                           r.get("LDS Size [bytes/block]"), r.get("Occupancy [waves/SIMD]")))

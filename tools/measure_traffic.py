@@ -31,8 +31,10 @@ def short(name):
         if k.startswith(ns):
             k = k[len(ns):]
     base = k.split("<")[0]
-    if base == "E2_update_stress" and k.rstrip().endswith(", 1>"):
-        return "E2G_geom_rotate_update_stress"          # the GEO variant: bench.py's name for it (profile id K_E2G)
+    if base == "E2_update_stress":
+        targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]      # <M, DEFER, GEO, RH>
+        if len(targs) >= 3 and targs[2] == "1":
+            return "E2G_geom_rotate_update_stress"      # the GEO variant: bench.py's name for it (profile id K_E2G)
     return base
 
 
