@@ -463,7 +463,9 @@ void launch_en1(des_dev *h, int part = PART_ALL)
         static const char *tenv = std::getenv("DES_EN1_THREADS");
         const int T = (tenv && std::atoi(tenv) == 512) ? 512 : 256;
         const bool fit = h->patch_max_inc <= 1600 && h->patch_max_pn <= 296 && h->patch_max_pe <= 872;
-#define DES_EN1_PICK(TT, II, NN, EE) (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0>)
+        const bool th = h->p.has_thermal_diffusion != 0;       // the common launch has kernels of its own (passes/en1.hpp)
+#define DES_EN1_PICK(TT, II, NN, EE) (th ? (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1, 1> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0, 1>) \
+                                         : (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1, 0> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0, 0>))
         if (fit) k = T == 512 ? DES_EN1_PICK(512, 1600, 296, 872) : DES_EN1_PICK(256, 1600, 296, 872);
         else     k = T == 512 ? DES_EN1_PICK(512, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE) : DES_EN1_PICK(256, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE);
 #undef DES_EN1_PICK
@@ -487,11 +489,16 @@ void launch_en3(des_dev *h)
                   const double *, const double *, double *, unsigned, const int *, const int *, const double *, const double *, const double *,
                   const double *, const double *, const int *, const d4 *, d4 *, d4 *, double *, double *, double *);
         const int T = h->patch_threads;
-        if (h->patch_max_inc <= 1024 && h->patch_max_pn <= 256) k = T == 512 ? EN3_force_nodes<512, 1024, 256> : EN3_force_nodes<256, 1024, 256>;
-        else if (h->patch_max_inc <= 1664 && h->patch_max_pn <= 320) k = T == 512 ? EN3_force_nodes<512, 1664, 320> : EN3_force_nodes<256, 1664, 320>;
-        else k = T == 512 ? EN3_force_nodes<512, DES_PATCH_INC, DES_PATCH_PN> : EN3_force_nodes<256, DES_PATCH_INC, DES_PATCH_PN>;
+        const bool nmd = h->p.is_using_mixed_stress && !h->iso && !h->in_pt;
+        const bool known = nmd && h->p.gravity != 0;           // the common launch has kernels of its own (passes/en3.hpp)
+#define EN3_PICK(I, P) (known ? (T == 512 ? EN3_force_nodes<512, I, P, 1> : EN3_force_nodes<256, I, P, 1>) \
+                              : (T == 512 ? EN3_force_nodes<512, I, P, 0> : EN3_force_nodes<256, I, P, 0>))
+        if (h->patch_max_inc <= 1024 && h->patch_max_pn <= 256) k = EN3_PICK(1024, 256);
+        else if (h->patch_max_inc <= 1664 && h->patch_max_pn <= 320) k = EN3_PICK(1664, 320);
+        else k = EN3_PICK(DES_PATCH_INC, DES_PATCH_PN);
+#undef EN3_PICK
         hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk,
-                           (int)(h->p.is_using_mixed_stress && !h->iso && !h->in_pt), h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb,
+                           (int)nmd, h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb,
                            h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag, h->ntmp, mat_data(h),
                            h->volume, h->dpressure, h->stress, h->ddp, h->bc_mask, h->bcn_idx, h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass,
                            h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part);

@@ -40,7 +40,8 @@ struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *s
 #define DES_PATCH_PE 1280         // elements of a patch (LDS records)
 #endif
 
-template <int THREADS, int INC, int PN, int PE, int CONSTM>
+// THERM = 1: has_thermal_diffusion known to be on (the common launch: that path only in the kernel), 0: read at run time
+template <int THREADS, int INC, int PN, int PE, int CONSTM, int THERM = 0>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 3)
 EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int ne, int b0, int c0, int b1, int c1, int do_clock, int npb,
      const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
@@ -73,7 +74,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     const int nown = min(npb, nn - n0);
     const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
     const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
-    const bool thermal = p->has_thermal_diffusion;
+    const bool thermal = THERM ? true : (bool)p->has_thermal_diffusion;
     const int nmat = p->nmat;
     // the node this lane finishes
     const int n = n0 + threadIdx.x;

@@ -31,9 +31,11 @@
 #define DES_PATCH_PN 512
 
 // (512 lanes: three workgroups per CU are 6 waves per SIMD, i.e. at most 80 VGPRs)
-template <int THREADS, int INC, int PN>
+// KNOWN = 1: the launch is the common one -- NMD_stress on, gravity on -- and the kernel holds that path only (the two flags
+// known at compile time: -2 us of 56 at 1M tets); KNOWN = 0: both read at run time.
+template <int THREADS, int INC, int PN, int KNOWN = 0>
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? 6 : 3)
-EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nmd, int o0, int nn_own_end,
+EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ clk, int nmd_arg, int o0, int nn_own_end,
      int nn, int nn_global, int ne, int nblocks, int npb,
      const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag,
@@ -59,6 +61,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
     const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
     const double gravity = p->gravity;
+    const bool nmd = KNOWN ? true : nmd_arg != 0, grav = KNOWN ? true : gravity != 0;
     const int nmat = p->nmat;
 
     // Everything below is ordered so that the global loads that do not depend on each other are in
@@ -77,7 +80,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         for (int k = 0; k < 6; ++k) E.s[k] = pl_ld(stress, k, ne, eo);
         E.vol = pl_ld(volume, 0, ne, eo);
         E.dpo = nmd ? pl_ld(dpressure, 0, ne, eo) : 0.0;
-        E.mono = gravity != 0 ? md.mono[e] : 0;
+        E.mono = grav ? md.mono[e] : 0;
     };
     // (a) this lane's first patch element: list entry, then stress / volume / dpressure (holding a
     //     second one in registers as well costs a wave of occupancy and more than it hides)
@@ -125,7 +128,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         double sx[4], sy[4], sz[4];
         desk::shape_fn(c, vol, sx, sy, sz);
         double buoy = 0;
-        if (gravity != 0) {
+        if (grav) {
             double T = 0;
             T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
             T /= 4;

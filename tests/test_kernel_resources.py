@@ -42,7 +42,7 @@ def pick(table, prefix):
     ("E2_update_stress<desk::MathPortable, 0, 1, 7>", 256, 2, 20480),   # ... with the evp law known at compile time (the headline)
     ("E2_return_mapping<desk::MathPortable, 1>", 256, 2, 20480),        # second pass
     ("EN1_mass_temperature_dvoldt<256, 1600, 296,", 168, 3, 54613),     # three workgroups per CU: LDS <= 160 KiB / 3
-    ("EN3_force_nodes<512, 1664, 320>", 80, 6, 54613),
+    ("EN3_force_nodes<512, 1664, 320,", 80, 6, 54613),
     ("EN2_nmd_gather<1664, 896>", 64, 8, 20480),
     ("k_s2", 256, 2, 1024),
     ("k_s3_finalize", 64, 8, 4096),
