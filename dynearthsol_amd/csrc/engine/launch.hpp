@@ -351,7 +351,7 @@ void launch_e2(des_dev *h, int part = PART_ALL)
             : (geo ? (defer ? E2_update_stress<desk::MathOcml, 1, 1> : E2_update_stress<desk::MathOcml, 0, 1>)
                    : (defer ? E2_update_stress<desk::MathOcml, 1, 0> : E2_update_stress<desk::MathOcml, 0, 0>));
         // the headline rheology has kernels of its own (the law known at compile time: passes/e2.hpp)
-        if (geo && h->portable_libm && h->p.rheol_type == DES_RH_EVP)
+        if (geo && h->portable_libm && h->p.rheol_type == DES_RH_EVP && h->p.is_using_mixed_stress && !h->p.is_outputting_averaged_fields)
             k = defer ? E2_update_stress<desk::MathPortable, 1, 1, DES_RH_EVP> : E2_update_stress<desk::MathPortable, 0, 1, DES_RH_EVP>;
         // with EN3 the stress-bc facet workgroups ride here (with the classic pair: in E3's launch)
         const int nbf = (h->patch && whole) ? nblk(h->nbcf) : 0;

@@ -58,8 +58,10 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     const double dt = clk->dt;
     const unsigned eo = (unsigned)e * 8u;
     const int4 cn = rec_ld(conn, e);
-    // (RH != 0: the rheology is known at compile time -- the kernel holds that law only: -2.5 us of 78 at 1M tets for evp)
+    // (RH != 0: the launch is the common one of that rheology -- NMD_stress on, no averaged output fields -- and the kernel
+    //  holds that path only: the law and the two switches known at compile time, -2.5 us of 78 at 1M tets for evp)
     const int rheol = RH ? RH : p->rheol_type;
+    const bool nmd_on = RH ? true : (bool)p->is_using_mixed_stress, averaging = RH ? false : true;
     const desk::Mix mx = mix_of(md, p->nmat, e);
     const ElemProps pr = load_props(p, md, mx, ne, e);
 
@@ -117,7 +119,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
             desk::jaumann_rate_3d(s, dtr, w3, w4, w5);
             if (!ES_DONE) desk::jaumann_rate_3d(es, dtr, w3, w4, w5);
         }
-        if (rp.stress_avg && !RM) {
+        if (averaging && rp.stress_avg && !RM) {
             // average_fields of the step this block has just finished (number clk->steps - 1: EN1 has counted on)
             const bool first = (clk->steps - 1) % rp.qcsi == 1;
             for (int i = 0; i < 6; ++i) pl_st(rp.stress_avg, i, ne, eo, first ? s[i] : pl_ld(rp.stress_avg, i, ne, eo) + s[i]);
@@ -226,7 +228,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         pl_st(volume, 0, ne, eo, vol);
     }
     if (outs) pl_st(delta_plstrain, 0, ne, eo, dpl);
-    if (rp.dplstrain_avg && rp.avg_dpl) {
+    if (averaging && rp.dplstrain_avg && rp.avg_dpl) {
         const bool first = clk->steps % rp.qcsi == 1;
         pl_st(rp.dplstrain_avg, 0, ne, eo, first ? dpl : pl_ld(rp.dplstrain_avg, 0, ne, eo) + dpl);
     }
@@ -236,7 +238,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     }
     if (!ES_EARLY && !ES_DONE && outs)
         for (int i = 0; i < 3; ++i) pl_st(strain_rate, i, ne, eo, edot[i]);   // only the diagonal changed (GEO: all six are new)
-    if (p->is_using_mixed_stress) {
+    if (nmd_on) {
         double dp = desk::trace3(s) - old_s;
         pl_st(dpressure, 0, ne, eo, dp);
         pl_st(etmp2, 0, ne, eo, dp * vol);
