@@ -521,7 +521,8 @@ __global__ void k2_edvoldt(int ne, const int *conn, const double *ntmp, double *
 // is not stored: 56 of the pass's 128 B of stores per element.  The last step of every call stores them all.
 __device__ __forceinline__ void jaumann_rate_2d(double *s, double dt, double w2);
 
-template <class M, int FUSED = 0>
+// RH != 0: the rheology is known at compile time (the kernel holds that law only).
+template <class M, int FUSED = 0, int RH = 0>
 __global__ void __launch_bounds__(DES_BLOCK)
 k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, const int *conn, const double *temperature,
           const double *props, const int *markers, double *edvoldt, double *volume, double *volume_old,
@@ -583,7 +584,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
 
     double dpls = 0.;
     int past = 0;                  // statistics only (des_scalars::n_return_mapping): reached the yield test
-    switch (p->rheol_type) {
+    switch (RH ? RH : p->rheol_type) {
     case DES_RH_ELASTIC:
         elastic2(bulkm, shearm, de, s);
         break;
@@ -1723,6 +1724,18 @@ void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr)
 {
     if (h->count_past) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
     const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? 1 : 0;
+    if (fused && h->p.rheol_type == DES_RH_EVP) {          // the common rheology has instantiations of its own
+        if (h->geo_pending)
+            L2((k2_stress<M, 2, DES_RH_EVP>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
+               h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
+               h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
+        else
+            L2((k2_stress<M, 1, DES_RH_EVP>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
+               h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
+               h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
+        h->geo_pending = false;
+        return;
+    }
     if (fused && h->geo_pending) {
         L2((k2_stress<M, 2>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
            h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
