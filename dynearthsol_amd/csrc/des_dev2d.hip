@@ -83,6 +83,7 @@ struct Engine {
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
     // node-block patch passes (des_dev2d_patch.hpp); DES2D_PATCH=0 or a mesh outside their LDS caps: the plain kernels
     bool patch = false, res_fin_pending = false, tick_pending = false;
+    bool geo_on = true, elide_on = true;       // DES2D_GEO / DES2D_ELIDE != 0 (read at create)
     bool elide = false;                        // this step's output-only element stores can go (a later step of the same call rewrites them)
     bool geo_pending = false;                  // compute_volume + rotate_stress of the last step left to the next k2_stress<M, 2>
     bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
@@ -1988,11 +1989,10 @@ void step_back(Engine *h, bool more = false)
     const int nn = h->nn, ne = h->ne;
     const bool rotate = !h->iso && (p.rheol_type & DES_RH_ELASTIC);
     const bool moved = p.has_moving_mesh || h->iso;
-    static const char *geo_env = std::getenv("DES2D_GEO");
     // the end-of-step element pass rides in the next stress update: a plain step (no compute_dt, which wants this step's
     // volumes; no averaging, which wants its rotated stress; no PT loop, which re-enters the passes)
     const bool defer = more && h->patch && moved && rotate && !p.is_outputting_averaged_fields && !p.has_PT
-                       && h->steps_host % 10 != 0 && !(geo_env && geo_env[0] == '0');
+                       && h->steps_host % 10 != 0 && h->geo_on;
     if (moved) launch_update_mesh_rest(h, h->steps_host, rotate, defer);
     if (h->iso) return;
     if (rotate && !(h->patch && moved))
@@ -2006,8 +2006,7 @@ void step_back(Engine *h, bool more = false)
 
 inline bool elide_ok(const Engine *h, bool more)
 {
-    static const char *env = std::getenv("DES2D_ELIDE");
-    return more && h->patch && !h->iso && !h->p.has_PT && !h->p.is_outputting_averaged_fields && !(env && env[0] == '0');
+    return more && h->patch && !h->iso && !h->p.has_PT && !h->p.is_outputting_averaged_fields && h->elide_on;
 }
 
 template <class M>
@@ -2139,6 +2138,8 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
         // LDS caps; runs of consecutive ids without coordinates or with DES2D_CLUSTER=0); DES2D_PATCH=<n>: n nodes per block
         const char *env = std::getenv("DES2D_PATCH");
         const char *cl = std::getenv("DES2D_CLUSTER");
+        const char *ge = std::getenv("DES2D_GEO"), *ee = std::getenv("DES2D_ELIDE");
+        h->geo_on = !(ge && ge[0] == '0'); h->elide_on = !(ee && ee[0] == '0');
         const bool cluster = !(cl && cl[0] == '0');
         Patch2 P;
         bool ok = false;

@@ -257,16 +257,19 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
     assert total >= 13
 
 
-@pytest.mark.parametrize("knob", ["0", "64", "40"])
+@pytest.mark.parametrize("knob", ["DES2D_PATCH=0", "DES2D_PATCH=64", "DES2D_PATCH=40", "DES2D_CLUSTER=0", "DES2D_GEO=0", "DES2D_ELIDE=0",
+                                  "DES2D_CLUSTER_ASPECT=1"])
 def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
     """The node-block patch passes (des_dev2d_patch.hpp: temperature + dvoldt, NMD + force, mass; the default) against the
-    one-kernel-per-loop path (DES2D_PATCH=0) and against other block sizes: every field equal, and equal to the oracle's."""
+    one-kernel-per-loop path (DES2D_PATCH=0), other block sizes and groupings, and with the end-of-step pass / the store
+    elision switched off: every field equal, and equal to the oracle's."""
     kw = dict(cfgs.EVP, nmat=2, res=1e3, qcsi=7, water="yes", control="surf_base_level = -100\nsurf_diff_ratio_marine = 0.5\n")
     with portable_libm():
         host, dev, ora = pair(kw)
-        monkeypatch.setenv("DES2D_PATCH", knob)
+        name, value = knob.split("=")
+        monkeypatch.setenv(name, value)
         other = des.DeviceEngine(host)
-        monkeypatch.delenv("DES2D_PATCH")
+        monkeypatch.delenv(name)
         other.init_from_host(host)
         for _ in range(3):
             sd, so = dev.step(23), other.step(23)
