@@ -358,6 +358,7 @@ def main():
             # of the slower first / last steps
             "steps_per_call": args.steps,
             "surface_step_in_next_steps_passes": os.environ.get("DES_S2_DEFER", "1") != "0",
+            "first_step_on_finished_state": world == 1 and os.environ.get("DES_FRESH", "1") != "0" and args.warmup > 0,
         },
     }
     if world > 1:

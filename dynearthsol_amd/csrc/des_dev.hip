@@ -194,6 +194,9 @@ struct des_dev {
     bool e2_not_last;                     // this step is not the last of its call (its end-of-step pass rides in the next stress update)
     bool e2_elide;                        // this step is not the last of its call: E2<GEO> skips the output-only stores
     bool e2geo_next;                      // the next E2 does what the skipped end-of-step pass would have done (E2<GEO>)
+    bool e2_fresh;                        // ... or: the next E2 is E2<GEO> on a finished state (engine/launch.hpp: fresh_ok)
+    bool finished;                        // the state is what the last des_dev_step call left: nothing has touched it since
+    bool fresh_on;                        // DES_FRESH != 0 (read at create)
     d4 *xt_alt;                           // the other buffer of the {x,y,z,T} pair (EN3 writes it, then they swap)
     // stress-bc lists
     int nbcf;                             // facets with a stress bc (incl. neumann)
@@ -375,6 +378,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     des_dev *h = new des_dev();       // value-initialised: every pointer/scalar member starts at 0
     h->device = device;
     h->p = *params;
+    { const char *fe = std::getenv("DES_FRESH"); h->fresh_on = !(fe && fe[0] == '0'); }
     {
         const char *gr = std::getenv("DES_GRAPH");
         h->use_graph = gr && gr[0] == '1';
@@ -789,6 +793,7 @@ static int packed_io(des_dev *h, int field, void *host, bool upload)
 
 int des_dev_upload(des_dev *h, int field, const void *host, long long count)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     D2_FORWARD(h, upload(h->d2, field, host, count));
     if (!h || !host) return DES_ERR_INTERNAL;
     if (count != des_dev_field_count(h, field)) { g_last_error = "field size mismatch"; return DES_ERR_INTERNAL; }
@@ -852,6 +857,7 @@ int des_dev_download(des_dev *h, int field, void *host, long long count)
 
 int des_dev_set_clock(des_dev *h, double dt, double time, long long steps)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     D2_FORWARD(h, set_clock(h->d2, dt, time, steps));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
@@ -870,6 +876,7 @@ int des_dev_set_clock(des_dev *h, double dt, double time, long long steps)
 // still stores dpressure and compute_mass the thermal mass, as in the reference.)
 int des_dev_set_isostasy(des_dev *h, int on)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     D2_FORWARD(h, set_isostasy(h->d2, on));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
@@ -892,6 +899,7 @@ int des_dev_sync(des_dev *h)
 
 int des_dev_init_geometry(des_dev *h)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     D2_FORWARD(h, init_geometry(h->d2));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
@@ -914,6 +922,7 @@ int des_dev_init_geometry(des_dev *h)
 
 int des_dev_compute_dt(des_dev *h, double *dt)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     D2_FORWARD(h, compute_dt(h->d2, dt));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
@@ -979,7 +988,10 @@ int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, boo
     const long long step_no = c.iso ? h->steps_host : ++h->steps_host;
     *step_no_out = step_no;
     *whole = false;
-    if (i == 0) launch_e1<MODE_A>(h);
+    const bool fresh = i == 0 && !c.iso && fresh_ok(h);
+    h->finished = false;
+    if (i == 0 && !fresh) launch_e1<MODE_A>(h);
+    h->e2_fresh = fresh;
     if (c.graphs && i < nsteps - 1 && step_no % c.qcsi != 0) {
         const int which = (step_no % 10 == 0) ? 1 : 0;
         if (!h->graph_exec[which] || h->graph_two_pass[which] != h->e2_two_pass) {
@@ -1039,7 +1051,7 @@ int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, boo
         if (split) { launch_en1(h, PART_REST); launch_e2(h, PART_REST); }
         else { if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h); launch_e2(h); }
     } else {
-        if (i > 0 && en1_ok(h)) launch_en1(h); else launch_n1(h);
+        if ((i > 0 || fresh) && en1_ok(h)) launch_en1(h); else launch_n1(h);
         launch_e2(h);
     }
     if (c.nmd) launch_n2(h);
@@ -1133,6 +1145,9 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     if (nsteps > 0) launch_mass_gather(h);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
+    // the state is now the one the reference holds after `steps` steps; the next call may start from it without the
+    // classic first step (engine/launch.hpp: fresh_ok) unless another entry point touches it first
+    if (nsteps > 0) h->finished = !c.iso && !c.multi;
     if (out) {
         if (h->comm_size > 1) {
             // l2_residual is a sum over all ranks' owned nodes
@@ -1281,6 +1296,7 @@ int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
 // control.has_PT the reference only forms the residual of the force_residual it holds; so does this.
 int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     if (!h) return DES_ERR_INTERNAL;
     D2_FORWARD(h, body_force_adjustment(h->d2, out));
     if (h->nnbr > 0 || h->group) { g_last_error = "the initial body-force adjustment's residual test is global: single domain only"; return DES_ERR_UNSUPPORTED; }
@@ -1307,6 +1323,7 @@ int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
 // ---- domain decomposition ---------------------------------------------------------
 int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     if (!h || !halo) return DES_ERR_INTERNAL;
     D2_FORWARD(h, set_halo(h->d2, halo, nnode_global));
     if (h->p.has_PT && (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn)) {
@@ -1430,6 +1447,7 @@ int des_dev_set_overlap(des_dev *h, int on)
 // between the two phases of a step); asynchronous on the engine's stream.
 int des_dev_exchange(des_dev *h)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     D2_REFUSE(h, "the RCCL communicator inside des_dev_step");
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
@@ -1441,6 +1459,7 @@ int des_dev_exchange(des_dev *h)
 // engines on one GPU.  Returns 1 after phase 1 when the compute_dt partials are ready.
 int des_dev_phase(des_dev *h, int phase)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     if (h && h->d2) {
         const int r = des2d::phase(h->d2, phase);
         if (r < 0) g_last_error = des2d::last_error(h->d2);
@@ -1515,6 +1534,7 @@ int des_dev_halo_pack(des_dev *h, int what, const int *idx, int n, double *buf)
 
 int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const double *buf)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     D2_FORWARD(h, halo_unpack(h->d2, what, idx, n, buf));
     return state_io(h, what, idx, n, const_cast<double *>(buf), false);
 }
@@ -1553,6 +1573,7 @@ int des_dev_dt_partials(des_dev *h, double out[6], int recompute)
 
 int des_dev_dt_finalize(des_dev *h, const double in[6], double *dt)
 {
+    if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     if (!h) return DES_ERR_INTERNAL;
     D2_FORWARD(h, dt_finalize(h->d2, in, dt));
     hipSetDevice(h->device);

@@ -145,6 +145,15 @@ inline bool e2geo_ok(const des_dev *h)
     return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h, true) && h->topflag;
 }
 
+// The first step of a call can start like an interior one -- EN1, then E2<GEO> with RotPending::fresh -- instead of
+// E1<A> + N1 + E2 when the state is the one the last des_dev_step call left (h->finished: no upload, clock change or
+// other entry point in between) and the fused step is available: EN1 and E2<GEO> form from the nodal records what E1<A>
+// would store for N1 / E2 to read back.  Single domain only.
+inline bool fresh_ok(const des_dev *h)
+{
+    return h->finished && h->fresh_on && h->nnbr == 0 && e2geo_ok(h) && !h->use_graph && !h->p.is_outputting_averaged_fields;
+}
+
 // The surface step (surface_processes, bc.cxx:1709-1872: S2 + S3 here) of a step can be left to the passes of the
 // NEXT step: its two launches do O(surface) work and cost ~5 us each whatever the mesh size -- 12 of a 57-us step on
 // a 137k-tet shard, 14 of 201 at 1M tets.  EN1 redoes the diffusion for the surface nodes of each patch while it
@@ -325,23 +334,24 @@ void launch_e2(des_dev *h, int part = PART_ALL)
     const d4 *const xt_now = part == PART_DEEP ? h->xt_alt : h->xt;
     // (the first step of a call in the fused flow is a classic stress update: three waves per SIMD in the first of two
     //  passes against two in one pass -- it keeps the classic rule when the mode is not pinned)
+    const bool fresh = h->e2_fresh;                        // first step of a call on a finished state (fresh_ok): E2<GEO>, nothing pending
     bool two_pass = h->e2_two_pass;
-    if (h->e2_defer == 2 && !h->e2geo_next && !h->use_graph) two_pass = h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
+    if (h->e2_defer == 2 && !h->e2geo_next && !fresh && !h->use_graph) two_pass = h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
     const bool defer = two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
-    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, nullptr, nullptr};
+    RotPending rp = {nullptr, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, nullptr, 0, 1, 0, nullptr, nullptr, nullptr, fresh ? 1 : 0};
     if (h->p.is_outputting_averaged_fields && e2geo_ok(h) && part == PART_ALL) {
         rp.dplstrain_avg = h->dplstrain_avg;
         rp.avg_dpl = h->e2_not_last ? 1 : 0;            // the last step of a call ends with E1 + k_average_fields
         rp.qcsi = (int)h->p.quality_check_step_interval;
     }
-    const bool geo = h->e2geo_next;
+    const bool geo = h->e2geo_next || fresh;
     if (h->rot_pending || geo) {
         rp.spin = h->spin; rp.topflag = h->topflag; rp.prev_dt = h->rot_prev_dt ? 1 : 0; rp.vm = h->vm;
         rp.ddp = pending_ddp(h);
         rp.outputs = (geo && h->e2_elide) ? 0 : 1;
-        if (geo && h->p.is_outputting_averaged_fields) { rp.stress_avg = h->stress_avg; rp.strain0 = h->strain0; }
+        if (geo && !fresh && h->p.is_outputting_averaged_fields) { rp.stress_avg = h->stress_avg; rp.strain0 = h->strain0; }
     }
     {
         Launch l(h, geo ? K_E2G : K_E2);
@@ -380,7 +390,7 @@ void launch_e2(des_dev *h, int part = PART_ALL)
     }
     if (whole) {                                           // (PART_DEEP is followed by PART_REST)
         if (h->rot_pending || geo) h->ddp_live = false;    // ... and has folded the pending NMD increments in
-        h->rot_pending = false; h->e2geo_next = false;
+        h->rot_pending = false; h->e2geo_next = false; h->e2_fresh = false;
     }
 }
 

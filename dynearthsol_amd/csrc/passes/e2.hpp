@@ -29,7 +29,8 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 // just done (passes/en1.hpp: SurfPending): extra workgroups behind the stress-bc facet ones.  edv_etop = 0: none.
 struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int prev_dt; const d4 *vm; int outputs;
                     double *stress_avg, *strain0, *dplstrain_avg; int avg_dpl, qcsi;
-                    int edv_etop; const int *edv_conn_surf; const double *edv_dh_n; double *edv_edvacc; };
+                    int edv_etop; const int *edv_conn_surf; const double *edv_dh_n; double *edv_edvacc;
+                    int fresh; };
 
 // GEO = 1: this pass also does what is left of the end-of-step pass of the step before AND the strain
 // rate of this step, from the nodal records it gathers anyway: compute_volume after the volume swap
@@ -39,6 +40,10 @@ struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int 
 // registers.  No E1 launch between two such steps (engine/launch.hpp: e2geo_ok); the coordinates,
 // velocities and dt it uses are the ones that pass would have seen (nothing but the temperature moves
 // in between, and steps with a compute_dt keep the fused E1).
+// RotPending::fresh = 1 (the first step of a call that follows a finished call with nothing uploaded in between,
+// engine/launch.hpp: fresh_ok): the end-of-step pass of the step before HAS run -- nothing is pending, volume[] / volume_old[]
+// hold this step's values already -- but the strain rate is still formed here from the nodal records instead of being
+// read back from an E1 launch that only exists to store it.
 // RotPending::outputs = 0 (a step of a call that is not its last one, engine/launch.hpp): what no pass reads
 // before the next E2<GEO> overwrites it -- strain_rate (recomputed from the nodal records every step),
 // viscosity, delta_plstrain, volume_old -- is not stored: 72 of the pass's 192 B of stores per element.
@@ -87,7 +92,8 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         g_vol = desk::tet_volume(c);
         double rdv = 0.0;
         g_top = rp.topflag[e] != 0;
-        if (g_top) { rdv = g_vol / vol_prev; g_vol_old = g_vol; }     // correct_surface_element stored the new volume before the swap
+        if (rp.fresh) g_vol_old = pl_ld(volume_old, 0, ne, eo);      // (the swap is done: vol_prev is this step's volume)
+        else if (g_top) { rdv = g_vol / vol_prev; g_vol_old = g_vol; }     // correct_surface_element stored the new volume before the swap
         else g_vol_old = vol_prev;
         double sx[4], sy[4], sz[4];
         desk::shape_fn(c, g_vol, sx, sy, sz);
@@ -114,7 +120,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
             for (int i = 0; i < 6; ++i) { s[i] /= rdv; if (!ES_DONE) es[i] /= rdv; }
             g_rescaled = true;
         }
-        if (rheol & DES_RH_ELASTIC) {
+        if ((rheol & DES_RH_ELASTIC) && !rp.fresh) {
             const double dtr = rp.prev_dt ? clk->dt_prev : dt;             // the dt of the step being finished
             desk::jaumann_rate_3d(s, dtr, w3, w4, w5);
             if (!ES_DONE) desk::jaumann_rate_3d(es, dtr, w3, w4, w5);
@@ -224,7 +230,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     }
     if (GEO) {
         if (g_rescaled) pl_st(plstrain, 0, ne, eo, g_pls);                 // rescaled by correct_surface_element, not changed by the law
-        if (outs) pl_st(volume_old, 0, ne, eo, g_top ? vol : pl_ld(volume, 0, ne, eo));             // (re-read rather than held in registers through the update)
+        if (outs && !rp.fresh) pl_st(volume_old, 0, ne, eo, g_top ? vol : pl_ld(volume, 0, ne, eo));             // (re-read rather than held in registers through the update)
         pl_st(volume, 0, ne, eo, vol);
     }
     if (outs) pl_st(delta_plstrain, 0, ne, eo, dpl);

@@ -130,6 +130,45 @@ def test_surface_step_left_to_the_next_steps_passes_same_bits(monkeypatch, ov):
     assert k.get("S2_surface_diffusion", 0) < k0.get("S2_surface_diffusion", 0) or "surface_process_option = 0" in ov
 
 
+@pytest.mark.parametrize("kw", ["EVP", "YIELD", "EVP2"])
+def test_first_step_of_a_call_on_a_finished_state_same_bits(monkeypatch, kw):
+    """A call that follows a finished call with nothing uploaded in between starts like an interior step -- EN1, then
+    E2<GEO> with nothing pending (engine/launch.hpp: fresh_ok) -- instead of E1<A> + N1 + E2: same bits as the DES_FRESH=0
+    engine and as the oracle after calls of any length; an upload or a clock change in between brings the classic first
+    step back; and the E1 launch is really gone."""
+    cfg = {"EVP": cfgs.EVP, "YIELD": cfgs.YIELD, "EVP2": dict(cfgs.EVP, nmat=2)}[kw]
+    host, dev, ora = pair(cfg)
+    monkeypatch.setenv("DES_FRESH", "0")
+    host2 = des.Host(cfg_text=cfgs.make(**cfg))
+    dev0 = des.DeviceEngine(host2)
+    dev0.init_from_host(host2)
+    monkeypatch.delenv("DES_FRESH")
+    dev.profile_enable(True); dev0.profile_enable(True)
+    ncalls = 0
+    for n in (3, 1, 1, 8, 12, 2, 5):
+        sd, s0, so = dev.step(n), dev0.step(n), ora.step(n)
+        ncalls += 1
+        assert (sd.dt, sd.time, sd.steps, sd.l2_residual, sd.max_surf_vel) == (s0.dt, s0.time, s0.steps, s0.l2_residual, s0.max_surf_vel)
+        assert (sd.dt, sd.time, sd.steps, sd.max_surf_vel) == (so.dt, so.time, so.steps, so.max_surf_vel)
+        assert_bit_exact(dev, dev0)
+        if kw != "YIELD":                            # (the yielding model against glibc: tests/test_gpu_parity_c_library.py)
+            assert_bit_exact(dev, ora)
+    k, k0 = (dict((name, calls) for name, _, calls in d.profile_read()) for d in (dev, dev0))
+    e1, e10 = k["E1_geom_rotate_strainrate"], k0["E1_geom_rotate_strainrate"]
+    assert e10 - e1 == ncalls - 1, (k, k0)           # one E1<A> per call but the first
+    # an upload between two calls: the next call must take the classic first step again (the uploaded field counts)
+    T = dev.download("TEMPERATURE") + 1.0
+    for eng in (dev, dev0, ora):
+        eng.upload("TEMPERATURE", T)
+    dev.step(4), dev0.step(4), ora.step(4)
+    assert_bit_exact(dev, dev0)
+    if kw != "YIELD":
+        assert_bit_exact(dev, ora)
+    k = dict((name, calls) for name, _, calls in dev.profile_read())
+    k0 = dict((name, calls) for name, _, calls in dev0.profile_read())
+    assert k0["E1_geom_rotate_strainrate"] - k["E1_geom_rotate_strainrate"] == ncalls - 1
+
+
 def test_step_splitting_is_invisible_on_the_device():
     # E1 fuses the end of step t with the start of step t+1; the API boundary must not show
     host, dev, ora = pair(cfgs.EP)
