@@ -1147,7 +1147,7 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
     // the state is now the one the reference holds after `steps` steps; the next call may start from it without the
     // classic first step (engine/launch.hpp: fresh_ok) unless another entry point touches it first
-    if (nsteps > 0) h->finished = !c.iso && !c.multi;
+    if (nsteps > 0) h->finished = !c.iso;
     if (out) {
         if (h->comm_size > 1) {
             // l2_residual is a sum over all ranks' owned nodes
@@ -1279,6 +1279,7 @@ int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
         if (nsteps > 0) launch_mass_gather(h);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
+        if (nsteps > 0) h->finished = !plan[k].iso;     // (as des_dev_step leaves it: engine/launch.hpp, fresh_ok)
         if (!out) continue;
         if ((rc = sync_clock(h))) return rc;
         choose_e2_mode(h);

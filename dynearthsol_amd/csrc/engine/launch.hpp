@@ -148,10 +148,11 @@ inline bool e2geo_ok(const des_dev *h)
 // The first step of a call can start like an interior one -- EN1, then E2<GEO> with RotPending::fresh -- instead of
 // E1<A> + N1 + E2 when the state is the one the last des_dev_step call left (h->finished: no upload, clock change or
 // other entry point in between) and the fused step is available: EN1 and E2<GEO> form from the nodal records what E1<A>
-// would store for N1 / E2 to read back.  Single domain only.
+// would store for N1 / E2 to read back.  (A decomposed mesh: the last step of a call ends in order, ghost region refreshed,
+// end-of-step pass on every local element -- the same holds.)
 inline bool fresh_ok(const des_dev *h)
 {
-    return h->finished && h->fresh_on && h->nnbr == 0 && e2geo_ok(h) && !h->use_graph && !h->p.is_outputting_averaged_fields;
+    return h->finished && h->fresh_on && e2geo_ok(h) && !h->use_graph && !h->p.is_outputting_averaged_fields;
 }
 
 // The surface step (surface_processes, bc.cxx:1709-1872: S2 + S3 here) of a step can be left to the passes of the
