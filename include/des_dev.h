@@ -79,7 +79,7 @@ int des_dev_set_isostasy(des_dev *h, int on);
 /* initial_body_force_adjustment (dynearthsol.cxx:546-591; main() calls it once before the time loop when
  * ic.has_body_force_adjustment is set, :753-761): the pseudo-transient loop of control.has_PT on the initial state,
  * apply_stress_bcs_neumann held back meanwhile (fields.cxx:690).  out (may be NULL): the scalars afterwards,
- * n_pt_iterations = the loop's iterations.  3-D, single domain. */
+ * n_pt_iterations = the loop's iterations.  Single domain. */
 int des_dev_body_force_adjustment(des_dev *h, des_scalars *out);
 
 /* Set time-step scalars: dt (Variables::dt), time, steps.  compute_dt semantics: if
@@ -99,7 +99,11 @@ int des_dev_compute_dt(des_dev *h, double *dt);
 /* Advance `nsteps` explicit time steps (dynearthsol.cxx:768-894 with PT, RSF, phase
  * changes, hydraulics, monitor and output off).  Asynchronous on the engine's stream;
  * des_dev_sync or any download waits.  `out` (may be NULL) receives the scalars after
- * the last step and forces a sync. */
+ * the last step and forces a sync.  After the call every field holds what the reference holds after that many steps
+ * (inside a multi-step call the engine leaves out stores and whole passes nothing reads; the call's last step ends
+ * with all of them).  A call that follows another one with nothing but downloads / checks in between starts like an
+ * interior step; an upload, a clock change or any other entry point that touches the state brings the full first step
+ * back.  The results do not depend on how the steps are grouped into calls. */
 int des_dev_step(des_dev *h, int nsteps, des_scalars *out);
 
 int des_dev_sync(des_dev *h);
