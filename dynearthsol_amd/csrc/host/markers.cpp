@@ -53,6 +53,40 @@ bool inside3(const double r[4])
     return r[0] >= -tolerance && r[1] >= -tolerance && r[2] >= -tolerance && (r[0] + r[1] + r[2]) <= 1 + tolerance;
 }
 
+// the same for a triangle (barycentric-fn.cxx:230-244 coefficients, 149-155 transform; is_inside :198-204)
+void bary2(const double a[2], const double b[2], const double c[2], double area, const double x[2], double eta[3])
+{
+    const double det = 2 * area;
+    double cf[3][2];
+    cf[0][0] = (b[0]*c[1] - b[1]*c[0]) / det;
+    cf[0][1] = (c[0]*a[1] - c[1]*a[0]) / det;
+    cf[1][0] = (b[1] - c[1]) / det;
+    cf[1][1] = (c[1] - a[1]) / det;
+    cf[2][0] = (c[0] - b[0]) / det;
+    cf[2][1] = (a[0] - c[0]) / det;
+    for (int k = 0; k < 2; ++k) {
+        eta[k] = cf[0][k];
+        for (int i = 0; i < 2; ++i) eta[k] += cf[i + 1][k] * x[i];
+    }
+    double tmp = 1;
+    for (int k = 0; k < 2; ++k) tmp -= eta[k];
+    eta[2] = tmp;
+}
+
+bool inside2(const double r[3])
+{
+    const double tolerance = 1e-12;
+    return r[0] >= -tolerance && r[1] >= -tolerance && (r[0] + r[1]) <= 1 + tolerance;
+}
+
+// triangle_area (geometry.cxx:77-93, !THREED)
+double tri_area(const double *a, const double *b, const double *c)
+{
+    double ab0 = b[0] - a[0], ab1 = b[1] - a[1];
+    double ac0 = c[0] - a[0], ac1 = c[1] - a[1];
+    return std::fabs(ab0*ac1 - ab1*ac0) / 2;
+}
+
 // tetrahedron_volume (geometry.cxx:36-56)
 double tet_volume(const double *a, const double *b, const double *c, const double *d)
 {
@@ -76,16 +110,20 @@ struct CentroidGrid {
     void build(const HostMesh &m, double cell)
     {
         ne = m.nelem;
-        const int nn = m.nnode;
+        const int nn = m.nnode, nd = m.nd, npe = nd + 1;
         cen.assign((size_t)3 * ne, 0.0);
         double hi[3];
         for (int d = 0; d < 3; ++d) { lo[d] = 1e300; hi[d] = -1e300; }
+        // (a 2-D mesh: {x, z} in the grid's first and last dimension, one layer of cells in between)
         for (int e = 0; e < ne; ++e)
             for (int d = 0; d < 3; ++d) {
-                // average_nodal_to_elem (utils): sum of the four nodes / 4
                 double s = 0;
-                for (int i = 0; i < 4; ++i) s += m.coord[(size_t)d*nn + m.conn[(size_t)i*ne + e]];
-                s /= 4;
+                if (nd == 3 || d != 1) {
+                    const int dm = nd == 3 ? d : (d == 0 ? 0 : 1);
+                    // average_nodal_to_elem (utils): sum of the element's nodes / their number
+                    for (int i = 0; i < npe; ++i) s += m.coord[(size_t)dm*nn + m.conn[(size_t)i*ne + e]];
+                    s /= npe;
+                }
                 cen[(size_t)d*ne + e] = s;
                 lo[d] = std::min(lo[d], s); hi[d] = std::max(hi[d], s);
             }
@@ -154,9 +192,7 @@ int initial_mattype_at(const des_params &p, const HostMesh &m, int mattype_optio
 // (:56-66) that no element is left without a marker
 void regularly_spaced_markers(const Config &cfg, const des_params &p, const HostMesh &m, HostFields &f)
 {
-    if (m.nd != 3)
-        throw Error(31, "markers.init_marker_option = 2 is built for the 3-D host only");
-    const int nn = m.nnode, ne = m.nelem, nmat = p.nmat;
+    const int nn = m.nnode, ne = m.nelem, nmat = p.nmat, nd = m.nd, npe = nd + 1;
     const int d = (int)(cfg.d("markers.init_marker_spacing") * cfg.d("mesh.resolution"));    // `const int d`, as in the reference
     if (d <= 0) throw Error(11, "markers.init_marker_spacing * mesh.resolution must be at least 1 m");
     const int mattype_option = cfg.i("ic.mattype_option");
@@ -169,15 +205,16 @@ void regularly_spaced_markers(const Config &cfg, const des_params &p, const Host
         if (!std::is_sorted(depths.begin(), depths.end()))
             throw Error(11, "Error: the content of ic.mattype_layer_depths is not ordered from small to big values.");
     }
-    double lo[3], hi[3];
-    for (int k = 0; k < 3; ++k) {
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int k = 0; k < nd; ++k) {
         lo[k] = hi[k] = m.coord[(size_t)k*nn];
         for (int i = 1; i < nn; ++i) { lo[k] = std::min(lo[k], m.coord[(size_t)k*nn + i]); hi[k] = std::max(hi[k], m.coord[(size_t)k*nn + i]); }
     }
-    const double xlength = hi[0] - lo[0], ylength = hi[1] - lo[1], zlength = hi[2] - lo[2];
-    const int nx = (int)(xlength / d + 1), ny = (int)(ylength / d + 1), nz = (int)(zlength / d + 1);
-    const double x0 = lo[0] + 0.5 * (xlength - (nx - 1) * d), y0 = lo[1] + 0.5 * (ylength - (ny - 1) * d),
-                 z0 = lo[2] + 0.5 * (zlength - (nz - 1) * d);
+    // (!THREED: ny = 1, the last coordinate is z -- markerset.cxx:577-590)
+    const double xlength = hi[0] - lo[0], ylength = nd == 3 ? hi[1] - lo[1] : 0.0, zlength = hi[nd-1] - lo[nd-1];
+    const int nx = (int)(xlength / d + 1), ny = nd == 3 ? (int)(ylength / d + 1) : 1, nz = (int)(zlength / d + 1);
+    const double x0 = lo[0] + 0.5 * (xlength - (nx - 1) * d), y0 = nd == 3 ? lo[1] + 0.5 * (ylength - (ny - 1) * d) : 0.0,
+                 z0 = lo[nd-1] + 0.5 * (zlength - (nz - 1) * d);
     const long long num_markers = (long long)nx * ny * nz;
     if (num_markers > 2000000000LL) throw Error(52, "too many markers");
 
@@ -187,31 +224,39 @@ void regularly_spaced_markers(const Config &cfg, const des_params &p, const Host
     std::vector<double> vol((size_t)ne);
     auto node = [&](int e, int i, double out[3]) {
         const int n = m.conn[(size_t)i*ne + e];
-        out[0] = m.coord[n]; out[1] = m.coord[(size_t)nn + n]; out[2] = m.coord[(size_t)2*nn + n];
+        for (int k = 0; k < nd; ++k) out[k] = m.coord[(size_t)k*nn + n];
     };
     for (int e = 0; e < ne; ++e) {
         double a[3], b[3], c[3], dd[3];
-        node(e, 0, a); node(e, 1, b); node(e, 2, c); node(e, 3, dd);
-        vol[e] = tet_volume(a, b, c, dd);
+        node(e, 0, a); node(e, 1, b); node(e, 2, c);
+        if (nd == 3) { node(e, 3, dd); vol[e] = tet_volume(a, b, c, dd); }
+        else vol[e] = tri_area(a, b, c);
     }
 
     HostMarkers &mk = f.markers;
     mk = HostMarkers();
     f.elemmarkers.assign((size_t)ne * nmat, 0);
-    std::vector<double> eta_aos;                  // [marker][4] while the count is unknown
+    std::vector<double> eta_aos;                  // [marker][npe] while the count is unknown
     std::vector<std::pair<double, int> > near;
     for (long long n = 0; n < num_markers; ++n) {
         const int ix = (int)(n % nx), iy = (int)((n / nx) % ny), iz = (int)(n / ((long long)nx * ny));
-        const double x[3] = {x0 + ix * d, y0 + iy * d, z0 + iz * d};
+        const double x[3] = {x0 + ix * d, y0 + iy * d, z0 + iz * d};         // (grid space: {x, y or 0, z})
         grid.knn(x, k, near);
         for (size_t j = 0; j < near.size(); ++j) {
             const int e = near[j].second;
             double a[3], b[3], c[3], dd[3], eta[4];
-            node(e, 0, a); node(e, 1, b); node(e, 2, c); node(e, 3, dd);
-            bary3(a, b, c, dd, vol[e], x, eta);
-            if (!inside3(eta)) continue;
+            node(e, 0, a); node(e, 1, b); node(e, 2, c);
+            if (nd == 3) {
+                node(e, 3, dd);
+                bary3(a, b, c, dd, vol[e], x, eta);
+                if (!inside3(eta)) continue;
+            } else {
+                const double x2[2] = {x[0], x[2]};
+                bary2(a, b, c, vol[e], x2, eta);
+                if (!inside2(eta)) continue;
+            }
             const int mt = initial_mattype_at(p, m, mattype_option, layer_mt, depths, e, x[2]);
-            eta_aos.insert(eta_aos.end(), eta, eta + 4);
+            eta_aos.insert(eta_aos.end(), eta, eta + npe);
             mk.elem.push_back(e); mk.mattype.push_back(mt); mk.id.push_back(mk.nmarkers);
             ++mk.nmarkers;
             ++f.elemmarkers[(size_t)e*nmat + mt];
@@ -222,8 +267,8 @@ void regularly_spaced_markers(const Config &cfg, const des_params &p, const Host
     const size_t nm = (size_t)mk.nmarkers;
     mk.last_id = mk.nmarkers;
     mk.reserved_space = (int)(num_markers * 2.0);                // over_alloc_ratio, markerset.cxx:25, 590
-    mk.eta.assign(4 * nm, 0.0);
-    for (size_t i = 0; i < nm; ++i) for (int j = 0; j < 4; ++j) mk.eta[(size_t)j*nm + i] = eta_aos[4*i + j];
+    mk.eta.assign((size_t)npe * nm, 0.0);
+    for (size_t i = 0; i < nm; ++i) for (int j = 0; j < npe; ++j) mk.eta[(size_t)j*nm + i] = eta_aos[(size_t)npe*i + j];
     mk.genesis.assign(nm, 0); mk.time.assign(nm, 0.0); mk.z.assign(nm, 0.0); mk.distance.assign(nm, 0.0); mk.slope.assign(nm, 0.0);
     for (int e = 0; e < ne; ++e) {
         int cnt = 0;

@@ -108,3 +108,32 @@ def test_regularly_spaced_markers():
     with pytest.raises(des.DesError) as e:
         des.Host(cfg_text=cfgs.make(**kw), overrides=ov.replace("init_marker_spacing = 0.2", "init_marker_spacing = 2"))
     assert e.value.code == 52
+
+
+def test_regularly_spaced_markers_2d():
+    """The same in the 2-D build (ny = 1; triangle barycentric coordinates, barycentric-fn.cxx:230-244; tolerance 1e-12)."""
+    kw = dict(cfgs.EP, lx=20e3, lz=10e3, res=2.5e3)
+    ov = ("markers.init_marker_option = 2\nmarkers.init_marker_spacing = 0.2\nmat.num_materials = 2\n"
+          "ic.mattype_option = 1\nic.num_mattype_layers = 2\nic.layer_mattypes = [0, 1]\nic.mattype_layer_depths = [0.5]\n")
+    host = des.Host(cfg_text=cfgs.make(**kw), overrides=ov, ndims=2)
+    nn, ne = host.nnode, host.nelem
+    d = int(0.2 * 2.5e3)
+    nx, nz = int(20e3 / d + 1), int(10e3 / d + 1)
+    eta = host.array("markerset.eta").reshape(3, -1)
+    elem, mt = host.array("markerset.elem"), host.array("markerset.mattype")
+    assert eta.shape[1] == nx * nz                         # a box: every grid point finds its element
+    assert np.all(eta >= -1e-12) and np.allclose(eta.sum(axis=0), 1, atol=1e-12)
+    coord = host.array("coord").reshape(2, nn)
+    conn = host.array("connectivity").reshape(3, ne)
+    pos = np.einsum("dkm,km->dm", coord[:, conn[:, elem]], eta)
+    n = np.arange(nx * nz)
+    grid = np.stack([(n % nx) * d, -10e3 + (n // nx) * d]).astype(float)
+    assert np.abs(pos - grid).max() < 1e-6                 # marker n sits on grid point n
+    assert np.array_equal(mt, np.where(grid[1] >= -5e3, 0, 1))
+    em = host.array("elemmarkers").reshape(ne, 2)
+    counts = np.zeros((ne, 2), dtype=np.int64)
+    np.add.at(counts, (elem, mt), 1)
+    assert np.array_equal(em, counts) and em.sum(axis=1).min() >= 1
+    with pytest.raises(des.DesError) as e:
+        des.Host(cfg_text=cfgs.make(**kw), overrides=ov.replace("init_marker_spacing = 0.2", "init_marker_spacing = 2"), ndims=2)
+    assert e.value.code == 52
