@@ -134,6 +134,7 @@ struct DiagBuf {
 struct des_dev {
     des2d::Engine *d2;       // a 2-D (triangle) model lives in the engine of des_dev2d.hip; everything below is then unused
     int device;
+    int n_cu;                // compute units of the device (launch shapes by size: engine/launch.hpp, e2_three_waves)
     int portable_libm;       // DES_LIBM=portable: des_libm.hpp instead of ocml in the stress update
     des_params p;
     int nn, ne, nmat;
@@ -377,6 +378,10 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     }
     des_dev *h = new des_dev();       // value-initialised: every pointer/scalar member starts at 0
     h->device = device;
+    {
+        int ncu = 0;
+        h->n_cu = (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ? ncu : 256;
+    }
     h->p = *params;
     { const char *fe = std::getenv("DES_FRESH"); h->fresh_on = !(fe && fe[0] == '0'); }
     {
@@ -1120,6 +1125,21 @@ void fill_scalars(const des_dev *h, des_scalars *out)
     out->steps = c.steps; out->status = c.status; out->n_return_mapping = c.n_defer; out->avg_time0 = c.avg_time0;
     out->n_pt_iterations = h->n_pt_iterations;
 }
+// A step that fails half-way (an RCCL or launch error in the exchange, the PT loop, a hipGraph capture) must not leave
+// the engine between two pieces of the overlapped schedule: work may still be on the side stream, and the flags that
+// tell the next step's front what the last one left to it would otherwise outlive the call -- des_dev_set_overlap
+// would refuse for ever ("inside a step"), the next des_dev_step would wait on a stale join event.  After this the
+// engine can be stepped again from uploads (the device state itself is that of an interrupted step: not a result).
+int step_abort(des_dev *h, int rc)
+{
+    hipSetDevice(h->device);
+    if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
+    hipStreamSynchronize(h->stream);
+    h->join_pending = false; h->s2_pending = false; h->edv_pending = false; h->s2_skipped = false;
+    h->e2geo_next = false; h->rot_pending = false; h->e2_fresh = false;
+    h->finished = false;
+    return rc;
+}
 } // namespace
 
 int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
@@ -1134,17 +1154,17 @@ int des_dev_step(des_dev *h, int nsteps, des_scalars *out)
     int rc;
     for (int i = 0; i < nsteps; ++i) {
         long long step_no; bool whole, do_dt;
-        if ((rc = step_front(h, c, i, &step_no, &whole))) return rc;
+        if ((rc = step_front(h, c, i, &step_no, &whole))) return step_abort(h, rc);
         if (whole) continue;
-        if (c.multi && (rc = step_overlapped(h, c) ? exchange_begin(h) : exchange(h))) return rc;
-        if ((rc = step_back(h, c, i, step_no, &do_dt))) return rc;
-        if (do_dt && (rc = reduce_dt(h))) return rc;
+        if (c.multi && (rc = step_overlapped(h, c) ? exchange_begin(h) : exchange(h))) return step_abort(h, rc);
+        if ((rc = step_back(h, c, i, step_no, &do_dt))) return step_abort(h, rc);
+        if (do_dt && (rc = reduce_dt(h))) return step_abort(h, rc);
     }
     // compute_mass gather of the last update_mesh, so that volume_n / mass / tmass hold the
     // reference's end-of-step values (inside a multi-step call it is fused into the next N1)
     if (nsteps > 0) launch_mass_gather(h);
     hipError_t le = hipGetLastError();
-    if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return DES_ERR_RESOURCE; }
+    if (le != hipSuccess) { g_last_error = std::string("kernel launch: ") + hipGetErrorString(le); return step_abort(h, DES_ERR_RESOURCE); }
     // the state is now the one the reference holds after `steps` steps; the next call may start from it without the
     // classic first step (engine/launch.hpp: fresh_ok) unless another entry point touches it first
     if (nsteps > 0) h->finished = !c.iso;
@@ -1251,6 +1271,7 @@ int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
         if (plan[k].graphs || plan[k].pgraphs || h->p.has_PT) { g_last_error = "des_dev_step_group: decomposed engines only (no hipGraph replay, no PT loop)"; return DES_ERR_UNSUPPORTED; }
     }
     int rc;
+    auto abort_all = [&](int code) { for (int k = 0; k < n; ++k) step_abort(engines[k], code); return code; };
     std::vector<long long> step_no((size_t)n);
     for (int i = 0; i < nsteps; ++i) {
         bool any_dt = false;
@@ -1258,18 +1279,18 @@ int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
             des_dev *h = engines[k];
             bool whole;
             hipSetDevice(h->device);
-            if ((rc = step_front(h, plan[k], i, &step_no[k], &whole))) return rc;
-            if (plan[k].multi && (rc = exchange_local_pack(h))) return rc;
+            if ((rc = step_front(h, plan[k], i, &step_no[k], &whole))) return abort_all(rc);
+            if (plan[k].multi && (rc = exchange_local_pack(h))) return abort_all(rc);
         }
         for (int k = 0; k < n; ++k) {                  // the messages change hands; the rest of the step
             des_dev *h = engines[k];
             bool do_dt;
             hipSetDevice(h->device);
-            if (plan[k].multi && (rc = exchange_local_take(h, step_overlapped(h, plan[k]) ? h->comm_stream : h->stream))) return rc;
-            if ((rc = step_back(h, plan[k], i, step_no[k], &do_dt))) return rc;
+            if (plan[k].multi && (rc = exchange_local_take(h, step_overlapped(h, plan[k]) ? h->comm_stream : h->stream))) return abort_all(rc);
+            if ((rc = step_back(h, plan[k], i, step_no[k], &do_dt))) return abort_all(rc);
             any_dt = any_dt || do_dt;
         }
-        if (any_dt && (rc = reduce_dt_group(engines, n))) return rc;
+        if (any_dt && (rc = reduce_dt_group(engines, n))) return abort_all(rc);
     }
     double l2sum = 0;
     int status = DES_OK;

@@ -930,7 +930,8 @@ __device__ __forceinline__ void residual_fin_block(int nb, const double *part, C
     v = desk::wave_sum(v);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) clk->l2_residual = sqrt((sm[0] + sm[1]) + (sm[2] + sm[3]));
+    // (l2_sum: the sum under the root -- on a decomposed mesh the owned nodes' share, added across ranks at the end of a call)
+    if (threadIdx.x == 0) { const double t = (sm[0] + sm[1]) + (sm[2] + sm[3]); clk->l2_sum = t; clk->l2_residual = sqrt(t); }
 }
 
 __global__ void k2_residual_fin(int nb, const double *part, Clock *clk) { residual_fin_block(nb, part, clk); }
@@ -2386,7 +2387,15 @@ int step(Engine *h, int nsteps, des_scalars *out)
             if (!h->iso && h->steps_host % 10 == 0 && (rc = dt_allreduce(h, true))) return rc;
         }
         HIP2(hipGetLastError());
-        return out ? fill_scalars(h, out) : DES_OK;
+        if (!out) return DES_OK;
+        // l2_residual is a sum over all ranks' owned nodes (des_dev.h): the partial sums are added before the root
+        HIP2(hipMemcpyAsync(h->d_red + 6, &h->d_clk->l2_sum, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        NCCL2(ncclAllReduce(h->d_red + 6, h->d_red + 6, 1, ncclDouble, ncclSum, h->comm, h->stream));
+        const int rcs = fill_scalars(h, out);
+        double l2sum = 0;
+        HIP2(hipMemcpy(&l2sum, h->d_red + 6, sizeof(double), hipMemcpyDeviceToHost));
+        out->l2_residual = std::sqrt(l2sum);
+        return rcs;
     }
     if (h->halo && nsteps > 0) {
         h->err = "a decomposed 2-D engine steps through des_dev_step (after des_dev_comm_init), des_dev_step_group, or des_dev_phase + the exchange entry points";
@@ -2651,10 +2660,13 @@ int step_group(Engine **g, int n, int nsteps, des_scalars *out)
     }
     HIP2(hipGetLastError());
     int worst = DES_OK;
+    double l2sum = 0;
     for (int k = 0; k < n; ++k) {
-        if (out) { const int rc = fill_scalars(g[k], &out[k]); if (rc && !worst) worst = rc; }
+        if (out) { const int rc = fill_scalars(g[k], &out[k]); if (rc && !worst) worst = rc; l2sum += g[k]->h_clk->l2_sum; }
         else HIP2(hipStreamSynchronize(g[k]->stream));
     }
+    // l2_residual over all ranks' owned nodes (every node counts once), as des_dev.h promises and the 3-D group does
+    if (out && n > 1) for (int k = 0; k < n; ++k) out[k].l2_residual = std::sqrt(l2sum);
     return worst;
 }
 

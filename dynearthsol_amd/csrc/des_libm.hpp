@@ -20,6 +20,11 @@
 // atan2 <= 1.5 ulp.  sin/cos use a three-term Cody-Waite reduction that is exact for
 // |x| < 2^20*pi/2 and lose accuracy (never determinism) beyond.
 //
+// Third-party notice: exp / pow below restate sysdeps/ieee754/dbl-64/e_exp.c and e_pow.c of the GNU C Library 2.35
+// (from Arm's Optimized Routines; Copyright (C) 2018-2022 Free Software Foundation, Inc., LGPL-2.1-or-later; upstream
+// Arm Optimized Routines: MIT OR Apache-2.0 WITH LLVM-exception) and regenerate their tables from the recipe those
+// sources document; that part of this file is distributed under LGPL-2.1-or-later, see THIRD_PARTY_NOTICES.md.
+//
 // Tables: tools/gen_libm_tables.py (the pow / exp tables are glibc's, recomputed from the recipe
 // its sources document; the sin / cos / atan coefficients are our own fits).
 #pragma once

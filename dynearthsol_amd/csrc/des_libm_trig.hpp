@@ -1,5 +1,12 @@
 // des_libm_trig.hpp -- sin, cos, tan, atan2 that return the bits of the C library the CPU reference runs on.
 //
+// Third-party notice: the routines below restate sysdeps/ieee754/dbl-64/s_sin.c, s_sincos.c, s_tan.c and e_atan2.c of the
+// GNU C Library 2.35 -- the IBM Accurate Mathematical Library, written by International Business Machines Corp.,
+// Copyright (C) 2001-2022 Free Software Foundation, Inc., licensed under the GNU Lesser General Public License,
+// version 2.1 or (at your option) any later version.  This file and des_libm_trig_tables.hpp are a derived work of
+// those sources and are distributed under the same licence (LGPL-2.1-or-later); see THIRD_PARTY_NOTICES.md at the
+// repository root.  No warranty; see the licence for details.
+//
 // Like exp / pow in des_libm.hpp these are NOT designs of our own: they restate, operation by operation, the
 // routines of glibc 2.35 (sysdeps/ieee754/dbl-64/s_sin.c, s_tan.c, e_atan2.c -- the IBM Accurate Mathematical
 // Library, in 2.35 without its multi-precision slow paths) in the form the C library executes on an x86-64 host
@@ -11,8 +18,8 @@
 // atan2, cos, sin); with them the device returns what the CPU build computes also for models that yield.
 //
 // Range: sin / cos for |x| < 105414350 (s_sin.c's limit of its own reduction; beyond it glibc calls __branred),
-// tan for |x| <= 25 (beyond it s_tan.c uses a longer reduction), atan2 for finite non-zero arguments whose ratio
-// needs no rescaling; des_libm.hpp falls back to its own routines outside (never reached from the stress update:
+// tan for |x| <= 1e8 (s_tan.c's own reductions, the longer one beyond 25 included; past 1e8 glibc calls __branred),
+// atan2 for finite non-zero arguments whose ratio needs no rescaling; des_libm.hpp falls back to its own routines outside (never reached from the stress update:
 // angles below pi/2, Cardano's phi in [0, pi/3]).  tests/test_libm.py sweeps them against the host's libm.
 #pragma once
 

@@ -323,6 +323,20 @@ void choose_e2_mode(des_dev *h)
 // rest around it
 enum { PART_ALL = 0, PART_DEEP = 1, PART_REST = 2 };
 
+// Launch shape of the one-pass E2<GEO> by size: the kernel runs at two waves per SIMD (2 x 4 x CUs wavefronts resident) and
+// has an instantiation held to three (passes/e2.hpp: W3).  Where the launch is a few rounds of workgroups at most, the
+// number of ROUNDS decides -- a shard whose wavefronts just overflow the two-wave residency pays a whole second round --
+// so take three waves when that saves a round; on large meshes (many rounds) two waves are as fast and spill nothing.
+// DES_E2_W3 = 0 / 1 pins the choice.
+inline bool e2_three_waves(const des_dev *h, long long nelem)
+{
+    static const char *env = std::getenv("DES_E2_W3");
+    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    const long long waves = (nelem + 63) / 64, res2 = 2LL * 4 * h->n_cu, res3 = 3LL * 4 * h->n_cu;
+    const long long r2 = (waves + res2 - 1) / res2, r3 = (waves + res3 - 1) / res3;
+    return r3 < r2 && r2 <= 4;
+}
+
 void launch_e2(des_dev *h, int part = PART_ALL)
 {
     int e_begin = 0, e_count = h->ne, e_begin2 = 0, e_count2 = 0;
@@ -338,6 +352,11 @@ void launch_e2(des_dev *h, int part = PART_ALL)
     const bool fresh = h->e2_fresh;                        // first step of a call on a finished state (fresh_ok): E2<GEO>, nothing pending
     bool two_pass = h->e2_two_pass;
     if (h->e2_defer == 2 && !h->e2geo_next && !fresh && !h->use_graph) two_pass = h->h_clk->n_defer <= DES_E2_DEFER_MAX * h->ne;
+    // The two parts of the overlapped schedule run ONE pass, whatever DES_E2_DEFER pins: both would append to the same
+    // defer_list / DevClock::n_defer (only EN1's clock lane resets the count, once per step), so the return-mapping launch
+    // behind PART_REST would walk the deep part's entries a second time -- and e2_element<RM = 1> is not idempotent (it
+    // re-reads the stress it has stored).  One pass gives the same bits and keeps the count (n_return_mapping) right.
+    if (part != PART_ALL) two_pass = false;
     const bool defer = two_pass && (h->p.rheol_type == DES_RH_EP || h->p.rheol_type == DES_RH_EVP);
     int *count = &h->d_clk->n_defer;
     // the rotation (and NMD increment) the fused E1<MODE_DEFER> of the step before left for this pass
@@ -364,6 +383,13 @@ void launch_e2(des_dev *h, int part = PART_ALL)
         // the headline rheology has kernels of its own (the law known at compile time: passes/e2.hpp)
         if (geo && h->portable_libm && h->p.rheol_type == DES_RH_EVP && h->p.is_using_mixed_stress && !h->p.is_outputting_averaged_fields)
             k = defer ? E2_update_stress<desk::MathPortable, 1, 1, DES_RH_EVP> : E2_update_stress<desk::MathPortable, 0, 1, DES_RH_EVP>;
+        // ... and the one-pass E2<GEO> a three-wave shape for launches that it saves a round of workgroups (e2_three_waves)
+        if (geo && !defer && h->portable_libm && e2_three_waves(h, e_count + e_count2)) {
+            if (h->p.rheol_type == DES_RH_EVP && h->p.is_using_mixed_stress && !h->p.is_outputting_averaged_fields)
+                k = E2_update_stress<desk::MathPortable, 0, 1, DES_RH_EVP, 1>;
+            else
+                k = E2_update_stress<desk::MathPortable, 0, 1, 0, 1>;
+        }
         // with EN3 the stress-bc facet workgroups ride here (with the classic pair: in E3's launch)
         const int nbf = (h->patch && whole) ? nblk(h->nbcf) : 0;
         // ... and so does the edvacc_surf update of a surface step EN1 has just done for the step before (s2_defer_ok)

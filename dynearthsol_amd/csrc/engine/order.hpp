@@ -81,13 +81,17 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
         spread(dhi, oe, nn);
     }
     pm.n_deep0 = ob; pm.n_deep1 = oe;
+    // (one domain: no groups -- the keys are the full 63-bit Morton codes; the group prefix, which costs the two or three
+    //  finest bits, is only there when the mesh is a slab of a decomposed one)
+    const bool cut = ob > 0 || oe < nn;
     {
         std::vector<std::pair<unsigned long long, int> > key((size_t)nn);
         for (int n = 0; n < nn; ++n) {
             // owned nodes: near the low cut, deep, near the high cut -- Morton order inside each group
             unsigned long long grp = 0;
             if (n >= ob && n < oe) grp = dlo[n] < DES_DEEP_DIST ? 0 : (dhi[n] < DES_DEEP_DIST ? 2 : 1);
-            key[n] = std::make_pair(grp << 62 | code(X[n], X[(size_t)nn + n], X[(size_t)2*nn + n]) >> 2, n);
+            const unsigned long long mc = code(X[n], X[(size_t)nn + n], X[(size_t)2*nn + n]);
+            key[n] = std::make_pair(cut ? (grp << 62 | mc >> 2) : mc, n);
         }
         // ... inside each of the three id ranges (the pairs break ties by caller id)
         std::sort(key.begin(), key.begin() + ob);
@@ -95,7 +99,7 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
         std::sort(key.begin() + oe, key.end());
         pm.n_new2old.resize((size_t)nn); pm.n_old2new.resize((size_t)nn);
         for (int i = 0; i < nn; ++i) { pm.n_new2old[i] = key[i].second; pm.n_old2new[key[i].second] = i; }
-        for (int i = ob; i < oe; ++i) {
+        for (int i = ob; cut && i < oe; ++i) {
             const unsigned long long grp = key[i].first >> 62;
             if (grp == 0) pm.n_deep0 = i + 1;
             if (grp == 2) { pm.n_deep1 = i; break; }
@@ -114,7 +118,7 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
             }
             // groups: 0 touches the low ghost range, 1 owned but not deep (low side), 2 deep, 3 owned but not deep (high
             // side), 4 touches the high ghost range
-            const bool cut = ob > 0 || oe < nn;            // (one domain: every element is deep, the order is the plain Morton one)
+            // (one domain: every element is deep, the order is the plain Morton one)
             const int d0 = cut ? pm.n_deep0 + DES_DEEP_MARGIN : 0, d1 = cut ? pm.n_deep1 - DES_DEEP_MARGIN : nn;
             bool deep = true, lowside = false;
             for (int i = 0; i < 4; ++i) {
@@ -124,12 +128,13 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
             }
             grp = deep ? 2 : (lowside ? 1 : 3);
             if (touches_lo) grp = 0; else if (touches_hi) grp = 4;
-            key[e] = std::make_pair(grp << 61 | code(c[0], c[1], c[2]) >> 3, e);      // group, then Morton
+            const unsigned long long mc = code(c[0], c[1], c[2]);
+            key[e] = std::make_pair(cut ? (grp << 61 | mc >> 3) : mc, e);             // group, then Morton
         }
         std::sort(key.begin(), key.end());
         pm.e_int0 = 0; pm.e_int1 = ne; pm.e_deep0 = 0; pm.e_deep1 = ne;
         bool seen_deep = false;
-        for (int i = 0; i < ne; ++i) {
+        for (int i = 0; cut && i < ne; ++i) {
             const unsigned long long grp = key[i].first >> 61;
             if (grp == 0) pm.e_int0 = i + 1;
             if (grp <= 1) pm.e_deep0 = i + 1;
@@ -137,7 +142,7 @@ void build_perm_mesh(const des_mesh *in, PermMesh &pm)
             if (grp >= 3 && pm.e_deep1 == ne) pm.e_deep1 = i;
             if (grp == 4) { pm.e_int1 = i; break; }
         }
-        if (!seen_deep) pm.e_deep1 = pm.e_deep0;
+        if (cut && !seen_deep) pm.e_deep1 = pm.e_deep0;
         pm.e_new2old.resize((size_t)ne); pm.e_old2new.resize((size_t)ne);
         for (int i = 0; i < ne; ++i) { pm.e_new2old[i] = key[i].second; pm.e_old2new[key[i].second] = i; }
     }

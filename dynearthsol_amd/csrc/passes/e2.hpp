@@ -260,8 +260,12 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
 #ifndef DES_E2GEO_WAVES
 #define DES_E2GEO_WAVES DES_E2_WAVES
 #endif
-template <class M, int DEFER, int GEO, int RH = 0>
-__global__ void __launch_bounds__(DES_BLOCK, DEFER ? (GEO ? DES_E2GEO_WAVES : DES_E2_WAVES_FAST) : DES_E2_WAVES)
+// W3 = 1: the same kernel held to three waves per SIMD (168 VGPRs, a few dozen bytes of scratch).  At 1M tets that is
+// no faster than two (the pass is not short of waves), but a SHARD of a strong-scaling run can be: 152,589 local tets
+// are 2,385 wavefronts against 2,048 resident at two per SIMD -- a second, nearly empty round of workgroups -- and
+// 3,072 at three: one round.  engine/launch.hpp (e2_three_waves) picks by the launch's wavefront count.
+template <class M, int DEFER, int GEO, int RH = 0, int W3 = 0>
+__global__ void __launch_bounds__(DES_BLOCK, W3 ? 3 : (DEFER ? (GEO ? DES_E2GEO_WAVES : DES_E2_WAVES_FAST) : DES_E2_WAVES))
 E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, int e_begin, int e_count, int e_begin2, int e_count2, int nblocks, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData md,

@@ -36,6 +36,9 @@ struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *s
 #ifndef DES_EN1_NB
 #define DES_EN1_NB 8              // incidences per batch of LDS requests in the node phase
 #endif
+#ifndef DES_EN1_SPLIT
+#define DES_EN1_SPLIT 1           // the node phase on three wavefronts, one group of sums each (0: one lane per node does all five)
+#endif
 #ifndef DES_PATCH_PE
 #define DES_PATCH_PE 1280         // elements of a patch (LDS records)
 #endif
@@ -76,9 +79,17 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
     const bool thermal = THERM ? true : (bool)p->has_thermal_diffusion;
     const int nmat = p->nmat;
-    // the node this lane finishes
-    const int n = n0 + threadIdx.x;
-    const bool has_node = (int)threadIdx.x < nown;
+    // the node this lane works for.  DES_EN1_SPLIT (blocks of up to 64 nodes): lane l of EVERY wavefront belongs to node
+    // n0 + l, and the node's independent sums go to different wavefronts (node phase below); otherwise lane t < nown alone.
+#if DES_EN1_SPLIT
+    const bool split = npb <= 64;
+#else
+    const bool split = false;
+#endif
+    const int nl = split ? (int)(threadIdx.x & 63) : (int)threadIdx.x;         // node of the block
+    const int part = split ? (int)(threadIdx.x >> 6) : 0;                      // which sums (split), else all
+    const int n = n0 + nl;
+    const bool has_node = nl < nown && part < 3;
     int r0 = 0, r1 = 0;
     unsigned flag = 0;
     if (has_node) {
@@ -161,14 +172,80 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     }
     __syncthreads();
     if (!has_node) return;
-    // the node: sums in CSR order (compute_mass / update_temperature / compute_dvoldt node loops)
     const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
     const double rho_m = p->bulk_modulus[0] / (pseudo_speed * pseudo_speed);
+    constexpr int NB = DES_EN1_NB;
+#if DES_EN1_SPLIT
+    if (split) {
+        // The node's five sums are independent of each other and each keeps its own CSR order -- the reference's
+        // association, the same bits -- whichever lane forms it: wavefront 0 takes {volume_n, dvoldt}, wavefront 1 the
+        // inertial mass, wavefront 2 {thermal mass, conduction}, each with one index + at most two terms per incidence
+        // instead of one lane walking index + five terms (64 of 256 lanes busy); every wavefront stores what its sums
+        // complete, so nothing has to change hands.
+        if (part == 0) {
+            double vn = 0, acc = 0;
+            int k = r0;
+            for (; k + NB <= r1; k += NB) {
+                int q[NB]; double a[NB], b[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) q[u] = lidx[k + u];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { a[u] = lvol[q[u]]; b[u] = ldv[q[u]]; }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { vn += a[u]; acc += b[u]; }
+            }
+            for (; k < r1; ++k) { const int q = lidx[k]; vn += lvol[q]; acc += ldv[q]; }
+            volume_n[n] = vn;
+            ntmp[n] = acc / vn;
+        } else if (part == 1) {
+            double ms = 0;
+            int k = r0;
+            for (; k + NB <= r1; k += NB) {
+                int q[NB]; double a[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) q[u] = lidx[k + u];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) a[u] = CONSTM ? lvol[q[u]] : lm[q[u]];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { if (CONSTM) ms += rho_m * a[u] / 4; else ms += a[u]; }
+            }
+            for (; k < r1; ++k) { const int q = lidx[k]; if (CONSTM) ms += rho_m * lvol[q] / 4; else ms += lm[q]; }
+            d4 m4;                                               // the velocity is the staged one (own node: local id nl)
+            m4.x = lvx[nl]; m4.y = lvy[nl]; m4.z = lvz[nl]; m4.w = ms;
+            vm[n] = m4;
+        } else {
+            double tms = 0, tdot = 0;
+            if (thermal) {
+                int k = r0;
+                for (; k + NB <= r1; k += NB) {
+                    int q[NB]; double a[NB], b[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) q[u] = lidx[k + u];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) { a[u] = ltm[q[u]]; b[u] = ltd[k + u]; }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) { tms += a[u]; tdot += b[u]; }
+                }
+                for (; k < r1; ++k) { tms += ltm[lidx[k]]; tdot += ltd[k]; }
+            }
+            tmass[n] = tms;
+            d4 x4 = lxt[nl];
+            if (thermal) {
+                if (flag & (1u << 5))
+                    x4.w = p->surface_temperature;
+                else
+                    x4.w -= dt * tdot / tms;
+            }
+            xt_out[n] = x4;
+        }
+        return;
+    }
+#endif
+    // the node: sums in CSR order (compute_mass / update_temperature / compute_dvoldt node loops)
     double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0;
     // DES_EN1_NB incidences at a time: their indices, then every term they point at, are requested from LDS
     // before the first is used (one lane walks its list alone; a dependent look-up per incidence made this
     // phase a third of the workgroup's life); the sums themselves stay in list order
-    constexpr int NB = DES_EN1_NB;
     int k = r0;
     for (; k + NB <= r1; k += NB) {
         int q[NB];

@@ -29,6 +29,9 @@
 // picks the smallest that holds the mesh's largest block (engine/launch.hpp, launch_en3).
 #define DES_PATCH_INC 2048        // caps of the largest shape = what build_patches() accepts
 #define DES_PATCH_PN 512
+#ifndef DES_EN3_SPLIT
+#define DES_EN3_SPLIT 1           // the three force sums of a node on three wavefronts (0: the node's lane forms all three)
+#endif
 
 // (512 lanes: three workgroups per CU are 6 waves per SIMD, i.e. at most 80 VGPRs)
 // KNOWN = 1: the launch is the common one -- NMD_stress on, gravity on -- and the kernel holds that path only (the two flags
@@ -87,16 +90,25 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     Elem E0;
     const int i0 = e_begin + threadIdx.x, i1 = i0 + THREADS;
     if (i0 < e_end) load_elem(i0, E0);
-    // (b) the node this lane will finish: its CSR segment and its records
+    // (b) the node this lane will finish: its CSR segment and its records.  DES_EN3_SPLIT (blocks of up to 64 nodes):
+    //     lane l of the first three wavefronts sums ONE force component of node n0 + l (below), so those lanes need the
+    //     segment too; the first wavefront's lanes finish the nodes as before.
+#if DES_EN3_SPLIT
+    const bool split = npb <= 64;
+#else
+    const bool split = false;
+#endif
     const int n = n0 + threadIdx.x;
     const bool has_node = (int)threadIdx.x < nown;
+    const int nl = split ? (int)(threadIdx.x & 63) : (int)threadIdx.x, part = split ? (int)(threadIdx.x >> 6) : 0;
+    const bool sums = nl < nown && part < 3;
     int r0 = 0, r1 = 0;
     unsigned flag = 0;
-    if (has_node) {
+    if (sums) {
         const int kb = sup_idx[n0];
-        r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
-        flag = bcflag[n];
+        r0 = sup_idx[n0 + nl] - kb; r1 = sup_idx[n0 + nl + 1] - kb;
     }
+    if (has_node) flag = bcflag[n];
     // (c) the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
         int id = j < nown ? n0 + j : (pn_id[h0 + j - nown] & 0x7fffffff);      // (bit 31: a surface node, for EN1)
@@ -156,6 +168,51 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
 
     // the block's nodes: force sums in CSR order, then the rest of the nodal update
     double l2 = 0.0;
+#if DES_EN3_SPLIT
+    if (split) {
+        // The three components of a node's force are independent sums over the same CSR segment: wavefront c forms
+        // component c for the block's 64 nodes -- each sum in list order, the reference's association (fields.cxx:667-675),
+        // the same bits -- instead of one wavefront of eight walking all three.  The sum goes back into the FIRST slot of
+        // the segment it was formed from (no other lane reads that segment; the last slot still holds the term
+        // force_residual is assigned, fields.cxx:673); a segment of one slot is left alone and finished below.
+        d4 m4;
+        if (has_node) m4 = vm[n];                           // {vx,vy,vz,mass}: requested behind the element phase (see below)
+        if (sums) {
+            double *L = lf[part];
+            double f = 0;
+            int k = r0;
+            for (; k + 8 <= r1; k += 8) {                   // eight slots requested from LDS before the first is used
+                double t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = L[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f -= t[u];
+            }
+            for (; k + 4 <= r1; k += 4) {
+                double t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = L[k + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) f -= t[u];
+            }
+            for (; k < r1; ++k) f -= L[k];
+            if (r1 - r0 >= 2) L[r0] = f;
+        }
+        __syncthreads();
+        if (has_node) {
+            double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
+            if (r1 - r0 >= 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { f[c] = lf[c][r0]; fr[c] = lf[c][r1 - 1]; }
+            } else if (r1 - r0 == 1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const double tv = lf[c][r0]; f[c] -= tv; fr[c] = tv; }
+            }
+            l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
+                                coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres);
+        }
+    } else
+#endif
     if (has_node) {
         // {vx,vy,vz,mass}: requested here, behind the force sums, not ahead of the element phase -- held across it
         // the record went to scratch (at 80 VGPRs), 24 MB of stores per launch for 2901 workgroups

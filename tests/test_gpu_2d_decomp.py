@@ -34,6 +34,8 @@ def _compare(group, ref, calls, phased=False):
         else:
             for s in group.step(n):
                 assert (s.dt, s.time, s.steps, s.status) == (sref.dt, sref.time, sref.steps, 0)
+                # over ALL ranks' owned nodes (des_dev.h), the same on every rank; summed over other blocks than one engine's
+                assert abs(s.l2_residual - sref.l2_residual) <= 1e-12 * sref.l2_residual
         for f, c in NODE_FIELDS:
             assert np.array_equal(group.download(f, c, "node"), ref.download(f)), f
         for f, c in ELEM_FIELDS:

@@ -101,6 +101,32 @@ def test_headline_mesh_overlapped_schedule_across_real_neighbours(monkeypatch, n
 
 
 @pytest.mark.skipif(OBLIQUE_MESH is None, reason="data/oblique-rift-3d-1250.desmesh.xz is missing")
+def test_overlapped_schedule_with_the_two_pass_stress_update_pinned(monkeypatch):
+    """DES_OVERLAP=1 together with DES_E2_DEFER=1 (the stress update pinned to two passes, also on the fused step) on a
+    model that yields: the deep and the rest part of the overlapped schedule share one list of set-aside elements, so
+    a return-mapping launch per part would work the deep part's entries off twice (round-3 advisor finding).  The split
+    parts run one pass; the result must be the single engine's (default mode), return-mapping counts included."""
+    host = des.Host(cfg_text=cfgs.OBLIQUE, overrides="mesh.resolution = 1250\n", mesh_file=OBLIQUE_MESH)
+    ref = des.DeviceEngine(host)
+    dt_ref = ref.init_from_host(host)
+    monkeypatch.setenv("DES_OVERLAP", "1")
+    monkeypatch.setenv("DES_E2_DEFER", "1")
+    group = DeviceGroup(host, 2)
+    monkeypatch.delenv("DES_OVERLAP")
+    monkeypatch.delenv("DES_E2_DEFER")
+    try:
+        assert all(e.comm_info()["overlapped"] for e in group.engines)
+        assert group.init_from_host() == dt_ref
+        kern = _compare(group, ref, (250, 150))
+        for k in kern:      # the deep / rest split really ran (two launches of each pass on the plain fused steps)
+            assert k.get("EN1_mass_temperature_dvoldt", 0) > 500, k
+        n_yield = int((ref.download("PLSTRAIN") > host.array("plstrain")).sum())
+        assert n_yield > 0
+    finally:
+        group.close()
+
+
+@pytest.mark.skipif(OBLIQUE_MESH is None, reason="data/oblique-rift-3d-1250.desmesh.xz is missing")
 def test_oblique_rift_resolution_scaled_8_ways_1000_steps():
     """examples/oblique-rift-3d.cfg (Mohr-Coulomb weak zone, two materials, vbc type 6, PREM reference
     pressure) on the reference's TetGen mesh of its box at resolution = 1250 m instead of 5000: 8 slabs

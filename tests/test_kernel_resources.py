@@ -35,11 +35,11 @@ def pick(table, prefix):
 
 
 @pytest.mark.parametrize("kernel,max_vgpr,min_waves,max_lds", [
-    ("E2_update_stress<desk::MathPortable, 1, 1, 0>", 256, 2, 20480),   # E2<GEO>, first pass of two
-    ("E2_update_stress<desk::MathOcml, 1, 1, 0>", 256, 2, 0),
-    ("E2_update_stress<desk::MathPortable, 1, 0, 0>", 168, 3, 20480),   # first step of a call
-    ("E2_update_stress<desk::MathPortable, 0, 1, 0>", 256, 2, 20480),   # one pass (return mapping inline): the fused step's mode
-    ("E2_update_stress<desk::MathPortable, 0, 1, 7>", 256, 2, 20480),   # ... with the evp law known at compile time (the headline)
+    ("E2_update_stress<desk::MathPortable, 1, 1, 0, 0>", 256, 2, 20480),   # E2<GEO>, first pass of two
+    ("E2_update_stress<desk::MathOcml, 1, 1, 0, 0>", 256, 2, 0),
+    ("E2_update_stress<desk::MathPortable, 1, 0, 0, 0>", 168, 3, 20480),   # first step of a call
+    ("E2_update_stress<desk::MathPortable, 0, 1, 0, 0>", 256, 2, 20480),   # one pass (return mapping inline): the fused step's mode
+    ("E2_update_stress<desk::MathPortable, 0, 1, 7, 0>", 256, 2, 20480),   # ... with the evp law known at compile time (the headline)
     ("E2_return_mapping<desk::MathPortable, 1>", 256, 2, 20480),        # second pass
     ("EN1_mass_temperature_dvoldt<256, 1600, 296,", 168, 3, 54613),     # three workgroups per CU: LDS <= 160 KiB / 3
     ("EN3_force_nodes<512, 1664, 320,", 80, 6, 54613),
@@ -52,3 +52,11 @@ def test_hot_kernels_stay_scratch_free_and_inside_their_budgets(table, kernel, m
     r = pick(table, kernel)
     assert r["scratch"] == 0, r
     assert r["vgpr"] <= max_vgpr and r["waves"] >= min_waves and r["lds"] <= max_lds, r
+
+
+@pytest.mark.parametrize("kernel", ["E2_update_stress<desk::MathPortable, 0, 1, 7, 1>", "E2_update_stress<desk::MathPortable, 0, 1, 0, 1>"])
+def test_three_wave_shape_of_the_fused_stress_update(table, kernel):
+    """E2<GEO> held to three waves per SIMD for launches that it saves a round of workgroups (a strong-scaling shard,
+    engine/launch.hpp: e2_three_waves): 168 VGPRs at the price of a few dozen bytes of scratch per lane -- bounded here."""
+    r = pick(table, kernel)
+    assert r["vgpr"] <= 168 and r["waves"] >= 3 and r["scratch"] <= 48, r
