@@ -491,6 +491,24 @@ class DeviceEngine(EngineBase):
         if rc:
             raise DesError(rc, self._lib.des_dev_last_error().decode())
 
+    def comm_selfcheck(self, world):
+        """des_dev_comm_selfcheck: rank count, the exchange's own messages filled with a verifiable pattern, the three
+        reductions -- collective, before the first step; raises DesError naming what failed"""
+        self._lib.des_dev_comm_selfcheck.argtypes = [C.c_void_p, C.c_int]
+        self._check(self._lib.des_dev_comm_selfcheck(self._h, int(world)), "comm_selfcheck")
+
+
+def config_string():
+    """the engine's environment switches that are set in this process and that the library has read so far
+    (des_dev_config_string): 'NAME=value NAME=value', '' when every switch is at its default"""
+    lib = load_hip_lib()
+    lib.des_dev_config_string.argtypes = [C.c_char_p, C.c_int]
+    lib.des_dev_config_string.restype = C.c_int
+    n = lib.des_dev_config_string(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.des_dev_config_string(buf, n + 1)
+    return buf.value.decode()
+
 
 __all__ = ["Host", "DeviceEngine", "reference_mesh", "EngineBase", "DesError", "DesParams", "DesMesh", "DesScalars",
-           "F", "FIELDS", "load_host_lib", "load_hip_lib", "bind_engine_api"]
+           "F", "FIELDS", "load_host_lib", "load_hip_lib", "bind_engine_api", "config_string"]

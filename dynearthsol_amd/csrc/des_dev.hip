@@ -42,6 +42,8 @@
 
 #include "des_dev.h"
 #include "des_dev2d.hpp"
+#include "engine/env.hpp"
+#include "engine/selfcheck.hpp"
 #define DES_LIBM_LDS_TABLES 1     // kernels that call deslibm:: stage its tables in LDS first
 #define DES_LIBM_LDS_WAVES 4      // = DES_BLOCK / 64, one private copy per wavefront
 #include "des_kernels.hpp"
@@ -383,20 +385,20 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         h->n_cu = (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ? ncu : 256;
     }
     h->p = *params;
-    { const char *fe = std::getenv("DES_FRESH"); h->fresh_on = !(fe && fe[0] == '0'); }
+    { const char *fe = des_env::get("DES_FRESH"); h->fresh_on = !(fe && fe[0] == '0'); }
     {
-        const char *gr = std::getenv("DES_GRAPH");
+        const char *gr = des_env::get("DES_GRAPH");
         h->use_graph = gr && gr[0] == '1';
-        const char *ov = std::getenv("DES_OVERLAP");
+        const char *ov = des_env::get("DES_OVERLAP");
         h->overlap = ov && ov[0] == '1';
-        const char *e2d = std::getenv("DES_E2_DEFER");
+        const char *e2d = des_env::get("DES_E2_DEFER");
         h->e2_defer = (e2d && (e2d[0] == '0' || e2d[0] == '1')) ? e2d[0] - '0' : 2;
         h->e2_two_pass = h->e2_defer != 0;
         // Default: des_libm.hpp, whose pow / exp return the bits of the C library the CPU reference
         // runs on (glibc, x86-64 with FMA) -- a model that does not yield then equals the CPU run
         // bit for bit (tests/test_gpu_headline.py).  DES_LIBM=ocml: ROCm's device libm, 1-2 ulp
         // away per call and ~2 % faster per step (E2 74 vs 81 us at 1M tets).
-        const char *env = std::getenv("DES_LIBM");
+        const char *env = des_env::get("DES_LIBM");
         h->portable_libm = !env || std::strcmp(env, "portable") == 0;
         if (env && !h->portable_libm && std::strcmp(env, "ocml") != 0) {
             *err = DES_ERR_CONFIG_VALUE; g_last_error = "DES_LIBM must be 'ocml' or 'portable'"; delete h; return nullptr;
@@ -404,7 +406,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     }
     PermMesh pm;
     {
-        const char *env = std::getenv("DES_REORDER");
+        const char *env = des_env::get("DES_REORDER");
         if (mesh->coord && mesh->nnode > 0 && mesh->nelem > 0 && !(env && env[0] == '0')) {
             build_perm_mesh(mesh, pm);
             h->n_new2old.swap(pm.n_new2old); h->n_old2new.swap(pm.n_old2new);
@@ -478,7 +480,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     // node-block patches for EN3 (DES_PATCH=0: the classic pair E3 + N3); blocks of 64 nodes, or 32
     // where a block of 64 would not fit the kernel's LDS slots
     {
-        const char *env = std::getenv("DES_PATCH");
+        const char *env = des_env::get("DES_PATCH");
         h->patch = false;
         if (!(env && env[0] == '0')) {
             PatchLists P;
@@ -499,13 +501,13 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             }
             if (h->patch) {
                 h->patch_npb = P.npb; h->patch_nb = P.nb; h->patch_max_inc = P.max_inc; h->patch_max_pn = P.max_pn; h->patch_max_pe = P.max_pe;
-                if (std::getenv("DES_PATCH_VERBOSE"))
+                if (des_env::get("DES_PATCH_VERBOSE"))
                     std::fprintf(stderr, "patches: %d nodes per block, %d blocks, max incidences %d, patch nodes %d, patch elements %d, "
                                  "elements listed %zu (%.2f x nelem)\n", P.npb, P.nb, P.max_inc, P.max_pn, P.max_pe, P.pe_elem.size(),
                                  (double)P.pe_elem.size() / ne);
-                const char *pn1 = std::getenv("DES_PATCH_N1");
+                const char *pn1 = des_env::get("DES_PATCH_N1");
                 h->patch_n1 = !(pn1 && pn1[0] == '0') && P.max_pe <= DES_PATCH_PE;
-                const char *pt = std::getenv("DES_PATCH_THREADS");
+                const char *pt = des_env::get("DES_PATCH_THREADS");
                 h->patch_threads = (pt && std::atoi(pt) == 256) ? 256 : 512;
                 CK(dev_alloc(h->pe_ptr, P.pe_ptr.size())); CK(dev_upload(h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size(), h->stream));
                 CK(dev_alloc(h->pe_pack, P.pe_pack.size())); CK(dev_upload(h->pe_pack, P.pe_pack.data(), P.pe_pack.size(), h->stream));
@@ -545,11 +547,11 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->defer_list, (size_t)ne));
     {
         // deferred rotate_stress (MODE_DEFER, passes/e1.hpp): on by default, DES_DEFER_ROT=0 keeps rotate_stress in E1
-        const char *el = std::getenv("DES_E2_ELIDE");      // =0: every step stores every field
+        const char *el = des_env::get("DES_E2_ELIDE");      // =0: every step stores every field
         h->elide_ok = !(el && el[0] == '0');
-        const char *sd = std::getenv("DES_S2_DEFER");      // =0: every step launches its own S2 / S3
+        const char *sd = des_env::get("DES_S2_DEFER");      // =0: every step launches its own S2 / S3
         h->s2_defer = !(sd && sd[0] == '0');
-        const char *dr = std::getenv("DES_DEFER_ROT");
+        const char *dr = des_env::get("DES_DEFER_ROT");
         h->defer_rot = !(dr && dr[0] == '0');
         if (h->defer_rot) { CK(dev_alloc(h->spin, (size_t)3*ne)); HK(hipMemsetAsync(h->spin, 0, 24*(size_t)ne, h->stream)); }
     }
@@ -560,7 +562,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     }
     if (params->rheol_type == DES_RH_EP || params->rheol_type == DES_RH_EVP) {
         // plastic_props outside the linear weakening range, by (material, marker count, regime): DES_PPTAB=0 switches it off
-        const char *pp = std::getenv("DES_PPTAB");
+        const char *pp = des_env::get("DES_PPTAB");
         if (!(pp && pp[0] == '0')) {
             const int n = nmat * DES_PPTAB_CNT * 3;
             CK(dev_alloc(h->pptab, (size_t)n * 5));
@@ -1436,6 +1438,37 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
     return DES_OK;
 }
 
+// Start-up self-check of the attached communicator (engine/selfcheck.hpp): rank count, the exchange's own messages
+// with a pattern the receiver can verify, the three reductions.  Collective: every rank calls it, before the first step.
+int des_dev_comm_selfcheck(des_dev *h, int expect_world)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    hipSetDevice(h->device);
+    if (h->d2) {
+        const int rc2 = des2d::comm_selfcheck(h->d2, expect_world, h->comm_rank);
+        if (rc2) g_last_error = des2d::last_error(h->d2);
+        return rc2;
+    }
+    HIP_OK(hipStreamSynchronize(h->stream));
+    const std::string bad = des_selfcheck::run(h->comm, h->stream, expect_world, h->comm_rank, h->nnbr, h->nbr_rank.data(),
+                                               h->send_off.data(), h->recv_off.data(), h->d_sendbuf, h->d_recvbuf, h->d_red);
+    if (!bad.empty()) { g_last_error = "RCCL self-check, rank " + std::to_string(h->comm_rank) + ": " + bad; return DES_ERR_RESOURCE; }
+    return DES_OK;
+}
+
+// The engine's environment switches that are SET in this process, as far as the library has read them (engine/env.hpp):
+// "NAME=value NAME=value", NUL-terminated, cut to len - 1 characters; returns the full length.
+int des_dev_config_string(char *buf, int len)
+{
+    const std::string s = des_env::summary();
+    if (buf && len > 0) {
+        const size_t n = std::min(s.size(), (size_t)len - 1);
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int)s.size();
+}
+
 int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
 {
     if (!h) return DES_ERR_INTERNAL;
@@ -1826,7 +1859,7 @@ int des_dev_timer_stop(des_dev *h, float *ms)
 
 int des_dev_profile_enable(des_dev *h, int on)
 {
-    if (h && h->d2) return DES_OK;                 // no per-kernel accounting in the 2-D engine
+    D2_FORWARD(h, profile_enable(h->d2, on));
     if (!h) return DES_ERR_INTERNAL;
     hipStreamSynchronize(h->stream);
     for (ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
@@ -1838,7 +1871,7 @@ int des_dev_profile_enable(des_dev *h, int on)
 
 int des_dev_profile_read(des_dev *h, int cap, char (*names)[64], double *ms, long long *calls)
 {
-    if (h && h->d2) return 0;
+    if (h && h->d2) return des2d::profile_read(h->d2, cap, names, ms, calls);
     if (!h) return 0;
     hipStreamSynchronize(h->stream);
     for (ProfRec &r : h->prof_recs) {
@@ -1871,4 +1904,16 @@ double des_dev_algorithmic_bytes_per_step(const des_dev *h)
     return be * h->ne + bn * h->nn;
 }
 
+#ifdef DES_STAMPS
+// instrumented builds only (passes/common.hpp): the stamps of the last EN1 (pass 0) / EN3 (pass 1) launch
+int des_dev_debug_stamps(int pass, unsigned long long *out, int cap)
+{
+    const size_t n = (size_t)DES_STAMP_SLOTS * DES_STAMP_WG;
+    if (!out || pass < 0 || pass > 1 || (size_t)cap < n) return (int)n;
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(des_hip::g_stamps), n * sizeof(unsigned long long), (size_t)pass * n * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
 } // extern "C"

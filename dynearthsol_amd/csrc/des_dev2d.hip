@@ -7,6 +7,8 @@
 // {x, z}; stress / strain / strain_rate [3][nelem] = {XX, ZZ, XZ}; connectivity [3][nelem].
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include "engine/env.hpp"
+#include "engine/selfcheck.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -111,6 +113,12 @@ struct Engine {
     long long n_pt_iterations = 0;   // pseudo-transient iterations of the current step() call
     std::vector<void *> allocs;
     std::string err;
+    // per-kernel HIP-event accounting of the main launches (des_dev_profile_enable / _read; off: no events at all)
+    bool prof = false;
+    struct ProfRec { hipEvent_t a, b; int k; };
+    std::vector<ProfRec> prof_recs;
+    double prof_ms[8] = {0};
+    long long prof_calls[8] = {0};
 };
 
 namespace {
@@ -1681,6 +1689,16 @@ FieldRef field_ref(const Engine *h, int field)
 
 #define L2(kernel, n, ...) hipLaunchKernelGGL(kernel, dim3(nblk(n)), dim3(DES_BLOCK), 0, h->stream, __VA_ARGS__)
 
+// the launches bench.py prices (HIP events on the engine's stream around each, only while profiling is on)
+enum { P2_TEMP = 0, P2_STRESS, P2_NODEAVG, P2_FORCE, P2_MASS, P2_ROTVOL, P2_EXCH, P2_COUNT };
+static const char *const p2_names[P2_COUNT] = {"K2P_temp_dvoldt", "K2_stress", "K2_node_avg", "K2P_force", "K2P_mass", "K2_rotate_vol",
+                                               "ghost_exchange"};
+struct Prof2 {
+    Engine *h; Engine::ProfRec rec; bool on;
+    Prof2(Engine *h_, int k) : h(h_), on(h_->prof) { if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, h->stream); } }
+    ~Prof2() { if (on) { hipEventRecord(rec.b, h->stream); h->prof_recs.push_back(rec); } }
+};
+
 void refresh_props(Engine *h)
 {
     if (!h->markers_dirty) return;
@@ -1725,6 +1743,7 @@ template <class M>
 void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr)
 {
     if (h->count_past) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
+    Prof2 pr(h, P2_STRESS);
     const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? 1 : 0;
     if (fused && h->p.rheol_type == DES_RH_EVP) {          // the common rheology has instantiations of its own
         if (h->geo_pending)
@@ -1840,7 +1859,8 @@ void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer
         // update (k2_stress<M, 2>), which reads and writes the same stress and strain anyway; compute_mass over the
         // node-block patches (it forms the volumes it sums from the coordinates)
         if (defer) h->geo_pending = true;
-        else L2(k2_rotate_vol, h->ne, h->d_clk, rotate ? 1 : 0, h->nn, h->ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain);
+        else { Prof2 pr(h, P2_ROTVOL); L2(k2_rotate_vol, h->ne, h->d_clk, rotate ? 1 : 0, h->nn, h->ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain); }
+        Prof2 pr(h, P2_MASS);
         hipLaunchKernelGGL(k2p_mass, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (3 * (size_t)h->p_pn_cap + 4 * (size_t)h->p_inc_cap), h->stream, h->d_p, patch_args(h), h->coord,
                            h->temperature, h->props, h->markers, h->volume_n, h->mass, h->tmass, h->ymass);
         return;
@@ -1872,16 +1892,20 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
     const int nn = h->nn, ne = h->ne;
     if (h->patch) {
         const PatchArgs a = patch_args(h);
+        { Prof2 pr(h, P2_TEMP);
         hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0,
                            h->geo_pending ? 1 : 0, a,
                            h->bcflag, h->coord, h->vel, h->temperature, h->temperature_alt, h->volume, h->radiogenic, h->props,
                            h->markers, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
+        }
         if (thermal) std::swap(h->temperature, h->temperature_alt);
         double *const s_law = nmd ? h->stress_pre : h->stress;
         launch_stress<M>(h, true, s_law);
-        if (nmd) L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp);
+        if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
+        { Prof2 pr(h, P2_FORCE);
         hipLaunchKernelGGL(k2p_force, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
                            h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->force, h->fres);
+        }
         launch_stress_bcs(h);
         if (tail) {
             launch_vbcs(h, false, h->tick_pending);     // the wall's extent into the clock (the coordinates have not moved yet)
@@ -2137,9 +2161,9 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     {
         // node-block patches (des_dev2d_patch.hpp): clusters of 128 nodes along a Morton curve (of 64 where 128 do not fit the
         // LDS caps; runs of consecutive ids without coordinates or with DES2D_CLUSTER=0); DES2D_PATCH=<n>: n nodes per block
-        const char *env = std::getenv("DES2D_PATCH");
-        const char *cl = std::getenv("DES2D_CLUSTER");
-        const char *ge = std::getenv("DES2D_GEO"), *ee = std::getenv("DES2D_ELIDE");
+        const char *env = des_env::get("DES2D_PATCH");
+        const char *cl = des_env::get("DES2D_CLUSTER");
+        const char *ge = des_env::get("DES2D_GEO"), *ee = des_env::get("DES2D_ELIDE");
         h->geo_on = !(ge && ge[0] == '0'); h->elide_on = !(ee && ee[0] == '0');
         const bool cluster = !(cl && cl[0] == '0');
         Patch2 P;
@@ -2153,7 +2177,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
         if (ok) {
             h->patch = true; h->p_npb = P.npb; h->p_nb = P.nb;
             h->p_pn_cap = (P.max_pn + 7) / 8 * 8; h->p_inc_cap = (P.max_inc + 7) / 8 * 8;
-            if (std::getenv("DES_PATCH_VERBOSE"))
+            if (des_env::get("DES_PATCH_VERBOSE"))
                 std::fprintf(stderr, "2-D patches: %d nodes per block, %d blocks, max incidences %d, patch nodes %d, patch elements %d, "
                              "elements listed %zu (%.2f x nelem)\n", P.npb, P.nb, P.max_inc, P.max_pn, P.max_pe, P.pe_pack.size(),
                              (double)P.pe_pack.size() / ne);
@@ -2233,7 +2257,7 @@ Engine *create(int device, const des_params *params, const des_mesh *mesh, int *
     Engine *h = new Engine();
     h->device = device;
     h->p = *params;
-    const char *env = std::getenv("DES_LIBM");
+    const char *env = des_env::get("DES_LIBM");
     h->portable_libm = !env || std::strcmp(env, "portable") == 0;
     if (env && !h->portable_libm && std::strcmp(env, "ocml") != 0) {
         *err = DES_ERR_CONFIG_VALUE; msg = "DES_LIBM must be 'ocml' or 'portable'"; delete h; return nullptr;
@@ -2345,6 +2369,7 @@ static int wall_allreduce(Engine *h)
 // one grouped send / recv per neighbour between the pack and the unpack launch, then the wall reduction
 static int exchange_rccl(Engine *h)
 {
+    Prof2 pr(h, P2_EXCH);
     launch_pack(h);
     NCCL2(ncclGroupStart());
     for (int q = 0; q < h->nnbr; ++q) {
@@ -2370,6 +2395,17 @@ int set_comm(Engine *h, void *comm)
 {
     if (comm && h->p.has_PT) { h->err = "control.has_PT on a decomposed mesh: the loop's residual test is global"; return DES_ERR_UNSUPPORTED; }
     h->comm = (ncclComm_t)comm;
+    return DES_OK;
+}
+
+// des_dev_comm_selfcheck for a 2-D engine (engine/selfcheck.hpp)
+int comm_selfcheck(Engine *h, int expect_world, int expect_rank)
+{
+    HIP2(hipSetDevice(h->device));
+    HIP2(hipStreamSynchronize(h->stream));
+    const std::string bad = des_selfcheck::run(h->comm, h->stream, expect_world, expect_rank, h->halo_set ? h->nnbr : 0, h->nbr_rank.data(),
+                                               h->send_off.data(), h->recv_off.data(), h->d_sendbuf, h->d_recvbuf, h->d_red);
+    if (!bad.empty()) { h->err = "RCCL self-check, rank " + std::to_string(expect_rank) + ": " + bad; return DES_ERR_RESOURCE; }
     return DES_OK;
 }
 
@@ -2702,6 +2738,37 @@ int mesh_quality(Engine *h, double smallest_vol, double bottom, double bottom_di
     hipFree(d_out);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return DES_ERR_RESOURCE; }
     return DES_OK;
+}
+
+int profile_enable(Engine *h, int on)
+{
+    HIP2(hipSetDevice(h->device));
+    HIP2(hipStreamSynchronize(h->stream));
+    for (Engine::ProfRec &r : h->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    h->prof_recs.clear();
+    for (int k = 0; k < P2_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_calls[k] = 0; }
+    h->prof = on != 0;
+    return DES_OK;
+}
+
+int profile_read(Engine *h, int cap, char (*names)[64], double *ms, long long *calls)
+{
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (Engine::ProfRec &r : h->prof_recs) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { h->prof_ms[r.k] += t; h->prof_calls[r.k] += 1; }
+        hipEventDestroy(r.a); hipEventDestroy(r.b);
+    }
+    h->prof_recs.clear();
+    int n = 0;
+    for (int k = 0; k < P2_COUNT && n < cap; ++k) {
+        if (!h->prof_calls[k]) continue;
+        std::strncpy(names[n], p2_names[k], 63); names[n][63] = 0;
+        ms[n] = h->prof_ms[k]; calls[n] = h->prof_calls[k];
+        ++n;
+    }
+    return n;
 }
 
 int timer_start(Engine *h) { HIP2(hipSetDevice(h->device)); HIP2(hipEventRecord(h->ev0, h->stream)); return DES_OK; }

@@ -40,6 +40,8 @@ int compute_dt(Engine *h, double *dt);
 int step(Engine *h, int nsteps, des_scalars *out);
 int check_nan(Engine *h, long long *n_nan);
 int mesh_quality(Engine *h, double smallest_vol, double bottom, double bottom_dist, des_quality *out);
+int profile_enable(Engine *h, int on);
+int profile_read(Engine *h, int cap, char (*names)[64], double *ms, long long *calls);
 int timer_start(Engine *h);
 int timer_stop(Engine *h, float *ms);
 double algorithmic_bytes_per_step(const Engine *h);
@@ -55,6 +57,7 @@ int dt_partials(Engine *h, double out[6], int recompute);
 int dt_finalize(Engine *h, const double in[6], double *dt);
 int step_group(Engine **g, int n, int nsteps, des_scalars *out);
 // the RCCL communicator (an ncclComm_t the caller owns) des_dev_step / init_geometry / compute_dt of a decomposed engine use
+int comm_selfcheck(Engine *h, int expect_world, int expect_rank);
 int set_comm(Engine *h, void *comm);
 
 } // namespace des2d

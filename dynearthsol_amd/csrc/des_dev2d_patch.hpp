@@ -58,7 +58,7 @@ static bool build_patches2(const des_mesh *m, int npb, bool cluster, Patch2 &P)
         // clusters `aspect` times as tall (z) as wide (x): the renumbered mesh is sorted along x, so the ids -- of nodes and of
         // elements -- inside a thin x-strip are contiguous, and a cluster that is a few columns wide reads longer runs of
         // the element planes than a square one (DES2D_CLUSTER_ASPECT, default 4)
-        const char *ae = std::getenv("DES2D_CLUSTER_ASPECT");
+        const char *ae = des_env::get("DES2D_CLUSTER_ASPECT");
         const double aspect = ae && std::atof(ae) > 0 ? std::atof(ae) : 4.0;
         const double ext = std::max(x1 - x0, (z1 - z0) / aspect);
         const double sc = ext > 0 ? 65535.0 / ext : 0.0, scz = sc / aspect;

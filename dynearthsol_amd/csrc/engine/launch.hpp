@@ -5,12 +5,15 @@
 // =====================================================================================
 // host side of the engine
 // =====================================================================================
+#define DES_ALLOC_SLACK 8192
 template <typename T>
 int dev_alloc(T *&ptr, size_t count)
 {
     ptr = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void **)&ptr, count * sizeof(T));
+    // DES_ALLOC_SLACK bytes behind every array: the pipelined stress update (passes/e2.hpp) moves whole 64-element pieces of
+    // the element arrays and the connectivity, so its last tile reads up to 255 records past the end (never used, never written)
+    hipError_t e = hipMalloc((void **)&ptr, count * sizeof(T) + DES_ALLOC_SLACK);
     if (e != hipSuccess) { g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return DES_ERR_RESOURCE; }
     return DES_OK;
 }
@@ -42,7 +45,7 @@ struct Launch {
 #ifdef DES_EXPERIMENTS
 inline bool exp_skip(const char *what)
 {
-    static const char *env = std::getenv("DES_EXP_SKIP");
+    static const char *env = des_env::get("DES_EXP_SKIP");
     return env && std::strstr(env, what) != nullptr;
 }
 #else
@@ -141,7 +144,7 @@ inline bool en1_ok(const des_dev *h)
 // alone, E1<DT | VOLX>).
 inline bool e2geo_ok(const des_dev *h)
 {
-    static const char *env = std::getenv("DES_E2GEO");
+    static const char *env = des_env::get("DES_E2GEO");
     return !(env && env[0] == '0') && en1_ok(h) && defer_rot_ok(h, true) && h->topflag;
 }
 
@@ -254,7 +257,7 @@ inline double *pending_ddp(const des_dev *h) { return (h->patch && h->ddp_live &
 // tiles one after the other)
 void choose_npb(des_dev *h)
 {
-    const char *env = std::getenv("DES_NPB");
+    const char *env = des_env::get("DES_NPB");
     const int nown = h->nn;
     h->npb = (nown < 512 * DES_BLOCK) ? 64 : DES_BLOCK;
     if (env && (std::atoi(env) == 64 || std::atoi(env) == 128 || std::atoi(env) == 256)) h->npb = std::atoi(env);
@@ -330,11 +333,24 @@ enum { PART_ALL = 0, PART_DEEP = 1, PART_REST = 2 };
 // DES_E2_W3 = 0 / 1 pins the choice.
 inline bool e2_three_waves(const des_dev *h, long long nelem)
 {
-    static const char *env = std::getenv("DES_E2_W3");
+    static const char *env = des_env::get("DES_E2_W3");
     if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
     const long long waves = (nelem + 63) / 64, res2 = 2LL * 4 * h->n_cu, res3 = 3LL * 4 * h->n_cu;
     const long long r2 = (waves + res2 - 1) / res2, r3 = (waves + res3 - 1) / res3;
     return r3 < r2 && r2 <= 4;
+}
+
+// The pipelined E2<GEO> (passes/e2.hpp: E2_update_stress_pipe): 2 x CUs resident workgroups walking the tiles, the next tile's
+// own-index data arriving in LDS by DMA under the current tile's arithmetic.  Worth it where a workgroup has several tiles to
+// walk (>= 4 per resident workgroup); a shard of a few rounds keeps the plain kernel (and its three-wave shape).  Needs the
+// whole mesh as one range and an even plane stride (16-byte DMA pieces).  DES_E2_PIPE = 0 / 1 pins the choice.
+inline bool e2_pipelined(const des_dev *h, int part, long long nelem)
+{
+    if (part != PART_ALL || (h->ne & 1) || !h->topflag) return false;
+    static const char *env = des_env::get("DES_E2_PIPE");
+    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    const long long tiles = (nelem + DES_BLOCK - 1) / DES_BLOCK;
+    return tiles >= 4LL * 2 * h->n_cu;
 }
 
 void launch_e2(des_dev *h, int part = PART_ALL)
@@ -400,6 +416,16 @@ void launch_e2(des_dev *h, int part = PART_ALL)
             h->edv_pending = false;
         }
         const int e_all = e_count + e_count2;
+        if (geo && !defer && h->portable_libm && e2_pipelined(h, part, e_all)) {
+            const int ntiles = nblk(e_all);
+            const int npers = std::min((2 * h->n_cu + 7) / 8 * 8, (ntiles + 7) / 8 * 8);
+            auto kp = (h->p.rheol_type == DES_RH_EVP && h->p.is_using_mixed_stress && !h->p.is_outputting_averaged_fields)
+                      ? E2_update_stress_pipe<desk::MathPortable, DES_RH_EVP> : E2_update_stress_pipe<desk::MathPortable, 0>;
+            hipLaunchKernelGGL(kp, dim3(npers + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+                               ntiles, npers, h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old,
+                               h->stress, h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
+                               h->etmp2, count, (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
+        } else
         hipLaunchKernelGGL(k, dim3(nblk8(e_all) + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                            e_begin, e_count, e_begin2, e_count2, nblk(e_all), h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
                            h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
@@ -423,7 +449,7 @@ void launch_e2(des_dev *h, int part = PART_ALL)
 
 void launch_n2(des_dev *h)
 {
-    static const char *en2 = std::getenv("DES_PATCH_N2");
+    static const char *en2 = des_env::get("DES_PATCH_N2");
     if (h->patch && !(en2 && en2[0] == '0') && h->patch_max_pe <= DES_PATCH_PE) {
         // the gather over node-block patches (passes/en2.hpp): one etmp2 fetch per patch element
         Launch l(h, K_EN2);
@@ -497,7 +523,7 @@ void launch_en1(des_dev *h, int part = PART_ALL)
             }
         }
         const bool cm = h->const_mass;
-        static const char *tenv = std::getenv("DES_EN1_THREADS");
+        static const char *tenv = des_env::get("DES_EN1_THREADS");
         const int T = (tenv && std::atoi(tenv) == 512) ? 512 : 256;
         const bool fit = h->patch_max_inc <= 1600 && h->patch_max_pn <= 296 && h->patch_max_pe <= 872;
         const bool th = h->p.has_thermal_diffusion != 0;       // the common launch has kernels of its own (passes/en1.hpp)

@@ -7,6 +7,21 @@
 // =====================================================================================
 struct ElemProps { double bulkm, shearm, phi, cp, k; };
 
+// Instrumented builds only (tools/build_variant.sh NAME -DDES_STAMPS; tools/patch_phase_timing.py): the first lane of a
+// wavefront of every workgroup of the patch passes stamps the 100-MHz wall clock at its phase boundaries into a buffer
+// of the code object, which the tool reads after the run (the last launch of each pass wins).  The shipped library
+// holds none of this.
+#ifdef DES_STAMPS
+#define DES_STAMP_WG 8192
+#define DES_STAMP_SLOTS 8
+__device__ unsigned long long g_stamps[2][DES_STAMP_SLOTS][DES_STAMP_WG];          // [EN1 | EN3][slot][workgroup]
+#define DES_STAMP(pass, slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < DES_STAMP_WG) g_stamps[pass][slot][blockIdx.x] = wall_clock64(); } while (0)
+#define DES_STAMP0(pass, slot) do { if (threadIdx.x == 0 && blockIdx.x < DES_STAMP_WG) g_stamps[pass][slot][blockIdx.x] = wall_clock64(); } while (0)
+#else
+#define DES_STAMP(pass, slot) do {} while (0)
+#define DES_STAMP0(pass, slot) do {} while (0)
+#endif
+
 // Element e of plane i of an SoA array [planes][ne], addressed as a UNIFORM plane base (a scalar register
 // pair) + a 32-bit byte offset eo = 8 e that every plane shares: the lane holds one offset register instead
 // of a 64-bit address per plane it loads and later stores (18 planes in the stress update = 36 VGPRs).

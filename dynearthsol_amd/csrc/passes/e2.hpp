@@ -51,27 +51,46 @@ struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int 
 // With GEO the first pass of two (DEFER = 1) stores the strain and the corrected strain-rate diagonal as
 // soon as they are final -- before the constitutive law, whose registers they would otherwise sit next to --
 // also for the elements it sets aside; the return-mapping pass (RM = 1) then leaves the strain alone.
-template <class M, int DEFER, int GEO, int RM = 0, int RH = 0>
+// ---- the pipelined form of E2<GEO> (E2_update_stress_pipe below) ---------------------------------------------------
+// What an element's stress update reads at its OWN index (planes, connectivity, marker word, top flag) -- there it arrives
+// in LDS one tile AHEAD of the arithmetic -- and what it gathers through the connectivity (nodal records), requested at the
+// top of its own tile.  Same values, same operations on them: e2_element<..., PIPE = 1> only takes them from here instead
+// of loading them itself.
+struct E2Pre { int4 cn; int mono, top; double s[6], es[6], vol_prev, pls, dd; };
+struct E2Gath { d4 c[4], v[4]; double nt[4]; };
+
+__device__ __forceinline__ void e2_gather(E2Gath &G, const int4 cn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
+                                          const double *__restrict__ ntmp)
+{
+    G.c[0] = rec_ld(xt, cn.x); G.c[1] = rec_ld(xt, cn.y); G.c[2] = rec_ld(xt, cn.z); G.c[3] = rec_ld(xt, cn.w);
+    G.v[0] = rec_ld(vm, cn.x); G.v[1] = rec_ld(vm, cn.y); G.v[2] = rec_ld(vm, cn.z); G.v[3] = rec_ld(vm, cn.w);
+    G.nt[0] = rec_ld(ntmp, cn.x); G.nt[1] = rec_ld(ntmp, cn.y); G.nt[2] = rec_ld(ntmp, cn.z); G.nt[3] = rec_ld(ntmp, cn.w);
+}
+
+template <class M, int DEFER, int GEO, int RM = 0, int RH = 0, int PIPE = 0>
 __device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
      const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData &md,
      double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
-     double *__restrict__ dpressure, double *__restrict__ etmp2, const RotPending rp)
+     double *__restrict__ dpressure, double *__restrict__ etmp2, const RotPending rp,
+     const E2Pre *__restrict__ pre = nullptr, const E2Gath *__restrict__ gath = nullptr)
 {
+    static_assert(!PIPE || (GEO && !DEFER && !RM), "the pipelined form is the one-pass E2<GEO>");
     const double dt = clk->dt;
     const unsigned eo = (unsigned)e * 8u;
-    const int4 cn = rec_ld(conn, e);
+    const int4 cn = PIPE ? pre->cn : rec_ld(conn, e);
     // (RH != 0: the launch is the common one of that rheology -- NMD_stress on, no averaged output fields -- and the kernel
     //  holds that path only: the law and the two switches known at compile time, -2.5 us of 78 at 1M tets for evp)
     const int rheol = RH ? RH : p->rheol_type;
     const bool nmd_on = RH ? true : (bool)p->is_using_mixed_stress, averaging = RH ? false : true;
-    const desk::Mix mx = mix_of(md, p->nmat, e);
+    const desk::Mix mx = PIPE ? mix_from_mono(md, p->nmat, e, pre->mono) : mix_of(md, p->nmat, e);
     const ElemProps pr = load_props(p, md, mx, ne, e);
 
     double dj = 0;
-    dj += rec_ld(ntmp, cn.x); dj += rec_ld(ntmp, cn.y); dj += rec_ld(ntmp, cn.z); dj += rec_ld(ntmp, cn.w);
+    if (PIPE) { dj += gath->nt[0]; dj += gath->nt[1]; dj += gath->nt[2]; dj += gath->nt[3]; }
+    else { dj += rec_ld(ntmp, cn.x); dj += rec_ld(ntmp, cn.y); dj += rec_ld(ntmp, cn.z); dj += rec_ld(ntmp, cn.w); }
     const double edvoldt = dj / 4;
 
     const bool outs = !GEO || rp.outputs;
@@ -84,14 +103,19 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     bool g_rescaled = false, g_top = false;
     if (GEO) {
         d4 c[4], v[4];
-        c[0] = rec_ld(xt, cn.x); c[1] = rec_ld(xt, cn.y); c[2] = rec_ld(xt, cn.z); c[3] = rec_ld(xt, cn.w);
-        v[0] = rec_ld(rp.vm, cn.x); v[1] = rec_ld(rp.vm, cn.y); v[2] = rec_ld(rp.vm, cn.z); v[3] = rec_ld(rp.vm, cn.w);
+        if (PIPE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[i] = gath->c[i]; v[i] = gath->v[i]; }
+        } else {
+            c[0] = rec_ld(xt, cn.x); c[1] = rec_ld(xt, cn.y); c[2] = rec_ld(xt, cn.z); c[3] = rec_ld(xt, cn.w);
+            v[0] = rec_ld(rp.vm, cn.x); v[1] = rec_ld(rp.vm, cn.y); v[2] = rec_ld(rp.vm, cn.z); v[3] = rec_ld(rp.vm, cn.w);
+        }
         g_T += c[0].w; g_T += c[1].w; g_T += c[2].w; g_T += c[3].w;
         g_T /= 4;
-        const double vol_prev = pl_ld(volume, 0, ne, eo);
+        const double vol_prev = PIPE ? pre->vol_prev : pl_ld(volume, 0, ne, eo);
         g_vol = desk::tet_volume(c);
         double rdv = 0.0;
-        g_top = rp.topflag[e] != 0;
+        g_top = (PIPE ? pre->top : (int)rp.topflag[e]) != 0;
         if (rp.fresh) g_vol_old = pl_ld(volume_old, 0, ne, eo);      // (the swap is done: vol_prev is this step's volume)
         else if (g_top) { rdv = g_vol / vol_prev; g_vol_old = g_vol; }     // correct_surface_element stored the new volume before the swap
         else g_vol_old = vol_prev;
@@ -109,11 +133,11 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
         for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
         for (int i = 0; i < 6; ++i) {
-            s[i] = pl_ld(stress, i, ne, eo);
-            if (!ES_DONE) es[i] = DES_STRAIN_LD(strain, i, ne, eo);
+            s[i] = PIPE ? pre->s[i] : pl_ld(stress, i, ne, eo);
+            if (!ES_DONE) es[i] = PIPE ? pre->es[i] : DES_STRAIN_LD(strain, i, ne, eo);
         }
-        g_pls = pl_ld(plstrain, 0, ne, eo);
-        const double dd = rp.ddp ? pl_ld(rp.ddp, 0, ne, eo) : 0.0;
+        g_pls = PIPE ? pre->pls : pl_ld(plstrain, 0, ne, eo);
+        const double dd = PIPE ? pre->dd : (rp.ddp ? pl_ld(rp.ddp, 0, ne, eo) : 0.0);
         if (dd != 0.0) for (int i = 0; i < 3; ++i) s[i] += dd;
         if (rdv >= 1.0) {                                                      // bc.cxx:1677
             g_pls /= rdv;
@@ -166,7 +190,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     const double vol = GEO ? g_vol : pl_ld(volume, 0, ne, eo);
     const double vol_old = GEO ? g_vol_old : ((rheol == DES_RH_MAXWELL || rheol == DES_RH_EVP) ? pl_ld(volume_old, 0, ne, eo) : 0.0);   // (dies at dv)
 
-    M::stage_end();
+    if (!PIPE) M::stage_end();         // (the pipelined kernel stages the libm tables once per workgroup, ahead of its tile loop)
     double visc = 0;
     if (rheol & DES_RH_VISCOUS) {
         double T = 0;
@@ -306,6 +330,116 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
             base = __shfl(base, leader);
             list[base + __popcll(mask & ((1ull << lane) - 1))] = e;
         }
+    }
+}
+
+// E2<GEO>, one pass, PIPELINED (round 4).  The plain kernel gives every wavefront one tile of 64 elements: index -> planes
+// and nodal records -> arithmetic -> stores, four to five dependent trips to memory, ~1150 fp64 instructions, and at two
+// waves per SIMD (175 VGPRs) the two hardly overlap -- the pass takes what its memory shape takes alone PLUS most of its
+// issue time (profiles/r03_b_pmc_counters_1M.txt: VALUBusy 38 %, a wave waits 60 % of its life).  Here 2 x CUs
+// workgroups stay resident and walk the tiles of their XCD's share of the mesh, and every wavefront has the own-index data
+// of its NEXT 64 elements -- fifteen planes, connectivity, marker word, top flag: 9.3 KB -- on its way into a private LDS
+// region while it computes the current ones: LDS-DMA (global_load_lds: no destination registers, so nothing is held in
+// VGPRs across the 1150-instruction body; holding them there spilled 200 B per lane).  Per tile a wavefront
+//   waits for its own DMA (counted: vmcnt is in issue order and only this tile's stores are younger), reads the 36
+//   values per lane out of LDS, issues the nodal gathers, THEN the next tile's DMA (so that the gathers' waits never
+//   cover it), computes, stores.
+// No workgroup barrier in the loop: a wavefront only ever reads what it requested itself.  The libm tables are staged
+// once per workgroup instead of once per tile.  Same element code (e2_element<..., PIPE = 1>): same operations, same bits.
+// Needs: one element range starting at 0 (not the split parts of the overlapped schedule), an even plane stride (16-byte
+// DMA pieces), and the 4 KB of slack dev_alloc() leaves behind every array (the last tile reads whole 64-element pieces).
+// npers: resident workgroups (a multiple of 8: blockIdx.x & 7 = the XCD under round-robin placement, for locality only).
+typedef const __attribute__((address_space(1))) void *des_gptr;
+typedef __attribute__((address_space(3))) void *des_lptr;
+template <class M, int RH>
+__global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
+E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
+     int ne, int ntiles, int npers, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
+     const double *__restrict__ ntmp, const MatData md,
+     double *__restrict__ volume, double *__restrict__ volume_old,
+     double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
+     double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
+     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ count,
+     int nbcf, const int *__restrict__ f_elem, const int *__restrict__ f_facet,
+     const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp, const RotPending rp)
+{
+    if ((int)blockIdx.x >= npers) {
+        // workgroups past the resident ones: the stress-bc facet terms and the edvacc_surf update (as in E2_update_stress)
+        const int g = ((int)blockIdx.x - npers) * DES_BLOCK + threadIdx.x;
+        const int nbcf_pad = (nbcf + DES_BLOCK - 1) / DES_BLOCK * DES_BLOCK;
+        if (g < nbcf) bc_facet_work(p, g, conn, xt, md, f_elem, f_facet, f_kind, f_val, f_tmp);
+        else if (g >= nbcf_pad && g - nbcf_pad < rp.edv_etop)
+            edvacc_facet(g - nbcf_pad, rp.edv_etop, rp.edv_conn_surf, xt, rp.edv_dh_n, rp.edv_edvacc);
+        return;
+    }
+    constexpr int NW = DES_BLOCK / 64;
+    __shared__ double lpl[NW][16][64];                   // per wavefront: stress 0-5, strain 6-11, volume 12, plstrain 13, ddp 14, (pad 15)
+    __shared__ int4 lcn[NW][64];
+    __shared__ int lmono[NW][64];
+    __shared__ unsigned char ltop[NW][256];
+    M::stage_begin();
+    M::stage_end();
+    // (w through readfirstlane: the LDS base of a DMA piece goes through M0 and must be known to be wave-uniform)
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    // tiles of this workgroup: XCD x sweeps the x-th eighth of the tiles (desk::logical_block's chunks), its npers / 8
+    // resident workgroups interleaved over it
+    const int per = (ntiles + 7) >> 3, wx = npers >> 3;
+    const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    const int t_end = min((x + 1) * per, ntiles);
+    const bool have_ddp = rp.ddp != nullptr;
+    // The DMA of one tile for this wavefront.  A piece = one instruction = 64 lanes x 16 B landing at the LDS base + 16 lane.
+    // 64 elements of a plane are 512 B, so a piece carries TWO planes: lanes 0-31 two consecutive elements of plane k each,
+    // lanes 32-63 of plane k + 1 (the same array's next plane, or the partner array's) -- every lane active, no divergent
+    // region around the requests.  Plane 15 is padding (the partner of ddp).  Then one connectivity record and one marker word
+    // per lane, and the top flags.
+    auto dma = [&](int tile) {
+        const size_t eb = (size_t)tile * DES_BLOCK + (size_t)w * 64;
+        const size_t o = eb + 2 * (size_t)(lane & 31);
+        const size_t hi = (size_t)(lane >> 5);
+#pragma unroll
+        for (int k = 0; k < 6; k += 2) {
+            __builtin_amdgcn_global_load_lds((des_gptr)(stress + ((size_t)k + hi) * ne + o), (des_lptr)&lpl[w][k][0], 16, 0, 0);
+            // (aux 2 = non-temporal, as DES_STRAIN_LD: the strain is read once and written once per step)
+            __builtin_amdgcn_global_load_lds((des_gptr)(strain + ((size_t)k + hi) * ne + o), (des_lptr)&lpl[w][6 + k][0], 16, 0, 2);
+        }
+        __builtin_amdgcn_global_load_lds((des_gptr)((hi ? plstrain : volume) + o), (des_lptr)&lpl[w][12][0], 16, 0, 0);
+        if (have_ddp) __builtin_amdgcn_global_load_lds((des_gptr)(rp.ddp + o), (des_lptr)&lpl[w][14][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((des_gptr)(conn + eb + lane), (des_lptr)&lcn[w][0], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((des_gptr)(md.mono + eb + lane), (des_lptr)&lmono[w][0], 4, 0, 0);
+        // (the top flags are bytes: a dword piece of 64 x 4 B covers them four times over -- bytes 0-63 are this tile's)
+        __builtin_amdgcn_global_load_lds((des_gptr)(rp.topflag + eb + 4 * (size_t)lane), (des_lptr)&ltop[w][0], 4, 0, 0);
+    };
+    int t = x * per + j;
+    if (t < t_end) dma(t);
+    while (t < t_end) {
+        const int e = t * DES_BLOCK + (int)threadIdx.x;
+        const int tn = t + wx;
+        // This tile's DMA has landed once at most the vector-memory operations issued BEHIND it are outstanding: the stores
+        // of the tile before (at least 13: stress 6, strain 6, volume) -- or nothing, for the first tile.
+        if (t == x * per + j) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else                  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        E2Pre cur;
+        cur.cn = lcn[w][lane]; cur.mono = lmono[w][lane]; cur.top = ltop[w][lane];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { cur.s[k] = lpl[w][k][lane]; cur.es[k] = lpl[w][6 + k][lane]; }
+        cur.vol_prev = lpl[w][12][lane]; cur.pls = lpl[w][13][lane];
+        cur.dd = have_ddp ? lpl[w][14][lane] : 0.0;
+        const bool valid = e < ne;
+        if (!valid) cur.cn = make_int4(0, 0, 0, 0);          // (lanes past the mesh: harmless gathers, nothing stored)
+        E2Gath G;
+        e2_gather(G, cur.cn, xt, rp.vm, ntmp);
+        // the region is free again once every value is in registers; the next tile's pieces are requested behind the gathers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tn < t_end) dma(tn);
+        asm volatile("" ::: "memory");
+        bool defer = false;
+        if (valid)
+            defer = e2_element<M, 0, 1, 0, RH, 1>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+                                                  plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp, &cur, &G);
+        // the count of elements past the yield pre-filter (des_scalars::n_return_mapping): one atomic per wavefront that has any
+        const unsigned long long mask = __ballot(defer);
+        if (defer && lane == __ffsll((long long)mask) - 1) atomicAdd(count, __popcll(mask));
+        t = tn;
     }
 }
 

@@ -36,8 +36,15 @@ struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *s
 #ifndef DES_EN1_NB
 #define DES_EN1_NB 8              // incidences per batch of LDS requests in the node phase
 #endif
+// DES_EN1_SPLIT = 1: the node phase on three wavefronts, one group of sums each, instead of one lane per node walking all
+// five (round 4, the round-3 review's proposal).  Same bits (every sum keeps its CSR order; the GPU suite passes either way).
+// Measured with phase stamps (profiles/r04_c_phase_*.txt, tools/patch_phase_timing.py): the node phase goes 2.18 -> 1.85 us
+// (it is bound by LDS latency under the other workgroups' element phases, not by the length of one lane's walk), the
+// element phase 5.98 -> 6.34 us (two more wavefronts compete for LDS and issue slots), a workgroup's life 10.79 -> 10.93 us,
+// the kernel 51.7 -> 51.3 us: nothing.  The pass is issue-bound (1100 fp64-heavy instructions per wavefront at 65-70 % issue
+// utilisation), not bound by a workgroup's critical path.  Off by default; kept as the measured alternative.
 #ifndef DES_EN1_SPLIT
-#define DES_EN1_SPLIT 1           // the node phase on three wavefronts, one group of sums each (0: one lane per node does all five)
+#define DES_EN1_SPLIT 0
 #endif
 #ifndef DES_PATCH_PE
 #define DES_PATCH_PE 1280         // elements of a patch (LDS records)
@@ -74,6 +81,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         clk->n_defer = 0;
     }
     if (L >= c0 + c1 || n0 >= nn) return;                  // grid padding
+    DES_STAMP0(0, 0);
     const int nown = min(npb, nn - n0);
     const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
     const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
@@ -133,6 +141,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         }
     }
     __syncthreads();
+    DES_STAMP0(0, 1);
     // the patch's elements: E1's element terms, recomputed
     for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) {
         const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
@@ -170,7 +179,9 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         if (sl.z >= 0) { ltd[sl.z] = tr[2]; lidx[sl.z] = (unsigned short)q; }
         if (sl.w >= 0) { ltd[sl.w] = tr[3]; lidx[sl.w] = (unsigned short)q; }
     }
+    DES_STAMP0(0, 2);                                       // (this wavefront's own elements done)
     __syncthreads();
+    DES_STAMP0(0, 3);
     if (!has_node) return;
     const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
     const double rho_m = p->bulk_modulus[0] / (pseudo_speed * pseudo_speed);
@@ -197,6 +208,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
             for (; k < r1; ++k) { const int q = lidx[k]; vn += lvol[q]; acc += ldv[q]; }
             volume_n[n] = vn;
             ntmp[n] = acc / vn;
+            DES_STAMP(0, 4);
         } else if (part == 1) {
             double ms = 0;
             int k = r0;
@@ -213,6 +225,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
             d4 m4;                                               // the velocity is the staged one (own node: local id nl)
             m4.x = lvx[nl]; m4.y = lvy[nl]; m4.z = lvz[nl]; m4.w = ms;
             vm[n] = m4;
+            DES_STAMP(0, 5);
         } else {
             double tms = 0, tdot = 0;
             if (thermal) {
@@ -237,6 +250,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
                     x4.w -= dt * tdot / tms;
             }
             xt_out[n] = x4;
+            DES_STAMP(0, 6);
         }
         return;
     }
@@ -292,4 +306,5 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     }
     xt_out[n] = x4;
     ntmp[n] = acc / vn;
+    DES_STAMP0(0, 4);
 }

@@ -29,8 +29,11 @@
 // picks the smallest that holds the mesh's largest block (engine/launch.hpp, launch_en3).
 #define DES_PATCH_INC 2048        // caps of the largest shape = what build_patches() accepts
 #define DES_PATCH_PN 512
+// DES_EN3_SPLIT = 1: the three force sums of a node on three wavefronts (round 4, the round-3 review's proposal; same bits).
+// Measured (profiles/r04_c_phase_*.txt): the force sums were 1.1 us of a workgroup's 11.3-us life to begin with, the second
+// barrier and the extra LDS round trip give the gain back (life 11.34 -> 11.71 us, kernel 54.1 -> 54.6 us).  Off by default.
 #ifndef DES_EN3_SPLIT
-#define DES_EN3_SPLIT 1           // the three force sums of a node on three wavefronts (0: the node's lane forms all three)
+#define DES_EN3_SPLIT 0
 #endif
 
 // (512 lanes: three workgroups per CU are 6 waves per SIMD, i.e. at most 80 VGPRs)
@@ -60,6 +63,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     const int lb = desk::logical_block(nblocks);
     const int n0 = lb * npb;
     if (n0 >= nn) return;                                 // grid padding
+    DES_STAMP0(1, 0);
     const int nown = min(npb, nn - n0);
     const int h0 = pn_ptr[lb], nh = pn_ptr[lb + 1] - h0;
     const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
@@ -119,6 +123,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         if (nmd) lnt[j] = ntmp[id];
     }
     __syncthreads();
+    DES_STAMP0(1, 1);
 
     // the force terms of one patch element into the LDS slots of its incidences in this block
     auto do_elem = [&](const Elem &E) {
@@ -164,7 +169,9 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         load_elem(i, E);
         do_elem(E);
     }
+    DES_STAMP0(1, 2);
     __syncthreads();
+    DES_STAMP0(1, 3);
 
     // the block's nodes: force sums in CSR order, then the rest of the nodal update
     double l2 = 0.0;
@@ -199,6 +206,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
             if (r1 - r0 >= 2) L[r0] = f;
         }
         __syncthreads();
+        DES_STAMP0(1, 4);
         if (has_node) {
             double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
             if (r1 - r0 >= 2) {
@@ -243,6 +251,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
                             coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres);
     }
+    DES_STAMP0(1, 5);
     // per-block partial of the residual; the partials are added in block order afterwards
     l2 = desk::wave_sum(l2);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;
@@ -252,4 +261,5 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         for (int i = 1; i < THREADS / 64; ++i) t += red[i];
         res_part[lb] = t;
     }
+    DES_STAMP0(1, 6);
 }

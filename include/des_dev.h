@@ -183,6 +183,14 @@ int des_dev_comm_init(des_dev *h, int nranks, int rank, const unsigned char *id1
  * side stream while the end-of-step pass of the interior elements runs; default: everything
  * in order on the engine's stream) */
 int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped);
+/* Start-up self-check of the attached communicator, collective (every rank calls it once, before the first step):
+ * ncclCommCount == expect_world; every neighbour message of the ghost-region exchange -- the buffers, lengths and grouped
+ * ncclSend / ncclRecv calls des_dev_step itself issues -- is sent filled with a pattern the receiver can verify double by
+ * double (sender, receiver, position), so a truncated, swapped or stale message fails; ncclAllReduce SUM / MIN / MAX give
+ * their closed forms.  DES_ERR_RESOURCE + des_dev_last_error() names what failed.  New (the reference is single-process);
+ * it exists because no multi-GPU node is available where this library is built: the first run on real xGMI must be able
+ * to tell "the wires carry my bytes" from "the step is wrong". */
+int des_dev_comm_selfcheck(des_dev *h, int expect_world);
 /* in-order (0) or overlapped (1) schedule from the next des_dev_step call on; every rank must choose the same */
 int des_dev_set_overlap(des_dev *h, int on);
 /* the ghost-region exchange through the attached communicator, asynchronous on the engine's
@@ -222,6 +230,11 @@ int des_dev_group_detach(des_dev **engines, int n);
 int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out);
 
 const char *des_dev_last_error(void);
+/* The engine's environment switches (DES_PATCH, DES_E2GEO, DES2D_CLUSTER, ... -- each selects between
+ * code paths that give the same bits) that are SET in this process, as far as the library has read them: "NAME=value
+ * NAME=value" in name order, NUL-terminated, cut to len - 1 characters; returns the full length (0: every switch at its
+ * default).  A benchmark line carries it so that the record says which path was measured. */
+int des_dev_config_string(char *buf, int len);
 
 #ifdef __cplusplus
 }

@@ -987,6 +987,7 @@ void compute_volume(des_oracle &o, dvec &volume)
 void update_temperature(des_oracle &o)
 {
     const int ne = o.ne, nn = o.nn;
+    (void)nn;
     Mat mat(o);
     #pragma omp parallel for
     for (int e = 0; e < ne; e++) {
@@ -1393,11 +1394,13 @@ void apply_damping(des_oracle &o)
                     o.force[j*nn+i] -= p.damping_factor * std::copysign(o.force[j*nn+i], o.vel[j*nn+i]);
         break;
     case 2:
+        #pragma omp parallel for
         for (int i = o.c0; i < o.c1; ++i)
             for (int j = 0; j < ND; j++)
                 o.force[j*nn+i] -= p.damping_factor * o.force[j*nn+i];
         break;
     case 3:
+        #pragma omp parallel for
         for (int i = o.c0; i < o.c1; ++i)
             for (int j = 0; j < ND; j++) {
                 if ((o.force[j*nn+i] < 0) == (o.vel[j*nn+i] < 0)) {
@@ -1409,6 +1412,7 @@ void apply_damping(des_oracle &o)
             }
         break;
     case 4:
+        #pragma omp parallel for
         for (int i = o.c0; i < o.c1; ++i) {
             double critical_coeff = 2.0 * std::sqrt(o.mass[i] * o.ymass[i]);
             for (int j = 0; j < ND; j++)

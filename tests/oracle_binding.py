@@ -12,7 +12,7 @@ _libs = {}
 
 
 def load_oracle(omp=False, ndims=3):
-    name = "libdes_oracle2d.so" if ndims == 2 else "libdes_oracle_omp.so" if omp else "libdes_oracle.so"
+    name = ("libdes_oracle2d_omp.so" if omp else "libdes_oracle2d.so") if ndims == 2 else "libdes_oracle_omp.so" if omp else "libdes_oracle.so"
     if name not in _libs:
         path = os.path.join(ORACLE_DIR, name)
         if not os.path.exists(path):

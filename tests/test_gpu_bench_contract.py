@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def test_single_gpu_line_has_every_field_of_the_contract():
     out = subprocess.run([sys.executable, os.path.join(des.REPO_ROOT, "bench.py"), "--steps", "20", "--warmup", "3",
-                          "--resolution", "2000", "--cpu-steps", "5"], capture_output=True, text=True, timeout=600)
+                          "--resolution", "2000", "--cpu-steps", "5", "--series-resolution", "2500", "--series-steps", "8"],
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -37,6 +38,48 @@ def test_single_gpu_line_has_every_field_of_the_contract():
     cpu = r["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "element-steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
     assert r["config"]["nan_entries"] == 0 and r["config"]["status"] == 0
+    # the path that was measured: every engine switch set in the environment (none here), both store policies, and
+    # the second series on a larger mesh of the same box
+    c = r["config"]
+    assert c["engine_switches"] == "" and c["interior_step_store_elision"] is True
+    assert c["ms_per_step_every_step_stores_every_field"] > 0
+    big = c["large_mesh_series"]
+    assert big["nelem"] == 160 * 8 * 4 * 5 and big["steps"] == 8 and big["value"] > 0 and big["status"] == 0
+    assert "real_traffic_bytes_per_plain_step" not in c           # PMC traffic is only quoted for the workload it was measured on
+
+
+def test_engine_switches_are_recorded_in_the_line():
+    """a stray DES_PATCH=0 changes the measured path: the line must say so (des_dev_config_string)"""
+    env = dict(os.environ, DES_PATCH="0", DES_E2_ELIDE="0")
+    out = subprocess.run([sys.executable, os.path.join(des.REPO_ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--resolution", "2000",
+                          "--cpu-steps", "0", "--no-large-series", "--no-ceiling"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
+    sw = r["config"]["engine_switches"].split()
+    assert "DES_PATCH=0" in sw and "DES_E2_ELIDE=0" in sw
+    assert r["config"]["interior_step_store_elision"] is False and r["config"]["ms_per_step_every_step_stores_every_field"] is None
+    assert r["config"]["large_mesh_series"] is None
+
+
+def test_two_d_line_has_roofline_and_cpu_baseline():
+    """bench.py --ndims 2: the tri-mesh line through the same entry point -- roofline of the 2-D engine's dominant launch on
+    its own minimum bytes (HIP events inside the engine), CPU baseline from the 2-D oracle's OpenMP build"""
+    out = subprocess.run([sys.executable, os.path.join(des.REPO_ROOT, "bench.py"), "--ndims", "2", "--steps", "20", "--warmup", "3",
+                          "--resolution", "1000", "--cpu-steps", "5"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["metric"] == "explicit time-steps/sec x #elements" and r["dtype"] == "f64" and c["ndims"] == 2
+    assert c["nelem"] == 2 * 400 * 100 and "triangle" in c["workload"] and c["nan_entries"] == 0 and c["status"] == 0
+    roof = r["roofline"]
+    assert roof["kernel"] == "K2_stress" and roof["bound"] == "hbm" and 0 < roof["frac"] < 1
+    assert roof["algorithmic_bytes_per_launch"] == pytest.approx((192 * 19 + 248) / 20 * c["nelem"] + 48 * c["nnode"])
+    assert set(c["kernel_ms_per_call"]) >= {"K2P_temp_dvoldt", "K2_stress", "K2P_force", "K2P_mass"}
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and "triangle" in cpu["sample"]
+    assert c["ms_per_step_every_step_stores_every_field"] > 0 and c["large_mesh_series"] is None
 
 
 def test_default_workload_is_the_reference_tetgen_mesh():
@@ -50,3 +93,7 @@ def test_default_workload_is_the_reference_tetgen_mesh():
     assert (r["config"]["nelem"], r["config"]["nnode"]) == (1001310, 185637)
     assert "TetGen mesh at mesh.resolution = 460 m" in r["config"]["workload"] and r["roofline"]["frac"] > 0.3
     assert r["cpu_baseline"] is None and r["config"]["nan_entries"] == 0
+    # ... with the large-mesh series of the same box beside it (N = 1 point of the second strong-scaling curve), and what the
+    # plain fused step really moves (PMC traffic of its four launches) beside the contract-bytes figure
+    assert r["config"]["large_mesh_series"]["nelem"] == 8780800 and r["config"]["large_mesh_series"]["value"] > 2e9
+    assert 0.2 < r["config"]["real_traffic_frac_of_hbm_peak"] < r["config"]["whole_step_frac_of_hbm_peak"]

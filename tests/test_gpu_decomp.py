@@ -118,6 +118,11 @@ def test_rccl_send_recv_path_moves_the_ghost_state():
         halo = DesHalo(0, nn, 4, 2, pi(nbr), pi(ptr), pi(send), pi(ptr), pi(recv), pi(eptr), pi(esend), pi(eptr), pi(erecv))
         eng.set_halo(types.SimpleNamespace(halo=halo, owned=(0, nn), host=host))
         eng.comm_init(dist, 0, 1)
+        # the start-up self-check bench.py runs on every rank: the exchange's own messages with a verifiable pattern, the
+        # reductions, the rank count -- and it must refuse a communicator of the wrong size
+        eng.comm_selfcheck(1)
+        with pytest.raises(des.DesError, match="ncclCommCount = 1, expected 2"):
+            eng.comm_selfcheck(2)
         eng.init_from_host(host)
         vel = rng.standard_normal((3, nn)); eng.upload("VEL", vel)
         tem = rng.standard_normal(nn); eng.upload("TEMPERATURE", tem)
@@ -159,7 +164,8 @@ def test_two_rank_bench_rehearsal(mode):
     port = 29400 + os.getpid() % 90 + (7 if mode == "weak" else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(des.REPO_ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "12", "--warmup", "2", "--resolution", "2000", "--cpu-steps", "0"]
+                          "--gpus", "2", "--steps", "12", "--warmup", "2", "--resolution", "2000", "--cpu-steps", "0",
+                          "--series-resolution", "2500", "--series-steps", "6"]
                          + (["--weak"] if mode == "weak" else []),
                          capture_output=True, text=True, timeout=170, env=env, cwd=des.REPO_ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -173,6 +179,16 @@ def test_two_rank_bench_rehearsal(mode):
     # this rehearsal must not be mistaken for an RCCL run
     assert c["rccl_ranks"] == 0 and "rehearsal" in c["parallelism"] and c["exchange_us_per_rank"] == [-1.0, -1.0]
     assert 0 < c["ghost_work_share"] < 0.5 and c["nelem_local_sum"] > c["nelem"]
+    # per rank: the step without the exchange (sum of the passes' HIP-event times), in us
+    assert len(c["step_us_without_exchange_per_rank"]) == 2 and all(t > 0 for t in c["step_us_without_exchange_per_rank"])
+    assert c["rccl_selfcheck"].startswith("not run")
+    # the second, larger mesh of the same box in the same line (strong scaling only)
+    big = c["large_mesh_series"]
+    if mode == "strong":
+        assert big["nelem"] == 160 * 8 * 4 * 5 and big["steps"] == 6 and big["value"] > 0 and big["status"] == 0
+        assert "cut 2 ways" in big["workload"] and 0 < big["ghost_work_share"] < 0.5
+    else:
+        assert big is None
 
 
 def test_bench_refuses_to_report_without_rccl():

@@ -7,7 +7,7 @@ res = {}
 for rnd in range(2):
     for lib in libs:
         env = dict(os.environ, DES_HIP_LIB=os.path.abspath(lib))
-        out = subprocess.check_output([sys.executable, "bench.py", "--steps", "60", "--warmup", "10", "--cpu-steps", "0"], env=env)
+        out = subprocess.check_output([sys.executable, "bench.py", "--steps", "60", "--warmup", "10", "--cpu-steps", "0", "--no-large-series", "--no-elide-compare"], env=env)
         r = json.loads(out.decode().strip().splitlines()[-1])
         res.setdefault(lib, []).append((r["ms_per_step"], r["config"]["kernel_ms_per_call"]))
 names = ["E1_geom_rotate_strainrate", "N1_mass_temperature_dvoldt", "E2_update_stress", "N2_nmd_gather", "E3_nmd_force", "N3_force_velocity_coord"]

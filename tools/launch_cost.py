@@ -19,7 +19,7 @@ def run(skip, extra):
     env.pop("DES_EXP_SKIP", None)
     if skip:
         env["DES_EXP_SKIP"] = skip
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "400", "--warmup", "40", "--cpu-steps", "0",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "400", "--warmup", "40", "--cpu-steps", "0", "--no-large-series", "--no-elide-compare",
                           "--no-profile", "--no-ceiling"] + extra, capture_output=True, text=True, env=env, check=True)
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["config"]["hip_event_ms_per_step"] * 1e3
 

@@ -10,7 +10,7 @@ HALF of the bytes moved, for 8 B per lane streams as for the 16 B per lane ones 
 gather shows 128 B moved per access, i.e. whole lines, in the same unit) -- so
 traffic = (FETCH_SIZE / 0.5 + WRITE_SIZE) x 1024 for every pass of this engine.
 
-  python tools/measure_traffic.py [bench args]      (on the MI355X box)   -> profiles/r02_pmc_traffic.json
+  python tools/measure_traffic.py [bench args]      (on the MI355X box)   -> profiles/r04_pmc_traffic.json (with --ndims 2: r04_pmc_traffic_2d.json)
 """
 import collections
 import csv
@@ -27,10 +27,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     """'void des_hip::E2_update_stress<desk::MathOcml, 1>(args)' -> 'E2_update_stress'"""
     k = name.split("(")[0].replace("void ", "").strip()
-    for ns in ("des_hip::", "(anonymous namespace)::"):
+    for ns in ("des_hip::", "des2d::", "(anonymous namespace)::"):
         if k.startswith(ns):
             k = k[len(ns):]
     base = k.split("<")[0]
+    # the 2-D engine's launches under the names its own accounting (and bench.py --ndims 2) uses
+    two_d = {"k2_stress": "K2_stress", "k2p_temp_dvoldt": "K2P_temp_dvoldt", "k2p_force": "K2P_force", "k2p_mass": "K2P_mass",
+             "k2_node_avg": "K2_node_avg", "k2_rotate_vol": "K2_rotate_vol"}
+    if base in two_d:
+        return two_d[base]
     if base == "E2_update_stress":
         targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]      # <M, DEFER, GEO, RH>
         if len(targs) >= 3 and targs[2] == "1":
@@ -43,7 +48,7 @@ def counters(counter, bench_args):
     d = tempfile.mkdtemp(prefix="pmc_", dir=base if os.path.isdir(base) else None)
     out = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--cpu-steps", "0",
-                          "--no-profile", "--no-ceiling"] + bench_args, capture_output=True, text=True, cwd="/tmp",
+                          "--no-profile", "--no-ceiling", "--no-large-series", "--no-elide-compare"] + bench_args, capture_output=True, text=True, cwd="/tmp",
                          env=dict(os.environ, TMPDIR="/tmp"))
     if out.returncode:
         sys.exit("rocprofv3 failed:\n" + out.stderr[-2000:])
@@ -73,14 +78,14 @@ def main():
     res = {"workload": {"nelem": line["config"]["nelem"], "nnode": line["config"]["nnode"]},
            "workload_text": line["config"]["workload"], "bench_args": bench_args, "calibration": cal}
     for k in sorted(f):
-        if k not in w or not k[:2] in ("E1", "E2", "E3", "N1", "N2", "N3", "EN", "S2", "S3"):
+        if k not in w or not k[:2] in ("E1", "E2", "E3", "N1", "N2", "N3", "EN", "S2", "S3", "K2"):
             continue
         fv, wv = sum(f[k]) / len(f[k]), sum(w[k]) / len(w[k])
         res[k] = {"fetch_size_kib_raw": fv, "write_size_kib_raw": wv, "launches": len(f[k]),
                   "traffic_bytes_per_launch": (fv / cal["fetch"] + wv / cal["write"]) * 1024}
         print("%-28s FETCH %.1f MiB raw, WRITE %.1f MiB -> traffic %.1f MB/launch" % (k, fv / 1024, wv / 1024, res[k]["traffic_bytes_per_launch"] / 1e6))
     # (on the GPU box only gpurun_out/ travels back: DES_PROFILE_OUT=gpurun_out/<dir>, then copy to profiles/)
-    json.dump(res, open(os.path.join(os.environ.get("DES_PROFILE_OUT", os.path.join(ROOT, "profiles")), os.environ.get("DES_TRAFFIC_NAME", "r03_pmc_traffic.json")), "w"), indent=1)
+    json.dump(res, open(os.path.join(os.environ.get("DES_PROFILE_OUT", os.path.join(ROOT, "profiles")), os.environ.get("DES_TRAFFIC_NAME", "r04_pmc_traffic_2d.json" if "--ndims" in bench_args else "r04_pmc_traffic.json")), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ def main():
     for g in groups:
         d = tempfile.mkdtemp(prefix="pmcp_", dir=base if os.path.isdir(base) else None)
         cmd = ["rocprofv3", "--pmc"] + g.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--cpu-steps", "0", "--no-profile", "--no-ceiling"] + bench_args
+               os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2", "--cpu-steps", "0", "--no-large-series", "--no-elide-compare", "--no-profile", "--no-ceiling"] + bench_args
         r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
         if r.returncode:
             log.append("# group '%s' failed: %s" % (g, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "?"))

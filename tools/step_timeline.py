@@ -25,7 +25,7 @@ def main():
     base = os.path.join(ROOT, "gpurun_out")
     d = tempfile.mkdtemp(prefix="tl_", dir=base if os.path.isdir(base) else None)
     cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--cpu-steps", "0", "--no-profile", "--no-ceiling"] + bench_args
+           os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--cpu-steps", "0", "--no-large-series", "--no-elide-compare", "--no-profile", "--no-ceiling"] + bench_args
     out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
     if out.returncode:
         sys.exit("rocprofv3 failed:\n" + out.stderr[-2000:])
