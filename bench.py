@@ -498,6 +498,9 @@ def main():
 
     bytes_step_local = dev.algorithmic_bytes_per_step()
     nn_local = nn if world == 1 else part.nnode
+    # every DES_* switch the library has found set so far ('' = all defaults): taken here, before the comparison engine below
+    # is created with its one deliberate switch
+    engine_switches = des.config_string()
 
     # ---- the same model with every step storing every field (no store elision): a second engine, N = 1 only ------------
     no_elide_ms = None
@@ -558,7 +561,7 @@ def main():
         # CONTRACT bytes (SURVEY 8d's B_alg: what the reference's pass structure would have to move) per second against
         # the peak -- work done per second, not a bandwidth: the fused step moves far less (real_traffic_* below)
         result["config"]["whole_step_frac_of_hbm_peak"] = bytes_step * args.steps / (ev_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
-        result["config"]["engine_switches"] = des.config_string()        # every DES_* switch set in this process ('' = all defaults)
+        result["config"]["engine_switches"] = engine_switches
         roof = None
         # HBM bytes from the PMC counters cannot be collected inside the timed run (separate rocprofv3 passes,
         # MI355X_MICROARCH.md): tools/measure_traffic.py makes them for a named workload and commits the summary; it is

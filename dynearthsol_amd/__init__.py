@@ -331,6 +331,9 @@ class EngineBase:
         if self.prefix == "des_oracle":
             f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
             self._check(f(self._h, part.owned[0], part.owned[1], part.host.nnode), "set_halo")
+            g = self._f("set_owned_global")
+            g.argtypes = [C.c_void_p, C.c_int]
+            self._check(g(self._h, int(part.halo.owned_global_begin)), "set_owned_global")
         else:
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
             self._check(f(self._h, C.byref(part.halo), part.host.nnode), "set_halo")
@@ -340,6 +343,26 @@ class EngineBase:
         f = self._f("phase")
         f.argtypes = [C.c_void_p, C.c_int]
         return f(self._h, ph)
+
+    def residual_blocks(self):
+        """(first global block, partials) of the partition-independent residual's blocks this rank owns (des_params.h:
+        DES_RES_BLOCK) -- the pseudo-transient loop's driver puts all ranks' together and hands them to residual_set"""
+        f = self._f("residual_blocks")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        first, count = C.c_int(0), C.c_int(0)
+        f(self._h, None, 0, C.byref(first), C.byref(count))
+        out = np.zeros(max(count.value, 1))
+        self._check(f(self._h, out.ctypes.data_as(C.c_void_p), count.value, C.byref(first), C.byref(count)), "residual_blocks")
+        return first.value, out[:count.value]
+
+    def residual_set(self, blocks):
+        """the fixed-shape sum over the GLOBAL block array: sets and returns l2_residual"""
+        f = self._f("residual_set")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        blocks = np.ascontiguousarray(blocks, dtype=np.float64)
+        l2 = C.c_double(0)
+        self._check(f(self._h, blocks.ctypes.data_as(C.c_void_p), len(blocks), C.byref(l2)), "residual_set")
+        return l2.value
 
     def halo_pack(self, kind, idx, width):
         f = self._f("halo_pack")

@@ -79,6 +79,7 @@ class DesHalo(C.Structure):
         ("nbr_rank", _pint), ("send_ptr", _pint), ("send_idx", _pint),
         ("recv_ptr", _pint), ("recv_idx", _pint),
         ("esend_ptr", _pint), ("esend_idx", _pint), ("erecv_ptr", _pint), ("erecv_idx", _pint),
+        ("owned_global_begin", C.c_int),
     ]
 
 

@@ -217,6 +217,12 @@ struct des_dev {
 
     // domain decomposition (des_halo): owned nodes [o0, o1), halo lists, exchange buffers
     int o0, o1, nn_global;
+    // the partition-independent residual of the pseudo-transient loop (des_params.h: DES_RES_BLOCK): global id of the first
+    // owned node, this rank's first block / block count, the global block count; res_gidx[i] = engine index of the i-th
+    // owned node in ascending global id; res_blocks = the GLOBAL block array (own part written here, the rest received)
+    int g0, res_b0, res_nb_own, res_nb_global;
+    int *res_gidx;
+    double *res_blocks;
     int nnbr;
     std::vector<int> nbr_rank, send_ptr, recv_ptr;         // host copies of the list offsets
     int *d_send_idx, *d_recv_idx;
@@ -291,6 +297,7 @@ namespace des_hip {
 #include "passes/small_kernels.hpp"
 #include "engine/patch.hpp"
 #include "engine/launch.hpp"
+#include "engine/residual.hpp"
 #include "engine/exchange.hpp"
 #include "engine/order.hpp"
 
@@ -425,6 +432,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     h->pending_c = true;
     h->const_mass = params->is_quasi_static && params->nmat == 1;
     h->o0 = 0; h->o1 = nn; h->nn_global = nn; h->nnbr = 0; h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
+    h->g0 = 0; h->res_gidx = nullptr; h->res_blocks = nullptr;
 
 #define CK(x) do { int rc_ = (x); if (rc_ != DES_OK) { *err = rc_; des_dev_destroy(h); return nullptr; } } while (0)
 #define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_last_error = std::string(#x) + ": " + hipGetErrorString(e_); \
@@ -582,6 +590,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     h->n3_blocks = res_part_size(h);
     h->res_nb = 0;
     CK(dev_alloc(h->res_part, (size_t)h->n3_blocks));
+    CK(build_residual_blocks(h));
     {
         struct { void *p; size_t bytes; } zero[] = {
             {h->xt, sizeof(d4)*(size_t)nn}, {h->vm, sizeof(d4)*(size_t)nn}, {h->ntmp, 8*(size_t)nn},
@@ -1350,13 +1359,10 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     if (!h || !halo) return DES_ERR_INTERNAL;
     D2_FORWARD(h, set_halo(h->d2, halo, nnode_global));
-    if (h->p.has_PT && (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn)) {
-        g_last_error = "control.has_PT on a decomposed mesh: the loop's residual test is global";
-        return DES_ERR_UNSUPPORTED;
-    }
     if (halo->owned_begin < 0 || halo->owned_end > h->nn || halo->owned_begin >= halo->owned_end) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     h->o0 = halo->owned_begin; h->o1 = halo->owned_end; h->nn_global = nnode_global;
+    h->g0 = (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn) ? halo->owned_global_begin : 0;
     h->nnbr = halo->nnbr;
     h->nbr_rank.assign(halo->nbr_rank, halo->nbr_rank + halo->nnbr);
     const int nq = halo->nnbr;
@@ -1909,7 +1915,7 @@ double des_dev_algorithmic_bytes_per_step(const des_dev *h)
 int des_dev_debug_stamps(int pass, unsigned long long *out, int cap)
 {
     const size_t n = (size_t)DES_STAMP_SLOTS * DES_STAMP_WG;
-    if (!out || pass < 0 || pass > 1 || (size_t)cap < n) return (int)n;
+    if (!out || pass < 0 || pass > 2 || (size_t)cap < n) return (int)n;
     hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(des_hip::g_stamps), n * sizeof(unsigned long long), (size_t)pass * n * sizeof(unsigned long long),
                             hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -46,6 +46,9 @@ static std::vector<int> split_nodes(const HostMesh &g, int nranks)
     for (int r = 1; r < nranks; ++r) {
         const long long target = total * r / nranks;
         while (n < g.nnode && g.sup_idx[n] < target) ++n;
+        // cuts at multiples of the residual's block size: a block of the partition-independent residual (des_params.h) has one owner
+        const int rb = des_res_block(g.nnode);
+        n = std::min(g.nnode, (n + rb - 1) / rb * rb);
         start[r] = n;
     }
     start[nranks] = g.nnode;
@@ -230,6 +233,7 @@ void build_partition(const HostMesh &g, int nranks, int rank, des_part &P)
     P.halo.owned_begin = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), a) - P.l2g_node.begin());
     P.halo.owned_end = (int)(std::lower_bound(P.l2g_node.begin(), P.l2g_node.end(), b) - P.l2g_node.begin());
     P.halo.nlayers = nlayers;
+    P.halo.owned_global_begin = a;
     P.halo.nnbr = (int)P.nbr_rank.size();
     P.halo.nbr_rank = P.nbr_rank.data();
     P.halo.send_ptr = P.send_ptr.data(); P.halo.send_idx = P.send_idx.data();

@@ -411,13 +411,23 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
     };
     int t = x * per + j;
     if (t < t_end) dma(t);
+#ifdef DES_STAMPS
+    unsigned long long st_wait = 0, st_issue = 0, st_gather = 0, st_body = 0, st_n = 0, st_a, st_b;
+    const unsigned long long st_begin = wall_clock64();
+#endif
     while (t < t_end) {
         const int e = t * DES_BLOCK + (int)threadIdx.x;
         const int tn = t + wx;
+#ifdef DES_STAMPS
+        st_a = wall_clock64();
+#endif
         // This tile's DMA has landed once at most the vector-memory operations issued BEHIND it are outstanding: the stores
         // of the tile before (at least 13: stress 6, strain 6, volume) -- or nothing, for the first tile.
         if (t == x * per + j) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else                  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#ifdef DES_STAMPS
+        st_b = wall_clock64(); st_wait += st_b - st_a; st_a = st_b;
+#endif
         E2Pre cur;
         cur.cn = lcn[w][lane]; cur.mono = lmono[w][lane]; cur.top = ltop[w][lane];
 #pragma unroll
@@ -432,6 +442,11 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tn < t_end) dma(tn);
         asm volatile("" ::: "memory");
+#ifdef DES_STAMPS
+        st_b = wall_clock64(); st_issue += st_b - st_a; st_a = st_b;
+        if (tn < t_end) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gathers have arrived
+        st_b = wall_clock64(); st_gather += st_b - st_a; st_a = st_b;
+#endif
         bool defer = false;
         if (valid)
             defer = e2_element<M, 0, 1, 0, RH, 1>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
@@ -439,8 +454,18 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
         // the count of elements past the yield pre-filter (des_scalars::n_return_mapping): one atomic per wavefront that has any
         const unsigned long long mask = __ballot(defer);
         if (defer && lane == __ffsll((long long)mask) - 1) atomicAdd(count, __popcll(mask));
+#ifdef DES_STAMPS
+        st_b = wall_clock64(); st_body += st_b - st_a; ++st_n;
+#endif
         t = tn;
     }
+#ifdef DES_STAMPS
+    if (lane == 0 && blockIdx.x * NW + w < DES_STAMP_WG) {
+        const int q = blockIdx.x * NW + w;
+        g_stamps[2][0][q] = st_begin; g_stamps[2][1][q] = wall_clock64(); g_stamps[2][2][q] = st_wait; g_stamps[2][3][q] = st_issue;
+        g_stamps[2][4][q] = st_gather; g_stamps[2][5][q] = st_body; g_stamps[2][6][q] = st_n;
+    }
+#endif
 }
 
 // Second pass: the elements the first pass set aside, full stress update with the return mapping

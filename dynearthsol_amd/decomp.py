@@ -127,16 +127,49 @@ def init_rank(engine, part, comm):
     return comm.reduce_dt(engine, recompute=True)
 
 
+def res_nblocks(nnode_global):
+    """blocks of the partition-independent residual (des_params.h: des_res_block)"""
+    b = 64 if nnode_global >= 64 * 64 else 1
+    return (nnode_global + b - 1) // b
+
+
+def pt_converged(l2, l2_old, tol):
+    """the reference's test (dynearthsol.cxx:829-833), on the value every rank holds"""
+    return abs((l2 - l2_old) / l2_old) < tol
+
+
 class PhasedStepper:
-    """The two phases of a step with the ghost-region exchange in between (des_params.h)."""
+    """The two phases of a step with the ghost-region exchange in between (des_params.h).  With control.has_PT phase 0
+    stops in front of the pseudo-transient loop (returns 2) and the loop runs here: ghost region refreshed, one iteration
+    (phase 2), the residual's block partials put together across ranks, the reference's convergence test; phase 3 is the
+    rest of phase 0."""
 
     def __init__(self, engine, part, comm):
         self.engine, self.part, self.comm = engine, part, comm
+        self.n_pt_iterations = 0
+
+    def pt_loop(self):
+        e, p = self.engine, self.part
+        par = p.params
+        l2_old = self.comm.residual(self)
+        for _ in range(int(par.PT_max_iter)):
+            self.comm.exchange(self)
+            if p.ndims == 2:
+                self.comm.reduce_wall(e)
+            e.phase(2)
+            l2 = self.comm.residual(self)
+            self.n_pt_iterations += 1
+            if pt_converged(l2, l2_old, par.PT_relative_tolerance):
+                break
+            l2_old = l2
+        e.phase(3)
 
     def step(self, nsteps):
         e = self.engine
+        self.n_pt_iterations = 0
         for _ in range(nsteps):
-            e.phase(0)
+            if e.phase(0) == 2:
+                self.pt_loop()
             self.comm.exchange(self)
             if self.part.ndims == 2:
                 self.comm.reduce_wall(e)
@@ -164,6 +197,16 @@ class LoopbackComm:
                 st.engine.halo_unpack(0, idx, nbuf)
                 st.engine.halo_unpack(1, eidx, ebuf)
 
+    def residual_all(self):
+        """every rank's block partials into the global array, then the fixed-shape sum on every rank: one value"""
+        blocks = np.zeros(res_nblocks(self.steppers[0].part.host.nnode))
+        for st in self.steppers:
+            first, vals = st.engine.residual_blocks()
+            blocks[first:first + len(vals)] = vals
+        l2 = [st.engine.residual_set(blocks) for st in self.steppers]
+        assert all(x == l2[0] for x in l2)
+        return l2[0]
+
     def reduce_wall_all(self):
         red = np.array([st.engine.wall_get() for st in self.steppers]).max(axis=0)
         for st in self.steppers:
@@ -177,8 +220,25 @@ class LoopbackComm:
 
 def run_loopback(steppers, nsteps):
     comm = LoopbackComm(steppers)
+    two_d = steppers[0].part.ndims == 2
+    par = steppers[0].part.params
+    for st in steppers: st.n_pt_iterations = 0
     for _ in range(nsteps):
-        for st in steppers: st.engine.phase(0)
+        flags = [st.engine.phase(0) for st in steppers]
+        if any(f == 2 for f in flags):               # the pseudo-transient loop, all ranks in step (PhasedStepper.pt_loop)
+            assert all(f == 2 for f in flags)
+            l2_old = comm.residual_all()
+            for _ in range(int(par.PT_max_iter)):
+                comm.exchange_all()
+                if two_d:
+                    comm.reduce_wall_all()
+                for st in steppers: st.engine.phase(2)
+                l2 = comm.residual_all()
+                for st in steppers: st.n_pt_iterations += 1
+                if pt_converged(l2, l2_old, par.PT_relative_tolerance):
+                    break
+                l2_old = l2
+            for st in steppers: st.engine.phase(3)
         comm.exchange_all()
         if steppers[0].part.ndims == 2:
             comm.reduce_wall_all()
@@ -215,6 +275,16 @@ class TorchComm:
         t = self.torch.from_numpy(engine.wall_get())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         engine.wall_set(t.numpy())
+
+    def residual(self, stepper):
+        """the partition-independent residual: every block has one owner, so a SUM of the zero-filled global arrays puts the
+        partials together exactly (x + 0 = x); the fixed-shape sum then runs on every rank"""
+        first, vals = stepper.engine.residual_blocks()
+        blocks = np.zeros(res_nblocks(stepper.part.host.nnode))
+        blocks[first:first + len(vals)] = vals
+        t = self.torch.from_numpy(blocks)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return stepper.engine.residual_set(t.numpy())
 
     def reduce_dt(self, engine, recompute):
         t = self.torch.from_numpy(engine.dt_partials(recompute))

@@ -191,7 +191,19 @@ typedef struct des_halo {
     const int *recv_idx;             /* local ids of GHOST nodes owned by each neighbour, ascending */
     const int *esend_ptr, *esend_idx;/* local ids of elements whose state each neighbour needs      */
     const int *erecv_ptr, *erecv_idx;/* local ids of stale-layer elements, by the rank that sends   */
+    int owned_global_begin;          /* global id of the first owned node (a multiple of des_res_block(nnode_global)) */
 } des_halo;
+
+/* The residual of calculate_residual_force (fields.cxx:700-722) where a DECISION hangs on it -- the pseudo-transient loop's
+ * convergence test (dynearthsol.cxx:803-864) and initial_body_force_adjustment's -- is summed in ONE association whatever
+ * the partition (the reference's OpenMP reduction leaves the order open): block b = the global node ids [B b, B b + B),
+ * P_b = the nodes' terms ((fr_0^2 / num + fr_1^2 / num) + fr_2^2 / num) added one after the other in ascending id from 0.0;
+ * the squared residual = the P_b reduced in a fixed shape over the GLOBAL block array (256 strided serial sums, then a
+ * pairwise tree).  B = des_res_block(nnode_global): 64, or 1 on meshes too small to be cut at multiples of 64.  Slabs are
+ * cut at multiples of B (des_host_partition), so every block belongs to one rank, and engine and oracle use the same
+ * shape: the same bits, the same decision, on 1 or N ranks. */
+#define DES_RES_BLOCK 64
+static inline int des_res_block(int nnode_global) { return nnode_global >= 64 * DES_RES_BLOCK ? DES_RES_BLOCK : 1; }
 
 /* The exchange of a step (after the surface heights are committed, before the end-of-step
  * geometry pass): widths in doubles per node / per element. */

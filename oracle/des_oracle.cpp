@@ -80,6 +80,8 @@ struct des_oracle {
     bool pt_jump = false;               // Param::control.PT_jump while the pseudo-transient loop runs
     bool body_force_adjustment = false; // Param::ic.has_body_force_adjustment while initial_body_force_adjustment runs (fields.cxx:690)
     long long n_pt_iterations = 0;      // iterations taken since the last des_oracle_step call began
+    int g0 = 0;                         // global id of the first owned node (des_halo::owned_global_begin)
+    std::vector<double> res_blocks;     // [global residual blocks] partials of the partition-independent residual (des_params.h)
     int n_return_mapping = 0;           // elements past the yield pre-filter in the last update_stress
     // topology
     ivec conn;                          // [NPE][ne]
@@ -1475,15 +1477,56 @@ void update_force(des_oracle &o)
     apply_damping(o);
 }
 
-// fields.cxx:700-722
+// fields.cxx:700-722.  The reference sums with an OpenMP reduction, i.e. in no particular order; where a decision hangs on the
+// value (the pseudo-transient loop) the sum is formed in ONE association whatever the partition -- des_params.h, DES_RES_BLOCK:
+// per block of B consecutive GLOBAL node ids the nodes' terms one after the other, then the blocks in a fixed shape.
+// residual_blocks_local: the partials of the blocks this rank owns, into their places of the global array.
+int residual_nblocks(const des_oracle &o) { const int B = des_res_block(o.nn_global); return (o.nn_global + B - 1) / B; }
+
+void residual_blocks_local(des_oracle &o)
+{
+    const int B = des_res_block(o.nn_global);
+    const double num = (double)o.nn_global * ND;
+    o.res_blocks.assign((size_t)residual_nblocks(o), 0.0);
+    for (int i = o.o0; i < o.o1; ++i) {
+        const int g = o.g0 + (i - o.o0);           // local numbering is ascending global order
+        double t = std::pow(o.force_residual[i], 2) / num;
+        for (int j = 1; j < ND; ++j) t += std::pow(o.force_residual[j*o.nn+i], 2) / num;
+        o.res_blocks[g / B] += t;
+    }
+}
+
+// the fixed shape over the global block array: 256 strided serial sums, then a pairwise tree (what the device's
+// k_residual_final does with its 256 lanes)
+double residual_final(const double *blocks, int nb)
+{
+    double s[256];
+    for (int j = 0; j < 256; ++j) {
+        double t = 0;
+        for (int i = j; i < nb; i += 256) t += blocks[i];
+        s[j] = t;
+    }
+    for (int off = 128; off > 0; off >>= 1)
+        for (int j = 0; j < off; ++j) s[j] += s[j + off];
+    return s[0];
+}
+
 double calculate_residual_force(des_oracle &o)
 {
+    residual_blocks_local(o);
+    if (o.o0 == 0 && o.o1 == o.nn && o.nn == o.nn_global) {
+        const double l2 = residual_final(o.res_blocks.data(), (int)o.res_blocks.size());
+        o.l2_part = l2;
+        return std::sqrt(l2);
+    }
+    // a rank of a decomposed run: its own nodes only (summed over ranks before the root; the pseudo-transient loop's
+    // driver takes the block partials instead: des_oracle_residual_blocks / des_oracle_residual_set)
     double l2 = 0.0;
     double num = (double)o.nn_global * ND;
     for (int i = o.o0; i < o.o1; ++i)
         for (int j = 0; j < ND; ++j)
             l2 += std::pow(o.force_residual[j*o.nn+i], 2) / num;
-    o.l2_part = l2;                      // summed over ranks before the root in a decomposed run
+    o.l2_part = l2;
     return std::sqrt(l2);
 }
 
@@ -2293,28 +2336,35 @@ int isostasy_phase(des_oracle &o, int phase)
 // repeated with the boundaries at rest (PT_jump: bc.cxx:330-343) and without surface processes
 // (update_mesh, dynearthsol.cxx:456-461) until the residual stops changing.  Not restated: the
 // mesh-quality check inside the loop (:839-859), which can only end in remesh().
+// one iteration (on a decomposed mesh: the ghost region refreshed just before)
+void pt_iteration(des_oracle &o)
+{
+    const des_params &p = o.p;
+    apply_vbcs(o);
+    if (p.has_moving_mesh) {
+        update_coordinate(o);                  // update_mesh with PT_jump: no surface_processes
+        o.volume.swap(o.volume_old);
+        compute_volume(o, o.volume);
+        refresh_elem_cache(o);
+        compute_mass(o);
+    }
+    update_strain_rate(o);
+    compute_dvoldt(o);
+    compute_edvoldt(o);
+    update_stress(o);
+    update_force(o);
+    update_velocity(o);
+    o.l2_residual = calculate_residual_force(o);
+    ++o.n_pt_iterations;
+}
+
 void pt_loop(des_oracle &o)
 {
     const des_params &p = o.p;
     double residual_old = o.l2_residual;
     o.pt_jump = true;
     for (int pt_step = 0; pt_step < p.PT_max_iter; ++pt_step) {
-        apply_vbcs(o);
-        if (p.has_moving_mesh) {
-            update_coordinate(o);                  // update_mesh with PT_jump: no surface_processes
-            o.volume.swap(o.volume_old);
-            compute_volume(o, o.volume);
-            refresh_elem_cache(o);
-            compute_mass(o);
-        }
-        update_strain_rate(o);
-        compute_dvoldt(o);
-        compute_edvoldt(o);
-        update_stress(o);
-        update_force(o);
-        update_velocity(o);
-        o.l2_residual = calculate_residual_force(o);
-        ++o.n_pt_iterations;
+        pt_iteration(o);
         double relative_change = std::fabs((o.l2_residual - residual_old) / residual_old);
         if (relative_change < p.PT_relative_tolerance) break;
         residual_old = o.l2_residual;
@@ -2344,13 +2394,27 @@ int step_phase(des_oracle &o, int phase)
         update_force(o);
         update_velocity(o);
         o.l2_residual = calculate_residual_force(o);
-        if (p.has_PT) pt_loop(o);
+        if (p.has_PT) {
+            if (o.o0 > 0 || o.o1 < o.nn || o.nn != o.nn_global) {
+                // a rank of a decomposed run: the loop is the caller's (ghost region refreshed and the residual's block
+                // partials put together across ranks every iteration: des_params.h) -- phase 2 = one iteration, 3 = the rest
+                o.pt_jump = true;
+                return 2;
+            }
+            pt_loop(o);
+        }
+        // fall through
+    case 3:
+        o.pt_jump = false;
         apply_vbcs(o);
         if (p.has_moving_mesh) {
             update_coordinate(o);
             surface_processes_a(o);
         }
         return 0;                                   // -> exchange of the ghost region
+    case 2:
+        pt_iteration(o);
+        return 0;
     case 1:
         if (p.has_moving_mesh)
             update_mesh_b(o);
@@ -2607,8 +2671,35 @@ int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, d
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global)
 {
     if (owned_begin < 0 || owned_end > h->nn || owned_begin > owned_end) return DES_ERR_INTERNAL;
-    if (h->p.has_PT && (owned_begin > 0 || owned_end < h->nn)) return DES_ERR_UNSUPPORTED;   // the loop's residual is global
     h->o0 = owned_begin; h->o1 = owned_end; h->nn_global = nnode_global;
+    return DES_OK;
+}
+
+// des_halo::owned_global_begin: where this rank's owned nodes sit in the global numbering (the residual's blocks)
+int des_oracle_set_owned_global(des_oracle *h, int owned_global_begin) { h->g0 = owned_global_begin; return DES_OK; }
+
+// The partition-independent residual across ranks (des_params.h: DES_RES_BLOCK): this rank's block partials -- first = the
+// global index of its first block --, and, once the caller has put every rank's together, the fixed-shape sum: sets and
+// returns l2_residual.
+int des_oracle_residual_blocks(des_oracle *h, double *out, int cap, int *first, int *count)
+{
+    des_oracle &o = *h;
+    const int B = des_res_block(o.nn_global);
+    residual_blocks_local(o);
+    const int b0 = o.g0 / B, nown = o.o1 - o.o0, nb = (nown + B - 1) / B;
+    if (first) *first = b0;
+    if (count) *count = nb;
+    if (!out || cap < nb) return DES_ERR_INTERNAL;
+    for (int k = 0; k < nb; ++k) out[k] = o.res_blocks[(size_t)b0 + k];
+    return DES_OK;
+}
+
+int des_oracle_residual_set(des_oracle *h, const double *blocks, int nblocks, double *l2)
+{
+    if (!blocks || nblocks != residual_nblocks(*h)) return DES_ERR_INTERNAL;
+    h->l2_part = residual_final(blocks, nblocks);
+    h->l2_residual = std::sqrt(h->l2_part);
+    if (l2) *l2 = h->l2_residual;
     return DES_OK;
 }
 

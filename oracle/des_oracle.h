@@ -31,6 +31,13 @@ int des_oracle_mesh_quality(des_oracle *h, double smallest_vol, double bottom, d
  * (what = 1) state by local index list, compute_dt across ranks */
 int des_oracle_set_halo(des_oracle *h, int owned_begin, int owned_end, int nnode_global);
 int des_oracle_phase(des_oracle *h, int phase);
+/* with control.has_PT on a decomposed mesh phase 0 stops in front of the pseudo-transient loop and returns 2; the caller
+ * then runs the loop: refresh the ghost region, phase 2 (one iteration), the residual put together across ranks
+ * (des_oracle_residual_blocks -> all ranks' partials in global block order -> des_oracle_residual_set), the reference's
+ * convergence test; phase 3 = the rest of phase 0.  Same protocol as include/des_dev.h. */
+int des_oracle_set_owned_global(des_oracle *h, int owned_global_begin);
+int des_oracle_residual_blocks(des_oracle *h, double *out, int cap, int *first, int *count);
+int des_oracle_residual_set(des_oracle *h, const double *blocks, int nblocks, double *l2);
 /* 1: des_oracle_step / des_oracle_phase run the body of isostasy_adjustment's loop
  * (dynearthsol.cxx:506-539) instead of a time step; 0: back to time steps. */
 int des_oracle_set_isostasy(des_oracle *h, int on);

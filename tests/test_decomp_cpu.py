@@ -123,21 +123,62 @@ def test_decomposed_oracle_random_option_combinations(seed):
         assert np.array_equal(assemble(parts, [e.download(f) for e in engines], c, host.nelem, "elem"), ref.download(f)), (f, ov)
 
 
-def _gloo_worker(rank, world, port, nsteps, out_dir):
+PT_OV = "control.has_PT = yes\ncontrol.PT_max_iter = 40\ncontrol.PT_relative_tolerance = %s\ncontrol.has_moving_mesh = %s\n"
+
+
+@pytest.mark.parametrize("ndims,nranks,tol,moving", [(3, 2, "1e-2", "yes"), (3, 3, "1e-4", "yes"), (3, 4, "1e-4", "no"), (2, 3, "1e-3", "yes")])
+def test_pseudo_transient_loop_on_a_decomposed_mesh(ndims, nranks, tol, moving):
+    """control.has_PT (dynearthsol.cxx:803-864) on N ranks: the ghost region refreshed before every iteration, the residual
+    put together across ranks in global block order (des_params.h: DES_RES_BLOCK), so that every rank -- and a run on one
+    rank -- takes the same decision.  Same iteration counts, same bits as the single-domain oracle."""
+    kw = dict(cfgs.EP, res=1e3) if ndims == 2 else cfgs.EP
+    host = des.Host(cfg_text=cfgs.make(**kw), overrides=PT_OV % (tol, moving), **({"ndims": 2} if ndims == 2 else {}))
+    parts = [Partition(host, nranks, r) for r in range(nranks)]
+    ref = OracleEngine(host)
+    dt_ref = ref.init_from_host(host)
+    engines = [OracleEngine(_LocalMeshHost(p)) for p in parts]
+    steppers = [PhasedStepper(e, p, None) for e, p in zip(engines, parts)]
+    comm = LoopbackComm(steppers)
+    from dynearthsol_amd.decomp import init_rank_mesh, init_rank_fields
+    for e, p in zip(engines, parts):
+        init_rank_mesh(e, p)
+    if ndims == 2:
+        comm.reduce_wall_all()
+    for e, p in zip(engines, parts):
+        init_rank_fields(e, p)
+    assert all(d == dt_ref for d in comm.reduce_dt_all(recompute=True))
+    total = 0
+    for n in (1, 4, 8):                                  # crosses step 10 (compute_dt)
+        so = ref.step(n)
+        run_loopback(steppers, n)
+        assert all(st.n_pt_iterations == so.n_pt_iterations > 0 for st in steppers)
+        assert all(e.step(0).l2_residual == so.l2_residual for e in engines)      # one association, whatever the partition
+        total += so.n_pt_iterations
+        nf, ef = (NODE_FIELDS_2D, ELEM_FIELDS_2D) if ndims == 2 else (NODE_FIELDS, ELEM_FIELDS)
+        for f, c in nf:
+            assert np.array_equal(assemble(parts, [e.download(f) for e in engines], c, host.nnode, "node"), ref.download(f)), f
+        for f, c in ef:
+            assert np.array_equal(assemble(parts, [e.download(f) for e in engines], c, host.nelem, "elem"), ref.download(f)), f
+    assert total >= 13
+
+
+def _gloo_worker(rank, world, port, nsteps, out_dir, overrides=None):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    host = des.Host(cfg_text=cfgs.make(**cfgs.EVP))
+    host = des.Host(cfg_text=cfgs.make(**(cfgs.EP if overrides else cfgs.EVP)), overrides=overrides)
     part = Partition(host, world, rank)
     eng = OracleEngine(_LocalMeshHost(part))
     comm = TorchComm(dist)
     dt = init_rank(eng, part, comm)
-    PhasedStepper(eng, part, comm).step(nsteps)
+    stepper = PhasedStepper(eng, part, comm)
+    stepper.step(nsteps)
     o0, o1 = part.owned
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dt0=dt, dt=eng.step(0).dt,
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), dt0=dt, dt=eng.step(0).dt, n_pt=stepper.n_pt_iterations,
+             l2=eng.step(0).l2_residual,
              nodes=part.l2g_node[o0:o1], elems=part.l2g_elem[part.elem_owned],
              vel=eng.download("VEL").reshape(3, -1)[:, o0:o1],
              T=eng.download("TEMPERATURE")[o0:o1], stress=eng.download("STRESS").reshape(6, -1)[:, part.elem_owned])
@@ -158,6 +199,27 @@ def test_two_ranks_over_gloo_match_one_rank(tmp_path):
     for r in range(world):
         d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert d["dt0"] == dt0 and d["dt"] == sc.dt
+        assert np.array_equal(d["vel"], vel[:, d["nodes"]])
+        assert np.array_equal(d["T"], T[d["nodes"]])
+        assert np.array_equal(d["stress"], stress[:, d["elems"]])
+
+
+def test_pseudo_transient_loop_two_ranks_over_gloo(tmp_path):
+    """the same loop with one process per rank: the exchange per iteration and the residual's all-reduce over torch.distributed"""
+    import torch.multiprocessing as mp
+    nsteps, world = 6, 2
+    ov = PT_OV % ("1e-4", "yes")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_gloo_worker, args=(world, port, nsteps, str(tmp_path), ov), nprocs=world, join=True)
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=ov)
+    ref = OracleEngine(host)
+    dt0 = ref.init_from_host(host)
+    sc = ref.step(nsteps)
+    vel, T, stress = ref.download("VEL").reshape(3, -1), ref.download("TEMPERATURE"), ref.download("STRESS").reshape(6, -1)
+    assert sc.n_pt_iterations > nsteps
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert d["dt0"] == dt0 and d["dt"] == sc.dt and d["n_pt"] == sc.n_pt_iterations and d["l2"] == sc.l2_residual
         assert np.array_equal(d["vel"], vel[:, d["nodes"]])
         assert np.array_equal(d["T"], T[d["nodes"]])
         assert np.array_equal(d["stress"], stress[:, d["elems"]])

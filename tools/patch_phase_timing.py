@@ -85,6 +85,22 @@ def main():
                 continue
             d = (t[b] - t[a])[ok]
             print("    %-52s %6.2f (%5.2f / %5.2f / %5.2f)" % (label, d.mean(), *np.percentile(d, [10, 50, 90])))
+    # the pipelined stress update: per wavefront, sums over its tiles
+    buf = np.zeros(SLOTS * WG, dtype=np.uint64)
+    if lib.des_dev_debug_stamps(2, buf.ctypes.data, buf.size) == buf.size:
+        t = buf.reshape(SLOTS, WG).astype(np.float64)
+        live = t[6] > 0
+        if live.any():
+            t = t[:, live]
+            ntile = t[6]
+            life = (t[1] - t[0]) * 0.01
+            print("E2<GEO> pipelined: %d wavefronts, %.1f tiles each (%d..%d), life %.1f us (p10 %.1f / p90 %.1f), span %.1f us"
+                  % (t.shape[1], ntile.mean(), ntile.min(), ntile.max(), life.mean(), *np.percentile(life, [10, 90]),
+                     (t[1].max() - t[0].min()) * 0.01))
+            for label, k in (("wait for this tile's DMA", 2), ("LDS reads, gathers issued, next DMA issued", 3), ("wait for the gathers", 4),
+                             ("arithmetic + stores issued", 5)):
+                d = t[k] * 0.01 / ntile
+                print("    %-52s %6.2f us per tile (%5.2f / %5.2f / %5.2f)" % (label, d.mean(), *np.percentile(d, [10, 50, 90])))
     dev.close()
 
 
