@@ -997,7 +997,28 @@ inline bool step_overlapped(const des_dev *h, const StepPlan &c)
 
 // Step i of the call up to the committed surface heights.  *whole = true: the step was replayed from a
 // hipGraph, end-of-step pass and compute_dt included (single GPU only) -- nothing is left to do for it.
-int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, bool *whole)
+// the rest of step_front behind the force pass (and the pseudo-transient loop, if any)
+int step_front_tail(des_dev *h, const StepPlan &c, int i, long long step_no)
+{
+    const int nsteps = c.nsteps;
+    if (s2_defer_ok(h, i < nsteps - 1, step_no)) {
+        // no S2 / S3 launch: the next step's EN1 and E2 do the surface step of this one; with diffusion switched off
+        // there is nothing to do at all (dh = 0: heights, dhacc and edvacc_surf keep their values)
+        h->s2_pending = surface_diffusion_on(h);
+        h->s2_skipped = true;
+        return DES_OK;
+    }
+    h->s2_skipped = false;
+    launch_s2(h, step_no);
+    // decomposed: only the commit of the surface heights -- the rest of S3 reads the ghost nodes' dh
+    if (c.multi) launch_s3(h, true, false, false);
+    else         launch_s3(h, true, true, true);
+    return DES_OK;
+}
+
+// pt_pending != nullptr (des_dev_step_group): with control.has_PT the front stops behind the force pass -- the loop runs for
+// all engines of the group in lockstep (pt_loop_group), step_front_tail follows
+int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, bool *whole, bool *pt_pending = nullptr)
 {
     int rc;
     const int nsteps = c.nsteps;
@@ -1072,20 +1093,12 @@ int step_front(des_dev *h, const StepPlan &c, int i, long long *step_no_out, boo
     }
     if (c.nmd) launch_n2(h);
     launch_force_pass(h);
-    if (h->p.has_PT && !c.iso && (rc = pt_loop(h))) return rc;
-    if (s2_defer_ok(h, i < nsteps - 1, step_no)) {
-        // no S2 / S3 launch: the next step's EN1 and E2 do the surface step of this one; with diffusion switched off
-        // there is nothing to do at all (dh = 0: heights, dhacc and edvacc_surf keep their values)
-        h->s2_pending = surface_diffusion_on(h);
-        h->s2_skipped = true;
-        return DES_OK;
+    if (pt_pending) *pt_pending = false;
+    if (h->p.has_PT && !c.iso) {
+        if (pt_pending) { *pt_pending = true; return DES_OK; }
+        if ((rc = pt_loop(h))) return rc;
     }
-    h->s2_skipped = false;
-    launch_s2(h, step_no);
-    // decomposed: only the commit of the surface heights -- the rest of S3 reads the ghost nodes' dh
-    if (c.multi) launch_s3(h, true, false, false);
-    else         launch_s3(h, true, true, true);
-    return DES_OK;
+    return step_front_tail(h, c, i, step_no);
 }
 
 // The rest of step i, once the exchange has been issued (decomposed meshes).  Returns through *do_dt
@@ -1279,19 +1292,32 @@ int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out)
         hipSetDevice(h->device);
         refresh_props(h);
         step_plan(h, nsteps, plan[k]);
-        if (plan[k].graphs || plan[k].pgraphs || h->p.has_PT) { g_last_error = "des_dev_step_group: decomposed engines only (no hipGraph replay, no PT loop)"; return DES_ERR_UNSUPPORTED; }
+        if (plan[k].graphs || plan[k].pgraphs) { g_last_error = "des_dev_step_group: decomposed engines only (no hipGraph replay)"; return DES_ERR_UNSUPPORTED; }
     }
     int rc;
     auto abort_all = [&](int code) { for (int k = 0; k < n; ++k) step_abort(engines[k], code); return code; };
     std::vector<long long> step_no((size_t)n);
     for (int i = 0; i < nsteps; ++i) {
         bool any_dt = false;
+        bool any_pt = false;
         for (int k = 0; k < n; ++k) {                  // every engine's step up to its packed messages
             des_dev *h = engines[k];
-            bool whole;
+            bool whole, pt = false;
             hipSetDevice(h->device);
-            if ((rc = step_front(h, plan[k], i, &step_no[k], &whole))) return abort_all(rc);
-            if (plan[k].multi && (rc = exchange_local_pack(h))) return abort_all(rc);
+            if ((rc = step_front(h, plan[k], i, &step_no[k], &whole, &pt))) return abort_all(rc);
+            any_pt = any_pt || pt;
+            if (!pt && plan[k].multi && (rc = exchange_local_pack(h))) return abort_all(rc);
+        }
+        if (any_pt) {
+            // control.has_PT: the fronts have stopped behind the force pass; the loop for all engines in lockstep (a ghost
+            // refresh and one residual per iteration), then the rest of every front and its messages
+            if ((rc = pt_loop_group(engines, n, true))) return abort_all(rc);
+            for (int k = 0; k < n; ++k) {
+                des_dev *h = engines[k];
+                hipSetDevice(h->device);
+                if ((rc = step_front_tail(h, plan[k], i, step_no[k]))) return abort_all(rc);
+                if (plan[k].multi && (rc = exchange_local_pack(h))) return abort_all(rc);
+            }
         }
         for (int k = 0; k < n; ++k) {                  // the messages change hands; the rest of the step
             des_dev *h = engines[k];
@@ -1332,7 +1358,11 @@ int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
     if (h) h->finished = false;            // (fresh_ok: the next des_dev_step call starts with the classic first step)
     if (!h) return DES_ERR_INTERNAL;
     D2_FORWARD(h, body_force_adjustment(h->d2, out));
-    if (h->nnbr > 0 || h->group) { g_last_error = "the initial body-force adjustment's residual test is global: single domain only"; return DES_ERR_UNSUPPORTED; }
+    if (h->group) { g_last_error = "this engine belongs to a group: des_dev_body_force_adjustment_group"; return DES_ERR_INTERNAL; }
+    if (h->nnbr > 0 && !(h->comm && h->comm_size > 1)) {
+        g_last_error = "the initial body-force adjustment on a decomposed mesh: through RCCL (des_dev_comm_init) or des_dev_body_force_adjustment_group";
+        return DES_ERR_UNSUPPORTED;
+    }
     hipSetDevice(h->device);
     refresh_props(h);
     h->n_pt_iterations = 0;
@@ -1343,14 +1373,53 @@ int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
         rc = pt_loop(h, false);
         HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &off, sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (rc) return rc;
+        if (h->nnbr > 0 && (rc = exchange(h))) return rc;      // the ghost region as the last iteration left the owners
         // (the loop leaves the masses of its last update_mesh in the element records: gathered as after a step)
         launch_mass_gather(h);
-    } else {
-        launch_s3(h, false, false, true);
-    }
+    } else if ((rc = residual_global(h))) return rc;
     if ((rc = sync_clock(h))) return rc;
     if (out) { fill_scalars(h, out); }
     return h->h_clk->status;
+}
+
+// ... for the engines of a group (des_dev_group_attach), in lockstep
+int des_dev_body_force_adjustment_group(des_dev **engines, int n, des_scalars *out)
+{
+    if (!engines || n < 1) return DES_ERR_INTERNAL;
+    for (int k = 0; k < n; ++k)
+        if (!engines[k] || engines[k]->d2 || engines[k]->group_n != n || engines[k]->group_rank != k) {
+            g_last_error = "des_dev_body_force_adjustment_group: not the group des_dev_group_attach was given (3-D engines)"; return DES_ERR_INTERNAL;
+        }
+    int rc;
+    static const int on = 1, off = 0;
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = engines[k];
+        hipSetDevice(h->device);
+        h->finished = false;
+        refresh_props(h);
+        h->n_pt_iterations = 0;
+        if (h->p.has_PT) HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &on, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    }
+    if (engines[0]->p.has_PT) {
+        if ((rc = pt_loop_group(engines, n, false))) return rc;
+        for (int k = 0; k < n; ++k) { hipSetDevice(engines[k]->device); if (engines[k]->nnbr > 0 && (rc = exchange_local_pack(engines[k]))) return rc; }
+        for (int k = 0; k < n; ++k) {
+            des_dev *h = engines[k];
+            hipSetDevice(h->device);
+            if (h->nnbr > 0 && (rc = exchange_local_take(h, h->stream))) return rc;
+            HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &off, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            launch_mass_gather(h);
+        }
+    } else if ((rc = residual_global_group(engines, n))) return rc;
+    int status = DES_OK;
+    for (int k = 0; k < n; ++k) {
+        des_dev *h = engines[k];
+        hipSetDevice(h->device);
+        if ((rc = sync_clock(h))) return rc;
+        if (out) fill_scalars(h, &out[k]);
+        if (h->h_clk->status) status = h->h_clk->status;
+    }
+    return status;
 }
 
 // ---- domain decomposition ---------------------------------------------------------
@@ -1420,6 +1489,39 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     choose_npb(h);
     h->n3_blocks = res_part_size(h);
     return dev_alloc(h->res_part, (size_t)h->n3_blocks);
+}
+
+// The partition-independent residual across ranks for a caller that moves the data itself (des_dev_phase; des_params.h:
+// DES_RES_BLOCK): this rank's block partials (first = global index of its first block), and -- every rank's put together in
+// global block order -- the fixed-shape sum, which sets and returns l2_residual.
+int des_dev_residual_blocks(des_dev *h, double *out, int cap, int *first, int *count)
+{
+    if (!h) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, residual_blocks(h->d2, out, cap, first, count));
+    hipSetDevice(h->device);
+    if (first) *first = h->res_b0;
+    if (count) *count = h->res_nb_own;
+    if (!out) return DES_OK;
+    if (cap < h->res_nb_own) return DES_ERR_INTERNAL;
+    launch_residual_blocks(h);
+    HIP_OK(hipMemcpyAsync(out, h->res_blocks + h->res_b0, (size_t)h->res_nb_own * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int des_dev_residual_set(des_dev *h, const double *blocks, int nblocks, double *l2)
+{
+    if (!h || !blocks) return DES_ERR_INTERNAL;
+    D2_FORWARD(h, residual_set(h->d2, blocks, nblocks, l2));
+    if (nblocks != h->res_nb_global) { g_last_error = "des_dev_residual_set: not the global block count"; return DES_ERR_INTERNAL; }
+    hipSetDevice(h->device);
+    HIP_OK(hipMemcpyAsync(h->res_blocks, blocks, (size_t)nblocks * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    launch_residual_final(h);
+    const int rc = sync_clock(h);
+    if (rc) return rc;
+    if (l2) *l2 = h->h_clk->l2_residual;
+    return DES_OK;
 }
 
 int des_dev_comm_unique_id(unsigned char *id128)
@@ -1537,6 +1639,23 @@ int des_dev_phase(des_dev *h, int phase)
         launch_e2(h);
         if (h->p.is_using_mixed_stress && !h->iso) launch_n2(h);
         launch_force_pass(h);
+        if (h->p.has_PT && !h->iso) {
+            // the pseudo-transient loop is the caller's (des_dev.h): ghost refresh, phase 2, the residual across ranks, the
+            // reference's test -- per iteration; phase 3 = the rest of this phase
+            h->n_pt_iterations = 0;
+            if (set_pt(h, 1)) return -DES_ERR_RESOURCE;
+            return 2;
+        }
+        launch_s2(h, h->steps_host);
+        launch_s3(h, true, false, false);
+        return 0;
+    case 2:
+        pt_iteration(h);
+        ++h->n_pt_iterations;
+        return 0;
+    case 3:
+        if (set_pt(h, 0)) return -DES_ERR_RESOURCE;
+        launch_vbcs_coord(h);                      // apply_vbcs + update_coordinate of the step itself
         launch_s2(h, h->steps_host);
         launch_s3(h, true, false, false);
         return 0;

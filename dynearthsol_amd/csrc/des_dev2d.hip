@@ -97,6 +97,10 @@ struct Engine {
     // domain decomposition (set_halo): this engine holds one node slab + its ghost region
     bool halo = false, halo_set = false;       // halo: the mesh has neighbours (set_halo with nnbr > 0)
     int o0 = 0, o1 = 0, nn_global = 0;         // owned nodes [o0, o1) of nn; the residual's divisor is global
+    // the partition-independent residual of the pseudo-transient loop (des_params.h: DES_RES_BLOCK; the 3-D engine's
+    // engine/residual.hpp): global id of the first owned node, the GLOBAL block array (own part computed, the rest received)
+    int g0 = 0;
+    double *res_blocks = nullptr; int res_nb_global = 0;
     int *top_pos = nullptr;                    // [nn] position of a node in top_nodes, -1 below the surface
     int nnbr = 0;
     std::vector<int> nbr_rank, send_ptr, recv_ptr, esend_ptr, erecv_ptr;
@@ -111,6 +115,7 @@ struct Engine {
     bool count_past = false;           // this step feeds des_scalars::n_return_mapping (the last one of a call)
     long long steps_host = 0;
     long long n_pt_iterations = 0;   // pseudo-transient iterations of the current step() call
+    bool pt_defer = false;           // step_front stops in front of the pseudo-transient loop (step_group, des_dev_phase)
     std::vector<void *> allocs;
     std::string err;
     // per-kernel HIP-event accounting of the main launches (des_dev_profile_enable / _read; off: no events at all)
@@ -120,6 +125,8 @@ struct Engine {
     double prof_ms[8] = {0};
     long long prof_calls[8] = {0};
 };
+
+static int exchange_rccl(Engine *h);       // (defined behind the anonymous namespace: the pseudo-transient loop on RCCL calls it)
 
 namespace {
 
@@ -943,6 +950,42 @@ __device__ __forceinline__ void residual_fin_block(int nb, const double *part, C
 }
 
 __global__ void k2_residual_fin(int nb, const double *part, Clock *clk) { residual_fin_block(nb, part, clk); }
+
+// The residual where a decision hangs on it (the pseudo-transient loop): ONE association whatever the partition -- per
+// block of B consecutive GLOBAL node ids the nodes' terms one after the other (one wavefront per block, lane 0's running sum
+// walks the lanes' terms in order), the blocks in a fixed shape over the global array (des_params.h: DES_RES_BLOCK).
+__global__ void __launch_bounds__(DES_BLOCK)
+k2_residual_blocks(int nown, int B, int nblocks, int nn, int o0, int nn_global, const double *fres, double *out)
+{
+    const int b = (int)(blockIdx.x * (DES_BLOCK / 64) + (threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    if (b >= nblocks) return;
+    const double num = (double)nn_global * 2;
+    const int i = b * B + lane;
+    double t = 0.0;
+    if (lane < B && i < nown) {
+        const double f0 = fres[o0 + i], f1 = fres[(size_t)nn + o0 + i];
+        t = f0 * f0 / num;
+        t += f1 * f1 / num;
+    }
+    double s = 0.0;
+    for (int k = 0; k < B; ++k) s += __shfl(t, k);
+    if (lane == 0) out[b] = s;
+}
+
+__global__ void __launch_bounds__(DES_BLOCK)
+k2_residual_final(Clock *clk, const double *blocks, int nb)
+{
+    __shared__ double red[DES_BLOCK];
+    double t = 0;
+    for (int i = threadIdx.x; i < nb; i += DES_BLOCK) t += blocks[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = DES_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { clk->l2_sum = red[0]; clk->l2_residual = sqrt(red[0]); }
+}
 
 // apply_vbcs, 2-D: vertical extent of the x0 wall (bc.cxx:251-290; only x0's is used, :292-300) over the list of
 // its nodes.  min / max: exact whatever the order.  One workgroup.
@@ -1942,28 +1985,78 @@ int set_pt(Engine *h, int on)
     return DES_OK;
 }
 
+// (re)built whenever the owned range is set: create (the whole mesh) and set_halo
+int build_residual_blocks(Engine *h)
+{
+    const int B = des_res_block(h->nn_global);
+    h->res_nb_global = (h->nn_global + B - 1) / B;
+    if (h->g0 % B != 0 || h->g0 / B + (h->o1 - h->o0 + B - 1) / B > h->res_nb_global) {
+        h->err = "des_halo::owned_global_begin is not a multiple of the residual's block size (des_params.h: des_res_block)";
+        return DES_ERR_INTERNAL;
+    }
+    int rc = dalloc(h, h->res_blocks, (size_t)h->res_nb_global);        // (an earlier array stays in h->allocs until destroy)
+    if (rc) return rc;
+    HIP2(hipMemsetAsync(h->res_blocks, 0, (size_t)h->res_nb_global * sizeof(double), h->stream));
+    return DES_OK;
+}
+
+// this rank's block partials into their places of the (zero-filled) global array
+void launch_residual_blocks(Engine *h)
+{
+    const int B = des_res_block(h->nn_global), nown = h->o1 - h->o0, nb_own = (nown + B - 1) / B;
+    if (nb_own < h->res_nb_global) hipMemsetAsync(h->res_blocks, 0, (size_t)h->res_nb_global * sizeof(double), h->stream);
+    hipLaunchKernelGGL(k2_residual_blocks, dim3((nb_own + DES_BLOCK / 64 - 1) / (DES_BLOCK / 64)), dim3(DES_BLOCK), 0, h->stream,
+                       nown, B, nb_own, h->nn, h->o0, h->nn_global, h->fres, h->res_blocks + h->g0 / B);
+}
+
+// the partition-independent residual on the engine's stream: one engine, or a rank on RCCL
+int residual_global(Engine *h)
+{
+    const int B = des_res_block(h->nn_global), nb_own = (h->o1 - h->o0 + B - 1) / B;
+    launch_residual_blocks(h);
+    if (nb_own < h->res_nb_global) {
+        if (!h->comm) { h->err = "the pseudo-transient loop on a decomposed mesh needs the ranks' residual partials: des_dev_step on RCCL, des_dev_step_group, or des_dev_phase + des_dev_residual_blocks / _set"; return DES_ERR_UNSUPPORTED; }
+        const ncclResult_t r = ncclAllReduce(h->res_blocks, h->res_blocks, (size_t)h->res_nb_global, ncclDouble, ncclSum, h->comm, h->stream);
+        if (r != ncclSuccess) { h->err = std::string("RCCL: ") + ncclGetErrorString(r); return DES_ERR_RESOURCE; }
+    }
+    hipLaunchKernelGGL(k2_residual_final, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->res_blocks, h->res_nb_global);
+    return DES_OK;
+}
+
+// one iteration of the pseudo-transient loop (on a decomposed mesh: the ghost region refreshed just before)
+template <class M>
+void pt_iteration(Engine *h)
+{
+    const des_params &p = h->p;
+    launch_vbcs(h);
+    if (p.has_moving_mesh) {
+        L2(k2_update_coord, 2 * h->nn, h->d_clk, 2 * h->nn, h->vel, h->coord);
+        std::swap(h->volume, h->volume_old);
+        refresh_props(h);
+        launch_volume_mass(h, true);
+    }
+    launch_mechanics<M>(h, false);
+}
+
 // The pseudo-transient loop of a step (dynearthsol.cxx:803-864): the quasi-static part of the step repeated
 // with the boundaries at rest (bc.cxx:330-343) and update_mesh without surface processes
 // (dynearthsol.cxx:456-461) until the relative change of the residual drops below the tolerance.  The host
-// joins the stream once per iteration for that decision, as the reference's loop does.
+// joins the stream once per iteration for that decision, as the reference's loop does.  A rank of a decomposed mesh on RCCL
+// (round 4): the ghost region (and the wall's extent) refreshed before every iteration, the residual the partition-
+// independent one, its block partials all-reduced -- every rank takes the decision a single engine takes.
 template <class M>
 int pt_loop(Engine *h)
 {
     const des_params &p = h->p;
     int rc;
-    if ((rc = sync_clock(h))) return rc;
+    const bool multi = h->halo && h->halo_set;
+    if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;
     double residual_old = h->h_clk->l2_residual;
     if ((rc = set_pt(h, 1))) return rc;
     for (int pt_step = 0; pt_step < p.PT_max_iter; ++pt_step) {
-        launch_vbcs(h);
-        if (p.has_moving_mesh) {
-            L2(k2_update_coord, 2 * h->nn, h->d_clk, 2 * h->nn, h->vel, h->coord);
-            std::swap(h->volume, h->volume_old);
-            refresh_props(h);
-            launch_volume_mass(h, true);
-        }
-        launch_mechanics<M>(h, false);
-        if ((rc = sync_clock(h))) return rc;
+        if (multi && (rc = exchange_rccl(h))) return rc;
+        pt_iteration<M>(h);
+        if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;
         ++h->n_pt_iterations;
         const double l2 = h->h_clk->l2_residual;
         const double relative_change = std::fabs((l2 - residual_old) / residual_old);
@@ -1972,6 +2065,8 @@ int pt_loop(Engine *h)
     }
     return set_pt(h, 0);
 }
+
+int step_front_rest(Engine *h);
 
 // A step up to the committed surface heights ...
 template <class M>
@@ -1992,7 +2087,21 @@ int step_front(Engine *h)
         L2(k2_temp_node, nn, h->d_p, h->d_clk, nn, ne, h->sup_idx, h->sup_arr, h->sup_lidx, h->bcflag, h->tmp_result, h->tmass, h->temperature);
     }
     launch_mechanics<M>(h, !h->iso && p.is_using_mixed_stress, thermal, tail);
-    if (!h->iso && p.has_PT) { int rc = pt_loop<M>(h); if (rc) return rc; }
+    if (!h->iso && p.has_PT) {
+        // (pt_defer: the loop is driven from outside -- the engines of a group in lockstep, or the caller of des_dev_phase --
+        //  and step_front_rest follows)
+        if (h->pt_defer) return DES_OK;
+        int rc = pt_loop<M>(h); if (rc) return rc;
+    }
+    return step_front_rest(h);
+}
+
+// ... the rest of the front, behind the pseudo-transient loop if there is one
+int step_front_rest(Engine *h)
+{
+    const des_params &p = h->p;
+    const int nn = h->nn;
+    const bool tail = h->patch && !h->iso && !p.has_PT && p.has_moving_mesh;
     if (h->iso) L2(k2_iso_vel, nn, h->d_p, nn, h->bcflag, h->vel);
     else if (!tail) launch_vbcs(h);
     if (p.has_moving_mesh || h->iso) {
@@ -2158,6 +2267,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->res_part, (size_t)nblk(nn)));
     A2(dalloc(h, h->neg_zmin, 1));
     A2(dalloc(h, h->d_red, 8));
+    A2(build_residual_blocks(h));
     {
         // node-block patches (des_dev2d_patch.hpp): clusters of 128 nodes along a Morton curve (of 64 where 128 do not fit the
         // LDS caps; runs of consecutive ids without coordinates or with DES2D_CLUSTER=0); DES2D_PATCH=<n>: n nodes per block
@@ -2393,7 +2503,6 @@ static int dt_allreduce(Engine *h, bool recompute)
 
 int set_comm(Engine *h, void *comm)
 {
-    if (comm && h->p.has_PT) { h->err = "control.has_PT on a decomposed mesh: the loop's residual test is global"; return DES_ERR_UNSUPPORTED; }
     h->comm = (ncclComm_t)comm;
     return DES_OK;
 }
@@ -2454,17 +2563,16 @@ int step(Engine *h, int nsteps, des_scalars *out)
 int body_force_adjustment(Engine *h, des_scalars *out)
 {
     HIP2(hipSetDevice(h->device));
-    if (h->halo) { h->err = "the initial body-force adjustment's residual test is global: single domain only"; return DES_ERR_UNSUPPORTED; }
+    if (h->halo && !h->comm) { h->err = "the initial body-force adjustment on a decomposed 2-D mesh: through RCCL (des_dev_comm_init)"; return DES_ERR_UNSUPPORTED; }
     refresh_props(h);
     h->n_pt_iterations = 0;
-    L2(k2_residual_part, h->o1 - h->o0, h->nn, h->o0, h->o1, h->nn_global, h->fres, h->res_part);
-    hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
     if (h->p.has_PT) {
         h->no_neumann = true;
-        const int rc = h->portable_libm ? pt_loop<desk::MathPortable>(h) : pt_loop<desk::MathOcml>(h);
+        int rc = h->portable_libm ? pt_loop<desk::MathPortable>(h) : pt_loop<desk::MathOcml>(h);
         h->no_neumann = false;
+        if (!rc && h->halo) rc = exchange_rccl(h);             // the ghost region as the last iteration left the owners
         if (rc) return rc;
-    }
+    } else { const int rc = residual_global(h); if (rc) return rc; }
     HIP2(hipGetLastError());
     if (out) return fill_scalars(h, out);
     return sync_clock(h);
@@ -2478,12 +2586,10 @@ int body_force_adjustment(Engine *h, des_scalars *out)
 int set_halo(Engine *h, const des_halo *halo, int nn_global)
 {
     HIP2(hipSetDevice(h->device));
-    if (h->p.has_PT && (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn)) {
-        h->err = "control.has_PT on a decomposed mesh: the loop's residual test is global";
-        return DES_ERR_UNSUPPORTED;
-    }
     if (halo->owned_begin < 0 || halo->owned_end > h->nn || halo->owned_begin >= halo->owned_end) return DES_ERR_INTERNAL;
     h->o0 = halo->owned_begin; h->o1 = halo->owned_end; h->nn_global = nn_global;
+    h->g0 = (halo->nnbr > 0 || halo->owned_begin > 0 || halo->owned_end < h->nn) ? halo->owned_global_begin : 0;
+    { const int rcb = build_residual_blocks(h); if (rcb) return rcb; }
     const int nq = h->nnbr = halo->nnbr;
     h->halo_set = true; h->halo = nq > 0;
     h->nbr_rank.assign(halo->nbr_rank, halo->nbr_rank + nq);
@@ -2530,13 +2636,58 @@ int set_halo(Engine *h, const des_halo *halo, int nn_global)
 
 // One phase of a step without any communication (the caller moves the ghost records and reduces the wall extent in
 // between).  Returns 1 after phase 1 when this is a compute_dt step (the partials are in the clock), < 0: -error.
+// the partition-independent residual for a caller that moves the data itself (des_dev.h: des_dev_residual_blocks / _set)
+int residual_blocks(Engine *h, double *out, int cap, int *first, int *count)
+{
+    HIP2(hipSetDevice(h->device));
+    const int B = des_res_block(h->nn_global), nb_own = (h->o1 - h->o0 + B - 1) / B;
+    if (first) *first = h->g0 / B;
+    if (count) *count = nb_own;
+    if (!out) return DES_OK;
+    if (cap < nb_own) return DES_ERR_INTERNAL;
+    launch_residual_blocks(h);
+    HIP2(hipMemcpyAsync(out, h->res_blocks + h->g0 / B, (size_t)nb_own * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP2(hipStreamSynchronize(h->stream));
+    return DES_OK;
+}
+
+int residual_set(Engine *h, const double *blocks, int nblocks, double *l2)
+{
+    HIP2(hipSetDevice(h->device));
+    if (nblocks != h->res_nb_global) { h->err = "des_dev_residual_set: not the global block count"; return DES_ERR_INTERNAL; }
+    HIP2(hipMemcpyAsync(h->res_blocks, blocks, (size_t)nblocks * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP2(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k2_residual_final, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_clk, h->res_blocks, h->res_nb_global);
+    const int rc = sync_clock(h);
+    if (rc) return rc;
+    if (l2) *l2 = h->h_clk->l2_residual;
+    return DES_OK;
+}
+
 int phase(Engine *h, int ph)
 {
     if (hipSetDevice(h->device) != hipSuccess) return -DES_ERR_RESOURCE;
     if (ph == 0) {
         h->count_past = true;
         h->elide = false;
+        // control.has_PT: the loop is the caller's (des_dev.h) -- the front stops in front of it and phase 0 returns 2
+        const bool pt = h->p.has_PT && !h->iso;
+        h->pt_defer = pt;
         const int rc = h->portable_libm ? step_front<desk::MathPortable>(h) : step_front<desk::MathOcml>(h);
+        h->pt_defer = false;
+        if (rc) return -rc;
+        if (!pt) return 0;
+        h->n_pt_iterations = 0;
+        return set_pt(h, 1) ? -DES_ERR_RESOURCE : 2;
+    }
+    if (ph == 2) {
+        if (h->portable_libm) pt_iteration<desk::MathPortable>(h); else pt_iteration<desk::MathOcml>(h);
+        ++h->n_pt_iterations;
+        return 0;
+    }
+    if (ph == 3) {
+        if (set_pt(h, 0)) return -DES_ERR_RESOURCE;
+        const int rc = step_front_rest(h);
         return rc ? -rc : 0;
     }
     if (ph != 1) return -DES_ERR_INTERNAL;
@@ -2639,37 +2790,83 @@ int step_group(Engine **g, int n, int nsteps, des_scalars *out)
     Engine *h = g[0];                               // (HIP2 books errors on rank 0)
     HIP2(hipSetDevice(h->device));
     for (int i = 0; i < nsteps; ++i) {
+        // the ghost region (and the wall's extent) of every engine refreshed from its neighbours' packed messages
+        auto exchange_all = [&](bool set_wall) -> int {
+            for (int k = 0; k < n; ++k) launch_pack(g[k]);
+            for (int k = 0; k < n; ++k) HIP2(hipStreamSynchronize(g[k]->stream));
+            for (int k = 0; k < n; ++k) {
+                Engine *e = g[k];
+                for (int q = 0; q < e->nnbr; ++q) {
+                    Engine *o = g[e->nbr_rank[q]];
+                    int qo = 0;
+                    for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
+                    const long long len = e->recv_off[q + 1] - e->recv_off[q];
+                    if (len) HIP2(hipMemcpyAsync(e->d_recvbuf + e->recv_off[q], o->d_sendbuf + o->send_off[qo], (size_t)len * sizeof(double),
+                                                 hipMemcpyDeviceToDevice, e->stream));
+                }
+                launch_unpack(e);
+                launch_wall_local(e);
+                HIP2(hipMemcpyAsync(e->h_red, e->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            }
+            double wall[3] = {-DBL_MAX, -DBL_MAX, 0.0};
+            for (int k = 0; k < n; ++k) {
+                HIP2(hipStreamSynchronize(g[k]->stream));
+                for (int q = 0; q < 3; ++q) wall[q] = std::max(wall[q], g[k]->h_red[q]);
+            }
+            if (set_wall) for (int k = 0; k < n; ++k) launch_wall_set(g[k], wall);
+            return DES_OK;
+        };
+        // the partition-independent residual of all engines: the parts through the host, the fixed-shape sum on each
+        auto residual_all = [&](double *l2) -> int {
+            std::vector<double> all((size_t)g[0]->res_nb_global, 0.0);
+            for (int k = 0; k < n; ++k) {
+                Engine *e = g[k];
+                const int B = des_res_block(e->nn_global), nb_own = (e->o1 - e->o0 + B - 1) / B;
+                launch_residual_blocks(e);
+                HIP2(hipMemcpyAsync(all.data() + e->g0 / B, e->res_blocks + e->g0 / B, (size_t)nb_own * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+                HIP2(hipStreamSynchronize(e->stream));
+            }
+            for (int k = 0; k < n; ++k) {
+                Engine *e = g[k];
+                HIP2(hipMemcpyAsync(e->res_blocks, all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+                HIP2(hipStreamSynchronize(e->stream));
+                hipLaunchKernelGGL(k2_residual_final, dim3(1), dim3(DES_BLOCK), 0, e->stream, e->d_clk, e->res_blocks, e->res_nb_global);
+                const int rc = sync_clock(e);
+                if (rc) return rc;
+            }
+            *l2 = g[0]->h_clk->l2_residual;
+            return DES_OK;
+        };
+        const bool pt = g[0]->p.has_PT && !g[0]->iso;
         for (int k = 0; k < n; ++k) {
             g[k]->count_past = (i == nsteps - 1);
             g[k]->elide = elide_ok(g[k], i < nsteps - 1);
+            g[k]->pt_defer = pt;
             const int rc = g[k]->portable_libm ? step_front<desk::MathPortable>(g[k]) : step_front<desk::MathOcml>(g[k]);
+            g[k]->pt_defer = false;
             if (rc) return rc;
-            launch_pack(g[k]);
         }
-        for (int k = 0; k < n; ++k) HIP2(hipStreamSynchronize(g[k]->stream));
-        for (int k = 0; k < n; ++k) {
-            Engine *e = g[k];
-            for (int q = 0; q < e->nnbr; ++q) {
-                Engine *o = g[e->nbr_rank[q]];
-                int qo = 0;
-                for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
-                const long long len = e->recv_off[q + 1] - e->recv_off[q];
-                if (len) HIP2(hipMemcpyAsync(e->d_recvbuf + e->recv_off[q], o->d_sendbuf + o->send_off[qo], (size_t)len * sizeof(double),
-                                             hipMemcpyDeviceToDevice, e->stream));
+        if (pt) {
+            // control.has_PT: the fronts have stopped in front of the loop; all engines in lockstep -- a ghost refresh and one
+            // residual per iteration -- then the rest of every front
+            int rc;
+            double residual_old = 0, l2 = 0;
+            if ((rc = residual_all(&residual_old))) return rc;
+            for (int k = 0; k < n; ++k) if ((rc = set_pt(g[k], 1))) return rc;
+            for (int pt_step = 0; pt_step < g[0]->p.PT_max_iter; ++pt_step) {
+                if ((rc = exchange_all(true))) return rc;
+                for (int k = 0; k < n; ++k) { if (g[k]->portable_libm) pt_iteration<desk::MathPortable>(g[k]); else pt_iteration<desk::MathOcml>(g[k]); }
+                if ((rc = residual_all(&l2))) return rc;
+                for (int k = 0; k < n; ++k) ++g[k]->n_pt_iterations;
+                if (std::fabs((l2 - residual_old) / residual_old) < g[0]->p.PT_relative_tolerance) break;
+                residual_old = l2;
             }
-            launch_unpack(e);
-            launch_wall_local(e);
-            HIP2(hipMemcpyAsync(e->h_red, e->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+            for (int k = 0; k < n; ++k) { if ((rc = set_pt(g[k], 0)) || (rc = step_front_rest(g[k]))) return rc; }
         }
-        double wall[3] = {-DBL_MAX, -DBL_MAX, 0.0};
-        for (int k = 0; k < n; ++k) {
-            HIP2(hipStreamSynchronize(g[k]->stream));
-            for (int q = 0; q < 3; ++q) wall[q] = std::max(wall[q], g[k]->h_red[q]);
-        }
+        { const int rcx = exchange_all(true); if (rcx) return rcx; }
         bool do_dt = false;
         for (int k = 0; k < n; ++k) {
             Engine *e = g[k];
-            launch_wall_set(e, wall);
             step_back(e, i < nsteps - 1);
             if (!e->iso && e->steps_host % 10 == 0) {
                 do_dt = true;

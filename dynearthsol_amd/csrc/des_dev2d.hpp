@@ -56,6 +56,8 @@ int wall_set(Engine *h, const double in[3]);
 int dt_partials(Engine *h, double out[6], int recompute);
 int dt_finalize(Engine *h, const double in[6], double *dt);
 int step_group(Engine **g, int n, int nsteps, des_scalars *out);
+int residual_blocks(Engine *h, double *out, int cap, int *first, int *count);
+int residual_set(Engine *h, const double *blocks, int nblocks, double *l2);
 // the RCCL communicator (an ncclComm_t the caller owns) des_dev_step / init_geometry / compute_dt of a decomposed engine use
 int comm_selfcheck(Engine *h, int expect_world, int expect_rank);
 int set_comm(Engine *h, void *comm);

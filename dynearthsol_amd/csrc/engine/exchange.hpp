@@ -130,7 +130,7 @@ int sync_clock(des_dev *h)
 // passes of a step under DevClock::pt (no clock, no temperature update, no NMD, no rotate_stress) --
 // until the relative change of the residual drops below the tolerance.  The host joins the stream
 // once per iteration to take that decision, as the reference's loop does; afterwards the real
-// apply_vbcs + update_coordinate of the step follow.  Single domain only (des_dev_set_halo refuses).
+// apply_vbcs + update_coordinate of the step follow.
 int set_pt(des_dev *h, int on)
 {
     static const int vals[2] = {0, 1};
@@ -145,31 +145,82 @@ void launch_vbcs_coord(des_dev *h)
                        h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vm, h->xt);
 }
 
+// The passes of one iteration (the ghost region of a decomposed mesh refreshed just before)
+void pt_iteration(des_dev *h)
+{
+    launch_vbcs_coord(h);
+    launch_e1<MODE_C | MODE_A>(h);
+    launch_n1(h);
+    launch_e2(h);
+    launch_force_pass(h);                              // E3 + N3, or EN3 (the facet terms then ride in E2's launch)
+}
+
+// the reference's test (dynearthsol.cxx:829-833) on the residual every rank holds
+inline bool pt_converged(const des_dev *h, double l2, double residual_old)
+{
+    return std::fabs((l2 - residual_old) / residual_old) < h->p.PT_relative_tolerance;
+}
+
 // in_step = false: initial_body_force_adjustment's loop (dynearthsol.cxx:546-591) -- the same iterations on the state
-// as it stands, no step around them (so no apply_vbcs + update_coordinate of a step behind the loop)
+// as it stands, no step around them (so no apply_vbcs + update_coordinate of a step behind the loop).
+// A decomposed mesh (round 4): every iteration starts with a refresh of the ghost region -- an iteration consumes two of
+// its four layers (the dvoldt gather, the force gather) -- and the residual is the partition-independent one of
+// engine/residual.hpp, its block partials put together over RCCL: every rank holds the same value and takes the same
+// decision, the one a single engine takes.
 int pt_loop(des_dev *h, bool in_step = true)
 {
     int rc;
-    launch_s3(h, false, false, true);                      // l2 of the step's own update_force
-    if ((rc = sync_clock(h))) return rc;
+    const bool multi = h->nnbr > 0;
+    if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;     // l2 of the step's own update_force
     double residual_old = h->h_clk->l2_residual;
     if ((rc = set_pt(h, 1))) return rc;
     for (int pt_step = 0; pt_step < h->p.PT_max_iter; ++pt_step) {
-        launch_vbcs_coord(h);
-        launch_e1<MODE_C | MODE_A>(h);
-        launch_n1(h);
-        launch_e2(h);
-        launch_force_pass(h);                              // E3 + N3, or EN3 (the facet terms then ride in E2's launch)
-        launch_s3(h, false, false, true);
-        if ((rc = sync_clock(h))) return rc;
+        if (multi && (rc = exchange(h))) return rc;
+        pt_iteration(h);
+        if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;
         ++h->n_pt_iterations;
         const double l2 = h->h_clk->l2_residual;
-        const double relative_change = std::fabs((l2 - residual_old) / residual_old);
-        if (relative_change < h->p.PT_relative_tolerance) break;
+        if (pt_converged(h, l2, residual_old)) break;
         residual_old = l2;
     }
     if ((rc = set_pt(h, 0))) return rc;
     if (in_step) launch_vbcs_coord(h);                     // apply_vbcs + update_coordinate of the step itself
+    return DES_OK;
+}
+
+// ... for the engines of a group in lockstep (des_dev_step_group, des_dev_body_force_adjustment_group)
+int pt_loop_group(des_dev **g, int n, bool in_step)
+{
+    int rc;
+    auto residual = [&](double *l2) -> int {
+        int r;
+        if ((r = residual_global_group(g, n))) return r;
+        for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); if ((r = sync_clock(g[k]))) return r; }
+        *l2 = g[0]->h_clk->l2_residual;
+        for (int k = 1; k < n; ++k)
+            if (g[k]->h_clk->l2_residual != *l2) { g_last_error = "pseudo-transient loop: the ranks of a group hold different residuals"; return DES_ERR_INTERNAL; }
+        return DES_OK;
+    };
+    double residual_old = 0, l2 = 0;
+    if ((rc = residual(&residual_old))) return rc;
+    for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); if ((rc = set_pt(g[k], 1))) return rc; }
+    for (int pt_step = 0; pt_step < g[0]->p.PT_max_iter; ++pt_step) {
+        for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); if (g[k]->nnbr > 0 && (rc = exchange_local_pack(g[k]))) return rc; }
+        for (int k = 0; k < n; ++k) {
+            hipSetDevice(g[k]->device);
+            if (g[k]->nnbr > 0 && (rc = exchange_local_take(g[k], g[k]->stream))) return rc;
+            pt_iteration(g[k]);
+        }
+        if ((rc = residual(&l2))) return rc;
+        for (int k = 0; k < n; ++k) ++g[k]->n_pt_iterations;
+        if (pt_converged(g[0], l2, residual_old)) break;
+        residual_old = l2;
+    }
+    for (int k = 0; k < n; ++k) {
+        hipSetDevice(g[k]->device);
+        if ((rc = set_pt(g[k], 0))) return rc;
+        if (in_step) launch_vbcs_coord(g[k]);
+    }
     return DES_OK;
 }
 

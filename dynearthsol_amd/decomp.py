@@ -338,6 +338,22 @@ class DeviceGroup:
             raise DesError(rc, self._lib.des_dev_last_error().decode())
         return list(out)
 
+    def body_force_adjustment(self):
+        """initial_body_force_adjustment (dynearthsol.cxx:546-591) on every rank in lockstep (3-D engines)"""
+        out = (self._scalars * self.nranks)()
+        self._lib.des_dev_body_force_adjustment_group.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        rc = self._lib.des_dev_body_force_adjustment_group(self._arr, self.nranks, out)
+        if rc:
+            raise DesError(rc, self._lib.des_dev_last_error().decode())
+        return list(out)
+
+    def upload(self, field, global_array, ncomp, kind):
+        """every rank's slice of a global SoA array (nodal or elemental) into its engine"""
+        a = np.asarray(global_array, dtype=np.float64).reshape(ncomp, -1)
+        for e, p in zip(self.engines, self.parts):
+            idx = p.l2g_node if kind == "node" else p.l2g_elem
+            e.upload(field, np.ascontiguousarray(a[:, idx]))
+
     def download(self, field, ncomp, kind):
         """the global SoA array of `field`, assembled from every rank's owned nodes / elements"""
         n = self.host.nnode if kind == "node" else self.host.nelem

@@ -203,6 +203,16 @@ int des_dev_exchange(des_dev *h);
  * DES_X_ELEM_WIDTH -- and the compute_dt partials: lets a host harness move the ghost region
  * itself (tests with several engines on one GPU; any other transport). */
 int des_dev_phase(des_dev *h, int phase);
+/* control.has_PT (the pseudo-transient loop of a step, dynearthsol.cxx:803-864) on a decomposed mesh: des_dev_step on RCCL
+ * and des_dev_step_group run the loop themselves -- the ghost region refreshed before every iteration, the residual summed
+ * in ONE association whatever the partition (des_params.h: DES_RES_BLOCK) so that every rank, and a run on one rank, takes
+ * the same decision.  With the two-phase entry points the loop is the caller's: phase 0 then stops in front of it and
+ * returns 2; per iteration: refresh the ghost region, des_dev_phase(h, 2), des_dev_residual_blocks on every rank -> the
+ * partials in global block order -> des_dev_residual_set on every rank (returns the residual), the reference's test
+ * |l2 - l2_old| / l2_old < PT_relative_tolerance (l2_old of iteration 0 = the residual before the loop); des_dev_phase(h, 3)
+ * is the rest of phase 0.  (tests/test_decomp_cpu.py, dynearthsol_amd/decomp.py: PhasedStepper.pt_loop) */
+int des_dev_residual_blocks(des_dev *h, double *out, int cap, int *first, int *count);
+int des_dev_residual_set(des_dev *h, const double *blocks, int nblocks, double *l2);
 int des_dev_halo_pack(des_dev *h, int what, const int *idx, int n, double *buf);
 int des_dev_halo_unpack(des_dev *h, int what, const int *idx, int n, const double *buf);
 int des_dev_dt_partials(des_dev *h, double out[6], int recompute);
@@ -228,6 +238,9 @@ int des_dev_wall_set(des_dev *h, const double in[3]);
 int des_dev_group_attach(des_dev **engines, int n);
 int des_dev_group_detach(des_dev **engines, int n);
 int des_dev_step_group(des_dev **engines, int n, int nsteps, des_scalars *out);
+/* initial_body_force_adjustment (dynearthsol.cxx:546-591) for the engines of a group; a rank on RCCL calls
+ * des_dev_body_force_adjustment itself (every rank, collectively) */
+int des_dev_body_force_adjustment_group(des_dev **engines, int n, des_scalars *out);
 
 const char *des_dev_last_error(void);
 /* The engine's environment switches (DES_PATCH, DES_E2GEO, DES2D_CLUSTER, ... -- each selects between

@@ -259,3 +259,30 @@ def test_the_2d_program_on_three_ranks_writes_the_frames_of_one(tmp_path):
                     assert np.array_equal(a[k], b[k]), (name, k)
     finally:
         os.chdir(cwd)
+
+
+def test_2d_pseudo_transient_loop_on_a_cut_mesh():
+    """control.has_PT on a 2-D model cut 3 ways (round 4): des_dev_step_group runs the loop for all engines in lockstep -- ghost
+    region and wall extent refreshed before every iteration, the residual in global block order -- against the single 2-D
+    engine: same iteration counts, same bits; then the same through the two-phase entry points"""
+    ov = "control.has_PT = yes\ncontrol.PT_max_iter = 40\ncontrol.PT_relative_tolerance = 1e-3\n"
+    host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EP, res=1e3)), overrides=ov, ndims=2)
+    for phased in (False, True):
+        ref, group = _pair(host, 3)
+        try:
+            steppers = [PhasedStepper(e, p, None) for e, p in zip(group.engines, group.parts)]
+            for n in (2, 9):
+                sref = ref.step(n)
+                assert sref.n_pt_iterations > 0
+                if phased:
+                    run_loopback(steppers, n)
+                    assert all(st.n_pt_iterations == sref.n_pt_iterations for st in steppers)
+                else:
+                    for s in group.step(n):
+                        assert (s.dt, s.steps, s.n_pt_iterations) == (sref.dt, sref.steps, sref.n_pt_iterations)
+                for f, c in NODE_FIELDS:
+                    assert np.array_equal(group.download(f, c, "node"), ref.download(f)), f
+                for f, c in ELEM_FIELDS:
+                    assert np.array_equal(group.download(f, c, "elem"), ref.download(f)), f
+        finally:
+            group.close()

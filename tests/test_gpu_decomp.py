@@ -360,3 +360,97 @@ def test_switching_schedules_between_calls_keeps_the_bits():
         else:
             os.environ["DES_S2_DEFER"] = old_defer
         dist.destroy_process_group()
+
+
+PT_OV = "control.has_PT = yes\ncontrol.PT_max_iter = 40\ncontrol.PT_relative_tolerance = %s\ncontrol.has_moving_mesh = %s\n"
+PT_NODE = (("COORD", 3), ("VEL", 3), ("TEMPERATURE", 1), ("MASS", 1), ("VOLUME_N", 1), ("FORCE", 3))
+PT_ELEM = (("STRESS", 6), ("STRAIN", 6), ("STRAIN_RATE", 6), ("PLSTRAIN", 1), ("VISCOSITY", 1), ("VOLUME", 1), ("VOLUME_OLD", 1))
+
+
+@pytest.mark.parametrize("nranks,tol,moving", [(2, "1e-2", "yes"), (4, "1e-4", "yes"), (3, "1e-4", "no")])
+def test_pseudo_transient_loop_on_a_decomposed_mesh(nranks, tol, moving):
+    """control.has_PT (dynearthsol.cxx:803-864) on N ranks (round 4; des_dev_set_halo used to refuse it): des_dev_step_group
+    refreshes the ghost region before every iteration and puts the residual together in global block order (des_params.h:
+    DES_RES_BLOCK), so every rank takes the decision the single engine takes.  Same iteration counts, same bits in every field --
+    and the residual itself equal to the bit, on the device as against the oracle (one association everywhere)."""
+    from oracle_binding import OracleEngine
+    from dynearthsol_amd.decomp import DeviceGroup
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=PT_OV % (tol, moving))
+    ref = des.DeviceEngine(host)
+    dt_ref = ref.init_from_host(host)
+    ora = OracleEngine(host)
+    ora.init_from_host(host)
+    group = DeviceGroup(host, nranks)
+    try:
+        assert group.init_from_host() == dt_ref
+        total = 0
+        for n in (1, 4, 8):                                  # crosses step 10 (compute_dt)
+            sref, so = ref.step(n), ora.step(n)
+            assert sref.n_pt_iterations == so.n_pt_iterations > 0
+            for s in group.step(n):
+                assert (s.dt, s.time, s.steps, s.status, s.n_pt_iterations) == (sref.dt, sref.time, sref.steps, 0, sref.n_pt_iterations)
+            total += sref.n_pt_iterations
+            for f, c in PT_NODE:
+                assert np.array_equal(group.download(f, c, "node"), ref.download(f)), f
+            for f, c in PT_ELEM:
+                assert np.array_equal(group.download(f, c, "elem"), ref.download(f)), f
+        assert total >= 13
+    finally:
+        group.close()
+
+
+def test_pseudo_transient_loop_through_the_two_phase_entry_points():
+    """the same loop driven by the caller (des_dev_phase 0 -> 2 ... 2 -> 3, des_dev_residual_blocks / _set: what a run over
+    another transport does, dynearthsol_amd/decomp.py: run_loopback) with three device engines on this GPU"""
+    from dynearthsol_amd.decomp import PhasedStepper, run_loopback, LoopbackComm, init_rank_mesh, init_rank_fields, assemble
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=PT_OV % ("1e-3", "yes"))
+    ref = des.DeviceEngine(host)
+    dt_ref = ref.init_from_host(host)
+    parts = [Partition(host, 3, r) for r in range(3)]
+    engines = [des.DeviceEngine(p) for p in parts]
+    steppers = [PhasedStepper(e, p, None) for e, p in zip(engines, parts)]
+    comm = LoopbackComm(steppers)
+    for e, p in zip(engines, parts):
+        init_rank_mesh(e, p)
+    for e, p in zip(engines, parts):
+        init_rank_fields(e, p)
+    assert all(d == dt_ref for d in comm.reduce_dt_all(recompute=True))
+    for n in (2, 9):
+        sref = ref.step(n)
+        run_loopback(steppers, n)
+        assert all(st.n_pt_iterations == sref.n_pt_iterations > 0 for st in steppers)
+        for f, c in PT_NODE:
+            assert np.array_equal(assemble(parts, [e.download(f) for e in engines], c, host.nnode, "node"), ref.download(f)), f
+        for f, c in PT_ELEM:
+            assert np.array_equal(assemble(parts, [e.download(f) for e in engines], c, host.nelem, "elem"), ref.download(f)), f
+
+
+def test_initial_body_force_adjustment_on_a_decomposed_mesh():
+    """ic.has_body_force_adjustment (dynearthsol.cxx:546-591) for the engines of a group: the pseudo-transient loop on the
+    initial state with the Neumann tractions held back, in lockstep -- iteration count and bits of the single engine, the
+    steps that follow included"""
+    from dynearthsol_amd.decomp import DeviceGroup
+    ov = ("control.has_PT = yes\ncontrol.PT_max_iter = 25\ncontrol.PT_relative_tolerance = 1e-4\n"
+          "bc.stress_bc_z1 = 3\nbc.stress_val_z1 = 2e6\nbc.stress_bc_x0 = 1\nbc.stress_val_x0 = -1e6\n")
+    host = des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides=ov)
+    ref = des.DeviceEngine(host)
+    ref.init_from_host(host)
+    group = DeviceGroup(host, 3)
+    try:
+        group.init_from_host()
+        pushed = ref.download("STRESS") * 1.03           # (the lithostatic start is in equilibrium: push it out of balance)
+        ref.upload("STRESS", pushed)
+        group.upload("STRESS", pushed, 6, "elem")
+        sref = ref.body_force_adjustment()
+        sg = group.body_force_adjustment()
+        assert sref.n_pt_iterations > 3 and all(s.n_pt_iterations == sref.n_pt_iterations and s.l2_residual == sref.l2_residual for s in sg)
+        for n in (1, 3, 8):
+            sref = ref.step(n)
+            for s in group.step(n):
+                assert (s.dt, s.steps, s.n_pt_iterations) == (sref.dt, sref.steps, sref.n_pt_iterations)
+        for f, c in PT_NODE:
+            assert np.array_equal(group.download(f, c, "node"), ref.download(f)), f
+        for f, c in PT_ELEM:
+            assert np.array_equal(group.download(f, c, "elem"), ref.download(f)), f
+    finally:
+        group.close()
