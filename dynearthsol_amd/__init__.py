@@ -518,7 +518,9 @@ class DeviceEngine(EngineBase):
         """des_dev_comm_selfcheck: rank count, the exchange's own messages filled with a verifiable pattern, the three
         reductions -- collective, before the first step; raises DesError naming what failed"""
         self._lib.des_dev_comm_selfcheck.argtypes = [C.c_void_p, C.c_int]
-        self._check(self._lib.des_dev_comm_selfcheck(self._h, int(world)), "comm_selfcheck")
+        rc = self._lib.des_dev_comm_selfcheck(self._h, int(world))
+        if rc:
+            raise DesError(rc, self._lib.des_dev_last_error().decode())
 
 
 def config_string():

@@ -1488,7 +1488,8 @@ int des_dev_set_halo(des_dev *h, const des_halo *halo, int nnode_global)
     if (h->res_part) hipFree(h->res_part);
     choose_npb(h);
     h->n3_blocks = res_part_size(h);
-    return dev_alloc(h->res_part, (size_t)h->n3_blocks);
+    { const int rcp = dev_alloc(h->res_part, (size_t)h->n3_blocks); if (rcp) return rcp; }
+    return build_residual_blocks(h);               // the owned range (and its place in the global numbering) has changed
 }
 
 // The partition-independent residual across ranks for a caller that moves the data itself (des_dev_phase; des_params.h:

@@ -306,21 +306,58 @@ def run_distributed(host, dist, engine_factory=None, stepper=None, quiet=True):
     return driver.run(host, quiet=quiet or ce.rank != 0, api=api)
 
 
+def run_distributed_with_remesher(make_host, remesher, dist, engine_factory=None, stepper=None, quiet=True, max_rounds=100):
+    """The remeshing round trip of include/des_run.h on N ranks (driver.run_with_remesher is the one-process form): where the
+    loop stops for a remesh -- every rank takes that decision from the same reduced mesh-quality numbers, rank 0 has written
+    the frame + checkpoint -- rank 0 runs `remesher(modelname, frame)` (a callable, or a command run as `<command> <modelname>
+    <frame>`), which must leave the remeshed model as frame + 1; then EVERY rank restarts from that pair: a new host model, a
+    new partition of the new mesh (node and element counts may have changed), new engines, the clock / frame numbering /
+    .info continued.  `make_host(overrides)`: overrides = None for the first round, the restart keys afterwards.
+    Returns the list of RunStats, one per mesh."""
+    import subprocess
+    stats, overrides = [], None
+    for _ in range(max_rounds):
+        host = make_host(overrides)
+        model = host.cfg_string("sim.modelname")
+        st = run_distributed(host, dist, engine_factory=engine_factory, stepper=stepper, quiet=quiet)
+        host.close()
+        stats.append(st)
+        if not st.remesh_needed:
+            return stats
+        if dist.get_rank() == 0:
+            if callable(remesher):
+                remesher(model, st.last_frame)
+            else:
+                subprocess.check_call("%s %s %d" % (remesher, model, st.last_frame), shell=True)
+        dist.barrier()
+        overrides = ("sim.is_restarting = yes\nsim.restarting_from_modelname = %s\nsim.restarting_from_frame = %d\n"
+                     % (model, st.last_frame + 1))
+    raise DesError(31, "the mesh needed remeshing more than %d times" % max_rounds)
+
+
 def main(argv=None):
     import torch
     import torch.distributed as dist
     argv = sys.argv[1:] if argv is None else argv
     if not argv:
-        sys.stderr.write("usage: torchrun --nproc-per-node N -m dynearthsol_amd.distributed [--ndims 2|3] config.cfg [mesh.desmesh]\n")
+        sys.stderr.write("usage: torchrun --nproc-per-node N -m dynearthsol_amd.distributed [--ndims 2|3] [--remesher CMD] config.cfg [mesh.desmesh]\n")
         return 1
-    ndims = 3
-    if argv[0] == "--ndims":
-        ndims, argv = int(argv[1]), argv[2:]
+    ndims, remesher = 3, os.environ.get("DES_REMESH_CMD")
+    while argv and argv[0] in ("--ndims", "--remesher"):
+        if argv[0] == "--ndims":
+            ndims = int(argv[1])
+        else:
+            remesher = argv[1]
+        argv = argv[2:]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
     dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
     try:
+        if remesher:
+            # (the restart reads the mesh from the frame the remesher left: the mesh file only serves the first round)
+            make_host = lambda ov: Host(cfg_path=argv[0], overrides=ov, mesh_file=(argv[1] if len(argv) > 1 and not ov else None), ndims=ndims)
+            return run_distributed_with_remesher(make_host, remesher, dist, quiet=False)[-1].exit_code
         host = Host(cfg_path=argv[0], mesh_file=argv[1] if len(argv) > 1 else None, ndims=ndims)
         st = run_distributed(host, dist, quiet=False)
         return st.exit_code

@@ -117,3 +117,78 @@ def test_two_ranks_write_the_2d_frames_of_one_rank(tmp_path):
                     assert np.array_equal(a[k], b[k]), (name, k)
     finally:
         os.chdir(cwd)
+
+
+# ---- the remeshing round trip on two ranks, with a remesher that changes the node and element counts ------
+REMESH_TOOL = os.path.join(des.REPO_ROOT, "tools", "remesh_tool.py")
+REMESH_OV = ("sim.max_steps = 400\nmesh.quality_check_step_interval = 300\nmesh.max_boundary_distortion = 0.00039\n"
+             "sim.modelname = rtd\n")
+
+
+def _remesh_text():
+    return "\n".join(l for l in cfgs.TEST3D.splitlines() if not l.startswith(("max_time_in_yr", "output_time_interval_in_yr")))
+
+
+def _worker_remesh(rank, world, port, out_dir):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    from dynearthsol_amd.decomp import PhasedStepper, TorchComm
+    from dynearthsol_amd.distributed import run_distributed_with_remesher
+    from oracle_binding import OracleEngine
+    from test_decomp_cpu import _LocalMeshHost
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mesh = os.path.join(here, "golden", "test-3d.desmesh")
+    comm = TorchComm(dist)
+
+    def make_host(extra):
+        return des.Host(cfg_text=_remesh_text(), overrides=REMESH_OV + (extra or ""), mesh_file=None if extra else mesh)
+    stats = run_distributed_with_remesher(make_host, "%s %s --resolution 1500" % (sys.executable, REMESH_TOOL), dist,
+                                          engine_factory=lambda part: OracleEngine(_LocalMeshHost(part)),
+                                          stepper=lambda e, p: PhasedStepper(e, p, comm))
+    assert [(s.steps, s.remesh_needed, s.exit_code) for s in stats] == [(300, 2, 31), (400, 0, 0)]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_remeshing_round_trip_on_two_ranks_with_a_changing_element_count(tmp_path):
+    """benchmarks-cores/test-3d-remesh.cfg's situation (a displaced bottom node trips bad_mesh_quality at step 300) on two
+    ranks: rank 0 runs tools/remesh_tool.py -- the reference's TetGen on the deformed box + nearest-neighbour remap, 13,850 ->
+    ~7,700 tets --, both ranks restart from the pair it leaves: a new partition of the new mesh, clock and frame numbering
+    continued.  The run after the remesh must be the one a single rank makes from the same pair, bit for bit."""
+    import pytest
+    import torch.multiprocessing as mp
+    from dynearthsol_amd import driver
+    from test_driver_output import oracle_api, read_frame, as_f64
+    if not os.access(os.path.join(des.REPO_ROOT, "oracle", "_ref", "tetmesh"), os.X_OK):
+        pytest.skip("oracle/_ref/tetmesh is missing (make -C oracle ref)")
+    world = 2
+    port = 32300 + os.getpid() % 500
+    mp.spawn(_worker_remesh, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        info = np.loadtxt("rtd.info").reshape(-1, 8)
+        assert info[:, 0].tolist() == [0, 1, 2, 3, 4, 5, 6] and info[:, 1].tolist() == [0, 100, 200, 300, 300, 300, 400]
+        assert info[4, 5:7].tolist() == [3018, 13850] and info[5, 6] != 13850 and info[5, 6] > 5000      # a new mesh of another size
+        new = read_frame("rtd.save.000005")
+        ne = int(info[5, 6])
+        assert as_f64(new["stress"], ne, 6).shape == (ne, 6) and np.isfinite(as_f64(new["stress"], ne, 6)).all()
+        # lithostatic state carried over: the mean vertical stress stays where it was
+        old = read_frame("rtd.save.000004")
+        szz_old, szz_new = as_f64(old["stress"], 13850, 6)[:, 2].mean(), as_f64(new["stress"], ne, 6)[:, 2].mean()
+        assert abs(szz_new - szz_old) < 0.05 * abs(szz_old)
+        # one rank restarting from the same pair takes the same 100 steps: the frame of step 400 equal to the bit
+        host = des.Host(cfg_text=_remesh_text(), overrides=REMESH_OV.replace("rtd", "rts")
+                        + "sim.is_restarting = yes\nsim.restarting_from_modelname = rtd\nsim.restarting_from_frame = 5\n")
+        assert host.nelem == ne
+        st = driver.run(host, api=oracle_api())
+        assert (st.steps, st.exit_code) == (400, 0)
+        a, b = read_frame("rtd.save.000006"), read_frame("rts.save.000006")
+        for k in ("coordinate", "velocity", "temperature", "stress", "strain", "plastic strain"):
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        os.chdir(cwd)
