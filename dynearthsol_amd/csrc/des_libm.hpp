@@ -53,7 +53,9 @@ namespace deslibm {
 #define DES_LIBM_LDS_WAVES 4
 #endif
 static __shared__ double lds_tab[DES_LIBM_LDS_WAVES][5 * 128];
-DES_LIBM_FN double *lds_mine() { return lds_tab[threadIdx.x >> 6]; }
+// (workgroups of more than DES_LIBM_LDS_WAVES wavefronts share the copies: every wavefront writes the whole of its copy itself
+//  before it reads -- the same values whoever writes them)
+DES_LIBM_FN double *lds_mine() { return lds_tab[(threadIdx.x >> 6) % DES_LIBM_LDS_WAVES]; }
 // lds_stage_begin() copies (every lane of the wave calls it, at the top of the kernel);
 // lds_stage_end() orders the copy before the first deslibm:: call of the wave.
 DES_LIBM_FN void lds_stage_begin()

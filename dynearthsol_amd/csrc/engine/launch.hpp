@@ -417,11 +417,16 @@ void launch_e2(des_dev *h, int part = PART_ALL)
         }
         const int e_all = e_count + e_count2;
         if (geo && !defer && h->portable_libm && e2_pipelined(h, part, e_all)) {
-            const int ntiles = nblk(e_all);
+            // (a variant with ONE resident workgroup of twelve wavefronts per CU -- three waves per SIMD at 168 VGPRs -- spills 350 B
+            //  per lane: the tile loop with its gathers in flight wants ~250 registers; not kept)
+            constexpr int nw = 4;
+            const int tile = nw * 64;
+            const int ntiles = (e_all + tile - 1) / tile;
             const int npers = std::min((2 * h->n_cu + 7) / 8 * 8, (ntiles + 7) / 8 * 8);
-            auto kp = (h->p.rheol_type == DES_RH_EVP && h->p.is_using_mixed_stress && !h->p.is_outputting_averaged_fields)
-                      ? E2_update_stress_pipe<desk::MathPortable, DES_RH_EVP> : E2_update_stress_pipe<desk::MathPortable, 0>;
-            hipLaunchKernelGGL(kp, dim3(npers + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
+            const bool evp = h->p.rheol_type == DES_RH_EVP && h->p.is_using_mixed_stress && !h->p.is_outputting_averaged_fields;
+            auto kp = evp ? E2_update_stress_pipe<desk::MathPortable, DES_RH_EVP, 4> : E2_update_stress_pipe<desk::MathPortable, 0, 4>;
+            const int nbf_p = nbf, nsf_p = nsf;
+            hipLaunchKernelGGL(kp, dim3(npers + nbf_p + nsf_p), dim3(tile), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                                ntiles, npers, h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old,
                                h->stress, h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
                                h->etmp2, count, (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);

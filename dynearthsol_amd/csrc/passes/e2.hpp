@@ -56,7 +56,11 @@ struct RotPending { const double *spin, *ddp; const unsigned char *topflag; int 
 // in LDS one tile AHEAD of the arithmetic -- and what it gathers through the connectivity (nodal records), requested at the
 // top of its own tile.  Same values, same operations on them: e2_element<..., PIPE = 1> only takes them from here instead
 // of loading them itself.
-struct E2Pre { int4 cn; int mono, top; double s[6], es[6], vol_prev, pls, dd; };
+// (the stress and strain planes stay in LDS until the arithmetic wants them -- lp[k * 64], k = 0-5 stress, 6-11 strain --:
+//  held in registers from the top of the tile they cost 24 VGPRs across the geometry, i.e. spills)
+struct E2Pre { int4 cn; int mono, top; double vol_prev, pls, dd; const double *lp; };
+// what the pipelined kernel does once an element has taken its last value out of LDS (request the next tile's pieces)
+struct E2NoAfter { __device__ __forceinline__ void operator()() const {} };
 struct E2Gath { d4 c[4], v[4]; double nt[4]; };
 
 __device__ __forceinline__ void e2_gather(E2Gath &G, const int4 cn, const d4 *__restrict__ xt, const d4 *__restrict__ vm,
@@ -67,7 +71,7 @@ __device__ __forceinline__ void e2_gather(E2Gath &G, const int4 cn, const d4 *__
     G.nt[0] = rec_ld(ntmp, cn.x); G.nt[1] = rec_ld(ntmp, cn.y); G.nt[2] = rec_ld(ntmp, cn.z); G.nt[3] = rec_ld(ntmp, cn.w);
 }
 
-template <class M, int DEFER, int GEO, int RM = 0, int RH = 0, int PIPE = 0>
+template <class M, int DEFER, int GEO, int RM = 0, int RH = 0, int PIPE = 0, class After = E2NoAfter>
 __device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
      const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData &md,
@@ -75,7 +79,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2, const RotPending rp,
-     const E2Pre *__restrict__ pre = nullptr, const E2Gath *__restrict__ gath = nullptr)
+     const E2Pre *__restrict__ pre = nullptr, const E2Gath *__restrict__ gath = nullptr, const After after = After())
 {
     static_assert(!PIPE || (GEO && !DEFER && !RM), "the pipelined form is the one-pass E2<GEO>");
     const double dt = clk->dt;
@@ -133,9 +137,10 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         for (int i = 0; i < 4; ++i) w4 += 0.5 * (v[i].x * sz[i] - v[i].z * sx[i]);
         for (int i = 0; i < 4; ++i) w5 += 0.5 * (v[i].y * sz[i] - v[i].z * sy[i]);
         for (int i = 0; i < 6; ++i) {
-            s[i] = PIPE ? pre->s[i] : pl_ld(stress, i, ne, eo);
-            if (!ES_DONE) es[i] = PIPE ? pre->es[i] : DES_STRAIN_LD(strain, i, ne, eo);
+            s[i] = PIPE ? pre->lp[i * 64] : pl_ld(stress, i, ne, eo);
+            if (!ES_DONE) es[i] = PIPE ? pre->lp[(6 + i) * 64] : DES_STRAIN_LD(strain, i, ne, eo);
         }
+        if (PIPE) after();                 // everything of this tile is out of LDS: the next tile's pieces may land
         g_pls = PIPE ? pre->pls : pl_ld(plstrain, 0, ne, eo);
         const double dd = PIPE ? pre->dd : (rp.ddp ? pl_ld(rp.ddp, 0, ne, eo) : 0.0);
         if (dd != 0.0) for (int i = 0; i < 3; ++i) s[i] += dd;
@@ -351,8 +356,10 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
 // npers: resident workgroups (a multiple of 8: blockIdx.x & 7 = the XCD under round-robin placement, for locality only).
 typedef const __attribute__((address_space(1))) void *des_gptr;
 typedef __attribute__((address_space(3))) void *des_lptr;
-template <class M, int RH>
-__global__ void __launch_bounds__(DES_BLOCK, DES_E2_WAVES)
+// NW = wavefronts per workgroup: 4 (two workgroups per CU = two waves per SIMD).  Tried: 12 -- ONE workgroup of 768 lanes per
+// CU, three waves per SIMD at 168 VGPRs, LDS 136 KB -- spills 350 B per lane (the loop wants ~250 registers); not instantiated.
+template <class M, int RH, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? DES_E2_WAVES : 3)
 E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, const DevClock *__restrict__ clk,
      int ne, int ntiles, int npers, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
      const double *__restrict__ ntmp, const MatData md,
@@ -365,14 +372,14 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
 {
     if ((int)blockIdx.x >= npers) {
         // workgroups past the resident ones: the stress-bc facet terms and the edvacc_surf update (as in E2_update_stress)
-        const int g = ((int)blockIdx.x - npers) * DES_BLOCK + threadIdx.x;
-        const int nbcf_pad = (nbcf + DES_BLOCK - 1) / DES_BLOCK * DES_BLOCK;
+        const int g = ((int)blockIdx.x - npers) * (NW * 64) + threadIdx.x;
+        const int nbcf_pad = (nbcf + NW * 64 - 1) / (NW * 64) * (NW * 64);
         if (g < nbcf) bc_facet_work(p, g, conn, xt, md, f_elem, f_facet, f_kind, f_val, f_tmp);
         else if (g >= nbcf_pad && g - nbcf_pad < rp.edv_etop)
             edvacc_facet(g - nbcf_pad, rp.edv_etop, rp.edv_conn_surf, xt, rp.edv_dh_n, rp.edv_edvacc);
         return;
     }
-    constexpr int NW = DES_BLOCK / 64;
+    constexpr int TILE = NW * 64;                        // elements per workgroup and tile
     __shared__ double lpl[NW][16][64];                   // per wavefront: stress 0-5, strain 6-11, volume 12, plstrain 13, ddp 14, (pad 15)
     __shared__ int4 lcn[NW][64];
     __shared__ int lmono[NW][64];
@@ -393,7 +400,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
     // region around the requests.  Plane 15 is padding (the partner of ddp).  Then one connectivity record and one marker word
     // per lane, and the top flags.
     auto dma = [&](int tile) {
-        const size_t eb = (size_t)tile * DES_BLOCK + (size_t)w * 64;
+        const size_t eb = (size_t)tile * TILE + (size_t)w * 64;
         const size_t o = eb + 2 * (size_t)(lane & 31);
         const size_t hi = (size_t)(lane >> 5);
 #pragma unroll
@@ -416,7 +423,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
     const unsigned long long st_begin = wall_clock64();
 #endif
     while (t < t_end) {
-        const int e = t * DES_BLOCK + (int)threadIdx.x;
+        const int e = t * TILE + (int)threadIdx.x;
         const int tn = t + wx;
 #ifdef DES_STAMPS
         st_a = wall_clock64();
@@ -430,27 +437,34 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
 #endif
         E2Pre cur;
         cur.cn = lcn[w][lane]; cur.mono = lmono[w][lane]; cur.top = ltop[w][lane];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { cur.s[k] = lpl[w][k][lane]; cur.es[k] = lpl[w][6 + k][lane]; }
         cur.vol_prev = lpl[w][12][lane]; cur.pls = lpl[w][13][lane];
         cur.dd = have_ddp ? lpl[w][14][lane] : 0.0;
+        cur.lp = &lpl[w][0][lane];
         const bool valid = e < ne;
         if (!valid) cur.cn = make_int4(0, 0, 0, 0);          // (lanes past the mesh: harmless gathers, nothing stored)
         E2Gath G;
         e2_gather(G, cur.cn, xt, rp.vm, ntmp);
-        // the region is free again once every value is in registers; the next tile's pieces are requested behind the gathers
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tn < t_end) dma(tn);
-        asm volatile("" ::: "memory");
+        asm volatile("" ::: "memory");                     // the gathers are issued before the next tile's pieces (vmcnt is in order)
+        // The region is free again once the element has read its stress and strain out of it -- behind the geometry, inside
+        // e2_element --: there the next tile's pieces are requested (all lanes of the wavefront get there together: a lane
+        // past the mesh runs the same code on its harmless gathers and stores nothing).
+        bool dma_done = false;
+        auto after = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tn < t_end) dma(tn);
+            asm volatile("" ::: "memory");
+            dma_done = true;
+        };
 #ifdef DES_STAMPS
         st_b = wall_clock64(); st_issue += st_b - st_a; st_a = st_b;
-        if (tn < t_end) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gathers have arrived
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gathers have arrived
         st_b = wall_clock64(); st_gather += st_b - st_a; st_a = st_b;
 #endif
         bool defer = false;
         if (valid)
             defer = e2_element<M, 0, 1, 0, RH, 1>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
-                                                  plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp, &cur, &G);
+                                                  plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp, &cur, &G, after);
+        if (!dma_done) after();                            // (a wavefront wholly past the mesh)
         // the count of elements past the yield pre-filter (des_scalars::n_return_mapping): one atomic per wavefront that has any
         const unsigned long long mask = __ballot(defer);
         if (defer && lane == __ffsll((long long)mask) - 1) atomicAdd(count, __popcll(mask));

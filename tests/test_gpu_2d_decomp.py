@@ -202,8 +202,7 @@ def test_a_cut_2d_engine_refuses_what_it_does_not_offer():
         assert e._lib.des_dev_exchange(e._h) == 30 and e._lib.des_dev_set_overlap(e._h, 1) == 30
     finally:
         group.close()
-    with pytest.raises(des.DesError):                   # the PT loop's residual test is global
-        DeviceGroup(des.Host(cfg_text=cfgs.make(**cfgs.EP), overrides="control.has_PT = yes\n", ndims=2), 2)
+    # (control.has_PT on a cut mesh used to be refused here; since round 4 it runs: test_2d_pseudo_transient_loop_on_a_cut_mesh)
 
 
 # ---- the whole 2-D program on several ranks (dynearthsol_amd/distributed.py) -----------------------------------
