@@ -36,6 +36,8 @@ def short(name):
              "k2_node_avg": "K2_node_avg", "k2_rotate_vol": "K2_rotate_vol"}
     if base in two_d:
         return two_d[base]
+    if base == "E2_update_stress_pipe":
+        return "E2G_geom_rotate_update_stress"          # the pipelined form of E2<GEO> (round 4): the same pass, the same profile id
     if base == "E2_update_stress":
         targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]      # <M, DEFER, GEO, RH>
         if len(targs) >= 3 and targs[2] == "1":
