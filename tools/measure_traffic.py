@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     """'void des_hip::E2_update_stress<desk::MathOcml, 1>(args)' -> 'E2_update_stress'"""
-    k = name.split("(")[0].replace("void ", "").strip()
+    k = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
     for ns in ("des_hip::", "des2d::", "(anonymous namespace)::"):
         if k.startswith(ns):
             k = k[len(ns):]
