@@ -244,9 +244,9 @@ def probe_schedules(ctx, dev, transport):
     beside the next step's passes on the deep part of the slab (engine/launch.hpp: deep_split_ok)?  Neither has run on two
     physical GPUs in the build container, so the untimed part of the run measures both (40 steps each, MAX over ranks)
     and the timed region takes the faster; DES_OVERLAP=0 / 1 pins it.  Both give the same bits
-    (tests/test_gpu_headline_decomp.py).  3-D engines only."""
+    (tests/test_gpu_headline_decomp.py; the 2-D engine's overlapped schedule: tests/test_gpu_2d_decomp.py)."""
     import torch
-    if ctx.world == 1 or not transport.startswith("RCCL") or os.environ.get("DES_OVERLAP") is not None or ctx.ndims == 2:
+    if ctx.world == 1 or not transport.startswith("RCCL") or os.environ.get("DES_OVERLAP") is not None:
         return None
     probe = {}
     for on in (0, 1):
@@ -269,7 +269,8 @@ def probe_schedules(ctx, dev, transport):
 def profile_leg(ctx, dev, nsteps=20):
     """per-kernel HIP-event timing on the engine's own stream (separate short run; EVERY rank takes these steps: a step
     is collective on a decomposed mesh).  Returns [(name, ms, calls)] and, for N > 1, per rank the exchange's us per call
-    and the step time WITHOUT the exchange (sum of every other pass's HIP-event time / steps)."""
+    and the step time WITHOUT the exchange (sum of every other pass's HIP-event time / steps; the 2-D engine times its six
+    priced launches only, so its figure is a lower bound: the small surface / boundary kernels are not in it)."""
     import torch
     dev.profile_enable(True)
     dev.step(nsteps, want_scalars=False)

@@ -1589,7 +1589,7 @@ int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
     }
     if (nranks) *nranks = h->comm ? n : 0;
     if (rank) *rank = r;
-    if (overlapped) *overlapped = !h->d2 && h->overlap && h->nnbr > 0 && h->e_int1 > h->e_int0;
+    if (overlapped) *overlapped = h->d2 ? des2d::overlapped(h->d2) : (h->overlap && h->nnbr > 0 && h->e_int1 > h->e_int0);
     return DES_OK;
 }
 
@@ -1597,7 +1597,7 @@ int des_dev_comm_info(des_dev *h, int *nranks, int *rank, int *overlapped)
 // create selects it from the start) between two des_dev_step calls.
 int des_dev_set_overlap(des_dev *h, int on)
 {
-    D2_REFUSE(h, "the overlapped schedule");
+    D2_FORWARD(h, set_overlap(h->d2, on));
     if (!h) return DES_ERR_INTERNAL;
     hipSetDevice(h->device);
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -2035,7 +2035,7 @@ double des_dev_algorithmic_bytes_per_step(const des_dev *h)
 int des_dev_debug_stamps(int pass, unsigned long long *out, int cap)
 {
     const size_t n = (size_t)DES_STAMP_SLOTS * DES_STAMP_WG;
-    if (!out || pass < 0 || pass > 2 || (size_t)cap < n) return (int)n;
+    if (!out || pass < 0 || pass > 3 || (size_t)cap < n) return (int)n;
     hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(des_hip::g_stamps), n * sizeof(unsigned long long), (size_t)pass * n * sizeof(unsigned long long),
                             hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -116,6 +116,20 @@ struct Engine {
     long long steps_host = 0;
     long long n_pt_iterations = 0;   // pseudo-transient iterations of the current step() call
     bool pt_defer = false;           // step_front stops in front of the pseudo-transient loop (step_group, des_dev_phase)
+    // Overlapped schedule of a decomposed mesh (round 4; DES_OVERLAP=1 or set_overlap): transfer, unpack and the wall's
+    // reduction of step t on a side stream beside compute_mass, update_temperature + compute_dvoldt and update_stress of
+    // step t + 1 on the blocks / elements far from the cut (set_halo: d_blist [0, nb_deep), d_elist [0, ne_deep)).
+    bool overlap = false, join_pending = false, wall_pending = false, far_issued = false;
+    const double *mT_in = nullptr; double *mT_out = nullptr;     // the two temperature buffers of the step whose far part is out
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_wall = nullptr;
+    int *d_blist = nullptr, *d_elist = nullptr;
+    int nb_deep = 0, ne_deep = 0;
+    long long back_steps = 0;        // the step whose surface bookkeeping waits behind the join
+    // host copies for set_halo's classification: the patch lists (own nodes, other nodes, elements of every block), the
+    // connectivity, the surface lists
+    std::vector<int> hp_po_ptr, hp_po_id, hp_pn_ptr, hp_pn_id, hp_pe_ptr, hp_pe_elem;
+    std::vector<int> h_conn, h_top_nodes, h_top_elems;
     std::vector<void *> allocs;
     std::string err;
     // per-kernel HIP-event accounting of the main launches (des_dev_profile_enable / _read; off: no events at all)
@@ -544,12 +558,15 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
           const double *props, const int *markers, double *edvoldt, double *volume, double *volume_old,
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
           double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
-          int nn, const double *coord, const double *vel, int rotate, int outs)
+          int nn, const double *coord, const double *vel, int rotate, int outs, const int *elist, int nlist)
 {
     M::stage_begin();
     M::stage_end();
-    const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (e >= ne) return;
+    // elist: the nlist elements of this launch (overlapped schedule of a decomposed mesh: the elements far from the cut, then
+    // the others); nullptr: elements 0 .. nlist - 1
+    const int t = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (t >= nlist) return;
+    const int e = elist ? elist[t] : t;
     const double dt = clk->dt;
     desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
     const double bulkm = props[e], shearm = props[ne + e];
@@ -1737,9 +1754,10 @@ enum { P2_TEMP = 0, P2_STRESS, P2_NODEAVG, P2_FORCE, P2_MASS, P2_ROTVOL, P2_EXCH
 static const char *const p2_names[P2_COUNT] = {"K2P_temp_dvoldt", "K2_stress", "K2_node_avg", "K2P_force", "K2P_mass", "K2_rotate_vol",
                                                "ghost_exchange"};
 struct Prof2 {
-    Engine *h; Engine::ProfRec rec; bool on;
-    Prof2(Engine *h_, int k) : h(h_), on(h_->prof) { if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, h->stream); } }
-    ~Prof2() { if (on) { hipEventRecord(rec.b, h->stream); h->prof_recs.push_back(rec); } }
+    Engine *h; Engine::ProfRec rec; bool on; hipStream_t s;
+    Prof2(Engine *h_, int k, hipStream_t s_ = nullptr) : h(h_), on(h_->prof), s(s_ ? s_ : h_->stream)
+    { if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, s); } }
+    ~Prof2() { if (on) { hipEventRecord(rec.b, s); h->prof_recs.push_back(rec); } }
 };
 
 void refresh_props(Engine *h)
@@ -1763,12 +1781,21 @@ inline bool wall_needs_zmin(const Engine *h) { return h->p.vbc_types[0] == 3 && 
 inline PatchArgs patch_args(const Engine *h)
 {
     PatchArgs a = {h->nn, h->ne, h->p_npb, h->p_nb, h->p_pn_cap, h->p_inc_cap, h->po_ptr, h->po_id, h->po_slot, h->pe_ptr, h->pe_pack, h->pn_ptr,
-                   h->pn_id, h->sup_idx};
+                   h->pn_id, h->sup_idx, nullptr};
     return a;
+}
+
+// overlapped schedule: the wall's extent of the step before may still be on its way through the side stream
+inline void join_wall(Engine *h)
+{
+    if (!h->wall_pending) return;
+    hipStreamWaitEvent(h->stream, h->ev_wall, 0);
+    h->wall_pending = false;
 }
 
 void launch_vbcs(Engine *h, bool apply = true, bool tick = false)
 {
+    join_wall(h);
     // (a decomposed mesh: the wall's extent is the cross-rank maximum wall_set left in the clock -- the coordinates
     // have not moved since it was taken, update_coordinate comes after apply_vbcs)
     if (!h->halo) {
@@ -1782,40 +1809,26 @@ void launch_vbcs(Engine *h, bool apply = true, bool tick = false)
     if (apply) L2(k2_apply_vbcs, h->nn, h->d_p, h->d_clk, h->nn, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->coord, h->vel);
 }
 
+// elist / nlist: the elements of this launch (nullptr: all ne); `first`: the first launch of this update_stress (a split one
+// has two); the caller clears geo_pending once the whole update is issued
 template <class M>
-void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr)
+void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr, const int *elist = nullptr, int nlist = -1, bool first = true)
 {
-    if (h->count_past) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
+    if (nlist < 0) nlist = h->ne;
+    if (nlist == 0) return;
+    if (h->count_past && first) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
     Prof2 pr(h, P2_STRESS);
     const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? 1 : 0;
+#define K2S_ARGS(out, outs) h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt, \
+        h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain, \
+        h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, out, h->nn, h->coord, h->vel, rot, outs, elist, nlist
     if (fused && h->p.rheol_type == DES_RH_EVP) {          // the common rheology has instantiations of its own
-        if (h->geo_pending)
-            L2((k2_stress<M, 2, DES_RH_EVP>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
-               h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-               h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
-        else
-            L2((k2_stress<M, 1, DES_RH_EVP>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
-               h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-               h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
-        h->geo_pending = false;
-        return;
-    }
-    if (fused && h->geo_pending) {
-        L2((k2_stress<M, 2>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
-           h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
-        h->geo_pending = false;
-        return;
-    }
-    if (fused) {
-        L2((k2_stress<M, 1>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
-           h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-           h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, stress_out, h->nn, h->coord, h->vel, rot, h->elide ? 0 : 1);
-        return;
-    }
-    L2((k2_stress<M, 0>), h->ne, h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt,
-       h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain,
-       h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, h->stress, h->nn, h->coord, h->vel, rot, 1);
+        if (h->geo_pending) L2((k2_stress<M, 2, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
+        else                L2((k2_stress<M, 1, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
+    } else if (fused && h->geo_pending) L2((k2_stress<M, 2>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
+    else if (fused)                     L2((k2_stress<M, 1>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
+    else                                L2((k2_stress<M, 0>), nlist, K2S_ARGS(h->stress, 1));
+#undef K2S_ARGS
 }
 
 // update_force's boundary terms in the reference's order (fields.cxx:682-691)
@@ -1870,8 +1883,8 @@ void launch_surface_commit(Engine *h)
            h->total_slope, h->coord, h->dhacc, h->dh);
 }
 
-// ... and the rest
-void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer = false)
+// ... and the rest, in two parts: the surface bookkeeping (it reads the ghost nodes' heights) ...
+void launch_update_mesh_surface(Engine *h, long long steps)
 {
     const des_params &p = h->p;
     const bool at_interval = steps % p.quality_check_step_interval == 0;
@@ -1884,7 +1897,8 @@ void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer
                                h->edvacc, h->volume, h->plstrain, h->stress, h->strain, h->strain_rate);
         hipLaunchKernelGGL(k2_cse_node_maxdh, dim3(nbn + 1), dim3(DES_BLOCK), 0, h->stream, h->ntop, nbn, h->top_nodes, h->sup_idx, h->sup_arr,
                            h->volume, h->volume_n, (steps != 0 && at_interval) ? 1 : 0, h->dhacc, h->o0, h->o1, h->dh, h->d_clk);
-    } else {
+        return;
+    }
     if (h->etop > 0)
         L2(k2_surf_edv, h->etop, h->etop, h->nn, h->ean, h->conn_surf, h->coord, h->dh, h->edvacc);
     hipLaunchKernelGGL(k2_surf_maxdh, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->ntop, h->top_nodes, h->o0, h->o1, h->dh, h->d_clk);
@@ -1894,18 +1908,32 @@ void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer
     if (h->ntop > 0)
         L2(k2_cse_node, h->ntop, h->ntop, h->top_nodes, h->sup_idx, h->sup_arr, h->volume, h->volume_n,
            (steps != 0 && at_interval) ? 1 : 0, h->dhacc);
-    }
+}
+
+// compute_mass over the node-block patches (it forms the volumes it sums from the coordinates); blist / nb: the blocks of this launch
+void launch_patch_mass(Engine *h, const int *blist = nullptr, int nb = -1, const double *T = nullptr)
+{
+    PatchArgs a = patch_args(h);
+    if (!T) T = h->temperature;
+    if (nb >= 0) { a.blist = blist; a.nb = nb; }
+    if (a.nb == 0) return;
+    Prof2 pr(h, P2_MASS);
+    hipLaunchKernelGGL(k2p_mass, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (3 * (size_t)h->p_pn_cap + 4 * (size_t)h->p_inc_cap), h->stream, h->d_p, a, h->coord,
+                       T, h->props, h->markers, h->volume_n, h->mass, h->tmass, h->ymass);
+}
+
+// ... and compute_volume, rotate_stress, compute_mass
+void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer = false)
+{
+    launch_update_mesh_surface(h, steps);
     if (!defer) std::swap(h->volume, h->volume_old);
     refresh_props(h);
     if (h->patch) {
         // compute_volume + rotate_stress in one element pass -- or, inside a multi-step call, left to the next step's stress
-        // update (k2_stress<M, 2>), which reads and writes the same stress and strain anyway; compute_mass over the
-        // node-block patches (it forms the volumes it sums from the coordinates)
+        // update (k2_stress<M, 2>), which reads and writes the same stress and strain anyway
         if (defer) h->geo_pending = true;
         else { Prof2 pr(h, P2_ROTVOL); L2(k2_rotate_vol, h->ne, h->d_clk, rotate ? 1 : 0, h->nn, h->ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain); }
-        Prof2 pr(h, P2_MASS);
-        hipLaunchKernelGGL(k2p_mass, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (3 * (size_t)h->p_pn_cap + 4 * (size_t)h->p_inc_cap), h->stream, h->d_p, patch_args(h), h->coord,
-                           h->temperature, h->props, h->markers, h->volume_n, h->mass, h->tmass, h->ymass);
+        launch_patch_mass(h);
         return;
     }
     launch_volume_mass(h, true);
@@ -1929,27 +1957,65 @@ int sync_clock(Engine *h)
 // strain rate -> stress -> force -> velocity -> residual: the part of a step the pseudo-transient loop repeats
 // Patch path: `thermal` -- update_temperature rides in the first patch pass; `tail` -- apply_vbcs and update_coordinate
 // follow in the velocity kernel (a plain step with a moving mesh), the residual's final sum is left to the surface kernel.
+// update_temperature + compute_dvoldt over the listed node blocks (nullptr / -1: all of them); T_in -> T_out
+void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_out, const int *blist = nullptr, int nb = -1)
+{
+    PatchArgs a = patch_args(h);
+    if (nb >= 0) { a.blist = blist; a.nb = nb; }
+    if (a.nb == 0) return;
+    Prof2 pr(h, P2_TEMP);
+    hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0,
+                       h->geo_pending ? 1 : 0, a,
+                       h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic, h->props,
+                       h->markers, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
+}
+
+// Overlapped schedule: the first two passes of a step on the blocks and elements far from the cut (set_halo: nothing they
+// read is written by the unpack or by the surface bookkeeping left over from the step before) -- issued while that step's
+// exchange is still on the side stream, by launch_mechanics or, earlier, by front_begin
+template <class M>
+void launch_mechanics_far(Engine *h, bool nmd, bool thermal)
+{
+    // (the new temperatures go to the other buffer: a block must not move a temperature another block may still read)
+    h->mT_in = h->temperature; h->mT_out = h->temperature_alt;
+    if (thermal) std::swap(h->temperature, h->temperature_alt);         // k2_stress reads the new ones
+    launch_temp_dvoldt(h, thermal, h->mT_in, h->mT_out, h->d_blist, h->nb_deep);
+    launch_stress<M>(h, true, nmd ? h->stress_pre : h->stress, h->d_elist, h->ne_deep, true);
+    h->far_issued = true;
+}
+
 template <class M>
 void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = false)
 {
     const int nn = h->nn, ne = h->ne;
     if (h->patch) {
         const PatchArgs a = patch_args(h);
-        { Prof2 pr(h, P2_TEMP);
-        hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0,
-                           h->geo_pending ? 1 : 0, a,
-                           h->bcflag, h->coord, h->vel, h->temperature, h->temperature_alt, h->volume, h->radiogenic, h->props,
-                           h->markers, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
-        }
-        if (thermal) std::swap(h->temperature, h->temperature_alt);
         double *const s_law = nmd ? h->stress_pre : h->stress;
-        launch_stress<M>(h, true, s_law);
+        if (h->join_pending) {
+            // overlapped schedule: behind the join with the exchange of the step before, that step's surface bookkeeping,
+            // compute_mass of the blocks near the cut (on the temperatures of that step), and the rest of the two passes
+            if (!h->far_issued) launch_mechanics_far<M>(h, nmd, thermal);
+            hipStreamWaitEvent(h->stream, h->ev_join, 0);
+            h->join_pending = false; h->far_issued = false;
+            launch_update_mesh_surface(h, h->back_steps);
+            launch_patch_mass(h, h->d_blist + h->nb_deep, h->p_nb - h->nb_deep, h->mT_in);
+            launch_temp_dvoldt(h, thermal, h->mT_in, h->mT_out, h->d_blist + h->nb_deep, h->p_nb - h->nb_deep);
+            launch_stress<M>(h, true, s_law, h->d_elist + h->ne_deep, ne - h->ne_deep, false);
+        } else {
+            const double *const T_in = h->temperature;
+            double *const T_out = h->temperature_alt;
+            if (thermal) std::swap(h->temperature, h->temperature_alt);
+            launch_temp_dvoldt(h, thermal, T_in, T_out);
+            launch_stress<M>(h, true, s_law);
+        }
+        h->geo_pending = false;
         if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
         { Prof2 pr(h, P2_FORCE);
         hipLaunchKernelGGL(k2p_force, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
                            h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->force, h->fres);
         }
         launch_stress_bcs(h);
+        join_wall(h);
         if (tail) {
             launch_vbcs(h, false, h->tick_pending);     // the wall's extent into the clock (the coordinates have not moved yet)
             h->tick_pending = false;
@@ -2068,12 +2134,10 @@ int pt_loop(Engine *h)
 
 int step_front_rest(Engine *h);
 
-// A step up to the committed surface heights ...
-template <class M>
-int step_front(Engine *h)
+// the step counted, the material means up to date
+void front_clock(Engine *h)
 {
     const des_params &p = h->p;
-    const int nn = h->nn, ne = h->ne;
     const bool tail = h->patch && !h->iso && !p.has_PT && p.has_moving_mesh;
     if (!h->iso) {
         if (tail && !h->halo) h->tick_pending = true;      // (k2_vbc_extent counts the step)
@@ -2081,6 +2145,25 @@ int step_front(Engine *h)
         ++h->steps_host;
     }
     refresh_props(h);
+}
+
+// Overlapped schedule: the beginning of the NEXT step, issued before the host turns to the exchange of this one (whose
+// RCCL calls cost the host tens of microseconds: the device has this much to do meanwhile).  step_front picks up behind it.
+template <class M>
+void front_begin(Engine *h)
+{
+    front_clock(h);
+    launch_mechanics_far<M>(h, !h->iso && h->p.is_using_mixed_stress, !h->iso && h->p.has_thermal_diffusion);
+}
+
+// A step up to the committed surface heights ...
+template <class M>
+int step_front(Engine *h)
+{
+    const des_params &p = h->p;
+    const int nn = h->nn, ne = h->ne;
+    const bool tail = h->patch && !h->iso && !p.has_PT && p.has_moving_mesh;
+    if (!h->far_issued) front_clock(h);                    // (else front_begin has done this much of the step already)
     const bool thermal = !h->iso && p.has_thermal_diffusion;
     if (thermal && !h->patch) {
         L2(k2_temp_elem, ne, h->d_p, nn, ne, h->conn, h->coord, h->temperature, h->volume, h->radiogenic, h->props, h->markers, h->tmp_result);
@@ -2115,6 +2198,36 @@ int step_front_rest(Engine *h)
     return DES_OK;
 }
 
+// the end-of-step element pass rides in the next stress update: a plain step (no compute_dt, which wants this step's
+// volumes; no averaging, which wants its rotated stress; no PT loop, which re-enters the passes)
+inline bool defer_ok(const Engine *h, bool more)
+{
+    const des_params &p = h->p;
+    const bool rotate = !h->iso && (p.rheol_type & DES_RH_ELASTIC);
+    const bool moved = p.has_moving_mesh || h->iso;
+    return more && h->patch && moved && rotate && !p.is_outputting_averaged_fields && !p.has_PT
+           && h->steps_host % 10 != 0 && h->geo_on;
+}
+
+// Overlapped schedule: this step's exchange may run beside the next step's first passes when nothing else of this step
+// is left to do (a deferring step) and the slab has blocks and elements far enough from the cut
+inline bool overlap_ok(const Engine *h, bool more)
+{
+    return h->overlap && h->halo && h->halo_set && h->nb_deep > 0 && h->ne_deep > 0 && defer_ok(h, more);
+}
+
+// step_back of such a step: what launch_update_mesh_rest(defer) would do, less everything that reads the ghost region --
+// the surface bookkeeping and compute_mass of the blocks near the cut wait behind the join in the next step's front
+// (launch_mechanics); compute_mass of the far blocks goes now
+void step_back_overlapped(Engine *h)
+{
+    h->back_steps = h->steps_host;
+    refresh_props(h);
+    h->geo_pending = true;
+    launch_patch_mass(h, h->d_blist, h->nb_deep);
+    h->join_pending = true;
+}
+
 // ... and from there on (a decomposed mesh has refreshed its ghost region in between); compute_dt excluded
 // `more`: another step of the same call follows at once (nothing reads the element fields in between)
 void step_back(Engine *h, bool more = false)
@@ -2123,10 +2236,7 @@ void step_back(Engine *h, bool more = false)
     const int nn = h->nn, ne = h->ne;
     const bool rotate = !h->iso && (p.rheol_type & DES_RH_ELASTIC);
     const bool moved = p.has_moving_mesh || h->iso;
-    // the end-of-step element pass rides in the next stress update: a plain step (no compute_dt, which wants this step's
-    // volumes; no averaging, which wants its rotated stress; no PT loop, which re-enters the passes)
-    const bool defer = more && h->patch && moved && rotate && !p.is_outputting_averaged_fields && !p.has_PT
-                       && h->steps_host % 10 != 0 && h->geo_on;
+    const bool defer = defer_ok(h, more);
     if (moved) launch_update_mesh_rest(h, h->steps_host, rotate, defer);
     if (h->iso) return;
     if (rotate && !(h->patch && moved))
@@ -2169,17 +2279,22 @@ void launch_pack(Engine *h)
        h->temperature, h->top_pos, h->dh, h->stress, h->strain, h->plstrain, h->stressyy, h->d_sendbuf);
 }
 
-void launch_unpack(Engine *h)
+// (xs: the engine's stream, or the side stream of the overlapped schedule)
+void launch_unpack(Engine *h, hipStream_t xs = nullptr)
 {
     const int nq = h->nnbr, n = h->recv_ptr[nq], m = h->erecv_ptr[nq];
     if (n + m == 0) return;
-    L2(k2_state_unpack, n + m, n, h->d_recv_idx, h->d_recv_noff, m, h->d_erecv_idx, h->d_recv_eoff, h->nn, h->ne, h->coord, h->vel,
-       h->temperature, h->top_pos, h->dh, h->stress, h->strain, h->plstrain, h->stressyy, h->d_recvbuf);
+    // (overlapped schedule: the far part of the next step is out already and has swapped the temperature buffers -- the
+    //  ghost nodes' temperatures belong into the one that step reads)
+    double *const T = h->far_issued ? const_cast<double *>(h->mT_in) : h->temperature;
+    hipLaunchKernelGGL(k2_state_unpack, dim3(nblk(n + m)), dim3(DES_BLOCK), 0, xs ? xs : h->stream, n, h->d_recv_idx, h->d_recv_noff, m,
+                       h->d_erecv_idx, h->d_recv_eoff, h->nn, h->ne, h->coord, h->vel,
+                       T, h->top_pos, h->dh, h->stress, h->strain, h->plstrain, h->stressyy, h->d_recvbuf);
 }
 
-void launch_wall_local(Engine *h)
+void launch_wall_local(Engine *h, hipStream_t xs = nullptr)
 {
-    hipLaunchKernelGGL(k2_wall_local, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord,
+    hipLaunchKernelGGL(k2_wall_local, dim3(1), dim3(DES_BLOCK), 0, xs ? xs : h->stream, h->nbn[iboundx0], h->bnodes[iboundx0], h->nn, h->coord,
                        wall_needs_zmin(h) ? 1 : 0, h->d_red);
 }
 
@@ -2197,11 +2312,16 @@ void destroy(Engine *h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->xstream) hipStreamSynchronize(h->xstream);
     for (void *q : h->allocs) hipFree(q);
     if (h->h_clk) hipHostFree(h->h_clk);
     if (h->h_red) hipHostFree(h->h_red);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->ev_wall) hipEventDestroy(h->ev_wall);
+    if (h->xstream) hipStreamDestroy(h->xstream);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2211,6 +2331,11 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     const int nn = h->nn = mesh->nnode, ne = h->ne = mesh->nelem, nmat = h->nmat = params->nmat;
     h->o0 = 0; h->o1 = nn; h->nn_global = nn;
     HIP2(hipStreamCreate(&h->stream));
+    HIP2(hipStreamCreate(&h->xstream));
+    HIP2(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP2(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIP2(hipEventCreateWithFlags(&h->ev_wall, hipEventDisableTiming));
+    { const char *ov = des_env::get("DES_OVERLAP"); h->overlap = ov && ov[0] == '1'; }
     HIP2(hipEventCreate(&h->ev0));
     HIP2(hipEventCreate(&h->ev1));
     HIP2(hipHostMalloc((void **)&h->h_clk, sizeof(Clock)));
@@ -2299,6 +2424,12 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
             A2(dcopy(h, h->pn_ptr, P.pn_ptr.data(), P.pn_ptr.size()));
             A2(dcopy(h, h->pn_id, P.pn_id.data(), P.pn_id.size()));
             A2(dalloc(h, h->temperature_alt, (size_t)nn));
+            h->hp_po_ptr = P.po_ptr; h->hp_po_id = P.po_id; h->hp_pn_ptr = P.pn_ptr; h->hp_pn_id = P.pn_id; h->hp_pe_ptr = P.pe_ptr;
+            h->hp_pe_elem.resize(P.pe_pack.size());
+            for (size_t q = 0; q < P.pe_pack.size(); ++q) h->hp_pe_elem[q] = (int)(P.pe_pack[q].x & 0x3fffffffull);
+            h->h_conn.assign(mesh->connectivity, mesh->connectivity + (size_t)3 * ne);
+            h->h_top_nodes.assign(mesh->top_nodes, mesh->top_nodes + h->ntop);
+            h->h_top_elems.assign(mesh->top_elems, mesh->top_elems + h->ntop_elems);
             for (int i = 0; i < DES_NBDRY; ++i) {
                 if (h->nbf[i] == 0 || h->nbn[i] == 0) continue;
                 // k2_sbc_node's walk, once: the marks k2_sbc_facet leaves (the last facet of an element wins), then for every
@@ -2491,6 +2622,47 @@ static int exchange_rccl(Engine *h)
     return wall_allreduce(h);
 }
 
+// Overlapped schedule: the pack on the engine's stream (it reads what the next step's stress update is about to change),
+// then transfer, unpack and the wall's reduction on the side stream; ev_join: the ghost region is refreshed, ev_wall: the
+// wall's extent is in the clock.  launch_mechanics / join_wall make the engine's stream wait for them.
+static int exchange_pack_fork(Engine *h)
+{
+    launch_pack(h);
+    HIP2(hipEventRecord(h->ev_fork, h->stream));
+    return DES_OK;
+}
+static int exchange_side(Engine *h)
+{
+    HIP2(hipStreamWaitEvent(h->xstream, h->ev_fork, 0));
+    const hipStream_t xs = h->xstream;
+    {
+        Prof2 pr(h, P2_EXCH, xs);
+        NCCL2(ncclGroupStart());
+        for (int q = 0; q < h->nnbr; ++q) {
+            NCCL2(ncclSend(h->d_sendbuf + h->send_off[q], (size_t)(h->send_off[q+1] - h->send_off[q]), ncclDouble, h->nbr_rank[q], h->comm, xs));
+            NCCL2(ncclRecv(h->d_recvbuf + h->recv_off[q], (size_t)(h->recv_off[q+1] - h->recv_off[q]), ncclDouble, h->nbr_rank[q], h->comm, xs));
+        }
+        NCCL2(ncclGroupEnd());
+        launch_unpack(h, xs);
+        HIP2(hipEventRecord(h->ev_join, xs));
+        launch_wall_local(h, xs);
+        NCCL2(ncclAllReduce(h->d_red, h->d_red, 3, ncclDouble, ncclMax, h->comm, xs));
+        hipLaunchKernelGGL(k2_wall_set_from, dim3(1), dim3(1), 0, xs, h->d_clk, h->d_red, wall_needs_zmin(h) ? 1 : 0);
+    }
+    HIP2(hipEventRecord(h->ev_wall, xs));
+    h->wall_pending = true;
+    return DES_OK;
+}
+
+// a step that fails half-way must not leave the engine between two pieces of the overlapped schedule
+static int step_abort(Engine *h, int rc)
+{
+    hipStreamSynchronize(h->xstream);
+    hipStreamSynchronize(h->stream);
+    h->join_pending = false; h->wall_pending = false; h->far_issued = false;
+    return rc;
+}
+
 static int dt_allreduce(Engine *h, bool recompute)
 {
     if (recompute) launch_dt_partials(h);
@@ -2527,9 +2699,21 @@ int step(Engine *h, int nsteps, des_scalars *out)
             h->count_past = (i == nsteps - 1);
             h->elide = elide_ok(h, i < nsteps - 1);
             int rc = h->portable_libm ? step_front<desk::MathPortable>(h) : step_front<desk::MathOcml>(h);
-            if (rc || (rc = exchange_rccl(h))) return rc;
+            if (rc) return step_abort(h, rc);
+            if (overlap_ok(h, i < nsteps - 1)) {
+                // the messages packed; then, BEFORE the host spends its time in RCCL, everything the device can do meanwhile:
+                // compute_mass of the far blocks and the far part of the next step's first two passes
+                if ((rc = exchange_pack_fork(h))) return step_abort(h, rc);
+                step_back_overlapped(h);
+                h->count_past = (i + 1 == nsteps - 1);
+                h->elide = elide_ok(h, i + 1 < nsteps - 1);
+                if (h->portable_libm) front_begin<desk::MathPortable>(h); else front_begin<desk::MathOcml>(h);
+                if ((rc = exchange_side(h))) return step_abort(h, rc);
+                continue;
+            }
+            if ((rc = exchange_rccl(h))) return step_abort(h, rc);
             step_back(h, i < nsteps - 1);
-            if (!h->iso && h->steps_host % 10 == 0 && (rc = dt_allreduce(h, true))) return rc;
+            if (!h->iso && h->steps_host % 10 == 0 && (rc = dt_allreduce(h, true))) return step_abort(h, rc);
         }
         HIP2(hipGetLastError());
         if (!out) return DES_OK;
@@ -2583,6 +2767,63 @@ int body_force_adjustment(Engine *h, des_scalars *out)
 // order + four element layers of ghost region); one exchange per step after the surface heights are committed.
 // Beside the ghost records two small reductions cross the ranks: the x0 wall's vertical extent apply_vbcs scales its
 // velocity profiles with (every step, MAX of three), and compute_dt's minima (every 10th step).
+// The split of the overlapped schedule.  A block is FAR from the cut when no node of its patch (its own and the others) is
+// written by the unpack -- a node of a receive list or any node outside the owned range -- or lies on the surface, and no
+// element of its patch is received or belongs to the surface elements (correct_surface_element rewrites their volume,
+// stress and strain in the bookkeeping that waits behind the join); an element when its three nodes belong to far blocks
+// and it is neither received nor a surface element.  What k2p_mass, k2p_temp_dvoldt and k2_stress read and write for
+// those is then disjoint from everything the side stream and the postponed bookkeeping touch.  d_blist / d_elist: the far
+// ones first (ascending), then the others.
+static int build_deep_lists(Engine *h, const des_halo *halo)
+{
+    h->nb_deep = 0; h->ne_deep = 0;
+    if (!h->patch || halo->nnbr == 0) return DES_OK;
+    const int nn = h->nn, ne = h->ne, nb = h->p_nb, nq = halo->nnbr;
+    std::vector<char> wn((size_t)nn, 0), we((size_t)ne, 0);
+    for (int n = 0; n < nn; ++n) if (n < h->o0 || n >= h->o1) wn[n] = 1;
+    for (int k = 0; k < halo->recv_ptr[nq]; ++k) wn[halo->recv_idx[k]] = 1;
+    for (int k = 0; k < halo->erecv_ptr[nq]; ++k) we[halo->erecv_idx[k]] = 1;
+    for (int n : h->h_top_nodes) wn[n] = 1;
+    for (int e : h->h_top_elems) we[e] = 1;
+    std::vector<char> far_b((size_t)nb, 1);
+    std::vector<int> blk_of((size_t)nn, 0);
+    for (int b = 0; b < nb; ++b) {
+        for (int k = h->hp_po_ptr[b]; k < h->hp_po_ptr[b + 1]; ++k) { blk_of[h->hp_po_id[k]] = b; if (wn[h->hp_po_id[k]]) far_b[b] = 0; }
+        for (int k = h->hp_pn_ptr[b]; k < h->hp_pn_ptr[b + 1] && far_b[b]; ++k) if (wn[h->hp_pn_id[k]]) far_b[b] = 0;
+        for (int k = h->hp_pe_ptr[b]; k < h->hp_pe_ptr[b + 1] && far_b[b]; ++k) if (we[h->hp_pe_elem[k]]) far_b[b] = 0;
+    }
+    std::vector<int> blist, elist;
+    blist.reserve((size_t)nb); elist.reserve((size_t)ne);
+    for (int b = 0; b < nb; ++b) if (far_b[b]) blist.push_back(b);
+    const int nb_deep = (int)blist.size();
+    for (int b = 0; b < nb; ++b) if (!far_b[b]) blist.push_back(b);
+    std::vector<char> far_e((size_t)ne, 0);
+    for (int e = 0; e < ne; ++e) {
+        if (we[e]) continue;
+        bool far = true;
+        for (int i = 0; i < 3; ++i) far = far && far_b[blk_of[h->h_conn[(size_t)i * ne + e]]];
+        far_e[e] = far;
+    }
+    for (int e = 0; e < ne; ++e) if (far_e[e]) elist.push_back(e);
+    const int ne_deep = (int)elist.size();
+    for (int e = 0; e < ne; ++e) if (!far_e[e]) elist.push_back(e);
+    int rc;
+    if ((rc = dcopy(h, h->d_blist, blist.data(), blist.size())) || (rc = dcopy(h, h->d_elist, elist.data(), elist.size()))) return rc;
+    h->nb_deep = nb_deep; h->ne_deep = ne_deep;
+    if (des_env::get("DES_PATCH_VERBOSE"))
+        std::fprintf(stderr, "2-D overlapped schedule: %d of %d blocks and %d of %d elements far from the cut\n", nb_deep, nb, ne_deep, ne);
+    return DES_OK;
+}
+
+// des_dev_set_overlap / des_dev_comm_info for a 2-D engine
+int set_overlap(Engine *h, int on)
+{
+    if (h->join_pending || h->wall_pending) { h->err = "des_dev_set_overlap inside a step"; return DES_ERR_INTERNAL; }
+    h->overlap = on != 0;
+    return DES_OK;
+}
+int overlapped(const Engine *h) { return h->overlap && h->halo && h->nb_deep > 0 && h->ne_deep > 0; }
+
 int set_halo(Engine *h, const des_halo *halo, int nn_global)
 {
     HIP2(hipSetDevice(h->device));
@@ -2630,6 +2871,7 @@ int set_halo(Engine *h, const des_halo *halo, int nn_global)
         for (int i = 0; i < h->ntop; ++i) pos[top[i]] = i;
         A2(dcopy(h, h->top_pos, pos.data(), pos.size()));
     }
+    A2(build_deep_lists(h, halo));
 #undef A2
     return DES_OK;
 }
@@ -2863,6 +3105,41 @@ int step_group(Engine **g, int n, int nsteps, des_scalars *out)
             }
             for (int k = 0; k < n; ++k) { if ((rc = set_pt(g[k], 0)) || (rc = step_front_rest(g[k]))) return rc; }
         }
+        // Overlapped schedule (every engine takes the same decision): messages, unpack and the wall's local extent on the side
+        // streams; compute_mass of the far blocks on the engines' streams at once, the rest of the step behind the join in the
+        // next step's front -- the launches of a rank on RCCL in the same order, the transfer a device-to-device copy
+        bool ov = true;
+        for (int k = 0; k < n; ++k) ov = ov && overlap_ok(g[k], i < nsteps - 1);
+        if (ov) {
+            for (int k = 0; k < n; ++k) launch_pack(g[k]);
+            for (int k = 0; k < n; ++k) HIP2(hipStreamSynchronize(g[k]->stream));
+            for (int k = 0; k < n; ++k) {
+                Engine *e = g[k];
+                for (int q = 0; q < e->nnbr; ++q) {
+                    Engine *o = g[e->nbr_rank[q]];
+                    int qo = 0;
+                    for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
+                    const long long len = e->recv_off[q + 1] - e->recv_off[q];
+                    if (len) HIP2(hipMemcpyAsync(e->d_recvbuf + e->recv_off[q], o->d_sendbuf + o->send_off[qo], (size_t)len * sizeof(double),
+                                                 hipMemcpyDeviceToDevice, e->xstream));
+                }
+                launch_unpack(e, e->xstream);
+                HIP2(hipEventRecord(e->ev_join, e->xstream));
+                launch_wall_local(e, e->xstream);
+                HIP2(hipMemcpyAsync(e->h_red, e->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, e->xstream));
+                step_back_overlapped(e);
+                e->count_past = (i + 1 == nsteps - 1);
+                e->elide = elide_ok(e, i + 1 < nsteps - 1);
+                if (e->portable_libm) front_begin<desk::MathPortable>(e); else front_begin<desk::MathOcml>(e);
+            }
+            double wall[3] = {-DBL_MAX, -DBL_MAX, 0.0};
+            for (int k = 0; k < n; ++k) {
+                HIP2(hipStreamSynchronize(g[k]->xstream));
+                for (int q = 0; q < 3; ++q) wall[q] = std::max(wall[q], g[k]->h_red[q]);
+            }
+            for (int k = 0; k < n; ++k) launch_wall_set(g[k], wall);
+            continue;
+        }
         { const int rcx = exchange_all(true); if (rcx) return rcx; }
         bool do_dt = false;
         for (int k = 0; k < n; ++k) {
@@ -2952,6 +3229,7 @@ int profile_read(Engine *h, int cap, char (*names)[64], double *ms, long long *c
 {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    hipStreamSynchronize(h->xstream);
     for (Engine::ProfRec &r : h->prof_recs) {
         float t = 0;
         if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { h->prof_ms[r.k] += t; h->prof_calls[r.k] += 1; }

@@ -9,7 +9,7 @@
 // (geometry.cxx:1566-1576, 1901-1906).  Every des_dev_* entry point dispatches here when the
 // handle holds a 2-D engine, the domain decomposition included (node slabs along x, the two-phase
 // step with the caller's exchange, des_dev_step_group, des_dev_step on an RCCL communicator);
-// what it does not offer (the overlapped schedule) returns DES_ERR_UNSUPPORTED_DIM.
+// the overlapped schedule of des_dev_set_overlap as well (round 4).
 //
 // Arrays stay in the reference's own SoA layout and the caller's numbering: the 2-D configs of
 // BASELINE.json are the CPU-runnable plumbing case (configs[0]), bit-for-bit parity with the
@@ -61,6 +61,9 @@ int residual_set(Engine *h, const double *blocks, int nblocks, double *l2);
 // the RCCL communicator (an ncclComm_t the caller owns) des_dev_step / init_geometry / compute_dt of a decomposed engine use
 int comm_selfcheck(Engine *h, int expect_world, int expect_rank);
 int set_comm(Engine *h, void *comm);
+// the overlapped schedule (des_dev_set_overlap, des_dev_comm_info)
+int set_overlap(Engine *h, int on);
+int overlapped(const Engine *h);
 
 } // namespace des2d
 

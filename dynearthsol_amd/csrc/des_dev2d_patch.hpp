@@ -146,7 +146,16 @@ __device__ __forceinline__ PatchElem2 patch_elem2(const ulonglong2 r)
 
 // pn_cap / inc_cap: LDS entries per nodal array / per slot array = the mesh's largest block, rounded up (dynamic LDS: a
 // workgroup takes what the mesh needs, not the caps, so that more of them fit a CU)
-struct PatchArgs { int nn, ne, npb, nb, pn_cap, inc_cap; const int *po_ptr, *po_id, *po_slot, *pe_ptr; const ulonglong2 *pe_pack; const int *pn_ptr, *pn_id, *sup_idx; };
+// nb / blist: the blocks of THIS launch -- all of them (blist = nullptr), or the nb listed ones (overlapped schedule of a
+// decomposed mesh: the blocks far from the cut first, the others behind the join with the exchange)
+struct PatchArgs { int nn, ne, npb, nb, pn_cap, inc_cap; const int *po_ptr, *po_id, *po_slot, *pe_ptr; const ulonglong2 *pe_pack; const int *pn_ptr, *pn_id, *sup_idx;
+                   const int *blist; };
+__device__ __forceinline__ int patch_block(const PatchArgs &a)
+{
+    const int b = desk::logical_block(a.nb);
+    if (b >= a.nb) return -1;
+    return a.blist ? a.blist[b] : b;
+}
 
 // ---- update_temperature + compute_dvoldt ------------------------------------------------------------
 // thermal = 0: the temperature stands (isostasy loop, pseudo-transient iterations, has_thermal_diffusion = no).
@@ -161,8 +170,8 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
     double *const lf0 = lT + a.pn_cap, *const lf1 = lf0 + a.inc_cap;
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
-    const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
-    if (b >= a.nb) return;
+    const int b = patch_block(a), nn = a.nn, ne = a.ne;
+    if (b < 0) return;
     const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     // everything that does not depend on the staged records is loaded first, so that a workgroup's trips to memory overlap:
@@ -258,8 +267,8 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap, *const lnt = lT + a.pn_cap;
     double *const lf0 = lnt + a.pn_cap, *const lf1 = lf0 + a.inc_cap;
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
-    const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
-    if (b >= a.nb) return;
+    const int b = patch_block(a), nn = a.nn, ne = a.ne;
+    if (b < 0) return;
     const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     const double gravity = p->gravity;
@@ -345,8 +354,8 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap;
     double *const lf0 = lT + a.pn_cap, *const lf1 = lf0 + a.inc_cap, *const lf2 = lf1 + a.inc_cap, *const lf3 = lf2 + a.inc_cap;
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
-    const int b = desk::logical_block(a.nb), nn = a.nn, ne = a.ne;
-    if (b >= a.nb) return;
+    const int b = patch_block(a), nn = a.nn, ne = a.ne;
+    if (b < 0) return;
     const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     ulonglong2 rec[DES2_PATCH_IT];

@@ -14,7 +14,7 @@ struct ElemProps { double bulkm, shearm, phi, cp, k; };
 #ifdef DES_STAMPS
 #define DES_STAMP_WG 8192
 #define DES_STAMP_SLOTS 8
-__device__ unsigned long long g_stamps[3][DES_STAMP_SLOTS][DES_STAMP_WG];          // [EN1 | EN3 | E2 pipelined: per wavefront, summed over its tiles][slot][workgroup]
+__device__ unsigned long long g_stamps[4][DES_STAMP_SLOTS][DES_STAMP_WG];          // [EN1 | EN3 | E2 pipelined: per wavefront, summed over its tiles][slot][workgroup]
 #define DES_STAMP(pass, slot) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < DES_STAMP_WG) g_stamps[pass][slot][blockIdx.x] = wall_clock64(); } while (0)
 #define DES_STAMP0(pass, slot) do { if (threadIdx.x == 0 && blockIdx.x < DES_STAMP_WG) g_stamps[pass][slot][blockIdx.x] = wall_clock64(); } while (0)
 #else

@@ -71,6 +71,14 @@ __device__ __forceinline__ void e2_gather(E2Gath &G, const int4 cn, const d4 *__
     G.nt[0] = rec_ld(ntmp, cn.x); G.nt[1] = rec_ld(ntmp, cn.y); G.nt[2] = rec_ld(ntmp, cn.z); G.nt[3] = rec_ld(ntmp, cn.w);
 }
 
+#ifdef DES_STAMPS
+// instrumented builds: where inside the element code a wavefront of the pipelined kernel spends its tile (sums per wavefront)
+struct E2Stamps { unsigned long long t, geo, dma, strain, visc, law, store; };
+#define DES_E2_STAMP(field) do { if (PIPE && est) { const unsigned long long now_ = wall_clock64(); est->field += now_ - est->t; est->t = now_; } } while (0)
+#else
+struct E2Stamps;
+#define DES_E2_STAMP(field) do {} while (0)
+#endif
 template <class M, int DEFER, int GEO, int RM = 0, int RH = 0, int PIPE = 0, class After = E2NoAfter>
 __device__ __forceinline__ bool e2_element(const int e, const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt,
      const DevClock *__restrict__ clk, int ne, const int4 *__restrict__ conn, const d4 *__restrict__ xt,
@@ -79,7 +87,8 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
      double *__restrict__ dpressure, double *__restrict__ etmp2, const RotPending rp,
-     const E2Pre *__restrict__ pre = nullptr, const E2Gath *__restrict__ gath = nullptr, const After after = After())
+     const E2Pre *__restrict__ pre = nullptr, const E2Gath *__restrict__ gath = nullptr, const After after = After(),
+     E2Stamps *est = nullptr)
 {
     static_assert(!PIPE || (GEO && !DEFER && !RM), "the pipelined form is the one-pass E2<GEO>");
     const double dt = clk->dt;
@@ -140,7 +149,9 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
             s[i] = PIPE ? pre->lp[i * 64] : pl_ld(stress, i, ne, eo);
             if (!ES_DONE) es[i] = PIPE ? pre->lp[(6 + i) * 64] : DES_STRAIN_LD(strain, i, ne, eo);
         }
+        DES_E2_STAMP(geo);
         if (PIPE) after();                 // everything of this tile is out of LDS: the next tile's pieces may land
+        DES_E2_STAMP(dma);
         g_pls = PIPE ? pre->pls : pl_ld(plstrain, 0, ne, eo);
         const double dd = PIPE ? pre->dd : (rp.ddp ? pl_ld(rp.ddp, 0, ne, eo) : 0.0);
         if (dd != 0.0) for (int i = 0; i < 3; ++i) s[i] += dd;
@@ -196,6 +207,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     const double vol_old = GEO ? g_vol_old : ((rheol == DES_RH_MAXWELL || rheol == DES_RH_EVP) ? pl_ld(volume_old, 0, ne, eo) : 0.0);   // (dies at dv)
 
     if (!PIPE) M::stage_end();         // (the pipelined kernel stages the libm tables once per workgroup, ahead of its tile loop)
+    DES_E2_STAMP(strain);
     double visc = 0;
     if (rheol & DES_RH_VISCOUS) {
         double T = 0;
@@ -208,6 +220,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         if (outs) pl_st(viscosity, 0, ne, eo, visc);
     }
 
+    DES_E2_STAMP(visc);
     switch (rheol) {
     case DES_RH_ELASTIC:
         desk::elastic(pr.bulkm, pr.shearm, de, s);
@@ -257,6 +270,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     }
     default: break;
     }
+    DES_E2_STAMP(law);
     if (GEO) {
         if (g_rescaled) pl_st(plstrain, 0, ne, eo, g_pls);                 // rescaled by correct_surface_element, not changed by the law
         if (outs && !rp.fresh) pl_st(volume_old, 0, ne, eo, g_top ? vol : pl_ld(volume, 0, ne, eo));             // (re-read rather than held in registers through the update)
@@ -278,6 +292,7 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
         pl_st(dpressure, 0, ne, eo, dp);
         pl_st(etmp2, 0, ne, eo, dp * vol);
     }
+    DES_E2_STAMP(store);
     return defer;                  // went past the yield pre-filter
 }
 
@@ -420,6 +435,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
     if (t < t_end) dma(t);
 #ifdef DES_STAMPS
     unsigned long long st_wait = 0, st_issue = 0, st_gather = 0, st_body = 0, st_n = 0, st_a, st_b;
+    E2Stamps est = {0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_begin = wall_clock64();
 #endif
     while (t < t_end) {
@@ -467,9 +483,16 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
         st_b = wall_clock64(); st_gather += st_b - st_a; st_a = st_b;
 #endif
         bool defer = false;
+#ifdef DES_STAMPS
+        est.t = wall_clock64();
+        if (valid)
+            defer = e2_element<M, 0, 1, 0, RH, 1>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
+                                                  plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp, &cur, &G, after, &est);
+#else
         if (valid)
             defer = e2_element<M, 0, 1, 0, RH, 1>(e, p, vt, clk, ne, conn, xt, ntmp, md, volume, volume_old, stress, strain, strain_rate,
                                                   plstrain, delta_plstrain, viscosity, dpressure, etmp2, rp, &cur, &G, after);
+#endif
         if (!dma_done) after();                            // (a wavefront wholly past the mesh)
         // the count of elements past the yield pre-filter (des_scalars::n_return_mapping): one atomic per wavefront that has any
         const unsigned long long mask = __ballot(defer);
@@ -484,6 +507,9 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
         const int q = blockIdx.x * NW + w;
         g_stamps[2][0][q] = st_begin; g_stamps[2][1][q] = wall_clock64(); g_stamps[2][2][q] = st_wait; g_stamps[2][3][q] = st_issue;
         g_stamps[2][4][q] = st_gather; g_stamps[2][5][q] = st_body; g_stamps[2][6][q] = st_n;
+        // inside the element code (pass 3 of the stamp array): geometry, DMA issue, strain update, viscosity, law, stores
+        g_stamps[3][0][q] = est.geo; g_stamps[3][1][q] = est.dma; g_stamps[3][2][q] = est.strain; g_stamps[3][3][q] = est.visc;
+        g_stamps[3][4][q] = est.law; g_stamps[3][5][q] = est.store; g_stamps[3][6][q] = st_n;
     }
 #endif
 }

@@ -102,7 +102,11 @@ def test_reference_test_topo_cut_3_ways_2000_steps():
         group.close()
 
 
-def test_a_million_triangles_cut_8_ways():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_a_million_triangles_cut_8_ways(overlap):
+    """overlap: the overlapped schedule (des_dev_set_overlap; round 4) -- transfer, unpack and the wall's extent of step t on
+    a side stream beside compute_mass, update_temperature + compute_dvoldt and update_stress of step t + 1 on the blocks /
+    elements far from the cut; the surface bookkeeping of step t and the blocks near the cut behind the join."""
     kw = dict(cfgs.EVP, lx=400e3, lz=100e3, res=250.0)
     host = des.Host(cfg_text=cfgs.make(**kw), ndims=2)
     assert host.nelem == 2 * 1600 * 400
@@ -110,7 +114,32 @@ def test_a_million_triangles_cut_8_ways():
     try:
         ghost_share = sum(p.nelem for p in group.parts) / host.nelem - 1
         print("8 ranks: %.2f %% ghost-region elements" % (100 * ghost_share))
+        for e in group.engines:
+            e.set_overlap(overlap)
+            assert e.comm_info()["overlapped"] == overlap
         _compare(group, ref, (21, 1))
+    finally:
+        group.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_2d_overlapped_schedule_on_a_cut_mesh(nranks):
+    """the model of test_2d_model_cut_n_ways (two materials, water load, surface diffusion with its marine branch, dhacc
+    reset + top-element rescaling every 7th step, compute_dt every 10th) on 200 x 50 km at 500 m, so that the slabs have
+    blocks far from the cut: the group on the overlapped schedule == the single engine; switching schedules between calls"""
+    kw = dict(cfgs.EVP, nmat=2, lx=200e3, lz=50e3, res=500.0, qcsi=7, water="yes", control="surf_base_level = -100\nsurf_diff_ratio_marine = 0.5\n")
+    host = des.Host(cfg_text=cfgs.make(**kw), ndims=2)
+    ref, group = _pair(host, nranks)
+    try:
+        for e in group.engines:
+            e.set_overlap(True)
+            assert e.comm_info()["overlapped"]
+        _compare(group, ref, (33, 1))
+        for e in group.engines: e.set_overlap(False)
+        _compare(group, ref, (12,))
+        for e in group.engines: e.set_overlap(True)
+        _compare(group, ref, (26,))
+        assert np.abs(ref.download("DHACC")).max() > 0
     finally:
         group.close()
 
@@ -130,7 +159,8 @@ def test_2d_step_on_rccl_equals_the_two_phase_step():
     os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 90))
     dist.init_process_group("gloo", rank=0, world_size=1)
     try:
-        host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, nmat=2, res=1e3)), ndims=2)
+        # (120 x 30 km at 500 m: the middle slab has blocks far from both cuts, which the overlapped schedule needs)
+        host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, nmat=2, lx=120e3, lz=30e3, res=500.0)), ndims=2)
         part = Partition(host, 3, 1)
         assert len(part.nbr_rank) == 2
         pi = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
@@ -147,12 +177,15 @@ def test_2d_step_on_rccl_equals_the_two_phase_step():
         fake = types.SimpleNamespace(halo=halo, owned=part.owned, host=host)
         fields = ("COORD", "VEL", "STRESS", "STRAIN", "TEMPERATURE", "PLSTRAIN", "VOLUME", "MASS", "STRAIN_RATE", "STRESSYY", "DHACC")
         results = []
-        for rccl in (True, False):
+        for rccl in (True, False, "overlapped"):
             eng = des.DeviceEngine(part)
             eng.set_halo(fake)
             if rccl:
                 eng.comm_init(dist, 0, 1)
                 assert eng.comm_info()["rccl_ranks"] == 1
+                # the overlapped schedule on RCCL: transfer + unpack + the wall's all-reduce on the side stream
+                eng.set_overlap(rccl == "overlapped")
+                assert eng.comm_info()["overlapped"] == (rccl == "overlapped")
             for f, name in (("COORD", "coord"), ("COORD0", "coord"), ("ELEMMARKERS", "elemmarkers"), ("VEL", "vel")):
                 eng.upload(f, part.local(name))
             if not rccl:
@@ -184,9 +217,11 @@ def test_2d_step_on_rccl_equals_the_two_phase_step():
         assert results[0][1] == results[1][1] or (np.isnan(results[0][1]) and np.isnan(results[1][1]))
         o0, o1 = part.owned
         assert np.isfinite(results[0][2][0]["VEL"].reshape(2, -1)[:, o0:o1]).mean() > 0.5, "nothing left to compare"
-        for a, b in zip(results[0][2], results[1][2]):
+        assert results[2][:2] == results[0][:2] or np.isnan(results[0][1])
+        for a, b, c in zip(results[0][2], results[1][2], results[2][2]):
             for f in fields:
                 assert np.array_equal(a[f], b[f], equal_nan=True), f
+                assert np.array_equal(a[f], c[f], equal_nan=True), f + " (overlapped schedule)"
     finally:
         dist.destroy_process_group()
 
@@ -199,7 +234,7 @@ def test_a_cut_2d_engine_refuses_what_it_does_not_offer():
         with pytest.raises(des.DesError) as ei:
             e.step(1)                                   # des_dev_step on its own, without a communicator
         assert ei.value.code == 31
-        assert e._lib.des_dev_exchange(e._h) == 30 and e._lib.des_dev_set_overlap(e._h, 1) == 30
+        assert e._lib.des_dev_exchange(e._h) == 30
     finally:
         group.close()
     # (control.has_PT on a cut mesh used to be refused here; since round 4 it runs: test_2d_pseudo_transient_loop_on_a_cut_mesh)

@@ -101,6 +101,18 @@ def main():
                              ("arithmetic + stores issued", 5)):
                 d = t[k] * 0.01 / ntile
                 print("    %-52s %6.2f us per tile (%5.2f / %5.2f / %5.2f)" % (label, d.mean(), *np.percentile(d, [10, 50, 90])))
+    buf = np.zeros(SLOTS * WG, dtype=np.uint64)
+    if lib.des_dev_debug_stamps(3, buf.ctypes.data, buf.size) == buf.size:
+        t = buf.reshape(SLOTS, WG).astype(np.float64)
+        live = t[6] > 0
+        if live.any():
+            t = t[:, live]
+            print("  inside the element code, us per tile:")
+            for label, k in (("geometry, strain rate, spin (gathers waited for here)", 0), ("LDS reads of stress / strain + next DMA issued", 1),
+                             ("rotation, strain update, early stores", 2), ("creep viscosity (pow, exp)", 3), ("maxwell + plastic_props + Mohr-Coulomb pre-filter", 4),
+                             ("stores", 5)):
+                d = t[k] * 0.01 / t[6]
+                print("    %-64s %6.2f (%5.2f / %5.2f / %5.2f)" % (label, d.mean(), *np.percentile(d, [10, 50, 90])))
     dev.close()
 
 
