@@ -303,7 +303,12 @@ def test_initial_body_force_adjustment_2d_bit_exact(moving):
 def test_what_a_2d_model_cannot_have_is_refused_with_the_dimension_code():
     host = des.Host(cfg_text=cfgs.make(**cfgs.EP), ndims=2)
     dev = des.DeviceEngine(host)
-    assert dev._lib.des_dev_exchange(dev._h) == 30 and dev._lib.des_dev_set_overlap(dev._h, 1) == 30      # (RCCL inside des_dev_step)
+    assert dev._lib.des_dev_exchange(dev._h) == 30                              # (RCCL inside des_dev_step)
+    # (des_dev_set_overlap used to be refused too; since round 4 the 2-D engine has the overlapped schedule -- on a mesh
+    #  without neighbours it selects nothing)
+    dev.set_overlap(True)
+    assert not dev.comm_info()["overlapped"]
+    dev.set_overlap(False)
     # an upload with the 3-D size of the field is refused
     with pytest.raises(des.DesError):
         dev.upload("COORD", np.zeros(3 * host.nnode))

@@ -8,7 +8,7 @@ buffers, where a multi-GPU run has RCCL.  The result must be the single engine's
 nodal and elemental field and in dt -- across three compute_dt steps.
 
 Also here: the resolution-scaled variant of examples/oblique-rift-3d.cfg SURVEY.md 8(d)-5 asks for (the
-file as written meshes to 2,991 tets), 8 ways, 1000 steps."""
+file as written meshes to 2,991 tets), 8 ways, for the 10,000 steps BASELINE.json's configs[4] names."""
 import os
 
 import numpy as np
@@ -127,11 +127,11 @@ def test_overlapped_schedule_with_the_two_pass_stress_update_pinned(monkeypatch)
 
 
 @pytest.mark.skipif(OBLIQUE_MESH is None, reason="data/oblique-rift-3d-1250.desmesh.xz is missing")
-def test_oblique_rift_resolution_scaled_8_ways_1000_steps():
+def test_oblique_rift_resolution_scaled_8_ways_10000_steps():
     """examples/oblique-rift-3d.cfg (Mohr-Coulomb weak zone, two materials, vbc type 6, PREM reference
     pressure) on the reference's TetGen mesh of its box at resolution = 1250 m instead of 5000: 8 slabs
-    against one engine for 1000 steps, yielding elements included (same device libm on both sides, so the
-    comparison is exact whatever the model does)."""
+    against one engine for the 10,000 steps of configs[4] (1000 until round 3), yielding elements included (same device
+    libm on both sides, so the comparison is exact whatever the model does)."""
     host = des.Host(cfg_text=cfgs.OBLIQUE, overrides="mesh.resolution = 1250\n", mesh_file=OBLIQUE_MESH)
     assert host.nelem > 100000
     ref = des.DeviceEngine(host)
@@ -139,9 +139,10 @@ def test_oblique_rift_resolution_scaled_8_ways_1000_steps():
     group = DeviceGroup(host, 8)
     try:
         assert group.init_from_host() == dt_ref
-        _compare(group, ref, (400, 599, 1))
+        _compare(group, ref, (400, 599, 1, 4000, 4999, 1))
+        assert ref.step(0).steps == 10000
         n_yield = int((ref.download("PLSTRAIN") > host.array("plstrain")).sum())
-        print("oblique rift at 1250 m: %d tets, %d elements have yielded in 1000 steps" % (host.nelem, n_yield))
+        print("oblique rift at 1250 m: %d tets, %d elements have yielded in 10,000 steps" % (host.nelem, n_yield))
         assert n_yield > 0
     finally:
         group.close()
