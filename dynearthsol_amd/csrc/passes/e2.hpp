@@ -468,8 +468,9 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
         auto after = [&]() {
             // Every vector load of this tile (the gathers) must have ARRIVED before the next tile's pieces are requested, and the
             // compiler must know it: vmcnt counts in issue order, so a gather result first used behind the DMA would be waited
-            // for with vmcnt(0) -- the DMA's whole trip to HBM, in the middle of the arithmetic (that is what the first build of
-            // this kernel did: SQ_WAIT_ANY 8,400 cycles per tile).  The builtin (not inline asm) puts an s_waitcnt the
+            // for with vmcnt(0) -- the DMA's whole trip to HBM, in the middle of the arithmetic (the first build of this kernel
+            // had such a wait; taking it out changed nothing measurable, 71.9 us either way: the pass is issue-bound,
+            // DESIGN.md section 5 -- it stays out because it is the right order).  The builtin (not inline asm) puts an s_waitcnt the
             // compiler's own scoreboard sees: vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding 0x0F70).
             __builtin_amdgcn_s_waitcnt(0x0F70);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
