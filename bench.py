@@ -636,7 +636,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             # host cores this job may really use: the affinity mask, capped at the GPU box's
             # per-GPU CPU share (16); must be set before libgomp starts its pool
-            ncores = min(16, len(os.sched_getaffinity(0)))
+            from oracle_binding import cpu_budget
+            ncores = min(16, cpu_budget())
             os.environ["OMP_NUM_THREADS"] = str(ncores)
             os.environ.setdefault("OMP_PROC_BIND", "close")
             from oracle_binding import OracleEngine, load_oracle

@@ -79,6 +79,8 @@ struct Engine {
            *delta_plstrain = nullptr, *viscosity = nullptr, *volume = nullptr, *volume_old = nullptr, *dpressure = nullptr,
            *edvoldt = nullptr, *radiogenic = nullptr, *etmp = nullptr, *tmp_result = nullptr /* [6][ne] */, *props = nullptr /* [5][ne] */;
     int *markers = nullptr, *etmp_int = nullptr;
+    int *mono = nullptr;               // per element: material << 16 | count of a single-material element, -1 mixed (k2_props)
+    double *pptab = nullptr;           // plastic_props of single-material elements outside the weakening range (k2_pptab)
     double *dh = nullptr, *edvacc = nullptr;
     double *stress_avg = nullptr, *dplstrain_avg = nullptr, *strain0 = nullptr, *coord_avg0 = nullptr;
     double *res_part = nullptr; int res_nb = 0;
@@ -447,17 +449,48 @@ __global__ void k2_clock(Clock *clk)                                  // dyneart
     clk->time += clk->dt;
 }
 
-// MatProps::refresh_elem_cache (matprops.cxx:259-303)
-__global__ void k2_props(const des_params *p, int ne, const int *markers, double *props)
+// The marker mix of element e from its mono[] word (k2_props: material << 16 | count of a single-material element, -1 a mixed
+// one): single-material elements answer desk::Mix::count from registers, the others read their nmat counts (des_kernels.hpp)
+__device__ __forceinline__ desk::Mix mix2(int mo, const int *markers, int nmat, int e)
+{
+    desk::Mix mx;
+    if (mo >= 0) { mx.mk = nullptr; mx.mat = mo >> 16; mx.cnt = mo & 0xffff; }
+    else         { mx.mk = markers + (size_t)e * nmat; mx.mat = -1; mx.cnt = 0; }
+    return mx;
+}
+
+// MatProps::refresh_elem_cache (matprops.cxx:259-303) + the mono[] word
+__global__ void k2_props(const des_params *p, int ne, const int *markers, double *props, int *mono)
 {
     const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (e >= ne) return;
     const int *mk = &markers[(size_t)e * p->nmat];
+    {
+        int used = 0, mat = 0, cnt = 0;
+        for (int m = 0; m < p->nmat; ++m) if (mk[m] != 0) { ++used; mat = m; cnt = mk[m]; }
+        mono[e] = (used == 1 && cnt > 0 && cnt < 65536) ? ((mat << 16) | cnt) : -1;
+    }
     props[e]          = desk::harmonic_mean(p->bulk_modulus, mk, p->nmat);
     props[ne + e]     = desk::harmonic_mean(p->shear_modulus, mk, p->nmat);
     props[2 * ne + e] = desk::arithmetic_mean(p->porosity, mk, p->nmat);
     props[3 * ne + e] = desk::arithmetic_mean(p->heat_capacity, mk, p->nmat);
     props[4 * ne + e] = desk::arithmetic_mean(p->therm_cond, mk, p->nmat);
+}
+
+// plastic_props of a single-material element by (material, marker count, weakening regime): desk::plastic_props itself,
+// run once per entry with a plastic strain of that regime (des_kernels.hpp; as the 3-D engine's k_pptab)
+template <class M>
+__global__ void k2_pptab(const des_params *p, double *pptab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nmat = p->nmat;
+    if (i >= nmat * DES_PPTAB_CNT * 3) return;
+    const int regime = i % 3, cnt = (i / 3) % DES_PPTAB_CNT, mat = i / (3 * DES_PPTAB_CNT);
+    desk::Mix mx;
+    mx.mk = nullptr; mx.mat = mat; mx.cnt = cnt > 0 ? cnt : 1;           // entry 0 is never read
+    const double pls = regime == 0 ? p->pls0[mat] - 1.0 : (regime == 1 ? p->pls0[mat] : p->pls1[mat]);
+    double *t = pptab + (size_t)i * 5;
+    desk::plastic_props<M>(p, mx, pls, t[0], t[1], t[2], t[3], t[4]);
 }
 
 // update_temperature (fields.cxx:197-278), element part
@@ -558,7 +591,8 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
           const double *props, const int *markers, double *edvoldt, double *volume, double *volume_old,
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
           double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
-          int nn, const double *coord, const double *vel, int rotate, int outs, const int *elist, int nlist)
+          int nn, const double *coord, const double *vel, int rotate, int outs, const int *elist, int nlist,
+          const int *mono, const double *pptab)
 {
     M::stage_begin();
     M::stage_end();
@@ -568,7 +602,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     if (t >= nlist) return;
     const int e = elist ? elist[t] : t;
     const double dt = clk->dt;
-    desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+    const desk::Mix mx = mix2(mono[e], markers, p->nmat, e);
     const double bulkm = props[e], shearm = props[ne + e];
     double s[3], es[3], edot[3];
     for (int i = 0; i < 3; ++i) {
@@ -638,7 +672,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     case DES_RH_EP: {
         double depls = 0;
         double amc, anphi, anpsi, hardn, ten_max;
-        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max);
+        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max, pptab);
         if (p->is_plane_strain) {
             double syy = stressyy[e];
             elasto_plastic2d(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, s, syy);
@@ -662,7 +696,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
         double svII = second_invariant2_2d(sv);
 
         double amc, anphi, anpsi, hardn, ten_max;
-        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max);
+        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max, pptab);
         double sp[3], spyy = 0;
         for (int i = 0; i < 3; ++i) sp[i] = s[i];
         if (p->is_plane_strain) {
@@ -1763,7 +1797,7 @@ struct Prof2 {
 void refresh_props(Engine *h)
 {
     if (!h->markers_dirty) return;
-    L2(k2_props, h->ne, h->d_p, h->ne, h->markers, h->props);
+    L2(k2_props, h->ne, h->d_p, h->ne, h->markers, h->props, h->mono);
     h->markers_dirty = false;
 }
 
@@ -1821,7 +1855,8 @@ void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr, 
     const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? 1 : 0;
 #define K2S_ARGS(out, outs) h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt, \
         h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain, \
-        h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, out, h->nn, h->coord, h->vel, rot, outs, elist, nlist
+        h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, out, h->nn, h->coord, h->vel, rot, outs, elist, nlist, \
+        h->mono, h->pptab
     if (fused && h->p.rheol_type == DES_RH_EVP) {          // the common rheology has instantiations of its own
         if (h->geo_pending) L2((k2_stress<M, 2, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
         else                L2((k2_stress<M, 1, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
@@ -1919,7 +1954,7 @@ void launch_patch_mass(Engine *h, const int *blist = nullptr, int nb = -1, const
     if (a.nb == 0) return;
     Prof2 pr(h, P2_MASS);
     hipLaunchKernelGGL(k2p_mass, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (3 * (size_t)h->p_pn_cap + 4 * (size_t)h->p_inc_cap), h->stream, h->d_p, a, h->coord,
-                       T, h->props, h->markers, h->volume_n, h->mass, h->tmass, h->ymass);
+                       T, h->props, h->markers, h->mono, h->volume_n, h->mass, h->tmass, h->ymass);
 }
 
 // ... and compute_volume, rotate_stress, compute_mass
@@ -1967,7 +2002,7 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
     hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0,
                        h->geo_pending ? 1 : 0, a,
                        h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic, h->props,
-                       h->markers, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
+                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
 }
 
 // Overlapped schedule: the first two passes of a step on the blocks and elements far from the cut (set_halo: nothing they
@@ -2012,7 +2047,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
         if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
         { Prof2 pr(h, P2_FORCE);
         hipLaunchKernelGGL(k2p_force, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
-                           h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->force, h->fres);
+                           h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres);
         }
         launch_stress_bcs(h);
         join_wall(h);
@@ -2386,6 +2421,13 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->tmp_result, (size_t)6 * ne));
     A2(dalloc(h, h->props, (size_t)5 * ne));
     A2(dalloc(h, h->markers, (size_t)ne * nmat));
+    A2(dalloc(h, h->mono, (size_t)ne));
+    {
+        const int n = nmat * DES_PPTAB_CNT * 3;
+        A2(dalloc(h, h->pptab, (size_t)n * 5));
+        if (h->portable_libm) hipLaunchKernelGGL(k2_pptab<desk::MathPortable>, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_p, h->pptab);
+        else                  hipLaunchKernelGGL(k2_pptab<desk::MathOcml>, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->d_p, h->pptab);
+    }
     A2(dalloc(h, h->etmp_int, (size_t)ne));
     A2(dalloc(h, h->dh, (size_t)h->ntop));
     A2(dalloc(h, h->edvacc, (size_t)h->etop));

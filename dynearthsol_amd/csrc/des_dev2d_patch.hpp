@@ -163,7 +163,7 @@ __device__ __forceinline__ int patch_block(const PatchArgs &a)
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from_coords, const PatchArgs a, const unsigned *bcflag,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
-                const double *radiogenic, const double *props, const int *markers, const double *tmass, const double *volume_n,
+                const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass, const double *volume_n,
                 double *ntmp, double *strain_rate)
 {
     extern __shared__ double lds[];
@@ -178,6 +178,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
     // this lane's list entries, then the element data they name, beside the nodal records
     ulonglong2 rec[DES2_PATCH_IT];
     double g_vol[DES2_PATCH_IT], g_kc[DES2_PATCH_IT], g_rad[DES2_PATCH_IT];
+    int g_mono[DES2_PATCH_IT];
     const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
 #pragma unroll
     for (int k = 0; k < DES2_PATCH_IT; ++k)
@@ -187,7 +188,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
             g_vol[k] = vol_from_coords ? 0.0 : volume[e];
-            if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; }
+            if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; g_mono[k] = mono[e]; }
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
         const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
@@ -209,7 +210,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
         shape_fn2(d, vol, shpdx, shpdz);
         if (thermal) {
             // k2_temp_elem's statements
-            desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+            const desk::Mix mx = mix2(g_mono[k], markers, p->nmat, e);
             double kv = g_kc[k] * vol;
             double Te = 0;
             for (int i = 0; i < 3; ++i) Te += T[i];
@@ -261,7 +262,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
           const double *volume, const double *dpressure, const double *stress_in, double *stress_out, const double *props,
-          const int *markers, double *force, double *fres)
+          const int *markers, const int *mono, double *force, double *fres)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap, *const lnt = lT + a.pn_cap;
@@ -274,6 +275,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
     const double gravity = p->gravity;
     ulonglong2 rec[DES2_PATCH_IT];
     double g_vol[DES2_PATCH_IT], g_s[DES2_PATCH_IT][3], g_dp[DES2_PATCH_IT], g_phi[DES2_PATCH_IT];
+    int g_mono[DES2_PATCH_IT];
     const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
 #pragma unroll
     for (int k = 0; k < DES2_PATCH_IT; ++k)
@@ -286,6 +288,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
             for (int i = 0; i < 3; ++i) g_s[k][i] = stress_in[i * ne + e];
             g_dp[k] = nmd ? dpressure[e] : 0.0;
             g_phi[k] = gravity != 0 ? props[2 * ne + e] : 0.0;
+            g_mono[k] = gravity != 0 ? mono[e] : 0;
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
         const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
@@ -317,7 +320,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
         }
         double buoy = 0;
         if (gravity != 0) {
-            desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+            const desk::Mix mx = mix2(g_mono[k], markers, p->nmat, e);
             const double phi = g_phi[k];
             double Te = 0;
             for (int i = 0; i < 3; ++i) Te += lT[E.ln[i]];
@@ -348,7 +351,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
 // stores the same value to volume[]).
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const double *temperature, const double *props,
-         const int *markers, double *volume_n, double *mass, double *tmass, double *ymass)
+         const int *markers, const int *mono, double *volume_n, double *mass, double *tmass, double *ymass)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap;
@@ -360,6 +363,7 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     ulonglong2 rec[DES2_PATCH_IT];
     double g_bulk[DES2_PATCH_IT], g_shear[DES2_PATCH_IT], g_cp[DES2_PATCH_IT];
+    int g_mono[DES2_PATCH_IT];
     const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
 #pragma unroll
     for (int k = 0; k < DES2_PATCH_IT; ++k)
@@ -368,7 +372,7 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
     for (int k = 0; k < DES2_PATCH_IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
-            g_bulk[k] = props[e]; g_shear[k] = props[ne + e]; g_cp[k] = props[3 * ne + e];
+            g_bulk[k] = props[e]; g_shear[k] = props[ne + e]; g_cp[k] = props[3 * ne + e]; g_mono[k] = mono[e];
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
         const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
@@ -385,7 +389,7 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
         for (int i = 0; i < 3; ++i) { d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; }
         const double vol = triangle_area(d[0], d[1], d[2]);
         // k2_volume_mass_elem's statements
-        desk::Mix mx = {&markers[(size_t)e * p->nmat], 0, 0};
+        const desk::Mix mx = mix2(g_mono[k], markers, p->nmat, e);
         const double bulkm = g_bulk[k], shearm = g_shear[k];
         double Te = 0;
         for (int i = 0; i < 3; ++i) Te += lT[E.ln[i]];

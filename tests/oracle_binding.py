@@ -11,6 +11,26 @@ ORACLE_DIR = os.path.join(REPO_ROOT, "oracle")
 _libs = {}
 
 
+def cpu_budget():
+    """CPUs this process may really use: the cgroup's quota when there is one (a box can show 256 CPUs and grant 16 --
+    an OpenMP team of 256 on 16 is orders of magnitude slower than one of 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                parts = fh.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max": n = min(n, max(1, -(-int(parts[0]) // int(parts[1]))))
+            else:
+                q = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh: per = int(fh.read())
+                if q > 0: n = min(n, max(1, -(-q // per)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def load_oracle(omp=False, ndims=3):
     name = ("libdes_oracle2d_omp.so" if omp else "libdes_oracle2d.so") if ndims == 2 else "libdes_oracle_omp.so" if omp else "libdes_oracle.so"
     if name not in _libs:
@@ -39,6 +59,7 @@ def load_oracle(omp=False, ndims=3):
         lib.des_oracle_elasto_plastic.restype = C.c_double
         lib.des_oracle_elasto_plastic.argtypes = [C.c_double] * 7 + [d6, d6, C.POINTER(C.c_int)]
         lib.des_oracle_maxwell.argtypes = [C.c_double] * 5 + [d6, d6]
+        if omp: lib.des_oracle_set_threads(min(16, cpu_budget()))      # (callers may set another count afterwards)
         _libs[name] = lib
     return _libs[name]
 
