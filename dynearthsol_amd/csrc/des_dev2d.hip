@@ -90,6 +90,7 @@ struct Engine {
     bool geo_on = true, elide_on = true;       // DES2D_GEO / DES2D_ELIDE != 0 (read at create)
     bool elide = false;                        // this step's output-only element stores can go (a later step of the same call rewrites them)
     bool geo_pending = false;                  // compute_volume + rotate_stress of the last step left to the next k2_stress<M, 2>
+    bool mass_fuse_on = true, mass_pending = false;   // DES2D_MASS_FUSE != 0; compute_mass of the last step left to the next k2p_temp_dvoldt<1>
     bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
     int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0;
     int *po_ptr = nullptr, *po_id = nullptr, *po_slot = nullptr, *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
@@ -1968,7 +1969,10 @@ void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer
         // update (k2_stress<M, 2>), which reads and writes the same stress and strain anyway
         if (defer) h->geo_pending = true;
         else { Prof2 pr(h, P2_ROTVOL); L2(k2_rotate_vol, h->ne, h->d_clk, rotate ? 1 : 0, h->nn, h->ne, h->conn, h->coord, h->vel, h->volume, h->stress, h->strain); }
-        launch_patch_mass(h);
+        // compute_mass: now -- or, when the next step follows at once and forms its volumes from the coordinates anyway
+        // (defer), inside that step's update_temperature + compute_dvoldt pass (k2p_temp_dvoldt<1>)
+        if (defer && h->mass_fuse_on) h->mass_pending = true;
+        else launch_patch_mass(h);
         return;
     }
     launch_volume_mass(h, true);
@@ -1993,16 +1997,21 @@ int sync_clock(Engine *h)
 // Patch path: `thermal` -- update_temperature rides in the first patch pass; `tail` -- apply_vbcs and update_coordinate
 // follow in the velocity kernel (a plain step with a moving mesh), the residual's final sum is left to the surface kernel.
 // update_temperature + compute_dvoldt over the listed node blocks (nullptr / -1: all of them); T_in -> T_out
+// (mass_pending: compute_mass of the step before rides in this pass -- step_back left it out)
 void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_out, const int *blist = nullptr, int nb = -1)
 {
     PatchArgs a = patch_args(h);
     if (nb >= 0) { a.blist = blist; a.nb = nb; }
     if (a.nb == 0) return;
     Prof2 pr(h, P2_TEMP);
-    hipLaunchKernelGGL(k2p_temp_dvoldt, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, h->d_clk, thermal ? 1 : 0,
-                       h->geo_pending ? 1 : 0, a,
-                       h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic, h->props,
-                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate);
+#define K2T_ARGS h->d_p, h->d_clk, thermal ? 1 : 0, h->geo_pending ? 1 : 0, a, \
+                       h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic, h->props, \
+                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass
+    if (h->mass_pending)
+        hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 4 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
+    else
+        hipLaunchKernelGGL(k2p_temp_dvoldt<0>, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
+#undef K2T_ARGS
 }
 
 // Overlapped schedule: the first two passes of a step on the blocks and elements far from the cut (set_halo: nothing they
@@ -2033,7 +2042,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             hipStreamWaitEvent(h->stream, h->ev_join, 0);
             h->join_pending = false; h->far_issued = false;
             launch_update_mesh_surface(h, h->back_steps);
-            launch_patch_mass(h, h->d_blist + h->nb_deep, h->p_nb - h->nb_deep, h->mT_in);
+            if (!h->mass_pending) launch_patch_mass(h, h->d_blist + h->nb_deep, h->p_nb - h->nb_deep, h->mT_in);
             launch_temp_dvoldt(h, thermal, h->mT_in, h->mT_out, h->d_blist + h->nb_deep, h->p_nb - h->nb_deep);
             launch_stress<M>(h, true, s_law, h->d_elist + h->ne_deep, ne - h->ne_deep, false);
         } else {
@@ -2043,7 +2052,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             launch_temp_dvoldt(h, thermal, T_in, T_out);
             launch_stress<M>(h, true, s_law);
         }
-        h->geo_pending = false;
+        h->geo_pending = false; h->mass_pending = false;
         if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
         { Prof2 pr(h, P2_FORCE);
         hipLaunchKernelGGL(k2p_force, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
@@ -2259,7 +2268,8 @@ void step_back_overlapped(Engine *h)
     h->back_steps = h->steps_host;
     refresh_props(h);
     h->geo_pending = true;
-    launch_patch_mass(h, h->d_blist, h->nb_deep);
+    if (h->mass_fuse_on) h->mass_pending = true;           // (compute_mass rides in both parts of the next pass)
+    else launch_patch_mass(h, h->d_blist, h->nb_deep);
     h->join_pending = true;
 }
 
@@ -2442,6 +2452,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
         const char *cl = des_env::get("DES2D_CLUSTER");
         const char *ge = des_env::get("DES2D_GEO"), *ee = des_env::get("DES2D_ELIDE");
         h->geo_on = !(ge && ge[0] == '0'); h->elide_on = !(ee && ee[0] == '0');
+        { const char *me = des_env::get("DES2D_MASS_FUSE"); h->mass_fuse_on = !(me && me[0] == '0'); }
         const bool cluster = !(cl && cl[0] == '0');
         Patch2 P;
         bool ok = false;
@@ -2701,7 +2712,7 @@ static int step_abort(Engine *h, int rc)
 {
     hipStreamSynchronize(h->xstream);
     hipStreamSynchronize(h->stream);
-    h->join_pending = false; h->wall_pending = false; h->far_issued = false;
+    h->join_pending = false; h->wall_pending = false; h->far_issued = false; h->mass_pending = false;
     return rc;
 }
 

@@ -160,15 +160,21 @@ __device__ __forceinline__ int patch_block(const PatchArgs &a)
 // ---- update_temperature + compute_dvoldt ------------------------------------------------------------
 // thermal = 0: the temperature stands (isostasy loop, pseudo-transient iterations, has_thermal_diffusion = no).
 // T_in / T_out: a block must not move a temperature another block may still be reading -- the host swaps the two.
+// MASS = 1 (round 4): compute_mass of the step BEFORE rides in this pass (k2p_mass's statements on the same staged patch,
+// the volumes from the coordinates as there; only together with vol_from_coords, i.e. on the steps whose end-of-step element
+// pass was left to the coming stress update): the four sums of a node go first -- their LDS slots are then reused for this
+// pass's two -- and the node's lane keeps volume_n and tmass for its own update.  One patch pass per step instead of two.
+template <int MASS>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from_coords, const PatchArgs a, const unsigned *bcflag,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
-                const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass, const double *volume_n,
-                double *ntmp, double *strain_rate)
+                const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass_in, const double *volume_n_in,
+                double *ntmp, double *strain_rate, double *volume_n_out, double *mass_out, double *tmass_out, double *ymass_out)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
     double *const lf0 = lT + a.pn_cap, *const lf1 = lf0 + a.inc_cap;
+    double *const lf2 = lf1 + a.inc_cap, *const lf3 = lf2 + a.inc_cap;          // (MASS only: the launch sizes the LDS)
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
     const int b = patch_block(a), nn = a.nn, ne = a.ne;
     if (b < 0) return;
@@ -178,6 +184,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
     // this lane's list entries, then the element data they name, beside the nodal records
     ulonglong2 rec[DES2_PATCH_IT];
     double g_vol[DES2_PATCH_IT], g_kc[DES2_PATCH_IT], g_rad[DES2_PATCH_IT];
+    double g_bulk[DES2_PATCH_IT], g_shear[DES2_PATCH_IT], g_cp[DES2_PATCH_IT];
     int g_mono[DES2_PATCH_IT];
     const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
 #pragma unroll
@@ -188,13 +195,59 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
             g_vol[k] = vol_from_coords ? 0.0 : volume[e];
-            if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; g_mono[k] = mono[e]; }
+            if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; }
+            if (thermal || MASS) g_mono[k] = mono[e];
+            if (MASS) { g_bulk[k] = props[e]; g_shear[k] = props[ne + e]; g_cp[k] = props[3 * ne + e]; }
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
         const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
         lx[j] = coord[id]; lz[j] = coord[nn + id]; lvx[j] = vel[id]; lvz[j] = vel[nn + id]; lT[j] = T_in[id];
     }
     __syncthreads();
+    double my_vn = 0, my_tm = 0;
+    if (MASS) {
+        const int mass_thermal = p->has_thermal_diffusion;
+#pragma unroll
+        for (int k = 0; k < DES2_PATCH_IT; ++k) {
+            if (q0 + k * DES2_PATCH_THREADS >= qe) break;
+            const PatchElem2 E = patch_elem2(rec[k]);
+            const int e = E.e;
+            double d[3][2];
+            for (int i = 0; i < 3; ++i) { d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; }
+            const double vol = triangle_area(d[0], d[1], d[2]);
+            // k2_volume_mass_elem's statements
+            const desk::Mix mx = mix2(g_mono[k], markers, p->nmat, e);
+            const double bulkm = g_bulk[k], shearm = g_shear[k];
+            double Te = 0;
+            for (int i = 0; i < 3; ++i) Te += lT[E.ln[i]];
+            Te /= 3;
+            const double mrho = desk::mat_rho(p, mx, Te);
+            const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
+            double rho = p->is_quasi_static ? bulkm / (pseudo_speed * pseudo_speed) : mrho;
+            double m = rho * vol / 3;
+            double tm = mrho * g_cp[k] * vol / 3;
+            double ym = 9 * bulkm * shearm / (3 * bulkm + shearm) / 3;
+            for (int i = 0; i < 3; ++i) {
+                if (E.sl[i] == 0xfff) continue;
+                lf0[E.sl[i]] = vol; lf1[E.sl[i]] = m; lf2[E.sl[i]] = tm; lf3[E.sl[i]] = ym;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nown) {
+            const int n = a.po_id[o0 + threadIdx.x];
+            const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
+            double vn = 0, ms = 0, tms = 0, yms = 0;
+            for (int k = r0; k < r1; ++k) {
+                vn += lf0[k];
+                ms += lf1[k];
+                if (mass_thermal) tms += lf2[k];
+                yms += lf3[k];
+            }
+            volume_n_out[n] = vn; mass_out[n] = ms; tmass_out[n] = tms; ymass_out[n] = yms;
+            my_vn = vn; my_tm = tms;
+        }
+        __syncthreads();                   // the slots are free again
+    }
 #pragma unroll
     for (int k = 0; k < DES2_PATCH_IT; ++k) {
         if (q0 + k * DES2_PATCH_THREADS >= qe) break;
@@ -243,14 +296,14 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
         const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
         double acc = 0.;
         for (int k = r0; k < r1; ++k) acc += lf1[k];
-        ntmp[n] = acc / volume_n[n];
+        ntmp[n] = acc / (MASS ? my_vn : volume_n_in[n]);
         if (thermal) {
             if (bcflag[n] & BOUNDZ1)
                 T_out[n] = p->surface_temperature;
             else {
                 double tdot = 0;
                 for (int k = r0; k < r1; ++k) tdot += lf0[k];
-                T_out[n] = lT[threadIdx.x] - clk->dt * tdot / tmass[n];
+                T_out[n] = lT[threadIdx.x] - clk->dt * tdot / (MASS ? my_tm : tmass_in[n]);
             }
         }
     }
