@@ -140,7 +140,7 @@ KERNEL_BYTES = {
     "E2G_geom_rotate_update_stress": (325, 64),
 }
 # The 2-D engine (csrc/des_dev2d.hip), dominant launch k2_stress<M, 2> = compute_volume + rotate_stress of the step before +
-# compute_edvoldt + update_stress: per triangle read conn 12, marker word 4 (nmat = 1), bulk / shear modulus 16, stress 24,
+# compute_edvoldt + update_stress: per triangle read conn 12, mono word 4, bulk / shear modulus 16, stress 24,
 # strain 24, strain_rate 24 (stored by the temperature / dvoldt pass's owner block), volume 8, plstrain 8 = 120; write
 # volume 8, stress 24, strain 24, dpressure 8, etmp 8 = 72; nodes once each: coord 16, vel 16, T 8, ntmp 8.  The last step
 # of a call also stores volume_old 8, edvoldt 8, strain_rate 24, viscosity 8, delta_plstrain 8 (K2_STRESS_LAST).
@@ -582,7 +582,8 @@ def main():
                 break
         if tj is not None:
             # what a PLAIN fused step really moves: the PMC traffic of its launches, summed
-            plain = ("K2P_temp_dvoldt", "K2_stress", "K2_node_avg", "K2P_force", "K2P_mass") if args.ndims == 2 else \
+            # (2-D: compute_mass rides in the temperature / dvoldt pass of a plain step unless DES2D_MASS_FUSE=0)
+            plain = (("K2P_temp_dvoldt", "K2_stress", "K2_node_avg", "K2P_force") + (("K2P_mass",) if os.environ.get("DES2D_MASS_FUSE") == "0" else ())) if args.ndims == 2 else \
                     ("EN1_mass_temperature_dvoldt", "E2G_geom_rotate_update_stress", "EN2_nmd_gather", "EN3_force_nodes")
             if all(k in tj for k in plain):
                 real = sum(tj[k]["traffic_bytes_per_launch"] for k in plain)
