@@ -33,8 +33,8 @@
  * (rheology.cxx:86-119, 364-483, 486-701), the 2-D apply_vbcs (bc.cxx:247-300, 425-481), the 1-D surface
  * diffusion (bc.cxx:1021-1033, 1067-1106), jaumann_rate_2d (fields.cxx:807-821), the pseudo-transient loop, and the
  * domain decomposition below (des_dev_wall_get / des_dev_wall_set: what a cut 2-D model shares beside the ghost region).
- * What a 2-D engine does not offer returns DES_ERR_UNSUPPORTED_DIM: the overlapped schedule (des_dev_set_overlap), the
- * stand-alone des_dev_exchange.
+ * What a 2-D engine does not offer returns DES_ERR_UNSUPPORTED_DIM: the stand-alone des_dev_exchange (a 2-D engine runs
+ * its exchange inside des_dev_step).  The overlapped schedule (des_dev_set_overlap) is there for both since round 4.
  */
 #ifndef DES_DEV_H
 #define DES_DEV_H
