@@ -324,12 +324,17 @@ def main():
     args = ap.parse_args()
 
     t_begin = time.perf_counter()
-    if os.environ.get("DES_BENCH_VERBOSE"):
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("DES_BENCH_WATCHDOG", "60")), repeat=False)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("DES_BENCH_VERBOSE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("DES_BENCH_WATCHDOG", "60")), repeat=False)
+    elif world > 1:
+        # first contact with several GPUs: a rank stuck in a collective (a neighbour that never arrives) must not hang the
+        # job silently -- after DES_BENCH_WATCHDOG seconds (default 900) every rank prints where it stands and exits non-zero
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("DES_BENCH_WATCHDOG", "900")), exit=True)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
@@ -656,6 +661,7 @@ def main():
                    "kind": "port", "sample": "%d steps of the same %d-%s mesh (oracle, OpenMP, %d threads)"
                                                 % (cpu_steps, ne, "triangle" if args.ndims == 2 else "tet", threads)}
         result["cpu_baseline"] = cpu
+        import faulthandler; faulthandler.cancel_dump_traceback_later()
         print(json.dumps(result))
 
     if dist is not None:
