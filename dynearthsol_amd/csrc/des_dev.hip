@@ -168,6 +168,8 @@ struct des_dev {
     hipGraphExec_t pgraph_exec[6];        // the fused (patch) step: plain, with compute_dt, after compute_dt;
     bool pgraph_two_pass[6];              // x which of the two coordinate buffers is the current one
     int e2_defer;                         // DES_E2_DEFER: 0 one pass, 1 two passes, 2 (default) chosen per call
+    bool verbose = false, said_pipe = false;  // DES_PATCH_VERBOSE at create: the engine says on stderr which shapes it picked
+    int e2_pipe_mode = -1, e2_w3_mode = -1;   // DES_E2_PIPE / DES_E2_W3 at create: 0 / 1 pinned, -1 chosen by size (engine/launch.hpp)
     bool e2_two_pass;                     // the current choice
     int *mono;                            // [ne] (material << 16) | count of single-material elements, else -1
     double *ptab;                         // [nmat][DES_PTAB_CNT][5] property means of single-material elements
@@ -398,6 +400,9 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
         h->use_graph = gr && gr[0] == '1';
         const char *ov = des_env::get("DES_OVERLAP");
         h->overlap = ov && ov[0] == '1';
+        h->verbose = des_env::get("DES_PATCH_VERBOSE") != nullptr;
+        { const char *e = des_env::get("DES_E2_PIPE"); h->e2_pipe_mode = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }
+        { const char *e = des_env::get("DES_E2_W3"); h->e2_w3_mode = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }
         const char *e2d = des_env::get("DES_E2_DEFER");
         h->e2_defer = (e2d && (e2d[0] == '0' || e2d[0] == '1')) ? e2d[0] - '0' : 2;
         h->e2_two_pass = h->e2_defer != 0;

@@ -330,11 +330,10 @@ enum { PART_ALL = 0, PART_DEEP = 1, PART_REST = 2 };
 // has an instantiation held to three (passes/e2.hpp: W3).  Where the launch is a few rounds of workgroups at most, the
 // number of ROUNDS decides -- a shard whose wavefronts just overflow the two-wave residency pays a whole second round --
 // so take three waves when that saves a round; on large meshes (many rounds) two waves are as fast and spill nothing.
-// DES_E2_W3 = 0 / 1 pins the choice.
+// DES_E2_W3 = 0 / 1 (read when the engine is created) pins the choice.
 inline bool e2_three_waves(const des_dev *h, long long nelem)
 {
-    static const char *env = des_env::get("DES_E2_W3");
-    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    if (h->e2_w3_mode >= 0) return h->e2_w3_mode == 1;
     const long long waves = (nelem + 63) / 64, res2 = 2LL * 4 * h->n_cu, res3 = 3LL * 4 * h->n_cu;
     const long long r2 = (waves + res2 - 1) / res2, r3 = (waves + res3 - 1) / res3;
     return r3 < r2 && r2 <= 4;
@@ -343,12 +342,11 @@ inline bool e2_three_waves(const des_dev *h, long long nelem)
 // The pipelined E2<GEO> (passes/e2.hpp: E2_update_stress_pipe): 2 x CUs resident workgroups walking the tiles, the next tile's
 // own-index data arriving in LDS by DMA under the current tile's arithmetic.  Worth it where a workgroup has several tiles to
 // walk (>= 4 per resident workgroup); a shard of a few rounds keeps the plain kernel (and its three-wave shape).  Needs the
-// whole mesh as one range and an even plane stride (16-byte DMA pieces).  DES_E2_PIPE = 0 / 1 pins the choice.
+// whole mesh as one range and an even plane stride (16-byte DMA pieces).  DES_E2_PIPE = 0 / 1 (read when the engine is created) pins the choice.
 inline bool e2_pipelined(const des_dev *h, int part, long long nelem)
 {
     if (part != PART_ALL || (h->ne & 1) || !h->topflag) return false;
-    static const char *env = des_env::get("DES_E2_PIPE");
-    if (env && (env[0] == '0' || env[0] == '1')) return env[0] == '1';
+    if (h->e2_pipe_mode >= 0) return h->e2_pipe_mode == 1;
     const long long tiles = (nelem + DES_BLOCK - 1) / DES_BLOCK;
     return tiles >= 4LL * 2 * h->n_cu;
 }
@@ -426,6 +424,10 @@ void launch_e2(des_dev *h, int part = PART_ALL)
             const bool evp = h->p.rheol_type == DES_RH_EVP && h->p.is_using_mixed_stress && !h->p.is_outputting_averaged_fields;
             auto kp = evp ? E2_update_stress_pipe<desk::MathPortable, DES_RH_EVP, 4> : E2_update_stress_pipe<desk::MathPortable, 0, 4>;
             const int nbf_p = nbf, nsf_p = nsf;
+            if (h->verbose && !h->said_pipe) {
+                std::fprintf(stderr, "E2<GEO>: pipelined launch, %d resident workgroups over %d tiles of %d elements%s\n", npers, ntiles, tile, evp ? " (evp instantiation)" : "");
+                h->said_pipe = true;
+            }
             hipLaunchKernelGGL(kp, dim3(npers + nbf_p + nsf_p), dim3(tile), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                                ntiles, npers, h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old,
                                h->stress, h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,

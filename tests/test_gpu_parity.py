@@ -498,3 +498,39 @@ def test_initial_body_force_adjustment_bit_exact(moving):
     # adjustment leaves other forces on the traction boundaries
     ref.step(12)
     assert not np.array_equal(ref.download("VEL"), ora.download("VEL"))
+
+
+@pytest.mark.parametrize("name,kw,overrides", [
+    ("evp_nmd", dict(cfgs.EVP, nmat=2), None),
+    ("evp_averaged_fields", cfgs.EVP, "sim.is_outputting_averaged_fields = yes\nmesh.quality_check_step_interval = 5\n"),
+    ("evp_no_nmd", cfgs.EVP, "control.is_using_mixed_stress = no\n"),
+    ("ep_yielding_water_load", dict(cfgs.EP, nmat=2), "bc.has_water_loading = yes\ncontrol.surf_base_level = 1e3\n"),
+    ("maxwell", dict(cfgs.EVP, rheol="maxwell"), None),
+    ("elastic_no_thermal", dict(cfgs.EVP, rheol="elastic"), "control.has_thermal_diffusion = no\n"),
+])
+def test_pipelined_stress_update_and_three_wave_shape_give_the_same_bits(monkeypatch, capfd, name, kw, overrides):
+    """E2<GEO> has three launch forms chosen by the size of the launch (engine/launch.hpp): the plain one-pass kernel, the
+    same held to three waves per SIMD (shards), and the pipelined kernel whose wavefronts take their tiles' planes out of
+    LDS, where they arrive by DMA a tile ahead (1M-tet meshes).  DES_E2_PIPE / DES_E2_W3 (read when an engine is created)
+    pin them: on a small mesh all three must leave the bits of the default engine in every field, across the rheologies, with
+    Output::average_fields riding in the pass, with and without NMD_stress, across call boundaries (the last step of a call
+    stores every field, the first one may start fresh) and compute_dt steps."""
+    host = des.Host(cfg_text=cfgs.make(**dict(kw, res=1e3)), overrides=overrides)
+    assert host.nelem % 2 == 0 and host.nelem > 4000                   # (the pipelined kernel wants an even plane stride)
+    monkeypatch.setenv("DES_PATCH_VERBOSE", "1")                       # the engine says which launch form it took
+    engines = [des.DeviceEngine(host)]
+    for var, val in (("DES_E2_PIPE", "1"), ("DES_E2_W3", "1")):
+        monkeypatch.setenv(var, val)
+        engines.append(des.DeviceEngine(host))
+        assert var + "=" + val in des.config_string()              # (the library has read it: des_dev_config_string)
+        monkeypatch.delenv(var)
+    dts = [e.init_from_host(host) for e in engines]
+    assert dts[0] == dts[1] == dts[2]
+    for n in (7, 1, 16, 9):
+        s = [e.step(n) for e in engines]
+        for k in (1, 2):
+            assert (s[k].dt, s[k].time, s[k].steps, s[k].n_return_mapping) == (s[0].dt, s[0].time, s[0].steps, s[0].n_return_mapping)
+            assert_bit_exact(engines[k], engines[0])
+    for e in engines:
+        e.close()
+    assert capfd.readouterr().err.count("E2<GEO>: pipelined launch") == 1         # the second engine only
