@@ -3086,23 +3086,28 @@ int step_group(Engine **g, int n, int nsteps, des_scalars *out)
     HIP2(hipSetDevice(h->device));
     for (int i = 0; i < nsteps; ++i) {
         // the ghost region (and the wall's extent) of every engine refreshed from its neighbours' packed messages
+        // engine k takes its neighbours' packed messages (device-to-device copies), unpacks them and forms its local wall
+        // extent, all on stream xs (its own, or its side stream on the overlapped schedule)
+        auto take_messages = [&](int k, hipStream_t xs) -> int {
+            Engine *e = g[k];
+            for (int q = 0; q < e->nnbr; ++q) {
+                Engine *o = g[e->nbr_rank[q]];
+                int qo = 0;
+                for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
+                const long long len = e->recv_off[q + 1] - e->recv_off[q];
+                if (len) HIP2(hipMemcpyAsync(e->d_recvbuf + e->recv_off[q], o->d_sendbuf + o->send_off[qo], (size_t)len * sizeof(double),
+                                             hipMemcpyDeviceToDevice, xs));
+            }
+            launch_unpack(e, xs);
+            if (xs != e->stream) HIP2(hipEventRecord(e->ev_join, xs));
+            launch_wall_local(e, xs);
+            HIP2(hipMemcpyAsync(e->h_red, e->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, xs));
+            return DES_OK;
+        };
         auto exchange_all = [&](bool set_wall) -> int {
             for (int k = 0; k < n; ++k) launch_pack(g[k]);
             for (int k = 0; k < n; ++k) HIP2(hipStreamSynchronize(g[k]->stream));
-            for (int k = 0; k < n; ++k) {
-                Engine *e = g[k];
-                for (int q = 0; q < e->nnbr; ++q) {
-                    Engine *o = g[e->nbr_rank[q]];
-                    int qo = 0;
-                    for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
-                    const long long len = e->recv_off[q + 1] - e->recv_off[q];
-                    if (len) HIP2(hipMemcpyAsync(e->d_recvbuf + e->recv_off[q], o->d_sendbuf + o->send_off[qo], (size_t)len * sizeof(double),
-                                                 hipMemcpyDeviceToDevice, e->stream));
-                }
-                launch_unpack(e);
-                launch_wall_local(e);
-                HIP2(hipMemcpyAsync(e->h_red, e->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-            }
+            for (int k = 0; k < n; ++k) { const int rc = take_messages(k, g[k]->stream); if (rc) return rc; }
             double wall[3] = {-DBL_MAX, -DBL_MAX, 0.0};
             for (int k = 0; k < n; ++k) {
                 HIP2(hipStreamSynchronize(g[k]->stream));
@@ -3168,18 +3173,7 @@ int step_group(Engine **g, int n, int nsteps, des_scalars *out)
             for (int k = 0; k < n; ++k) HIP2(hipStreamSynchronize(g[k]->stream));
             for (int k = 0; k < n; ++k) {
                 Engine *e = g[k];
-                for (int q = 0; q < e->nnbr; ++q) {
-                    Engine *o = g[e->nbr_rank[q]];
-                    int qo = 0;
-                    for (int j = 0; j < o->nnbr; ++j) if (o->nbr_rank[j] == k) qo = j;
-                    const long long len = e->recv_off[q + 1] - e->recv_off[q];
-                    if (len) HIP2(hipMemcpyAsync(e->d_recvbuf + e->recv_off[q], o->d_sendbuf + o->send_off[qo], (size_t)len * sizeof(double),
-                                                 hipMemcpyDeviceToDevice, e->xstream));
-                }
-                launch_unpack(e, e->xstream);
-                HIP2(hipEventRecord(e->ev_join, e->xstream));
-                launch_wall_local(e, e->xstream);
-                HIP2(hipMemcpyAsync(e->h_red, e->d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, e->xstream));
+                { const int rc = take_messages(k, e->xstream); if (rc) return rc; }
                 step_back_overlapped(e);
                 e->count_past = (i + 1 == nsteps - 1);
                 e->elide = elide_ok(e, i + 1 < nsteps - 1);
