@@ -3067,7 +3067,17 @@ int dt_finalize(Engine *h, const double in[6], double *dt)
 // Several engines of ONE process as the ranks of one decomposed model (des_dev_step_group): ghost records by
 // device-to-device copies between the message buffers; the two reductions through the host, which joins every
 // engine's stream for them (the 2-D models are the small ones: simplicity over overlap here).
+static int step_group_impl(Engine **g, int n, int nsteps, des_scalars *out);
+
+// (a call that fails half-way must not leave an engine between two pieces of the overlapped schedule: step_abort)
 int step_group(Engine **g, int n, int nsteps, des_scalars *out)
+{
+    const int rc = step_group_impl(g, n, nsteps, out);
+    if (rc) for (int k = 0; k < n; ++k) if (g[k]) { hipSetDevice(g[k]->device); step_abort(g[k], rc); }
+    return rc;
+}
+
+static int step_group_impl(Engine **g, int n, int nsteps, des_scalars *out)
 {
     for (int k = 0; k < n; ++k) {
         Engine *h = g[k];
