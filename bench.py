@@ -3,6 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+works as written for every N: with N > 1 and no launcher around it (WORLD_SIZE unset) the process starts its own ranks
+-- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
+<same arguments>` as a child process, before torch or HIP are touched -- relays rank 0's JSON line and exits with the
+ranks' code.  Launched BY torch.distributed.run (RANK / WORLD_SIZE set) it is one rank, as before.
+
 One "step" is one explicit time step (dynearthsol.cxx:768-894) of the whole mesh.  The workload
 is BASELINE.json configs[2] / configs[3] as SURVEY.md 8(d) pins it down: the
 benchmarks-cores/test-3d-big.cfg box (400 x 20 x 10 km), elasto-visco-plastic variant, thermal
@@ -188,26 +193,30 @@ def make_engine(ctx, host, des):
     # explicitly (the same step driven in its two phases, ghost state staged through the host over gloo).
     want_host = os.environ.get("DES_BENCH_TRANSPORT", "rccl") != "rccl"
     if not want_host:
+        def agree(ok, why, what, rc):
+            """every rank learns whether ALL ranks got through `what`; if not, all of them leave together with `rc`"""
+            if why:
+                sys.stderr.write("rank %d: %s\n" % (rank, why))
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctx.tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                sys.stderr.write("bench.py: %s; no result (DES_BENCH_TRANSPORT=host selects the host-staged rehearsal transport)\n" % what)
+                _set_exit_code(rc)
+                dist.destroy_process_group()
+                sys.exit(rc)
         ok, why = 1, ""
         try:
             dev.comm_init(dist, rank, world)
         except des.DesError as e:
             ok, why = 0, str(e)
-        if ok:
-            try:
-                dev.comm_selfcheck(world)
-            except des.DesError as e:
-                ok, why = -1, str(e)
-        if why:
-            sys.stderr.write("rank %d: %s\n" % (rank, why))
-        flag = torch.tensor([ok], dtype=torch.int32, device=ctx.tdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) != 1:
-            sys.stderr.write("bench.py: %s; no result (DES_BENCH_TRANSPORT=host selects the host-staged rehearsal transport)\n"
-                             % ("the RCCL self-check failed on at least one rank" if int(flag.item()) < 0 else
-                                "the RCCL communicator of the engine did not come up on every rank"))
-            dist.destroy_process_group()
-            sys.exit(4 if int(flag.item()) < 0 else 3)
+        agree(ok, why, "the RCCL communicator of the engine did not come up on every rank", 3)
+        # the self-check is collective: entered only once every rank is known to hold a communicator
+        ok, why = 1, ""
+        try:
+            dev.comm_selfcheck(world)
+        except des.DesError as e:
+            ok, why = 0, str(e)
+        agree(ok, why, "the RCCL self-check failed on at least one rank", 4)
         init_rank(dev, part, _Comm())
     else:
         from dynearthsol_amd.decomp import PhasedStepper, TorchComm
@@ -290,6 +299,60 @@ def profile_leg(ctx, dev, nsteps=20):
     return prof, per_rank
 
 
+def _set_exit_code(rc):
+    """a rank that refuses to report (3: no RCCL communicator, 4: its self-check failed) leaves its code for the launcher:
+    torch.distributed.run itself exits 1 whatever its children returned"""
+    path = os.environ.get("DES_BENCH_RC_FILE")
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write("%d\n" % rc)
+        except OSError:
+            pass
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks as `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` in a child process,
+    relay rank 0's JSON line on stdout and everything else on stderr, return the exit code (3 / 4 of the RCCL refusals
+    kept).  Called before torch is imported."""
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rc_file = tempfile.NamedTemporaryFile(prefix="des_bench_rc_", delete=False)
+    rc_file.close()
+    env = dict(os.environ, DES_BENCH_RC_FILE=rc_file.name)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    try:
+        for line in proc.stdout:
+            is_result = line.startswith("{") and '"metric"' in line
+            (sys.stdout if is_result else sys.stderr).write(line)
+            (sys.stdout if is_result else sys.stderr).flush()
+        rc = proc.wait()
+    except BaseException:
+        proc.terminate()
+        try:
+            proc.wait(10)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        raise
+    finally:
+        try:
+            left = open(rc_file.name).read().strip()
+            os.unlink(rc_file.name)
+        except OSError:
+            left = ""
+    if rc != 0 and left.isdigit() and int(left) != 0:
+        rc = int(left)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,10 +398,13 @@ def main():
         # job silently -- after DES_BENCH_WATCHDOG seconds (default 900) every rank prints where it stands and exits non-zero
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("DES_BENCH_WATCHDOG", "900")), exit=True)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has imported torch or
+        # touched HIP, and the ranks are CHILD processes (never an exec of a process that has initialised the GPU).
+        sys.exit(launch_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch `python bench.py --gpus N`, or torch.distributed.run with "
+                 "--nproc-per-node equal to --gpus)" % (args.gpus, world))
 
     import torch
     dist = None
