@@ -162,6 +162,7 @@ struct des_dev {
            *volume_old, *dpressure, *radiogenic;
     int *markers;
     int *defer_list;                      // [ne] elements set aside by the first stress pass of the step
+    unsigned *e2_tile_ctr;                // [8] the pipelined stress update's tile counters, one per XCD share (DES_E2_DYN builds; self-resetting)
     bool use_graph;                       // DES_GRAPH=1
     hipGraphExec_t graph_exec[2];
     bool graph_two_pass[2];
@@ -505,9 +506,13 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
             if (want >= 16 && want <= 128 && want % 8 == 0)
                 h->patch = build_patches(mesh, want, DES_PATCH_INC, DES_PATCH_PN, P);
             else {
+                // (three workgroups per CU in both patch kernels: their dynamic LDS for this mesh's largest block <= 160 KiB / 3)
                 const int fits[5] = {64, 56, 48, 40, 32};
+                const size_t lds3 = 160 * 1024 / 3;
                 for (int t = 0; t < 5 && !h->patch; ++t)
-                    h->patch = build_patches(mesh, fits[t], 1600, 296, P) && P.max_pe <= 872;
+                    h->patch = build_patches(mesh, fits[t], DES_PATCH_INC, DES_PATCH_PN, P) && P.max_pe <= DES_PATCH_PE
+                               && en1_lds_bytes(patch_cap(P.max_inc), patch_cap(P.max_pn), patch_cap(P.max_pe), h->const_mass) <= lds3
+                               && en3_lds_bytes(patch_cap(P.max_inc), patch_cap(P.max_pn)) <= lds3;
                 const int tries[3] = {64, 32, 16};
                 for (int t = 0; t < 3 && !h->patch; ++t)
                     h->patch = build_patches(mesh, tries[t], DES_PATCH_INC, DES_PATCH_PN, P);
@@ -558,6 +563,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->radiogenic, (size_t)ne)); CK(dev_alloc(h->markers, (size_t)ne * nmat));
     CK(dev_alloc(h->mono, (size_t)ne));
     CK(dev_alloc(h->defer_list, (size_t)ne));
+    CK(dev_alloc(h->e2_tile_ctr, 8)); HK(hipMemsetAsync(h->e2_tile_ctr, 0, 8 * sizeof(unsigned), h->stream));
     {
         // deferred rotate_stress (MODE_DEFER, passes/e1.hpp): on by default, DES_DEFER_ROT=0 keeps rotate_stress in E1
         const char *el = des_env::get("DES_E2_ELIDE");      // =0: every step stores every field
@@ -1167,6 +1173,12 @@ int step_abort(des_dev *h, int rc)
     h->join_pending = false; h->s2_pending = false; h->edv_pending = false; h->s2_skipped = false;
     h->e2geo_next = false; h->rot_pending = false; h->e2_fresh = false;
     h->finished = false;
+    // the two device flags a loop may have been inside of when the error came (DevClock::pt: boundaries at rest, no clock;
+    // no_neumann: initial_body_force_adjustment) -- a later step must not inherit them
+    static const int zero = 0;
+    hipMemcpy(&h->d_clk->pt, &zero, sizeof(int), hipMemcpyHostToDevice);
+    hipMemcpy(&h->d_clk->no_neumann, &zero, sizeof(int), hipMemcpyHostToDevice);
+    h->in_pt = false;
     return rc;
 }
 } // namespace
@@ -1376,9 +1388,9 @@ int des_dev_body_force_adjustment(des_dev *h, des_scalars *out)
         static const int on = 1, off = 0;
         HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &on, sizeof(int), hipMemcpyHostToDevice, h->stream));
         rc = pt_loop(h, false);
+        if (rc) return step_abort(h, rc);                       // (clears DevClock::pt / no_neumann too)
         HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &off, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        if (rc) return rc;
-        if (h->nnbr > 0 && (rc = exchange(h))) return rc;      // the ghost region as the last iteration left the owners
+        if (h->nnbr > 0 && (rc = exchange(h))) return step_abort(h, rc);      // the ghost region as the last iteration left the owners
         // (the loop leaves the masses of its last update_mesh in the element records: gathered as after a step)
         launch_mass_gather(h);
     } else if ((rc = residual_global(h))) return rc;
@@ -1405,13 +1417,14 @@ int des_dev_body_force_adjustment_group(des_dev **engines, int n, des_scalars *o
         h->n_pt_iterations = 0;
         if (h->p.has_PT) HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &on, sizeof(int), hipMemcpyHostToDevice, h->stream));
     }
+    auto abort_all = [&](int code) { for (int k = 0; k < n; ++k) step_abort(engines[k], code); return code; };
     if (engines[0]->p.has_PT) {
-        if ((rc = pt_loop_group(engines, n, false))) return rc;
-        for (int k = 0; k < n; ++k) { hipSetDevice(engines[k]->device); if (engines[k]->nnbr > 0 && (rc = exchange_local_pack(engines[k]))) return rc; }
+        if ((rc = pt_loop_group(engines, n, false))) return abort_all(rc);
+        for (int k = 0; k < n; ++k) { hipSetDevice(engines[k]->device); if (engines[k]->nnbr > 0 && (rc = exchange_local_pack(engines[k]))) return abort_all(rc); }
         for (int k = 0; k < n; ++k) {
             des_dev *h = engines[k];
             hipSetDevice(h->device);
-            if (h->nnbr > 0 && (rc = exchange_local_take(h, h->stream))) return rc;
+            if (h->nnbr > 0 && (rc = exchange_local_take(h, h->stream))) return abort_all(rc);
             HIP_OK(hipMemcpyAsync(&h->d_clk->no_neumann, &off, sizeof(int), hipMemcpyHostToDevice, h->stream));
             launch_mass_gather(h);
         }

@@ -44,7 +44,8 @@ struct Clock {
     double avg_time0;
     long long steps;
     int status, iso, n_past, x0_init;
-    int pt, pad;                       // inside the pseudo-transient loop of a step (Param::control.PT_jump)
+    int pt;                            // inside the pseudo-transient loop of a step (Param::control.PT_jump)
+    int l2_global;                     // l2_residual / l2_sum hold the GLOBAL block sum (k2_residual_final), not this rank's owned share
 };
 
 inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
@@ -67,6 +68,7 @@ struct Engine {
     int nbf[DES_NBDRY] = {0}, nbn[DES_NBDRY] = {0};
     int *bf_elem[DES_NBDRY] = {nullptr}, *bf_facet[DES_NBDRY] = {nullptr}, *bnodes[DES_NBDRY] = {nullptr};
     int4 *binc[DES_NBDRY] = {nullptr};         // [2 * nbn] per boundary with facets: the boundary-facet incidences of its nodes (k2_sbc_direct)
+    std::vector<int4> h_binc[DES_NBDRY];       // (host copies, create only)
     double *bnormals = nullptr, *edge_vec = nullptr; int *edge_slot = nullptr;
     int ntop = 0, etop = 0, ntop_elems = 0;
     int *top_nodes = nullptr, *ean = nullptr, *conn_surf = nullptr, *top_elems = nullptr;
@@ -87,6 +89,13 @@ struct Engine {
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
     // node-block patch passes (des_dev2d_patch.hpp); DES2D_PATCH=0 or a mesh outside their LDS caps: the plain kernels
     bool patch = false, res_fin_pending = false, tick_pending = false;
+    bool chain_on = true, surface_chained = false;   // DES2D_CHAIN: the surface step as one single-workgroup launch (k2_surface_chain)
+    // DES2D_FOLD (round 5): a plain step's stress bcs, damping / velocity / vbcs / coordinates and residual partials inside
+    // k2p_force's node phase (k2p_force<1>); fold_ok: this model's boundary loads can all be formed per node (create)
+    bool fold_on = true, fold_ok = false;
+    double *coord_alt = nullptr;                // the other buffer of the coordinate pair (k2p_force<1> writes the moved nodes there)
+    int *sbcn_idx = nullptr; int4 *sbcn_ent = nullptr;      // per node: its boundary-facet incidences {element, facet, which node, boundary}
+    int res_count = 0;                          // partials in res_part[] (blocks of 256 owned nodes, or the patch blocks)
     bool geo_on = true, elide_on = true;       // DES2D_GEO / DES2D_ELIDE != 0 (read at create)
     bool elide = false;                        // this step's output-only element stores can go (a later step of the same call rewrites them)
     bool geo_pending = false;                  // compute_volume + rotate_stress of the last step left to the next k2_stress<M, 2>
@@ -998,7 +1007,7 @@ __device__ __forceinline__ void residual_fin_block(int nb, const double *part, C
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
     // (l2_sum: the sum under the root -- on a decomposed mesh the owned nodes' share, added across ranks at the end of a call)
-    if (threadIdx.x == 0) { const double t = (sm[0] + sm[1]) + (sm[2] + sm[3]); clk->l2_sum = t; clk->l2_residual = sqrt(t); }
+    if (threadIdx.x == 0) { const double t = (sm[0] + sm[1]) + (sm[2] + sm[3]); clk->l2_sum = t; clk->l2_residual = sqrt(t); clk->l2_global = 0; }
 }
 
 __global__ void k2_residual_fin(int nb, const double *part, Clock *clk) { residual_fin_block(nb, part, clk); }
@@ -1036,7 +1045,8 @@ k2_residual_final(Clock *clk, const double *blocks, int nb)
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { clk->l2_sum = red[0]; clk->l2_residual = sqrt(red[0]); }
+    // (the sum over EVERY rank's blocks: the end of a call must not add it across ranks again -- l2_global says so)
+    if (threadIdx.x == 0) { clk->l2_sum = red[0]; clk->l2_residual = sqrt(red[0]); clk->l2_global = 1; }
 }
 
 // apply_vbcs, 2-D: vertical extent of the x0 wall (bc.cxx:251-290; only x0's is used, :292-300) over the list of
@@ -1433,6 +1443,64 @@ __global__ void k2_cse_node_maxdh(int ntop, int nb_node, const int *top_nodes, c
     if ((int)blockIdx.x >= nb_node) { surf_maxdh_block(ntop, top_nodes, o0, o1, dh, clk); return; }
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (i < ntop) cse_node_at(i, ntop, top_nodes, sup_idx, sup_arr, volume, volume_n, reset_dhacc, dhacc);
+}
+
+// Round 5: the whole surface step of a plain step in ONE launch of ONE workgroup.  A 2-D model's surface is a line -- a few
+// thousand nodes on the largest meshes -- and its four dependent loops (segments -> nodes -> edvacc_surf / correct_surface_element
+// -> nodal volumes / max |dh|) cost four launches of ~5 us each for a few hundred nanoseconds of work (profiles/r04_v_kernel_stats_2d:
+// 26 us of a 288-us step).  Here the workgroup walks the loops one after the other with a barrier in between (what a loop
+// writes, the next reads through the same CU's cache); the residual's final sum rides along as before.  Same statements, same
+// order per item: same bits.  Not on a decomposed mesh (the ghost exchange falls between the second and the third loop).
+#define DES2_CHAIN_THREADS 1024
+__global__ void __launch_bounds__(DES2_CHAIN_THREADS)
+k2_surface_chain(const des_params *p, Clock *clk, int etop, int ntop, int ntop_elems, int nn, int ne, const int *top_nodes, const int *ean,
+                 const int *conn_surf, const int *top_elems, const int *conn, const int *markers, const int *sup_idx, const int *sup_arr,
+                 int decay, int reset_dhacc, int o0, int o1, int res_nb, const double *res_part,
+                 double *coord, double *etmp, double *tmp_result, double *total_dx, double *total_slope, double *dhacc, double *dh,
+                 double *edvacc, double *volume, double *volume_n, double *plstrain, double *stress, double *strain, double *strain_rate)
+{
+    const int T = DES2_CHAIN_THREADS, t = (int)threadIdx.x;
+    __shared__ double sm[DES_BLOCK / 64], smx[DES_BLOCK / 64];
+    // calculate_residual_force's final sum over the per-block partials: residual_fin_block's shape (256 lanes, the same tree)
+    if (res_nb > 0) {
+        if (t < DES_BLOCK) {
+            double v = 0;
+            for (int i = t; i < res_nb; i += DES_BLOCK) v += res_part[i];
+            v = desk::wave_sum(v);
+            if ((t & 63) == 0) sm[t >> 6] = v;
+        }
+        __syncthreads();
+        if (t == 0) { const double tt = (sm[0] + sm[1]) + (sm[2] + sm[3]); clk->l2_sum = tt; clk->l2_residual = sqrt(tt); clk->l2_global = 0; }
+    }
+    // simple_diffusion: segments, then nodes (bc.cxx:916-1112, 1773-1786)
+    if (p->surface_process_option == 1 && etop > 0) {
+        for (int i = t; i < etop; i += T) surf_seg_at(i, etop, nn, ne, top_nodes, coord, etmp, tmp_result);
+        __threadfence(); __syncthreads();
+    }
+    for (int i = t; i < ntop; i += T) surf_node_at(i, p, clk, ntop, nn, ne, top_nodes, etmp, tmp_result, total_dx, total_slope, coord, dhacc, dh);
+    __threadfence(); __syncthreads();
+    // edvacc_surf (bc.cxx:1788-1805) and correct_surface_element's element part (bc.cxx:1655-1707): independent of each other
+    for (int i = t; i < etop; i += T) surf_edv_at(i, etop, nn, ean, conn_surf, coord, dh, edvacc);
+    for (int i = t; i < ntop_elems; i += T)
+        cse_elem_at(i, p, clk, ntop_elems, top_elems, nn, ne, conn, coord, markers, decay, volume, plstrain, stress, strain, strain_rate);
+    __threadfence(); __syncthreads();
+    for (int i = t; i < ntop; i += T) cse_node_at(i, ntop, top_nodes, sup_idx, sup_arr, volume, volume_n, reset_dhacc, dhacc);
+    // max |dh| -> max_surf_vel (bc.cxx:1820-1836): surf_maxdh_block's shape (256 lanes)
+    if (t < DES_BLOCK) {
+        double m = 0.;
+        for (int i = t; i < ntop; i += DES_BLOCK) {
+            const int n = top_nodes[i];
+            if (n >= o0 && n < o1) m = fmax(m, fabs(dh[i]));
+        }
+        m = desk::wave_max(m);
+        if ((t & 63) == 0) smx[t >> 6] = m;
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < DES_BLOCK / 64; ++w) smx[0] = fmax(smx[0], smx[w]);
+        clk->maxdh = smx[0];
+        clk->max_surf_vel = smx[0] / clk->dt;
+    }
 }
 
 // compute_volume (geometry.cxx:170-201) + the element part of compute_mass (geometry.cxx:1743-1870)
@@ -1902,13 +1970,30 @@ void launch_stress_bcs(Engine *h)
 
 // update_mesh (dynearthsol.cxx:448-493) after update_coordinate, in two parts: up to the committed surface heights
 // (where a decomposed mesh refreshes its ghost region) ...
+// the whole surface step as one single-workgroup launch (k2_surface_chain): the patch path of an engine that owns the whole
+// mesh (DES2D_CHAIN=0: the four launches)
+inline bool chain_ok(const Engine *h) { return h->chain_on && h->patch && !h->halo && h->ntop > 0; }
+
 void launch_surface_commit(Engine *h)
 {
     const des_params &p = h->p;
+    if (chain_ok(h)) {
+        const long long steps = h->steps_host;
+        const bool at_interval = steps % p.quality_check_step_interval == 0;
+        const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
+        hipLaunchKernelGGL(k2_surface_chain, dim3(1), dim3(DES2_CHAIN_THREADS), 0, h->stream, h->d_p, h->d_clk, h->etop, h->ntop, h->ntop_elems,
+                           h->nn, h->ne, h->top_nodes, h->ean, h->conn_surf, h->top_elems, h->conn, h->markers, h->sup_idx, h->sup_arr,
+                           decay, (steps != 0 && at_interval) ? 1 : 0, h->o0, h->o1, h->res_fin_pending ? h->res_count : 0, h->res_part,
+                           h->coord, h->etmp, h->tmp_result, h->total_dx, h->total_slope, h->dhacc, h->dh, h->edvacc, h->volume, h->volume_n,
+                           h->plstrain, h->stress, h->strain, h->strain_rate);
+        h->res_fin_pending = false;
+        h->surface_chained = true;                         // launch_update_mesh_surface of this step has nothing left to do
+        return;
+    }
     if (h->res_fin_pending && p.surface_process_option == 1 && h->etop > 0) {
         const int nbs = nblk(h->etop);
         hipLaunchKernelGGL(k2_surf_seg_resfin, dim3(nbs + 1), dim3(DES_BLOCK), 0, h->stream, h->etop, h->nn, h->ne, h->top_nodes, h->coord,
-                           h->etmp, h->tmp_result, nbs, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
+                           h->etmp, h->tmp_result, nbs, h->res_count, h->res_part, h->d_clk);
         h->res_fin_pending = false;
     } else
     // surface_processes (bc.cxx:1709-1872)
@@ -1925,6 +2010,7 @@ void launch_update_mesh_surface(Engine *h, long long steps)
     const des_params &p = h->p;
     const bool at_interval = steps % p.quality_check_step_interval == 0;
     const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
+    if (h->surface_chained) { h->surface_chained = false; return; }         // (k2_surface_chain did it all)
     if (h->patch && h->ntop > 0) {
         const int nbe = nblk(h->etop), nbc = nblk(h->ntop_elems), nbn = nblk(h->ntop);
         if (nbe + nbc > 0)
@@ -2028,6 +2114,10 @@ void launch_mechanics_far(Engine *h, bool nmd, bool thermal)
     h->far_issued = true;
 }
 
+// k2p_force<1> (the nodal tail of a plain step inside the force pass): an engine that owns the whole mesh, boundary loads
+// that can all be formed per node, no Neumann tractions / elastic foundation behind them (create: fold_ok)
+inline bool fold_now(const Engine *h) { return h->fold_on && h->fold_ok && h->patch && !h->halo && !h->no_neumann; }
+
 template <class M>
 void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = false)
 {
@@ -2054,9 +2144,26 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
         }
         h->geo_pending = false; h->mass_pending = false;
         if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
+        ForceTail ft = {h->d_clk, h->mass, h->ymass, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vel, h->coord_alt, h->conn,
+                        h->sbcn_idx, h->sbcn_ent, h->res_part, h->o0, h->o1, h->nn_global};
+        if (tail && fold_now(h)) {
+            // Everything nodal behind the force sums rides in k2p_force<1>.  The wall's extent first (the coordinates have not
+            // moved since the step began; with it the step is counted: nothing between here and apply_vbcs reads the clock's time)
+            launch_vbcs(h, false, h->tick_pending);
+            h->tick_pending = false;
+            { Prof2 pr(h, P2_FORCE);
+            hipLaunchKernelGGL(k2p_force<1>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+                               h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
+            }
+            std::swap(h->coord, h->coord_alt);             // the moved coordinates are the current ones from here on
+            h->res_count = h->p_nb;
+            if (chain_ok(h) || (h->p.surface_process_option == 1 && h->etop > 0)) h->res_fin_pending = true;
+            else hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->res_count, h->res_part, h->d_clk);
+            return;
+        }
         { Prof2 pr(h, P2_FORCE);
-        hipLaunchKernelGGL(k2p_force, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
-                           h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres);
+        hipLaunchKernelGGL(k2p_force<0>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+                           h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
         }
         launch_stress_bcs(h);
         join_wall(h);
@@ -2068,8 +2175,9 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
         } else
             L2(k2_damp_vel, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->force, h->vel);
         L2(k2_residual_part, h->o1 - h->o0, nn, h->o0, h->o1, h->nn_global, h->fres, h->res_part);
-        if (tail && h->p.surface_process_option == 1 && h->etop > 0) h->res_fin_pending = true;
-        else hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
+        h->res_count = nblk(h->o1 - h->o0);
+        if (tail && (chain_ok(h) || (h->p.surface_process_option == 1 && h->etop > 0))) h->res_fin_pending = true;
+        else hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->res_count, h->res_part, h->d_clk);
         return;
     }
     L2(k2_strain_rate, ne, nn, ne, h->conn, h->coord, h->vel, h->volume, h->strain_rate, h->etmp);
@@ -2163,17 +2271,22 @@ int pt_loop(Engine *h)
     if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;
     double residual_old = h->h_clk->l2_residual;
     if ((rc = set_pt(h, 1))) return rc;
-    for (int pt_step = 0; pt_step < p.PT_max_iter; ++pt_step) {
-        if (multi && (rc = exchange_rccl(h))) return rc;
-        pt_iteration<M>(h);
-        if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;
-        ++h->n_pt_iterations;
-        const double l2 = h->h_clk->l2_residual;
-        const double relative_change = std::fabs((l2 - residual_old) / residual_old);
-        if (relative_change < p.PT_relative_tolerance) break;
-        residual_old = l2;
-    }
-    return set_pt(h, 0);
+    rc = [&]() -> int {
+        int r;
+        for (int pt_step = 0; pt_step < p.PT_max_iter; ++pt_step) {
+            if (multi && (r = exchange_rccl(h))) return r;
+            pt_iteration<M>(h);
+            if ((r = residual_global(h)) || (r = sync_clock(h))) return r;
+            ++h->n_pt_iterations;
+            const double l2 = h->h_clk->l2_residual;
+            const double relative_change = std::fabs((l2 - residual_old) / residual_old);
+            if (relative_change < p.PT_relative_tolerance) break;
+            residual_old = l2;
+        }
+        return DES_OK;
+    }();
+    const int rc_off = set_pt(h, 0);       // on EVERY exit: an error inside the loop must not leave Clock::pt set for later steps
+    return rc ? rc : rc_off;
 }
 
 int step_front_rest(Engine *h);
@@ -2236,7 +2349,7 @@ int step_front_rest(Engine *h)
         launch_surface_commit(h);
     }
     if (h->res_fin_pending) {
-        hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, nblk(h->o1 - h->o0), h->res_part, h->d_clk);
+        hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->res_count, h->res_part, h->d_clk);
         h->res_fin_pending = false;
     }
     return DES_OK;
@@ -2441,7 +2554,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->etmp_int, (size_t)ne));
     A2(dalloc(h, h->dh, (size_t)h->ntop));
     A2(dalloc(h, h->edvacc, (size_t)h->etop));
-    A2(dalloc(h, h->res_part, (size_t)nblk(nn)));
+    A2(dalloc(h, h->res_part, (size_t)std::max(nblk(nn), nn / 16 + 2)));      // (blocks of 256 owned nodes, or the patch blocks: DES2D_PATCH >= 16)
     A2(dalloc(h, h->neg_zmin, 1));
     A2(dalloc(h, h->d_red, 8));
     A2(build_residual_blocks(h));
@@ -2453,6 +2566,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
         const char *ge = des_env::get("DES2D_GEO"), *ee = des_env::get("DES2D_ELIDE");
         h->geo_on = !(ge && ge[0] == '0'); h->elide_on = !(ee && ee[0] == '0');
         { const char *me = des_env::get("DES2D_MASS_FUSE"); h->mass_fuse_on = !(me && me[0] == '0'); }
+        { const char *ce = des_env::get("DES2D_CHAIN"); h->chain_on = !(ce && ce[0] == '0'); }
         const bool cluster = !(cl && cl[0] == '0');
         Patch2 P;
         bool ok = false;
@@ -2508,6 +2622,45 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                     }
                 }
                 if (fits) A2(dcopy(h, h->binc[i], inc.data(), inc.size()));      // (else: the three-launch form for this boundary)
+                if (fits) h->h_binc[i] = inc;
+            }
+            // k2p_force<1>: the boundary loads of launch_stress_bcs as ONE list per node, in that function's order (boundary by
+            // boundary, then the node's incidences); possible when every loaded boundary has its per-node incidences and nothing
+            // else follows the loads (no elastic foundation, no Neumann tractions)
+            {
+                const des_params &p = *params;
+                bool ok = true;
+                std::vector<std::vector<int4>> per_node((size_t)nn);
+                if (p.gravity != 0) {
+                    for (int i = 0; i < DES_NBDRY && ok; i++) {
+                        if (p.vbc_types[i] != 0 && p.vbc_types[i] != 2 && p.vbc_types[i] != 4) continue;
+                        if (i == iboundz0 && !p.has_winkler_foundation) continue;
+                        if (i == iboundz1 && !p.has_water_loading) continue;
+                        if (h->nbf[i] == 0) continue;
+                        if (h->nbn[i] == 0) continue;                         // (launch_stress_bcs: nothing to launch either)
+                        if (h->h_binc[i].empty()) { ok = false; break; }
+                        for (int j = 0; j < h->nbn[i]; ++j)
+                            for (int q = 0; q < DES2_SBC_INC; ++q) {
+                                const int4 e = h->h_binc[i][(size_t)DES2_SBC_INC * j + q];
+                                if (e.x < 0) break;
+                                per_node[mesh->bnodes[i][j]].push_back(make_int4(e.x, e.y, e.z, i));
+                            }
+                    }
+                    if (p.has_elastic_foundation && h->nbn[iboundz0]) ok = false;
+                }
+                for (int i = 0; i < 6; ++i) if (p.stress_bc_types[i] != 0 && h->nbf[i] != 0) ok = false;
+                if (ok) {
+                    std::vector<int> idx((size_t)nn + 1, 0);
+                    std::vector<int4> ent;
+                    for (int n = 0; n < nn; ++n) { idx[n] = (int)ent.size(); ent.insert(ent.end(), per_node[n].begin(), per_node[n].end()); }
+                    idx[nn] = (int)ent.size();
+                    if (ent.empty()) ent.push_back(make_int4(-1, 0, 0, 0));
+                    A2(dcopy(h, h->sbcn_idx, idx.data(), idx.size()));
+                    A2(dcopy(h, h->sbcn_ent, ent.data(), ent.size()));
+                    A2(dalloc(h, h->coord_alt, (size_t)2 * nn));
+                    h->fold_ok = true;
+                }
+                const char *fe = des_env::get("DES2D_FOLD"); h->fold_on = !(fe && fe[0] == '0');
             }
             A2(dalloc(h, h->stress_pre, (size_t)3 * ne));
         }
@@ -2713,6 +2866,9 @@ static int step_abort(Engine *h, int rc)
     hipStreamSynchronize(h->xstream);
     hipStreamSynchronize(h->stream);
     h->join_pending = false; h->wall_pending = false; h->far_issued = false; h->mass_pending = false;
+    static const int zero = 0;
+    hipMemcpy(&h->d_clk->pt, &zero, sizeof(int), hipMemcpyHostToDevice);     // a loop the error may have come from
+    h->no_neumann = false;
     return rc;
 }
 
@@ -2776,7 +2932,8 @@ int step(Engine *h, int nsteps, des_scalars *out)
         const int rcs = fill_scalars(h, out);
         double l2sum = 0;
         HIP2(hipMemcpy(&l2sum, h->d_red + 6, sizeof(double), hipMemcpyDeviceToHost));
-        out->l2_residual = std::sqrt(l2sum);
+        // (a step that ended in the pseudo-transient loop left the global block sum on every rank: nothing to add)
+        if (!h->h_clk->l2_global) out->l2_residual = std::sqrt(l2sum);
         return rcs;
     }
     if (h->halo && nsteps > 0) {
@@ -2808,7 +2965,7 @@ int body_force_adjustment(Engine *h, des_scalars *out)
         int rc = h->portable_libm ? pt_loop<desk::MathPortable>(h) : pt_loop<desk::MathOcml>(h);
         h->no_neumann = false;
         if (!rc && h->halo) rc = exchange_rccl(h);             // the ghost region as the last iteration left the owners
-        if (rc) return rc;
+        if (rc) return step_abort(h, rc);
     } else { const int rc = residual_global(h); if (rc) return rc; }
     HIP2(hipGetLastError());
     if (out) return fill_scalars(h, out);
@@ -3162,16 +3319,23 @@ static int step_group_impl(Engine **g, int n, int nsteps, des_scalars *out)
             int rc;
             double residual_old = 0, l2 = 0;
             if ((rc = residual_all(&residual_old))) return rc;
-            for (int k = 0; k < n; ++k) if ((rc = set_pt(g[k], 1))) return rc;
-            for (int pt_step = 0; pt_step < g[0]->p.PT_max_iter; ++pt_step) {
-                if ((rc = exchange_all(true))) return rc;
-                for (int k = 0; k < n; ++k) { if (g[k]->portable_libm) pt_iteration<desk::MathPortable>(g[k]); else pt_iteration<desk::MathOcml>(g[k]); }
-                if ((rc = residual_all(&l2))) return rc;
-                for (int k = 0; k < n; ++k) ++g[k]->n_pt_iterations;
-                if (std::fabs((l2 - residual_old) / residual_old) < g[0]->p.PT_relative_tolerance) break;
-                residual_old = l2;
-            }
-            for (int k = 0; k < n; ++k) { if ((rc = set_pt(g[k], 0)) || (rc = step_front_rest(g[k]))) return rc; }
+            auto pt_all = [&](int on) -> int { int first = DES_OK; for (int k = 0; k < n; ++k) { const int r = set_pt(g[k], on); if (r && !first) first = r; } return first; };
+            if ((rc = pt_all(1))) { pt_all(0); return rc; }
+            rc = [&]() -> int {
+                int r;
+                for (int pt_step = 0; pt_step < g[0]->p.PT_max_iter; ++pt_step) {
+                    if ((r = exchange_all(true))) return r;
+                    for (int k = 0; k < n; ++k) { if (g[k]->portable_libm) pt_iteration<desk::MathPortable>(g[k]); else pt_iteration<desk::MathOcml>(g[k]); }
+                    if ((r = residual_all(&l2))) return r;
+                    for (int k = 0; k < n; ++k) ++g[k]->n_pt_iterations;
+                    if (std::fabs((l2 - residual_old) / residual_old) < g[0]->p.PT_relative_tolerance) break;
+                    residual_old = l2;
+                }
+                return DES_OK;
+            }();
+            const int rc_off = pt_all(0);                     // on every exit of the loop
+            if (rc || (rc = rc_off)) return rc;
+            for (int k = 0; k < n; ++k) if ((rc = step_front_rest(g[k]))) return rc;
         }
         // Overlapped schedule (every engine takes the same decision): messages, unpack and the wall's local extent on the side
         // streams; compute_mass of the far blocks on the engines' streams at once, the rest of the step behind the join in the
@@ -3233,7 +3397,8 @@ static int step_group_impl(Engine **g, int n, int nsteps, des_scalars *out)
         else HIP2(hipStreamSynchronize(g[k]->stream));
     }
     // l2_residual over all ranks' owned nodes (every node counts once), as des_dev.h promises and the 3-D group does
-    if (out && n > 1) for (int k = 0; k < n; ++k) out[k].l2_residual = std::sqrt(l2sum);
+    // (unless the last residual of the call was the pseudo-transient loop's global block sum, which every engine holds whole)
+    if (out && n > 1 && !g[0]->h_clk->l2_global) for (int k = 0; k < n; ++k) out[k].l2_residual = std::sqrt(l2sum);
     return worst;
 }
 

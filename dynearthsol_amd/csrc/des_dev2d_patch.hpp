@@ -312,10 +312,22 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
 // ---- NMD_stress (element update) + update_force ---------------------------------------------------------
 // nmd: the stress k2_stress left in stress_in gets its diagonal corrected here; the block that owns the element stores the
 // result to stress_out (another buffer: a neighbouring block may still be reading stress_in).  nmd = 0: stress_in is read only.
+// TAIL = 1 (round 5, the launch diet the 3-D engine's EN3 has had since round 2): everything nodal that follows the force sums
+// of a plain step rides in the node phase -- apply_stress_bcs for the node's own boundary facets (k2_sbc_direct's statements,
+// from one list per node in that kernel's order: boundary by boundary, incidence by incidence), apply_damping +
+// update_velocity, apply_vbcs, update_coordinate (k2_node_final's statements: the very device functions) and the node's share
+// of calculate_residual_force, summed per patch block -- instead of k2_sbc_direct, k2_node_final and k2_residual_part as
+// launches of their own.  The moved coordinates go to the OTHER buffer of a pair (another block may still be staging this
+// block's nodes); the host swaps.  The wall's extent (apply_vbcs' depth profiles) is in the clock before this launch.
+struct ForceTail {
+    const Clock *clk; const double *mass, *ymass; const unsigned *bcflag; const double *bnormals, *edge_vec; const int *edge_slot;
+    double *vel, *coord_out; const int *conn; const int *sbcn_idx; const int4 *sbcn_ent; double *res_part; int o0, o1, nn_global;
+};
+template <int TAIL>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
           const double *volume, const double *dpressure, const double *stress_in, double *stress_out, const double *props,
-          const int *markers, const int *mono, double *force, double *fres)
+          const int *markers, const int *mono, double *force, double *fres, const ForceTail ft)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap, *const lnt = lT + a.pn_cap;
@@ -397,6 +409,43 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
         }
         for (int j = 0; j < 2; j++) { force[j*nn + n] = f[j]; fres[j*nn + n] = fr[j]; }
     }
+    if (!TAIL) return;
+    double l2 = 0.0;
+    if ((int)threadIdx.x < nown) {
+        const int n = a.po_id[o0 + threadIdx.x];
+        const unsigned flag = ft.bcflag[n];
+        if (flag & BOUND_ANY) {
+            // apply_stress_bcs (bc.cxx:661-827): k2_sbc_direct's walk for this node, one loaded boundary after the other
+            const int b0 = ft.sbcn_idx[n], b1 = ft.sbcn_idx[n + 1];
+            if (b1 > b0) {
+                double f0 = force[n], f1 = force[nn + n];
+                for (int k = b0; k < b1; ++k) {
+                    const int4 ent = ft.sbcn_ent[k];
+                    double normal[2];
+                    const double pr = sbc_facet_pressure(p, ent.w, ent.x, ent.y, nn, ne, ft.conn, coord, temperature, markers, normal);
+                    f0 -= pr * normal[0] / 2;
+                    f1 -= pr * normal[1] / 2;
+                }
+                force[n] = f0; force[nn + n] = f1;
+            }
+        }
+        // k2_node_final's statements (the node's own entries only)
+        damp_vel_node(p, ft.clk, n, nn, ft.mass, ft.ymass, force, ft.vel);
+        vbcs_node(p, ft.clk, n, nn, ft.bcflag, ft.bnormals, ft.edge_vec, ft.edge_slot, coord, ft.vel);
+        ft.coord_out[n] = coord[n] + ft.vel[n] * ft.clk->dt;
+        ft.coord_out[nn + n] = coord[nn + n] + ft.vel[nn + n] * ft.clk->dt;
+        // calculate_residual_force (fields.cxx:700-722): this node's terms (k2_residual_part's expression)
+        if (n >= ft.o0 && n < ft.o1) {
+            const double num = (double)ft.nn_global * 2;
+            for (int j = 0; j < 2; ++j) { const double fj = fres[j*nn + n]; l2 += fj * fj / num; }
+        }
+    }
+    // per-block partial; the partials are added in block order afterwards (k2_residual_fin / k2_surface_chain)
+    __shared__ double red[DES2_PATCH_THREADS / 64];
+    l2 = desk::wave_sum(l2);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;
+    __syncthreads();
+    if (threadIdx.x == 0) ft.res_part[b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---- compute_mass (with the volumes it sums) ----------------------------------------------------------------

@@ -174,16 +174,23 @@ int pt_loop(des_dev *h, bool in_step = true)
     if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;     // l2 of the step's own update_force
     double residual_old = h->h_clk->l2_residual;
     if ((rc = set_pt(h, 1))) return rc;
-    for (int pt_step = 0; pt_step < h->p.PT_max_iter; ++pt_step) {
-        if (multi && (rc = exchange(h))) return rc;
-        pt_iteration(h);
-        if ((rc = residual_global(h)) || (rc = sync_clock(h))) return rc;
-        ++h->n_pt_iterations;
-        const double l2 = h->h_clk->l2_residual;
-        if (pt_converged(h, l2, residual_old)) break;
-        residual_old = l2;
-    }
-    if ((rc = set_pt(h, 0))) return rc;
+    rc = [&]() -> int {
+        int r;
+        for (int pt_step = 0; pt_step < h->p.PT_max_iter; ++pt_step) {
+            if (multi && (r = exchange(h))) return r;
+            pt_iteration(h);
+            if ((r = residual_global(h)) || (r = sync_clock(h))) return r;
+            ++h->n_pt_iterations;
+            const double l2 = h->h_clk->l2_residual;
+            if (pt_converged(h, l2, residual_old)) break;
+            residual_old = l2;
+        }
+        return DES_OK;
+    }();
+    // DevClock::pt goes back to 0 on EVERY exit of the loop: an exchange / RCCL / sync error inside it must not leave an
+    // engine that is "steppable again" running its later steps with the boundaries at rest and no clock
+    const int rc_off = set_pt(h, 0);
+    if (rc || (rc = rc_off)) return rc;
     if (in_step) launch_vbcs_coord(h);                     // apply_vbcs + update_coordinate of the step itself
     return DES_OK;
 }
@@ -203,24 +210,31 @@ int pt_loop_group(des_dev **g, int n, bool in_step)
     };
     double residual_old = 0, l2 = 0;
     if ((rc = residual(&residual_old))) return rc;
-    for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); if ((rc = set_pt(g[k], 1))) return rc; }
-    for (int pt_step = 0; pt_step < g[0]->p.PT_max_iter; ++pt_step) {
-        for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); if (g[k]->nnbr > 0 && (rc = exchange_local_pack(g[k]))) return rc; }
-        for (int k = 0; k < n; ++k) {
-            hipSetDevice(g[k]->device);
-            if (g[k]->nnbr > 0 && (rc = exchange_local_take(g[k], g[k]->stream))) return rc;
-            pt_iteration(g[k]);
+    auto pt_all = [&](int on) -> int {
+        int first = DES_OK;
+        for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); const int r = set_pt(g[k], on); if (r && !first) first = r; }
+        return first;
+    };
+    if ((rc = pt_all(1))) { pt_all(0); return rc; }
+    rc = [&]() -> int {
+        int r;
+        for (int pt_step = 0; pt_step < g[0]->p.PT_max_iter; ++pt_step) {
+            for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); if (g[k]->nnbr > 0 && (r = exchange_local_pack(g[k]))) return r; }
+            for (int k = 0; k < n; ++k) {
+                hipSetDevice(g[k]->device);
+                if (g[k]->nnbr > 0 && (r = exchange_local_take(g[k], g[k]->stream))) return r;
+                pt_iteration(g[k]);
+            }
+            if ((r = residual(&l2))) return r;
+            for (int k = 0; k < n; ++k) ++g[k]->n_pt_iterations;
+            if (pt_converged(g[0], l2, residual_old)) break;
+            residual_old = l2;
         }
-        if ((rc = residual(&l2))) return rc;
-        for (int k = 0; k < n; ++k) ++g[k]->n_pt_iterations;
-        if (pt_converged(g[0], l2, residual_old)) break;
-        residual_old = l2;
-    }
-    for (int k = 0; k < n; ++k) {
-        hipSetDevice(g[k]->device);
-        if ((rc = set_pt(g[k], 0))) return rc;
-        if (in_step) launch_vbcs_coord(g[k]);
-    }
+        return DES_OK;
+    }();
+    const int rc_off = pt_all(0);                          // on every exit of the loop (see pt_loop)
+    if (rc || (rc = rc_off)) return rc;
+    if (in_step) for (int k = 0; k < n; ++k) { hipSetDevice(g[k]->device); launch_vbcs_coord(g[k]); }
     return DES_OK;
 }
 

@@ -6,6 +6,9 @@
 // host side of the engine
 // =====================================================================================
 #define DES_ALLOC_SLACK 8192
+// the over-read of the pipelined stress update's last tile: up to TILE - 1 = 255 records past the end of an array, the widest
+// being a connectivity record (passes/e2.hpp: dma)
+static_assert(DES_ALLOC_SLACK >= 255 * sizeof(int4), "DES_ALLOC_SLACK no longer covers the last tile of E2_update_stress_pipe");
 template <typename T>
 int dev_alloc(T *&ptr, size_t count)
 {
@@ -28,6 +31,8 @@ int dev_upload(T *dst, const T *src, size_t count, hipStream_t s)
 }
 
 inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
+// LDS array lengths of the patch passes for a mesh's largest block (multiples of 8 entries: 16-byte aligned sub-arrays)
+inline int patch_cap(int n) { return (n + 7) & ~7; }
 // grids are rounded up to a multiple of 8 so the XCD-aware block map covers every chunk
 inline int nblk8(long long n) { int b = nblk(n); return (b + 7) / 8 * 8; }
 
@@ -431,7 +436,7 @@ void launch_e2(des_dev *h, int part = PART_ALL)
             hipLaunchKernelGGL(kp, dim3(npers + nbf_p + nsf_p), dim3(tile), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                                ntiles, npers, h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old,
                                h->stress, h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
-                               h->etmp2, count, (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
+                               h->etmp2, count, h->e2_tile_ctr, (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
         } else
         hipLaunchKernelGGL(k, dim3(nblk8(e_all) + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                            e_begin, e_count, e_begin2, e_count2, nblk(e_all), h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,
@@ -516,7 +521,7 @@ void launch_en1(des_dev *h, int part = PART_ALL)
     }
     if (c0 + c1 > 0) {
         Launch l(h, K_EN1);
-        void (*k)(const des_params *, DevClock *, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *,
+        void (*k)(const des_params *, DevClock *, int, int, int, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *,
                   const int *, const int *, const int *, const unsigned *, const MatData, const double *, const d4 *, d4 *, d4 *,
                   double *, double *, double *, const SurfPending);
         // the surface step of the step before, if its S2 / S3 launches were left out (s2_defer_ok)
@@ -532,15 +537,17 @@ void launch_en1(des_dev *h, int part = PART_ALL)
         const bool cm = h->const_mass;
         static const char *tenv = des_env::get("DES_EN1_THREADS");
         const int T = (tenv && std::atoi(tenv) == 512) ? 512 : 256;
-        const bool fit = h->patch_max_inc <= 1600 && h->patch_max_pn <= 296 && h->patch_max_pe <= 872;
         const bool th = h->p.has_thermal_diffusion != 0;       // the common launch has kernels of its own (passes/en1.hpp)
-#define DES_EN1_PICK(TT, II, NN, EE) (th ? (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1, 1> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0, 1>) \
-                                         : (cm ? EN1_mass_temperature_dvoldt<TT, II, NN, EE, 1, 0> : EN1_mass_temperature_dvoldt<TT, II, NN, EE, 0, 0>))
-        if (fit) k = T == 512 ? DES_EN1_PICK(512, 1600, 296, 872) : DES_EN1_PICK(256, 1600, 296, 872);
-        else     k = T == 512 ? DES_EN1_PICK(512, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE) : DES_EN1_PICK(256, DES_PATCH_INC, DES_PATCH_PN, DES_PATCH_PE);
+#define DES_EN1_PICK(TT) (th ? (cm ? EN1_mass_temperature_dvoldt<TT, 1, 1> : EN1_mass_temperature_dvoldt<TT, 0, 1>) \
+                             : (cm ? EN1_mass_temperature_dvoldt<TT, 1, 0> : EN1_mass_temperature_dvoldt<TT, 0, 0>))
+        k = T == 512 ? DES_EN1_PICK(512) : DES_EN1_PICK(256);
 #undef DES_EN1_PICK
-        hipLaunchKernelGGL(k, dim3((c0 + c1 + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk, h->nn, h->ne, b0, c0, b1, c1,
-                           (int)(part != PART_REST), h->patch_npb, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
+        // LDS for the mesh's largest block (dynamic: the workgroups per CU follow from the mesh and the block size)
+        const int ci = patch_cap(h->patch_max_inc), cn = patch_cap(h->patch_max_pn), ce = patch_cap(h->patch_max_pe);
+        const size_t lds = en1_lds_bytes(ci, cn, ce, cm);
+        if (lds > 65536) hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3((c0 + c1 + 7) / 8 * 8), dim3(T), lds, h->stream, h->d_p, h->d_clk, h->nn, h->ne, b0, c0, b1, c1,
+                           (int)(part != PART_REST), h->patch_npb, ci, cn, ce, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
                            mat_data(h), h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n,
                            h->tmass, h->ntmp, sp);
     }
@@ -554,21 +561,19 @@ void launch_en3(des_dev *h)
     h->res_nb = h->patch_nb;
     {
         Launch l(h, K_EN3);
-        // the smallest LDS shape that holds this mesh's largest block -> most workgroups per CU
-        void (*k)(const des_params *, const DevClock *, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *, const int *, const int *, const int *, const unsigned *, const double *, const MatData, const double *,
+        // LDS for the mesh's largest block (dynamic) -> as many workgroups per CU as the mesh allows
+        void (*k)(const des_params *, const DevClock *, int, int, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *, const int *, const int *, const int *, const unsigned *, const double *, const MatData, const double *,
                   const double *, const double *, double *, unsigned, const int *, const int *, const double *, const double *, const double *,
                   const double *, const double *, const int *, const d4 *, d4 *, d4 *, double *, double *, double *);
         const int T = h->patch_threads;
         const bool nmd = h->p.is_using_mixed_stress && !h->iso && !h->in_pt;
         const bool known = nmd && h->p.gravity != 0;           // the common launch has kernels of its own (passes/en3.hpp)
-#define EN3_PICK(I, P) (known ? (T == 512 ? EN3_force_nodes<512, I, P, 1> : EN3_force_nodes<256, I, P, 1>) \
-                              : (T == 512 ? EN3_force_nodes<512, I, P, 0> : EN3_force_nodes<256, I, P, 0>))
-        if (h->patch_max_inc <= 1024 && h->patch_max_pn <= 256) k = EN3_PICK(1024, 256);
-        else if (h->patch_max_inc <= 1664 && h->patch_max_pn <= 320) k = EN3_PICK(1664, 320);
-        else k = EN3_PICK(DES_PATCH_INC, DES_PATCH_PN);
-#undef EN3_PICK
-        hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), 0, h->stream, h->d_p, h->d_clk,
-                           (int)nmd, h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb,
+        k = known ? (T == 512 ? EN3_force_nodes<512, 1> : EN3_force_nodes<256, 1>) : (T == 512 ? EN3_force_nodes<512, 0> : EN3_force_nodes<256, 0>);
+        const int ci = patch_cap(h->patch_max_inc), cn = patch_cap(h->patch_max_pn);
+        const size_t lds = en3_lds_bytes(ci, cn);
+        if (lds > 65536) hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3((h->patch_nb + 7) / 8 * 8), dim3(T), lds, h->stream, h->d_p, h->d_clk,
+                           (int)nmd, h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb, ci, cn,
                            h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag, h->ntmp, mat_data(h),
                            h->volume, h->dpressure, h->stress, h->ddp, h->bc_mask, h->bcn_idx, h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass,
                            h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part);

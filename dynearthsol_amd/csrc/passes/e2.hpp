@@ -19,6 +19,12 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 // traffic): loaded and stored non-temporally they do not evict what the next passes re-read (the stress, the patch
 // lists): -3..5 us per step, spread over E2<GEO>, EN3 and EN1.  (The same on the stress / plstrain / volume / ddp
 // loads and on the output-only stores: no further gain, EN3 a little slower.)
+#ifndef DES_E2_PIPE_LANDED
+#define DES_E2_PIPE_LANDED 1
+#endif
+#ifndef DES_E2_DYN
+#define DES_E2_DYN 0
+#endif
 #define DES_STRAIN_LD pl_ld_nt
 #define DES_STRAIN_ST pl_st_nt
 // avg_*: Output::average_fields (output.cxx:327-370) folded into this pass when the end-of-step pass is (engine/launch.hpp):
@@ -271,6 +277,14 @@ __device__ __forceinline__ bool e2_element(const int e, const des_params *__rest
     default: break;
     }
     DES_E2_STAMP(law);
+#if DES_E2_PIPE_LANDED
+    // Pipelined form: the next tile's LDS-DMA pieces were requested half a tile ago (after(), behind the geometry) and the
+    // early stores of this tile before the law -- by now all of them have long completed, so this wait costs nothing; what it
+    // buys is an INVARIANT instead of a count: every piece has landed before the last group of stores is issued, whatever
+    // the compiler makes of the stores (the first form of this kernel waited at the head of the next tile with vmcnt(12),
+    // i.e. relied on at least 13 younger stores in every tile).
+    if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     if (GEO) {
         if (g_rescaled) pl_st(plstrain, 0, ne, eo, g_pls);                 // rescaled by correct_surface_element, not changed by the law
         if (outs && !rp.fresh) pl_st(volume_old, 0, ne, eo, g_top ? vol : pl_ld(volume, 0, ne, eo));             // (re-read rather than held in registers through the update)
@@ -369,6 +383,10 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
 // Needs: one element range starting at 0 (not the split parts of the overlapped schedule), an even plane stride (16-byte
 // DMA pieces), and the 4 KB of slack dev_alloc() leaves behind every array (the last tile reads whole 64-element pieces).
 // npers: resident workgroups (a multiple of 8: blockIdx.x & 7 = the XCD under round-robin placement, for locality only).
+// DES_E2_PIPE_LANDED = 1 (default): "this tile's pieces have landed" is established inside the tile before (e2_element: one
+// s_waitcnt vmcnt(0) in front of the last group of stores); 0: the first form, a counted wait at the head of the tile.
+// DES_E2_DYN = 1: tiles of 64 elements handed out per WAVEFRONT from one counter per XCD share (the first round static, then
+// one atomic per wavefront and tile, requested a tile ahead so that the DMA knows where to go); 0: the static interleave.
 typedef const __attribute__((address_space(1))) void *des_gptr;
 typedef __attribute__((address_space(3))) void *des_lptr;
 // NW = wavefronts per workgroup: 4 (two workgroups per CU = two waves per SIMD).  Tried: 12 -- ONE workgroup of 768 lanes per
@@ -381,7 +399,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
      double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
-     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ count,
+     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ count, unsigned *__restrict__ tile_ctr,
      int nbcf, const int *__restrict__ f_elem, const int *__restrict__ f_facet,
      const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp, const RotPending rp)
 {
@@ -394,7 +412,6 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
             edvacc_facet(g - nbcf_pad, rp.edv_etop, rp.edv_conn_surf, xt, rp.edv_dh_n, rp.edv_edvacc);
         return;
     }
-    constexpr int TILE = NW * 64;                        // elements per workgroup and tile
     __shared__ double lpl[NW][16][64];                   // per wavefront: stress 0-5, strain 6-11, volume 12, plstrain 13, ddp 14, (pad 15)
     __shared__ int4 lcn[NW][64];
     __shared__ int lmono[NW][64];
@@ -403,19 +420,23 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
     M::stage_end();
     // (w through readfirstlane: the LDS base of a DMA piece goes through M0 and must be known to be wave-uniform)
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
-    // tiles of this workgroup: XCD x sweeps the x-th eighth of the tiles (desk::logical_block's chunks), its npers / 8
-    // resident workgroups interleaved over it
+    // Every wavefront walks WAVE-TILES of 64 elements.  XCD x sweeps the x-th eighth of the 256-element tiles (desk::logical_block's
+    // chunks), i.e. the wave-tiles [x per NW, wt_end); its npers / 8 resident workgroups -- nwx wavefronts -- share them: statically
+    // interleaved (the four wavefronts of a workgroup side by side on one 256-element tile), or handed out one by one
+    // (DES_E2_DYN: the first round as in the static form, then tile_ctr[x] counts on; requested one tile AHEAD, at the top
+    // of the tile, so that the DMA of the next tile knows where to go when this tile's LDS region is free).
     const int per = (ntiles + 7) >> 3, wx = npers >> 3;
     const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
-    const int t_end = min((x + 1) * per, ntiles);
+    const int wt_begin = x * per * NW, wt_end = min((x + 1) * per, ntiles) * NW;
+    const int nwx = wx * NW;
     const bool have_ddp = rp.ddp != nullptr;
-    // The DMA of one tile for this wavefront.  A piece = one instruction = 64 lanes x 16 B landing at the LDS base + 16 lane.
+    // The DMA of one wave-tile.  A piece = one instruction = 64 lanes x 16 B landing at the LDS base + 16 lane.
     // 64 elements of a plane are 512 B, so a piece carries TWO planes: lanes 0-31 two consecutive elements of plane k each,
     // lanes 32-63 of plane k + 1 (the same array's next plane, or the partner array's) -- every lane active, no divergent
     // region around the requests.  Plane 15 is padding (the partner of ddp).  Then one connectivity record and one marker word
     // per lane, and the top flags.
-    auto dma = [&](int tile) {
-        const size_t eb = (size_t)tile * TILE + (size_t)w * 64;
+    auto dma = [&](int wtile) {
+        const size_t eb = (size_t)wtile * 64;
         const size_t o = eb + 2 * (size_t)(lane & 31);
         const size_t hi = (size_t)(lane >> 5);
 #pragma unroll
@@ -431,23 +452,42 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
         // (the top flags are bytes: a dword piece of 64 x 4 B covers them four times over -- bytes 0-63 are this tile's)
         __builtin_amdgcn_global_load_lds((des_gptr)(rp.topflag + eb + 4 * (size_t)lane), (des_lptr)&ltop[w][0], 4, 0, 0);
     };
-    int t = x * per + j;
-    if (t < t_end) dma(t);
+#if DES_E2_DYN
+    const int wt_first = wt_begin + j * NW + w;
+#else
+    const int wt_first = wt_begin + j * NW + w, wt_step = nwx;
+#endif
+    int t = wt_first;
+    if (t < wt_end) dma(t);
 #ifdef DES_STAMPS
     unsigned long long st_wait = 0, st_issue = 0, st_gather = 0, st_body = 0, st_n = 0, st_a, st_b;
     E2Stamps est = {0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_begin = wall_clock64();
 #endif
-    while (t < t_end) {
-        const int e = t * TILE + (int)threadIdx.x;
-        const int tn = t + wx;
+    while (t < wt_end) {
+        const int e = t * 64 + lane;
+#if DES_E2_DYN
+        // the tile after this one: one atomic per wavefront, in flight under the LDS reads and the gathers (after() waits for it
+        // with them).  The wavefront that draws the LAST number of the launch -- every wavefront that works draws exactly one
+        // number past the end -- puts the counter back to zero for the next launch.
+        unsigned grab = 0;
+        if (lane == 0) grab = atomicAdd(&tile_ctr[x], 1u);
+        int tn = wt_end;
+#else
+        const int tn = t + wt_step;
+#endif
 #ifdef DES_STAMPS
         st_a = wall_clock64();
 #endif
+#if DES_E2_PIPE_LANDED
+        // this tile's pieces: landed before the last stores of the tile before were issued (e2_element); the first tile's here
+        if (t == wt_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         // This tile's DMA has landed once at most the vector-memory operations issued BEHIND it are outstanding: the stores
         // of the tile before (at least 13: stress 6, strain 6, volume) -- or nothing, for the first tile.
-        if (t == x * per + j) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else                  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (t == wt_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else               asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#endif
 #ifdef DES_STAMPS
         st_b = wall_clock64(); st_wait += st_b - st_a; st_a = st_b;
 #endif
@@ -474,7 +514,15 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
             // compiler's own scoreboard sees: vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding 0x0F70).
             __builtin_amdgcn_s_waitcnt(0x0F70);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (tn < t_end) dma(tn);
+#if DES_E2_DYN
+            // (lane 0's number whatever lanes are active here: the lanes past the mesh come through after() a second time, below,
+            //  without lane 0 -- readfirstlane would hand them a lane that never drew)
+            const unsigned g = (unsigned)__builtin_amdgcn_readlane((int)grab, 0);
+            tn = wt_begin + nwx + (int)g;
+            if (g == (unsigned)(wt_end - wt_begin) - 1u && lane == 0) atomicExch(&tile_ctr[x], 0u);
+            if (tn > wt_end) tn = wt_end;
+#endif
+            if (tn < wt_end) dma(tn);
             asm volatile("" ::: "memory");
             dma_done = true;
         };

@@ -49,22 +49,56 @@ struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *s
 #ifndef DES_PATCH_PE
 #define DES_PATCH_PE 1280         // elements of a patch (LDS records)
 #endif
+#ifndef DES_EN1_PREF
+#define DES_EN1_PREF 0            // n: the list entries (and marker words) of a lane's first n rounds of patch elements requested up front
+#endif
+#ifndef DES_EN1_MINWAVES
+#define DES_EN1_MINWAVES 3        // waves per SIMD the register budget of the 256-lane kernel is held to (168 VGPRs; 4: 128)
+#endif
 
 // THERM = 1: has_thermal_diffusion known to be on (the common launch: that path only in the kernel), 0: read at run time
-template <int THREADS, int INC, int PN, int PE, int CONSTM, int THERM = 0>
-__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : 3)
+// LDS is DYNAMIC, sized by the host to the mesh's largest block (cap_inc incidences, cap_pn patch nodes, cap_pe patch elements:
+// engine/launch.hpp, en1_lds_bytes) -- the number of workgroups a CU holds follows from the mesh and the block size, not from a
+// handful of compiled shapes (round 5; rounds 2-4: template shapes <1600, 296, 872> / <2048, 512, 1280>).
+__host__ __device__ inline size_t en1_lds_bytes(int cap_inc, int cap_pn, int cap_pe, bool constm)
+{
+    return (size_t)cap_pn * (32 + 24) + (size_t)cap_pe * (constm ? 24 : 32) + (size_t)cap_inc * 10;
+}
+template <int THREADS, int CONSTM, int THERM = 0>
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? 4 : DES_EN1_MINWAVES)
 EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restrict__ clk, int nn, int ne, int b0, int c0, int b1, int c1, int do_clock, int npb,
+     int cap_inc, int cap_pn, int cap_pe,
      const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag, const MatData md,
      const double *__restrict__ radiogenic, const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm,
      double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp, const SurfPending sp)
 {
-    __shared__ d4 lxt[PN];
-    __shared__ double lvx[PN], lvy[PN], lvz[PN];
-    __shared__ double lvol[PE], ltm[PE], ldv[PE];
-    __shared__ double lm[CONSTM ? 1 : PE];
-    __shared__ double ltd[INC];
-    __shared__ unsigned short lidx[INC];
+    extern __shared__ __attribute__((aligned(32))) unsigned char des_smem[];
+    // The staged {x,y,z,T} records as two 16-byte halves in arrays of their own (DES_LXY, passes/common.hpp): a ds_read_b128
+    // serves 16 lanes per LDS cycle over sixteen 16-byte bank groups, and 32-byte records put every lane's first half on the
+    // EVEN groups only (8 bins for 16 random lanes, then the same for the second half); 16-byte strides use all sixteen.
+    unsigned char *sm = des_smem;
+#if DES_LXY
+    double2 *const lxy = (double2 *)sm; sm += (size_t)cap_pn * 16;
+    double2 *const lzt = (double2 *)sm; sm += (size_t)cap_pn * 16;
+    auto lget = [&](int j) { const double2 a = lxy[j], b = lzt[j]; d4 r; r.x = a.x; r.y = a.y; r.z = b.x; r.w = b.y; return r; };
+    auto lput = [&](int j, const d4 &r) { lxy[j] = make_double2(r.x, r.y); lzt[j] = make_double2(r.z, r.w); };
+    auto laddz = [&](int j, double d) { lzt[j].x = lzt[j].x + d; };
+#else
+    d4 *const lxt = (d4 *)sm; sm += (size_t)cap_pn * 32;
+    auto lget = [&](int j) { return lxt[j]; };
+    auto lput = [&](int j, const d4 &r) { lxt[j] = r; };
+    auto laddz = [&](int j, double d) { lxt[j].z = lxt[j].z + d; };
+#endif
+    double *const lvx = (double *)sm; sm += (size_t)cap_pn * 8;
+    double *const lvy = (double *)sm; sm += (size_t)cap_pn * 8;
+    double *const lvz = (double *)sm; sm += (size_t)cap_pn * 8;
+    double *const lvol = (double *)sm; sm += (size_t)cap_pe * 8;
+    double *const ltm = (double *)sm; sm += (size_t)cap_pe * 8;
+    double *const ldv = (double *)sm; sm += (size_t)cap_pe * 8;
+    double *const lm = (double *)sm; sm += CONSTM ? 0 : (size_t)cap_pe * 8;
+    double *const ltd = (double *)sm; sm += (size_t)cap_inc * 8;
+    unsigned short *const lidx = (unsigned short *)sm;
     // this launch covers the node blocks [b0, b0 + c0) and [b1, b1 + c1): all of them (0, nb, 0, 0), or -- overlapped
     // multi-GPU schedule -- first the blocks deep inside the slab, later the ones near its cuts (engine/launch.hpp)
     const int L = desk::logical_block(c0 + c1);
@@ -105,9 +139,22 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
         flag = bcflag[n];
     }
+#if DES_EN1_PREF
+    // this lane's list entries of EVERY round of the element phase, requested here -- ahead of the staging loads, with which
+    // they arrive (vmcnt is in order): the rounds then start without a trip to memory for the entry, and the marker words the
+    // entries point at are all requested at once behind the barrier (one exposed trip for the whole phase instead of two per round)
+    constexpr int PREF = DES_EN1_PREF;
+    ulonglong2 pk[PREF];
+#pragma unroll
+    for (int r = 0; r < PREF; ++r) {
+        const int i = e_begin + (int)threadIdx.x + r * THREADS;
+        pk[r] = make_ulonglong2(0, 0);
+        if (i < e_end) pk[r] = pe_pack[i];
+    }
+#endif
     // the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     // (every record of the patch is requested before anything waits: the surface nodes, which need more, come after)
-    constexpr int ROUNDS = (PN + THREADS - 1) / THREADS;
+    constexpr int ROUNDS = DES_PATCH_PN / THREADS;          // (cap_pn <= DES_PATCH_PN = 512)
     int2 tf[ROUNDS];
     int ids[ROUNDS];
     const bool blk_top = sp.tfan && sp.pb_top[lb];
@@ -120,7 +167,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
             const int raw = j < nown ? n0 + j : pn_id[h0 + j - nown];
             const int id = raw & 0x7fffffff;
             ids[r] = id;
-            lxt[j] = xt[id];
+            lput(j, xt[id]);
             const d4 v = vm[id];
             lvx[j] = v.x; lvy[j] = v.y; lvz[j] = v.z;
             if (blk_top && (j < nown || raw < 0)) tf[r] = sp.tfan[id];
@@ -136,26 +183,36 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
             // (dt: the step before ran with it too -- a step with a compute_dt keeps its own S2 / S3 launches)
             const double dhacc_old = j < nown ? sp.dhacc[id] : 0.0;
             const double d = s2_node_dh_range<DES_EN1_S2_BATCH>(id, tf[r].y, tf[r].y + nf, sp.ssup_nodes, xt, p->surface_diffusivity, dt);
-            lxt[j].z = lxt[j].z + d;                    // (this lane staged the record itself)
+            laddz(j, d);                                // (this lane staged the record itself)
             if (j < nown) { sp.dh[ti] = d; sp.dhacc[id] = dhacc_old + d; sp.dh_n[id] = d; }
         }
     }
+#if DES_EN1_PREF
+    // (the marker words: requested in front of the barrier, on their way while the wavefronts meet)
+    int mo[PREF];
+#pragma unroll
+    for (int r = 0; r < PREF; ++r) {
+        const int i = e_begin + (int)threadIdx.x + r * THREADS;
+        mo[r] = 0;
+        if (i < e_end) mo[r] = md.mono[(int)(pk[r].x & 0x3fffffffull)];
+    }
+#endif
     __syncthreads();
     DES_STAMP0(0, 1);
     // the patch's elements: E1's element terms, recomputed
-    for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) {
-        const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
+    auto do_elem = [&](const int i, const ulonglong2 pkr, const int mono_pre, const bool have_mono) {
+        const PatchElem PE_ = patch_elem_unpack(pkr);
         const int e = PE_.ew & 0x3fffffff;
         const ushort4 ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
         const short4 sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
         const int q = i - e_begin;                          // position in the patch
         d4 c[4], v[4];
-        c[0] = lxt[ln.x]; c[1] = lxt[ln.y]; c[2] = lxt[ln.z]; c[3] = lxt[ln.w];
+        c[0] = lget(ln.x); c[1] = lget(ln.y); c[2] = lget(ln.z); c[3] = lget(ln.w);
         v[0].x = lvx[ln.x]; v[0].y = lvy[ln.x]; v[0].z = lvz[ln.x]; v[0].w = 0;
         v[1].x = lvx[ln.y]; v[1].y = lvy[ln.y]; v[1].z = lvz[ln.y]; v[1].w = 0;
         v[2].x = lvx[ln.z]; v[2].y = lvy[ln.z]; v[2].z = lvz[ln.z]; v[2].w = 0;
         v[3].x = lvx[ln.w]; v[3].y = lvy[ln.w]; v[3].z = lvz[ln.w]; v[3].w = 0;
-        const desk::Mix mx = mix_of(md, nmat, e);
+        const desk::Mix mx = have_mono ? mix_from_mono(md, nmat, e, mono_pre) : mix_of(md, nmat, e);
         const ElemProps pr = load_props(p, md, mx, ne, e);
         double T = 0;
         T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
@@ -178,7 +235,17 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         if (sl.y >= 0) { ltd[sl.y] = tr[1]; lidx[sl.y] = (unsigned short)q; }
         if (sl.z >= 0) { ltd[sl.z] = tr[2]; lidx[sl.z] = (unsigned short)q; }
         if (sl.w >= 0) { ltd[sl.w] = tr[3]; lidx[sl.w] = (unsigned short)q; }
+    };
+#if DES_EN1_PREF
+#pragma unroll
+    for (int r = 0; r < PREF; ++r) {
+        const int i = e_begin + (int)threadIdx.x + r * THREADS;
+        if (i < e_end) do_elem(i, pk[r], mo[r], true);
     }
+    for (int i = e_begin + (int)threadIdx.x + PREF * THREADS; i < e_end; i += THREADS) do_elem(i, pe_pack[i], 0, false);
+#else
+    for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) do_elem(i, pe_pack[i], 0, false);
+#endif
     DES_STAMP0(0, 2);                                       // (this wavefront's own elements done)
     __syncthreads();
     DES_STAMP0(0, 3);
@@ -242,7 +309,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
                 for (; k < r1; ++k) { tms += ltm[lidx[k]]; tdot += ltd[k]; }
             }
             tmass[n] = tms;
-            d4 x4 = lxt[nl];
+            d4 x4 = lget(nl);
             if (thermal) {
                 if (flag & (1u << 5))
                     x4.w = p->surface_temperature;
@@ -297,7 +364,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     d4 m4;                                                   // the velocity is the staged one (own node: local id = lane)
     m4.x = lvx[threadIdx.x]; m4.y = lvy[threadIdx.x]; m4.z = lvz[threadIdx.x]; m4.w = ms;
     vm[n] = m4;
-    d4 x4 = lxt[threadIdx.x];
+    d4 x4 = lget(threadIdx.x);
     if (thermal) {
         if (flag & (1u << 5))
             x4.w = p->surface_temperature;

@@ -295,12 +295,13 @@ def run_distributed(host, dist, engine_factory=None, stepper=None, quiet=True):
     two_d = int(host.params.ndims) == 2
     # RCCL wants one device per rank: several 2-D ranks on ONE GPU (tests, rehearsals; DES_2D_TRANSPORT=host) step in two
     # phases with the ghost records and the two small reductions moved by torch.distributed instead
+    callers_stepper = stepper is not None              # the caller moves the ghost state itself (tests: PhasedStepper over gloo)
     staged = two_d and stepper is None and os.environ.get("DES_2D_TRANSPORT", "rccl" if dist.get_backend() == "nccl" else "host") == "host"
     if staged:
         comm = TorchComm(dist, group=None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo"))
         stepper = lambda e, p: PhasedStepper(e, p, comm)
     ce = CollectiveEngine(host, dist, engine_factory, stepper)
-    if isinstance(ce.engine, DeviceEngine) and not staged:
+    if isinstance(ce.engine, DeviceEngine) and not staged and not callers_stepper:
         ce.engine.comm_init(dist, ce.rank, ce.world)
     api = collective_api(ce)
     return driver.run(host, quiet=quiet or ce.rank != 0, api=api)
@@ -324,12 +325,21 @@ def run_distributed_with_remesher(make_host, remesher, dist, engine_factory=None
         stats.append(st)
         if not st.remesh_needed:
             return stats
+        # rank 0 remeshes; EVERY rank then learns how that went (a bare barrier would leave the others waiting for the
+        # backend's timeout while rank 0 is long gone) and they all raise together
+        why = ""
         if dist.get_rank() == 0:
-            if callable(remesher):
-                remesher(model, st.last_frame)
-            else:
-                subprocess.check_call("%s %s %d" % (remesher, model, st.last_frame), shell=True)
-        dist.barrier()
+            try:
+                if callable(remesher):
+                    remesher(model, st.last_frame)
+                else:
+                    subprocess.check_call("%s %s %d" % (remesher, model, st.last_frame), shell=True)
+            except Exception as e:          # noqa: BLE001 -- whatever the tool raised is reported on every rank
+                why = "%s: %s" % (type(e).__name__, e)
+        box = [why]
+        dist.broadcast_object_list(box, src=0)
+        if box[0]:
+            raise DesError(21, "the remesher failed on rank 0 for %s frame %d (%s)" % (model, st.last_frame, box[0]))
         overrides = ("sim.is_restarting = yes\nsim.restarting_from_modelname = %s\nsim.restarting_from_frame = %d\n"
                      % (model, st.last_frame + 1))
     raise DesError(31, "the mesh needed remeshing more than %d times" % max_rounds)

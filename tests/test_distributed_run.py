@@ -154,6 +154,37 @@ def _worker_remesh(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_remesh_fails(rank, world, port, out_dir):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    from dynearthsol_amd.decomp import PhasedStepper, TorchComm
+    from dynearthsol_amd.distributed import run_distributed_with_remesher
+    from oracle_binding import OracleEngine
+    from test_decomp_cpu import _LocalMeshHost
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mesh = os.path.join(here, "golden", "test-3d.desmesh")
+    comm = TorchComm(dist)
+    make_host = lambda extra: des.Host(cfg_text=_remesh_text(), overrides=REMESH_OV + (extra or ""), mesh_file=None if extra else mesh)
+    try:
+        run_distributed_with_remesher(make_host, "false", dist, engine_factory=lambda part: OracleEngine(_LocalMeshHost(part)),
+                                      stepper=lambda e, p: PhasedStepper(e, p, comm))
+        raise AssertionError("rank %d: a failed remesher went unnoticed" % rank)
+    except des.DesError as e:
+        # EVERY rank learns of rank 0's failure at once (no rank left in a barrier until the backend's timeout)
+        assert e.code == 21 and "remesher failed on rank 0" in str(e) and "CalledProcessError" in str(e), str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_remesher_ends_every_rank_with_the_reason(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_remesh_fails, args=(2, 32900 + os.getpid() % 500, str(tmp_path)), nprocs=2, join=True)
+
+
 def test_remeshing_round_trip_on_two_ranks_with_a_changing_element_count(tmp_path):
     """benchmarks-cores/test-3d-remesh.cfg's situation (a displaced bottom node trips bad_mesh_quality at step 300) on two
     ranks: rank 0 runs tools/remesh_tool.py -- the reference's TetGen on the deformed box + nearest-neighbour remap, 13,850 ->

@@ -258,7 +258,7 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
 
 
 @pytest.mark.parametrize("knob", ["DES2D_PATCH=0", "DES2D_PATCH=64", "DES2D_PATCH=40", "DES2D_CLUSTER=0", "DES2D_GEO=0", "DES2D_ELIDE=0",
-                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0"])
+                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0", "DES2D_FOLD=0", "DES2D_CHAIN=0"])
 def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
     """The node-block patch passes (des_dev2d_patch.hpp: temperature + dvoldt, NMD + force, mass; the default) against the
     one-kernel-per-loop path (DES2D_PATCH=0), other block sizes and groupings, and with the end-of-step pass / the store
@@ -274,7 +274,10 @@ def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
         for _ in range(3):
             sd, so = dev.step(23), other.step(23)
             ora.step(23)
-            assert (sd.dt, sd.time, sd.steps, sd.l2_residual, sd.max_surf_vel) == (so.dt, so.time, so.steps, so.l2_residual, so.max_surf_vel)
+            assert (sd.dt, sd.time, sd.steps, sd.max_surf_vel) == (so.dt, so.time, so.steps, so.max_surf_vel)
+            # (the per-step residual is the by-product of the force pass: summed per patch block since round 5 -- k2p_force<1> --,
+            #  per 256 node ids by the plain kernels; the terms are the same bits, the association is the grouping's)
+            assert abs(sd.l2_residual - so.l2_residual) <= 1e-12 * so.l2_residual
             assert_bit_exact(dev, other)
             assert_bit_exact(dev, ora)
 

@@ -314,6 +314,9 @@ def test_2d_pseudo_transient_loop_on_a_cut_mesh():
                 else:
                     for s in group.step(n):
                         assert (s.dt, s.steps, s.n_pt_iterations) == (sref.dt, sref.steps, sref.n_pt_iterations)
+                        # the step ends in the loop's residual: the GLOBAL block sum, the same bits on every engine -- not
+                        # added across the engines once more (it used to come back sqrt(3) too large here)
+                        assert s.l2_residual == sref.l2_residual
                 for f, c in NODE_FIELDS:
                     assert np.array_equal(group.download(f, c, "node"), ref.download(f)), f
                 for f, c in ELEM_FIELDS:

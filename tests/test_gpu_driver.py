@@ -192,3 +192,95 @@ def test_executable_takes_a_remesher_command(in_tmp):
     assert "Remeshing:" in out.stdout and "bottom_flattener" in out.stdout and out.stdout.count("Ending simulation.") == 1
     info = np.loadtxt("exe.info").reshape(-1, 8)
     assert info[-1, 1] == 700 and len(info) == 10
+
+
+# ---- the remeshing round trip with a mesh whose node and element counts CHANGE, on the device (SURVEY.md 8 f4) -----------------
+# tools/remesh_tool.py (a test tool: the reference's TetGen on the deformed box + nearest-neighbour remap, 13,850 -> ~7,700 tets)
+# as the remesher: the restart runs on a NEW engine -- new allocations, new internal order, new patch lists and LDS sizes, new
+# residual blocks -- which is where an allocation or patch-list bug of a changing mesh would sit.
+def _remesh_pieces():
+    import sys
+    from test_distributed_run import REMESH_TOOL, REMESH_OV, _remesh_text
+    if not os.access(os.path.join(des.REPO_ROOT, "oracle", "_ref", "tetmesh"), os.X_OK):
+        pytest.skip("oracle/_ref/tetmesh is missing (make -C oracle ref)")
+    mesh = os.path.join(des.REPO_ROOT, "tests", "golden", "test-3d.desmesh")
+    cmd = "%s %s --resolution 1500" % (sys.executable, REMESH_TOOL)
+    return _remesh_text(), REMESH_OV, mesh, cmd
+
+
+def test_remeshing_round_trip_with_a_changing_element_count_on_the_device(in_tmp):
+    text, ov, mesh, cmd = _remesh_pieces()
+    make_host = lambda extra: des.Host(cfg_text=text, overrides=ov.replace("rtd", "gpu") + (extra or ""), mesh_file=None if extra else mesh)
+    stats = driver.run_with_remesher(make_host, cmd)
+    assert [(s.steps, s.remesh_needed, s.exit_code) for s in stats] == [(300, 2, 31), (400, 0, 0)]
+    info = np.loadtxt("gpu.info").reshape(-1, 8)
+    assert info[:, 1].tolist() == [0, 100, 200, 300, 300, 300, 400]
+    assert info[4, 5:7].tolist() == [3018, 13850] and info[5, 6] != 13850 and info[5, 6] > 5000           # another mesh, another size
+    ne = int(info[5, 6])
+    # up to the remesh: the oracle loop writes the same frames (and stops for the same reason)
+    st = driver.run(des.Host(cfg_text=text, overrides=ov.replace("rtd", "cpu"), mesh_file=mesh), api=oracle_api())
+    assert (st.steps, st.remesh_needed) == (300, 2)
+    for frame in range(5):
+        a, b = read_frame("gpu.save.%06d" % frame), read_frame("cpu.save.%06d" % frame)
+        for name in a:
+            if name != "walltime_sec":
+                assert np.array_equal(a[name], b[name]), (frame, name)
+    # after it: the oracle loop restarted from the SAME pair (the one the device run's remesher left) takes the same 100 steps
+    host = des.Host(cfg_text=text, overrides=ov.replace("rtd", "cpr")
+                    + "sim.is_restarting = yes\nsim.restarting_from_modelname = gpu\nsim.restarting_from_frame = 5\n")
+    assert host.nelem == ne
+    st = driver.run(host, api=oracle_api())
+    assert (st.steps, st.exit_code) == (400, 0)
+    a, b = read_frame("gpu.save.000006"), read_frame("cpr.save.000006")
+    for name in a:
+        if name != "walltime_sec":
+            assert np.array_equal(a[name], b[name]), name
+
+
+def _worker_remesh_device(rank, world, port, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    from dynearthsol_amd.decomp import PhasedStepper, TorchComm
+    from dynearthsol_amd.distributed import run_distributed_with_remesher
+    from test_distributed_run import REMESH_TOOL, REMESH_OV, _remesh_text
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.chdir(out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mesh = os.path.join(here, "golden", "test-3d.desmesh")
+    comm = TorchComm(dist)
+    make_host = lambda extra: des.Host(cfg_text=_remesh_text(), overrides=REMESH_OV + (extra or ""), mesh_file=None if extra else mesh)
+    # one DEVICE engine per rank, both on this box's one GPU (RCCL refuses that: the two-phase step, ghost state over gloo)
+    stats = run_distributed_with_remesher(make_host, "%s %s --resolution 1500" % (sys.executable, REMESH_TOOL), dist,
+                                          engine_factory=lambda part: des.DeviceEngine(part, device=0),
+                                          stepper=lambda e, p: PhasedStepper(e, p, comm))
+    assert [(s.steps, s.remesh_needed, s.exit_code) for s in stats] == [(300, 2, 31), (400, 0, 0)]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_remeshing_round_trip_on_two_device_ranks(tmp_path):
+    """... and on a decomposed mesh: two device engines (two processes on the one GPU), rank 0 remeshes, both restart on a new
+    PARTITION of the new mesh -- new slabs, ghost regions, patch lists, residual blocks on the device; the 100 steps after the
+    remesh equal those of ONE device engine restarted from the same pair, bit for bit."""
+    import torch.multiprocessing as mp
+    _remesh_pieces()
+    from test_distributed_run import REMESH_OV, _remesh_text
+    mp.spawn(_worker_remesh_device, args=(2, 33400 + os.getpid() % 500, str(tmp_path)), nprocs=2, join=True)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        info = np.loadtxt("rtd.info").reshape(-1, 8)
+        assert info[:, 1].tolist() == [0, 100, 200, 300, 300, 300, 400] and info[5, 6] != 13850
+        host = des.Host(cfg_text=_remesh_text(), overrides=REMESH_OV.replace("rtd", "rts")
+                        + "sim.is_restarting = yes\nsim.restarting_from_modelname = rtd\nsim.restarting_from_frame = 5\n")
+        assert host.nelem == int(info[5, 6])
+        st = driver.run(host)
+        assert (st.steps, st.exit_code) == (400, 0)
+        a, b = read_frame("rtd.save.000006"), read_frame("rts.save.000006")
+        for k in ("coordinate", "velocity", "temperature", "stress", "strain", "plastic strain"):
+            assert np.array_equal(a[k], b[k]), k
+    finally:
+        os.chdir(cwd)

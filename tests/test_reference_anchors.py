@@ -55,6 +55,34 @@ def test_elasto_visco_plastic_variant_anchor_after_300_steps():
     assert observe(o)[:3] == ("1.312445e-09", "-2.644199e+08", "6.240221e+13")
 
 
+def test_blocked_residual_sum_against_the_references_serial_association():
+    """The ONE place where the oracle follows the device instead of the reference's loop (deviations):
+    calculate_residual_force (fields.cxx:700-722) is `l2 += pow(force_residual[i][j], 2) / num` over i, j -- one running sum
+    when the reference's regression runs execute it on one thread, an OpenMP reduction of open order otherwise.  Oracle and
+    engine sum per block of 64 consecutive global node ids, then 256 strided sums and a pairwise tree over the blocks
+    (oracle/des_oracle.cpp: residual_blocks_local / residual_final), so that a decomposed run takes the pseudo-transient
+    loop's decision a single engine takes.  Both are sums of the same nn * NDIMS non-negative terms: they may differ by
+    rounding only, at most (nn * NDIMS - 1) eps relative (every partial sum of non-negative terms is within that of the exact
+    one) -- in practice a few ulp.  Held here on the test-3d.cfg state after 200 steps, next to the recorded anchor."""
+    h = des.Host(cfg_text=cfgs.TEST3D, mesh_file=MESH)
+    o = OracleEngine(h)
+    o.init_from_host(h)
+    o.step(200)
+    fr = o.download("FORCE_RESIDUAL").reshape(3, -1)
+    nn = fr.shape[1]
+    num = float(nn * 3)                                  # double num = var.nnode * NDIMS
+    l2 = 0.0
+    for i in range(nn):                                  # the reference's loop order: i outer, j inner (fields.cxx:711-713)
+        for j in range(3):
+            l2 += float(fr[j, i]) ** 2 / num             # (x ** 2 is x * x in CPython and in glibc's pow(x, 2): exact to the bit)
+    serial = float(np.sqrt(l2))
+    blocked = o.step(0).l2_residual
+    assert fmt(serial) == "6.289321e+13" == fmt(blocked)                    # SURVEY Appendix A's recorded digits, both ways
+    eps = np.finfo(float).eps
+    assert abs(blocked - serial) <= nn * 3 * eps * serial
+    assert abs(blocked - serial) <= 8 * eps * serial, (blocked, serial)     # what it is in practice
+
+
 @pytest.mark.gpu
 def test_device_reproduces_the_reference_anchors_and_the_oracle_bits():
     """The same 1000 steps on the MI355X: every field bit-identical to the oracle (no element
