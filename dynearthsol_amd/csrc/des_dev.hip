@@ -162,7 +162,6 @@ struct des_dev {
            *volume_old, *dpressure, *radiogenic;
     int *markers;
     int *defer_list;                      // [ne] elements set aside by the first stress pass of the step
-    unsigned *e2_tile_ctr;                // [8] the pipelined stress update's tile counters, one per XCD share (DES_E2_DYN builds; self-resetting)
     bool use_graph;                       // DES_GRAPH=1
     hipGraphExec_t graph_exec[2];
     bool graph_two_pass[2];
@@ -563,7 +562,6 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
     CK(dev_alloc(h->radiogenic, (size_t)ne)); CK(dev_alloc(h->markers, (size_t)ne * nmat));
     CK(dev_alloc(h->mono, (size_t)ne));
     CK(dev_alloc(h->defer_list, (size_t)ne));
-    CK(dev_alloc(h->e2_tile_ctr, 8)); HK(hipMemsetAsync(h->e2_tile_ctr, 0, 8 * sizeof(unsigned), h->stream));
     {
         // deferred rotate_stress (MODE_DEFER, passes/e1.hpp): on by default, DES_DEFER_ROT=0 keeps rotate_stress in E1
         const char *el = des_env::get("DES_E2_ELIDE");      // =0: every step stores every field

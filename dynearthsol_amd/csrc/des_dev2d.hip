@@ -89,12 +89,12 @@ struct Engine {
     double *neg_zmin = nullptr;        // scratch of k2_vbc_zmin
     // node-block patch passes (des_dev2d_patch.hpp); DES2D_PATCH=0 or a mesh outside their LDS caps: the plain kernels
     bool patch = false, res_fin_pending = false, tick_pending = false;
-    bool chain_on = true, surface_chained = false;   // DES2D_CHAIN: the surface step as one single-workgroup launch (k2_surface_chain)
     // DES2D_FOLD (round 5): a plain step's stress bcs, damping / velocity / vbcs / coordinates and residual partials inside
     // k2p_force's node phase (k2p_force<1>); fold_ok: this model's boundary loads can all be formed per node (create)
     bool fold_on = true, fold_ok = false;
     double *coord_alt = nullptr;                // the other buffer of the coordinate pair (k2p_force<1> writes the moved nodes there)
     int *sbcn_idx = nullptr; int4 *sbcn_ent = nullptr;      // per node: its boundary-facet incidences {element, facet, which node, boundary}
+    double2 *xz_pre = nullptr; int *fold_top_pos = nullptr; bool xz_pre_valid = false;   // k2p_force<1>: the moved top nodes, in top_nodes order (k2_surf_commit)
     int res_count = 0;                          // partials in res_part[] (blocks of 256 owned nodes, or the patch blocks)
     bool geo_on = true, elide_on = true;       // DES2D_GEO / DES2D_ELIDE != 0 (read at create)
     bool elide = false;                        // this step's output-only element stores can go (a later step of the same call rewrites them)
@@ -938,15 +938,14 @@ __global__ void k2_neumann(const des_params *p, int ib, int bound, const int *bf
     }
 }
 
-// apply_damping (fields.cxx:483-579) + update_velocity (fields.cxx:725-742) of a node
-__device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *clk, int i, int nn, const double *mass,
-                                              const double *ymass, double *force, double *vel)
+// apply_damping (fields.cxx:483-579) + update_velocity (fields.cxx:725-742) of a node, on values the caller holds:
+// f[] in: the force sums, out: the damped force; v[] in / out: the velocity
+__device__ __forceinline__ void damp_vel_regs(const des_params *p, double dt, double mass_i, double ymass_i, double f_io[2], double v_io[2])
 {
     const double small_vel = 1e-13;
-    const double dt = clk->dt;
     for (int j = 0; j < 2; j++) {
-        double f = force[j*nn + i];
-        const double v = vel[j*nn + i];
+        double f = f_io[j];
+        const double v = v_io[j];
         switch (p->damping_option) {
         case 1:
             if (fabs(v) > small_vel) f -= p->damping_factor * copysign(f, v);
@@ -960,7 +959,7 @@ __device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *
             break;
         case 4:
             if (fabs(v) > small_vel) {
-                double critical_coeff = 2.0 * sqrt(mass[i] * ymass[i]);
+                double critical_coeff = 2.0 * sqrt(mass_i * ymass_i);
                 double f_C = p->damping_factor * copysign(f, v);
                 double f_V = critical_coeff * v;
                 double f_damping = (fabs(f_C) < fabs(f_V)) ? f_V : f_C;
@@ -969,9 +968,18 @@ __device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *
             break;
         default: break;
         }
-        force[j*nn + i] = f;
-        vel[j*nn + i] = v + dt * f / mass[i];
+        f_io[j] = f;
+        v_io[j] = v + dt * f / mass_i;
     }
+}
+
+// ... and on the node's entries of the global arrays (ymass is only read by damping option 4)
+__device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *clk, int i, int nn, const double *mass,
+                                              const double *ymass, double *force, double *vel)
+{
+    double f[2] = {force[i], force[nn + i]}, v[2] = {vel[i], vel[nn + i]};
+    damp_vel_regs(p, clk->dt, mass[i], p->damping_option == 4 ? ymass[i] : 0.0, f, v);
+    for (int j = 0; j < 2; j++) { force[j*nn + i] = f[j]; vel[j*nn + i] = v[j]; }
 }
 
 __global__ void k2_damp_vel(const des_params *p, const Clock *clk, int nn, const double *mass, const double *ymass,
@@ -1053,7 +1061,7 @@ k2_residual_final(Clock *clk, const double *blocks, int nb)
 // its nodes.  min / max: exact whatever the order.  One workgroup.
 // (tick: the step counter and the model time move on here, k2_clock's two statements -- the patch path's plain step, where
 //  nothing before this launch reads them)
-__global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double *coord, Clock *clk, int tick = 0)
+__device__ __forceinline__ void vbc_extent_block(int nb, const int *bnodes_x0, int nn, const double *coord, Clock *clk, int tick)
 {
     __shared__ double s_max[DES_BLOCK / 64], s_min[DES_BLOCK / 64];
     double mx = -DBL_MAX, mn = DBL_MAX;
@@ -1072,6 +1080,24 @@ __global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double
         clk->zmin = 0;                       // k2_vbc_zmin lowers it when the sheared bottom zone needs it
         if (tick) { clk->steps++; clk->time += clk->dt; }
     }
+}
+
+__global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double *coord, Clock *clk, int tick = 0)
+{
+    vbc_extent_block(nb, bnodes_x0, nn, coord, clk, tick);
+}
+
+// NMD_stress' nodal average with the wall's extent as one extra workgroup (round 5: the plain step of the patch path, where the
+// extent -- and with it the step's count -- only has to be in the clock before the force pass's node phase)
+__global__ void k2_node_avg_extent(int nn, int nb_avg, const int *sup_idx, const int *sup_arr, const double *etmp, const double *volume_n, double *ntmp,
+                                   int nb, const int *bnodes_x0, const double *coord, Clock *clk, int tick)
+{
+    if ((int)blockIdx.x >= nb_avg) { vbc_extent_block(nb, bnodes_x0, nn, coord, clk, tick); return; }
+    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (n >= nn) return;
+    double acc = 0.;
+    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) acc += etmp[sup_arr[k]];
+    ntmp[n] = acc / volume_n[n];
 }
 
 // ... and the lowest node of the mesh, zmin = min(0, min z) (bc.cxx:350-361): read only by vbc_x0 = 3 with a
@@ -1093,11 +1119,10 @@ __global__ void k2_vbc_zmin(int nn, const double *coord, double *neg_zmin)
 __global__ void k2_vbc_zmin_fin(Clock *clk, double *neg_zmin) { clk->zmin = -(*neg_zmin); *neg_zmin = 0.0; }
 
 // apply_vbcs (bc.cxx:227-659, !THREED) of a node; Clock::pt = PT_jump: boundaries at rest (bc.cxx:330-343)
-__device__ __forceinline__ void vbcs_node(const des_params *p, const Clock *clk, int i, int nn, const unsigned *bcflag,
-                                          const double *bnormals, const double *edge_vec, const int *edge_slot,
-                                          const double *coord, double *vel)
+// (register form: flag = bcflag of the node, x1 = its z BEFORE it moves, v[] = its velocity in / out)
+__device__ __forceinline__ void vbcs_regs(const des_params *p, const Clock *clk, const unsigned flag, const double x1,
+                                          const double *bnormals, const double *edge_vec, const int *edge_slot, double v[2])
 {
-    const unsigned flag = bcflag[i];
     if (!(flag & BOUND_ANY)) return;
 
     double t_now = clk->time / DES2_YEAR2SEC;
@@ -1122,8 +1147,6 @@ __device__ __forceinline__ void vbcs_node(const des_params *p, const Clock *clk,
     if (clk->time > p->vbc_val_z1_loading_period) bc_z1 = 0;
     const double zmin = clk->zmin;
 
-    double v[2] = {vel[i], vel[nn + i]};
-    const double x1 = coord[nn + i];
     double vbc_exact_x0 = vbc_applied_x0 * interp1(div_x0, p->vbc_vertical_ratio_x0, 4, -x1);
     double vbc_exact_x1 = vbc_applied_x1 * interp1(div_x1, p->vbc_vertical_ratio_x1, 4, -x1);
 
@@ -1225,6 +1248,16 @@ __device__ __forceinline__ void vbcs_node(const des_params *p, const Clock *clk,
             }
         }
     }
+}
+
+__device__ __forceinline__ void vbcs_node(const des_params *p, const Clock *clk, int i, int nn, const unsigned *bcflag,
+                                          const double *bnormals, const double *edge_vec, const int *edge_slot,
+                                          const double *coord, double *vel)
+{
+    const unsigned flag = bcflag[i];
+    if (!(flag & BOUND_ANY)) return;
+    double v[2] = {vel[i], vel[nn + i]};
+    vbcs_regs(p, clk, flag, coord[nn + i], bnormals, edge_vec, edge_slot, v);
     vel[i] = v[0]; vel[nn + i] = v[1];
 }
 
@@ -1312,6 +1345,42 @@ __global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, in
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (i < ntop) surf_node_at(i, p, clk, ntop, nn, ne, top_nodes, etmp, tmp_result, total_dx, total_slope, coord, dhacc, dh);
+}
+
+// Round 5: segments + nodes of simple_diffusion in ONE launch (the plain step of the patch path with the nodal tail folded
+// into the force pass).  A node needs the two segments it sits between; each is a function of its two end nodes alone, so the
+// node's lane forms both itself -- surf_seg_at's expressions -- instead of a launch of its own writing them first.  What
+// stood in the way was the update in place: a lane moves its node's z while its neighbours' lanes still want the old one.
+// k2p_force<1> therefore leaves the moved {x, z} of every top node in a compact array in top_nodes order as well (xz_pre:
+// the coordinates update_coordinate left, before the surface step), which is all this kernel reads of other nodes.
+// The last workgroup forms calculate_residual_force's final sum (as in k2_surf_seg_resfin).
+__global__ void k2_surf_commit(const des_params *p, Clock *clk, int ntop, int nn, const int *top_nodes, const double2 *xz_pre,
+                               double *total_dx, double *total_slope, double *coord, double *dhacc, double *dh,
+                               int nb_node, int res_nb, const double *res_part)
+{
+    if ((int)blockIdx.x >= nb_node) { residual_fin_block(res_nb, res_part, clk); return; }
+    const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
+    if (i >= ntop) return;
+    const int n = top_nodes[i];
+    const double2 c = xz_pre[i];
+    // the segment to the left (i - 1 .. i) and to the right (i .. i + 1): dx, and the two slope terms surf_seg_at stores
+    double dxl = 0, sl1 = 0, dxr = 0, sr0 = 0;
+    if (i > 0) { const double2 a = xz_pre[i - 1]; dxl = fabs(c.x - a.x); sl1 = (c.y - a.y) / dxl; }
+    if (i < ntop - 1) { const double2 b = xz_pre[i + 1]; dxr = fabs(b.x - c.x); sr0 = -(b.y - c.y) / dxr; }
+    double tdx, tsl;
+    if (i == 0) { tdx = dxr; tsl = sr0; }
+    else if (i == ntop-1) { tdx = dxl; tsl = sl1; }
+    else { tdx = dxl + dxr; tsl = sl1 + sr0; }
+    total_dx[n] = tdx; total_slope[n] = tsl;
+    double d = 0.;
+    double conv = p->surface_diffusivity * clk->dt * tsl / tdx;
+    const double z = c.y;
+    if (z > p->surf_base_level && conv > 0.) d -= p->surf_diff_ratio_terrig * conv;
+    else if (z <= p->surf_base_level && conv < 0.) d -= p->surf_diff_ratio_marine * conv;
+    else d -= conv;
+    dh[i] = d;
+    coord[nn + n] = z + d;
+    dhacc[n] += d;
 }
 
 // edvacc_surf (bc.cxx:1788-1805)
@@ -1437,6 +1506,51 @@ __global__ void k2_surf_edv_cse_elem(const des_params *p, const Clock *clk, int 
     if (i < ntop_elems) cse_elem_at(i, p, clk, ntop_elems, top_elems, nn, ne, conn, coord, markers, decay, volume, plstrain, stress, strain, strain_rate);
 }
 
+// correct_surface_element's nodal part WITHOUT waiting for its element part: every element of a top node's support list is a
+// top element (create_top_elems), whose volume the element part has just set to triangle_area of its moved nodes -- the same
+// expression on the same coordinates gives the same bits, so the node's lane forms the areas itself
+__device__ __forceinline__ void cse_node_areas_at(int i, int nn, int ne, const int *top_nodes, const int *sup_idx, const int *sup_arr,
+                                                  const int *conn, const double *coord, double *volume_n, int reset_dhacc, double *dhacc)
+{
+    const int nt = top_nodes[i];
+    double acc = 0.;
+    for (int k = sup_idx[nt]; k < sup_idx[nt+1]; ++k) {
+        double d[3][2];
+        elem_coords(coord, conn, nn, ne, sup_arr[k], d);
+        acc += triangle_area(d[0], d[1], d[2]);
+    }
+    volume_n[nt] = acc;
+    if (reset_dhacc) dhacc[nt] = 0.;                      // bc.cxx:1837-1838
+}
+
+// ... and with that edvacc_surf, both parts of correct_surface_element and the max |dh| reduction are ONE launch (round 5)
+__global__ void k2_surf_edv_cse_all(const des_params *p, Clock *clk, int etop, int ntop_elems, int ntop, int nb_edv, int nb_elem, int nb_node,
+                                    int nn, int ne, const int *ean, const int *conn_surf, const int *top_elems, const int *top_nodes,
+                                    const int *conn, const int *markers, const int *sup_idx, const int *sup_arr, int decay, int reset_dhacc,
+                                    int o0, int o1, const double *coord, const double *dh, double *edvacc, double *volume, double *volume_n,
+                                    double *dhacc, double *plstrain, double *stress, double *strain, double *strain_rate)
+{
+    int b = (int)blockIdx.x;
+    if (b < nb_edv) {
+        const int i = b * DES_BLOCK + threadIdx.x;
+        if (i < etop) surf_edv_at(i, etop, nn, ean, conn_surf, coord, dh, edvacc);
+        return;
+    }
+    b -= nb_edv;
+    if (b < nb_elem) {
+        const int i = b * DES_BLOCK + threadIdx.x;
+        if (i < ntop_elems) cse_elem_at(i, p, clk, ntop_elems, top_elems, nn, ne, conn, coord, markers, decay, volume, plstrain, stress, strain, strain_rate);
+        return;
+    }
+    b -= nb_elem;
+    if (b < nb_node) {
+        const int i = b * DES_BLOCK + threadIdx.x;
+        if (i < ntop) cse_node_areas_at(i, nn, ne, top_nodes, sup_idx, sup_arr, conn, coord, volume_n, reset_dhacc, dhacc);
+        return;
+    }
+    surf_maxdh_block(ntop, top_nodes, o0, o1, dh, clk);
+}
+
 __global__ void k2_cse_node_maxdh(int ntop, int nb_node, const int *top_nodes, const int *sup_idx, const int *sup_arr, const double *volume,
                                   double *volume_n, int reset_dhacc, double *dhacc, int o0, int o1, const double *dh, Clock *clk)
 {
@@ -1445,64 +1559,10 @@ __global__ void k2_cse_node_maxdh(int ntop, int nb_node, const int *top_nodes, c
     if (i < ntop) cse_node_at(i, ntop, top_nodes, sup_idx, sup_arr, volume, volume_n, reset_dhacc, dhacc);
 }
 
-// Round 5: the whole surface step of a plain step in ONE launch of ONE workgroup.  A 2-D model's surface is a line -- a few
-// thousand nodes on the largest meshes -- and its four dependent loops (segments -> nodes -> edvacc_surf / correct_surface_element
-// -> nodal volumes / max |dh|) cost four launches of ~5 us each for a few hundred nanoseconds of work (profiles/r04_v_kernel_stats_2d:
-// 26 us of a 288-us step).  Here the workgroup walks the loops one after the other with a barrier in between (what a loop
-// writes, the next reads through the same CU's cache); the residual's final sum rides along as before.  Same statements, same
-// order per item: same bits.  Not on a decomposed mesh (the ghost exchange falls between the second and the third loop).
-#define DES2_CHAIN_THREADS 1024
-__global__ void __launch_bounds__(DES2_CHAIN_THREADS)
-k2_surface_chain(const des_params *p, Clock *clk, int etop, int ntop, int ntop_elems, int nn, int ne, const int *top_nodes, const int *ean,
-                 const int *conn_surf, const int *top_elems, const int *conn, const int *markers, const int *sup_idx, const int *sup_arr,
-                 int decay, int reset_dhacc, int o0, int o1, int res_nb, const double *res_part,
-                 double *coord, double *etmp, double *tmp_result, double *total_dx, double *total_slope, double *dhacc, double *dh,
-                 double *edvacc, double *volume, double *volume_n, double *plstrain, double *stress, double *strain, double *strain_rate)
-{
-    const int T = DES2_CHAIN_THREADS, t = (int)threadIdx.x;
-    __shared__ double sm[DES_BLOCK / 64], smx[DES_BLOCK / 64];
-    // calculate_residual_force's final sum over the per-block partials: residual_fin_block's shape (256 lanes, the same tree)
-    if (res_nb > 0) {
-        if (t < DES_BLOCK) {
-            double v = 0;
-            for (int i = t; i < res_nb; i += DES_BLOCK) v += res_part[i];
-            v = desk::wave_sum(v);
-            if ((t & 63) == 0) sm[t >> 6] = v;
-        }
-        __syncthreads();
-        if (t == 0) { const double tt = (sm[0] + sm[1]) + (sm[2] + sm[3]); clk->l2_sum = tt; clk->l2_residual = sqrt(tt); clk->l2_global = 0; }
-    }
-    // simple_diffusion: segments, then nodes (bc.cxx:916-1112, 1773-1786)
-    if (p->surface_process_option == 1 && etop > 0) {
-        for (int i = t; i < etop; i += T) surf_seg_at(i, etop, nn, ne, top_nodes, coord, etmp, tmp_result);
-        __threadfence(); __syncthreads();
-    }
-    for (int i = t; i < ntop; i += T) surf_node_at(i, p, clk, ntop, nn, ne, top_nodes, etmp, tmp_result, total_dx, total_slope, coord, dhacc, dh);
-    __threadfence(); __syncthreads();
-    // edvacc_surf (bc.cxx:1788-1805) and correct_surface_element's element part (bc.cxx:1655-1707): independent of each other
-    for (int i = t; i < etop; i += T) surf_edv_at(i, etop, nn, ean, conn_surf, coord, dh, edvacc);
-    for (int i = t; i < ntop_elems; i += T)
-        cse_elem_at(i, p, clk, ntop_elems, top_elems, nn, ne, conn, coord, markers, decay, volume, plstrain, stress, strain, strain_rate);
-    __threadfence(); __syncthreads();
-    for (int i = t; i < ntop; i += T) cse_node_at(i, ntop, top_nodes, sup_idx, sup_arr, volume, volume_n, reset_dhacc, dhacc);
-    // max |dh| -> max_surf_vel (bc.cxx:1820-1836): surf_maxdh_block's shape (256 lanes)
-    if (t < DES_BLOCK) {
-        double m = 0.;
-        for (int i = t; i < ntop; i += DES_BLOCK) {
-            const int n = top_nodes[i];
-            if (n >= o0 && n < o1) m = fmax(m, fabs(dh[i]));
-        }
-        m = desk::wave_max(m);
-        if ((t & 63) == 0) smx[t >> 6] = m;
-    }
-    __syncthreads();
-    if (t == 0) {
-        for (int w = 1; w < DES_BLOCK / 64; ++w) smx[0] = fmax(smx[0], smx[w]);
-        clk->maxdh = smx[0];
-        clk->max_surf_vel = smx[0] / clk->dt;
-    }
-}
-
+// (Round 5, measured and dropped: the four dependent loops of the surface step -- segments, nodes, edvacc_surf /
+//  correct_surface_element, nodal volumes / max |dh| -- as ONE launch of ONE workgroup walking them with barriers in between: a 2-D
+//  surface is a line of a few thousand nodes.  130-140 us against 28 for the four launches (profiles/r05_f_*, r05_g_*): one CU
+//  has too little memory-level parallelism for chains of dependent loads, each thread walking its items one after the other.)
 // compute_volume (geometry.cxx:170-201) + the element part of compute_mass (geometry.cxx:1743-1870)
 __global__ void k2_volume_mass_elem(const des_params *p, int nn, int ne, const int *conn, const double *coord,
                                     const double *temperature, const double *props, const int *markers, int with_mass,
@@ -1970,26 +2030,19 @@ void launch_stress_bcs(Engine *h)
 
 // update_mesh (dynearthsol.cxx:448-493) after update_coordinate, in two parts: up to the committed surface heights
 // (where a decomposed mesh refreshes its ghost region) ...
-// the whole surface step as one single-workgroup launch (k2_surface_chain): the patch path of an engine that owns the whole
-// mesh (DES2D_CHAIN=0: the four launches)
-inline bool chain_ok(const Engine *h) { return h->chain_on && h->patch && !h->halo && h->ntop > 0; }
-
 void launch_surface_commit(Engine *h)
 {
     const des_params &p = h->p;
-    if (chain_ok(h)) {
-        const long long steps = h->steps_host;
-        const bool at_interval = steps % p.quality_check_step_interval == 0;
-        const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
-        hipLaunchKernelGGL(k2_surface_chain, dim3(1), dim3(DES2_CHAIN_THREADS), 0, h->stream, h->d_p, h->d_clk, h->etop, h->ntop, h->ntop_elems,
-                           h->nn, h->ne, h->top_nodes, h->ean, h->conn_surf, h->top_elems, h->conn, h->markers, h->sup_idx, h->sup_arr,
-                           decay, (steps != 0 && at_interval) ? 1 : 0, h->o0, h->o1, h->res_fin_pending ? h->res_count : 0, h->res_part,
-                           h->coord, h->etmp, h->tmp_result, h->total_dx, h->total_slope, h->dhacc, h->dh, h->edvacc, h->volume, h->volume_n,
-                           h->plstrain, h->stress, h->strain, h->strain_rate);
+    if (h->xz_pre_valid && p.surface_process_option == 1 && h->etop > 0 && h->ntop > 0) {
+        // (k2p_force<1> of this step left the moved top nodes in xz_pre: segments and nodes in one launch)
+        const int nbn = nblk(h->ntop);
+        hipLaunchKernelGGL(k2_surf_commit, dim3(nbn + (h->res_fin_pending ? 1 : 0)), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->ntop, h->nn,
+                           h->top_nodes, h->xz_pre, h->total_dx, h->total_slope, h->coord, h->dhacc, h->dh, nbn, h->res_count, h->res_part);
         h->res_fin_pending = false;
-        h->surface_chained = true;                         // launch_update_mesh_surface of this step has nothing left to do
+        h->xz_pre_valid = false;
         return;
     }
+    h->xz_pre_valid = false;
     if (h->res_fin_pending && p.surface_process_option == 1 && h->etop > 0) {
         const int nbs = nblk(h->etop);
         hipLaunchKernelGGL(k2_surf_seg_resfin, dim3(nbs + 1), dim3(DES_BLOCK), 0, h->stream, h->etop, h->nn, h->ne, h->top_nodes, h->coord,
@@ -2010,7 +2063,15 @@ void launch_update_mesh_surface(Engine *h, long long steps)
     const des_params &p = h->p;
     const bool at_interval = steps % p.quality_check_step_interval == 0;
     const int decay = !(steps % p.quality_check_step_interval && steps != 0) ? 1 : 0;     // bc.cxx:1848
-    if (h->surface_chained) { h->surface_chained = false; return; }         // (k2_surface_chain did it all)
+    if (h->patch && h->ntop > 0 && h->fold_on) {
+        // one launch: the nodal part forms the areas it sums itself (cse_node_areas_at)
+        const int nbe = nblk(h->etop), nbc = nblk(h->ntop_elems), nbn = nblk(h->ntop);
+        hipLaunchKernelGGL(k2_surf_edv_cse_all, dim3(nbe + nbc + nbn + 1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->etop, h->ntop_elems,
+                           h->ntop, nbe, nbc, nbn, h->nn, h->ne, h->ean, h->conn_surf, h->top_elems, h->top_nodes, h->conn, h->markers,
+                           h->sup_idx, h->sup_arr, decay, (steps != 0 && at_interval) ? 1 : 0, h->o0, h->o1, h->coord, h->dh, h->edvacc,
+                           h->volume, h->volume_n, h->dhacc, h->plstrain, h->stress, h->strain, h->strain_rate);
+        return;
+    }
     if (h->patch && h->ntop > 0) {
         const int nbe = nblk(h->etop), nbc = nblk(h->ntop_elems), nbn = nblk(h->ntop);
         if (nbe + nbc > 0)
@@ -2143,21 +2204,29 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             launch_stress<M>(h, true, s_law);
         }
         h->geo_pending = false; h->mass_pending = false;
-        if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
+        const bool fold = tail && fold_now(h);
+        // (the folded tail wants the wall's extent in the clock before the force pass: it rides in the nodal average's launch)
+        const bool avg_extent = fold && nmd && !wall_needs_zmin(h);
+        if (avg_extent) {
+            Prof2 pr(h, P2_NODEAVG);
+            hipLaunchKernelGGL(k2_node_avg_extent, dim3(nblk(nn) + 1), dim3(DES_BLOCK), 0, h->stream, nn, nblk(nn), h->sup_idx, h->sup_arr, h->etmp,
+                               h->volume_n, h->ntmp, h->nbn[iboundx0], h->bnodes[iboundx0], h->coord, h->d_clk, h->tick_pending ? 1 : 0);
+            h->tick_pending = false;
+        } else if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
         ForceTail ft = {h->d_clk, h->mass, h->ymass, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vel, h->coord_alt, h->conn,
-                        h->sbcn_idx, h->sbcn_ent, h->res_part, h->o0, h->o1, h->nn_global};
-        if (tail && fold_now(h)) {
+                        h->sbcn_idx, h->sbcn_ent, h->res_part, h->o0, h->o1, h->nn_global, h->fold_top_pos, h->xz_pre};
+        if (fold) {
             // Everything nodal behind the force sums rides in k2p_force<1>.  The wall's extent first (the coordinates have not
             // moved since the step began; with it the step is counted: nothing between here and apply_vbcs reads the clock's time)
-            launch_vbcs(h, false, h->tick_pending);
-            h->tick_pending = false;
+            if (!avg_extent) { launch_vbcs(h, false, h->tick_pending); h->tick_pending = false; }
             { Prof2 pr(h, P2_FORCE);
             hipLaunchKernelGGL(k2p_force<1>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
                                h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
             }
             std::swap(h->coord, h->coord_alt);             // the moved coordinates are the current ones from here on
+            h->xz_pre_valid = true;
             h->res_count = h->p_nb;
-            if (chain_ok(h) || (h->p.surface_process_option == 1 && h->etop > 0)) h->res_fin_pending = true;
+            if (h->p.surface_process_option == 1 && h->etop > 0) h->res_fin_pending = true;
             else hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->res_count, h->res_part, h->d_clk);
             return;
         }
@@ -2176,7 +2245,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             L2(k2_damp_vel, nn, h->d_p, h->d_clk, nn, h->mass, h->ymass, h->force, h->vel);
         L2(k2_residual_part, h->o1 - h->o0, nn, h->o0, h->o1, h->nn_global, h->fres, h->res_part);
         h->res_count = nblk(h->o1 - h->o0);
-        if (tail && (chain_ok(h) || (h->p.surface_process_option == 1 && h->etop > 0))) h->res_fin_pending = true;
+        if (tail && h->p.surface_process_option == 1 && h->etop > 0) h->res_fin_pending = true;
         else hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->res_count, h->res_part, h->d_clk);
         return;
     }
@@ -2566,7 +2635,6 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
         const char *ge = des_env::get("DES2D_GEO"), *ee = des_env::get("DES2D_ELIDE");
         h->geo_on = !(ge && ge[0] == '0'); h->elide_on = !(ee && ee[0] == '0');
         { const char *me = des_env::get("DES2D_MASS_FUSE"); h->mass_fuse_on = !(me && me[0] == '0'); }
-        { const char *ce = des_env::get("DES2D_CHAIN"); h->chain_on = !(ce && ce[0] == '0'); }
         const bool cluster = !(cl && cl[0] == '0');
         Patch2 P;
         bool ok = false;
@@ -2658,6 +2726,12 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                     A2(dcopy(h, h->sbcn_idx, idx.data(), idx.size()));
                     A2(dcopy(h, h->sbcn_ent, ent.data(), ent.size()));
                     A2(dalloc(h, h->coord_alt, (size_t)2 * nn));
+                    {
+                        std::vector<int> tpos((size_t)nn, -1);
+                        for (int i = 0; i < h->ntop; ++i) tpos[mesh->top_nodes[i]] = i;
+                        A2(dcopy(h, h->fold_top_pos, tpos.data(), tpos.size()));
+                        A2(dalloc(h, h->xz_pre, (size_t)std::max(h->ntop, 1)));
+                    }
                     h->fold_ok = true;
                 }
                 const char *fe = des_env::get("DES2D_FOLD"); h->fold_on = !(fe && fe[0] == '0');

@@ -322,6 +322,7 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
 struct ForceTail {
     const Clock *clk; const double *mass, *ymass; const unsigned *bcflag; const double *bnormals, *edge_vec; const int *edge_slot;
     double *vel, *coord_out; const int *conn; const int *sbcn_idx; const int4 *sbcn_ent; double *res_part; int o0, o1, nn_global;
+    const int *top_pos; double2 *xz_pre;        // a top node's position in top_nodes (-1: below the surface); its moved {x, z} there (k2_surf_commit)
 };
 template <int TAIL>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
@@ -355,6 +356,20 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
             g_phi[k] = gravity != 0 ? props[2 * ne + e] : 0.0;
             g_mono[k] = gravity != 0 ? mono[e] : 0;
         }
+    // TAIL: what the node phase needs of its own node is requested HERE, with everything else (one trip to memory for the
+    // whole workgroup, not another chain of them behind the force sums)
+    int t_n = 0, t_b0 = 0, t_b1 = 0, t_top = -1;
+    unsigned t_flag = 0;
+    double t_mass = 1.0, t_ymass = 0.0, t_v[2] = {0, 0};
+    if (TAIL && (int)threadIdx.x < nown) {
+        t_n = a.po_id[o0 + threadIdx.x];
+        t_flag = ft.bcflag[t_n];
+        t_mass = ft.mass[t_n];
+        if (p->damping_option == 4) t_ymass = ft.ymass[t_n];
+        t_v[0] = ft.vel[t_n]; t_v[1] = ft.vel[nn + t_n];
+        if (t_flag & BOUND_ANY) { t_b0 = ft.sbcn_idx[t_n]; t_b1 = ft.sbcn_idx[t_n + 1]; }
+        if (t_flag & BOUNDZ1) t_top = ft.top_pos[t_n];
+    }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
         const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
         lx[j] = coord[id]; lz[j] = coord[nn + id];
@@ -399,6 +414,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
         }
     }
     __syncthreads();
+    double l2 = 0.0;
     if ((int)threadIdx.x < nown) {
         const int n = a.po_id[o0 + threadIdx.x];
         const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
@@ -407,40 +423,38 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
             f[0] -= lf0[k]; fr[0] = lf0[k];            // assignment: fields.cxx:673
             f[1] -= lf1[k]; fr[1] = lf1[k];
         }
-        for (int j = 0; j < 2; j++) { force[j*nn + n] = f[j]; fres[j*nn + n] = fr[j]; }
-    }
-    if (!TAIL) return;
-    double l2 = 0.0;
-    if ((int)threadIdx.x < nown) {
-        const int n = a.po_id[o0 + threadIdx.x];
-        const unsigned flag = ft.bcflag[n];
-        if (flag & BOUND_ANY) {
+        for (int j = 0; j < 2; j++) fres[j*nn + n] = fr[j];
+        if (!TAIL) { for (int j = 0; j < 2; j++) force[j*nn + n] = f[j]; }
+        else {
             // apply_stress_bcs (bc.cxx:661-827): k2_sbc_direct's walk for this node, one loaded boundary after the other
-            const int b0 = ft.sbcn_idx[n], b1 = ft.sbcn_idx[n + 1];
-            if (b1 > b0) {
-                double f0 = force[n], f1 = force[nn + n];
-                for (int k = b0; k < b1; ++k) {
-                    const int4 ent = ft.sbcn_ent[k];
-                    double normal[2];
-                    const double pr = sbc_facet_pressure(p, ent.w, ent.x, ent.y, nn, ne, ft.conn, coord, temperature, markers, normal);
-                    f0 -= pr * normal[0] / 2;
-                    f1 -= pr * normal[1] / 2;
-                }
-                force[n] = f0; force[nn + n] = f1;
+            for (int k = t_b0; k < t_b1; ++k) {
+                const int4 ent = ft.sbcn_ent[k];
+                double normal[2];
+                const double pr = sbc_facet_pressure(p, ent.w, ent.x, ent.y, nn, ne, ft.conn, coord, temperature, markers, normal);
+                f[0] -= pr * normal[0] / 2;
+                f[1] -= pr * normal[1] / 2;
+            }
+            // k2_node_final's statements on the values held here: apply_damping + update_velocity, apply_vbcs (the node's z
+            // before it moves: the staged one), update_coordinate into the other buffer of the pair
+            const double dt = ft.clk->dt;
+            damp_vel_regs(p, dt, t_mass, t_ymass, f, t_v);
+            for (int j = 0; j < 2; j++) force[j*nn + n] = f[j];
+            const double x0 = lx[threadIdx.x], z0 = lz[threadIdx.x];
+            vbcs_regs(p, ft.clk, t_flag, z0, ft.bnormals, ft.edge_vec, ft.edge_slot, t_v);
+            ft.vel[n] = t_v[0]; ft.vel[nn + n] = t_v[1];
+            const double x_new = x0 + t_v[0] * dt, z_new = z0 + t_v[1] * dt;
+            ft.coord_out[n] = x_new;
+            ft.coord_out[nn + n] = z_new;
+            if (t_top >= 0) ft.xz_pre[t_top] = make_double2(x_new, z_new);
+            // calculate_residual_force (fields.cxx:700-722): this node's terms (k2_residual_part's expression)
+            if (n >= ft.o0 && n < ft.o1) {
+                const double num = (double)ft.nn_global * 2;
+                for (int j = 0; j < 2; ++j) l2 += fr[j] * fr[j] / num;
             }
         }
-        // k2_node_final's statements (the node's own entries only)
-        damp_vel_node(p, ft.clk, n, nn, ft.mass, ft.ymass, force, ft.vel);
-        vbcs_node(p, ft.clk, n, nn, ft.bcflag, ft.bnormals, ft.edge_vec, ft.edge_slot, coord, ft.vel);
-        ft.coord_out[n] = coord[n] + ft.vel[n] * ft.clk->dt;
-        ft.coord_out[nn + n] = coord[nn + n] + ft.vel[nn + n] * ft.clk->dt;
-        // calculate_residual_force (fields.cxx:700-722): this node's terms (k2_residual_part's expression)
-        if (n >= ft.o0 && n < ft.o1) {
-            const double num = (double)ft.nn_global * 2;
-            for (int j = 0; j < 2; ++j) { const double fj = fres[j*nn + n]; l2 += fj * fj / num; }
-        }
     }
-    // per-block partial; the partials are added in block order afterwards (k2_residual_fin / k2_surface_chain)
+    if (!TAIL) return;
+    // per-block partial; the partials are added in block order afterwards (k2_residual_fin / k2_surf_seg_resfin)
     __shared__ double red[DES2_PATCH_THREADS / 64];
     l2 = desk::wave_sum(l2);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l2;

@@ -436,7 +436,7 @@ void launch_e2(des_dev *h, int part = PART_ALL)
             hipLaunchKernelGGL(kp, dim3(npers + nbf_p + nsf_p), dim3(tile), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                                ntiles, npers, h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old,
                                h->stress, h->strain, h->strain_rate, h->plstrain, h->delta_plstrain, h->viscosity, h->dpressure,
-                               h->etmp2, count, h->e2_tile_ctr, (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
+                               h->etmp2, count, (nbf || nsf) ? h->nbcf : 0, h->bcf_elem, h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, rp);
         } else
         hipLaunchKernelGGL(k, dim3(nblk8(e_all) + nbf + nsf), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_vt, h->d_clk, h->ne,
                            e_begin, e_count, e_begin2, e_count2, nblk(e_all), h->conn, xt_now, h->ntmp, mat_data(h), h->volume, h->volume_old, h->stress,

@@ -7,11 +7,6 @@
 // =====================================================================================
 struct ElemProps { double bulkm, shearm, phi, cp, k; };
 
-// DES_LXY = 1: the patch passes keep the staged {x,y,z,T} records as two 16-byte halves in LDS arrays of their own instead of
-// one 32-byte record (fewer bank conflicts of the random ds_read_b128 of the element phase; passes/en1.hpp)
-#ifndef DES_LXY
-#define DES_LXY 0
-#endif
 
 // Instrumented builds only (tools/build_variant.sh NAME -DDES_STAMPS; tools/patch_phase_timing.py): the first lane of a
 // wavefront of every workgroup of the patch passes stamps the 100-MHz wall clock at its phase boundaries into a buffer

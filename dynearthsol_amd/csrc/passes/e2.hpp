@@ -22,9 +22,6 @@ __device__ void bc_facet_work(const des_params *__restrict__ p, int g, const int
 #ifndef DES_E2_PIPE_LANDED
 #define DES_E2_PIPE_LANDED 1
 #endif
-#ifndef DES_E2_DYN
-#define DES_E2_DYN 0
-#endif
 #define DES_STRAIN_LD pl_ld_nt
 #define DES_STRAIN_ST pl_st_nt
 // avg_*: Output::average_fields (output.cxx:327-370) folded into this pass when the end-of-step pass is (engine/launch.hpp):
@@ -385,8 +382,10 @@ E2_update_stress(const des_params *__restrict__ p, const desk::ViscTerms *__rest
 // npers: resident workgroups (a multiple of 8: blockIdx.x & 7 = the XCD under round-robin placement, for locality only).
 // DES_E2_PIPE_LANDED = 1 (default): "this tile's pieces have landed" is established inside the tile before (e2_element: one
 // s_waitcnt vmcnt(0) in front of the last group of stores); 0: the first form, a counted wait at the head of the tile.
-// DES_E2_DYN = 1: tiles of 64 elements handed out per WAVEFRONT from one counter per XCD share (the first round static, then
-// one atomic per wavefront and tile, requested a tile ahead so that the DMA knows where to go); 0: the static interleave.
+// (Round 5, measured and dropped: the wave-tiles handed out one by one from a counter per XCD share -- one atomic per
+//  wavefront and tile, drawn a tile ahead -- 195 against 67 us: two thousand same-address device-scope atomics per counter
+//  and launch serialise at the memory side; profiles/r05_c_ab_patch_variants.txt.  The 7-or-8-tiles tail it was aimed at is
+//  granularity, not imbalance: 15,646 wave-tiles over 2,048 resident wavefronts are 7.64 rounds however they are dealt.)
 typedef const __attribute__((address_space(1))) void *des_gptr;
 typedef __attribute__((address_space(3))) void *des_lptr;
 // NW = wavefronts per workgroup: 4 (two workgroups per CU = two waves per SIMD).  Tried: 12 -- ONE workgroup of 768 lanes per
@@ -399,7 +398,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
      double *__restrict__ volume, double *__restrict__ volume_old,
      double *__restrict__ stress, double *__restrict__ strain, double *__restrict__ strain_rate,
      double *__restrict__ plstrain, double *__restrict__ delta_plstrain, double *__restrict__ viscosity,
-     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ count, unsigned *__restrict__ tile_ctr,
+     double *__restrict__ dpressure, double *__restrict__ etmp2, int *__restrict__ count,
      int nbcf, const int *__restrict__ f_elem, const int *__restrict__ f_facet,
      const int *__restrict__ f_kind, const double *__restrict__ f_val, double *__restrict__ f_tmp, const RotPending rp)
 {
@@ -422,9 +421,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
     // Every wavefront walks WAVE-TILES of 64 elements.  XCD x sweeps the x-th eighth of the 256-element tiles (desk::logical_block's
     // chunks), i.e. the wave-tiles [x per NW, wt_end); its npers / 8 resident workgroups -- nwx wavefronts -- share them: statically
-    // interleaved (the four wavefronts of a workgroup side by side on one 256-element tile), or handed out one by one
-    // (DES_E2_DYN: the first round as in the static form, then tile_ctr[x] counts on; requested one tile AHEAD, at the top
-    // of the tile, so that the DMA of the next tile knows where to go when this tile's LDS region is free).
+    // interleaved (the four wavefronts of a workgroup side by side on one 256-element tile).
     const int per = (ntiles + 7) >> 3, wx = npers >> 3;
     const int x = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
     const int wt_begin = x * per * NW, wt_end = min((x + 1) * per, ntiles) * NW;
@@ -452,11 +449,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
         // (the top flags are bytes: a dword piece of 64 x 4 B covers them four times over -- bytes 0-63 are this tile's)
         __builtin_amdgcn_global_load_lds((des_gptr)(rp.topflag + eb + 4 * (size_t)lane), (des_lptr)&ltop[w][0], 4, 0, 0);
     };
-#if DES_E2_DYN
-    const int wt_first = wt_begin + j * NW + w;
-#else
     const int wt_first = wt_begin + j * NW + w, wt_step = nwx;
-#endif
     int t = wt_first;
     if (t < wt_end) dma(t);
 #ifdef DES_STAMPS
@@ -466,16 +459,7 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
 #endif
     while (t < wt_end) {
         const int e = t * 64 + lane;
-#if DES_E2_DYN
-        // the tile after this one: one atomic per wavefront, in flight under the LDS reads and the gathers (after() waits for it
-        // with them).  The wavefront that draws the LAST number of the launch -- every wavefront that works draws exactly one
-        // number past the end -- puts the counter back to zero for the next launch.
-        unsigned grab = 0;
-        if (lane == 0) grab = atomicAdd(&tile_ctr[x], 1u);
-        int tn = wt_end;
-#else
         const int tn = t + wt_step;
-#endif
 #ifdef DES_STAMPS
         st_a = wall_clock64();
 #endif
@@ -514,14 +498,6 @@ E2_update_stress_pipe(const des_params *__restrict__ p, const desk::ViscTerms *_
             // compiler's own scoreboard sees: vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding 0x0F70).
             __builtin_amdgcn_s_waitcnt(0x0F70);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if DES_E2_DYN
-            // (lane 0's number whatever lanes are active here: the lanes past the mesh come through after() a second time, below,
-            //  without lane 0 -- readfirstlane would hand them a lane that never drew)
-            const unsigned g = (unsigned)__builtin_amdgcn_readlane((int)grab, 0);
-            tn = wt_begin + nwx + (int)g;
-            if (g == (unsigned)(wt_end - wt_begin) - 1u && lane == 0) atomicExch(&tile_ctr[x], 0u);
-            if (tn > wt_end) tn = wt_end;
-#endif
             if (tn < wt_end) dma(tn);
             asm volatile("" ::: "memory");
             dma_done = true;

@@ -49,8 +49,9 @@ struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *s
 #ifndef DES_PATCH_PE
 #define DES_PATCH_PE 1280         // elements of a patch (LDS records)
 #endif
-#ifndef DES_EN1_PREF
-#define DES_EN1_PREF 0            // n: the list entries (and marker words) of a lane's first n rounds of patch elements requested up front
+#ifndef DES_EXP_EN1
+#define DES_EXP_EN1 0             // timing experiments (wrong results; profiles/r05_d_patch_phase_removal.txt), bits: 1 no element arithmetic,
+                                  // 2 no node sums, 4 no staging gathers, 8 no conduction terms, 16 no LDS reads in the element phase
 #endif
 #ifndef DES_EN1_MINWAVES
 #define DES_EN1_MINWAVES 3        // waves per SIMD the register budget of the 256-lane kernel is held to (168 VGPRs; 4: 128)
@@ -74,22 +75,8 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
      double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp, const SurfPending sp)
 {
     extern __shared__ __attribute__((aligned(32))) unsigned char des_smem[];
-    // The staged {x,y,z,T} records as two 16-byte halves in arrays of their own (DES_LXY, passes/common.hpp): a ds_read_b128
-    // serves 16 lanes per LDS cycle over sixteen 16-byte bank groups, and 32-byte records put every lane's first half on the
-    // EVEN groups only (8 bins for 16 random lanes, then the same for the second half); 16-byte strides use all sixteen.
     unsigned char *sm = des_smem;
-#if DES_LXY
-    double2 *const lxy = (double2 *)sm; sm += (size_t)cap_pn * 16;
-    double2 *const lzt = (double2 *)sm; sm += (size_t)cap_pn * 16;
-    auto lget = [&](int j) { const double2 a = lxy[j], b = lzt[j]; d4 r; r.x = a.x; r.y = a.y; r.z = b.x; r.w = b.y; return r; };
-    auto lput = [&](int j, const d4 &r) { lxy[j] = make_double2(r.x, r.y); lzt[j] = make_double2(r.z, r.w); };
-    auto laddz = [&](int j, double d) { lzt[j].x = lzt[j].x + d; };
-#else
     d4 *const lxt = (d4 *)sm; sm += (size_t)cap_pn * 32;
-    auto lget = [&](int j) { return lxt[j]; };
-    auto lput = [&](int j, const d4 &r) { lxt[j] = r; };
-    auto laddz = [&](int j, double d) { lxt[j].z = lxt[j].z + d; };
-#endif
     double *const lvx = (double *)sm; sm += (size_t)cap_pn * 8;
     double *const lvy = (double *)sm; sm += (size_t)cap_pn * 8;
     double *const lvz = (double *)sm; sm += (size_t)cap_pn * 8;
@@ -139,19 +126,6 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
         flag = bcflag[n];
     }
-#if DES_EN1_PREF
-    // this lane's list entries of EVERY round of the element phase, requested here -- ahead of the staging loads, with which
-    // they arrive (vmcnt is in order): the rounds then start without a trip to memory for the entry, and the marker words the
-    // entries point at are all requested at once behind the barrier (one exposed trip for the whole phase instead of two per round)
-    constexpr int PREF = DES_EN1_PREF;
-    ulonglong2 pk[PREF];
-#pragma unroll
-    for (int r = 0; r < PREF; ++r) {
-        const int i = e_begin + (int)threadIdx.x + r * THREADS;
-        pk[r] = make_ulonglong2(0, 0);
-        if (i < e_end) pk[r] = pe_pack[i];
-    }
-#endif
     // the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     // (every record of the patch is requested before anything waits: the surface nodes, which need more, come after)
     constexpr int ROUNDS = DES_PATCH_PN / THREADS;          // (cap_pn <= DES_PATCH_PN = 512)
@@ -164,12 +138,22 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         tf[r] = make_int2(-1, 0);
         ids[r] = 0;
         if (j < nown + nh) {
+#if DES_EXP_EN1 & 4
+            // timing experiment only (wrong results): the staging without its gathers
+            const int raw = n0 + (j & 63);
+            const int id = raw & 0x7fffffff;
+            ids[r] = id;
+            d4 xr; xr.x = 1.0 * j; xr.y = 2.0 * (j & 7); xr.z = 3.0 * (j & 3) + 0.5 * j; xr.w = 300.0;
+            lxt[j] = xr;
+            lvx[j] = 1e-9 * j; lvy[j] = 2e-9; lvz[j] = 3e-9;
+#else
             const int raw = j < nown ? n0 + j : pn_id[h0 + j - nown];
             const int id = raw & 0x7fffffff;
             ids[r] = id;
-            lput(j, xt[id]);
+            lxt[j] = xt[id];
             const d4 v = vm[id];
             lvx[j] = v.x; lvy[j] = v.y; lvz[j] = v.z;
+#endif
             if (blk_top && (j < nown || raw < 0)) tf[r] = sp.tfan[id];
         }
     }
@@ -183,36 +167,49 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
             // (dt: the step before ran with it too -- a step with a compute_dt keeps its own S2 / S3 launches)
             const double dhacc_old = j < nown ? sp.dhacc[id] : 0.0;
             const double d = s2_node_dh_range<DES_EN1_S2_BATCH>(id, tf[r].y, tf[r].y + nf, sp.ssup_nodes, xt, p->surface_diffusivity, dt);
-            laddz(j, d);                                // (this lane staged the record itself)
+            lxt[j].z = lxt[j].z + d;                                // (this lane staged the record itself)
             if (j < nown) { sp.dh[ti] = d; sp.dhacc[id] = dhacc_old + d; sp.dh_n[id] = d; }
         }
     }
-#if DES_EN1_PREF
-    // (the marker words: requested in front of the barrier, on their way while the wavefronts meet)
-    int mo[PREF];
-#pragma unroll
-    for (int r = 0; r < PREF; ++r) {
-        const int i = e_begin + (int)threadIdx.x + r * THREADS;
-        mo[r] = 0;
-        if (i < e_end) mo[r] = md.mono[(int)(pk[r].x & 0x3fffffffull)];
-    }
-#endif
     __syncthreads();
     DES_STAMP0(0, 1);
     // the patch's elements: E1's element terms, recomputed
-    auto do_elem = [&](const int i, const ulonglong2 pkr, const int mono_pre, const bool have_mono) {
-        const PatchElem PE_ = patch_elem_unpack(pkr);
+    auto do_elem = [&](const int i) {
+        const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
         const int e = PE_.ew & 0x3fffffff;
         const ushort4 ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
         const short4 sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
         const int q = i - e_begin;                          // position in the patch
+#if DES_EXP_EN1 & 1
+        // timing experiment only (wrong results): the element phase without its LDS reads and arithmetic (list entry, marker
+        // word and the LDS stores stay)
+        {
+            const double fake = (double)(e & 1023) + md.mono[e];
+            lvol[q] = fake + 1.0; ltm[q] = fake; ldv[q] = fake;
+            if (!CONSTM) lm[q] = fake;
+            if (sl.x >= 0) { ltd[sl.x] = fake; lidx[sl.x] = (unsigned short)q; }
+            if (sl.y >= 0) { ltd[sl.y] = fake; lidx[sl.y] = (unsigned short)q; }
+            if (sl.z >= 0) { ltd[sl.z] = fake; lidx[sl.z] = (unsigned short)q; }
+            if (sl.w >= 0) { ltd[sl.w] = fake; lidx[sl.w] = (unsigned short)q; }
+            return;
+        }
+#endif
         d4 c[4], v[4];
-        c[0] = lget(ln.x); c[1] = lget(ln.y); c[2] = lget(ln.z); c[3] = lget(ln.w);
+#if DES_EXP_EN1 & 16
+        // timing experiment only (wrong results): the arithmetic on values made up in registers instead of read from LDS
+        for (int u = 0; u < 4; ++u) {
+            const int l = u == 0 ? ln.x : (u == 1 ? ln.y : (u == 2 ? ln.z : ln.w));
+            c[u].x = 1.0 * l + 0.25 * u * u; c[u].y = 2.0 * (l & 7) + 1.5 * u; c[u].z = 0.5 * l + (u == 3 ? 7.0 : 0.0); c[u].w = 300.0 + l;
+            v[u].x = 1e-9 * l; v[u].y = 2e-9 * u; v[u].z = 3e-9 * l; v[u].w = 0;
+        }
+#else
+        c[0] = lxt[ln.x]; c[1] = lxt[ln.y]; c[2] = lxt[ln.z]; c[3] = lxt[ln.w];
         v[0].x = lvx[ln.x]; v[0].y = lvy[ln.x]; v[0].z = lvz[ln.x]; v[0].w = 0;
         v[1].x = lvx[ln.y]; v[1].y = lvy[ln.y]; v[1].z = lvz[ln.y]; v[1].w = 0;
         v[2].x = lvx[ln.z]; v[2].y = lvy[ln.z]; v[2].z = lvz[ln.z]; v[2].w = 0;
         v[3].x = lvx[ln.w]; v[3].y = lvy[ln.w]; v[3].z = lvz[ln.w]; v[3].w = 0;
-        const desk::Mix mx = have_mono ? mix_from_mono(md, nmat, e, mono_pre) : mix_of(md, nmat, e);
+#endif
+        const desk::Mix mx = mix_of(md, nmat, e);
         const ElemProps pr = load_props(p, md, mx, ne, e);
         double T = 0;
         T += c[0].w; T += c[1].w; T += c[2].w; T += c[3].w;
@@ -225,7 +222,11 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         desk::shape_fn(c, vol, sx, sy, sz);
         double tr[4] = {0, 0, 0, 0};
         // (radiogenic == nullptr: every heat source is +0.0, engine/launch.hpp -- the same arithmetic without the fetch)
+#if DES_EXP_EN1 & 8
+        tr[0] = sx[0]; tr[1] = sy[1]; tr[2] = sz[2]; tr[3] = vol;     // timing experiment only (wrong results): no conduction terms
+#else
         if (thermal) e1_thermal_terms(c, sx, sy, sz, pr.k, vol, radiogenic ? radiogenic[e] : 0.0, rho, tr);
+#endif
         double s0, s1, s2;
         e1_strain_rate_diag(v, sx, sy, sz, s0, s1, s2);
         double dj = s0 + s1 + s2;
@@ -236,16 +237,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         if (sl.z >= 0) { ltd[sl.z] = tr[2]; lidx[sl.z] = (unsigned short)q; }
         if (sl.w >= 0) { ltd[sl.w] = tr[3]; lidx[sl.w] = (unsigned short)q; }
     };
-#if DES_EN1_PREF
-#pragma unroll
-    for (int r = 0; r < PREF; ++r) {
-        const int i = e_begin + (int)threadIdx.x + r * THREADS;
-        if (i < e_end) do_elem(i, pk[r], mo[r], true);
-    }
-    for (int i = e_begin + (int)threadIdx.x + PREF * THREADS; i < e_end; i += THREADS) do_elem(i, pe_pack[i], 0, false);
-#else
-    for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) do_elem(i, pe_pack[i], 0, false);
-#endif
+    for (int i = e_begin + threadIdx.x; i < e_end; i += THREADS) do_elem(i);
     DES_STAMP0(0, 2);                                       // (this wavefront's own elements done)
     __syncthreads();
     DES_STAMP0(0, 3);
@@ -309,7 +301,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
                 for (; k < r1; ++k) { tms += ltm[lidx[k]]; tdot += ltd[k]; }
             }
             tmass[n] = tms;
-            d4 x4 = lget(nl);
+            d4 x4 = lxt[nl];
             if (thermal) {
                 if (flag & (1u << 5))
                     x4.w = p->surface_temperature;
@@ -321,6 +313,10 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         }
         return;
     }
+#endif
+#if DES_EXP_EN1 & 2
+    // timing experiment only (wrong results): the node phase without its sums (one term each; the stores stay)
+    if (r1 > r0) r1 = r0 + 1;
 #endif
     // the node: sums in CSR order (compute_mass / update_temperature / compute_dvoldt node loops)
     double vn = 0, ms = 0, tms = 0, acc = 0, tdot = 0;
@@ -364,7 +360,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     d4 m4;                                                   // the velocity is the staged one (own node: local id = lane)
     m4.x = lvx[threadIdx.x]; m4.y = lvy[threadIdx.x]; m4.z = lvz[threadIdx.x]; m4.w = ms;
     vm[n] = m4;
-    d4 x4 = lget(threadIdx.x);
+    d4 x4 = lxt[threadIdx.x];
     if (thermal) {
         if (flag & (1u << 5))
             x4.w = p->surface_temperature;

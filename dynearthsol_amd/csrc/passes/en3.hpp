@@ -40,13 +40,10 @@
 // KNOWN = 1: the launch is the common one -- NMD_stress on, gravity on -- and the kernel holds that path only (the two flags
 // known at compile time: -2 us of 56 at 1M tets); KNOWN = 0: both read at run time.
 // LDS is DYNAMIC, sized by the host to the mesh's largest block (cap_inc incidences, cap_pn patch nodes; engine/launch.hpp).
-#ifndef DES_EN3_LVM
-#define DES_EN3_LVM 0             // 1: the block's own {vx,vy,vz,mass} records parked in LDS during the staging (see the node phase)
+#ifndef DES_EXP_EN3
+#define DES_EXP_EN3 0             // timing experiments (wrong results; profiles/r05_d_patch_phase_removal.txt), bits: 1 no element arithmetic, 2 no force sums, 4 no staging gathers, 8 no element loads
 #endif
-#ifndef DES_EN3_PK2
-#define DES_EN3_PK2 0             // 1: the list entry of a lane's SECOND patch element requested with the first (one trip less in round two)
-#endif
-__host__ __device__ inline size_t en3_lds_bytes(int cap_inc, int cap_pn) { return (size_t)cap_pn * (32 + 8) + (size_t)cap_inc * 24 + (DES_EN3_LVM ? 64 * 32 : 0); }
+__host__ __device__ inline size_t en3_lds_bytes(int cap_inc, int cap_pn) { return (size_t)cap_pn * (32 + 8) + (size_t)cap_inc * 24; }
 #ifndef DES_EN3_MINWAVES
 #define DES_EN3_MINWAVES 3        // 256-lane form: waves per SIMD its register budget is held to
 #endif
@@ -69,21 +66,9 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     // two after the launch) -- a block must not move a node another block may still be reading
     extern __shared__ __attribute__((aligned(32))) unsigned char des_smem[];
     unsigned char *sm = des_smem;
-#if DES_LXY
-    double2 *const lxy = (double2 *)sm; sm += (size_t)cap_pn * 16;        // (two 16-byte halves: passes/en1.hpp)
-    double2 *const lzt = (double2 *)sm; sm += (size_t)cap_pn * 16;
-    auto lget = [&](int j) { const double2 a = lxy[j], b = lzt[j]; d4 r; r.x = a.x; r.y = a.y; r.z = b.x; r.w = b.y; return r; };
-    auto lput = [&](int j, const d4 &r) { lxy[j] = make_double2(r.x, r.y); lzt[j] = make_double2(r.z, r.w); };
-#else
     d4 *const lxt = (d4 *)sm; sm += (size_t)cap_pn * 32;
-    auto lget = [&](int j) { return lxt[j]; };
-    auto lput = [&](int j, const d4 &r) { lxt[j] = r; };
-#endif
     double *const lnt = (double *)sm; sm += (size_t)cap_pn * 8;
     double *const lf[3] = {(double *)sm, (double *)sm + cap_inc, (double *)sm + 2 * (size_t)cap_inc};
-#if DES_EN3_LVM
-    d4 *const lvm = (d4 *)(sm + 3 * (size_t)cap_inc * 8);    // [64] (blocks of up to 64 nodes; larger blocks load in the node phase)
-#endif
     __shared__ double red[THREADS / 64];
     const int lb = desk::logical_block(nblocks);
     const int n0 = lb * npb;
@@ -100,8 +85,8 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     // flight TOGETHER: a workgroup's critical path is two round trips to memory (index, then record),
     // not one per phase -- with three workgroups per CU there is little else to hide them behind.
     struct Elem { int ew, mono; ushort4 ln; short4 sl; double s[6], vol, dpo; };
-    auto load_elem_pk = [&](const ulonglong2 pk, Elem &E) {
-        const PatchElem PE_ = patch_elem_unpack(pk);
+    auto load_elem = [&](int i, Elem &E) {
+        const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
         E.ew = PE_.ew; E.ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
         E.sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
         int e = E.ew & 0x3fffffff;
@@ -109,20 +94,21 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         e = (e & 1023) + (lb & 7) * 1024; // timing experiment only (wrong results): the element loads hit a few hot lines
 #endif
         const unsigned eo = (unsigned)e * 8u;               // scalar plane base + one 32-bit offset (passes/common.hpp)
+#if DES_EXP_EN3 & 8
+        // timing experiment only (wrong results): no per-element global loads
+        for (int k = 0; k < 6; ++k) E.s[k] = 1e6 * (k + 1) + e;
+        E.vol = 1e7 + e; E.dpo = 1e3; E.mono = (0 << 16) | 4;
+#else
         for (int k = 0; k < 6; ++k) E.s[k] = pl_ld(stress, k, ne, eo);
         E.vol = pl_ld(volume, 0, ne, eo);
         E.dpo = nmd ? pl_ld(dpressure, 0, ne, eo) : 0.0;
         E.mono = grav ? md.mono[e] : 0;
+#endif
     };
-    auto load_elem = [&](int i, Elem &E) { load_elem_pk(pe_pack[i], E); };
     // (a) this lane's first patch element: list entry, then stress / volume / dpressure (holding a
     //     second one in registers as well costs a wave of occupancy and more than it hides)
     Elem E0;
     const int i0 = e_begin + threadIdx.x, i1 = i0 + THREADS;
-#if DES_EN3_PK2
-    ulonglong2 pk1 = make_ulonglong2(0, 0);
-    if (i1 < e_end) pk1 = pe_pack[i1];
-#endif
     if (i0 < e_end) load_elem(i0, E0);
     // (b) the node this lane will finish: its CSR segment and its records.  DES_EN3_SPLIT (blocks of up to 64 nodes):
     //     lane l of the first three wavefronts sums ONE force component of node n0 + l (below), so those lanes need the
@@ -143,34 +129,36 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         r0 = sup_idx[n0 + nl] - kb; r1 = sup_idx[n0 + nl + 1] - kb;
     }
     if (has_node) flag = bcflag[n];
-#if DES_EN3_LVM
-    // {vx,vy,vz,mass} of the block's own nodes: requested HERE, ahead of the staging loads (it arrives with them: vmcnt is in
-    // order), parked in LDS by the lane that will want it after the force sums -- requested behind the element phase it cost
-    // the node phase a whole exposed trip to memory, held in registers across the element phase it went to scratch (80 VGPRs)
-    const bool park = has_node && npb <= 64;
-    double mp0 = 0, mp1 = 0, mp2 = 0, mp3 = 0;
-    if (park) { const d4 t = vm[n]; mp0 = t.x; mp1 = t.y; mp2 = t.z; mp3 = t.w; }
-#endif
     // (c) the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
         int id = j < nown ? n0 + j : (pn_id[h0 + j - nown] & 0x7fffffff);      // (bit 31: a surface node, for EN1)
 #ifdef DES_EXP_EN3_FAKE_STAGE
         id = n0 + (j & 63);              // timing experiment only (wrong results): the staging gathers hit lines already on their way
 #endif
-        lput(j, xt[id]);
+#if DES_EXP_EN3 & 4
+        { d4 xr; xr.x = 1.0 * j; xr.y = 2.0 * (j & 7); xr.z = 3.0 * (j & 3) + 0.5 * j; xr.w = 300.0; lxt[j] = xr; lnt[j] = 1.0 * id; }   // timing experiment only
+#else
+        lxt[j] = xt[id];
         if (nmd) lnt[j] = ntmp[id];
-    }
-#if DES_EN3_LVM
-    if (park) { d4 t; t.x = mp0; t.y = mp1; t.z = mp2; t.w = mp3; lvm[threadIdx.x] = t; }
 #endif
+    }
     __syncthreads();
     DES_STAMP0(1, 1);
 
     // the force terms of one patch element into the LDS slots of its incidences in this block
     auto do_elem = [&](const Elem &E) {
         const int e = E.ew & 0x3fffffff;
+#if DES_EXP_EN3 & 1
+        // timing experiment only (wrong results): the element phase without LDS reads and arithmetic (loads and LDS stores stay)
+        {
+            const double fake = E.s[0] + E.s[1] + E.s[2] + E.s[3] + E.s[4] + E.s[5] + E.vol + E.dpo + E.mono;
+            const int slot_[4] = {E.sl.x, E.sl.y, E.sl.z, E.sl.w};
+            for (int k = 0; k < 4; ++k) if (slot_[k] >= 0) { lf[0][slot_[k]] = fake; lf[1][slot_[k]] = fake; lf[2][slot_[k]] = fake; }
+            return;
+        }
+#endif
         d4 c[4];
-        c[0] = lget(E.ln.x); c[1] = lget(E.ln.y); c[2] = lget(E.ln.z); c[3] = lget(E.ln.w);
+        c[0] = lxt[E.ln.x]; c[1] = lxt[E.ln.y]; c[2] = lxt[E.ln.z]; c[3] = lxt[E.ln.w];
         double s[6];
         for (int k = 0; k < 6; ++k) s[k] = E.s[k];
         if (nmd) {                                          // is_using_mixed_stress, outside the isostasy loop
@@ -205,12 +193,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         }
     };
     if (i0 < e_end) do_elem(E0);
-#if DES_EN3_PK2
-    if (i1 < e_end) { Elem E; load_elem_pk(pk1, E); do_elem(E); }
-    for (int i = i1 + THREADS; i < e_end; i += THREADS) {   // (a third round: the largest patches only)
-#else
     for (int i = i1; i < e_end; i += THREADS) {             // the rest of the patch (one more round, seldom two)
-#endif
         Elem E;
         load_elem(i, E);
         do_elem(E);
@@ -263,18 +246,17 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
                 for (int c = 0; c < 3; ++c) { const double tv = lf[c][r0]; f[c] -= tv; fr[c] = tv; }
             }
             l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
-                                coord0, ymass, bnormals, edge_vec, edge_slot, flag, lget(threadIdx.x), m4, xt_out, true, vm, force, fres);
+                                coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres);
         }
     } else
+#endif
+#if DES_EXP_EN3 & 2
+    if (r1 > r0) r1 = r0 + 1;          // timing experiment only (wrong results): one term per force sum
 #endif
     if (has_node) {
         // {vx,vy,vz,mass}: requested here, behind the force sums, not ahead of the element phase -- held across it
         // the record went to scratch (at 80 VGPRs), 24 MB of stores per launch for 2901 workgroups
-#if DES_EN3_LVM
-        const d4 m4 = park ? lvm[threadIdx.x] : vm[n];      // (this lane parked it itself)
-#else
         const d4 m4 = vm[n];
-#endif
         double f[3] = {0, 0, 0}, fr[3] = {0, 0, 0};
         int k = r0;
         for (; k + 8 <= r1; k += 8) {                       // eight slots requested from LDS before the first is used
@@ -299,7 +281,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
             fr[0] = t0v; fr[1] = t1v; fr[2] = t2v;          // assignment: fields.cxx:673
         }
         l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
-                            coord0, ymass, bnormals, edge_vec, edge_slot, flag, lget(threadIdx.x), m4, xt_out, true, vm, force, fres);
+                            coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres);
     }
     DES_STAMP0(1, 5);
     // per-block partial of the residual; the partials are added in block order afterwards
