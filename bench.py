@@ -639,7 +639,8 @@ def main():
         # MI355X_MICROARCH.md): tools/measure_traffic.py makes them for a named workload and commits the summary; it is
         # quoted only for that very workload
         tj, tsrc = None, None
-        for tname in (("r04_pmc_traffic_2d.json",) if args.ndims == 2 else ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json")):
+        for tname in (("r05_pmc_traffic_2d.json", "r04_pmc_traffic_2d.json") if args.ndims == 2 else
+                      ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json")):
             tpath = os.path.join(ROOT, "profiles", tname)
             if not os.path.exists(tpath):
                 continue

@@ -51,7 +51,8 @@ struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *s
 #endif
 #ifndef DES_EXP_EN1
 #define DES_EXP_EN1 0             // timing experiments (wrong results; profiles/r05_d_patch_phase_removal.txt), bits: 1 no element arithmetic,
-                                  // 2 no node sums, 4 no staging gathers, 8 no conduction terms, 16 no LDS reads in the element phase
+                                  // 2 no node sums, 4 no staging gathers, 8 no conduction terms, 16 no LDS reads in the element phase; on top of 1|2|4 (the skeleton):
+                                  // 128 no list-entry loads, 256 no LDS stores of the element phase, 512 no node stores, 1024 header loads only
 #endif
 #ifndef DES_EN1_MINWAVES
 #define DES_EN1_MINWAVES 3        // waves per SIMD the register budget of the 256-lane kernel is held to (168 VGPRs; 4: 128)
@@ -108,6 +109,10 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     const int e_begin = pe_ptr[lb], e_end = pe_ptr[lb + 1];
     const bool thermal = THERM ? true : (bool)p->has_thermal_diffusion;
     const int nmat = p->nmat;
+#if DES_EXP_EN1 & 1024
+    if (nh + e_end == -12345) volume_n[n0] = nown;         // timing experiment only: header loads, then out
+    if (nh + e_end != -12345) return;
+#endif
     // the node this lane works for.  DES_EN1_SPLIT (blocks of up to 64 nodes): lane l of EVERY wavefront belongs to node
     // n0 + l, and the node's independent sums go to different wavefronts (node phase below); otherwise lane t < nown alone.
 #if DES_EN1_SPLIT
@@ -175,7 +180,14 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     DES_STAMP0(0, 1);
     // the patch's elements: E1's element terms, recomputed
     auto do_elem = [&](const int i) {
+#if DES_EXP_EN1 & 128
+        // timing experiment only (wrong results): the list entry made up from the position (no load)
+        const unsigned long long q_ = (unsigned long long)(i - e_begin);
+        const PatchElem PE_ = patch_elem_unpack(make_ulonglong2((unsigned long long)((lb * 345 + (int)q_) % ne) | ((q_ % 64) << 31) | (((q_ + 1) % 64) << 40) | (((q_ + 2) % 64) << 49),
+                                                                ((q_ + 3) % 64) | ((q_ % 1200) << 9) | (0xfffull << 21) | (0xfffull << 33) | (0xfffull << 45)));
+#else
         const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
+#endif
         const int e = PE_.ew & 0x3fffffff;
         const ushort4 ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
         const short4 sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
@@ -185,6 +197,10 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         // word and the LDS stores stay)
         {
             const double fake = (double)(e & 1023) + md.mono[e];
+#if DES_EXP_EN1 & 256
+            if (fake == -1.2345) lvol[q] = fake;             // (keeps the marker-word load; no LDS stores)
+            return;
+#endif
             lvol[q] = fake + 1.0; ltm[q] = fake; ldv[q] = fake;
             if (!CONSTM) lm[q] = fake;
             if (sl.x >= 0) { ltd[sl.x] = fake; lidx[sl.x] = (unsigned short)q; }
@@ -355,6 +371,9 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
         if (thermal) { tms += ltm[q]; tdot += ltd[k]; }
         acc += ldv[q];
     }
+#if DES_EXP_EN1 & 512
+    if (vn != -1.2345) return;                               // timing experiment only: no stores of the node phase
+#endif
     volume_n[n] = vn;
     tmass[n] = tms;
     d4 m4;                                                   // the velocity is the staged one (own node: local id = lane)

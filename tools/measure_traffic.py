@@ -10,7 +10,7 @@ HALF of the bytes moved, for 8 B per lane streams as for the 16 B per lane ones 
 gather shows 128 B moved per access, i.e. whole lines, in the same unit) -- so
 traffic = (FETCH_SIZE / 0.5 + WRITE_SIZE) x 1024 for every pass of this engine.
 
-  python tools/measure_traffic.py [bench args]      (on the MI355X box)   -> profiles/r04_pmc_traffic.json (with --ndims 2: r04_pmc_traffic_2d.json)
+  python tools/measure_traffic.py [bench args]      (on the MI355X box)   -> profiles/r05_pmc_traffic.json (with --ndims 2: r05_pmc_traffic_2d.json)
 """
 import collections
 import csv
@@ -33,7 +33,8 @@ def short(name):
     base = k.split("<")[0]
     # the 2-D engine's launches under the names its own accounting (and bench.py --ndims 2) uses
     two_d = {"k2_stress": "K2_stress", "k2p_temp_dvoldt": "K2P_temp_dvoldt", "k2p_force": "K2P_force", "k2p_mass": "K2P_mass",
-             "k2_node_avg": "K2_node_avg", "k2_rotate_vol": "K2_rotate_vol"}
+             "k2_node_avg": "K2_node_avg", "k2_node_avg_extent": "K2_node_avg", "k2_rotate_vol": "K2_rotate_vol",
+             "k2_surf_commit": "K2_surf_commit", "k2_surf_edv_cse_all": "K2_surf_edv_cse_all"}
     if base in two_d:
         return two_d[base]
     if base == "E2_update_stress_pipe":
@@ -87,7 +88,7 @@ def main():
                   "traffic_bytes_per_launch": (fv / cal["fetch"] + wv / cal["write"]) * 1024}
         print("%-28s FETCH %.1f MiB raw, WRITE %.1f MiB -> traffic %.1f MB/launch" % (k, fv / 1024, wv / 1024, res[k]["traffic_bytes_per_launch"] / 1e6))
     # (on the GPU box only gpurun_out/ travels back: DES_PROFILE_OUT=gpurun_out/<dir>, then copy to profiles/)
-    json.dump(res, open(os.path.join(os.environ.get("DES_PROFILE_OUT", os.path.join(ROOT, "profiles")), os.environ.get("DES_TRAFFIC_NAME", "r04_pmc_traffic_2d.json" if "--ndims" in bench_args else "r04_pmc_traffic.json")), "w"), indent=1)
+    json.dump(res, open(os.path.join(os.environ.get("DES_PROFILE_OUT", os.path.join(ROOT, "profiles")), os.environ.get("DES_TRAFFIC_NAME", "r05_pmc_traffic_2d.json" if "--ndims" in bench_args else "r05_pmc_traffic.json")), "w"), indent=1)
 
 
 if __name__ == "__main__":
