@@ -60,8 +60,9 @@ def portable_device_libm():
         os.environ["DES_LIBM"] = old
 
 
-def test_headline_evp_1000_steps_against_the_c_library_oracle(portable_device_libm):
+def test_headline_evp_1000_steps_against_the_c_library_oracle(portable_device_libm, monkeypatch, capfd):
     host = _host("elasto-visco-plastic")
+    monkeypatch.setenv("DES_PATCH_VERBOSE", "1")       # the engine says on stderr which launch shapes it picked
     lib = load_oracle(omp=True)
     assert lib.des_oracle_set_libm(-1) == 0, "the oracle must run on the C library's libm here"
     lib.des_oracle_set_threads(int(os.environ.get("DES_ORACLE_THREADS", "16")))
@@ -91,6 +92,11 @@ def test_headline_evp_1000_steps_against_the_c_library_oracle(portable_device_li
     bitwise = all(np.array_equal(dev.download(f), ora.download(f)) for f in ("COORD", "VEL", "STRESS", "STRAIN", "TEMPERATURE", "VISCOSITY"))
     print("bit-identical to the C-library oracle: %s" % bitwise)
     assert bitwise or n_yield > 0 or worst <= TOL
+    # ... and the stress update that ran was the one the bench line times: the LDS-DMA pipelined form of E2<GEO>, the evp
+    # instantiation (the default at this size; engine/launch.hpp: e2_pipelined), on patches of 64 nodes
+    err = capfd.readouterr().err
+    assert err.count("E2<GEO>: pipelined launch") == 1 and "(evp instantiation)" in err, err[-2000:]
+    assert "patches: 64 nodes per block, 2901 blocks" in err
 
 
 def test_headline_mesh_elasto_plastic_bit_exact():
