@@ -940,27 +940,29 @@ __global__ void k2_neumann(const des_params *p, int ib, int bound, const int *bf
 
 // apply_damping (fields.cxx:483-579) + update_velocity (fields.cxx:725-742) of a node, on values the caller holds:
 // f[] in: the force sums, out: the damped force; v[] in / out: the velocity
-__device__ __forceinline__ void damp_vel_regs(const des_params *p, double dt, double mass_i, double ymass_i, double f_io[2], double v_io[2])
+// (dopt, dfac = Param::control.damping_option / damping_factor: read by the caller, which may do so long before the values
+//  are used -- a scalar load behind a barrier is a trip to memory the compiler may not hoist)
+__device__ __forceinline__ void damp_vel_regs(const int dopt, const double dfac, double dt, double mass_i, double ymass_i, double f_io[2], double v_io[2])
 {
     const double small_vel = 1e-13;
     for (int j = 0; j < 2; j++) {
         double f = f_io[j];
         const double v = v_io[j];
-        switch (p->damping_option) {
+        switch (dopt) {
         case 1:
-            if (fabs(v) > small_vel) f -= p->damping_factor * copysign(f, v);
+            if (fabs(v) > small_vel) f -= dfac * copysign(f, v);
             break;
         case 2:
-            f -= p->damping_factor * f;
+            f -= dfac * f;
             break;
         case 3:
-            if ((f < 0) == (v < 0)) f -= p->damping_factor * f;          // fields.cxx:538: comma operator
-            else f += (1 - p->damping_factor) * f;
+            if ((f < 0) == (v < 0)) f -= dfac * f;          // fields.cxx:538: comma operator
+            else f += (1 - dfac) * f;
             break;
         case 4:
             if (fabs(v) > small_vel) {
                 double critical_coeff = 2.0 * sqrt(mass_i * ymass_i);
-                double f_C = p->damping_factor * copysign(f, v);
+                double f_C = dfac * copysign(f, v);
                 double f_V = critical_coeff * v;
                 double f_damping = (fabs(f_C) < fabs(f_V)) ? f_V : f_C;
                 f -= f_damping;
@@ -978,7 +980,7 @@ __device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *
                                               const double *ymass, double *force, double *vel)
 {
     double f[2] = {force[i], force[nn + i]}, v[2] = {vel[i], vel[nn + i]};
-    damp_vel_regs(p, clk->dt, mass[i], p->damping_option == 4 ? ymass[i] : 0.0, f, v);
+    damp_vel_regs(p->damping_option, p->damping_factor, clk->dt, mass[i], p->damping_option == 4 ? ymass[i] : 0.0, f, v);
     for (int j = 0; j < 2; j++) { force[j*nn + i] = f[j]; vel[j*nn + i] = v[j]; }
 }
 
@@ -1089,15 +1091,33 @@ __global__ void k2_vbc_extent(int nb, const int *bnodes_x0, int nn, const double
 
 // NMD_stress' nodal average with the wall's extent as one extra workgroup (round 5: the plain step of the patch path, where the
 // extent -- and with it the step's count -- only has to be in the clock before the force pass's node phase)
-__global__ void k2_node_avg_extent(int nn, int nb_avg, const int *sup_idx, const int *sup_arr, const double *etmp, const double *volume_n, double *ntmp,
-                                   int nb, const int *bnodes_x0, const double *coord, Clock *clk, int tick)
+// The gather itself as an LDS-staged segmented sum: a workgroup owns 256 consecutive nodes, i.e. one contiguous slice of the
+// support list; all lanes first fetch the slice's element values (coalesced index reads, one gather each) into LDS, then
+// every node's lane adds its own segment in list order -- the thread-per-node walk's order, the same bits, without a chain
+// of three dependent trips to memory per incidence.
+#define DES2_AVG_TILE 2048
+__global__ void __launch_bounds__(DES_BLOCK)
+k2_node_avg_extent(int nn, int nb_avg, const int *sup_idx, const int *sup_arr, const double *etmp, const double *volume_n, double *ntmp,
+                   int nb, const int *bnodes_x0, const double *coord, Clock *clk, int tick)
 {
     if ((int)blockIdx.x >= nb_avg) { vbc_extent_block(nb, bnodes_x0, nn, coord, clk, tick); return; }
-    const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
-    if (n >= nn) return;
+    __shared__ double lv[DES2_AVG_TILE];
+    const int n0 = blockIdx.x * DES_BLOCK, n1 = min(nn, n0 + DES_BLOCK);
+    const int n = n0 + threadIdx.x;
+    const int kb = sup_idx[n0], ke = sup_idx[n1];
+    int r0 = ke, r1 = ke;
+    double vn = 1.0;
+    if (n < nn) { r0 = sup_idx[n]; r1 = sup_idx[n + 1]; vn = volume_n[n]; }
     double acc = 0.;
-    for (int k = sup_idx[n]; k < sup_idx[n+1]; ++k) acc += etmp[sup_arr[k]];
-    ntmp[n] = acc / volume_n[n];
+    for (int t0 = kb; t0 < ke; t0 += DES2_AVG_TILE) {
+        const int tn = min(DES2_AVG_TILE, ke - t0);
+        for (int j = threadIdx.x; j < tn; j += DES_BLOCK) lv[j] = etmp[sup_arr[t0 + j]];
+        __syncthreads();
+        const int a = max(r0, t0) - t0, b = min(r1, t0 + tn) - t0;
+        for (int j = a; j < b; ++j) acc += lv[j];
+        __syncthreads();
+    }
+    if (n < nn) ntmp[n] = acc / vn;
 }
 
 // ... and the lowest node of the mesh, zmin = min(0, min z) (bc.cxx:350-361): read only by vbc_x0 = 3 with a

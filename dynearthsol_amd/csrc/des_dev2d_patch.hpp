@@ -358,6 +358,8 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
         }
     // TAIL: what the node phase needs of its own node is requested HERE, with everything else (one trip to memory for the
     // whole workgroup, not another chain of them behind the force sums)
+    const int t_dopt = TAIL ? p->damping_option : 0;
+    const double t_dfac = TAIL ? p->damping_factor : 0.0, t_dt = TAIL ? ft.clk->dt : 0.0;
     int t_n = 0, t_b0 = 0, t_b1 = 0, t_top = -1;
     unsigned t_flag = 0;
     double t_mass = 1.0, t_ymass = 0.0, t_v[2] = {0, 0};
@@ -365,7 +367,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
         t_n = a.po_id[o0 + threadIdx.x];
         t_flag = ft.bcflag[t_n];
         t_mass = ft.mass[t_n];
-        if (p->damping_option == 4) t_ymass = ft.ymass[t_n];
+        if (t_dopt == 4) t_ymass = ft.ymass[t_n];
         t_v[0] = ft.vel[t_n]; t_v[1] = ft.vel[nn + t_n];
         if (t_flag & BOUND_ANY) { t_b0 = ft.sbcn_idx[t_n]; t_b1 = ft.sbcn_idx[t_n + 1]; }
         if (t_flag & BOUNDZ1) t_top = ft.top_pos[t_n];
@@ -436,8 +438,8 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
             }
             // k2_node_final's statements on the values held here: apply_damping + update_velocity, apply_vbcs (the node's z
             // before it moves: the staged one), update_coordinate into the other buffer of the pair
-            const double dt = ft.clk->dt;
-            damp_vel_regs(p, dt, t_mass, t_ymass, f, t_v);
+            const double dt = t_dt;
+            damp_vel_regs(t_dopt, t_dfac, dt, t_mass, t_ymass, f, t_v);
             for (int j = 0; j < 2; j++) force[j*nn + n] = f[j];
             const double x0 = lx[threadIdx.x], z0 = lz[threadIdx.x];
             vbcs_regs(p, ft.clk, t_flag, z0, ft.bnormals, ft.edge_vec, ft.edge_slot, t_v);
