@@ -1065,6 +1065,10 @@ k2_residual_final(Clock *clk, const double *blocks, int nb)
 //  nothing before this launch reads them)
 __device__ __forceinline__ void vbc_extent_block(int nb, const int *bnodes_x0, int nn, const double *coord, Clock *clk, int tick)
 {
+    if (tick == 2) {                     // a rank of a decomposed mesh: the extent in the clock is the cross-rank one (k2_wall_set); count the step
+        if (threadIdx.x == 0) { clk->steps++; clk->time += clk->dt; }
+        return;
+    }
     __shared__ double s_max[DES_BLOCK / 64], s_min[DES_BLOCK / 64];
     double mx = -DBL_MAX, mn = DBL_MAX;
     for (int j = threadIdx.x; j < nb; j += DES_BLOCK) {
@@ -2195,9 +2199,11 @@ void launch_mechanics_far(Engine *h, bool nmd, bool thermal)
     h->far_issued = true;
 }
 
-// k2p_force<1> (the nodal tail of a plain step inside the force pass): an engine that owns the whole mesh, boundary loads
-// that can all be formed per node, no Neumann tractions / elastic foundation behind them (create: fold_ok)
-inline bool fold_now(const Engine *h) { return h->fold_on && h->fold_ok && h->patch && !h->halo && !h->no_neumann; }
+// k2p_force<1> (the nodal tail of a plain step inside the force pass): boundary loads that can all be formed per node, no Neumann
+// tractions / elastic foundation behind them (create: fold_ok).  A rank of a decomposed mesh takes it too: every local node is
+// some block's own (the ghost region goes stale as before), the wall's extent is the cross-rank one the clock already holds,
+// the residual partial only counts owned nodes.
+inline bool fold_now(const Engine *h) { return h->fold_on && h->fold_ok && h->patch && !h->no_neumann; }
 
 template <class M>
 void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = false)
@@ -2226,11 +2232,14 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
         h->geo_pending = false; h->mass_pending = false;
         const bool fold = tail && fold_now(h);
         // (the folded tail wants the wall's extent in the clock before the force pass: it rides in the nodal average's launch)
-        const bool avg_extent = fold && nmd && !wall_needs_zmin(h);
+        const bool avg_extent = fold && nmd && (h->halo || !wall_needs_zmin(h));
         if (avg_extent) {
             Prof2 pr(h, P2_NODEAVG);
-            hipLaunchKernelGGL(k2_node_avg_extent, dim3(nblk(nn) + 1), dim3(DES_BLOCK), 0, h->stream, nn, nblk(nn), h->sup_idx, h->sup_arr, h->etmp,
-                               h->volume_n, h->ntmp, h->nbn[iboundx0], h->bnodes[iboundx0], h->coord, h->d_clk, h->tick_pending ? 1 : 0);
+            // (decomposed: no local extent -- the clock holds the cross-rank one --, the extra workgroup only counts the step)
+            const int tick = h->tick_pending ? (h->halo ? 2 : 1) : 0;
+            const int extra = (h->halo && !tick) ? 0 : 1;
+            hipLaunchKernelGGL(k2_node_avg_extent, dim3(nblk(nn) + extra), dim3(DES_BLOCK), 0, h->stream, nn, nblk(nn), h->sup_idx, h->sup_arr, h->etmp,
+                               h->volume_n, h->ntmp, h->nbn[iboundx0], h->bnodes[iboundx0], h->coord, h->d_clk, tick);
             h->tick_pending = false;
         } else if (nmd) { Prof2 pr(h, P2_NODEAVG); L2(k2_node_avg, nn, nn, h->sup_idx, h->sup_arr, h->etmp, h->volume_n, h->ntmp); }
         ForceTail ft = {h->d_clk, h->mass, h->ymass, h->bcflag, h->bnormals, h->edge_vec, h->edge_slot, h->vel, h->coord_alt, h->conn,
@@ -2238,7 +2247,11 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
         if (fold) {
             // Everything nodal behind the force sums rides in k2p_force<1>.  The wall's extent first (the coordinates have not
             // moved since the step began; with it the step is counted: nothing between here and apply_vbcs reads the clock's time)
-            if (!avg_extent) { launch_vbcs(h, false, h->tick_pending); h->tick_pending = false; }
+            if (!avg_extent) {
+                if (h->halo) { join_wall(h); if (h->tick_pending) hipLaunchKernelGGL(k2_clock, dim3(1), dim3(1), 0, h->stream, h->d_clk); }
+                else launch_vbcs(h, false, h->tick_pending);
+                h->tick_pending = false;
+            } else join_wall(h);
             { Prof2 pr(h, P2_FORCE);
             hipLaunchKernelGGL(k2p_force<1>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
                                h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
@@ -2386,7 +2399,7 @@ void front_clock(Engine *h)
     const des_params &p = h->p;
     const bool tail = h->patch && !h->iso && !p.has_PT && p.has_moving_mesh;
     if (!h->iso) {
-        if (tail && !h->halo) h->tick_pending = true;      // (k2_vbc_extent counts the step)
+        if (tail && (!h->halo || fold_now(h))) h->tick_pending = true;      // (k2_vbc_extent / the nodal average's extra workgroup counts the step)
         else hipLaunchKernelGGL(k2_clock, dim3(1), dim3(1), 0, h->stream, h->d_clk);
         ++h->steps_host;
     }
