@@ -95,6 +95,8 @@ struct Engine {
     double *coord_alt = nullptr;                // the other buffer of the coordinate pair (k2p_force<1> writes the moved nodes there)
     int *sbcn_idx = nullptr; int4 *sbcn_ent = nullptr;      // per node: its boundary-facet incidences {element, facet, which node, boundary}
     double2 *xz_pre = nullptr; int *fold_top_pos = nullptr; bool xz_pre_valid = false;   // k2p_force<1>: the moved top nodes, in top_nodes order (k2_surf_commit)
+    bool radiogenic_zero = true;                // every heat source is +0.0 (the array starts zeroed; upload looks at what it is given)
+    double *dt_part = nullptr;                  // [5][nblk(ne)] compute_dt partials, one slot per workgroup of k2_dt_partials
     int res_count = 0;                          // partials in res_part[] (blocks of 256 owned nodes, or the patch blocks)
     bool geo_on = true, elide_on = true;       // DES2D_GEO / DES2D_ELIDE != 0 (read at create)
     bool elide = false;                        // this step's output-only element stores can go (a later step of the same call rewrites them)
@@ -221,6 +223,16 @@ __device__ __forceinline__ void shape_fn2(const double d[3][2], double vol, doub
     shpdz[0] = iv * (d[2][0] - d[1][0]);
     shpdz[1] = iv * (d[0][0] - d[2][0]);
     shpdz[2] = iv * (d[1][0] - d[0][0]);
+}
+
+// The five property means of an element (refresh_elem_cache, matprops.cxx:259-303: bulk modulus 0, shear modulus 1, porosity 2,
+// heat capacity 3, conductivity 4).  With ONE material the means ARE its values (matprops.cxx:118, 136: k2_props stores exactly
+// these) -- nothing to fetch: a wave-uniform branch instead of an 8-byte gather per element, pass and property (round 5).
+__device__ __forceinline__ double prop2(const des_params *p, const double *props, int ne, int e, int w)
+{
+    if (p->nmat == 1)
+        return w == 0 ? p->bulk_modulus[0] : (w == 1 ? p->shear_modulus[0] : (w == 2 ? p->porosity[0] : (w == 3 ? p->heat_capacity[0] : p->therm_cond[0])));
+    return props[(size_t)w * ne + e];
 }
 
 __device__ __forceinline__ double elemT(const double *temperature, const int *conn, int ne, int e)    // matprops.cxx:338-343
@@ -613,7 +625,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     const int e = elist ? elist[t] : t;
     const double dt = clk->dt;
     const desk::Mix mx = mix2(mono[e], markers, p->nmat, e);
-    const double bulkm = props[e], shearm = props[ne + e];
+    const double bulkm = prop2(p, props, ne, e, 0), shearm = prop2(p, props, ne, e, 1);
     double s[3], es[3], edot[3];
     for (int i = 0; i < 3; ++i) {
         s[i] = stress[i * ne + e];
@@ -1679,7 +1691,11 @@ __global__ void k2_dt_init(Clock *clk)
     clk->r_global_dt_min = DBL_MAX; clk->r_max_vem = 0.0;
 }
 
-__global__ void k2_dt_partials(const des_params *p, Clock *clk, int nn, int ne, const int *conn, const double *coord,
+// (Round 5: every workgroup stores its five partials to a slot of its own -- dt_part[q * nb + block] -- and k2_dt_reduce, one
+//  workgroup, reduces them: five thousand workgroups doing five 64-bit atomic min / max on the five words of ONE cache line
+//  serialised in the L2, 80-93 us for 1.28M triangles against 23 us for the 3-D engine's pass, which has stored partials since
+//  round 2.  min and max are exact whatever the order: the same bits.)
+__global__ void k2_dt_partials(const des_params *p, double *dt_part, int nn, int ne, const int *conn, const double *coord,
                                const double *vel, const double *temperature, const double *volume, const double *props,
                                const int *markers)
 {
@@ -1699,7 +1715,7 @@ __global__ void k2_dt_partials(const des_params *p, Clock *clk, int nn, int ne, 
         elem_coords(coord, conn, nn, ne, e, d);
         double maxl = sqrt(fmax(fmax(dist2(d[0], d[1]), dist2(d[1], d[2])), dist2(d[0], d[2])));
         double minh = 2 * volume[e] / maxl;
-        const double shearm = props[ne + e];
+        const double shearm = prop2(p, props, ne, e, 1);
         dt_maxwell = 0.5 * p->visc_min / (1e-40 + shearm);
         if (p->has_thermal_diffusion) dt_diffusion = 0.5 * minh * minh / p->therm_diff_max;
         minl = minh;
@@ -1718,16 +1734,40 @@ __global__ void k2_dt_partials(const des_params *p, Clock *clk, int nn, int ne, 
             for (int q = 0; q < 4; ++q) sm[q][0] = fmin(sm[q][0], sm[q][w]);
             sm[4][0] = fmax(sm[4][0], sm[4][w]);
         }
-        desk::atomic_min_double(&clk->r_minl, sm[0][0]);
-        desk::atomic_min_double(&clk->r_dt_maxwell, sm[1][0]);
-        desk::atomic_min_double(&clk->r_dt_diffusion, sm[2][0]);
-        desk::atomic_min_double(&clk->r_global_dt_min, sm[3][0]);
-        desk::atomic_max_double(&clk->r_max_vem, sm[4][0]);
+        const size_t nb = gridDim.x;
+        for (int q = 0; q < 5; ++q) dt_part[q * nb + blockIdx.x] = sm[q][0];
+    }
+}
+
+// ... the partials reduced into the clock's five slots by one workgroup (what k2_dt_init + the atomics left there);
+// finalize != 0: k2_dt_finalize's statements follow at once (the single engine: one launch less)
+__device__ __forceinline__ void dt_finalize_body(const des_params *p, Clock *clk);
+__global__ void __launch_bounds__(DES_BLOCK)
+k2_dt_reduce(const des_params *p, Clock *clk, const double *dt_part, int nb, int finalize)
+{
+    __shared__ double sm[5][DES_BLOCK / 64];
+    double r[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, 0.0};
+    for (int i = threadIdx.x; i < nb; i += DES_BLOCK) {
+        for (int q = 0; q < 4; ++q) r[q] = fmin(r[q], dt_part[(size_t)q * nb + i]);
+        r[4] = fmax(r[4], dt_part[(size_t)4 * nb + i]);
+    }
+    for (int q = 0; q < 4; ++q) r[q] = desk::wave_min(r[q]);
+    r[4] = desk::wave_max(r[4]);
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 5; ++q) sm[q][threadIdx.x >> 6] = r[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < DES_BLOCK / 64; ++w) {
+            for (int q = 0; q < 4; ++q) sm[q][0] = fmin(sm[q][0], sm[q][w]);
+            sm[4][0] = fmax(sm[4][0], sm[4][w]);
+        }
+        clk->r_minl = sm[0][0]; clk->r_dt_maxwell = sm[1][0]; clk->r_dt_diffusion = sm[2][0];
+        clk->r_global_dt_min = sm[3][0]; clk->r_max_vem = sm[4][0];
+        if (finalize) dt_finalize_body(p, clk);
     }
 }
 
 // ... and its tail (geometry.cxx:1597-1646)
-__global__ void k2_dt_finalize(const des_params *p, Clock *clk)
+__device__ __forceinline__ void dt_finalize_body(const des_params *p, Clock *clk)
 {
     const double minl = clk->r_minl, dt_maxwell = clk->r_dt_maxwell, dt_diffusion = clk->r_dt_diffusion;
     const double dt_hydro_diffusion = DBL_MAX;
@@ -1750,6 +1790,8 @@ __global__ void k2_dt_finalize(const des_params *p, Clock *clk)
     if (dt <= 0) clk->status = DES_ERR_RUNTIME_NAN;
     clk->dt = dt;
 }
+
+__global__ void k2_dt_finalize(const des_params *p, Clock *clk) { dt_finalize_body(p, clk); }
 
 __global__ void k2_count_nan(long long n, const double *a, unsigned long long *count)
 {
@@ -2152,9 +2194,8 @@ void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer
 void launch_dt(Engine *h)
 {
     refresh_props(h);
-    hipLaunchKernelGGL(k2_dt_init, dim3(1), dim3(1), 0, h->stream, h->d_clk);
-    L2(k2_dt_partials, h->ne, h->d_p, h->d_clk, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
-    hipLaunchKernelGGL(k2_dt_finalize, dim3(1), dim3(1), 0, h->stream, h->d_p, h->d_clk);
+    L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
+    hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 1);
 }
 
 int sync_clock(Engine *h)
@@ -2176,7 +2217,7 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
     if (a.nb == 0) return;
     Prof2 pr(h, P2_TEMP);
 #define K2T_ARGS h->d_p, h->d_clk, thermal ? 1 : 0, h->geo_pending ? 1 : 0, a, \
-                       h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic, h->props, \
+                       h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->props, \
                        h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass
     if (h->mass_pending)
         hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 4 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
@@ -2527,8 +2568,8 @@ int one_step(Engine *h, bool more = false)
 void launch_dt_partials(Engine *h)
 {
     refresh_props(h);
-    hipLaunchKernelGGL(k2_dt_init, dim3(1), dim3(1), 0, h->stream, h->d_clk);
-    L2(k2_dt_partials, h->ne, h->d_p, h->d_clk, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
+    L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
+    hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 0);
 }
 
 void launch_pack(Engine *h)
@@ -2656,6 +2697,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->etmp_int, (size_t)ne));
     A2(dalloc(h, h->dh, (size_t)h->ntop));
     A2(dalloc(h, h->edvacc, (size_t)h->etop));
+    A2(dalloc(h, h->dt_part, (size_t)5 * std::max(nblk(ne), 1)));
     A2(dalloc(h, h->res_part, (size_t)std::max(nblk(nn), nn / 16 + 2)));      // (blocks of 256 owned nodes, or the patch blocks: DES2D_PATCH >= 16)
     A2(dalloc(h, h->neg_zmin, 1));
     A2(dalloc(h, h->d_red, 8));
@@ -2835,6 +2877,13 @@ int upload(Engine *h, int field, const void *host, long long count)
     HIP2(hipStreamSynchronize(h->stream));
     if (count) HIP2(hipMemcpy(r.ptr, host, (size_t)count * r.elsize, hipMemcpyHostToDevice));
     if (field == DES_F_ELEMMARKERS) h->markers_dirty = true;
+    if (field == DES_F_RADIOGENIC) {
+        // every heat source +0.0 (ic.cxx's default)?  then the temperature pass does not fetch them: the same arithmetic on a literal 0.0
+        const unsigned long long *b = (const unsigned long long *)host;
+        bool z = true;
+        for (long long i = 0; i < count && z; ++i) z = b[i] == 0ull;
+        h->radiogenic_zero = z;
+    }
     return DES_OK;
 }
 

@@ -195,9 +195,10 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
             g_vol[k] = vol_from_coords ? 0.0 : volume[e];
-            if (thermal) { g_kc[k] = props[4 * ne + e]; g_rad[k] = radiogenic[e]; }
+            // (radiogenic == nullptr: every heat source is +0.0 -- the same arithmetic on a literal; prop2: nothing to fetch with one material)
+            if (thermal) { g_kc[k] = prop2(p, props, ne, e, 4); g_rad[k] = radiogenic ? radiogenic[e] : 0.0; }
             if (thermal || MASS) g_mono[k] = mono[e];
-            if (MASS) { g_bulk[k] = props[e]; g_shear[k] = props[ne + e]; g_cp[k] = props[3 * ne + e]; }
+            if (MASS) { g_bulk[k] = prop2(p, props, ne, e, 0); g_shear[k] = prop2(p, props, ne, e, 1); g_cp[k] = prop2(p, props, ne, e, 3); }
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
         const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
@@ -353,7 +354,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
             g_vol[k] = volume[e];
             for (int i = 0; i < 3; ++i) g_s[k][i] = stress_in[i * ne + e];
             g_dp[k] = nmd ? dpressure[e] : 0.0;
-            g_phi[k] = gravity != 0 ? props[2 * ne + e] : 0.0;
+            g_phi[k] = gravity != 0 ? prop2(p, props, ne, e, 2) : 0.0;
             g_mono[k] = gravity != 0 ? mono[e] : 0;
         }
     // TAIL: what the node phase needs of its own node is requested HERE, with everything else (one trip to memory for the
@@ -490,7 +491,7 @@ k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const doub
     for (int k = 0; k < DES2_PATCH_IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
-            g_bulk[k] = props[e]; g_shear[k] = props[ne + e]; g_cp[k] = props[3 * ne + e]; g_mono[k] = mono[e];
+            g_bulk[k] = prop2(p, props, ne, e, 0); g_shear[k] = prop2(p, props, ne, e, 1); g_cp[k] = prop2(p, props, ne, e, 3); g_mono[k] = mono[e];
         }
     for (int j = threadIdx.x; j < nown + nh; j += DES2_PATCH_THREADS) {
         const int id = j < nown ? a.po_id[o0 + j] : a.pn_id[h0 + j - nown];
