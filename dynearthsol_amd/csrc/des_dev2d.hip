@@ -127,6 +127,8 @@ struct Engine {
     ncclComm_t comm = nullptr;                 // set_comm: the exchange and the two reductions run inside step() on RCCL (not owned)
     bool markers_dirty = true, iso = false;
     bool count_past = false;           // this step feeds des_scalars::n_return_mapping (the last one of a call)
+    int *past_part = nullptr; int past_cap = 0, past_base = 0, n_past_host = 0; bool past_used = false;   // its per-wavefront counts (k2_stress)
+    std::vector<int> past_host;
     long long steps_host = 0;
     long long n_pt_iterations = 0;   // pseudo-transient iterations of the current step() call
     bool pt_defer = false;           // step_front stops in front of the pseudo-transient loop (step_group, des_dev_phase)
@@ -614,7 +616,7 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
           double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
           int nn, const double *coord, const double *vel, int rotate, int outs, const int *elist, int nlist,
-          const int *mono, const double *pptab)
+          const int *mono, const double *pptab, int *past_part, int past_base)
 {
     M::stage_begin();
     M::stage_end();
@@ -742,9 +744,12 @@ k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, co
     default: break;
     }
     if (outs) delta_plstrain[e] = dpls;
-    if (count_past) {                  // (the last step of a call only: one address, thousands of wavefronts)
+    if (count_past) {
+        // (the last step of a call only.  Every wavefront leaves its count in a slot of its own -- past_part[base + wavefront of
+        //  the launch] -- and fill_scalars adds them up: with the pure-2-D Mohr-Coulomb law EVERY element reaches the yield test,
+        //  and twenty thousand wavefronts adding to one word took 200 us, 10 us per step of a 20-step call; round 5)
         const unsigned long long b = __ballot(past);
-        if (b && (int)(threadIdx.x & 63) == __ffsll((long long)b) - 1) atomicAdd(&clk->n_past, (int)__popcll(b));
+        if ((threadIdx.x & 63) == 0) past_part[past_base + (int)(blockIdx.x * (DES_BLOCK / 64) + (threadIdx.x >> 6))] = (int)__popcll(b);
     }
     if (p->is_using_mixed_stress) {
         const double dp = trace2(s) - old_s;
@@ -1985,7 +1990,8 @@ static const char *const p2_names[P2_COUNT] = {"K2P_temp_dvoldt", "K2_stress", "
 struct Prof2 {
     Engine *h; Engine::ProfRec rec; bool on; hipStream_t s;
     Prof2(Engine *h_, int k, hipStream_t s_ = nullptr) : h(h_), on(h_->prof), s(s_ ? s_ : h_->stream)
-    { if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, s); } }
+    { if (on) { hipEventCreateWithFlags(&rec.a, hipEventDisableSystemFence); hipEventCreateWithFlags(&rec.b, hipEventDisableSystemFence);       // (timing-only events: engine/launch.hpp)
+                rec.k = k; hipEventRecord(rec.a, s); } }
     ~Prof2() { if (on) { hipEventRecord(rec.b, s); h->prof_recs.push_back(rec); } }
 };
 
@@ -2045,13 +2051,17 @@ void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr, 
 {
     if (nlist < 0) nlist = h->ne;
     if (nlist == 0) return;
-    if (h->count_past && first) hipMemsetAsync(&h->d_clk->n_past, 0, sizeof(int), h->stream);    // the count of THIS update_stress
+    // the count of THIS update_stress: one slot per wavefront, zeroed once per counted step (a split update -- the overlapped
+    // schedule's far and near elements -- writes the second launch's slots behind the first's)
+    if (h->count_past && first) { hipMemsetAsync(h->past_part, 0, (size_t)h->past_cap * sizeof(int), h->stream); h->past_base = 0; h->past_used = true; }
+    const int past_base = h->past_base;
+    if (h->count_past) h->past_base += nblk(nlist) * (DES_BLOCK / 64);
     Prof2 pr(h, P2_STRESS);
     const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? 1 : 0;
 #define K2S_ARGS(out, outs) h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt, \
         h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain, \
         h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, out, h->nn, h->coord, h->vel, rot, outs, elist, nlist, \
-        h->mono, h->pptab
+        h->mono, h->pptab, h->past_part, past_base
     if (fused && h->p.rheol_type == DES_RH_EVP) {          // the common rheology has instantiations of its own
         if (h->geo_pending) L2((k2_stress<M, 2, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
         else                L2((k2_stress<M, 1, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
@@ -2698,6 +2708,8 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
     A2(dalloc(h, h->dh, (size_t)h->ntop));
     A2(dalloc(h, h->edvacc, (size_t)h->etop));
     A2(dalloc(h, h->dt_part, (size_t)5 * std::max(nblk(ne), 1)));
+    h->past_cap = (nblk(ne) + 2) * (DES_BLOCK / 64);        // (+ the round-up of a split update's two launches)
+    A2(dalloc(h, h->past_part, (size_t)h->past_cap));
     A2(dalloc(h, h->res_part, (size_t)std::max(nblk(nn), nn / 16 + 2)));      // (blocks of 256 owned nodes, or the patch blocks: DES2D_PATCH >= 16)
     A2(dalloc(h, h->neg_zmin, 1));
     A2(dalloc(h, h->d_red, 8));
@@ -2952,7 +2964,16 @@ static int fill_scalars(Engine *h, des_scalars *out)
     const Clock &c = *h->h_clk;
     out->dt = c.dt; out->time = c.time; out->l2_residual = c.l2_residual; out->max_surf_vel = c.max_surf_vel;
     out->max_global_vel_mag = c.max_global_vel_mag; out->global_dt_min = c.global_dt_min; out->steps = c.steps;
-    out->status = c.status; out->n_return_mapping = c.n_past; out->avg_time0 = c.avg_time0; out->n_pt_iterations = h->n_pt_iterations;
+    if (h->past_used) {
+        // des_scalars::n_return_mapping of the call's last update_stress: the wavefronts' counts (k2_stress), added here
+        h->past_host.resize((size_t)h->past_cap);
+        if (hipMemcpy(h->past_host.data(), h->past_part, (size_t)h->past_cap * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return DES_ERR_RESOURCE;
+        long long n = 0;
+        for (int v : h->past_host) n += v;
+        h->n_past_host = (int)n;
+        h->past_used = false;
+    }
+    out->status = c.status; out->n_return_mapping = h->n_past_host; out->avg_time0 = c.avg_time0; out->n_pt_iterations = h->n_pt_iterations;
     return c.status;
 }
 

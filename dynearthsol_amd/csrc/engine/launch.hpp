@@ -39,7 +39,11 @@ inline int nblk8(long long n) { int b = nblk(n); return (b + 7) / 8 * 8; }
 struct Launch {
     des_dev *h; int k; ProfRec rec; bool on; hipStream_t s;
     Launch(des_dev *h_, int k_, hipStream_t s_ = nullptr) : h(h_), k(k_), on(h_->prof), s(s_ ? s_ : h_->stream) {
-        if (on) { hipEventCreate(&rec.a); hipEventCreate(&rec.b); rec.k = k; hipEventRecord(rec.a, s); }
+        // (timing-only events: no system-scope fence when they complete -- hip_runtime_api.h: hipEventDisableSystemFence, "for events
+        //  that are only being used to measure timing ... avoiding the cost of cache writeback and invalidation"; with the default
+        //  flags the end event of a pass that has just written ~100 MB also times the write-back of the dirty L2 lines, which a
+        //  dependent kernel of the same stream never waits for: the 2-D stress update read 79 us by events against 71 by rocprofv3)
+        if (on) { hipEventCreateWithFlags(&rec.a, hipEventDisableSystemFence); hipEventCreateWithFlags(&rec.b, hipEventDisableSystemFence); rec.k = k; hipEventRecord(rec.a, s); }
     }
     ~Launch() { if (on) { hipEventRecord(rec.b, s); h->prof_recs.push_back(rec); } }
 };
