@@ -537,7 +537,7 @@ def main():
             # surface step rides in the next step's EN1 / E2 unless DES_S2_DEFER=0) -- a shorter call has a larger share
             # of the slower first / last steps
             "steps_per_call": args.steps,
-            "surface_step_in_next_steps_passes": os.environ.get("DES_S2_DEFER", "1") != "0",
+            "surface_step_in_next_steps_passes": os.environ.get("DES2D_SURF_DEFER" if args.ndims == 2 else "DES_S2_DEFER", "1") != "0",
             "first_step_on_finished_state": world == 1 and os.environ.get("DES_FRESH", "1") != "0" and args.warmup > 0,
         },
     }

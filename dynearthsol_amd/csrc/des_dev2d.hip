@@ -94,6 +94,13 @@ struct Engine {
     bool fold_on = true, fold_ok = false;
     double *coord_alt = nullptr;                // the other buffer of the coordinate pair (k2p_force<1> writes the moved nodes there)
     int *sbcn_idx = nullptr; int4 *sbcn_ent = nullptr;      // per node: its boundary-facet incidences {element, facet, which node, boundary}
+    // (round 5) a plain step inside a multi-step call leaves its surface step to the next step's first two passes as well
+    // (one_step: surf_late -> surf_pending; DES2D_SURF_DEFER=0: off); topflag: the top elements
+    bool surf_defer_on = true, surf_late = false, surf_pending = false;
+    unsigned char *topflag = nullptr;
+    int *pt_ptr = nullptr, *pt_zero = nullptr; int4 *pt_ent = nullptr; bool surf_defer_fits = true;
+    int *d_bperm = nullptr;                      // the blocks in launch order: every XCD its share of the surface blocks, first
+    unsigned char *d_surfpre = nullptr;          // (a SurfPre, des_dev2d_patch.hpp)
     double2 *xz_pre = nullptr; int *fold_top_pos = nullptr; bool xz_pre_valid = false;   // k2p_force<1>: the moved top nodes, in top_nodes order (k2_surf_commit)
     bool radiogenic_zero = true;                // every heat source is +0.0 (the array starts zeroed; upload looks at what it is given)
     double *dt_part = nullptr;                  // [5][nblk(ne)] compute_dt partials, one slot per workgroup of k2_dt_partials
@@ -1388,6 +1395,34 @@ __global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, in
     if (i < ntop) surf_node_at(i, p, clk, ntop, nn, ne, top_nodes, etmp, tmp_result, total_dx, total_slope, coord, dhacc, dh);
 }
 
+// a top node's step of simple_diffusion (bc.cxx:1709-1787) from the moved {x, z} of the top nodes in top_nodes order
+// (a, c, b: the entries of node i - 1, i, i + 1; a / b unused at the ends of the line)
+__device__ __forceinline__ double surf_commit_dh_regs(const des_params *p, double dt, int ntop, int i, const double2 a, const double2 c, const double2 b,
+                                                      double &tdx, double &tsl)
+{
+    // the segment to the left (i - 1 .. i) and to the right (i .. i + 1): dx, and the two slope terms surf_seg_at stores
+    double dxl = 0, sl1 = 0, dxr = 0, sr0 = 0;
+    if (i > 0) { dxl = fabs(c.x - a.x); sl1 = (c.y - a.y) / dxl; }
+    if (i < ntop - 1) { dxr = fabs(b.x - c.x); sr0 = -(b.y - c.y) / dxr; }
+    if (i == 0) { tdx = dxr; tsl = sr0; }
+    else if (i == ntop-1) { tdx = dxl; tsl = sl1; }
+    else { tdx = dxl + dxr; tsl = sl1 + sr0; }
+    double d = 0.;
+    double conv = p->surface_diffusivity * dt * tsl / tdx;
+    const double z = c.y;
+    if (z > p->surf_base_level && conv > 0.) d -= p->surf_diff_ratio_terrig * conv;
+    else if (z <= p->surf_base_level && conv < 0.) d -= p->surf_diff_ratio_marine * conv;
+    else d -= conv;
+    return d;
+}
+
+__device__ __forceinline__ double surf_commit_dh(const des_params *p, double dt, int ntop, int i, const double2 *xz_pre, double &tdx, double &tsl)
+{
+    const double2 c = xz_pre[i];
+    const double2 a = i > 0 ? xz_pre[i - 1] : c, b = i < ntop - 1 ? xz_pre[i + 1] : c;
+    return surf_commit_dh_regs(p, dt, ntop, i, a, c, b, tdx, tsl);
+}
+
 // Round 5: segments + nodes of simple_diffusion in ONE launch (the plain step of the patch path with the nodal tail folded
 // into the force pass).  A node needs the two segments it sits between; each is a function of its two end nodes alone, so the
 // node's lane forms both itself -- surf_seg_at's expressions -- instead of a launch of its own writing them first.  What
@@ -1403,22 +1438,10 @@ __global__ void k2_surf_commit(const des_params *p, Clock *clk, int ntop, int nn
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (i >= ntop) return;
     const int n = top_nodes[i];
-    const double2 c = xz_pre[i];
-    // the segment to the left (i - 1 .. i) and to the right (i .. i + 1): dx, and the two slope terms surf_seg_at stores
-    double dxl = 0, sl1 = 0, dxr = 0, sr0 = 0;
-    if (i > 0) { const double2 a = xz_pre[i - 1]; dxl = fabs(c.x - a.x); sl1 = (c.y - a.y) / dxl; }
-    if (i < ntop - 1) { const double2 b = xz_pre[i + 1]; dxr = fabs(b.x - c.x); sr0 = -(b.y - c.y) / dxr; }
     double tdx, tsl;
-    if (i == 0) { tdx = dxr; tsl = sr0; }
-    else if (i == ntop-1) { tdx = dxl; tsl = sl1; }
-    else { tdx = dxl + dxr; tsl = sl1 + sr0; }
+    const double d = surf_commit_dh(p, clk->dt, ntop, i, xz_pre, tdx, tsl);
+    const double z = xz_pre[i].y;
     total_dx[n] = tdx; total_slope[n] = tsl;
-    double d = 0.;
-    double conv = p->surface_diffusivity * clk->dt * tsl / tdx;
-    const double z = c.y;
-    if (z > p->surf_base_level && conv > 0.) d -= p->surf_diff_ratio_terrig * conv;
-    else if (z <= p->surf_base_level && conv < 0.) d -= p->surf_diff_ratio_marine * conv;
-    else d -= conv;
     dh[i] = d;
     coord[nn + n] = z + d;
     dhacc[n] += d;
@@ -2016,7 +2039,7 @@ inline bool wall_needs_zmin(const Engine *h) { return h->p.vbc_types[0] == 3 && 
 inline PatchArgs patch_args(const Engine *h)
 {
     PatchArgs a = {h->nn, h->ne, h->p_npb, h->p_nb, h->p_pn_cap, h->p_inc_cap, h->po_ptr, h->po_id, h->po_slot, h->pe_ptr, h->pe_pack, h->pn_ptr,
-                   h->pn_id, h->sup_idx, nullptr};
+                   h->pn_id, h->sup_idx, h->d_bperm};
     return a;
 }
 
@@ -2184,7 +2207,7 @@ void launch_patch_mass(Engine *h, const int *blist = nullptr, int nb = -1, const
 // ... and compute_volume, rotate_stress, compute_mass
 void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer = false)
 {
-    launch_update_mesh_surface(h, steps);
+    if (!h->surf_pending) launch_update_mesh_surface(h, steps);
     if (!defer) std::swap(h->volume, h->volume_old);
     refresh_props(h);
     if (h->patch) {
@@ -2228,9 +2251,16 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
     Prof2 pr(h, P2_TEMP);
 #define K2T_ARGS h->d_p, h->d_clk, thermal ? 1 : 0, h->geo_pending ? 1 : 0, a, \
                        h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->props, \
-                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass
+                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass, pre, nb_tail, pre ? h->pt_ptr : h->pt_zero
+    const SurfPre *pre = nullptr;
+    int nb_tail = 0;
+    if (h->surf_pending && h->mass_pending) {
+        // (the surface step the step before left behind: one_step)
+        nb_tail = ((h->etop + DES2_PATCH_THREADS - 1) / DES2_PATCH_THREADS + 7) / 8 * 8;     // (in front of the blocks: a multiple of 8)
+        pre = reinterpret_cast<const SurfPre *>(h->d_surfpre);
+    }
     if (h->mass_pending)
-        hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 4 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
+        hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 4 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
     else
         hipLaunchKernelGGL(k2p_temp_dvoldt<0>, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
 #undef K2T_ARGS
@@ -2280,7 +2310,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             launch_temp_dvoldt(h, thermal, T_in, T_out);
             launch_stress<M>(h, true, s_law);
         }
-        h->geo_pending = false; h->mass_pending = false;
+        h->geo_pending = false; h->mass_pending = false; h->surf_pending = false;
         const bool fold = tail && fold_now(h);
         // (the folded tail wants the wall's extent in the clock before the force pass: it rides in the nodal average's launch)
         const bool avg_extent = fold && nmd && (h->halo || !wall_needs_zmin(h));
@@ -2310,7 +2340,9 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             std::swap(h->coord, h->coord_alt);             // the moved coordinates are the current ones from here on
             h->xz_pre_valid = true;
             h->res_count = h->p_nb;
-            if (h->p.surface_process_option == 1 && h->etop > 0) h->res_fin_pending = true;
+            // (surf_late: never the last step of a call -- nothing reads this step's residual sum)
+            if (h->surf_late) ;
+            else if (h->p.surface_process_option == 1 && h->etop > 0) h->res_fin_pending = true;
             else hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->res_count, h->res_part, h->d_clk);
             return;
         }
@@ -2499,7 +2531,9 @@ int step_front_rest(Engine *h)
     else if (!tail) launch_vbcs(h);
     if (p.has_moving_mesh || h->iso) {
         if (!tail) L2(k2_update_coord, 2 * nn, h->d_clk, 2 * nn, h->vel, h->coord);
-        launch_surface_commit(h);
+        // (surf_late: xz_pre keeps the moved top nodes for the next step's k2p_temp_dvoldt<1>)
+        if (h->surf_late && h->xz_pre_valid) { h->xz_pre_valid = false; h->surf_pending = true; }
+        else launch_surface_commit(h);
     }
     if (h->res_fin_pending) {
         hipLaunchKernelGGL(k2_residual_fin, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->res_count, h->res_part, h->d_clk);
@@ -2559,6 +2593,17 @@ void step_back(Engine *h, bool more = false)
     }
 }
 
+// ... and so does the surface step (simple_diffusion, edvacc_surf, correct_surface_element): a single engine on the folded
+// patch path, on a step that is neither a compute_dt step (it wants max_surf_vel) nor one of the quality-check interval
+// (plastic-strain decay, dhacc reset).  `steps`: the number this step will carry.
+inline bool surf_late_ok(const Engine *h, bool more, long long steps)
+{
+    const des_params &p = h->p;
+    return more && h->surf_defer_on && h->surf_defer_fits && h->topflag && !h->halo && !h->iso && h->patch && p.has_moving_mesh && (p.rheol_type & DES_RH_ELASTIC)
+           && !p.is_outputting_averaged_fields && !p.has_PT && steps % 10 != 0 && steps % p.quality_check_step_interval != 0
+           && h->geo_on && h->mass_fuse_on && fold_now(h) && p.surface_process_option == 1 && h->etop > 0 && h->ntop > 0;
+}
+
 inline bool elide_ok(const Engine *h, bool more)
 {
     return more && h->patch && !h->iso && !h->p.has_PT && !h->p.is_outputting_averaged_fields && h->elide_on;
@@ -2568,7 +2613,9 @@ template <class M>
 int one_step(Engine *h, bool more = false)
 {
     h->elide = elide_ok(h, more);
+    h->surf_late = surf_late_ok(h, more, h->steps_host + 1);
     int rc = step_front<M>(h);
+    h->surf_late = false;
     if (rc) return rc;
     step_back(h, more);
     if (!h->iso && h->steps_host % 10 == 0) launch_dt(h);
@@ -2740,6 +2787,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                              (double)P.pe_pack.size() / ne);
             A2(dcopy(h, h->po_ptr, P.po_ptr.data(), P.po_ptr.size()));
             A2(dcopy(h, h->po_id, P.po_id.data(), P.po_id.size()));
+            { const std::vector<int> z((size_t)P.nb + 1, 0); A2(dcopy(h, h->pt_zero, z.data(), z.size())); }
             A2(dcopy(h, h->po_slot, P.po_slot.data(), P.po_slot.size()));
             A2(dcopy(h, h->pe_ptr, P.pe_ptr.data(), P.pe_ptr.size()));
             A2(dcopy(h, h->pe_pack, P.pe_pack.data(), P.pe_pack.size()));
@@ -2818,10 +2866,66 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                         for (int i = 0; i < h->ntop; ++i) tpos[mesh->top_nodes[i]] = i;
                         A2(dcopy(h, h->fold_top_pos, tpos.data(), tpos.size()));
                         A2(dalloc(h, h->xz_pre, (size_t)std::max(h->ntop, 1)));
+                        std::vector<unsigned char> tf((size_t)ne, 0), bt((size_t)std::max(h->p_nb, 1), 0);
+                        for (int i = 0; i < h->ntop_elems; ++i) tf[mesh->top_elems[i]] = 1;
+                        for (int b = 0; b < h->p_nb; ++b) {
+                            for (int k = h->hp_po_ptr[b]; k < h->hp_po_ptr[b + 1] && !bt[b]; ++k) if (tpos[h->hp_po_id[k]] >= 0) bt[b] = 1;
+                            for (int k = h->hp_pn_ptr[b]; k < h->hp_pn_ptr[b + 1] && !bt[b]; ++k) if (tpos[h->hp_pn_id[k]] >= 0) bt[b] = 1;
+                        }
+                        A2(dcopy(h, h->topflag, tf.data(), tf.size()));
+                        // The surface blocks carry extra work (the boundary loads and the top nodes' bookkeeping in k2p_force<1>, the
+                        // late surface step in k2p_temp_dvoldt<1>) and the Morton order packs them into two of the eight
+                        // contiguous runs desk::logical_block hands the XCDs: those two then finish late (k2p_temp_dvoldt<1>: 70 us
+                        // against 59).  Launch order: run k = an eighth of the surface blocks, first, then its share of the others,
+                        // both in Morton order.  (Which block does what does not change: results are the same bits.)
+                        const char *be = des_env::get("DES2D_TOP_BALANCE");
+                        if (!h->halo && h->p_nb >= 64 && !(be && be[0] == '0')) {
+                            std::vector<int> T, O, perm;
+                            for (int b = 0; b < h->p_nb; ++b) (bt[b] ? T : O).push_back(b);
+                            const int per = (h->p_nb + 7) / 8;
+                            size_t ot = 0;
+                            for (int k = 0; k < 8; ++k) {
+                                const int want = std::max(0, std::min(per, h->p_nb - k * per));
+                                const size_t t0 = T.size() * k / 8, t1 = T.size() * (k + 1) / 8;
+                                int got = 0;
+                                for (size_t t = t0; t < t1 && got < want; ++t, ++got) perm.push_back(T[t]);
+                                for (; got < want && ot < O.size(); ++got) perm.push_back(O[ot++]);
+                            }
+                            // (a run too short for its share of the surface blocks: the rest of either list goes to the end -- never in practice)
+                            if ((int)perm.size() == h->p_nb) {
+                                std::vector<char> seen((size_t)h->p_nb, 0);
+                                bool ok = true;
+                                for (int b : perm) { if (seen[b]) ok = false; seen[b] = 1; }
+                                if (ok) A2(dcopy(h, h->d_bperm, perm.data(), perm.size()));
+                            }
+                        }
+                        // per block: the top nodes of its patch, {staged slot, position in top_nodes, node}
+                        {
+                            std::vector<int> pp(1, 0);
+                            std::vector<int4> pe;
+                            bool fits = true;
+                            for (int b = 0; b < h->p_nb; ++b) {
+                                const int nown = h->hp_po_ptr[b + 1] - h->hp_po_ptr[b];
+                                for (int k = h->hp_po_ptr[b]; k < h->hp_po_ptr[b + 1]; ++k)
+                                    if (tpos[h->hp_po_id[k]] >= 0) pe.push_back(make_int4(k - h->hp_po_ptr[b], tpos[h->hp_po_id[k]], h->hp_po_id[k], 0));
+                                for (int k = h->hp_pn_ptr[b]; k < h->hp_pn_ptr[b + 1]; ++k)
+                                    if (tpos[h->hp_pn_id[k]] >= 0) pe.push_back(make_int4(nown + k - h->hp_pn_ptr[b], tpos[h->hp_pn_id[k]], h->hp_pn_id[k], 0));
+                                if ((int)pe.size() - pp.back() > DES2_PATCH_THREADS) fits = false;      // (one lane per entry)
+                                pp.push_back((int)pe.size());
+                            }
+                            if (pe.empty()) pe.push_back(make_int4(0, 0, 0, 0));
+                            A2(dcopy(h, h->pt_ptr, pp.data(), pp.size()));
+                            A2(dcopy(h, h->pt_ent, pe.data(), pe.size()));
+                            if (!fits) h->surf_defer_fits = false;
+                        }
+                        const SurfPre sp = {h->xz_pre, h->pt_ptr, h->pt_ent, h->topflag, h->ntop, h->etop, h->ean, h->conn_surf, h->total_dx,
+                                            h->total_slope, h->dhacc, h->dh, h->edvacc, h->plstrain, h->stress, h->strain};
+                        A2(dcopy(h, h->d_surfpre, reinterpret_cast<const unsigned char *>(&sp), sizeof(sp)));
                     }
                     h->fold_ok = true;
                 }
                 const char *fe = des_env::get("DES2D_FOLD"); h->fold_on = !(fe && fe[0] == '0');
+                const char *se = des_env::get("DES2D_SURF_DEFER"); h->surf_defer_on = !(se && se[0] == '0');
             }
             A2(dalloc(h, h->stress_pre, (size_t)3 * ne));
         }
@@ -3042,7 +3146,7 @@ static int step_abort(Engine *h, int rc)
 {
     hipStreamSynchronize(h->xstream);
     hipStreamSynchronize(h->stream);
-    h->join_pending = false; h->wall_pending = false; h->far_issued = false; h->mass_pending = false;
+    h->join_pending = false; h->wall_pending = false; h->far_issued = false; h->mass_pending = false; h->surf_pending = false;
     static const int zero = 0;
     hipMemcpy(&h->d_clk->pt, &zero, sizeof(int), hipMemcpyHostToDevice);     // a loop the error may have come from
     h->no_neumann = false;

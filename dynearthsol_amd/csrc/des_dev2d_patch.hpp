@@ -150,9 +150,11 @@ __device__ __forceinline__ PatchElem2 patch_elem2(const ulonglong2 r)
 // decomposed mesh: the blocks far from the cut first, the others behind the join with the exchange)
 struct PatchArgs { int nn, ne, npb, nb, pn_cap, inc_cap; const int *po_ptr, *po_id, *po_slot, *pe_ptr; const ulonglong2 *pe_pack; const int *pn_ptr, *pn_id, *sup_idx;
                    const int *blist; };
-__device__ __forceinline__ int patch_block(const PatchArgs &a)
+__device__ __forceinline__ int patch_block(const PatchArgs &a, int front = 0)
 {
-    const int b = desk::logical_block(a.nb);
+    // (front: workgroups in front of the blocks' -- a multiple of 8, so that the blocks keep their XCDs)
+    const int id = (int)blockIdx.x - front, per = (a.nb + 7) >> 3;
+    const int b = (id & 7) * per + (id >> 3);              // desk::logical_block
     if (b >= a.nb) return -1;
     return a.blist ? a.blist[b] : b;
 }
@@ -164,22 +166,59 @@ __device__ __forceinline__ int patch_block(const PatchArgs &a)
 // the volumes from the coordinates as there; only together with vol_from_coords, i.e. on the steps whose end-of-step element
 // pass was left to the coming stress update): the four sums of a node go first -- their LDS slots are then reused for this
 // pass's two -- and the node's lane keeps volume_n and tmass for its own update.  One patch pass per step instead of two.
+// pre.xz_pre (round 5, MASS = 1 only): the surface step of the step BEFORE rides here as well (one_step: surf_late).
+//  - simple_diffusion (bc.cxx:1709-1787): that step's k2p_force<1> left the moved top nodes in xz_pre; a top node's committed
+//    height is a function of its own and its two surface neighbours' entries alone (surf_commit_dh: k2_surf_commit's
+//    statements), so every block that stages a top node forms the same height for it -- never using the z in memory, which
+//    the node's own block is replacing meanwhile -- and the node's own lane stores what k2_surf_commit stores;
+//  - correct_surface_element's element part (bc.cxx:1655-1707): the block that owns a top element rescales it at the end, on
+//    the area of the staged (committed) coordinates -- cse_elem_at's statements; the coming k2_stress<M, 2> then finds in
+//    volume[] the value compute_volume would find again (its nodal part is this pass's compute_mass anyway);
+//  - edvacc_surf (bc.cxx:1788-1805): `nb_front` workgroups in front of the blocks', each segment from its two end
+//    nodes' surf_commit_dh.
+// pt_ptr / pt_ent: per block, the top nodes its patch holds as {staged slot, position in top_nodes, node, -}.
+// (the struct lives in device memory -- `pre` is nullptr on every other step --: as kernel arguments its nineteen words cost the
+//  pass 48 spilled SGPRs and 16 us.  coord and volume, which the host swaps, are the pass's own arguments.)
+struct SurfPre { const double2 *xz_pre; const int *pt_ptr; const int4 *pt_ent; const unsigned char *topflag; int ntop, etop; const int *ean, *conn_surf;
+                 double *total_dx, *total_slope, *dhacc, *dh, *edvacc, *plstrain, *stress, *strain; };
+
 template <int MASS>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from_coords, const PatchArgs a, const unsigned *bcflag,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
                 const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass_in, const double *volume_n_in,
-                double *ntmp, double *strain_rate, double *volume_n_out, double *mass_out, double *tmass_out, double *ymass_out)
+                double *ntmp, double *strain_rate, double *volume_n_out, double *mass_out, double *tmass_out, double *ymass_out,
+                const SurfPre *pre, int nb_front, const int *pt_ptr)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
     double *const lf0 = lT + a.pn_cap, *const lf1 = lf0 + a.inc_cap;
     double *const lf2 = lf1 + a.inc_cap, *const lf3 = lf2 + a.inc_cap;          // (MASS only: the launch sizes the LDS)
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
-    const int b = patch_block(a), nn = a.nn, ne = a.ne;
+    const int nn = a.nn, ne = a.ne;
+    if (MASS && (int)blockIdx.x < nb_front) {
+        // (in front: at the end of the grid they would start when the last blocks do and finish after them)
+        const int i = (int)blockIdx.x * DES2_PATCH_THREADS + threadIdx.x;
+        if (i < pre->etop) {
+            // surf_edv_at's statements, the two heights from the nodes' own step
+            double dh_e = 0., tdx, tsl;
+            for (int j = 0; j < 2; j++) dh_e += surf_commit_dh(p, clk->dt, pre->ntop, pre->ean[j * pre->etop + i], pre->xz_pre, tdx, tsl);
+            const double base = fabs(coord[pre->conn_surf[i]] - coord[pre->conn_surf[pre->etop + i]]);
+            pre->edvacc[i] += dh_e * base / 2;
+        }
+        return;
+    }
+    const int b = patch_block(a, MASS ? nb_front : 0);
     if (b < 0) return;
     const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
+    // (pt_ptr: SurfPre's, or all zeros on the other steps -- an argument of its own and read unconditionally, so that the
+    //  request goes out beside the block's other list bounds: behind `pre->` and a test it was two more trips for EVERY block)
+    const int pt0 = MASS ? pt_ptr[b] : 0, npt = MASS ? pt_ptr[b + 1] - pt0 : 0;
+    const bool topb = npt > 0;
+    // (read here, in front of everything the pass may store: two scalar loads -- behind the surface blocks' part the compiler
+    //  makes them per-lane loads inside the compute_mass loop)
+    const double pseudo_speed = MASS ? p->max_vbc_val * p->inertial_scaling : 0.0;
     // everything that does not depend on the staged records is loaded first, so that a workgroup's trips to memory overlap:
     // this lane's list entries, then the element data they name, beside the nodal records
     ulonglong2 rec[DES2_PATCH_IT];
@@ -205,6 +244,17 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
         lx[j] = coord[id]; lz[j] = coord[nn + id]; lvx[j] = vel[id]; lvz[j] = vel[nn + id]; lT[j] = T_in[id];
     }
     __syncthreads();
+    if (topb) {
+        // A surface block (one in twenty).  The staged z of a top node is stale or half-way replaced: the committed one goes
+        // over it.  Nothing is stored to memory here -- see the end of the pass.
+        if ((int)threadIdx.x < npt) {
+            const int4 en = pre->pt_ent[pt0 + threadIdx.x];
+            double t_tdx, t_tsl;
+            const double t_d = surf_commit_dh(p, clk->dt, pre->ntop, en.y, pre->xz_pre, t_tdx, t_tsl);
+            lz[en.x] = pre->xz_pre[en.y].y + t_d;
+        }
+        __syncthreads();
+    }
     double my_vn = 0, my_tm = 0;
     if (MASS) {
         const int mass_thermal = p->has_thermal_diffusion;
@@ -223,7 +273,6 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
             for (int i = 0; i < 3; ++i) Te += lT[E.ln[i]];
             Te /= 3;
             const double mrho = desk::mat_rho(p, mx, Te);
-            const double pseudo_speed = p->max_vbc_val * p->inertial_scaling;
             double rho = p->is_quasi_static ? bulkm / (pseudo_speed * pseudo_speed) : mrho;
             double m = rho * vol / 3;
             double tm = mrho * g_cp[k] * vol / 3;
@@ -305,6 +354,43 @@ k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from
                 double tdot = 0;
                 for (int k = r0; k < r1; ++k) tdot += lf0[k];
                 T_out[n] = lT[threadIdx.x] - clk->dt * tdot / (MASS ? my_tm : tmass_in[n]);
+            }
+        }
+    }
+    if (topb) {
+        // The late surface step's stores, all at the very end: a store through a pointer the compiler cannot tell from `p`
+        // turns every later read of the parameters from a scalar load into a per-lane one (three in the compute_mass loop alone;
+        // with the stores up front the pass was 6 us longer for EVERY block).  The heights once more, then
+        // correct_surface_element's element part by the block that owns the element (lx / lz still hold the staged patch).
+        if ((int)threadIdx.x < npt) {
+            const int4 en = pre->pt_ent[pt0 + threadIdx.x];
+            const int t_slot = en.x, t_pos = en.y, t_node = en.z;
+            if (t_slot < nown) {
+                double t_tdx, t_tsl;
+                const double t_d = surf_commit_dh(p, clk->dt, pre->ntop, t_pos, pre->xz_pre, t_tdx, t_tsl);
+                pre->total_dx[t_node] = t_tdx; pre->total_slope[t_node] = t_tsl;
+                pre->dh[t_pos] = t_d;
+                const_cast<double *>(coord)[nn + t_node] = pre->xz_pre[t_pos].y + t_d;
+                pre->dhacc[t_node] += t_d;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DES2_PATCH_IT; ++k) {
+            if (q0 + k * DES2_PATCH_THREADS >= qe) break;
+            const PatchElem2 E = patch_elem2(rec[k]);
+            const int e = E.e;
+            if (!E.owner || !pre->topflag[e]) continue;
+            double d[3][2];
+            for (int i = 0; i < 3; ++i) { d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; }
+            const double new_volumes = triangle_area(d[0], d[1], d[2]);
+            const double rdv = new_volumes / volume[e];
+            const_cast<double *>(volume)[e] = new_volumes;
+            if (!(rdv < 1.0)) {
+                pre->plstrain[e] = pre->plstrain[e] / rdv;
+                for (int j = 0; j < 3; j++) {
+                    pre->stress[j*ne+e] /= rdv;
+                    pre->strain[j*ne+e] /= rdv;
+                }
             }
         }
     }

@@ -131,6 +131,31 @@ def test_320k_triangles_500_steps_against_the_oracle_on_the_c_library():
     assert (dev.download("PLSTRAIN") > 0).sum() > 100
 
 
+def test_late_surface_step_across_every_kind_of_call_boundary():
+    """Round 5: a plain step inside a multi-step call leaves its surface step (simple_diffusion, edvacc_surf,
+    correct_surface_element) to the next step's k2p_temp_dvoldt<1> -- except on compute_dt steps, on the steps of the
+    quality-check interval and on the last step of a call.  Call lengths that put every one of those next to every other,
+    on a mesh with enough blocks for the balanced launch order (DES2D_TOP_BALANCE): all fields, dh / dhacc / edvacc_surf
+    among them, equal to the oracle's after every call -- and to an engine with both switched off."""
+    import os
+    kw = dict(cfgs.EVP, nmat=2, lx=100e3, lz=30e3, res=500.0, qcsi=7, water="yes", control="surf_base_level = -100\nsurf_diff_ratio_marine = 0.5\n")
+    host = des.Host(cfg_text=cfgs.make(**kw), ndims=2)
+    dev, ora = des.DeviceEngine(host), OracleEngine(host, omp=True)
+    os.environ["DES2D_SURF_DEFER"] = "0"; os.environ["DES2D_TOP_BALANCE"] = "0"
+    try:
+        plain = des.DeviceEngine(host)
+    finally:
+        del os.environ["DES2D_SURF_DEFER"], os.environ["DES2D_TOP_BALANCE"]
+    assert dev.init_from_host(host) == ora.init_from_host(host) == plain.init_from_host(host)
+    for n in (1, 2, 3, 9, 10, 11, 19, 7, 14, 41):
+        sd, so, sp = dev.step(n), ora.step(n), plain.step(n)
+        assert (sd.dt, sd.time, sd.steps, sd.max_surf_vel) == (so.dt, so.time, so.steps, so.max_surf_vel) == (sp.dt, sp.time, sp.steps, sp.max_surf_vel)
+        assert sd.l2_residual == sp.l2_residual
+        assert_bit_exact(dev, ora)
+        assert_bit_exact(dev, plain)
+    assert np.abs(dev.download("DH")).max() > 0 and np.abs(dev.download("EDVACC_SURF")).max() > 0
+
+
 @pytest.mark.parametrize("rheol", ["elasto-plastic", "elasto-visco-plastic"])
 def test_plane_strain_elasto_plastic2d_is_bit_exact(rheol):
     # mat.is_plane_strain: elasto_plastic2d with the out-of-plane stress (rheology.cxx:486-701)
@@ -258,7 +283,7 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
 
 
 @pytest.mark.parametrize("knob", ["DES2D_PATCH=0", "DES2D_PATCH=64", "DES2D_PATCH=40", "DES2D_CLUSTER=0", "DES2D_GEO=0", "DES2D_ELIDE=0",
-                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0", "DES2D_FOLD=0"])
+                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0", "DES2D_FOLD=0", "DES2D_SURF_DEFER=0", "DES2D_TOP_BALANCE=0"])
 def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
     """The node-block patch passes (des_dev2d_patch.hpp: temperature + dvoldt, NMD + force, mass; the default) against the
     one-kernel-per-loop path (DES2D_PATCH=0), other block sizes and groupings, and with the end-of-step pass / the store
