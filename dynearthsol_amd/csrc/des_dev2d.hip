@@ -237,7 +237,7 @@ __device__ __forceinline__ void shape_fn2(const double d[3][2], double vol, doub
 // The five property means of an element (refresh_elem_cache, matprops.cxx:259-303: bulk modulus 0, shear modulus 1, porosity 2,
 // heat capacity 3, conductivity 4).  With ONE material the means ARE its values (matprops.cxx:118, 136: k2_props stores exactly
 // these) -- nothing to fetch: a wave-uniform branch instead of an 8-byte gather per element, pass and property (round 5).
-__device__ __forceinline__ double prop2(const des_params *p, const double *props, int ne, int e, int w)
+__device__ __forceinline__ double prop2(const des_params *__restrict__ p, const double *props, int ne, int e, int w)
 {
     if (p->nmat == 1)
         return w == 0 ? p->bulk_modulus[0] : (w == 1 ? p->shear_modulus[0] : (w == 2 ? p->porosity[0] : (w == 3 ? p->heat_capacity[0] : p->therm_cond[0])));
@@ -254,7 +254,7 @@ __device__ __forceinline__ double elemT(const double *temperature, const int *co
 
 // matprops.cxx:333-377 with the 2-D trace / second invariant
 template <class M>
-__device__ __forceinline__ double mat_visc2(const des_params *p, const desk::ViscTerms *vt, const desk::Mix &mx,
+__device__ __forceinline__ double mat_visc2(const des_params *__restrict__ p, const desk::ViscTerms *vt, const desk::Mix &mx,
                                             double T, const double *s, const double *edot3)
 {
     const double min_strain_rate = 1e-30;
@@ -491,7 +491,7 @@ __device__ __forceinline__ desk::Mix mix2(int mo, const int *markers, int nmat, 
 }
 
 // MatProps::refresh_elem_cache (matprops.cxx:259-303) + the mono[] word
-__global__ void k2_props(const des_params *p, int ne, const int *markers, double *props, int *mono)
+__global__ void k2_props(const des_params *__restrict__ p, int ne, const int *markers, double *props, int *mono)
 {
     const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (e >= ne) return;
@@ -511,7 +511,7 @@ __global__ void k2_props(const des_params *p, int ne, const int *markers, double
 // plastic_props of a single-material element by (material, marker count, weakening regime): desk::plastic_props itself,
 // run once per entry with a plastic strain of that regime (des_kernels.hpp; as the 3-D engine's k_pptab)
 template <class M>
-__global__ void k2_pptab(const des_params *p, double *pptab)
+__global__ void k2_pptab(const des_params *__restrict__ p, double *pptab)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nmat = p->nmat;
@@ -525,7 +525,7 @@ __global__ void k2_pptab(const des_params *p, double *pptab)
 }
 
 // update_temperature (fields.cxx:197-278), element part
-__global__ void k2_temp_elem(const des_params *p, int nn, int ne, const int *conn, const double *coord,
+__global__ void k2_temp_elem(const des_params *__restrict__ p, int nn, int ne, const int *conn, const double *coord,
                              const double *temperature, const double *volume, const double *radiogenic,
                              const double *props, const int *markers, double *tmp_result)
 {
@@ -545,7 +545,7 @@ __global__ void k2_temp_elem(const des_params *p, int nn, int ne, const int *con
     }
 }
 
-__global__ void k2_temp_node(const des_params *p, const Clock *clk, int nn, int ne, const int *sup_idx, const int *sup_arr,
+__global__ void k2_temp_node(const des_params *__restrict__ p, const Clock *clk, int nn, int ne, const int *sup_idx, const int *sup_arr,
                              const int *sup_lidx, const unsigned *bcflag, const double *tmp_result, const double *tmass,
                              double *temperature)
 {
@@ -616,9 +616,12 @@ __global__ void k2_edvoldt(int ne, const int *conn, const double *ntmp, double *
 __device__ __forceinline__ void jaumann_rate_2d(double *s, double dt, double w2);
 
 // RH != 0: the rheology is known at compile time (the kernel holds that law only).
+// (p, vt: __restrict__ -- the parameters are never written on the device, and without the promise every store of the pass turns
+//  the later reads of them from scalar loads into per-lane ones: 24 in this kernel, 71 -> 65 us at 1.28M triangles; round 5.
+//  The same promise for the read-only arrays, tried with it: nothing.)
 template <class M, int FUSED = 0, int RH = 0>
 __global__ void __launch_bounds__(DES_BLOCK)
-k2_stress(const des_params *p, const desk::ViscTerms *vt, Clock *clk, int ne, const int *conn, const double *temperature,
+k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ vt, Clock *clk, int ne, const int *conn, const double *temperature,
           const double *props, const int *markers, double *edvoldt, double *volume, double *volume_old,
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
           double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
@@ -783,7 +786,7 @@ __global__ void k2_nmd_apply(int ne, const int *conn, const double *ntmp, const 
 }
 
 // update_force (fields.cxx:609-698): element part
-__global__ void k2_force_elem(const des_params *p, int nn, int ne, const int *conn, const double *coord, const double *temperature,
+__global__ void k2_force_elem(const des_params *__restrict__ p, int nn, int ne, const int *conn, const double *coord, const double *temperature,
                               const double *volume, const double *stress, const double *props, const int *markers, double *tmp_result)
 {
     const int e = blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -825,7 +828,7 @@ __global__ void k2_force_node(int nn, int ne, const int *sup_idx, const int *sup
 
 // apply_stress_bcs (bc.cxx:661-827) of boundary `ib`: facet part ...
 // the pressure on a boundary facet and its (unnormalised) outward normal
-__device__ __forceinline__ double sbc_facet_pressure(const des_params *p, int ib, int e, int f, int nn, int ne, const int *conn,
+__device__ __forceinline__ double sbc_facet_pressure(const des_params *__restrict__ p, int ib, int e, int f, int nn, int ne, const int *conn,
                                                      const double *coord, const double *temperature, const int *markers, double normal[2])
 {
     double zcenter, fc[2][2];
@@ -850,7 +853,7 @@ __device__ __forceinline__ double sbc_facet_pressure(const des_params *p, int ib
     return pr;
 }
 
-__global__ void k2_sbc_facet(const des_params *p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
+__global__ void k2_sbc_facet(const des_params *__restrict__ p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
                              const int *conn, const double *coord, const double *temperature, const int *markers,
                              double *tmp_result, int *etmp_int)
 {
@@ -869,7 +872,7 @@ __global__ void k2_sbc_facet(const des_params *p, int ib, int bound, const int *
 // expressions, subtracted in the order of its support list as k2_sbc_node does -- from a list built once per mesh:
 // binc[(2*j + q)] = {element, facet, which of the facet's two nodes} of the q-th such incidence of boundary node j, element -1: none.
 #define DES2_SBC_INC 2
-__global__ void k2_sbc_direct(const des_params *p, int ib, int nbdry_nodes, const int *bnodes, const int4 *binc,
+__global__ void k2_sbc_direct(const des_params *__restrict__ p, int ib, int nbdry_nodes, const int *bnodes, const int4 *binc,
                               int nn, int ne, const int *conn, const double *coord, const double *temperature, const int *markers,
                               double *force)
 {
@@ -925,7 +928,7 @@ __global__ void k2_fill_int(int n, int *a, int v)
 }
 
 // elastic foundation (bc.cxx:819-825)
-__global__ void k2_elastic_foundation(const des_params *p, int nb, const int *bnodes, int nn, const double *coord,
+__global__ void k2_elastic_foundation(const des_params *__restrict__ p, int nb, const int *bnodes, int nn, const double *coord,
                                       const double *coord0, double *force)
 {
     const int j = blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -936,7 +939,7 @@ __global__ void k2_elastic_foundation(const des_params *p, int nb, const int *bn
 
 // apply_stress_bcs_neumann (bc.cxx:829-912) of one boundary: a serial loop in the reference, and
 // facets of one boundary share nodes, so one lane walks them in the reference's order
-__global__ void k2_neumann(const des_params *p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
+__global__ void k2_neumann(const des_params *__restrict__ p, int ib, int bound, const int *bf_elem, const int *bf_facet, int nn, int ne,
                            const int *conn, const double *coord, double *force)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -1000,7 +1003,7 @@ __device__ __forceinline__ void damp_vel_regs(const int dopt, const double dfac,
 }
 
 // ... and on the node's entries of the global arrays (ymass is only read by damping option 4)
-__device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *clk, int i, int nn, const double *mass,
+__device__ __forceinline__ void damp_vel_node(const des_params *__restrict__ p, const Clock *clk, int i, int nn, const double *mass,
                                               const double *ymass, double *force, double *vel)
 {
     double f[2] = {force[i], force[nn + i]}, v[2] = {vel[i], vel[nn + i]};
@@ -1008,7 +1011,7 @@ __device__ __forceinline__ void damp_vel_node(const des_params *p, const Clock *
     for (int j = 0; j < 2; j++) { force[j*nn + i] = f[j]; vel[j*nn + i] = v[j]; }
 }
 
-__global__ void k2_damp_vel(const des_params *p, const Clock *clk, int nn, const double *mass, const double *ymass,
+__global__ void k2_damp_vel(const des_params *__restrict__ p, const Clock *clk, int nn, const double *mass, const double *ymass,
                             double *force, double *vel)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -1168,7 +1171,7 @@ __global__ void k2_vbc_zmin_fin(Clock *clk, double *neg_zmin) { clk->zmin = -(*n
 
 // apply_vbcs (bc.cxx:227-659, !THREED) of a node; Clock::pt = PT_jump: boundaries at rest (bc.cxx:330-343)
 // (register form: flag = bcflag of the node, x1 = its z BEFORE it moves, v[] = its velocity in / out)
-__device__ __forceinline__ void vbcs_regs(const des_params *p, const Clock *clk, const unsigned flag, const double x1,
+__device__ __forceinline__ void vbcs_regs(const des_params *__restrict__ p, const Clock *clk, const unsigned flag, const double x1,
                                           const double *bnormals, const double *edge_vec, const int *edge_slot, double v[2])
 {
     if (!(flag & BOUND_ANY)) return;
@@ -1298,7 +1301,7 @@ __device__ __forceinline__ void vbcs_regs(const des_params *p, const Clock *clk,
     }
 }
 
-__device__ __forceinline__ void vbcs_node(const des_params *p, const Clock *clk, int i, int nn, const unsigned *bcflag,
+__device__ __forceinline__ void vbcs_node(const des_params *__restrict__ p, const Clock *clk, int i, int nn, const unsigned *bcflag,
                                           const double *bnormals, const double *edge_vec, const int *edge_slot,
                                           const double *coord, double *vel)
 {
@@ -1309,7 +1312,7 @@ __device__ __forceinline__ void vbcs_node(const des_params *p, const Clock *clk,
     vel[i] = v[0]; vel[nn + i] = v[1];
 }
 
-__global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, const unsigned *bcflag, const double *bnormals,
+__global__ void k2_apply_vbcs(const des_params *__restrict__ p, const Clock *clk, int nn, const unsigned *bcflag, const double *bnormals,
                               const double *edge_vec, const int *edge_slot, const double *coord, double *vel)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -1318,7 +1321,7 @@ __global__ void k2_apply_vbcs(const des_params *p, const Clock *clk, int nn, con
 
 // apply_damping + update_velocity, apply_vbcs and update_coordinate of a node in one launch: each touches the node's own
 // entries only (apply_vbcs reads the wall extent the clock already holds and the node's own z before it moves)
-__global__ void k2_node_final(const des_params *p, const Clock *clk, int nn, const double *mass, const double *ymass,
+__global__ void k2_node_final(const des_params *__restrict__ p, const Clock *clk, int nn, const double *mass, const double *ymass,
                               const unsigned *bcflag, const double *bnormals, const double *edge_vec, const int *edge_slot,
                               double *force, double *vel, double *coord)
 {
@@ -1331,7 +1334,7 @@ __global__ void k2_node_final(const des_params *p, const Clock *clk, int nn, con
 }
 
 // isostasy_adjustment's velocity filter (dynearthsol.cxx:524-533)
-__global__ void k2_iso_vel(const des_params *p, int nn, const unsigned *bcflag, double *vel)
+__global__ void k2_iso_vel(const des_params *__restrict__ p, int nn, const unsigned *bcflag, double *vel)
 {
     const int i = blockIdx.x * DES_BLOCK + threadIdx.x;
     if (i >= nn) return;
@@ -1364,7 +1367,7 @@ __global__ void k2_surf_seg(int etop, int nn, int ne, const int *top_nodes, cons
 
 // ... then the height change of every top node; surface_processes moves the node and books dhacc
 // (bc.cxx:1773-1786).  dh[] starts from 0 (bc.cxx:1718-1724).
-__device__ __forceinline__ void surf_node_at(int i, const des_params *p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
+__device__ __forceinline__ void surf_node_at(int i, const des_params *__restrict__ p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
                              const double *etmp, const double *tmp_result, double *total_dx, double *total_slope,
                              double *coord, double *dhacc, double *dh)
 {
@@ -1387,7 +1390,7 @@ __device__ __forceinline__ void surf_node_at(int i, const des_params *p, const C
     dhacc[n] += d;
 }
 
-__global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
+__global__ void k2_surf_node(const des_params *__restrict__ p, const Clock *clk, int ntop, int nn, int ne, const int *top_nodes,
                              const double *etmp, const double *tmp_result, double *total_dx, double *total_slope,
                              double *coord, double *dhacc, double *dh)
 {
@@ -1397,7 +1400,7 @@ __global__ void k2_surf_node(const des_params *p, const Clock *clk, int ntop, in
 
 // a top node's step of simple_diffusion (bc.cxx:1709-1787) from the moved {x, z} of the top nodes in top_nodes order
 // (a, c, b: the entries of node i - 1, i, i + 1; a / b unused at the ends of the line)
-__device__ __forceinline__ double surf_commit_dh_regs(const des_params *p, double dt, int ntop, int i, const double2 a, const double2 c, const double2 b,
+__device__ __forceinline__ double surf_commit_dh_regs(const des_params *__restrict__ p, double dt, int ntop, int i, const double2 a, const double2 c, const double2 b,
                                                       double &tdx, double &tsl)
 {
     // the segment to the left (i - 1 .. i) and to the right (i .. i + 1): dx, and the two slope terms surf_seg_at stores
@@ -1416,7 +1419,7 @@ __device__ __forceinline__ double surf_commit_dh_regs(const des_params *p, doubl
     return d;
 }
 
-__device__ __forceinline__ double surf_commit_dh(const des_params *p, double dt, int ntop, int i, const double2 *xz_pre, double &tdx, double &tsl)
+__device__ __forceinline__ double surf_commit_dh(const des_params *__restrict__ p, double dt, int ntop, int i, const double2 *xz_pre, double &tdx, double &tsl)
 {
     const double2 c = xz_pre[i];
     const double2 a = i > 0 ? xz_pre[i - 1] : c, b = i < ntop - 1 ? xz_pre[i + 1] : c;
@@ -1430,7 +1433,7 @@ __device__ __forceinline__ double surf_commit_dh(const des_params *p, double dt,
 // k2p_force<1> therefore leaves the moved {x, z} of every top node in a compact array in top_nodes order as well (xz_pre:
 // the coordinates update_coordinate left, before the surface step), which is all this kernel reads of other nodes.
 // The last workgroup forms calculate_residual_force's final sum (as in k2_surf_seg_resfin).
-__global__ void k2_surf_commit(const des_params *p, Clock *clk, int ntop, int nn, const int *top_nodes, const double2 *xz_pre,
+__global__ void k2_surf_commit(const des_params *__restrict__ p, Clock *clk, int ntop, int nn, const int *top_nodes, const double2 *xz_pre,
                                double *total_dx, double *total_slope, double *coord, double *dhacc, double *dh,
                                int nb_node, int res_nb, const double *res_part)
 {
@@ -1488,7 +1491,7 @@ __global__ void k2_surf_maxdh(int ntop, const int *top_nodes, int o0, int o1, co
 
 // correct_surface_element (bc.cxx:1655-1707), element part; surface_plstrain_diffusion (bc.cxx:1633-1653)
 // rides along when `decay` (same elements, applied after the correction as in surface_processes)
-__device__ __forceinline__ void cse_elem_at(int i, const des_params *p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
+__device__ __forceinline__ void cse_elem_at(int i, const des_params *__restrict__ p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
                             const int *conn, const double *coord, const int *markers, int decay, double *volume,
                             double *plstrain, double *stress, double *strain, double *strain_rate)
 {
@@ -1520,7 +1523,7 @@ __device__ __forceinline__ void cse_elem_at(int i, const des_params *p, const Cl
     plstrain[e] = pls;
 }
 
-__global__ void k2_cse_elem(const des_params *p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
+__global__ void k2_cse_elem(const des_params *__restrict__ p, const Clock *clk, int ntop_elems, const int *top_elems, int nn, int ne,
                             const int *conn, const double *coord, const int *markers, int decay, double *volume,
                             double *plstrain, double *stress, double *strain, double *strain_rate)
 {
@@ -1556,7 +1559,7 @@ __global__ void k2_surf_seg_resfin(int etop, int nn, int ne, const int *top_node
     if (i < etop) surf_seg_at(i, etop, nn, ne, top_nodes, coord, etmp, tmp_result);
 }
 
-__global__ void k2_surf_edv_cse_elem(const des_params *p, const Clock *clk, int etop, int ntop_elems, int nb_edv, int nn, int ne,
+__global__ void k2_surf_edv_cse_elem(const des_params *__restrict__ p, const Clock *clk, int etop, int ntop_elems, int nb_edv, int nn, int ne,
                                      const int *ean, const int *conn_surf, const int *top_elems, const int *conn, const int *markers,
                                      int decay, const double *coord, const double *dh, double *edvacc, double *volume, double *plstrain,
                                      double *stress, double *strain, double *strain_rate)
@@ -1588,7 +1591,7 @@ __device__ __forceinline__ void cse_node_areas_at(int i, int nn, int ne, const i
 }
 
 // ... and with that edvacc_surf, both parts of correct_surface_element and the max |dh| reduction are ONE launch (round 5)
-__global__ void k2_surf_edv_cse_all(const des_params *p, Clock *clk, int etop, int ntop_elems, int ntop, int nb_edv, int nb_elem, int nb_node,
+__global__ void k2_surf_edv_cse_all(const des_params *__restrict__ p, Clock *clk, int etop, int ntop_elems, int ntop, int nb_edv, int nb_elem, int nb_node,
                                     int nn, int ne, const int *ean, const int *conn_surf, const int *top_elems, const int *top_nodes,
                                     const int *conn, const int *markers, const int *sup_idx, const int *sup_arr, int decay, int reset_dhacc,
                                     int o0, int o1, const double *coord, const double *dh, double *edvacc, double *volume, double *volume_n,
@@ -1628,7 +1631,7 @@ __global__ void k2_cse_node_maxdh(int ntop, int nb_node, const int *top_nodes, c
 //  surface is a line of a few thousand nodes.  130-140 us against 28 for the four launches (profiles/r05_f_*, r05_g_*): one CU
 //  has too little memory-level parallelism for chains of dependent loads, each thread walking its items one after the other.)
 // compute_volume (geometry.cxx:170-201) + the element part of compute_mass (geometry.cxx:1743-1870)
-__global__ void k2_volume_mass_elem(const des_params *p, int nn, int ne, const int *conn, const double *coord,
+__global__ void k2_volume_mass_elem(const des_params *__restrict__ p, int nn, int ne, const int *conn, const double *coord,
                                     const double *temperature, const double *props, const int *markers, int with_mass,
                                     double *volume, double *tmp_result)
 {
@@ -1652,7 +1655,7 @@ __global__ void k2_volume_mass_elem(const des_params *p, int nn, int ne, const i
     tmp_result[2 * ne + e] = ym;
 }
 
-__global__ void k2_mass_node(const des_params *p, int nn, int ne, const int *sup_idx, const int *sup_arr, const double *volume,
+__global__ void k2_mass_node(const des_params *__restrict__ p, int nn, int ne, const int *sup_idx, const int *sup_arr, const double *volume,
                              const double *tmp_result, double *volume_n, double *mass, double *tmass, double *ymass)
 {
     const int n = blockIdx.x * DES_BLOCK + threadIdx.x;
@@ -1723,7 +1726,7 @@ __global__ void k2_dt_init(Clock *clk)
 //  workgroup, reduces them: five thousand workgroups doing five 64-bit atomic min / max on the five words of ONE cache line
 //  serialised in the L2, 80-93 us for 1.28M triangles against 23 us for the 3-D engine's pass, which has stored partials since
 //  round 2.  min and max are exact whatever the order: the same bits.)
-__global__ void k2_dt_partials(const des_params *p, double *dt_part, int nn, int ne, const int *conn, const double *coord,
+__global__ void k2_dt_partials(const des_params *__restrict__ p, double *dt_part, int nn, int ne, const int *conn, const double *coord,
                                const double *vel, const double *temperature, const double *volume, const double *props,
                                const int *markers)
 {
@@ -1769,9 +1772,9 @@ __global__ void k2_dt_partials(const des_params *p, double *dt_part, int nn, int
 
 // ... the partials reduced into the clock's five slots by one workgroup (what k2_dt_init + the atomics left there);
 // finalize != 0: k2_dt_finalize's statements follow at once (the single engine: one launch less)
-__device__ __forceinline__ void dt_finalize_body(const des_params *p, Clock *clk);
+__device__ __forceinline__ void dt_finalize_body(const des_params *__restrict__ p, Clock *clk);
 __global__ void __launch_bounds__(DES_BLOCK)
-k2_dt_reduce(const des_params *p, Clock *clk, const double *dt_part, int nb, int finalize)
+k2_dt_reduce(const des_params *__restrict__ p, Clock *clk, const double *dt_part, int nb, int finalize)
 {
     __shared__ double sm[5][DES_BLOCK / 64];
     double r[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, 0.0};
@@ -1795,7 +1798,7 @@ k2_dt_reduce(const des_params *p, Clock *clk, const double *dt_part, int nb, int
 }
 
 // ... and its tail (geometry.cxx:1597-1646)
-__device__ __forceinline__ void dt_finalize_body(const des_params *p, Clock *clk)
+__device__ __forceinline__ void dt_finalize_body(const des_params *__restrict__ p, Clock *clk)
 {
     const double minl = clk->r_minl, dt_maxwell = clk->r_dt_maxwell, dt_diffusion = clk->r_dt_diffusion;
     const double dt_hydro_diffusion = DBL_MAX;
@@ -1819,7 +1822,7 @@ __device__ __forceinline__ void dt_finalize_body(const des_params *p, Clock *clk
     clk->dt = dt;
 }
 
-__global__ void k2_dt_finalize(const des_params *p, Clock *clk) { dt_finalize_body(p, clk); }
+__global__ void k2_dt_finalize(const des_params *__restrict__ p, Clock *clk) { dt_finalize_body(p, clk); }
 
 __global__ void k2_count_nan(long long n, const double *a, unsigned long long *count)
 {

@@ -184,7 +184,7 @@ struct SurfPre { const double2 *xz_pre; const int *pt_ptr; const int4 *pt_ent; c
 
 template <int MASS>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
-k2p_temp_dvoldt(const des_params *p, const Clock *clk, int thermal, int vol_from_coords, const PatchArgs a, const unsigned *bcflag,
+k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk, int thermal, int vol_from_coords, const PatchArgs a, const unsigned *bcflag,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
                 const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass_in, const double *volume_n_in,
                 double *ntmp, double *strain_rate, double *volume_n_out, double *mass_out, double *tmass_out, double *ymass_out,
@@ -413,7 +413,7 @@ struct ForceTail {
 };
 template <int TAIL>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
-k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
+k2p_force(const des_params *__restrict__ p, int nmd, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
           const double *volume, const double *dpressure, const double *stress_in, double *stress_out, const double *props,
           const int *markers, const int *mono, double *force, double *fres, const ForceTail ft)
 {
@@ -555,7 +555,7 @@ k2p_force(const des_params *p, int nmd, const PatchArgs a, const double *coord, 
 // The element volumes are recomputed from the staged coordinates with compute_volume's own expression (k2_rotate_vol
 // stores the same value to volume[]).
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
-k2p_mass(const des_params *p, const PatchArgs a, const double *coord, const double *temperature, const double *props,
+k2p_mass(const des_params *__restrict__ p, const PatchArgs a, const double *coord, const double *temperature, const double *props,
          const int *markers, const int *mono, double *volume_n, double *mass, double *tmass, double *ymass)
 {
     extern __shared__ double lds[];
