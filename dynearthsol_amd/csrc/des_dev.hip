@@ -263,7 +263,8 @@ struct des_dev {
     des_dev **group;           // [group_n], indexed by rank (des_halo::nbr_rank); null: no group
     int group_n, group_rank;
     hipEvent_t ev_packed, ev_taken;   // messages packed (my stream) / the neighbours' messages copied out and unpacked
-    unsigned char *pb_top;     // [patch_nb] the block's patch holds a surface node
+    int *bperm;                // [patch_nb] launch order of the patch blocks (nullptr: as numbered)
+    int *pb_top;               // [patch_nb] the block's patch holds a surface node (an int: EN1 reads it with a scalar load)
     int2 *tfan;                // [nn] {position in top_nodes | fan size << 27, start of the fan in ssup_nodes}, {-1, 0} below the surface (passes/en1.hpp)
     bool s2_defer;             // DES_S2_DEFER != 0 (read at create)
     bool s2_pending;           // the surface step of the last step has not run: the next EN1 does it (s2_defer_ok)
@@ -350,7 +351,7 @@ void des_dev_destroy(des_dev *h)
         h->stress_avg, h->dplstrain_avg, h->strain0, h->coord_avg0,
         h->radiogenic, h->markers, h->props, h->mono, h->defer_list, h->ptab, h->pptab, h->mrec, h->ttmp, h->etmp2, h->ftmp, h->res_part, h->bcf_elem,
         h->bcf_facet, h->bcf_kind, h->bcf_val, h->bcf_tmp, h->bcn_idx, h->bcn_ent, h->top_nodes, h->ean,
-        h->conn_surf, h->ssup_idx, h->ssup_arr, h->ssup_nodes, h->topflag, h->tfan, h->pb_top, h->dh, h->edvacc,
+        h->conn_surf, h->ssup_idx, h->ssup_arr, h->ssup_nodes, h->topflag, h->tfan, h->pb_top, h->bperm, h->dh, h->edvacc,
         h->znew, h->bnormals, h->edge_vec, h->edge_slot };
     for (void *q : ptrs) if (q) hipFree(q);
     if (h->h_clk) hipHostFree(h->h_clk);
@@ -532,7 +533,7 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
                 {
                     // surface nodes among a patch's foreign nodes: bit 31 of their pn_id entry; blocks whose patch has any
                     // (EN1's deferred surface step, passes/en1.hpp)
-                    std::vector<unsigned char> is_top((size_t)nn, 0), pbt((size_t)P.nb, 0);
+                    std::vector<unsigned char> is_top((size_t)nn, 0); std::vector<int> pbt((size_t)P.nb, 0);
                     for (int i = 0; i < mesh->ntop; ++i) is_top[mesh->top_nodes[i]] = 1;
                     for (int b = 0; b < P.nb; ++b) {
                         for (int n = b * P.npb; n < std::min(nn, (b + 1) * P.npb); ++n) pbt[b] |= is_top[n];
@@ -540,7 +541,30 @@ des_dev *des_dev_create(int device, const des_params *params, const des_mesh *me
                             if (is_top[P.pn_id[k]]) { P.pn_id[k] |= (int)0x80000000u; pbt[b] = 1; }
                     }
                     CK(dev_alloc(h->pb_top, pbt.size())); CK(dev_upload(h->pb_top, pbt.data(), pbt.size(), h->stream));
+                    // The surface blocks carry extra work (the deferred surface step in EN1: +5 us of the pass at 1M tets) and the
+                    // Morton order packs them into half of the eight contiguous runs desk::logical_block hands the XCDs.  Launch
+                    // order: run k = an eighth of the surface blocks, first, then its share of the others, both as numbered.
+                    // (Which block does what does not change: the same bits.  DES_TOP_BALANCE=0: off.)
+                    const char *be = des_env::get("DES_TOP_BALANCE");
+                    if (P.nb >= 64 && !(be && be[0] == '0')) {
+                        std::vector<int> T, O, perm;
+                        for (int b = 0; b < P.nb; ++b) (pbt[b] ? T : O).push_back(b);
+                        const int per = (P.nb + 7) / 8;
+                        size_t ot = 0;
+                        for (int k = 0; k < 8; ++k) {
+                            const int want = std::max(0, std::min(per, P.nb - k * per));
+                            const size_t t0 = T.size() * k / 8, t1 = T.size() * (k + 1) / 8;
+                            int got = 0;
+                            for (size_t t = t0; t < t1 && got < want; ++t, ++got) perm.push_back(T[t]);
+                            for (; got < want && ot < O.size(); ++got) perm.push_back(O[ot++]);
+                        }
+                        std::vector<char> seen((size_t)P.nb, 0);
+                        bool ok = (int)perm.size() == P.nb;
+                        for (int b : perm) { if (seen[b]) ok = false; seen[b] = 1; }
+                        if (ok) { CK(dev_alloc(h->bperm, perm.size())); CK(dev_upload(h->bperm, perm.data(), perm.size(), h->stream)); }
+                    }
                 }
+                P.pn_id.push_back(0);                       // (a spare entry: EN1 / EN3 read pn_id without a branch, passes/en3.hpp)
                 CK(dev_alloc(h->pn_id, P.pn_id.size())); CK(dev_upload(h->pn_id, P.pn_id.data(), P.pn_id.size(), h->stream));
                 CK(dev_alloc(h->ddp, (size_t)ne)); CK(dev_alloc(h->xt_alt, (size_t)nn));
                 HK(hipMemsetAsync(h->ddp, 0, 8*(size_t)ne, h->stream));

@@ -527,11 +527,11 @@ void launch_en1(des_dev *h, int part = PART_ALL)
         Launch l(h, K_EN1);
         void (*k)(const des_params *, DevClock *, int, int, int, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *,
                   const int *, const int *, const int *, const unsigned *, const MatData, const double *, const d4 *, d4 *, d4 *,
-                  double *, double *, double *, const SurfPending);
+                  double *, double *, double *, const SurfPending, const int *, const int *);
         // the surface step of the step before, if its S2 / S3 launches were left out (s2_defer_ok)
-        SurfPending sp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        SurfPending sp = {nullptr, nullptr, nullptr, nullptr, nullptr};
         if (h->s2_pending) {
-            sp.tfan = h->tfan; sp.pb_top = h->pb_top; sp.ssup_nodes = h->ssup_nodes;
+            sp.tfan = h->tfan; sp.ssup_nodes = h->ssup_nodes;
             sp.dh = h->dh; sp.dhacc = h->dhacc; sp.dh_n = h->dh_n;
             if (part != PART_DEEP) {                // (PART_DEEP is followed by PART_REST, which needs it too)
                 h->s2_pending = false;
@@ -553,7 +553,7 @@ void launch_en1(des_dev *h, int part = PART_ALL)
         hipLaunchKernelGGL(k, dim3((c0 + c1 + 7) / 8 * 8), dim3(T), lds, h->stream, h->d_p, h->d_clk, h->nn, h->ne, b0, c0, b1, c1,
                            (int)(part != PART_REST), h->patch_npb, ci, cn, ce, h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag,
                            mat_data(h), h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->xt, h->xt_alt, h->vm, h->volume_n,
-                           h->tmass, h->ntmp, sp);
+                           h->tmass, h->ntmp, sp, h->pb_top, (b0 == 0 && c0 == h->patch_nb && c1 == 0) ? h->bperm : (const int *)nullptr);
     }
     if (part != PART_DEEP) std::swap(h->xt, h->xt_alt);      // EN1 wrote the records with the new temperatures there
 }

@@ -28,7 +28,7 @@
 // the nodes below the surface: one look-up instead of topidx -> ssup_idx.
 // pb_top[block] != 0: the block's patch holds a surface node at all (the others never touch tfan); the surface nodes
 // among a patch's foreign nodes carry bit 31 in pn_id (engine/patch.hpp), so only they cost a look-up.
-struct SurfPending { const int2 *tfan; const unsigned char *pb_top; const int *ssup_nodes; double *dh, *dhacc, *dh_n; };
+struct SurfPending { const int2 *tfan; const int *ssup_nodes; double *dh, *dhacc, *dh_n; };
 #ifndef DES_EN1_S2_BATCH
 #define DES_EN1_S2_BATCH 2
 #endif
@@ -73,7 +73,8 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
      const int *__restrict__ pe_ptr, const ulonglong2 *__restrict__ pe_pack, const int *__restrict__ pn_ptr, const int *__restrict__ pn_id,
      const int *__restrict__ sup_idx, const unsigned *__restrict__ bcflag, const MatData md,
      const double *__restrict__ radiogenic, const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm,
-     double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp, const SurfPending sp)
+     double *__restrict__ volume_n, double *__restrict__ tmass, double *__restrict__ ntmp, const SurfPending sp,
+     const int *__restrict__ pb_top, const int *__restrict__ bperm)
 {
     extern __shared__ __attribute__((aligned(32))) unsigned char des_smem[];
     unsigned char *sm = des_smem;
@@ -90,7 +91,9 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     // this launch covers the node blocks [b0, b0 + c0) and [b1, b1 + c1): all of them (0, nb, 0, 0), or -- overlapped
     // multi-GPU schedule -- first the blocks deep inside the slab, later the ones near its cuts (engine/launch.hpp)
     const int L = desk::logical_block(c0 + c1);
-    const int lb = L < c0 ? b0 + L : b1 + (L - c0);
+    // (bperm: the launch order of a launch over all blocks -- every XCD its share of the surface blocks, engine/patch.hpp)
+    int lb = L < c0 ? b0 + L : b1 + (L - c0);
+    if (bperm && L < c0 + c1) lb = bperm[lb];
     const int n0 = lb * npb;
     const double dt = clk->dt;
     if (do_clock && blockIdx.x == 0 && threadIdx.x == 0) { // never in the isostasy loop (en1_ok); once per step
@@ -124,19 +127,34 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
     const int part = split ? (int)(threadIdx.x >> 6) : 0;                      // which sums (split), else all
     const int n = n0 + nl;
     const bool has_node = nl < nown && part < 3;
-    int r0 = 0, r1 = 0;
-    unsigned flag = 0;
-    if (has_node) {
-        const int kb = sup_idx[n0];
-        r0 = sup_idx[n] - kb; r1 = sup_idx[n + 1] - kb;
-        flag = bcflag[n];
-    }
+    // Requests first, uses later (round 5): the node's list bounds and flags, the block's surface flag and the ids of the patch's
+    // other nodes all go out in ONE round behind the block's scalar bounds, and nothing waits before the ids are needed.  (Used
+    // where they were written -- the bounds subtracted at once, the flag tested in the loop head -- each was a round of its own:
+    // six dependent trips to memory from the kernel arguments to the first nodal record, now four.)
+    // (a lane without a node reads the block's first node's -- no branch around the requests: merging its results made the
+    //  compiler wait for them on the spot)
+    const int top_raw = pb_top[lb];                        // (an argument of its own, __restrict__: a scalar load beside the bounds)
+    const int nc = has_node ? n : n0;
+    const int s_k = sup_idx[n0], s_a = sup_idx[nc], s_b = sup_idx[nc + 1];
+    const unsigned flag_raw = bcflag[nc];
     // the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
     // (every record of the patch is requested before anything waits: the surface nodes, which need more, come after)
     constexpr int ROUNDS = DES_PATCH_PN / THREADS;          // (cap_pn <= DES_PATCH_PN = 512)
     int2 tf[ROUNDS];
     int ids[ROUNDS];
-    const bool blk_top = sp.tfan && sp.pb_top[lb];
+    int raws[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int j = threadIdx.x + r * THREADS;
+        // (no branch around the request; pn_id ends in a spare entry for a block without foreign nodes)
+        const int raw = pn_id[h0 + min(max(j - nown, 0), max(nh - 1, 0))];
+        raws[r] = j < nown ? n0 + j : raw;
+    }
+    // (pinned here -- an empty asm that "changes" them --: the compiler otherwise sinks the request into the conditional block
+    //  that uses the ids)
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) asm volatile("" : "+v"(raws[r]));
+    const bool blk_top = sp.tfan && top_raw != 0;
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const int j = threadIdx.x + r * THREADS;
@@ -152,7 +170,7 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
             lxt[j] = xr;
             lvx[j] = 1e-9 * j; lvy[j] = 2e-9; lvz[j] = 3e-9;
 #else
-            const int raw = j < nown ? n0 + j : pn_id[h0 + j - nown];
+            const int raw = raws[r];
             const int id = raw & 0x7fffffff;
             ids[r] = id;
             lxt[j] = xt[id];
@@ -176,6 +194,8 @@ EN1_mass_temperature_dvoldt(const des_params *__restrict__ p, DevClock *__restri
             if (j < nown) { sp.dh[ti] = d; sp.dhacc[id] = dhacc_old + d; sp.dh_n[id] = d; }
         }
     }
+    int r0 = has_node ? s_a - s_k : 0, r1 = has_node ? s_b - s_k : 0;
+    const unsigned flag = has_node ? flag_raw : 0u;
     __syncthreads();
     DES_STAMP0(0, 1);
     // the patch's elements: E1's element terms, recomputed

@@ -70,6 +70,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     double *const lnt = (double *)sm; sm += (size_t)cap_pn * 8;
     double *const lf[3] = {(double *)sm, (double *)sm + cap_inc, (double *)sm + 2 * (size_t)cap_inc};
     __shared__ double red[THREADS / 64];
+    // (EN1's launch order -- every XCD its share of the surface blocks, engine/launch.hpp -- tried here too: 52.1 -> 53.1 us)
     const int lb = desk::logical_block(nblocks);
     const int n0 = lb * npb;
     if (n0 >= nn) return;                                 // grid padding
@@ -85,8 +86,8 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     // flight TOGETHER: a workgroup's critical path is two round trips to memory (index, then record),
     // not one per phase -- with three workgroups per CU there is little else to hide them behind.
     struct Elem { int ew, mono; ushort4 ln; short4 sl; double s[6], vol, dpo; };
-    auto load_elem = [&](int i, Elem &E) {
-        const PatchElem PE_ = patch_elem_unpack(pe_pack[i]);
+    auto load_elem_rec = [&](const ulonglong2 rec_, Elem &E) {
+        const PatchElem PE_ = patch_elem_unpack(rec_);
         E.ew = PE_.ew; E.ln = make_ushort4(PE_.ln[0], PE_.ln[1], PE_.ln[2], PE_.ln[3]);
         E.sl = make_short4(PE_.sl[0], PE_.sl[1], PE_.sl[2], PE_.sl[3]);
         int e = E.ew & 0x3fffffff;
@@ -105,11 +106,27 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         E.mono = grav ? md.mono[e] : 0;
 #endif
     };
-    // (a) this lane's first patch element: list entry, then stress / volume / dpressure (holding a
-    //     second one in registers as well costs a wave of occupancy and more than it hides)
+    auto load_elem = [&](int i, Elem &E) { load_elem_rec(pe_pack[i], E); };
+    // Round 5: REQUESTS first, uses later.  The waits count requests in order, so a result used where it was asked for holds the
+    // lane until everything asked for before it is back: written phase by phase -- list entry, element data, list bounds (used on the
+    // spot), ids, records -- the pass made five dependent trips to memory from the block's scalar bounds to the barrier.  Now three:
+    //   1. this lane's list entry, the ids of the patch's other nodes, the node's list bounds and flags (none needs another);
+    //   2. the element's stress / volume / dpressure / marker word (behind 1's first) and the nodal records (behind 1's second);
+    //   3. nothing -- the barrier.
     Elem E0;
     const int i0 = e_begin + threadIdx.x, i1 = i0 + THREADS;
-    if (i0 < e_end) load_elem(i0, E0);
+    // (no branches around the requests -- a lane past the end of a list asks for the list's last entry and drops it: where two
+    //  paths meet, the compiler waits for the count that is safe on both, i.e. for nearly everything)
+    const ulonglong2 rec0 = pe_pack[min(i0, e_end - 1)];
+    constexpr int ROUNDS = DES_PATCH_PN / THREADS;          // (cap_pn <= DES_PATCH_PN = 512)
+    int ids[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int j = threadIdx.x + r * THREADS;
+        // (pn_id ends in a spare entry: a block without foreign nodes reads that; used -- and bit 31 masked -- in the staging loop)
+        const int raw = pn_id[h0 + min(max(j - nown, 0), max(nh - 1, 0))];
+        ids[r] = j < nown ? n0 + j : raw;
+    }
     // (b) the node this lane will finish: its CSR segment and its records.  DES_EN3_SPLIT (blocks of up to 64 nodes):
     //     lane l of the first three wavefronts sums ONE force component of node n0 + l (below), so those lanes need the
     //     segment too; the first wavefront's lanes finish the nodes as before.
@@ -122,26 +139,42 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
     const bool has_node = (int)threadIdx.x < nown;
     const int nl = split ? (int)(threadIdx.x & 63) : (int)threadIdx.x, part = split ? (int)(threadIdx.x >> 6) : 0;
     const bool sums = nl < nown && part < 3;
-    int r0 = 0, r1 = 0;
-    unsigned flag = 0;
-    if (sums) {
-        const int kb = sup_idx[n0];
-        r0 = sup_idx[n0 + nl] - kb; r1 = sup_idx[n0 + nl + 1] - kb;
-    }
-    if (has_node) flag = bcflag[n];
-    // (c) the patch's nodes into LDS: own range first (local id = n - n0), then the listed others
-    for (int j = threadIdx.x; j < nown + nh; j += THREADS) {
-        int id = j < nown ? n0 + j : (pn_id[h0 + j - nown] & 0x7fffffff);      // (bit 31: a surface node, for EN1)
+    // (a lane without a node reads the block's first node's: no branch around the requests)
+    const int nc = sums ? n0 + nl : n0;
+    const int s_k = sup_idx[n0], s_a = sup_idx[nc], s_b = sup_idx[nc + 1];
+    const unsigned flag_raw = bcflag[has_node ? n : n0];
+    // (the ids are pinned HERE -- an empty asm that "changes" them: the compiler otherwise sinks their request into the
+    //  conditional block that uses them, behind the element data, and the records wait a trip longer)
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) asm volatile("" : "+v"(ids[r]));
+    // (c) the patch's nodes: own range first (local id = n - n0), then the listed others -- requested into registers, stored to LDS
+    //     behind (a)'s requests (a lane past the patch asks for the block's first node and drops it)
+    d4 xr[ROUNDS];
+    double ntr[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int j = threadIdx.x + r * THREADS;
+        int id = j < nown + nh ? (ids[r] & 0x7fffffff) : n0;      // (bit 31: a surface node, for EN1)
 #ifdef DES_EXP_EN3_FAKE_STAGE
         id = n0 + (j & 63);              // timing experiment only (wrong results): the staging gathers hit lines already on their way
 #endif
 #if DES_EXP_EN3 & 4
-        { d4 xr; xr.x = 1.0 * j; xr.y = 2.0 * (j & 7); xr.z = 3.0 * (j & 3) + 0.5 * j; xr.w = 300.0; lxt[j] = xr; lnt[j] = 1.0 * id; }   // timing experiment only
+        xr[r].x = 1.0 * j; xr[r].y = 2.0 * (j & 7); xr[r].z = 3.0 * (j & 3) + 0.5 * j; xr[r].w = 300.0; ntr[r] = 1.0 * id;   // timing experiment only
 #else
-        lxt[j] = xt[id];
-        if (nmd) lnt[j] = ntmp[id];
+        xr[r] = xt[id];
+        ntr[r] = nmd ? ntmp[id] : 0.0;
 #endif
     }
+    // (a) this lane's first patch element: stress / volume / dpressure (holding a second one in registers as well costs a wave
+    //     of occupancy and more than it hides)
+    load_elem_rec(rec0, E0);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int j = threadIdx.x + r * THREADS;
+        if (j < nown + nh) { lxt[j] = xr[r]; if (nmd) lnt[j] = ntr[r]; }
+    }
+    int r0 = sums ? s_a - s_k : 0, r1 = sums ? s_b - s_k : 0;
+    const unsigned flag = has_node ? flag_raw : 0u;
     __syncthreads();
     DES_STAMP0(1, 1);
 
