@@ -3,7 +3,7 @@
 # default, the driver's command, 2-D), rocprofv3 kernel statistics of both, PMC traffic of both, SQ counters of the 3-D step.
 # Everything goes to gpurun_out/TAG_*; copy what is to be judged into profiles/.
 set -e
-tag=${1:-r05_z}
+tag=${1:-r05_zz}
 out=gpurun_out
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
