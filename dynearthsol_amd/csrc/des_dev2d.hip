@@ -2262,8 +2262,12 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
         nb_tail = ((h->etop + DES2_PATCH_THREADS - 1) / DES2_PATCH_THREADS + 7) / 8 * 8;     // (in front of the blocks: a multiple of 8)
         pre = reinterpret_cast<const SurfPre *>(h->d_surfpre);
     }
-    if (h->mass_pending)
-        hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 4 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
+    if (h->mass_pending) {
+        // (six slot arrays: compute_mass's four and this pass's two in one node phase)
+        const size_t lds = 8 * (5 * (size_t)a.pn_cap + 6 * (size_t)a.inc_cap);
+        if (lds > 65536) hipFuncSetAttribute((const void *)k2p_temp_dvoldt<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), lds, h->stream, K2T_ARGS);
+    }
     else
         hipLaunchKernelGGL(k2p_temp_dvoldt<0>, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
 #undef K2T_ARGS

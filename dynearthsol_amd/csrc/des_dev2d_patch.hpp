@@ -255,49 +255,81 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
         }
         __syncthreads();
     }
-    double my_vn = 0, my_tm = 0;
     if (MASS) {
+        // Round 5: ONE element loop and ONE node phase for compute_mass of the step before and this step's two sums (six LDS slot
+        // arrays instead of four reused: three workgroups per CU instead of four, but two barriers instead of four, and the area,
+        // the mean temperature and mat_rho of an element formed once instead of twice -- the same expressions on the same
+        // values, so the same bits).
+        double *const lf4 = lf3 + a.inc_cap, *const lf5 = lf4 + a.inc_cap;
         const int mass_thermal = p->has_thermal_diffusion;
 #pragma unroll
         for (int k = 0; k < DES2_PATCH_IT; ++k) {
             if (q0 + k * DES2_PATCH_THREADS >= qe) break;
             const PatchElem2 E = patch_elem2(rec[k]);
             const int e = E.e;
-            double d[3][2];
-            for (int i = 0; i < 3; ++i) { d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; }
-            const double vol = triangle_area(d[0], d[1], d[2]);
+            double d[3][2], v[3][2], shpdx[3], shpdz[3], T[3];
+            for (int i = 0; i < 3; ++i) {
+                d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; v[i][0] = lvx[E.ln[i]]; v[i][1] = lvz[E.ln[i]]; T[i] = lT[E.ln[i]];
+            }
+            const double vol_m = triangle_area(d[0], d[1], d[2]);
             // k2_volume_mass_elem's statements
             const desk::Mix mx = mix2(g_mono[k], markers, p->nmat, e);
             const double bulkm = g_bulk[k], shearm = g_shear[k];
             double Te = 0;
-            for (int i = 0; i < 3; ++i) Te += lT[E.ln[i]];
+            for (int i = 0; i < 3; ++i) Te += T[i];
             Te /= 3;
             const double mrho = desk::mat_rho(p, mx, Te);
             double rho = p->is_quasi_static ? bulkm / (pseudo_speed * pseudo_speed) : mrho;
-            double m = rho * vol / 3;
-            double tm = mrho * g_cp[k] * vol / 3;
+            double m = rho * vol_m / 3;
+            double tm = mrho * g_cp[k] * vol_m / 3;
             double ym = 9 * bulkm * shearm / (3 * bulkm + shearm) / 3;
+            // (vol_from_coords: see below; MASS is only launched with it)
+            const double vol = vol_from_coords ? vol_m : g_vol[k];
+            shape_fn2(d, vol, shpdx, shpdz);
+            double kv = 0, rh = 0;
+            if (thermal) { kv = g_kc[k] * vol; rh = g_rad[k] * vol * mrho / 3; }       // k2_temp_elem's statements
+            // k2_strain_rate's statements; the block that owns the element stores the strain rate
+            double s0 = 0, s1 = 0;
+            for (int i = 0; i < 3; ++i) s0 += v[i][0] * shpdx[i];
+            for (int i = 0; i < 3; ++i) s1 += v[i][1] * shpdz[i];
+            if (E.owner) {
+                double s2 = 0;
+                for (int i = 0; i < 3; ++i) s2 += 0.5 * (v[i][0] * shpdz[i] + v[i][1] * shpdx[i]);
+                strain_rate[e] = s0; strain_rate[ne + e] = s1; strain_rate[2 * ne + e] = s2;
+            }
+            double dj = s0 + s1;
+            const double et = dj * vol;
             for (int i = 0; i < 3; ++i) {
                 if (E.sl[i] == 0xfff) continue;
-                lf0[E.sl[i]] = vol; lf1[E.sl[i]] = m; lf2[E.sl[i]] = tm; lf3[E.sl[i]] = ym;
+                lf0[E.sl[i]] = vol_m; lf1[E.sl[i]] = m; lf2[E.sl[i]] = tm; lf3[E.sl[i]] = ym;
+                if (thermal) {
+                    double diffusion = 0.;
+                    for (int j = 0; j < 3; ++j)
+                        diffusion += (shpdx[i] * shpdx[j] + shpdz[i] * shpdz[j]) * T[j];
+                    lf4[E.sl[i]] = diffusion * kv - rh;
+                }
+                lf5[E.sl[i]] = et;
             }
         }
         __syncthreads();
         if ((int)threadIdx.x < nown) {
             const int n = a.po_id[o0 + threadIdx.x];
             const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
-            double vn = 0, ms = 0, tms = 0, yms = 0;
+            const bool t_node = thermal && !(bcflag[n] & BOUNDZ1);
+            double vn = 0, ms = 0, tms = 0, yms = 0, acc = 0., tdot = 0;
             for (int k = r0; k < r1; ++k) {
                 vn += lf0[k];
                 ms += lf1[k];
                 if (mass_thermal) tms += lf2[k];
                 yms += lf3[k];
+                acc += lf5[k];
+                if (t_node) tdot += lf4[k];
             }
             volume_n_out[n] = vn; mass_out[n] = ms; tmass_out[n] = tms; ymass_out[n] = yms;
-            my_vn = vn; my_tm = tms;
+            ntmp[n] = acc / vn;
+            if (thermal) T_out[n] = t_node ? lT[threadIdx.x] - clk->dt * tdot / tms : p->surface_temperature;
         }
-        __syncthreads();                   // the slots are free again
-    }
+    } else {
 #pragma unroll
     for (int k = 0; k < DES2_PATCH_IT; ++k) {
         if (q0 + k * DES2_PATCH_THREADS >= qe) break;
@@ -346,16 +378,17 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
         const int r0 = a.po_slot[o0 + threadIdx.x], r1 = r0 + (a.sup_idx[n + 1] - a.sup_idx[n]);
         double acc = 0.;
         for (int k = r0; k < r1; ++k) acc += lf1[k];
-        ntmp[n] = acc / (MASS ? my_vn : volume_n_in[n]);
+        ntmp[n] = acc / volume_n_in[n];
         if (thermal) {
             if (bcflag[n] & BOUNDZ1)
                 T_out[n] = p->surface_temperature;
             else {
                 double tdot = 0;
                 for (int k = r0; k < r1; ++k) tdot += lf0[k];
-                T_out[n] = lT[threadIdx.x] - clk->dt * tdot / (MASS ? my_tm : tmass_in[n]);
+                T_out[n] = lT[threadIdx.x] - clk->dt * tdot / tmass_in[n];
             }
         }
+    }
     }
     if (topb) {
         // The late surface step's stores, all at the very end: a store through a pointer the compiler cannot tell from `p`
