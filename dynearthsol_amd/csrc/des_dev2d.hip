@@ -644,20 +644,38 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
         es[i] = strain[i * ne + e];
         edot[i] = strain_rate[i * ne + e];
     }
+    // (round 5: the mean temperature and the plastic strain the law wants are asked for HERE, beside the other fields -- inside the
+    //  law's case they were two more dependent trips to memory in the middle of the pass)
+    const int rh_ = RH ? RH : p->rheol_type;
+    const bool law_T = rh_ == DES_RH_VISCOUS || rh_ == DES_RH_MAXWELL || rh_ == DES_RH_EVP;
+    const bool law_pls = rh_ == DES_RH_EP || rh_ == DES_RH_EVP;
+    double Tm = 0, pls0 = 0;
+    if (law_pls) pls0 = plstrain[e];
+    // ... and every nodal value the pass gathers through the connectivity in ONE round behind it: the coordinates and velocities
+    // of the step before's end-of-step part (FUSED = 2), the nodal dvoldt (FUSED), the temperatures
+    int cn[3];
+    for (int i = 0; i < 3; ++i) cn[i] = conn[i * ne + e];
+    double d[3][2], vv[3][2], nt3[3] = {0, 0, 0};
+    if (FUSED == 2) for (int i = 0; i < 3; ++i) { d[i][0] = coord[cn[i]]; d[i][1] = coord[nn + cn[i]]; }
+    if (FUSED == 2 && rotate) for (int i = 0; i < 3; ++i) { vv[i][0] = vel[cn[i]]; vv[i][1] = vel[nn + cn[i]]; }
+    if (FUSED) for (int i = 0; i < 3; ++i) nt3[i] = ntmp[cn[i]];
+    if (law_T) {                                           // elemT's statements (matprops.cxx:338-343)
+        double T = 0;
+        for (int i = 0; i < 3; ++i) T += temperature[cn[i]];
+        T /= 3;
+        Tm = T;
+    }
     double vol, vol_old;
     if (FUSED == 2) {
         vol_old = volume[e];
-        double d[3][2];
-        elem_coords(coord, conn, nn, ne, e, d);
         vol = triangle_area(d[0], d[1], d[2]);
         volume[e] = vol;
         if (outs) volume_old[e] = vol_old;
         if (rotate) {
-            double shpdx[3], shpdz[3], v[3][2];
+            double shpdx[3], shpdz[3];
             shape_fn2(d, vol, shpdx, shpdz);
-            elem_coords(vel, conn, nn, ne, e, v);
             double w2 = 0;
-            for (int i = 0; i < 3; ++i) w2 += 0.5 * (v[i][1] * shpdx[i] - v[i][0] * shpdz[i]);
+            for (int i = 0; i < 3; ++i) w2 += 0.5 * (vv[i][1] * shpdx[i] - vv[i][0] * shpdz[i]);
             jaumann_rate_2d(s, dt, w2);
             jaumann_rate_2d(es, dt, w2);
         }
@@ -668,7 +686,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
     double edv;
     if (FUSED) {
         double dj = 0;
-        for (int i = 0; i < 3; ++i) dj += ntmp[conn[i * ne + e]];
+        for (int i = 0; i < 3; ++i) dj += nt3[i];
         edv = dj / 3;
         if (outs) edvoldt[e] = edv;
     } else
@@ -690,14 +708,14 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
         elastic2(bulkm, shearm, de, s);
         break;
     case DES_RH_VISCOUS: {
-        double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
+        double visc = mat_visc2<M>(p, vt, mx, Tm, s, edot);
         if (outs) viscosity[e] = visc;
         double total_dv = trace2(es);
         viscous2(bulkm, visc, total_dv, edot, s);
         break;
     }
     case DES_RH_MAXWELL: {
-        double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
+        double visc = mat_visc2<M>(p, vt, mx, Tm, s, edot);
         if (outs) viscosity[e] = visc;
         double dv = vol / vol_old - 1;
         maxwell2(bulkm, shearm, visc, dt, dv, de, s);
@@ -706,7 +724,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
     case DES_RH_EP: {
         double depls = 0;
         double amc, anphi, anpsi, hardn, ten_max;
-        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max, pptab);
+        desk::plastic_props<M>(p, mx, pls0, amc, anphi, anpsi, hardn, ten_max, pptab);
         if (p->is_plane_strain) {
             double syy = stressyy[e];
             elasto_plastic2d(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, s, syy);
@@ -715,13 +733,13 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
             elasto_plastic(bulkm, shearm, amc, anphi, anpsi, hardn, ten_max, de, depls, s);
             past = 1;
         }
-        plstrain[e] += depls;
+        plstrain[e] = pls0 + depls;
         dpls = depls;
         break;
     }
     case DES_RH_EVP: {
         double depls = 0;
-        double visc = mat_visc2<M>(p, vt, mx, elemT(temperature, conn, ne, e), s, edot);
+        double visc = mat_visc2<M>(p, vt, mx, Tm, s, edot);
         if (outs) viscosity[e] = visc;
         double dv = vol / vol_old - 1;
         double sv[3];
@@ -730,7 +748,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
         double svII = second_invariant2_2d(sv);
 
         double amc, anphi, anpsi, hardn, ten_max;
-        desk::plastic_props<M>(p, mx, plstrain[e], amc, anphi, anpsi, hardn, ten_max, pptab);
+        desk::plastic_props<M>(p, mx, pls0, amc, anphi, anpsi, hardn, ten_max, pptab);
         double sp[3], spyy = 0;
         for (int i = 0; i < 3; ++i) sp[i] = s[i];
         if (p->is_plane_strain) {
@@ -745,7 +763,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
             for (int i = 0; i < 3; ++i) s[i] = sv[i];
         } else {
             for (int i = 0; i < 3; ++i) s[i] = sp[i];
-            plstrain[e] += depls;
+            plstrain[e] = pls0 + depls;
             dpls = depls;
             if (p->is_plane_strain) stressyy[e] = spyy;
         }
