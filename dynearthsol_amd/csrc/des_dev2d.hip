@@ -46,6 +46,7 @@ struct Clock {
     int status, iso, n_past, x0_init;
     int pt;                            // inside the pseudo-transient loop of a step (Param::control.PT_jump)
     int l2_global;                     // l2_residual / l2_sum hold the GLOBAL block sum (k2_residual_final), not this rank's owned share
+    double dt_prev;                    // the dt a compute_dt step ran with (its end-of-step rotation may ride in the next stress update)
 };
 
 inline int nblk(long long n) { return (int)((n + DES_BLOCK - 1) / DES_BLOCK); }
@@ -97,6 +98,9 @@ struct Engine {
     // (round 5) a plain step inside a multi-step call leaves its surface step to the next step's first two passes as well
     // (one_step: surf_late -> surf_pending; DES2D_SURF_DEFER=0: off); topflag: the top elements
     bool surf_defer_on = true, surf_late = false, surf_pending = false;
+    // (round 5) ... and a compute_dt step inside a call leaves its end-of-step element pass and compute_mass behind like any other
+    // (the single engine; DES2D_DT_DEFER=0: off): compute_dt forms the volumes it wants from the coordinates, the rotation keeps its dt
+    bool dt_defer_on = true, rot_prev_dt = false;
     unsigned char *topflag = nullptr;
     int *pt_ptr = nullptr, *pt_zero = nullptr; int4 *pt_ent = nullptr; bool surf_defer_fits = true;
     int *d_bperm = nullptr;                      // the blocks in launch order: every XCD its share of the surface blocks, first
@@ -676,8 +680,10 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
             shape_fn2(d, vol, shpdx, shpdz);
             double w2 = 0;
             for (int i = 0; i < 3; ++i) w2 += 0.5 * (vv[i][1] * shpdx[i] - vv[i][0] * shpdz[i]);
-            jaumann_rate_2d(s, dt, w2);
-            jaumann_rate_2d(es, dt, w2);
+            // (rotate = 2: the step being finished was a compute_dt step -- it ran with the dt before the new one)
+            const double dt_rot = rotate == 2 ? clk->dt_prev : dt;
+            jaumann_rate_2d(s, dt_rot, w2);
+            jaumann_rate_2d(es, dt_rot, w2);
         }
     } else {
         vol = volume[e];
@@ -1744,6 +1750,8 @@ __global__ void k2_dt_init(Clock *clk)
 //  workgroup, reduces them: five thousand workgroups doing five 64-bit atomic min / max on the five words of ONE cache line
 //  serialised in the L2, 80-93 us for 1.28M triangles against 23 us for the 3-D engine's pass, which has stored partials since
 //  round 2.  min and max are exact whatever the order: the same bits.)
+// volume == nullptr (round 5): compute_volume of this step has been left to the next stress update -- its own expression on the
+// moved coordinates gives the value it will store
 __global__ void k2_dt_partials(const des_params *__restrict__ p, double *dt_part, int nn, int ne, const int *conn, const double *coord,
                                const double *vel, const double *temperature, const double *volume, const double *props,
                                const int *markers)
@@ -1763,7 +1771,7 @@ __global__ void k2_dt_partials(const des_params *__restrict__ p, double *dt_part
         double d[3][2];
         elem_coords(coord, conn, nn, ne, e, d);
         double maxl = sqrt(fmax(fmax(dist2(d[0], d[1]), dist2(d[1], d[2])), dist2(d[0], d[2])));
-        double minh = 2 * volume[e] / maxl;
+        double minh = 2 * (volume ? volume[e] : triangle_area(d[0], d[1], d[2])) / maxl;
         const double shearm = prop2(p, props, ne, e, 1);
         dt_maxwell = 0.5 * p->visc_min / (1e-40 + shearm);
         if (p->has_thermal_diffusion) dt_diffusion = 0.5 * minh * minh / p->therm_diff_max;
@@ -1820,6 +1828,7 @@ __device__ __forceinline__ void dt_finalize_body(const des_params *__restrict__ 
 {
     const double minl = clk->r_minl, dt_maxwell = clk->r_dt_maxwell, dt_diffusion = clk->r_dt_diffusion;
     const double dt_hydro_diffusion = DBL_MAX;
+    clk->dt_prev = clk->dt;
     double global_max_vem = clk->r_max_vem;
     double max_vbc_val;
     if (p->characteristic_speed == 0) {
@@ -2101,7 +2110,7 @@ void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr, 
     const int past_base = h->past_base;
     if (h->count_past) h->past_base += nblk(nlist) * (DES_BLOCK / 64);
     Prof2 pr(h, P2_STRESS);
-    const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? 1 : 0;
+    const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? (h->rot_prev_dt ? 2 : 1) : 0;
 #define K2S_ARGS(out, outs) h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt, \
         h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain, \
         h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, out, h->nn, h->coord, h->vel, rot, outs, elist, nlist, \
@@ -2248,7 +2257,10 @@ void launch_update_mesh_rest(Engine *h, long long steps, bool rotate, bool defer
 void launch_dt(Engine *h)
 {
     refresh_props(h);
-    L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
+    // (geo_pending: this step's compute_volume waits in the next stress update -- and its rotation must keep this step's dt)
+    if (h->geo_pending) h->rot_prev_dt = true;
+    L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature,
+       h->geo_pending ? (const double *)nullptr : h->volume, h->props, h->markers);
     hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 1);
 }
 
@@ -2335,7 +2347,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             launch_temp_dvoldt(h, thermal, T_in, T_out);
             launch_stress<M>(h, true, s_law);
         }
-        h->geo_pending = false; h->mass_pending = false; h->surf_pending = false;
+        h->geo_pending = false; h->mass_pending = false; h->surf_pending = false; h->rot_prev_dt = false;
         const bool fold = tail && fold_now(h);
         // (the folded tail wants the wall's extent in the clock before the force pass: it rides in the nodal average's launch)
         const bool avg_extent = fold && nmd && (h->halo || !wall_needs_zmin(h));
@@ -2575,7 +2587,7 @@ inline bool defer_ok(const Engine *h, bool more)
     const bool rotate = !h->iso && (p.rheol_type & DES_RH_ELASTIC);
     const bool moved = p.has_moving_mesh || h->iso;
     return more && h->patch && moved && rotate && !p.is_outputting_averaged_fields && !p.has_PT
-           && h->steps_host % 10 != 0 && h->geo_on;
+           && (h->steps_host % 10 != 0 || (h->dt_defer_on && !h->halo && h->mass_fuse_on)) && h->geo_on;
 }
 
 // Overlapped schedule: this step's exchange may run beside the next step's first passes when nothing else of this step
@@ -2951,6 +2963,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                 }
                 const char *fe = des_env::get("DES2D_FOLD"); h->fold_on = !(fe && fe[0] == '0');
                 const char *se = des_env::get("DES2D_SURF_DEFER"); h->surf_defer_on = !(se && se[0] == '0');
+                const char *de = des_env::get("DES2D_DT_DEFER"); h->dt_defer_on = !(de && de[0] == '0');
             }
             A2(dalloc(h, h->stress_pre, (size_t)3 * ne));
         }
@@ -3171,7 +3184,7 @@ static int step_abort(Engine *h, int rc)
 {
     hipStreamSynchronize(h->xstream);
     hipStreamSynchronize(h->stream);
-    h->join_pending = false; h->wall_pending = false; h->far_issued = false; h->mass_pending = false; h->surf_pending = false;
+    h->join_pending = false; h->wall_pending = false; h->far_issued = false; h->mass_pending = false; h->surf_pending = false; h->rot_prev_dt = false;
     static const int zero = 0;
     hipMemcpy(&h->d_clk->pt, &zero, sizeof(int), hipMemcpyHostToDevice);     // a loop the error may have come from
     h->no_neumann = false;

@@ -134,18 +134,19 @@ def test_320k_triangles_500_steps_against_the_oracle_on_the_c_library():
 def test_late_surface_step_across_every_kind_of_call_boundary():
     """Round 5: a plain step inside a multi-step call leaves its surface step (simple_diffusion, edvacc_surf,
     correct_surface_element) to the next step's k2p_temp_dvoldt<1> -- except on compute_dt steps, on the steps of the
-    quality-check interval and on the last step of a call.  Call lengths that put every one of those next to every other,
+    quality-check interval and on the last step of a call; a compute_dt step leaves its end-of-step element pass and
+    compute_mass behind like any other step (its rotation keeps the dt it ran with).  Call lengths that put every one of those next to every other,
     on a mesh with enough blocks for the balanced launch order (DES2D_TOP_BALANCE): all fields, dh / dhacc / edvacc_surf
     among them, equal to the oracle's after every call -- and to an engine with both switched off."""
     import os
     kw = dict(cfgs.EVP, nmat=2, lx=100e3, lz=30e3, res=500.0, qcsi=7, water="yes", control="surf_base_level = -100\nsurf_diff_ratio_marine = 0.5\n")
     host = des.Host(cfg_text=cfgs.make(**kw), ndims=2)
     dev, ora = des.DeviceEngine(host), OracleEngine(host, omp=True)
-    os.environ["DES2D_SURF_DEFER"] = "0"; os.environ["DES2D_TOP_BALANCE"] = "0"
+    os.environ["DES2D_SURF_DEFER"] = "0"; os.environ["DES2D_TOP_BALANCE"] = "0"; os.environ["DES2D_DT_DEFER"] = "0"
     try:
         plain = des.DeviceEngine(host)
     finally:
-        del os.environ["DES2D_SURF_DEFER"], os.environ["DES2D_TOP_BALANCE"]
+        del os.environ["DES2D_SURF_DEFER"], os.environ["DES2D_TOP_BALANCE"], os.environ["DES2D_DT_DEFER"]
     assert dev.init_from_host(host) == ora.init_from_host(host) == plain.init_from_host(host)
     for n in (1, 2, 3, 9, 10, 11, 19, 7, 14, 41):
         sd, so, sp = dev.step(n), ora.step(n), plain.step(n)
@@ -283,7 +284,7 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
 
 
 @pytest.mark.parametrize("knob", ["DES2D_PATCH=0", "DES2D_PATCH=64", "DES2D_PATCH=40", "DES2D_CLUSTER=0", "DES2D_GEO=0", "DES2D_ELIDE=0",
-                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0", "DES2D_FOLD=0", "DES2D_SURF_DEFER=0", "DES2D_TOP_BALANCE=0"])
+                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0", "DES2D_FOLD=0", "DES2D_SURF_DEFER=0", "DES2D_TOP_BALANCE=0", "DES2D_DT_DEFER=0"])
 def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
     """The node-block patch passes (des_dev2d_patch.hpp: temperature + dvoldt, NMD + force, mass; the default) against the
     one-kernel-per-loop path (DES2D_PATCH=0), other block sizes and groupings, and with the end-of-step pass / the store
