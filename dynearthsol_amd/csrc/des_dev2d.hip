@@ -2662,7 +2662,9 @@ int one_step(Engine *h, bool more = false)
 void launch_dt_partials(Engine *h)
 {
     refresh_props(h);
-    L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature, h->volume, h->props, h->markers);
+    if (h->geo_pending) h->rot_prev_dt = true;             // (as launch_dt)
+    L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature,
+       h->geo_pending ? (const double *)nullptr : h->volume, h->props, h->markers);
     hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 0);
 }
 
