@@ -640,7 +640,9 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
     if (t >= nlist) return;
     const int e = elist ? elist[t] : t;
     const double dt = clk->dt;
-    const desk::Mix mx = mix2(mono[e], markers, p->nmat, e);
+    // (the marker word is asked for here and USED below, behind the other requests: mix2 branches on it, and in front of
+    //  them that was a trip to memory of its own)
+    const int mono_e = mono[e];
     const double bulkm = prop2(p, props, ne, e, 0), shearm = prop2(p, props, ne, e, 1);
     double s[3], es[3], edot[3];
     for (int i = 0; i < 3; ++i) {
@@ -669,6 +671,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
         T /= 3;
         Tm = T;
     }
+    const desk::Mix mx = mix2(mono_e, markers, p->nmat, e);
     double vol, vol_old;
     if (FUSED == 2) {
         vol_old = volume[e];
