@@ -114,7 +114,7 @@ struct Engine {
     bool geo_pending = false;                  // compute_volume + rotate_stress of the last step left to the next k2_stress<M, 2>
     bool mass_fuse_on = true, mass_pending = false;   // DES2D_MASS_FUSE != 0; compute_mass of the last step left to the next k2p_temp_dvoldt<1>
     bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
-    int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0;
+    int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0, p_pe_cap = 0;
     int *po_ptr = nullptr, *po_id = nullptr, *po_slot = nullptr, *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
     ulonglong2 *pe_pack = nullptr;
     double *temperature_alt = nullptr;         // the other buffer of the temperature pair (k2p_temp_dvoldt)
@@ -2287,7 +2287,7 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
     Prof2 pr(h, P2_TEMP);
 #define K2T_ARGS h->d_p, h->d_clk, thermal ? 1 : 0, h->geo_pending ? 1 : 0, a, \
                        h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->props, \
-                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass, pre, nb_tail, pre ? h->pt_ptr : h->pt_zero
+                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass, pre, nb_tail, pre ? h->pt_ptr : h->pt_zero, h->p_pe_cap
     const SurfPre *pre = nullptr;
     int nb_tail = 0;
     if (h->surf_pending && h->mass_pending) {
@@ -2296,8 +2296,9 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
         pre = reinterpret_cast<const SurfPre *>(h->d_surfpre);
     }
     if (h->mass_pending) {
-        // (six slot arrays: compute_mass's four and this pass's two in one node phase)
-        const size_t lds = 8 * (5 * (size_t)a.pn_cap + 6 * (size_t)a.inc_cap);
+        // (compute_mass's four sums and this pass's two in one node phase: five values per patch ELEMENT, one per incidence and
+        //  the incidence's element as 16 bits -- des_dev2d_patch.hpp)
+        const size_t lds = 8 * (5 * (size_t)a.pn_cap + 5 * (size_t)h->p_pe_cap + (size_t)a.inc_cap) + 2 * (size_t)a.inc_cap;
         if (lds > 65536) hipFuncSetAttribute((const void *)k2p_temp_dvoldt<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), lds, h->stream, K2T_ARGS);
     }
@@ -2822,7 +2823,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
         }
         if (ok) {
             h->patch = true; h->p_npb = P.npb; h->p_nb = P.nb;
-            h->p_pn_cap = (P.max_pn + 7) / 8 * 8; h->p_inc_cap = (P.max_inc + 7) / 8 * 8;
+            h->p_pn_cap = (P.max_pn + 7) / 8 * 8; h->p_inc_cap = (P.max_inc + 7) / 8 * 8; h->p_pe_cap = (P.max_pe + 7) / 8 * 8;
             if (des_env::get("DES_PATCH_VERBOSE"))
                 std::fprintf(stderr, "2-D patches: %d nodes per block, %d blocks, max incidences %d, patch nodes %d, patch elements %d, "
                              "elements listed %zu (%.2f x nelem)\n", P.npb, P.nb, P.max_inc, P.max_pn, P.max_pe, P.pe_pack.size(),

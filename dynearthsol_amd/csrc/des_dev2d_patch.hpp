@@ -188,7 +188,7 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
                 const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass_in, const double *volume_n_in,
                 double *ntmp, double *strain_rate, double *volume_n_out, double *mass_out, double *tmass_out, double *ymass_out,
-                const SurfPre *pre, int nb_front, const int *pt_ptr)
+                const SurfPre *pre, int nb_front, const int *pt_ptr, int pe_cap)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
@@ -260,7 +260,13 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
         // arrays instead of four reused: three workgroups per CU instead of four, but two barriers instead of four, and the area,
         // the mean temperature and mat_rho of an element formed once instead of twice -- the same expressions on the same
         // values, so the same bits).
-        double *const lf4 = lf3 + a.inc_cap, *const lf5 = lf4 + a.inc_cap;
+        // LDS (the launch sizes it): behind the five nodal arrays, five values per patch ELEMENT (volume, the three mass terms, the
+        // dvoldt term: the same for each of the element's nodes), the conduction term per INCIDENCE (it differs per node) and the
+        // incidence's patch element as 16 bits -- 31 KB for the 1.28M-triangle mesh's blocks instead of 46 with six values per
+        // incidence: five workgroups per CU instead of three, and 11 LDS stores per element instead of 18
+        double *const lvol = lf0, *const lm = lvol + pe_cap, *const ltm = lm + pe_cap, *const lym = ltm + pe_cap, *const let = lym + pe_cap;
+        double *const ltd = let + pe_cap;
+        unsigned short *const lidx = (unsigned short *)(ltd + a.inc_cap);
         const int mass_thermal = p->has_thermal_diffusion;
 #pragma unroll
         for (int k = 0; k < DES2_PATCH_IT; ++k) {
@@ -299,16 +305,17 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
             }
             double dj = s0 + s1;
             const double et = dj * vol;
+            const int q = (int)threadIdx.x + k * DES2_PATCH_THREADS;         // the element's position in the patch
+            lvol[q] = vol_m; lm[q] = m; ltm[q] = tm; lym[q] = ym; let[q] = et;
             for (int i = 0; i < 3; ++i) {
                 if (E.sl[i] == 0xfff) continue;
-                lf0[E.sl[i]] = vol_m; lf1[E.sl[i]] = m; lf2[E.sl[i]] = tm; lf3[E.sl[i]] = ym;
+                lidx[E.sl[i]] = (unsigned short)q;
                 if (thermal) {
                     double diffusion = 0.;
                     for (int j = 0; j < 3; ++j)
                         diffusion += (shpdx[i] * shpdx[j] + shpdz[i] * shpdz[j]) * T[j];
-                    lf4[E.sl[i]] = diffusion * kv - rh;
+                    ltd[E.sl[i]] = diffusion * kv - rh;
                 }
-                lf5[E.sl[i]] = et;
             }
         }
         __syncthreads();
@@ -318,12 +325,13 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
             const bool t_node = thermal && !(bcflag[n] & BOUNDZ1);
             double vn = 0, ms = 0, tms = 0, yms = 0, acc = 0., tdot = 0;
             for (int k = r0; k < r1; ++k) {
-                vn += lf0[k];
-                ms += lf1[k];
-                if (mass_thermal) tms += lf2[k];
-                yms += lf3[k];
-                acc += lf5[k];
-                if (t_node) tdot += lf4[k];
+                const int q = lidx[k];
+                vn += lvol[q];
+                ms += lm[q];
+                if (mass_thermal) tms += ltm[q];
+                yms += lym[q];
+                acc += let[q];
+                if (t_node) tdot += ltd[k];
             }
             volume_n_out[n] = vn; mass_out[n] = ms; tmass_out[n] = tms; ymass_out[n] = yms;
             ntmp[n] = acc / vn;
