@@ -2299,8 +2299,14 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
         // (compute_mass's four sums and this pass's two in one node phase: five values per patch ELEMENT, one per incidence and
         //  the incidence's element as 16 bits -- des_dev2d_patch.hpp)
         const size_t lds = 8 * (5 * (size_t)a.pn_cap + 5 * (size_t)h->p_pe_cap + (size_t)a.inc_cap) + 2 * (size_t)a.inc_cap;
-        if (lds > 65536) hipFuncSetAttribute((const void *)k2p_temp_dvoldt<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k2p_temp_dvoldt<1>, dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), lds, h->stream, K2T_ARGS);
+        // (two patch elements per lane at most when the mesh's largest patch allows: 17 registers less)
+        if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS) {
+            if (lds > 65536) hipFuncSetAttribute((const void *)k2p_temp_dvoldt<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k2p_temp_dvoldt<1, 2>), dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), lds, h->stream, K2T_ARGS);
+        } else {
+            if (lds > 65536) hipFuncSetAttribute((const void *)k2p_temp_dvoldt<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k2p_temp_dvoldt<1, 3>), dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), lds, h->stream, K2T_ARGS);
+        }
     }
     else
         hipLaunchKernelGGL(k2p_temp_dvoldt<0>, dim3((a.nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (5 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, K2T_ARGS);
@@ -2375,7 +2381,11 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
                 h->tick_pending = false;
             } else join_wall(h);
             { Prof2 pr(h, P2_FORCE);
-            hipLaunchKernelGGL(k2p_force<1>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+            if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS)
+            hipLaunchKernelGGL((k2p_force<1, 2>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+                               h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
+            else
+            hipLaunchKernelGGL((k2p_force<1, 3>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
                                h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
             }
             std::swap(h->coord, h->coord_alt);             // the moved coordinates are the current ones from here on

@@ -182,8 +182,9 @@ __device__ __forceinline__ int patch_block(const PatchArgs &a, int front = 0)
 struct SurfPre { const double2 *xz_pre; const int *pt_ptr; const int4 *pt_ent; const unsigned char *topflag; int ntop, etop; const int *ean, *conn_surf;
                  double *total_dx, *total_slope, *dhacc, *dh, *edvacc, *plstrain, *stress, *strain; };
 
-template <int MASS>
-__global__ void __launch_bounds__(DES2_PATCH_THREADS)
+// IT: patch elements per lane at most (2 when the mesh's largest patch has at most 512: 17 registers less than with 3)
+template <int MASS, int IT = DES2_PATCH_IT>
+__global__ void __launch_bounds__(DES2_PATCH_THREADS, 5)
 k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk, int thermal, int vol_from_coords, const PatchArgs a, const unsigned *bcflag,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
                 const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass_in, const double *volume_n_in,
@@ -221,16 +222,16 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
     const double pseudo_speed = MASS ? p->max_vbc_val * p->inertial_scaling : 0.0;
     // everything that does not depend on the staged records is loaded first, so that a workgroup's trips to memory overlap:
     // this lane's list entries, then the element data they name, beside the nodal records
-    ulonglong2 rec[DES2_PATCH_IT];
-    double g_vol[DES2_PATCH_IT], g_kc[DES2_PATCH_IT], g_rad[DES2_PATCH_IT];
-    double g_bulk[DES2_PATCH_IT], g_shear[DES2_PATCH_IT], g_cp[DES2_PATCH_IT];
-    int g_mono[DES2_PATCH_IT];
+    ulonglong2 rec[IT];
+    double g_vol[IT], g_kc[IT], g_rad[IT];
+    double g_bulk[IT], g_shear[IT], g_cp[IT];
+    int g_mono[IT];
     const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
 #pragma unroll
-    for (int k = 0; k < DES2_PATCH_IT; ++k)
+    for (int k = 0; k < IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) rec[k] = a.pe_pack[q0 + k * DES2_PATCH_THREADS];
 #pragma unroll
-    for (int k = 0; k < DES2_PATCH_IT; ++k)
+    for (int k = 0; k < IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
             g_vol[k] = vol_from_coords ? 0.0 : volume[e];
@@ -269,7 +270,7 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
         unsigned short *const lidx = (unsigned short *)(ltd + a.inc_cap);
         const int mass_thermal = p->has_thermal_diffusion;
 #pragma unroll
-        for (int k = 0; k < DES2_PATCH_IT; ++k) {
+        for (int k = 0; k < IT; ++k) {
             if (q0 + k * DES2_PATCH_THREADS >= qe) break;
             const PatchElem2 E = patch_elem2(rec[k]);
             const int e = E.e;
@@ -339,7 +340,7 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
         }
     } else {
 #pragma unroll
-    for (int k = 0; k < DES2_PATCH_IT; ++k) {
+    for (int k = 0; k < IT; ++k) {
         if (q0 + k * DES2_PATCH_THREADS >= qe) break;
         const PatchElem2 E = patch_elem2(rec[k]);
         const int e = E.e;
@@ -416,7 +417,7 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
             }
         }
 #pragma unroll
-        for (int k = 0; k < DES2_PATCH_IT; ++k) {
+        for (int k = 0; k < IT; ++k) {
             if (q0 + k * DES2_PATCH_THREADS >= qe) break;
             const PatchElem2 E = patch_elem2(rec[k]);
             const int e = E.e;
@@ -452,7 +453,7 @@ struct ForceTail {
     double *vel, *coord_out; const int *conn; const int *sbcn_idx; const int4 *sbcn_ent; double *res_part; int o0, o1, nn_global;
     const int *top_pos; double2 *xz_pre;        // a top node's position in top_nodes (-1: below the surface); its moved {x, z} there (k2_surf_commit)
 };
-template <int TAIL>
+template <int TAIL, int IT = DES2_PATCH_IT>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_force(const des_params *__restrict__ p, int nmd, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
           const double *volume, const double *dpressure, const double *stress_in, double *stress_out, const double *props,
@@ -467,15 +468,15 @@ k2p_force(const des_params *__restrict__ p, int nmd, const PatchArgs a, const do
     const int o0 = a.po_ptr[b], nown = a.po_ptr[b + 1] - o0;
     const int h0 = a.pn_ptr[b], nh = a.pn_ptr[b + 1] - h0;
     const double gravity = p->gravity;
-    ulonglong2 rec[DES2_PATCH_IT];
-    double g_vol[DES2_PATCH_IT], g_s[DES2_PATCH_IT][3], g_dp[DES2_PATCH_IT], g_phi[DES2_PATCH_IT];
-    int g_mono[DES2_PATCH_IT];
+    ulonglong2 rec[IT];
+    double g_vol[IT], g_s[IT][3], g_dp[IT], g_phi[IT];
+    int g_mono[IT];
     const int q0 = a.pe_ptr[b] + threadIdx.x, qe = a.pe_ptr[b + 1];
 #pragma unroll
-    for (int k = 0; k < DES2_PATCH_IT; ++k)
+    for (int k = 0; k < IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) rec[k] = a.pe_pack[q0 + k * DES2_PATCH_THREADS];
 #pragma unroll
-    for (int k = 0; k < DES2_PATCH_IT; ++k)
+    for (int k = 0; k < IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
             g_vol[k] = volume[e];
@@ -508,7 +509,7 @@ k2p_force(const des_params *__restrict__ p, int nmd, const PatchArgs a, const do
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < DES2_PATCH_IT; ++k) {
+    for (int k = 0; k < IT; ++k) {
         if (q0 + k * DES2_PATCH_THREADS >= qe) break;
         const PatchElem2 E = patch_elem2(rec[k]);
         const int e = E.e;
