@@ -80,3 +80,31 @@ def test_patch_pass_lds_follows_the_mesh():
     en3 = lambda inc, pn: cap(pn) * 40 + cap(inc) * 24
     assert en1(1596, 290, 870) <= 160 * 1024 // 3 and en3(1596, 290) <= 160 * 1024 // 3
     assert en1(1048, 212, 608) <= 160 * 1024 // 4 and en3(1048, 212) <= 160 * 1024 // 4
+
+
+@pytest.fixture(scope="module")
+def table2d():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--2d"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = []
+    for line in out.stdout.splitlines()[1:]:
+        f = line.split()
+        if len(f) < 6:
+            continue
+        rows.append((" ".join(f[:-5]), dict(vgpr=int(f[-5]), sgpr=int(f[-4]), scratch=int(f[-3]), lds=int(f[-2]), waves=int(f[-1]))))
+    assert len(rows) > 40
+    return rows
+
+
+@pytest.mark.parametrize("kernel,max_vgpr,min_waves", [
+    # the 2-D step's four launches (round 5: the patch passes' time follows the workgroups a CU holds -- DESIGN.md section 2.3 --,
+    # so their register budgets are pinned like the 3-D ones: two patch elements per lane at most on meshes whose largest patch allows)
+    ("k2p_temp_dvoldt<1, 2>", 96, 5),
+    ("k2p_force<1, 2>", 80, 6),
+    ("k2_stress<desk::MathPortable, 2, 7>", 128, 4),
+    ("k2_node_avg_extent", 64, 8),
+])
+def test_2d_step_kernels_stay_scratch_free_and_inside_their_budgets(table2d, kernel, max_vgpr, min_waves):
+    r = pick(table2d, kernel)
+    assert r["scratch"] == 0, r
+    assert r["vgpr"] <= max_vgpr and r["waves"] >= min_waves, r
