@@ -115,6 +115,7 @@ struct Engine {
     bool mass_fuse_on = true, mass_pending = false;   // DES2D_MASS_FUSE != 0; compute_mass of the last step left to the next k2p_temp_dvoldt<1>
     bool no_neumann = false;                   // initial_body_force_adjustment: Neumann tractions held back (fields.cxx:690)
     int p_npb = 0, p_nb = 0, p_pn_cap = 0, p_inc_cap = 0, p_pe_cap = 0;
+    bool it3_forced = false;                   // DES2D_PATCH_IT=3: the three-elements-per-lane forms of the patch passes whatever the mesh (tests)
     int *po_ptr = nullptr, *po_id = nullptr, *po_slot = nullptr, *pe_ptr = nullptr, *pn_ptr = nullptr, *pn_id = nullptr;
     ulonglong2 *pe_pack = nullptr;
     double *temperature_alt = nullptr;         // the other buffer of the temperature pair (k2p_temp_dvoldt)
@@ -2300,7 +2301,7 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
         //  the incidence's element as 16 bits -- des_dev2d_patch.hpp)
         const size_t lds = 8 * (5 * (size_t)a.pn_cap + 5 * (size_t)h->p_pe_cap + (size_t)a.inc_cap) + 2 * (size_t)a.inc_cap;
         // (two patch elements per lane at most when the mesh's largest patch allows: 17 registers less)
-        if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS) {
+        if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS && !h->it3_forced) {
             if (lds > 65536) hipFuncSetAttribute((const void *)k2p_temp_dvoldt<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k2p_temp_dvoldt<1, 2>), dim3((a.nb + 7) / 8 * 8 + nb_tail), dim3(DES2_PATCH_THREADS), lds, h->stream, K2T_ARGS);
         } else {
@@ -2381,7 +2382,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
                 h->tick_pending = false;
             } else join_wall(h);
             { Prof2 pr(h, P2_FORCE);
-            if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS)
+            if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS && !h->it3_forced)
             hipLaunchKernelGGL((k2p_force<1, 2>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
                                h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
             else
@@ -2980,6 +2981,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                 const char *fe = des_env::get("DES2D_FOLD"); h->fold_on = !(fe && fe[0] == '0');
                 const char *se = des_env::get("DES2D_SURF_DEFER"); h->surf_defer_on = !(se && se[0] == '0');
                 const char *de = des_env::get("DES2D_DT_DEFER"); h->dt_defer_on = !(de && de[0] == '0');
+                const char *ie = des_env::get("DES2D_PATCH_IT"); h->it3_forced = ie && ie[0] == '3';
             }
             A2(dalloc(h, h->stress_pre, (size_t)3 * ne));
         }
