@@ -2383,10 +2383,10 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             } else join_wall(h);
             { Prof2 pr(h, P2_FORCE);
             if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS && !h->it3_forced)
-            hipLaunchKernelGGL((k2p_force<1, 2>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+            hipLaunchKernelGGL((k2p_force<1, 2>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, h->elide ? 0 : 1, a, h->coord,
                                h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
             else
-            hipLaunchKernelGGL((k2p_force<1, 3>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+            hipLaunchKernelGGL((k2p_force<1, 3>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, h->elide ? 0 : 1, a, h->coord,
                                h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
             }
             std::swap(h->coord, h->coord_alt);             // the moved coordinates are the current ones from here on
@@ -2399,7 +2399,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             return;
         }
         { Prof2 pr(h, P2_FORCE);
-        hipLaunchKernelGGL(k2p_force<0>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, a, h->coord,
+        hipLaunchKernelGGL(k2p_force<0>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, h->elide ? 0 : 1, a, h->coord,
                            h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
         }
         launch_stress_bcs(h);

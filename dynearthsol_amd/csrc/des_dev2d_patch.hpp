@@ -455,7 +455,7 @@ struct ForceTail {
 };
 template <int TAIL, int IT = DES2_PATCH_IT>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
-k2p_force(const des_params *__restrict__ p, int nmd, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
+k2p_force(const des_params *__restrict__ p, int nmd, int outs, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
           const double *volume, const double *dpressure, const double *stress_in, double *stress_out, const double *props,
           const int *markers, const int *mono, double *force, double *fres, const ForceTail ft)
 {
@@ -554,7 +554,9 @@ k2p_force(const des_params *__restrict__ p, int nmd, const PatchArgs a, const do
             f[0] -= lf0[k]; fr[0] = lf0[k];            // assignment: fields.cxx:673
             f[1] -= lf1[k]; fr[1] = lf1[k];
         }
-        for (int j = 0; j < 2; j++) fres[j*nn + n] = fr[j];
+        // (outs = 0: a step of a multi-step call that is not its last -- force and force_residual are formed anew by the next
+        //  step's pass before anything reads them, and what the step needs of them it has here in registers)
+        if (!TAIL || outs) for (int j = 0; j < 2; j++) fres[j*nn + n] = fr[j];
         if (!TAIL) { for (int j = 0; j < 2; j++) force[j*nn + n] = f[j]; }
         else {
             // apply_stress_bcs (bc.cxx:661-827): k2_sbc_direct's walk for this node, one loaded boundary after the other
@@ -569,7 +571,7 @@ k2p_force(const des_params *__restrict__ p, int nmd, const PatchArgs a, const do
             // before it moves: the staged one), update_coordinate into the other buffer of the pair
             const double dt = t_dt;
             damp_vel_regs(t_dopt, t_dfac, dt, t_mass, t_ymass, f, t_v);
-            for (int j = 0; j < 2; j++) force[j*nn + n] = f[j];
+            if (outs) for (int j = 0; j < 2; j++) force[j*nn + n] = f[j];
             const double x0 = lx[threadIdx.x], z0 = lz[threadIdx.x];
             vbcs_regs(p, ft.clk, t_flag, z0, ft.bnormals, ft.edge_vec, ft.edge_slot, t_v);
             ft.vel[n] = t_v[0]; ft.vel[nn + n] = t_v[1];
