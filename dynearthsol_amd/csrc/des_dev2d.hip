@@ -2288,7 +2288,7 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
     Prof2 pr(h, P2_TEMP);
 #define K2T_ARGS h->d_p, h->d_clk, thermal ? 1 : 0, h->geo_pending ? 1 : 0, a, \
                        h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->props, \
-                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass, pre, nb_tail, pre ? h->pt_ptr : h->pt_zero, h->p_pe_cap
+                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass, pre, nb_tail, pre ? h->pt_ptr : h->pt_zero, h->p_pe_cap, h->elide ? 0 : 1
     const SurfPre *pre = nullptr;
     int nb_tail = 0;
     if (h->surf_pending && h->mass_pending) {

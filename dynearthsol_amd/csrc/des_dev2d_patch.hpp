@@ -189,7 +189,7 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
                 const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass_in, const double *volume_n_in,
                 double *ntmp, double *strain_rate, double *volume_n_out, double *mass_out, double *tmass_out, double *ymass_out,
-                const SurfPre *pre, int nb_front, const int *pt_ptr, int pe_cap)
+                const SurfPre *pre, int nb_front, const int *pt_ptr, int pe_cap, int outs)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
@@ -334,7 +334,11 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
                 acc += let[q];
                 if (t_node) tdot += ltd[k];
             }
-            volume_n_out[n] = vn; mass_out[n] = ms; tmass_out[n] = tms; ymass_out[n] = yms;
+            // (outs = 0: a step of a multi-step call that is not its last -- the thermal mass is used right here and formed anew by
+            //  the next pass; ymass only enters damping option 4)
+            volume_n_out[n] = vn; mass_out[n] = ms;
+            if (outs) tmass_out[n] = tms;
+            if (outs || p->damping_option == 4) ymass_out[n] = yms;
             ntmp[n] = acc / vn;
             if (thermal) T_out[n] = t_node ? lT[threadIdx.x] - clk->dt * tdot / tms : p->surface_temperature;
         }
