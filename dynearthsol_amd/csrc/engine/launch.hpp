@@ -568,7 +568,7 @@ void launch_en3(des_dev *h)
         // LDS for the mesh's largest block (dynamic) -> as many workgroups per CU as the mesh allows
         void (*k)(const des_params *, const DevClock *, int, int, int, int, int, int, int, int, int, int, const int *, const ulonglong2 *, const int *, const int *, const int *, const unsigned *, const double *, const MatData, const double *,
                   const double *, const double *, double *, unsigned, const int *, const int *, const double *, const double *, const double *,
-                  const double *, const double *, const int *, const d4 *, d4 *, d4 *, double *, double *, double *);
+                  const double *, const double *, const int *, const d4 *, d4 *, d4 *, double *, double *, double *, int);
         const int T = h->patch_threads;
         const bool nmd = h->p.is_using_mixed_stress && !h->iso && !h->in_pt;
         const bool known = nmd && h->p.gravity != 0;           // the common launch has kernels of its own (passes/en3.hpp)
@@ -580,7 +580,7 @@ void launch_en3(des_dev *h)
                            (int)nmd, h->o0, h->o1, h->nn, h->nn_global, h->ne, h->patch_nb, h->patch_npb, ci, cn,
                            h->pe_ptr, h->pe_pack, h->pn_ptr, h->pn_id, h->sup_idx, h->bcflag, h->ntmp, mat_data(h),
                            h->volume, h->dpressure, h->stress, h->ddp, h->bc_mask, h->bcn_idx, h->bcn_ent, h->bcf_tmp, h->coord0, h->ymass,
-                           h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part);
+                           h->bnormals, h->edge_vec, h->edge_slot, h->xt, h->xt_alt, h->vm, h->force, h->fres, h->res_part, (h->e2_elide && !h->p.has_PT && !h->in_pt && !h->iso) ? 0 : 1);
     }
     std::swap(h->xt, h->xt_alt);               // the records EN3 wrote are the current ones from here on
     if (h->p.is_using_mixed_stress && !h->iso && !h->in_pt) h->ddp_live = true;      // ddp[] now holds this step's NMD increments

@@ -59,7 +59,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
      const double *__restrict__ coord0, const double *__restrict__ ymass,
      const double *__restrict__ bnormals, const double *__restrict__ edge_vec, const int *__restrict__ edge_slot,
      const d4 *__restrict__ xt, d4 *__restrict__ xt_out, d4 *__restrict__ vm, double *__restrict__ force,
-     double *__restrict__ fres, double *__restrict__ res_part)
+     double *__restrict__ fres, double *__restrict__ res_part, int outs)
 {
     // xt: the nodal records as the last pass left them (read for the whole patch); xt_out: the other
     // buffer of the pair, where this block stores the records of its own nodes (the host swaps the
@@ -279,7 +279,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
                 for (int c = 0; c < 3; ++c) { const double tv = lf[c][r0]; f[c] -= tv; fr[c] = tv; }
             }
             l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
-                                coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres);
+                                coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres, outs != 0);
         }
     } else
 #endif
@@ -314,7 +314,7 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
             fr[0] = t0v; fr[1] = t1v; fr[2] = t2v;          // assignment: fields.cxx:673
         }
         l2 = n3_finish_node(p, clk, n, nn, o0, nn_own_end, nn_global, f, fr, bcflag, bc_mask, bcn_idx, bcn_ent, bcf_tmp,
-                            coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres);
+                            coord0, ymass, bnormals, edge_vec, edge_slot, flag, lxt[threadIdx.x], m4, xt_out, true, vm, force, fres, outs != 0);
     }
     DES_STAMP0(1, 5);
     // per-block partial of the residual; the partials are added in block order afterwards

@@ -127,8 +127,10 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
      const double *__restrict__ coord0, const double *__restrict__ ymass,
      const double *__restrict__ bnormals, const double *__restrict__ edge_vec, const int *__restrict__ edge_slot,
      const unsigned flag, d4 x4, d4 m4, d4 *xt_out, bool always_store_xt, d4 *__restrict__ vm,
-     double *__restrict__ force, double *__restrict__ fres)
+     double *__restrict__ force, double *__restrict__ fres, bool outs = true)
 {
+    // outs = false (EN3, a step of a multi-step call that is not its last): force and force_residual are not stored -- the next
+    // step's pass forms them anew before anything reads them, and what this step needs of them it has in registers.
     // flag, x4, m4: bcflag[n], the node's {x,y,z,T} and {vx,vy,vz,mass} records, loaded by the caller
     // (EN3 has them in flight long before the force sums are ready).  xt_out: the array itself for
     // N3; EN3 reads the coordinates of other blocks' nodes in the same launch, so it writes the
@@ -198,8 +200,7 @@ __device__ __forceinline__ double n3_finish_node(const des_params *__restrict__ 
     default: break;
     }
     for (int j = 0; j < 3; j++) {
-        force[(size_t)j*nn + n] = f[j];
-        fres[(size_t)j*nn + n] = fr[j];
+        if (outs) { force[(size_t)j*nn + n] = f[j]; fres[(size_t)j*nn + n] = fr[j]; }
         v[j] += dt * f[j] / m4.w;
     }
     if (n >= o0 && n < nn_own_end) {
