@@ -101,6 +101,10 @@ struct Engine {
     // (round 5) ... and a compute_dt step inside a call leaves its end-of-step element pass and compute_mass behind like any other
     // (the single engine; DES2D_DT_DEFER=0: off): compute_dt forms the volumes it wants from the coordinates, the rotation keeps its dt
     bool dt_defer_on = true, rot_prev_dt = false;
+    // (round 5) the strain rate of a step whose stress update also finishes the step before (k2_stress<M, 2>) is formed THERE, from
+    // the coordinates and velocities that pass gathers anyway -- k2p_temp_dvoldt<1> does not store it (the single engine;
+    // DES2D_SR_FUSE=0: off).  sr_fused: decided for this step's two launches together.
+    bool sr_fuse_on = true, sr_fused = false;
     unsigned char *topflag = nullptr;
     int *pt_ptr = nullptr, *pt_zero = nullptr; int4 *pt_ent = nullptr; bool surf_defer_fits = true;
     int *d_bperm = nullptr;                      // the blocks in launch order: every XCD its share of the surface blocks, first
@@ -630,7 +634,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
           const double *props, const int *markers, double *edvoldt, double *volume, double *volume_old,
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
           double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
-          int nn, const double *coord, const double *vel, int rotate, int outs, const int *elist, int nlist,
+          int nn, const double *coord, const double *vel, int rotate_arg, int outs, const int *elist, int nlist,
           const int *mono, const double *pptab, int *past_part, int past_base)
 {
     M::stage_begin();
@@ -645,11 +649,15 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
     //  them that was a trip to memory of its own)
     const int mono_e = mono[e];
     const double bulkm = prop2(p, props, ne, e, 0), shearm = prop2(p, props, ne, e, 1);
-    double s[3], es[3], edot[3];
+    // (rotate_arg: bit 0-1 rotate_stress of the step before / with the dt before, bit 2 (round 5): the strain rate is formed HERE
+    //  from the coordinates and velocities this pass gathers -- k2_strain_rate's statements; k2p_temp_dvoldt<1> has not stored it)
+    const int rotate = rotate_arg & 3;
+    const bool sr_here = FUSED == 2 && (rotate_arg & 4);
+    double s[3], es[3], edot[3] = {0, 0, 0};
     for (int i = 0; i < 3; ++i) {
         s[i] = stress[i * ne + e];
         es[i] = strain[i * ne + e];
-        edot[i] = strain_rate[i * ne + e];
+        if (!sr_here) edot[i] = strain_rate[i * ne + e];
     }
     // (round 5: the mean temperature and the plastic strain the law wants are asked for HERE, beside the other fields -- inside the
     //  law's case they were two more dependent trips to memory in the middle of the pass)
@@ -664,7 +672,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
     for (int i = 0; i < 3; ++i) cn[i] = conn[i * ne + e];
     double d[3][2], vv[3][2], nt3[3] = {0, 0, 0};
     if (FUSED == 2) for (int i = 0; i < 3; ++i) { d[i][0] = coord[cn[i]]; d[i][1] = coord[nn + cn[i]]; }
-    if (FUSED == 2 && rotate) for (int i = 0; i < 3; ++i) { vv[i][0] = vel[cn[i]]; vv[i][1] = vel[nn + cn[i]]; }
+    if (FUSED == 2 && (rotate || sr_here)) for (int i = 0; i < 3; ++i) { vv[i][0] = vel[cn[i]]; vv[i][1] = vel[nn + cn[i]]; }
     if (FUSED) for (int i = 0; i < 3; ++i) nt3[i] = ntmp[cn[i]];
     if (law_T) {                                           // elemT's statements (matprops.cxx:338-343)
         double T = 0;
@@ -679,9 +687,17 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
         vol = triangle_area(d[0], d[1], d[2]);
         volume[e] = vol;
         if (outs) volume_old[e] = vol_old;
+        double shpdx[3], shpdz[3];
+        if (rotate || sr_here) shape_fn2(d, vol, shpdx, shpdz);
+        if (sr_here) {
+            // k2_strain_rate's statements (the patch pass forms the same sums from the same staged values for its dvoldt)
+            double s0 = 0, s1 = 0, s2 = 0;
+            for (int i = 0; i < 3; ++i) s0 += vv[i][0] * shpdx[i];
+            for (int i = 0; i < 3; ++i) s1 += vv[i][1] * shpdz[i];
+            for (int i = 0; i < 3; ++i) s2 += 0.5 * (vv[i][0] * shpdz[i] + vv[i][1] * shpdx[i]);
+            edot[0] = s0; edot[1] = s1; edot[2] = s2;
+        }
         if (rotate) {
-            double shpdx[3], shpdz[3];
-            shape_fn2(d, vol, shpdx, shpdz);
             double w2 = 0;
             for (int i = 0; i < 3; ++i) w2 += 0.5 * (vv[i][1] * shpdx[i] - vv[i][0] * shpdz[i]);
             // (rotate = 2: the step being finished was a compute_dt step -- it ran with the dt before the new one)
@@ -2114,7 +2130,7 @@ void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr, 
     const int past_base = h->past_base;
     if (h->count_past) h->past_base += nblk(nlist) * (DES_BLOCK / 64);
     Prof2 pr(h, P2_STRESS);
-    const int rot = (h->p.rheol_type & DES_RH_ELASTIC) ? (h->rot_prev_dt ? 2 : 1) : 0;
+    const int rot = ((h->p.rheol_type & DES_RH_ELASTIC) ? (h->rot_prev_dt ? 2 : 1) : 0) | (h->sr_fused ? 4 : 0);
 #define K2S_ARGS(out, outs) h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt, \
         h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain, \
         h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, out, h->nn, h->coord, h->vel, rot, outs, elist, nlist, \
@@ -2288,7 +2304,7 @@ void launch_temp_dvoldt(Engine *h, bool thermal, const double *T_in, double *T_o
     Prof2 pr(h, P2_TEMP);
 #define K2T_ARGS h->d_p, h->d_clk, thermal ? 1 : 0, h->geo_pending ? 1 : 0, a, \
                        h->bcflag, h->coord, h->vel, T_in, T_out, h->volume, h->radiogenic_zero ? (const double *)nullptr : h->radiogenic, h->props, \
-                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass, pre, nb_tail, pre ? h->pt_ptr : h->pt_zero, h->p_pe_cap, h->elide ? 0 : 1
+                       h->markers, h->mono, h->tmass, h->volume_n, h->ntmp, h->strain_rate, h->volume_n, h->mass, h->tmass, h->ymass, pre, nb_tail, pre ? h->pt_ptr : h->pt_zero, h->p_pe_cap, (h->elide ? 0 : 1) | (h->sr_fused ? 2 : 0)
     const SurfPre *pre = nullptr;
     int nb_tail = 0;
     if (h->surf_pending && h->mass_pending) {
@@ -2355,8 +2371,10 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             const double *const T_in = h->temperature;
             double *const T_out = h->temperature_alt;
             if (thermal) std::swap(h->temperature, h->temperature_alt);
+            h->sr_fused = h->sr_fuse_on && !h->halo && h->geo_pending && h->mass_pending;
             launch_temp_dvoldt(h, thermal, T_in, T_out);
             launch_stress<M>(h, true, s_law);
+            h->sr_fused = false;
         }
         h->geo_pending = false; h->mass_pending = false; h->surf_pending = false; h->rot_prev_dt = false;
         const bool fold = tail && fold_now(h);
@@ -2982,6 +3000,7 @@ static int create_impl(Engine *h, const des_params *params, const des_mesh *mesh
                 const char *se = des_env::get("DES2D_SURF_DEFER"); h->surf_defer_on = !(se && se[0] == '0');
                 const char *de = des_env::get("DES2D_DT_DEFER"); h->dt_defer_on = !(de && de[0] == '0');
                 const char *ie = des_env::get("DES2D_PATCH_IT"); h->it3_forced = ie && ie[0] == '3';
+                const char *re = des_env::get("DES2D_SR_FUSE"); h->sr_fuse_on = !(re && re[0] == '0');
             }
             A2(dalloc(h, h->stress_pre, (size_t)3 * ne));
         }

@@ -189,7 +189,7 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
                 const double *coord, const double *vel, const double *T_in, double *T_out, const double *volume,
                 const double *radiogenic, const double *props, const int *markers, const int *mono, const double *tmass_in, const double *volume_n_in,
                 double *ntmp, double *strain_rate, double *volume_n_out, double *mass_out, double *tmass_out, double *ymass_out,
-                const SurfPre *pre, int nb_front, const int *pt_ptr, int pe_cap, int outs)
+                const SurfPre *pre, int nb_front, const int *pt_ptr, int pe_cap, int outs_arg)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
@@ -269,6 +269,9 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
         double *const ltd = let + pe_cap;
         unsigned short *const lidx = (unsigned short *)(ltd + a.inc_cap);
         const int mass_thermal = p->has_thermal_diffusion;
+        // (outs_arg: bit 0 the output-only stores, bit 1: the coming k2_stress<M, 2> forms the strain rate itself -- none stored here)
+        const int outs = outs_arg & 1;
+        const bool sr_store = !(outs_arg & 2);
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
             if (q0 + k * DES2_PATCH_THREADS >= qe) break;
@@ -299,7 +302,7 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
             double s0 = 0, s1 = 0;
             for (int i = 0; i < 3; ++i) s0 += v[i][0] * shpdx[i];
             for (int i = 0; i < 3; ++i) s1 += v[i][1] * shpdz[i];
-            if (E.owner) {
+            if (E.owner && sr_store) {
                 double s2 = 0;
                 for (int i = 0; i < 3; ++i) s2 += 0.5 * (v[i][0] * shpdz[i] + v[i][1] * shpdx[i]);
                 strain_rate[e] = s0; strain_rate[ne + e] = s1; strain_rate[2 * ne + e] = s2;
