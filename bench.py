@@ -146,13 +146,15 @@ KERNEL_BYTES = {
 }
 # The 2-D engine (csrc/des_dev2d.hip), dominant launch k2_stress<M, 2> = compute_volume + rotate_stress of the step before +
 # compute_edvoldt + update_stress: per triangle read conn 12, mono word 4, bulk / shear modulus 16, stress 24,
-# strain 24, strain_rate 24 (stored by the temperature / dvoldt pass's owner block), volume 8, plstrain 8 = 120; write
+# strain 24, volume 8, plstrain 8 = 96 (round 5, late: NOT the strain rate any more -- the pass forms it from the coordinates and
+# velocities it gathers anyway and the temperature / dvoldt pass no longer stores it; DES2D_SR_FUSE=0: + 24, K2_SR_STORED); write
 # volume 8, stress 24, strain 24, dpressure 8, etmp 8 = 72; nodes once each: coord 16, vel 16, T 8, ntmp 8.  The last step
 # of a call also stores volume_old 8, edvoldt 8, strain_rate 24, viscosity 8, delta_plstrain 8 (K2_STRESS_LAST).
 # (Round 5: a model with ONE material does not read the two moduli per triangle -- the means of one material are its values,
 #  des_dev2d.hip: prop2 --: 16 B less, K2_ONE_MATERIAL; the bench model is such a model.)
-KERNEL_BYTES_2D = {"K2_stress": (192, 48)}
-K2_STRESS_LAST = (248, 48)
+KERNEL_BYTES_2D = {"K2_stress": (168, 48)}
+K2_STRESS_LAST = (224, 48)
+K2_SR_STORED = 24
 K2_ONE_MATERIAL = 16
 E2G_INTERIOR = (261, 64)          # read 141 (as above) + write stress 48, strain 48, dpressure 8, etmp 8, volume 8
 KERNEL_ROWS = {"E2G_geom_rotate_update_stress": (364 + 364, 56 + 8), "EN3_force_nodes": (260 + 160, 40 + 160),
@@ -690,6 +692,8 @@ def main():
                         be = K2_STRESS_LAST[0]
                     elif calls > 1:
                         be = (be * (calls - 1) + K2_STRESS_LAST[0]) / calls
+                    if os.environ.get("DES2D_SR_FUSE") == "0" or world > 1:
+                        be += K2_SR_STORED           # (a decomposed mesh keeps the stored strain rate)
                     if int(host.params.nmat) == 1:
                         be -= K2_ONE_MATERIAL
                 kbytes = be * ne_local + bn * nn_local     # rank 0's launch

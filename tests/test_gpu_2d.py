@@ -284,7 +284,7 @@ def test_pseudo_transient_loop_bit_exact(tol, moving):
 
 
 @pytest.mark.parametrize("knob", ["DES2D_PATCH=0", "DES2D_PATCH=64", "DES2D_PATCH=40", "DES2D_CLUSTER=0", "DES2D_GEO=0", "DES2D_ELIDE=0",
-                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0", "DES2D_FOLD=0", "DES2D_SURF_DEFER=0", "DES2D_TOP_BALANCE=0", "DES2D_DT_DEFER=0", "DES2D_PATCH_IT=3"])
+                                  "DES2D_CLUSTER_ASPECT=1", "DES2D_MASS_FUSE=0", "DES2D_FOLD=0", "DES2D_SURF_DEFER=0", "DES2D_TOP_BALANCE=0", "DES2D_DT_DEFER=0", "DES2D_PATCH_IT=3", "DES2D_SR_FUSE=0"])
 def test_patch_passes_and_plain_kernels_give_the_same_bits(monkeypatch, knob):
     """The node-block patch passes (des_dev2d_patch.hpp: temperature + dvoldt, NMD + force, mass; the default) against the
     one-kernel-per-loop path (DES2D_PATCH=0), other block sizes and groupings, and with the end-of-step pass / the store
