@@ -486,7 +486,9 @@ k2p_force(const des_params *__restrict__ p, int nmd, int outs, const PatchArgs a
     for (int k = 0; k < IT; ++k)
         if (q0 + k * DES2_PATCH_THREADS < qe) {
             const int e = (int)(rec[k].x & 0x3fffffffull);
-            g_vol[k] = volume[e];
+            // (TAIL: the plain step -- volume[] holds compute_volume's expression on the very coordinates staged here, so the pass
+            //  forms it instead of reading 8 B per patch element)
+            g_vol[k] = TAIL ? 0.0 : volume[e];
             for (int i = 0; i < 3; ++i) g_s[k][i] = stress_in[i * ne + e];
             g_dp[k] = nmd ? dpressure[e] : 0.0;
             g_phi[k] = gravity != 0 ? prop2(p, props, ne, e, 2) : 0.0;
@@ -522,7 +524,7 @@ k2p_force(const des_params *__restrict__ p, int nmd, int outs, const PatchArgs a
         const int e = E.e;
         double d[3][2], shpdx[3], shpdz[3];
         for (int i = 0; i < 3; ++i) { d[i][0] = lx[E.ln[i]]; d[i][1] = lz[E.ln[i]]; }
-        double vol = g_vol[k];
+        double vol = TAIL ? triangle_area(d[0], d[1], d[2]) : g_vol[k];
         shape_fn2(d, vol, shpdx, shpdz);
         double s[3];
         for (int i = 0; i < 3; ++i) s[i] = g_s[k][i];
