@@ -635,7 +635,7 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
           const double *stress, double *strain, double *strain_rate, double *stressyy, double *plstrain, double *delta_plstrain,
           double *viscosity, double *dpressure, double *etmp, int count_past, const double *ntmp, double *stress_out,
           int nn, const double *coord, const double *vel, int rotate_arg, int outs, const int *elist, int nlist,
-          const int *mono, const double *pptab, int *past_part, int past_base)
+          const int *mono, const double *pptab, int *past_part, int past_base, double *stress_out_shear)
 {
     M::stage_begin();
     M::stage_end();
@@ -810,10 +810,11 @@ k2_stress(const des_params *__restrict__ p, const desk::ViscTerms *__restrict__ 
         dpressure[e] = dp;
         etmp[e] = dp * vol;                      // NMD_stress, geometry.cxx:292-296
     }
-    for (int i = 0; i < 3; ++i) {
-        stress_out[i * ne + e] = s[i];
-        strain[i * ne + e] = es[i];
-    }
+    // (stress_out_shear: where the shear component goes -- with NMD_stress behind this pass the diagonal goes to another buffer,
+    //  from which the force pass writes the corrected diagonal; the shear component, which NMD_stress does not touch, goes straight
+    //  to the stress array: one plane less for the force pass to copy)
+    stress_out[e] = s[0]; stress_out[ne + e] = s[1]; stress_out_shear[e] = s[2];
+    for (int i = 0; i < 3; ++i) strain[i * ne + e] = es[i];
 }
 
 // NMD_stress (geometry.cxx:311-331), element update
@@ -2134,7 +2135,7 @@ void launch_stress(Engine *h, bool fused = false, double *stress_out = nullptr, 
 #define K2S_ARGS(out, outs) h->d_p, h->d_vt, h->d_clk, h->ne, h->conn, h->temperature, h->props, h->markers, h->edvoldt, \
         h->volume, h->volume_old, h->stress, h->strain, h->strain_rate, h->stressyy, h->plstrain, h->delta_plstrain, \
         h->viscosity, h->dpressure, h->etmp, h->count_past ? 1 : 0, h->ntmp, out, h->nn, h->coord, h->vel, rot, outs, elist, nlist, \
-        h->mono, h->pptab, h->past_part, past_base
+        h->mono, h->pptab, h->past_part, past_base, h->stress + 2 * (size_t)h->ne
     if (fused && h->p.rheol_type == DES_RH_EVP) {          // the common rheology has instantiations of its own
         if (h->geo_pending) L2((k2_stress<M, 2, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
         else                L2((k2_stress<M, 1, DES_RH_EVP>), nlist, K2S_ARGS(stress_out, h->elide ? 0 : 1));
@@ -2402,10 +2403,10 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
             { Prof2 pr(h, P2_FORCE);
             if (h->p_pe_cap <= 2 * DES2_PATCH_THREADS && !h->it3_forced)
             hipLaunchKernelGGL((k2p_force<1, 2>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, h->elide ? 0 : 1, a, h->coord,
-                               h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
+                               h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft, h->stress + 2 * (size_t)h->ne);
             else
             hipLaunchKernelGGL((k2p_force<1, 3>), dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, h->elide ? 0 : 1, a, h->coord,
-                               h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
+                               h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft, h->stress + 2 * (size_t)h->ne);
             }
             std::swap(h->coord, h->coord_alt);             // the moved coordinates are the current ones from here on
             h->xz_pre_valid = true;
@@ -2418,7 +2419,7 @@ void launch_mechanics(Engine *h, bool nmd, bool thermal = false, bool tail = fal
         }
         { Prof2 pr(h, P2_FORCE);
         hipLaunchKernelGGL(k2p_force<0>, dim3((h->p_nb + 7) / 8 * 8), dim3(DES2_PATCH_THREADS), 8 * (4 * (size_t)a.pn_cap + 2 * (size_t)a.inc_cap), h->stream, h->d_p, nmd ? 1 : 0, h->elide ? 0 : 1, a, h->coord,
-                           h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft);
+                           h->temperature, h->ntmp, h->volume, h->dpressure, s_law, h->stress, h->props, h->markers, h->mono, h->force, h->fres, ft, h->stress + 2 * (size_t)h->ne);
         }
         launch_stress_bcs(h);
         join_wall(h);

@@ -464,7 +464,7 @@ template <int TAIL, int IT = DES2_PATCH_IT>
 __global__ void __launch_bounds__(DES2_PATCH_THREADS)
 k2p_force(const des_params *__restrict__ p, int nmd, int outs, const PatchArgs a, const double *coord, const double *temperature, const double *ntmp,
           const double *volume, const double *dpressure, const double *stress_in, double *stress_out, const double *props,
-          const int *markers, const int *mono, double *force, double *fres, const ForceTail ft)
+          const int *markers, const int *mono, double *force, double *fres, const ForceTail ft, const double *stress_shear)
 {
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lT = lz + a.pn_cap, *const lnt = lT + a.pn_cap;
@@ -489,7 +489,8 @@ k2p_force(const des_params *__restrict__ p, int nmd, int outs, const PatchArgs a
             // (TAIL: the plain step -- volume[] holds compute_volume's expression on the very coordinates staged here, so the pass
             //  forms it instead of reading 8 B per patch element)
             g_vol[k] = TAIL ? 0.0 : volume[e];
-            for (int i = 0; i < 3; ++i) g_s[k][i] = stress_in[i * ne + e];
+            // (the shear component comes from the stress array itself: k2_stress put it there, NMD_stress does not touch it)
+            g_s[k][0] = stress_in[e]; g_s[k][1] = stress_in[ne + e]; g_s[k][2] = stress_shear[e];
             g_dp[k] = nmd ? dpressure[e] : 0.0;
             g_phi[k] = gravity != 0 ? prop2(p, props, ne, e, 2) : 0.0;
             g_mono[k] = gravity != 0 ? mono[e] : 0;
@@ -536,7 +537,7 @@ k2p_force(const des_params *__restrict__ p, int nmd, int outs, const PatchArgs a
             double dp_orig = g_dp[k];
             double ddp = (-dp_orig + dp_el) / 2;
             for (int i = 0; i < 2; ++i) s[i] += ddp;
-            if (E.owner) for (int i = 0; i < 3; ++i) stress_out[i * ne + e] = s[i];
+            if (E.owner) for (int i = 0; i < 2; ++i) stress_out[i * ne + e] = s[i];
         }
         double buoy = 0;
         if (gravity != 0) {
