@@ -194,7 +194,6 @@ k2p_temp_dvoldt(const des_params *__restrict__ p, const Clock *__restrict__ clk,
     extern __shared__ double lds[];
     double *const lx = lds, *const lz = lx + a.pn_cap, *const lvx = lz + a.pn_cap, *const lvz = lvx + a.pn_cap, *const lT = lvz + a.pn_cap;
     double *const lf0 = lT + a.pn_cap, *const lf1 = lf0 + a.inc_cap;
-    double *const lf2 = lf1 + a.inc_cap, *const lf3 = lf2 + a.inc_cap;          // (MASS only: the launch sizes the LDS)
     // (blocks next to each other share half their patch: desk::logical_block keeps them on one XCD, i.e. one L2)
     const int nn = a.nn, ne = a.ne;
     if (MASS && (int)blockIdx.x < nb_front) {
