@@ -1820,12 +1820,14 @@ __global__ void k2_dt_partials(const des_params *__restrict__ p, double *dt_part
 // ... the partials reduced into the clock's five slots by one workgroup (what k2_dt_init + the atomics left there);
 // finalize != 0: k2_dt_finalize's statements follow at once (the single engine: one launch less)
 __device__ __forceinline__ void dt_finalize_body(const des_params *__restrict__ p, Clock *clk);
-__global__ void __launch_bounds__(DES_BLOCK)
+// (one workgroup of 1024 lanes: five rounds of requests for the 1.28M-triangle mesh's five thousand partials instead of twenty)
+#define DES2_DT_REDUCE_THREADS 1024
+__global__ void __launch_bounds__(DES2_DT_REDUCE_THREADS)
 k2_dt_reduce(const des_params *__restrict__ p, Clock *clk, const double *dt_part, int nb, int finalize)
 {
-    __shared__ double sm[5][DES_BLOCK / 64];
+    __shared__ double sm[5][DES2_DT_REDUCE_THREADS / 64];
     double r[5] = {DBL_MAX, DBL_MAX, DBL_MAX, DBL_MAX, 0.0};
-    for (int i = threadIdx.x; i < nb; i += DES_BLOCK) {
+    for (int i = threadIdx.x; i < nb; i += DES2_DT_REDUCE_THREADS) {
         for (int q = 0; q < 4; ++q) r[q] = fmin(r[q], dt_part[(size_t)q * nb + i]);
         r[4] = fmax(r[4], dt_part[(size_t)4 * nb + i]);
     }
@@ -1834,7 +1836,7 @@ k2_dt_reduce(const des_params *__restrict__ p, Clock *clk, const double *dt_part
     if ((threadIdx.x & 63) == 0) for (int q = 0; q < 5; ++q) sm[q][threadIdx.x >> 6] = r[q];
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < DES_BLOCK / 64; ++w) {
+        for (int w = 1; w < DES2_DT_REDUCE_THREADS / 64; ++w) {
             for (int q = 0; q < 4; ++q) sm[q][0] = fmin(sm[q][0], sm[q][w]);
             sm[4][0] = fmax(sm[4][0], sm[4][w]);
         }
@@ -2282,7 +2284,7 @@ void launch_dt(Engine *h)
     if (h->geo_pending) h->rot_prev_dt = true;
     L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature,
        h->geo_pending ? (const double *)nullptr : h->volume, h->props, h->markers);
-    hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 1);
+    hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES2_DT_REDUCE_THREADS), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 1);
 }
 
 int sync_clock(Engine *h)
@@ -2699,7 +2701,7 @@ void launch_dt_partials(Engine *h)
     if (h->geo_pending) h->rot_prev_dt = true;             // (as launch_dt)
     L2(k2_dt_partials, h->ne, h->d_p, h->dt_part, h->nn, h->ne, h->conn, h->coord, h->vel, h->temperature,
        h->geo_pending ? (const double *)nullptr : h->volume, h->props, h->markers);
-    hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES_BLOCK), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 0);
+    hipLaunchKernelGGL(k2_dt_reduce, dim3(1), dim3(DES2_DT_REDUCE_THREADS), 0, h->stream, h->d_p, h->d_clk, h->dt_part, nblk(h->ne), 0);
 }
 
 void launch_pack(Engine *h)
