@@ -5,7 +5,7 @@ the oracle against itself after a 1-ulp change of its initial stress -- the yard
 "equal" can mean on this model.  Not part of the test suite (minutes of CPU); results are
 kept in profiles/.
 
-  python tests/soak_parity.py [--steps 1000] [--sensitivity | --portable-libm] [--threads 16]
+  python tests/soak_parity.py [--steps 1000] [--ndims 2] [--per-call 100] [--sensitivity | --portable-libm] [--threads 16]
 """
 import argparse
 import os
@@ -32,13 +32,19 @@ def main():
     ap.add_argument("--portable-libm", action="store_true",
                     help="both sides use csrc/des_libm.hpp instead of ocml / glibc: expect zeros")
     ap.add_argument("--mesh-file", default=des.reference_mesh("test-3d-big-460"))
+    ap.add_argument("--ndims", type=int, default=3, help="2: the bench's 2-D box (1.28M triangles, evp) instead of the 1M-tet mesh")
+    ap.add_argument("--per-call", type=int, default=100, help="steps per des_dev_step call (and per comparison)")
     a = ap.parse_args()
     load_oracle(omp=True).des_oracle_set_threads(a.threads)
     if a.portable_libm:
         load_oracle(omp=True).des_oracle_set_libm(1)
         os.environ["DES_LIBM"] = "portable"
     ov = "mesh.meshing_option = 2\nmesh.meshing_elem_shape = 0\n"
-    host = des.Host(cfg_text=bench.BENCH_CFG.format(res="460.0", xlen="400e3"), overrides=ov, mesh_file=a.mesh_file)
+    if a.ndims == 2:
+        import cfgs
+        host = des.Host(cfg_text=cfgs.make(**dict(cfgs.EVP, lx=400e3, lz=100e3, res=250.0)), ndims=2)
+    else:
+        host = des.Host(cfg_text=bench.BENCH_CFG.format(res="460.0", xlen="400e3"), overrides=ov, mesh_file=a.mesh_file)
     ref = OracleEngine(host, omp=True)
     if a.sensitivity:
         other = OracleEngine(host, omp=True)
@@ -53,8 +59,8 @@ def main():
                                                        "des_libm.hpp" if a.portable_libm else "the C library's libm"))
     print("# nnode %d nelem %d" % (host.mesh.nnode, host.mesh.nelem))
     t = time.time()
-    for _ in range(a.steps // 100):
-        so, sr = other.step(100), ref.step(100)
+    for _ in range(a.steps // a.per_call):
+        so, sr = other.step(a.per_call), ref.step(a.per_call)
         cols = []
         for f in FIELDS:
             x, y = other.download(f), ref.download(f)
