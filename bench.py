@@ -572,6 +572,15 @@ def main():
             ceiling = des.copy_ceiling(1 << 30, 20, ctx.device)
         except des.DesError as e:
             sys.stderr.write("copy ceiling: %s\n" % e)
+    # ... and what a kernel reaches from HBM that ONLY moves bytes in the dominant launch's memory shape (SoA planes of doubles,
+    # one element per lane: 18 read + 15 written for E2<GEO>, 12 + 9 for the 2-D stress update; 8.8M elements, past the 256-MiB
+    # Infinity Cache): the pass could not be faster than that if its arithmetic were free (des_dev_plane_ceiling)
+    shape_ceiling = None
+    if rank == 0 and not args.no_ceiling:
+        try:
+            shape_ceiling = des.plane_ceiling(12 if args.ndims == 2 else 18, 9 if args.ndims == 2 else 15, 8800000, 10, ctx.device)
+        except des.DesError as e:
+            sys.stderr.write("plane ceiling: %s\n" % e)
 
     bytes_step_local = dev.algorithmic_bytes_per_step()
     nn_local = nn if world == 1 else part.nnode
@@ -702,7 +711,10 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc if traffic else None,
                         "ceiling_GBs": ceiling, "frac_of_ceiling": (achieved / ceiling) if ceiling else None,
+                        "shape_ceiling_GBs": shape_ceiling if dom in ("E2G_geom_rotate_update_stress", "K2_stress") else None,
                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": ms / calls}
+                if roof["shape_ceiling_GBs"]:
+                    roof["frac_of_shape_ceiling"] = achieved / roof["shape_ceiling_GBs"]
                 if dom in KERNEL_ROWS:
                     # the same launch priced with the SURVEY rows it replaces (E1 + E2; evp + 24 / + 8)
                     re_, rn_ = KERNEL_ROWS[dom]

@@ -141,6 +141,17 @@ def copy_ceiling(nbytes=1 << 30, reps=20, device=0):
     return g.value
 
 
+def plane_ceiling(nr=18, nw=15, nelem=8800000, reps=10, device=0):
+    """GB/s of a bytes-only kernel in the stress update's memory shape (nr planes read, nw written, 8 B per lane and plane)."""
+    lib = load_hip_lib()
+    lib.des_dev_plane_ceiling.argtypes = [C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_double)]
+    g = C.c_double(0)
+    rc = lib.des_dev_plane_ceiling(device, nr, nw, nelem, reps, C.byref(g))
+    if rc:
+        raise DesError(rc, lib.des_dev_last_error().decode())
+    return g.value
+
+
 def libm_eval(fn, x, y=None, device=0):
     """One function of the portable libm (csrc/des_libm.hpp) evaluated on the GPU."""
     import numpy as np

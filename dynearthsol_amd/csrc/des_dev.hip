@@ -1954,6 +1954,39 @@ int des_dev_copy_ceiling(int device, long long bytes, int reps, double *gbs)
     return rc;
 }
 
+int des_dev_plane_ceiling(int device, int nr, int nw, long long nelem, int reps, double *gbs)
+{
+    if (!gbs || nelem < 256 || nelem > (1ll << 31) * 255 || reps < 1) return DES_ERR_INTERNAL;
+    if (!((nr == 18 && nw == 15) || (nr == 12 && nw == 9))) { g_last_error = "plane ceiling: shapes 18 + 15 and 12 + 9 only"; return DES_ERR_UNSUPPORTED; }
+    if (des_dev_device_count() <= device) { g_last_error = "no such HIP device"; return DES_ERR_UNSUPPORTED; }
+    HIP_OK(hipSetDevice(device));
+    const size_t n = (size_t)nelem;
+    double *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DES_OK;
+    *gbs = 0;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == DES_OK) { rc = DES_ERR_RESOURCE; g_last_error = hipGetErrorString(e); } return e == hipSuccess; };
+    if (ok(hipMalloc((void **)&a, n * 8 * nr)) && ok(hipMalloc((void **)&b, n * 8 * nw)) && ok(hipMemset(a, 0, n * 8 * nr))
+        && ok(hipMemset(b, 0, n * 8 * nw)) && ok(hipEventCreate(&e0)) && ok(hipEventCreate(&e1))) {
+        const dim3 grid((unsigned)((n + 255) / 256));
+        auto launch = [&]() {
+            if (nr == 18) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_plane_stream<18, 15>), grid, dim3(256), 0, 0, a, b, nelem);
+            else          hipLaunchKernelGGL(HIP_KERNEL_NAME(k_plane_stream<12, 9>), grid, dim3(256), 0, 0, a, b, nelem);
+        };
+        launch();                                                                         // warm-up
+        ok(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; ++r) launch();
+        ok(hipEventRecord(e1, 0));
+        ok(hipEventSynchronize(e1));
+        float ms = 0;
+        if (ok(hipEventElapsedTime(&ms, e0, e1)) && ms > 0) *gbs = (double)n * 8 * (nr + nw) * reps / (ms * 1e-3) / 1e9;
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    return rc;
+}
+
 // items: lanes of the launch.  Bytes per launch: pattern 0 reads 16 and writes 16 per item; 1 reads 8,
 // writes 8; 2 reads 4 (index) + 32 (record), writes 8; 3 reads 4 + 8, writes 8 (gathers touch every
 // record exactly once, in a random order that defeats coalescing but not the caches' line reuse).

@@ -193,6 +193,25 @@ __global__ void __launch_bounds__(256) k_access(const double *__restrict__ src, 
     else                   dst[i] = src[perm[i]];
 }
 
+// nr planes read + nw planes written per element, 8 B per lane and plane, one element per lane, no arithmetic but the sum
+// that ties the loads to the stores: what a pass with the stress update's MEMORY SHAPE reaches when it only moves its bytes
+// (tools/plane_stream_bench.hip is the stand-alone form).  Shapes: 18 + 15 (E2<GEO>, interior step: 141 B read, 120 B written)
+// and 12 + 9 (the 2-D k2_stress<M, 2>: 96 + 72 B).
+template <int NR, int NW>
+__global__ void __launch_bounds__(256) k_plane_stream(const double *__restrict__ src, double *__restrict__ dst, long long ne)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne) return;
+    double v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = src[(size_t)k * ne + e];
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) s += v[k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) dst[(size_t)k * ne + e] = s + v[k % NR];
+}
+
 __global__ void k_count_nan(const double *a, long long n, unsigned long long *count)
 {
     long long i = (long long)blockIdx.x * DES_BLOCK + threadIdx.x;

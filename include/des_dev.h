@@ -146,6 +146,13 @@ int des_dev_elasto_plastic_eval(int device, int libm, long long n, const double 
  * bytes (16 B per lane), `reps` launches timed with HIP events; *gbs = (read + written) / time. */
 int des_dev_copy_ceiling(int device, long long bytes, int reps, double *gbs);
 
+/* The same for the stress update's MEMORY SHAPE (no reference counterpart; measurement only): a kernel that does nothing
+ * but read `nr` and write `nw` SoA planes of doubles, one element per lane -- 18 + 15 (the 3-D stress update of an interior
+ * step: 141 B read, 120 B written per element, rheology.cxx:703-1030 with the end-of-step pass riding in it) or 12 + 9 (the
+ * 2-D one) -- over `nelem` elements, `reps` launches; *gbs = (read + written) / time.  With nelem large enough to leave the
+ * 256-MiB Infinity Cache behind (bench.py: 8.8M) this is what the pass could reach from HBM if its arithmetic were free. */
+int des_dev_plane_ceiling(int device, int nr, int nw, long long nelem, int reps, double *gbs);
+
 /* Calibration of the rocprofv3 HBM counters on the engine's own access shapes (tools/pmc_calibrate.py):
  * `reps` launches over `items` lanes of pattern 0 (16 B/lane stream copy), 1 (8 B/lane stream copy),
  * 2 (32-B record gather through a permutation + 8 B/lane store), 3 (8-B gather + 8 B/lane store). */

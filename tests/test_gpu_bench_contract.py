@@ -34,6 +34,13 @@ def test_single_gpu_line_has_every_field_of_the_contract():
     assert roof["traffic"] is None and roof["traffic_source"] is None     # PMC traffic is only quoted for the workload it was measured on
     # measured device-copy ceiling: between a third of and the nominal peak
     assert 2500 < roof["ceiling_GBs"] < 8000 and roof["frac_of_ceiling"] == pytest.approx(roof["achieved"] / roof["ceiling_GBs"])
+    # ... and what a bytes-only kernel in the dominant launch's memory shape reaches from HBM (des_dev_plane_ceiling): below the
+    # plain copy, above what the pass itself reaches
+    if roof["kernel"] == "E2G_geom_rotate_update_stress":
+        assert 2500 < roof["shape_ceiling_GBs"] <= 1.05 * roof["ceiling_GBs"]
+        assert roof["frac_of_shape_ceiling"] == pytest.approx(roof["achieved"] / roof["shape_ceiling_GBs"]) and roof["frac_of_shape_ceiling"] < 1.0
+    else:           # (a mesh this small may have another dominant launch: the shape is the stress update's)
+        assert roof["shape_ceiling_GBs"] is None
     assert "regular 5-tet mesher" in r["config"]["workload"]
     cpu = r["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "element-steps/s" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
