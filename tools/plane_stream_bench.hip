@@ -57,6 +57,26 @@ __global__ void __launch_bounds__(256) k_planes8x2(const double *__restrict__ sr
     for (int k = 0; k < NW; ++k) { double2 o; o.x = s + v[k % NR].x; o.y = s + v[k % NR].y; ((double2 *)(dst + (size_t)k * ne))[e2] = o; }
 }
 
+// TILE-MAJOR layout: the NR (NW) values of the 64 elements of a wave-tile lie together, [tile][plane][64] -- one contiguous
+// NR * 512-byte record per wavefront instead of NR streams `ne * 8` bytes apart (what a re-laid-out element store would be)
+template <int NR, int NW>
+__global__ void __launch_bounds__(256) k_tiles8(const double *__restrict__ src, double *__restrict__ dst, int ne)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ne) return;
+    const size_t tile = (size_t)(e >> 6), lane = (size_t)(e & 63);
+    const double *sp = src + tile * (NR * 64) + lane;
+    double *dp = dst + tile * (NW * 64) + lane;
+    double v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = sp[k * 64];
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) s += v[k];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) dp[k * 64] = s + v[k % NR];
+}
+
 __global__ void __launch_bounds__(256) k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -98,6 +118,8 @@ int main(int argc, char **argv)
                 (double)(NR / 2 + (NW + 1) / 2) * 16 * ne / t / 1e6);
     t = time_ms([&] { hipLaunchKernelGGL((k_planes8x2<NR, NW>), g2, dim3(256), 0, 0, src, dst, ne); }, reps);
     std::printf("%d + %d planes of 8 B, two elements per lane     : %7.1f us  %6.0f GB/s\n", NR, NW, t * 1e3, bytes / t / 1e6);
+    t = time_ms([&] { hipLaunchKernelGGL((k_tiles8<NR, NW>), dim3(ne / 256), dim3(256), 0, 0, src, dst, ne / 256 * 256); }, reps);
+    std::printf("%d + %d values of 8 B, TILE-MAJOR [tile][plane][64]  : %7.1f us  %6.0f GB/s\n", NR, NW, t * 1e3, (double)(NR + NW) * 8 * (ne / 256 * 256) / t / 1e6);
     const size_t n16 = (size_t)NW * ne / 2;
     t = time_ms([&] { hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, (const double2 *)src, (double2 *)dst, n16); }, reps);
     std::printf("plain copy, 16 B per lane, %zu MB each way         : %7.1f us  %6.0f GB/s\n", n16 * 16 / 1000000, t * 1e3, 2.0 * n16 * 16 / t / 1e6);
