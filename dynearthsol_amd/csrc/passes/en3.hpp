@@ -41,7 +41,7 @@
 // known at compile time: -2 us of 56 at 1M tets); KNOWN = 0: both read at run time.
 // LDS is DYNAMIC, sized by the host to the mesh's largest block (cap_inc incidences, cap_pn patch nodes; engine/launch.hpp).
 #ifndef DES_EXP_EN3
-#define DES_EXP_EN3 0             // timing experiments (wrong results; profiles/r05_d_patch_phase_removal.txt), bits: 1 no element arithmetic, 2 no force sums, 4 no staging gathers, 8 no element loads
+#define DES_EXP_EN3 0             // timing experiments (wrong results; profiles/r05_d_patch_phase_removal.txt), bits: 1 no element arithmetic, 2 no force sums, 4 no staging gathers, 8 no element loads, 16 the element loads as one 64-byte record
 #endif
 __host__ __device__ inline size_t en3_lds_bytes(int cap_inc, int cap_pn) { return (size_t)cap_pn * (32 + 8) + (size_t)cap_inc * 24; }
 #ifndef DES_EN3_MINWAVES
@@ -95,7 +95,17 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
         e = (e & 1023) + (lb & 7) * 1024; // timing experiment only (wrong results): the element loads hit a few hot lines
 #endif
         const unsigned eo = (unsigned)e * 8u;               // scalar plane base + one 32-bit offset (passes/common.hpp)
-#if DES_EXP_EN3 & 8
+#if DES_EXP_EN3 & 16
+        // timing experiment only (wrong results): the element's stress / volume / dpressure as ONE 64-byte record (two 32-byte
+        // loads from consecutive addresses, read out of the stress planes' memory) instead of eight loads from eight planes
+        {
+            const d4 *rec = (const d4 *)stress;
+            const size_t q = (size_t)(e % (ne / 4 * 3)) * 2;
+            const d4 ra = rec[q], rb = rec[q + 1];
+            E.s[0] = ra.x; E.s[1] = ra.y; E.s[2] = ra.z; E.s[3] = ra.w; E.s[4] = rb.x; E.s[5] = rb.y;
+            E.vol = 1e7 + fabs(rb.z) * 1e-30; E.dpo = rb.w * 1e-30; E.mono = grav ? md.mono[e] : 0;
+        }
+#elif DES_EXP_EN3 & 8
         // timing experiment only (wrong results): no per-element global loads
         for (int k = 0; k < 6; ++k) E.s[k] = 1e6 * (k + 1) + e;
         E.vol = 1e7 + e; E.dpo = 1e3; E.mono = (0 << 16) | 4;
