@@ -44,9 +44,6 @@
 #define DES_EXP_EN3 0             // timing experiments (wrong results; profiles/r05_d_patch_phase_removal.txt), bits: 1 no element arithmetic, 2 no force sums, 4 no staging gathers, 8 no element loads, 16 the element loads as one 64-byte record
 #endif
 __host__ __device__ inline size_t en3_lds_bytes(int cap_inc, int cap_pn) { return (size_t)cap_pn * (32 + 8) + (size_t)cap_inc * 24; }
-#ifndef DES_EN3_PIPE
-#define DES_EN3_PIPE 0            // 256-lane form with the next patch element's loads in flight under the current one's arithmetic
-#endif
 #ifndef DES_EN3_MINWAVES
 #define DES_EN3_MINWAVES 3        // 256-lane form: waves per SIMD its register budget is held to
 #endif
@@ -238,32 +235,11 @@ EN3_force_nodes(const des_params *__restrict__ p, const DevClock *__restrict__ c
             lf[2][slot[k]] = (s[4]*sx[k] + s[5]*sy[k] + s[2]*sz[k] + buoy) * vol;
         }
     };
-#if DES_EN3_PIPE
-    if (THREADS == 256) {
-        // 256 lanes (168 VGPRs at three workgroups per CU): the stress / volume / dpressure of a lane's NEXT patch element are
-        // requested before the current one's arithmetic, branch-free (past the patch's end: its last element again, dropped) --
-        // the per-round dependent trip list entry -> element data -> arithmetic (10.8 us of the pass: profiles/r05_d_*) runs
-        // under the arithmetic of the round before
-        const int nrounds = (e_end - e_begin + THREADS - 1) / THREADS;
-        ulonglong2 rec_next = pe_pack[min(i1, e_end - 1)];
-        Elem Ecur = E0;
-        for (int r = 0; r < nrounds; ++r) {
-            const int icur = i0 + r * THREADS;
-            Elem En;
-            load_elem_rec(rec_next, En);
-            rec_next = pe_pack[min(icur + 2 * THREADS, e_end - 1)];
-            if (icur < e_end) do_elem(Ecur);
-            Ecur = En;
-        }
-    } else
-#endif
-    {
     if (i0 < e_end) do_elem(E0);
     for (int i = i1; i < e_end; i += THREADS) {             // the rest of the patch (one more round, seldom two)
         Elem E;
         load_elem(i, E);
         do_elem(E);
-    }
     }
     DES_STAMP0(1, 2);
     __syncthreads();
