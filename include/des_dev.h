@@ -53,7 +53,7 @@ int des_dev_device_count(void);
 /* Create an engine on HIP device `device`, copy params and mesh topology to HBM and
  * allocate every field.  Replaces allocate_variables (fields.cxx:56-122) + the topology
  * uploads an OpenACC build does implicitly.  With mesh->coord (initial coordinates, a layout
- * hint) the engine keeps its arrays in a Morton order of its own; everything crossing this
+ * hint) the engine keeps its arrays in a space-filling-curve (Hilbert) order of its own; everything crossing this
  * interface stays in the caller's numbering and list order (des_params.h, des_mesh).
  * params->ndims = 2 creates the 2-D (triangle) engine (see the header above).
  * Returns NULL on failure and stores a DES_ERR_* code in *err (may be NULL). */
